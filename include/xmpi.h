@@ -1,0 +1,192 @@
+/*
+ * xmpi.h -- C ABI of the MI355X-native message-passing / collectives library.
+ *
+ * This header is the drop-in boundary: it is what a cgo shim (see INTEGRATION.md and
+ * go/mpi/xgmi.go) binds to put an xGMI/HIP backend behind btracey/mpi's Go API.  Every
+ * entry point names the reference interface it replaces (file:line are relative to the
+ * reference repository root).
+ *
+ * Conventions
+ *   - plain C: opaque handle, raw pointers, sizes in ELEMENTS of `dtype` unless stated;
+ *   - every function returns 0 (XMPI_OK) or a negative xmpi error code; HIP failures are
+ *     mapped to XMPI_ERR_HIP and the HIP error text is kept for xmpi_last_error();
+ *   - all calls are blocking (reference: mpi.go:47-48) and may be called from any OS thread
+ *     (cgo moves goroutines between threads; each entry point re-selects the comm's device);
+ *   - buffers may be device pointers (HBM, the hot path) or host pointers (staged by HIP);
+ *   - one communicator == one rank == one process == one MI355X.
+ */
+#ifndef XMPI_H
+#define XMPI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct xmpi_comm xmpi_comm;
+
+/* element types (the reference types payloads by Go reflection through gob,
+ * network.go:539,597; a device buffer needs an explicit tag) */
+typedef enum {
+  XMPI_U8 = 0,
+  XMPI_I32 = 1,
+  XMPI_I64 = 2,
+  XMPI_F16 = 3,
+  XMPI_F32 = 4,
+  XMPI_F64 = 5,
+  XMPI_BF16 = 6,
+  XMPI_DTYPE_COUNT = 7
+} xmpi_dtype;
+
+typedef enum { XMPI_SUM = 0, XMPI_PROD = 1, XMPI_MIN = 2, XMPI_MAX = 3, XMPI_OP_COUNT = 4 } xmpi_op;
+
+/* collective schedules */
+typedef enum {
+  XMPI_ALGO_AUTO = 0,
+  XMPI_ALGO_RING = 1,   /* multi-channel ring: reduce-scatter + allgather            */
+  XMPI_ALGO_RHD = 2,    /* recursive halving (reduce-scatter) + doubling (allgather) */
+  XMPI_ALGO_DIRECT = 3, /* full-mesh one-hop reduce-scatter + allgather; rank-order sum */
+  XMPI_ALGO_TREE = 4,   /* binary tree (bcast / reduce)                              */
+  XMPI_ALGO_COUNT = 5
+} xmpi_algo;
+
+/* error codes */
+#define XMPI_OK 0
+#define XMPI_ERR_ARG (-1)        /* bad argument                                          */
+#define XMPI_ERR_HIP (-2)        /* a HIP runtime call failed (see xmpi_last_error)       */
+#define XMPI_ERR_BOOTSTRAP (-3)  /* shared control block could not be created / joined    */
+#define XMPI_ERR_TIMEOUT (-4)    /* a peer did not arrive within XMPI_TIMEOUT_S           */
+#define XMPI_ERR_TAG_EXISTS (-5) /* {peer,tag} already in use (mpi.go:172-182 TagExists)  */
+#define XMPI_ERR_TRUNCATE (-6)   /* receive buffer smaller than the message               */
+#define XMPI_ERR_NOMEM (-7)
+#define XMPI_ERR_STATE (-8)      /* not initialised / already finalised                   */
+#define XMPI_ERR_UNSUPPORTED (-9)
+#define XMPI_ERR_NOGPU (-10)     /* no usable HIP device: the product has no CPU fallback */
+#define XMPI_ERR_PEER (-11)      /* a peer rank reported failure                          */
+
+/* ---- lifecycle -------------------------------------------------------------------------- */
+
+/* Replaces mpi.Init -> (*Network).Init (mpi.go:96-98, network.go:53-65): instead of a TCP
+ * mesh, ranks meet in a POSIX shared-memory control block named after `job_key`, pin
+ * `device` (rank i -> GPU i is the launcher's job), allocate their HBM receive windows and
+ * exchange hipIpc handles.  rank/size come from the launcher (reference: index of -mpi-addr
+ * in the sorted -mpi-alladdr list, network.go:94-109).  device < 0 selects rank % ndev. */
+int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** out);
+
+/* Replaces mpi.Finalize -> (*Network).close (mpi.go:102-104, network.go:354-369). */
+int xmpi_finalize(xmpi_comm* comm);
+
+/* Replace mpi.Rank / mpi.Size (mpi.go:112-119, network.go:41-50): rank is -1 and size 0 for
+ * a NULL (uninitialised) communicator, exactly the reference's "not initialised" answer. */
+int xmpi_rank(const xmpi_comm* comm);
+int xmpi_size(const xmpi_comm* comm);
+int xmpi_device(const xmpi_comm* comm);
+
+/* Host-side rendezvous of all ranks (the reference has no barrier; needed for timing). */
+int xmpi_barrier(xmpi_comm* comm);
+
+const char* xmpi_strerror(int code);
+/* Text of the last failure on this thread ("" if none). */
+const char* xmpi_last_error(void);
+const char* xmpi_version(void);
+
+/* ---- HBM buffers ------------------------------------------------------------------------ */
+
+void* xmpi_malloc(xmpi_comm* comm, size_t bytes);
+int xmpi_free(xmpi_comm* comm, void* dptr);
+/* Blocking copy between any two of {host, this rank's HBM}. */
+int xmpi_memcpy(xmpi_comm* comm, void* dst, const void* src, size_t bytes);
+int xmpi_memset(xmpi_comm* comm, void* dst, int byte, size_t bytes);
+/* Wait until every stream of the communicator has drained. */
+int xmpi_sync(xmpi_comm* comm);
+
+/* ---- point to point --------------------------------------------------------------------- */
+
+/* Replaces mpi.Send -> (*Network).Send (mpi.go:126-128, network.go:518-572): the payload is
+ * pushed peer-to-peer into the destination's HBM window over xGMI instead of being gob-encoded
+ * onto a net.Conn.  Rendezvous semantics are kept: returns only after the matching receive
+ * consumed the message (network.go:569).  {dest,tag} must be unique among concurrent sends
+ * (mpi.go:121-125) -> XMPI_ERR_TAG_EXISTS otherwise.  dest == own rank is allowed
+ * (network.go:545-548) when a concurrent xmpi_recv is posted from another thread. */
+int xmpi_send(xmpi_comm* comm, const void* buf, size_t count, xmpi_dtype dtype, int dest, int tag);
+
+/* Replaces mpi.Receive -> (*Network).Receive + receiveReader (mpi.go:157-159,
+ * network.go:575-625).  `capacity` is the room in `buf` (elements); `*got` (optional) is the
+ * element count of the message.  The dtype must match the sender's. */
+int xmpi_recv(xmpi_comm* comm, void* buf, size_t capacity, xmpi_dtype dtype, int src, int tag,
+              size_t* got);
+
+/* ---- collectives (absent from the reference: mpi.go:130 is a commented-out stub, mpi.go:69-71
+ *      an unused probe variable; defined here in the reference's delegate style) -------------- */
+
+/* root's buffer replicated to every rank, bit-exact.  algo: TREE (binary tree) | AUTO. */
+int xmpi_bcast(xmpi_comm* comm, void* buf, size_t count, xmpi_dtype dtype, int root, int algo);
+
+/* recvbuf (significant at root only) = op over ranks of sendbuf.  algo: TREE | DIRECT | AUTO. */
+int xmpi_reduce(xmpi_comm* comm, const void* sendbuf, void* recvbuf, size_t count,
+                xmpi_dtype dtype, xmpi_op op, int root, int algo);
+
+/* recvbuf = op over ranks of sendbuf, on every rank (sendbuf == recvbuf allowed).
+ * algo: RING | RHD | DIRECT | AUTO.  DIRECT sums in rank order 0..N-1 (bit-identical to the
+ * reference-user composition "gather everything, add on the host in rank order"). */
+int xmpi_allreduce(xmpi_comm* comm, const void* sendbuf, void* recvbuf, size_t count,
+                   xmpi_dtype dtype, xmpi_op op, int algo);
+
+/* recvbuf[r*count : (r+1)*count] = rank r's sendbuf, bit-exact.  algo: RING | DIRECT | AUTO. */
+int xmpi_allgather(xmpi_comm* comm, const void* sendbuf, void* recvbuf, size_t count,
+                   xmpi_dtype dtype, int algo);
+
+/* ---- local kernels (the HBM-bound pieces, exposed for parity tests and rooflines) --------- */
+
+/* dst[i] = a[i] op b[i]  (the per-chunk reduction every ring / halving step runs). */
+int xmpi_reduce_local(xmpi_comm* comm, void* dst, const void* a, const void* b, size_t count,
+                      xmpi_dtype dtype, xmpi_op op);
+/* dst[i] = ((src[0][i] op src[1][i]) op src[2][i]) ... strictly left to right, nsrc <= 16. */
+int xmpi_reduce_local_n(xmpi_comm* comm, void* dst, const void* const* srcs, int nsrc,
+                        size_t count, xmpi_dtype dtype, xmpi_op op);
+/* dst = src through the library's streaming copy kernel. */
+int xmpi_copy_local(xmpi_comm* comm, void* dst, const void* src, size_t bytes);
+
+/* Verification kernels (LDS + wavefront-shuffle reductions; replace bytes.Equal /
+ * floats.Equal of examples/bounce/bounce.go:105,133 for HBM-resident data). */
+int xmpi_count_mismatch(xmpi_comm* comm, const void* a, const void* b, size_t bytes,
+                        uint64_t* mismatching_bytes);
+/* sum of the buffer read as little-endian u32 words (mod 2^64) + trailing bytes. */
+int xmpi_checksum(xmpi_comm* comm, const void* buf, size_t bytes, uint64_t* sum);
+/* stats[0] = max_i |a_i - b_i|, stats[1] = sum_i |b_i|, stats[2] = count of i with a NaN
+ * mismatch; a, b of dtype F16/BF16/F32/F64; accumulated in double. */
+int xmpi_diff_stats(xmpi_comm* comm, const void* a, const void* b, size_t count,
+                    xmpi_dtype dtype, double stats[3]);
+/* Fill with the deterministic test pattern shared with the CPU oracle (oracle/xmpi_oracle.c
+ * `oracle_fill`): see DESIGN.md "synthetic inputs". */
+int xmpi_fill_pattern(xmpi_comm* comm, void* buf, size_t count, xmpi_dtype dtype, int pattern,
+                      uint64_t seed);
+
+/* ---- tuning / introspection ------------------------------------------------------------- */
+
+/* name in {"channels","piece_bytes","copy_engine","signal","timeout_s","fifo_depth"...};
+ * see DESIGN.md.  Must be called identically on every rank. */
+int xmpi_set_param(xmpi_comm* comm, const char* name, long value);
+long xmpi_get_param(const xmpi_comm* comm, const char* name);
+
+/* Kernel profiling: when enabled every reduction / copy kernel launch is bracketed by HIP
+ * events on the stream it runs on.  kind: 0 = reduce2, 1 = reduceN, 2 = copy kernel,
+ * 3 = peer copy (hipMemcpyAsync or kernel push). */
+int xmpi_prof_enable(xmpi_comm* comm, int on);
+int xmpi_prof_reset(xmpi_comm* comm);
+int xmpi_prof_get(xmpi_comm* comm, int kind, uint64_t* launches, double* total_ms,
+                  uint64_t* bytes);
+
+/* Schedule introspection (host logic only, no GPU needed): writes the step table the executor
+ * would run for (coll, algo, size, rank, count) as text into out; returns needed length. */
+int xmpi_plan_dump(int coll, int algo, int size, int rank, int root, size_t count,
+                   size_t elem_size, int channels, size_t piece_elems, char* out, size_t cap);
+
+size_t xmpi_dtype_size(xmpi_dtype dtype);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XMPI_H */

@@ -1,0 +1,619 @@
+// api.cpp -- the extern "C" entry points of include/xmpi.h.  Compiled by hipcc as host code.
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "comm.h"
+#include "kernels.h"
+
+namespace xmpi {
+
+static thread_local std::string g_last_error;
+
+void set_last_error(const std::string& s) { g_last_error = s; }
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  const char* base = strrchr(file, '/');
+  g_last_error = std::string(what) + " failed: " + hipGetErrorString(e) + " (" + (base ? base + 1 : file) + ":" +
+                 std::to_string(line) + ")";
+  (void)hipGetLastError();
+  return XMPI_ERR_HIP;
+}
+
+static long env_long(const char* name, long dflt) {
+  const char* v = getenv(name);
+  if (!v || !*v) return dflt;
+  char* end = nullptr;
+  long x = strtol(v, &end, 0);
+  return (end && end != v) ? x : dflt;
+}
+
+static int use_device(const xmpi_comm* c) {
+  // HIP's current device is per OS thread and cgo moves goroutines between threads
+  XMPI_HIP(hipSetDevice(c->device));
+  return XMPI_OK;
+}
+
+#define XMPI_ENTER(c)                          \
+  do {                                         \
+    if (!(c) || (c)->finalized) {              \
+      ::xmpi::set_last_error("communicator not initialised"); \
+      return XMPI_ERR_STATE;                   \
+    }                                          \
+    int _rc = ::xmpi::use_device(c);           \
+    if (_rc) return _rc;                       \
+  } while (0)
+
+static size_t choose_piece(const xmpi_comm* c, size_t bytes_per_rank_chunk) {
+  if (c->piece_bytes > 0) return std::min<size_t>((size_t)c->piece_bytes, c->slot_bytes);
+  // ~4 pieces per chunk so a chunk's transfer overlaps its reduction, within [64 KiB, slot]
+  size_t p = 64u << 10;
+  while (p * 4 < bytes_per_rank_chunk && p < c->slot_bytes) p <<= 1;
+  return std::min(p, c->slot_bytes);
+}
+
+static int collective(xmpi_comm* c, int coll, int algo, int root, const void* sendbuf, void* recvbuf, size_t count,
+                      int dtype, int op) {
+  const size_t es = xmpi_dtype_size((xmpi_dtype)dtype);
+  if (es == 0 || op < 0 || op >= XMPI_OP_COUNT || root < 0 || root >= c->size || algo < 0 || algo >= XMPI_ALGO_COUNT) {
+    set_last_error("bad dtype / op / root / algo");
+    return XMPI_ERR_ARG;
+  }
+  if (count == 0) return XMPI_OK;
+  if (!recvbuf || !sendbuf) {
+    set_last_error("null buffer");
+    return XMPI_ERR_ARG;
+  }
+  std::lock_guard<std::mutex> g(c->coll_mu);
+  PlanParams pp;
+  pp.coll = coll;
+  pp.algo = algo;
+  pp.size = c->size;
+  pp.rank = c->rank;
+  pp.root = root;
+  pp.count = count;
+  pp.elem_size = es;
+  pp.channels = (int)c->channels;
+  pp.lanes = c->lanes;
+  const size_t total = count * es;
+  size_t chunk = total;
+  if (coll == COLL_ALLREDUCE) chunk = total / (size_t)c->size / (size_t)std::max<long>(1, c->channels);
+  pp.piece_bytes = choose_piece(c, chunk);
+  Plan plan;
+  int rc = build_plan(pp, &plan);
+  if (rc != XMPI_OK) {
+    set_last_error("no schedule for this collective / algorithm / size");
+    return rc;
+  }
+
+  // host-resident buffers: stage through this rank's HBM (convenience path; the hot path is HBM)
+  const bool send_dev = is_device_pointer(sendbuf), recv_dev = is_device_pointer(recvbuf);
+  const size_t send_bytes = total;
+  const size_t recv_bytes = (coll == COLL_ALLGATHER) ? total * (size_t)c->size : total;
+  void *dsend = const_cast<void*>(sendbuf), *drecv = recvbuf;
+  void *tmp_send = nullptr, *tmp_recv = nullptr;
+  if (!recv_dev) {
+    XMPI_HIP(hipMalloc(&tmp_recv, recv_bytes));
+    drecv = tmp_recv;
+    if (coll == COLL_BCAST) XMPI_HIP(hipMemcpy(tmp_recv, recvbuf, recv_bytes, hipMemcpyHostToDevice));
+  }
+  if (!send_dev) {
+    if (sendbuf == recvbuf && coll != COLL_ALLGATHER) {
+      if (coll != COLL_BCAST) XMPI_HIP(hipMemcpy(drecv, sendbuf, send_bytes, hipMemcpyHostToDevice));
+      dsend = drecv;
+    } else {
+      XMPI_HIP(hipMalloc(&tmp_send, send_bytes));
+      XMPI_HIP(hipMemcpy(tmp_send, sendbuf, send_bytes, hipMemcpyHostToDevice));
+      dsend = tmp_send;
+    }
+  }
+  rc = run_plan(c, plan, dsend, drecv, dtype, op);
+  if (rc == XMPI_OK && !recv_dev) {
+    const bool significant = (coll != COLL_REDUCE) || c->rank == root;
+    if (significant) XMPI_HIP(hipMemcpy(recvbuf, drecv, recv_bytes, hipMemcpyDeviceToHost));
+  }
+  if (tmp_send) (void)hipFree(tmp_send);
+  if (tmp_recv) (void)hipFree(tmp_recv);
+  return rc;
+}
+
+}  // namespace xmpi
+
+using namespace xmpi;
+
+extern "C" {
+
+size_t xmpi_dtype_size(xmpi_dtype dtype) {
+  switch (dtype) {
+    case XMPI_U8: return 1;
+    case XMPI_I32: return 4;
+    case XMPI_I64: return 8;
+    case XMPI_F16: return 2;
+    case XMPI_F32: return 4;
+    case XMPI_F64: return 8;
+    case XMPI_BF16: return 2;
+    default: return 0;
+  }
+}
+
+const char* xmpi_version(void) { return "xmpi 0.1 (gfx950, HIP)"; }
+
+const char* xmpi_last_error(void) { return g_last_error.c_str(); }
+
+const char* xmpi_strerror(int code) {
+  switch (code) {
+    case XMPI_OK: return "ok";
+    case XMPI_ERR_ARG: return "invalid argument";
+    case XMPI_ERR_HIP: return "HIP runtime error";
+    case XMPI_ERR_BOOTSTRAP: return "bootstrap (shared control block) failed";
+    case XMPI_ERR_TIMEOUT: return "timed out waiting for a peer";
+    case XMPI_ERR_TAG_EXISTS: return "tag already in use";
+    case XMPI_ERR_TRUNCATE: return "message larger than the receive buffer";
+    case XMPI_ERR_NOMEM: return "out of memory";
+    case XMPI_ERR_STATE: return "communicator not initialised";
+    case XMPI_ERR_UNSUPPORTED: return "unsupported";
+    case XMPI_ERR_NOGPU: return "no usable HIP device (there is no CPU fallback)";
+    case XMPI_ERR_PEER: return "a peer rank failed";
+    default: return "unknown xmpi error";
+  }
+}
+
+int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** out) {
+  if (!out || size < 1 || size > kMaxRanks || rank < 0 || rank >= size) {
+    set_last_error("xmpi_init: bad rank/size/out");
+    return XMPI_ERR_ARG;
+  }
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev < 1) {
+    (void)hipGetLastError();
+    set_last_error("xmpi_init: no HIP device is visible; xmpi has no CPU fallback");
+    return XMPI_ERR_NOGPU;
+  }
+  if (device < 0) device = rank % ndev;
+  if (device >= ndev) {
+    set_last_error("xmpi_init: device " + std::to_string(device) + " does not exist (" + std::to_string(ndev) + " visible)");
+    return XMPI_ERR_ARG;
+  }
+  XMPI_HIP(hipSetDevice(device));
+
+  CtlConfig cfg;
+  cfg.lanes = (int32_t)std::min<long>(kMaxLanes, std::max<long>(1, env_long("XMPI_LANES", 2)));
+  cfg.fifo_depth = (int32_t)std::min<long>(64, std::max<long>(2, env_long("XMPI_FIFO_DEPTH", 8)));
+  cfg.slot_bytes = (uint64_t)std::max<long>(4096, env_long("XMPI_SLOT_BYTES", 4l << 20)) / 256 * 256;
+  cfg.p2p_depth = (int32_t)std::min<long>(16, std::max<long>(2, env_long("XMPI_P2P_DEPTH", 2)));
+  cfg.p2p_slot_bytes = (uint64_t)std::max<long>(4096, env_long("XMPI_P2P_SLOT_BYTES", 4l << 20)) / 256 * 256;
+  const double timeout = (double)env_long("XMPI_TIMEOUT_S", 60);
+
+  std::string key = (job_key && *job_key) ? job_key : "default";
+  std::string err;
+  Ctl* ctl = nullptr;
+  int rc = Ctl::join(key, rank, size, cfg, timeout > 0 ? timeout : 3600.0, &ctl, &err);
+  if (rc != XMPI_OK) {
+    set_last_error("xmpi_init: " + err);
+    return rc;
+  }
+  xmpi_comm* c = new xmpi_comm;
+  c->rank = rank;
+  c->size = size;
+  c->device = device;
+  c->ctl = ctl;
+  c->timeout_s = (long)timeout;
+  const CtlConfig& g = ctl->cfg();  // rank 0's values are the job's
+  c->lanes = g.lanes;
+  c->fifo_depth = g.fifo_depth;
+  c->slot_bytes = g.slot_bytes;
+  c->p2p_depth = g.p2p_depth;
+  c->p2p_slot_bytes = g.p2p_slot_bytes;
+  c->channels = env_long("XMPI_CHANNELS", 4);
+  c->piece_bytes = env_long("XMPI_PIECE_BYTES", 0);
+  c->copy_engine = env_long("XMPI_COPY_ENGINE", 0);
+  c->coll_region_bytes = (size_t)size * c->lanes * c->fifo_depth * c->slot_bytes;
+  c->window_bytes = c->coll_region_bytes + (size_t)size * kMailEntries * c->p2p_depth * c->p2p_slot_bytes;
+
+  auto fail = [&](int code) {
+    ctl->set_abort(code);
+    delete ctl;
+    delete c;
+    return code;
+  };
+  if (hipMalloc((void**)&c->window, c->window_bytes) != hipSuccess) {
+    hip_fail(hipGetLastError(), "hipMalloc(window)", __FILE__, __LINE__);
+    return fail(XMPI_ERR_NOMEM);
+  }
+  RankInfo* me = ctl->info(rank);
+  me->device = device;
+  me->window_addr = (uint64_t)(uintptr_t)c->window;
+  me->window_bytes = c->window_bytes;
+  (void)hipDeviceGetPCIBusId(me->busid, (int)sizeof me->busid, device);
+  if (size > 1) {
+    hipIpcMemHandle_t h;
+    e = hipIpcGetMemHandle(&h, c->window);
+    if (e != hipSuccess) {
+      hip_fail(e, "hipIpcGetMemHandle", __FILE__, __LINE__);
+      return fail(XMPI_ERR_HIP);
+    }
+    static_assert(sizeof(h) <= sizeof(me->ipc_handle), "ipc handle size");
+    memcpy(me->ipc_handle, &h, sizeof h);
+  }
+  me->state.store(2, std::memory_order_release);
+  rc = ctl->wait_all_state(2, timeout > 0 ? timeout : 3600.0);
+  if (rc != XMPI_OK) {
+    set_last_error("xmpi_init: a peer did not publish its HBM window");
+    return fail(rc);
+  }
+  const int mypid = (int)getpid();
+  for (int p = 0; p < size; p++) {
+    if (p == rank) {
+      c->peer_window[p] = c->window;
+      continue;
+    }
+    RankInfo* pi = ctl->info(p);
+    if (pi->pid == mypid) {  // rank hosted by a thread of this process
+      c->peer_window[p] = (char*)(uintptr_t)pi->window_addr;
+      if (pi->device != device) {
+        e = hipDeviceEnablePeerAccess(pi->device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+          hip_fail(e, "hipDeviceEnablePeerAccess", __FILE__, __LINE__);
+          return fail(XMPI_ERR_HIP);
+        }
+        (void)hipGetLastError();
+      }
+    } else {
+      hipIpcMemHandle_t h;
+      memcpy(&h, pi->ipc_handle, sizeof h);
+      void* ptr = nullptr;
+      e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess) {
+        hip_fail(e, "hipIpcOpenMemHandle", __FILE__, __LINE__);
+        return fail(XMPI_ERR_HIP);
+      }
+      c->peer_window[p] = (char*)ptr;
+      c->peer_opened[p] = true;
+    }
+  }
+  for (int p = 0; p < size; p++) {
+    if (p == rank) continue;
+    if (hipStreamCreateWithFlags(&c->send_stream[p], hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->recv_stream[p], hipStreamNonBlocking) != hipSuccess) {
+      hip_fail(hipGetLastError(), "hipStreamCreate", __FILE__, __LINE__);
+      return fail(XMPI_ERR_HIP);
+    }
+  }
+  if (hipStreamCreateWithFlags(&c->local_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc((void**)&c->dev_words, 4 * sizeof(uint64_t)) != hipSuccess) {
+    hip_fail(hipGetLastError(), "hipStreamCreate/hipMalloc", __FILE__, __LINE__);
+    return fail(XMPI_ERR_HIP);
+  }
+  rc = ctl->barrier(timeout > 0 ? timeout : 3600.0);
+  if (rc != XMPI_OK) {
+    set_last_error("xmpi_init: barrier failed");
+    return fail(rc);
+  }
+  *out = c;
+  return XMPI_OK;
+}
+
+int xmpi_finalize(xmpi_comm* c) {
+  if (!c) return XMPI_ERR_STATE;
+  if (c->finalized) return XMPI_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  // nobody may still be writing into a window that is about to be unmapped
+  if (!c->ctl->aborted()) (void)c->ctl->barrier(c->timeout_s > 0 ? (double)c->timeout_s : 3600.0);
+  for (int p = 0; p < c->size; p++) {
+    if (c->peer_opened[p]) (void)hipIpcCloseMemHandle(c->peer_window[p]);
+    if (c->send_stream[p]) (void)hipStreamDestroy(c->send_stream[p]);
+    if (c->recv_stream[p]) (void)hipStreamDestroy(c->recv_stream[p]);
+  }
+  if (c->local_stream) (void)hipStreamDestroy(c->local_stream);
+  for (hipStream_t s : c->p2p_streams) (void)hipStreamDestroy(s);
+  for (hipEvent_t e : c->ev_free) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->ev_timed_free) (void)hipEventDestroy(e);
+  if (!c->ctl->aborted()) (void)c->ctl->barrier(c->timeout_s > 0 ? (double)c->timeout_s : 3600.0);
+  if (c->window) (void)hipFree(c->window);
+  if (c->temp) (void)hipFree(c->temp);
+  if (c->dev_words) (void)hipFree(c->dev_words);
+  c->ctl->info(c->rank)->state.store(3, std::memory_order_release);
+  delete c->ctl;
+  c->ctl = nullptr;
+  c->finalized = true;
+  delete c;
+  return XMPI_OK;
+}
+
+int xmpi_rank(const xmpi_comm* c) { return (c && !c->finalized && c->size > 0) ? c->rank : -1; }
+int xmpi_size(const xmpi_comm* c) { return (c && !c->finalized) ? c->size : 0; }
+int xmpi_device(const xmpi_comm* c) { return (c && !c->finalized) ? c->device : -1; }
+
+int xmpi_barrier(xmpi_comm* c) {
+  XMPI_ENTER(c);
+  int rc = c->ctl->barrier(c->timeout_s > 0 ? (double)c->timeout_s : 3600.0);
+  if (rc != XMPI_OK) set_last_error("barrier: a peer did not arrive");
+  return rc;
+}
+
+void* xmpi_malloc(xmpi_comm* c, size_t bytes) {
+  if (!c || c->finalized || use_device(c) != XMPI_OK) return nullptr;
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+    hip_fail(hipGetLastError(), "hipMalloc", __FILE__, __LINE__);
+    return nullptr;
+  }
+  return p;
+}
+
+int xmpi_free(xmpi_comm* c, void* p) {
+  XMPI_ENTER(c);
+  if (p) XMPI_HIP(hipFree(p));
+  return XMPI_OK;
+}
+
+int xmpi_memcpy(xmpi_comm* c, void* dst, const void* src, size_t bytes) {
+  XMPI_ENTER(c);
+  if (bytes) XMPI_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDefault));
+  return XMPI_OK;
+}
+
+int xmpi_memset(xmpi_comm* c, void* dst, int byte, size_t bytes) {
+  XMPI_ENTER(c);
+  if (bytes) {
+    XMPI_HIP(hipMemsetAsync(dst, byte, bytes, c->local_stream));
+    XMPI_HIP(hipStreamSynchronize(c->local_stream));
+  }
+  return XMPI_OK;
+}
+
+int xmpi_sync(xmpi_comm* c) {
+  XMPI_ENTER(c);
+  XMPI_HIP(hipDeviceSynchronize());
+  return XMPI_OK;
+}
+
+int xmpi_send(xmpi_comm* c, const void* buf, size_t count, xmpi_dtype dtype, int dest, int tag) {
+  XMPI_ENTER(c);
+  const size_t es = xmpi_dtype_size(dtype);
+  if (!es || dest < 0 || dest >= c->size || (count && !buf)) {
+    set_last_error("send: bad dtype / destination / buffer");
+    return XMPI_ERR_ARG;
+  }
+  return p2p_send(c, buf, count * es, (int)dtype, dest, tag);
+}
+
+int xmpi_recv(xmpi_comm* c, void* buf, size_t capacity, xmpi_dtype dtype, int src, int tag, size_t* got) {
+  XMPI_ENTER(c);
+  const size_t es = xmpi_dtype_size(dtype);
+  if (!es || src < 0 || src >= c->size || (capacity && !buf)) {
+    set_last_error("receive: bad dtype / source / buffer");
+    return XMPI_ERR_ARG;
+  }
+  size_t got_bytes = 0;
+  int rc = p2p_recv(c, buf, capacity * es, (int)dtype, src, tag, &got_bytes);
+  if (got) *got = got_bytes / es;
+  return rc;
+}
+
+int xmpi_bcast(xmpi_comm* c, void* buf, size_t count, xmpi_dtype dtype, int root, int algo) {
+  XMPI_ENTER(c);
+  return collective(c, COLL_BCAST, algo, root, buf, buf, count, (int)dtype, XMPI_SUM);
+}
+
+int xmpi_reduce(xmpi_comm* c, const void* sendbuf, void* recvbuf, size_t count, xmpi_dtype dtype, xmpi_op op, int root,
+                int algo) {
+  XMPI_ENTER(c);
+  // recvbuf is only significant at the root; other ranks may pass NULL
+  void* rb = recvbuf ? recvbuf : const_cast<void*>(sendbuf);
+  if (c->rank == root && !recvbuf) {
+    set_last_error("reduce: root needs a receive buffer");
+    return XMPI_ERR_ARG;
+  }
+  return collective(c, COLL_REDUCE, algo, root, sendbuf, rb, count, (int)dtype, (int)op);
+}
+
+int xmpi_allreduce(xmpi_comm* c, const void* sendbuf, void* recvbuf, size_t count, xmpi_dtype dtype, xmpi_op op,
+                   int algo) {
+  XMPI_ENTER(c);
+  return collective(c, COLL_ALLREDUCE, algo, 0, sendbuf, recvbuf, count, (int)dtype, (int)op);
+}
+
+int xmpi_allgather(xmpi_comm* c, const void* sendbuf, void* recvbuf, size_t count, xmpi_dtype dtype, int algo) {
+  XMPI_ENTER(c);
+  return collective(c, COLL_ALLGATHER, algo, 0, sendbuf, recvbuf, count, (int)dtype, XMPI_SUM);
+}
+
+// ---- local kernels -----------------------------------------------------------------------------
+
+static int timed_launch(xmpi_comm* c, int kind, size_t bytes, hipError_t (*launch)(void*), void* ctx) {
+  hipStream_t s = c->local_stream;
+  if (!c->prof_on) {
+    XMPI_HIP(launch(ctx));
+    XMPI_HIP(hipStreamSynchronize(s));
+    return XMPI_OK;
+  }
+  hipEvent_t a = ev_get(c, true), b = ev_get(c, true);
+  if (!a || !b) return XMPI_ERR_HIP;
+  XMPI_HIP(hipEventRecord(a, s));
+  XMPI_HIP(launch(ctx));
+  XMPI_HIP(hipEventRecord(b, s));
+  XMPI_HIP(hipStreamSynchronize(s));
+  float ms = 0.f;
+  XMPI_HIP(hipEventElapsedTime(&ms, a, b));
+  c->prof[kind].launches++;
+  c->prof[kind].total_ms += ms;
+  c->prof[kind].bytes += bytes;
+  ev_put(c, a, true);
+  ev_put(c, b, true);
+  return XMPI_OK;
+}
+
+int xmpi_reduce_local(xmpi_comm* c, void* dst, const void* a, const void* b, size_t count, xmpi_dtype dtype, xmpi_op op) {
+  XMPI_ENTER(c);
+  const size_t es = xmpi_dtype_size(dtype);
+  if (!es || op < 0 || op >= XMPI_OP_COUNT) return XMPI_ERR_ARG;
+  struct Ctx { xmpi_comm* c; void* dst; const void *a, *b; size_t n; int dt, op; } ctx{c, dst, a, b, count, (int)dtype, (int)op};
+  return timed_launch(c, PROF_REDUCE2, 3 * count * es,
+                      [](void* p) {
+                        Ctx* x = (Ctx*)p;
+                        return launch_reduce2(x->dst, x->a, x->b, x->n, x->dt, x->op, x->c->local_stream);
+                      },
+                      &ctx);
+}
+
+int xmpi_reduce_local_n(xmpi_comm* c, void* dst, const void* const* srcs, int nsrc, size_t count, xmpi_dtype dtype,
+                        xmpi_op op) {
+  XMPI_ENTER(c);
+  const size_t es = xmpi_dtype_size(dtype);
+  if (!es || op < 0 || op >= XMPI_OP_COUNT || nsrc < 1 || nsrc > kMaxReduceSrcs) return XMPI_ERR_ARG;
+  struct Ctx { xmpi_comm* c; void* dst; const void* const* s; int ns; size_t n; int dt, op; } ctx{c, dst, srcs, nsrc, count, (int)dtype, (int)op};
+  return timed_launch(c, PROF_REDUCEN, (size_t)(nsrc + 1) * count * es,
+                      [](void* p) {
+                        Ctx* x = (Ctx*)p;
+                        return launch_reduce_n(x->dst, x->s, x->ns, x->n, x->dt, x->op, x->c->local_stream);
+                      },
+                      &ctx);
+}
+
+int xmpi_copy_local(xmpi_comm* c, void* dst, const void* src, size_t bytes) {
+  XMPI_ENTER(c);
+  struct Ctx { xmpi_comm* c; void* dst; const void* src; size_t n; } ctx{c, dst, src, bytes};
+  return timed_launch(c, PROF_COPY, 2 * bytes,
+                      [](void* p) {
+                        Ctx* x = (Ctx*)p;
+                        return launch_copy(x->dst, x->src, x->n, x->c->local_stream);
+                      },
+                      &ctx);
+}
+
+int xmpi_count_mismatch(xmpi_comm* c, const void* a, const void* b, size_t bytes, uint64_t* out) {
+  XMPI_ENTER(c);
+  if (!out) return XMPI_ERR_ARG;
+  std::lock_guard<std::mutex> g(c->coll_mu);
+  hipStream_t s = c->local_stream;
+  XMPI_HIP(hipMemsetAsync(c->dev_words, 0, 32, s));
+  XMPI_HIP(launch_count_mismatch(a, b, bytes, c->dev_words, s));
+  XMPI_HIP(hipMemcpyAsync(out, c->dev_words, 8, hipMemcpyDeviceToHost, s));
+  XMPI_HIP(hipStreamSynchronize(s));
+  return XMPI_OK;
+}
+
+int xmpi_checksum(xmpi_comm* c, const void* buf, size_t bytes, uint64_t* out) {
+  XMPI_ENTER(c);
+  if (!out) return XMPI_ERR_ARG;
+  std::lock_guard<std::mutex> g(c->coll_mu);
+  hipStream_t s = c->local_stream;
+  XMPI_HIP(hipMemsetAsync(c->dev_words, 0, 32, s));
+  XMPI_HIP(launch_checksum(buf, bytes, c->dev_words, s));
+  XMPI_HIP(hipMemcpyAsync(out, c->dev_words, 8, hipMemcpyDeviceToHost, s));
+  XMPI_HIP(hipStreamSynchronize(s));
+  return XMPI_OK;
+}
+
+int xmpi_diff_stats(xmpi_comm* c, const void* a, const void* b, size_t count, xmpi_dtype dtype, double stats[3]) {
+  XMPI_ENTER(c);
+  if (!stats) return XMPI_ERR_ARG;
+  if (dtype != XMPI_F16 && dtype != XMPI_BF16 && dtype != XMPI_F32 && dtype != XMPI_F64) return XMPI_ERR_ARG;
+  std::lock_guard<std::mutex> g(c->coll_mu);
+  hipStream_t s = c->local_stream;
+  uint64_t w[4] = {0, 0, 0, 0};
+  XMPI_HIP(hipMemsetAsync(c->dev_words, 0, 32, s));
+  XMPI_HIP(launch_diff_stats(a, b, count, (int)dtype, c->dev_words, s));
+  XMPI_HIP(hipMemcpyAsync(w, c->dev_words, 24, hipMemcpyDeviceToHost, s));
+  XMPI_HIP(hipStreamSynchronize(s));
+  memcpy(&stats[0], &w[0], 8);
+  memcpy(&stats[1], &w[1], 8);
+  stats[2] = (double)w[2];
+  return XMPI_OK;
+}
+
+int xmpi_fill_pattern(xmpi_comm* c, void* buf, size_t count, xmpi_dtype dtype, int pattern, uint64_t seed) {
+  XMPI_ENTER(c);
+  if (!xmpi_dtype_size(dtype) || pattern < 0 || pattern > 3) return XMPI_ERR_ARG;
+  XMPI_HIP(launch_fill(buf, count, (int)dtype, pattern, seed, c->local_stream));
+  XMPI_HIP(hipStreamSynchronize(c->local_stream));
+  return XMPI_OK;
+}
+
+// ---- tuning / introspection ----------------------------------------------------------------------
+
+int xmpi_set_param(xmpi_comm* c, const char* name, long value) {
+  if (!c || c->finalized || !name) return XMPI_ERR_STATE;
+  std::lock_guard<std::mutex> g(c->coll_mu);
+  const std::string n = name;
+  if (n == "channels") c->channels = std::max<long>(1, value);
+  else if (n == "piece_bytes") c->piece_bytes = std::max<long>(0, value);
+  else if (n == "copy_engine") c->copy_engine = value ? 1 : 0;
+  else if (n == "timeout_s") c->timeout_s = value;
+  else return XMPI_ERR_ARG;
+  return XMPI_OK;
+}
+
+long xmpi_get_param(const xmpi_comm* c, const char* name) {
+  if (!c || c->finalized || !name) return -1;
+  const std::string n = name;
+  if (n == "channels") return c->channels;
+  if (n == "piece_bytes") return c->piece_bytes;
+  if (n == "copy_engine") return c->copy_engine;
+  if (n == "timeout_s") return c->timeout_s;
+  if (n == "lanes") return c->lanes;
+  if (n == "fifo_depth") return c->fifo_depth;
+  if (n == "slot_bytes") return (long)c->slot_bytes;
+  if (n == "p2p_slot_bytes") return (long)c->p2p_slot_bytes;
+  if (n == "window_bytes") return (long)c->window_bytes;
+  if (n == "ring_channels_max") return ring_channel_count(c->size) * c->lanes;
+  return -1;
+}
+
+int xmpi_prof_enable(xmpi_comm* c, int on) {
+  if (!c || c->finalized) return XMPI_ERR_STATE;
+  std::lock_guard<std::mutex> g(c->coll_mu);
+  c->prof_on = on != 0;
+  return XMPI_OK;
+}
+
+int xmpi_prof_reset(xmpi_comm* c) {
+  if (!c || c->finalized) return XMPI_ERR_STATE;
+  std::lock_guard<std::mutex> g(c->coll_mu);
+  for (auto& p : c->prof) p = ProfCounter();
+  return XMPI_OK;
+}
+
+int xmpi_prof_get(xmpi_comm* c, int kind, uint64_t* launches, double* total_ms, uint64_t* bytes) {
+  if (!c || c->finalized) return XMPI_ERR_STATE;
+  if (kind < 0 || kind >= PROF_KINDS) return XMPI_ERR_ARG;
+  std::lock_guard<std::mutex> g(c->coll_mu);
+  if (launches) *launches = c->prof[kind].launches;
+  if (total_ms) *total_ms = c->prof[kind].total_ms;
+  if (bytes) *bytes = c->prof[kind].bytes;
+  return XMPI_OK;
+}
+
+int xmpi_plan_dump(int coll, int algo, int size, int rank, int root, size_t count, size_t elem_size, int channels,
+                   size_t piece_elems, char* out, size_t cap) {
+  PlanParams pp;
+  pp.coll = coll;
+  pp.algo = algo;
+  pp.size = size;
+  pp.rank = rank;
+  pp.root = root;
+  pp.count = count;
+  pp.elem_size = elem_size;
+  pp.channels = channels;
+  pp.lanes = 2;
+  pp.piece_bytes = piece_elems * elem_size;
+  Plan plan;
+  int rc = build_plan(pp, &plan);
+  if (rc != XMPI_OK) return rc;
+  const std::string t = plan_to_text(plan);
+  if (out && cap) {
+    const size_t n = std::min(cap - 1, t.size());
+    memcpy(out, t.data(), n);
+    out[n] = 0;
+  }
+  return (int)std::min<size_t>(t.size() + 1, 0x7fffffff);
+}
+
+}  // extern "C"

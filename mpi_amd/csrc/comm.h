@@ -1,0 +1,106 @@
+// comm.h -- the communicator object behind the C ABI (include/xmpi.h).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <deque>
+#include <mutex>
+#include <set>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/xmpi.h"
+#include "ctl.h"
+#include "plan.h"
+
+namespace xmpi {
+
+void set_last_error(const std::string& s);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define XMPI_HIP(call)                                                     \
+  do {                                                                     \
+    hipError_t _e = (call);                                                \
+    if (_e != hipSuccess) return ::xmpi::hip_fail(_e, #call, __FILE__, __LINE__); \
+  } while (0)
+
+struct ProfCounter {
+  uint64_t launches = 0;
+  double total_ms = 0.0;
+  uint64_t bytes = 0;
+};
+
+enum ProfKind { PROF_REDUCE2 = 0, PROF_REDUCEN = 1, PROF_COPY = 2, PROF_PEER = 3, PROF_KINDS = 4 };
+
+}  // namespace xmpi
+
+struct xmpi_comm {
+  int rank = 0, size = 0, device = 0;
+  xmpi::Ctl* ctl = nullptr;
+
+  // HBM receive window of this rank and the mapped windows of the peers
+  char* window = nullptr;
+  size_t window_bytes = 0;
+  char* peer_window[xmpi::kMaxRanks] = {nullptr};
+  bool peer_opened[xmpi::kMaxRanks] = {false};
+
+  // window layout (identical on every rank)
+  int lanes = 2, fifo_depth = 8, p2p_depth = 2;
+  size_t slot_bytes = 4u << 20, p2p_slot_bytes = 4u << 20;
+  size_t coll_region_bytes = 0;
+  size_t coll_slot_off(int src, int lane, uint64_t seq) const {
+    return (((size_t)src * lanes + lane) * fifo_depth + (size_t)(seq % (uint64_t)fifo_depth)) * slot_bytes;
+  }
+  size_t p2p_slot_off(int src, int entry, uint64_t seq) const {
+    return coll_region_bytes +
+           (((size_t)src * xmpi::kMailEntries + entry) * p2p_depth + (size_t)(seq % (uint64_t)p2p_depth)) *
+               p2p_slot_bytes;
+  }
+
+  // streams: one per peer and direction so independent links progress independently
+  hipStream_t send_stream[xmpi::kMaxRanks] = {nullptr};
+  hipStream_t recv_stream[xmpi::kMaxRanks] = {nullptr};
+  hipStream_t local_stream = nullptr;
+
+  // per collective pipe: slots issued / consumed so far (monotonic across operations)
+  uint64_t sent[xmpi::kMaxRanks][xmpi::kMaxLanes] = {{0}};
+  uint64_t recvd[xmpi::kMaxRanks][xmpi::kMaxLanes] = {{0}};
+  // ... and how many of those have been published to the peer (head of my sends, tail of my receives)
+  uint64_t sent_done[xmpi::kMaxRanks][xmpi::kMaxLanes] = {{0}};
+  uint64_t recvd_released[xmpi::kMaxRanks][xmpi::kMaxLanes] = {{0}};
+
+  // tunables (xmpi_set_param)
+  long channels = 4;
+  long piece_bytes = 0;  // 0 = choose per operation
+  long copy_engine = 0;  // 0 = hipMemcpyAsync (SDMA / runtime blit), 1 = xmpi copy kernel
+  long timeout_s = 60;
+
+  // scratch
+  void* temp = nullptr;
+  size_t temp_bytes = 0;
+  void* host_stage = nullptr;  // HBM bounce buffer for host-resident p2p payloads
+  uint64_t* dev_words = nullptr;  // 4 x u64 result words for the verification kernels
+
+  // event pools
+  std::mutex ev_mu;
+  std::vector<hipEvent_t> ev_free, ev_timed_free;
+
+  // profiling
+  bool prof_on = false;
+  xmpi::ProfCounter prof[xmpi::PROF_KINDS];
+
+  std::mutex coll_mu;  // collectives are serialised per communicator
+  std::mutex p2p_mu;   // guards the tag registries and the p2p stream pool
+  std::set<std::pair<int, int>> send_tags, recv_tags;  // active {peer, tag} (network.go:448-497)
+  std::vector<hipStream_t> p2p_streams;
+  bool finalized = false;
+};
+
+namespace xmpi {
+int run_plan(xmpi_comm* c, const Plan& plan, const void* sendbuf, void* recvbuf, int dtype, int op);
+int p2p_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, int tag);
+int p2p_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int tag, size_t* got_bytes);
+hipEvent_t ev_get(xmpi_comm* c, bool timed);
+void ev_put(xmpi_comm* c, hipEvent_t e, bool timed);
+bool is_device_pointer(const void* p);
+}  // namespace xmpi

@@ -1,0 +1,265 @@
+// ctl.cpp -- shared-memory control block (see ctl.h).  Host logic only, no HIP.
+#include "ctl.h"
+
+#include <fcntl.h>
+#include <sched.h>
+#include <signal.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/xmpi.h"
+
+namespace xmpi {
+
+double now_seconds() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+void Backoff::pause() {
+  n++;
+  if (n < 4096) {
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  } else if (n < 65536) {
+    sched_yield();
+  } else {
+    timespec ts{0, 50000};
+    nanosleep(&ts, nullptr);
+  }
+}
+
+static uint64_t proc_start_time(int pid) {
+  char path[64], buf[1024];
+  snprintf(path, sizeof path, "/proc/%d/stat", pid);
+  FILE* f = fopen(path, "r");
+  if (!f) return 0;
+  size_t n = fread(buf, 1, sizeof buf - 1, f);
+  fclose(f);
+  buf[n] = 0;
+  const char* p = strrchr(buf, ')');  // comm may contain spaces
+  if (!p) return 0;
+  p++;
+  unsigned long long start = 0;
+  int field = 2;  // the field after ')' is #3 (state)
+  while (*p) {
+    while (*p == ' ') p++;
+    field++;
+    if (field == 22) {
+      sscanf(p, "%llu", &start);
+      break;
+    }
+    while (*p && *p != ' ') p++;
+  }
+  return start;
+}
+
+size_t Ctl::layout_bytes(int size) {
+  size_t b = sizeof(CtlHeader);
+  b += sizeof(RankInfo) * (size_t)size;
+  b += sizeof(PipeCtl) * (size_t)size * size * kMaxLanes;
+  b += sizeof(MailEntry) * (size_t)size * size * kMailEntries;
+  return (b + 4095) / 4096 * 4096;
+}
+
+static std::string shm_name(const std::string& key) {
+  std::string n = "/xmpi-" + std::to_string((unsigned)getuid()) + "-";
+  for (char c : key) n += (isalnum((unsigned char)c) || c == '-' || c == '_' || c == '.') ? c : '_';
+  if (n.size() > 200) n.resize(200);
+  return n;
+}
+
+int Ctl::join(const std::string& key, int rank, int size, const CtlConfig& cfg, double timeout_s, Ctl** out,
+              std::string* err) {
+  if (size < 1 || size > kMaxRanks || rank < 0 || rank >= size) {
+    *err = "rank/size out of range (size <= " + std::to_string(kMaxRanks) + ")";
+    return XMPI_ERR_ARG;
+  }
+  const std::string name = shm_name(key);
+  const size_t bytes = layout_bytes(size);
+  const double t0 = now_seconds();
+  void* base = nullptr;
+  bool creator = false;
+
+  if (rank == 0) {
+    shm_unlink(name.c_str());  // a stale block of a crashed job with the same key
+    int fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0) {
+      *err = "shm_open(create " + name + "): " + strerror(errno);
+      return XMPI_ERR_BOOTSTRAP;
+    }
+    if (ftruncate(fd, (off_t)bytes) != 0) {
+      *err = std::string("ftruncate: ") + strerror(errno);
+      close(fd);
+      shm_unlink(name.c_str());
+      return XMPI_ERR_BOOTSTRAP;
+    }
+    base = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (base == MAP_FAILED) {
+      *err = std::string("mmap: ") + strerror(errno);
+      shm_unlink(name.c_str());
+      return XMPI_ERR_BOOTSTRAP;
+    }
+    memset(base, 0, bytes);  // every counter, state and flag starts at zero
+    CtlHeader* h = new (base) CtlHeader;
+    h->version = 1;
+    h->size = size;
+    h->total_bytes = bytes;
+    h->creator_pid = (int32_t)getpid();
+    h->creator_start = proc_start_time(getpid());
+    h->cfg = cfg;
+    h->abort_code.store(0);
+    h->bar_count.store(0);
+    h->bar_gen.store(0);
+    h->magic.store(kCtlMagic, std::memory_order_release);
+    creator = true;
+  } else {
+    Backoff bo;
+    for (;;) {
+      if (now_seconds() - t0 > timeout_s) {
+        *err = "timed out waiting for rank 0 to create " + name;
+        return XMPI_ERR_TIMEOUT;
+      }
+      int fd = shm_open(name.c_str(), O_RDWR, 0600);
+      if (fd < 0) {
+        timespec ts{0, 1000000};
+        nanosleep(&ts, nullptr);
+        continue;
+      }
+      struct stat st;
+      if (fstat(fd, &st) != 0 || (size_t)st.st_size < bytes) {  // still being sized, or another job's
+        close(fd);
+        timespec ts{0, 1000000};
+        nanosleep(&ts, nullptr);
+        continue;
+      }
+      void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+      close(fd);
+      if (m == MAP_FAILED) {
+        *err = std::string("mmap: ") + strerror(errno);
+        return XMPI_ERR_BOOTSTRAP;
+      }
+      CtlHeader* h = reinterpret_cast<CtlHeader*>(m);
+      bool ok = false;
+      const double tw = now_seconds();
+      while (now_seconds() - tw < 0.05) {
+        if (h->magic.load(std::memory_order_acquire) == kCtlMagic) {
+          ok = true;
+          break;
+        }
+        bo.pause();
+      }
+      if (ok) {
+        const int cp = h->creator_pid;
+        const bool alive = (kill(cp, 0) == 0 || errno == EPERM) && proc_start_time(cp) == h->creator_start;
+        ok = alive && h->size == size && h->total_bytes == bytes && h->abort_code.load() == 0 &&
+             h->version == 1;
+      }
+      if (ok) {
+        base = m;
+        break;
+      }
+      munmap(m, bytes);  // stale (dead creator) or foreign: wait for rank 0 to replace it
+      timespec ts{0, 2000000};
+      nanosleep(&ts, nullptr);
+    }
+  }
+
+  Ctl* c = new Ctl;
+  c->name_ = name;
+  c->rank_ = rank;
+  c->size_ = size;
+  c->base_ = base;
+  c->bytes_ = bytes;
+  c->creator_ = creator;
+  char* p = reinterpret_cast<char*>(base);
+  c->hdr_ = reinterpret_cast<CtlHeader*>(p);
+  p += sizeof(CtlHeader);
+  c->ranks_ = reinterpret_cast<RankInfo*>(p);
+  p += sizeof(RankInfo) * (size_t)size;
+  c->pipes_ = reinterpret_cast<PipeCtl*>(p);
+  p += sizeof(PipeCtl) * (size_t)size * size * kMaxLanes;
+  c->mail_ = reinterpret_cast<MailEntry*>(p);
+
+  RankInfo* me = c->info(rank);
+  if (me->state.load() != 0) {  // two processes claim the same rank
+    *err = "rank " + std::to_string(rank) + " already joined " + name;
+    c->set_abort(XMPI_ERR_BOOTSTRAP);
+    delete c;
+    return XMPI_ERR_BOOTSTRAP;
+  }
+  me->pid = (int32_t)getpid();
+  me->device = -1;
+  me->state.store(1, std::memory_order_release);
+  const double left = timeout_s - (now_seconds() - t0);
+  int rc = c->wait_all_state(1, left > 1.0 ? left : 1.0);
+  if (rc != XMPI_OK) {
+    *err = "not every rank joined " + name;
+    delete c;
+    return rc;
+  }
+  *out = c;
+  return XMPI_OK;
+}
+
+Ctl::~Ctl() {
+  if (base_) {
+    if (creator_) shm_unlink(name_.c_str());
+    munmap(base_, bytes_);
+  }
+}
+
+void Ctl::unlink_name() {
+  if (creator_) {
+    shm_unlink(name_.c_str());
+    creator_ = false;
+  }
+}
+
+int Ctl::wait_all_state(int state, double timeout_s) {
+  const double t0 = now_seconds();
+  Backoff bo;
+  for (;;) {
+    bool all = true;
+    for (int r = 0; r < size_; r++)
+      if (ranks_[r].state.load(std::memory_order_acquire) < state) {
+        all = false;
+        break;
+      }
+    if (all) return XMPI_OK;
+    if (aborted()) return XMPI_ERR_PEER;
+    if (now_seconds() - t0 > timeout_s) return XMPI_ERR_TIMEOUT;
+    bo.pause();
+  }
+}
+
+int Ctl::barrier(double timeout_s) {
+  if (size_ == 1) return XMPI_OK;
+  const uint32_t gen = hdr_->bar_gen.load(std::memory_order_acquire);
+  const uint32_t arrived = hdr_->bar_count.fetch_add(1, std::memory_order_acq_rel) + 1;
+  if (arrived == (uint32_t)size_) {
+    hdr_->bar_count.store(0, std::memory_order_relaxed);
+    hdr_->bar_gen.store(gen + 1, std::memory_order_release);
+    return XMPI_OK;
+  }
+  const double t0 = now_seconds();
+  Backoff bo;
+  while (hdr_->bar_gen.load(std::memory_order_acquire) == gen) {
+    if (aborted()) return XMPI_ERR_PEER;
+    if (now_seconds() - t0 > timeout_s) return XMPI_ERR_TIMEOUT;
+    bo.pause();
+  }
+  return XMPI_OK;
+}
+
+}  // namespace xmpi

@@ -1,0 +1,128 @@
+// ctl.h -- the shared-memory control block all ranks of one job map (host logic only, no HIP).
+//
+// It replaces the control traffic of the reference's TCP mesh: the password/id handshake of
+// (*Network).listenHandshake / dialHandshake (network.go:211-339) becomes "join the block and
+// publish a RankInfo", the per-connection tagManager (network.go:448-497) becomes the mail
+// entries of an ordered rank pair, and the ack message of receiveReader (network.go:616-624)
+// becomes the entry's DONE state.  Payload bytes never pass through here: they move
+// GPU-to-GPU into HBM windows; the block only carries counters and small headers.
+#pragma once
+#include <atomic>
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+namespace xmpi {
+
+constexpr int kMaxRanks = 16;
+constexpr int kMaxLanes = 4;
+constexpr int kMailEntries = 4;  // concurrent messages per ordered rank pair
+constexpr uint64_t kCtlMagic = 0x584D504943544C31ull;  // "XMPICTL1"
+
+struct alignas(64) Counter {
+  std::atomic<uint64_t> v;
+  char pad[56];
+};
+
+// One-directional FIFO of slots in the receiver's HBM window.  head = slots filled (written by
+// the sender after its copy completed), tail = slots drained (written by the receiver).
+struct PipeCtl {
+  Counter head;
+  Counter tail;
+};
+
+enum MailState : uint32_t { MAIL_FREE = 0, MAIL_CLAIMED = 1, MAIL_POSTED = 2, MAIL_MATCHED = 3, MAIL_DONE = 4 };
+
+struct alignas(64) MailEntry {
+  std::atomic<uint32_t> state;
+  int32_t tag;
+  int32_t dtype;
+  std::atomic<int32_t> status;  // receiver's verdict (XMPI_OK / XMPI_ERR_TRUNCATE / ...)
+  uint64_t bytes;
+  char pad[40];
+  PipeCtl pipe;
+};
+
+struct alignas(64) RankInfo {
+  std::atomic<int32_t> state;  // 0 absent, 1 joined, 2 window published, 3 left
+  int32_t pid;
+  int32_t device;
+  int32_t reserved;
+  uint64_t window_addr;   // device VA in the owner's process (used when peer pid == own pid)
+  uint64_t window_bytes;
+  uint8_t ipc_handle[64];  // hipIpcMemHandle_t of the window
+  char busid[32];
+};
+
+struct CtlConfig {
+  int32_t lanes;        // FIFO lanes per ordered pair for collectives
+  int32_t fifo_depth;   // slots per collective pipe
+  uint64_t slot_bytes;  // bytes per collective slot
+  int32_t p2p_depth;    // slots per mail entry
+  uint64_t p2p_slot_bytes;
+};
+
+struct alignas(64) CtlHeader {
+  std::atomic<uint64_t> magic;
+  uint32_t version;
+  int32_t size;
+  uint64_t total_bytes;
+  int32_t creator_pid;
+  uint64_t creator_start;  // /proc/<pid>/stat starttime of the creator (stale-segment check)
+  CtlConfig cfg;
+  std::atomic<int32_t> abort_code;  // != 0: some rank failed; everybody stops waiting
+  alignas(64) std::atomic<uint32_t> bar_count;
+  alignas(64) std::atomic<uint32_t> bar_gen;
+};
+
+class Ctl {
+ public:
+  // Joins (rank 0: creates) the block named after `key`.  Returns 0 or a negative xmpi code.
+  static int join(const std::string& key, int rank, int size, const CtlConfig& cfg_if_creator,
+                  double timeout_s, Ctl** out, std::string* err);
+  ~Ctl();
+
+  int rank() const { return rank_; }
+  int size() const { return size_; }
+  const CtlConfig& cfg() const { return hdr_->cfg; }
+  CtlHeader* header() { return hdr_; }
+  RankInfo* info(int r) { return &ranks_[r]; }
+  PipeCtl* pipe(int src, int dst, int lane) { return &pipes_[((size_t)src * size_ + dst) * kMaxLanes + lane]; }
+  MailEntry* mail(int src, int dst, int e) { return &mail_[((size_t)src * size_ + dst) * kMailEntries + e]; }
+  void* base() const { return base_; }
+  size_t bytes() const { return bytes_; }
+
+  // all ranks reach `state` (RankInfo.state >= state) or timeout / abort
+  int wait_all_state(int state, double timeout_s);
+  int barrier(double timeout_s);
+  void set_abort(int code) {
+    int32_t z = 0;
+    hdr_->abort_code.compare_exchange_strong(z, code);
+  }
+  int aborted() const { return hdr_->abort_code.load(std::memory_order_acquire); }
+  // rank 0 removes the name (the mapping stays valid until every rank unmaps)
+  void unlink_name();
+
+  static size_t layout_bytes(int size);
+
+ private:
+  Ctl() = default;
+  std::string name_;
+  int rank_ = 0, size_ = 0;
+  void* base_ = nullptr;
+  size_t bytes_ = 0;
+  CtlHeader* hdr_ = nullptr;
+  RankInfo* ranks_ = nullptr;
+  PipeCtl* pipes_ = nullptr;
+  MailEntry* mail_ = nullptr;
+  bool creator_ = false;
+};
+
+// polite spin: pause a while, then yield the core (ranks may outnumber cores)
+struct Backoff {
+  unsigned n = 0;
+  void pause();
+};
+double now_seconds();
+
+}  // namespace xmpi

@@ -1,0 +1,688 @@
+// engine.cpp -- executes a step table (plan.h) over the HBM pipes, and the tagged
+// point-to-point rendezvous.  Compiled by hipcc as host code.
+//
+// Data path of one SEND/RECV pair (replaces gob-encode -> net.Conn -> gob-decode of
+// network.go:518-625):
+//   sender    : peer copy  local HBM -> slot in the RECEIVER's window (xGMI write, SDMA or copy
+//               kernel) on send_stream[peer]; when its event completes the host publishes
+//               head++ in the shared control block.
+//   receiver  : sees head > consumed, launches the reduction / copy-out kernel on
+//               recv_stream[peer] reading the slot from its own HBM; when that completes it
+//               publishes tail++ (the ack of network.go:616-624, one counter instead of a message).
+// Nothing on the GPU ever blocks on another process: a step is enqueued only once its
+// cross-process precondition already holds, so streams cannot deadlock however HIP maps them
+// to hardware queues.  Same-process dependencies are chained with events (no host round trip).
+#include <algorithm>
+#include <cstring>
+
+#include "comm.h"
+#include "kernels.h"
+
+namespace xmpi {
+
+hipEvent_t ev_get(xmpi_comm* c, bool timed) {
+  std::lock_guard<std::mutex> g(c->ev_mu);
+  std::vector<hipEvent_t>& pool = timed ? c->ev_timed_free : c->ev_free;
+  if (!pool.empty()) {
+    hipEvent_t e = pool.back();
+    pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreateWithFlags(&e, timed ? hipEventDefault : hipEventDisableTiming) != hipSuccess) return nullptr;
+  return e;
+}
+
+void ev_put(xmpi_comm* c, hipEvent_t e, bool timed) {
+  std::lock_guard<std::mutex> g(c->ev_mu);
+  if (e) (timed ? c->ev_timed_free : c->ev_free).push_back(e);
+}
+
+bool is_device_pointer(const void* p) {
+  hipPointerAttribute_t a;
+  memset(&a, 0, sizeof a);
+  hipError_t e = hipPointerGetAttributes(&a, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();  // unregistered host memory: clear the sticky error
+    return false;
+  }
+  return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged || a.type == hipMemoryTypeArray;
+}
+
+namespace {
+
+struct InFlight {
+  int step;
+  hipEvent_t done;
+  hipEvent_t start;  // only when profiling
+  int prof_kind;
+  size_t prof_bytes;
+};
+
+int peer_copy(xmpi_comm* c, void* dst, const void* src, size_t bytes, hipStream_t s) {
+  if (c->copy_engine == 1) {
+    XMPI_HIP(launch_copy(dst, src, bytes, s));
+  } else {
+    XMPI_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+  }
+  return XMPI_OK;
+}
+
+struct Exec {
+  xmpi_comm* c;
+  const Plan& plan;
+  char* bufs[3];
+  int dtype, op;
+  int N, L;
+  size_t es;
+
+  std::vector<std::deque<int>> sq, rq;  // per (peer, lane): pending SEND / RECV steps in FIFO order
+  std::deque<int> lq;                   // LOCAL_COPY / REDUCE_N
+  std::vector<uint8_t> state;           // 0 pending, 1 issued, 2 complete
+  std::vector<hipEvent_t> ev;
+  std::vector<int> stream_of;
+  std::vector<char*> slot_ptr;          // RECV_*: the slot this step reads
+  std::vector<uint64_t> slot_seq;
+  std::vector<std::deque<InFlight>> fl;  // per stream, completion is in issue order
+  std::vector<std::deque<char>> unreleased;  // per (peer, lane): popped slots not yet released
+  size_t remaining;
+  double last_progress;
+
+  Exec(xmpi_comm* comm, const Plan& p, const void* sb, void* rb, int dt, int o)
+      : c(comm), plan(p), dtype(dt), op(o), N(comm->size), L(comm->lanes) {
+    bufs[BUF_SEND] = (char*)const_cast<void*>(sb);
+    bufs[BUF_RECV] = (char*)rb;
+    bufs[BUF_TEMP] = (char*)comm->temp;
+    es = xmpi_dtype_size((xmpi_dtype)dt);
+    const size_t n = p.steps.size();
+    sq.resize((size_t)N * L);
+    rq.resize((size_t)N * L);
+    state.assign(n, 0);
+    ev.assign(n, nullptr);
+    stream_of.assign(n, -1);
+    slot_ptr.assign(n, nullptr);
+    slot_seq.assign(n, 0);
+    fl.resize((size_t)2 * N + 1);
+    unreleased.resize((size_t)N * L);
+    remaining = n;
+    for (size_t i = 0; i < n; i++) {
+      const Step& s = p.steps[i];
+      if (s.kind == STEP_SEND) sq[(size_t)s.peer * L + s.lane].push_back((int)i);
+      else if (s.kind == STEP_RECV_REDUCE || s.kind == STEP_RECV_COPY || s.kind == STEP_RECV_HOLD)
+        rq[(size_t)s.peer * L + s.lane].push_back((int)i);
+      else lq.push_back((int)i);
+    }
+    last_progress = now_seconds();
+  }
+
+  hipStream_t stream(int sid) const {
+    if (sid < N) return c->send_stream[sid];
+    if (sid < 2 * N) return c->recv_stream[sid - N];
+    return c->local_stream;
+  }
+
+  bool deps_issued(const Step& s) const {
+    for (int d = 0; d < s.ndeps; d++)
+      if (state[(size_t)s.deps[d]] == 0) return false;
+    return true;
+  }
+
+  int chain_deps(const Step& s, int sid) {
+    for (int d = 0; d < s.ndeps; d++) {
+      const int j = s.deps[d];
+      if (state[(size_t)j] == 1 && stream_of[(size_t)j] != sid && ev[(size_t)j])
+        XMPI_HIP(hipStreamWaitEvent(stream(sid), ev[(size_t)j], 0));
+    }
+    return XMPI_OK;
+  }
+
+  int begin_op(int i, int sid, InFlight* f, int prof_kind, size_t prof_bytes) {
+    f->step = i;
+    f->start = nullptr;
+    f->prof_kind = prof_kind;
+    f->prof_bytes = prof_bytes;
+    if (c->prof_on && prof_kind >= 0) {
+      f->start = ev_get(c, true);
+      if (!f->start) return XMPI_ERR_HIP;
+      XMPI_HIP(hipEventRecord(f->start, stream(sid)));
+    }
+    return XMPI_OK;
+  }
+
+  int end_op(int i, int sid, InFlight* f) {
+    const bool timed = f->start != nullptr;
+    f->done = ev_get(c, timed);
+    if (!f->done) return XMPI_ERR_HIP;
+    XMPI_HIP(hipEventRecord(f->done, stream(sid)));
+    ev[(size_t)i] = f->done;
+    stream_of[(size_t)i] = sid;
+    state[(size_t)i] = 1;
+    fl[(size_t)sid].push_back(*f);
+    return XMPI_OK;
+  }
+
+  void release_slot(int peer, int lane, uint64_t seq) {
+    std::deque<char>& u = unreleased[(size_t)peer * L + lane];
+    uint64_t& base = c->recvd_released[peer][lane];
+    u[(size_t)(seq - base)] = 1;
+    while (!u.empty() && u.front()) {
+      u.pop_front();
+      base++;
+    }
+    c->ctl->pipe(peer, c->rank, lane)->tail.v.store(base, std::memory_order_release);
+  }
+
+  int complete(const InFlight& f) {
+    const Step& s = plan.steps[(size_t)f.step];
+    if (f.start) {
+      float ms = 0.f;
+      XMPI_HIP(hipEventElapsedTime(&ms, f.start, f.done));
+      ProfCounter& pc = c->prof[f.prof_kind];
+      pc.launches++;
+      pc.total_ms += ms;
+      pc.bytes += f.prof_bytes;
+      ev_put(c, f.start, true);
+    }
+    ev_put(c, f.done, f.start != nullptr);
+    ev[(size_t)f.step] = nullptr;
+    state[(size_t)f.step] = 2;
+    remaining--;
+    switch (s.kind) {
+      case STEP_SEND: {
+        const uint64_t h = ++c->sent_done[s.peer][s.lane];
+        c->ctl->pipe(c->rank, s.peer, s.lane)->head.v.store(h, std::memory_order_release);
+        break;
+      }
+      case STEP_RECV_REDUCE:
+      case STEP_RECV_COPY:
+        release_slot(s.peer, s.lane, slot_seq[(size_t)f.step]);
+        break;
+      case STEP_REDUCE_N:
+        for (int k = 0; k < s.nsrcs; k++)
+          if (s.srcs[k] >= 0) {
+            const Step& h = plan.steps[(size_t)s.srcs[k]];
+            release_slot(h.peer, h.lane, slot_seq[(size_t)s.srcs[k]]);
+          }
+        break;
+      default:
+        break;
+    }
+    return XMPI_OK;
+  }
+
+  // returns 1 if issued, 0 if not ready, <0 on error
+  int try_send(int i) {
+    const Step& s = plan.steps[(size_t)i];
+    if (!deps_issued(s)) return 0;
+    const uint64_t seq = c->sent[s.peer][s.lane];
+    const uint64_t tail = c->ctl->pipe(c->rank, s.peer, s.lane)->tail.v.load(std::memory_order_acquire);
+    if (seq - tail >= (uint64_t)c->fifo_depth) return 0;
+    if (s.bytes > c->slot_bytes) return XMPI_ERR_ARG;
+    const int sid = s.peer;
+    int rc = chain_deps(s, sid);
+    if (rc) return rc;
+    InFlight f;
+    rc = begin_op(i, sid, &f, PROF_PEER, s.bytes);
+    if (rc) return rc;
+    char* dst = c->peer_window[s.peer] + c->coll_slot_off(c->rank, s.lane, seq);
+    rc = peer_copy(c, dst, bufs[s.src_buf] + s.src_off, s.bytes, stream(sid));
+    if (rc) return rc;
+    rc = end_op(i, sid, &f);
+    if (rc) return rc;
+    c->sent[s.peer][s.lane] = seq + 1;
+    return 1;
+  }
+
+  int try_recv(int i) {
+    const Step& s = plan.steps[(size_t)i];
+    if (!deps_issued(s)) return 0;
+    const uint64_t seq = c->recvd[s.peer][s.lane];
+    const uint64_t head = c->ctl->pipe(s.peer, c->rank, s.lane)->head.v.load(std::memory_order_acquire);
+    if (head <= seq) return 0;
+    char* slot = c->window + c->coll_slot_off(s.peer, s.lane, seq);
+    slot_ptr[(size_t)i] = slot;
+    slot_seq[(size_t)i] = seq;
+    c->recvd[s.peer][s.lane] = seq + 1;
+    unreleased[(size_t)s.peer * L + s.lane].push_back(0);
+    if (s.kind == STEP_RECV_HOLD) {
+      state[(size_t)i] = 2;
+      remaining--;
+      return 1;
+    }
+    const int sid = N + s.peer;
+    int rc = chain_deps(s, sid);
+    if (rc) return rc;
+    InFlight f;
+    if (s.kind == STEP_RECV_REDUCE) {
+      rc = begin_op(i, sid, &f, PROF_REDUCE2, 3 * s.bytes);
+      if (rc) return rc;
+      XMPI_HIP(launch_reduce2(bufs[s.dst_buf] + s.dst_off, bufs[s.src_buf] + s.src_off, slot, s.bytes / es, dtype,
+                              op, stream(sid)));
+    } else {
+      rc = begin_op(i, sid, &f, PROF_COPY, 2 * s.bytes);
+      if (rc) return rc;
+      XMPI_HIP(launch_copy(bufs[s.dst_buf] + s.dst_off, slot, s.bytes, stream(sid)));
+    }
+    return end_op(i, sid, &f) ? XMPI_ERR_HIP : 1;
+  }
+
+  int try_local(int i) {
+    const Step& s = plan.steps[(size_t)i];
+    if (!deps_issued(s)) return 0;
+    const int sid = 2 * N;
+    if (s.kind == STEP_REDUCE_N) {
+      for (int k = 0; k < s.nsrcs; k++)
+        if (s.srcs[k] >= 0 && state[(size_t)s.srcs[k]] == 0) return 0;
+    }
+    int rc = chain_deps(s, sid);
+    if (rc) return rc;
+    InFlight f;
+    if (s.kind == STEP_REDUCE_N) {
+      const void* srcs[kMaxSrcs];
+      for (int k = 0; k < s.nsrcs; k++)
+        srcs[k] = (s.srcs[k] < 0) ? (const void*)(bufs[s.src_buf] + s.src_off) : (const void*)slot_ptr[(size_t)s.srcs[k]];
+      rc = begin_op(i, sid, &f, PROF_REDUCEN, (size_t)(s.nsrcs + 1) * s.bytes);
+      if (rc) return rc;
+      XMPI_HIP(launch_reduce_n(bufs[s.dst_buf] + s.dst_off, srcs, s.nsrcs, s.bytes / es, dtype, op, stream(sid)));
+    } else {
+      rc = begin_op(i, sid, &f, PROF_COPY, 2 * s.bytes);
+      if (rc) return rc;
+      const char* src = bufs[s.src_buf] + s.src_off;
+      char* dst = bufs[s.dst_buf] + s.dst_off;
+      if (src != dst) XMPI_HIP(launch_copy(dst, src, s.bytes, stream(sid)));
+    }
+    return end_op(i, sid, &f) ? XMPI_ERR_HIP : 1;
+  }
+
+  int run() {
+    Backoff bo;
+    while (remaining > 0) {
+      bool progressed = false;
+      for (auto& q : sq)
+        while (!q.empty()) {
+          int r = try_send(q.front());
+          if (r < 0) return r;
+          if (r == 0) break;
+          q.pop_front();
+          progressed = true;
+        }
+      for (auto& q : rq)
+        while (!q.empty()) {
+          int r = try_recv(q.front());
+          if (r < 0) return r;
+          if (r == 0) break;
+          q.pop_front();
+          progressed = true;
+        }
+      // local steps may become ready out of order (different pieces wait on different pipes)
+      for (size_t k = 0; k < lq.size();) {
+        int r = try_local(lq[k]);
+        if (r < 0) return r;
+        if (r == 1) {
+          lq.erase(lq.begin() + (long)k);
+          progressed = true;
+        } else {
+          k++;
+          if (k >= 8) break;  // look a few steps ahead only
+        }
+      }
+      for (auto& q : fl)
+        while (!q.empty()) {
+          hipError_t e = hipEventQuery(q.front().done);
+          if (e == hipErrorNotReady) {
+            (void)hipGetLastError();
+            break;
+          }
+          if (e != hipSuccess) return hip_fail(e, "hipEventQuery", __FILE__, __LINE__);
+          int rc = complete(q.front());
+          if (rc) return rc;
+          q.pop_front();
+          progressed = true;
+        }
+      if (progressed) {
+        last_progress = now_seconds();
+        bo.n = 0;
+        continue;
+      }
+      if (c->ctl->aborted()) {
+        set_last_error("a peer rank aborted the job");
+        return XMPI_ERR_PEER;
+      }
+      if (c->timeout_s > 0 && now_seconds() - last_progress > (double)c->timeout_s) {
+        set_last_error("collective made no progress for " + std::to_string(c->timeout_s) + " s");
+        return XMPI_ERR_TIMEOUT;
+      }
+      bo.pause();
+    }
+    return XMPI_OK;
+  }
+};
+
+}  // namespace
+
+int run_plan(xmpi_comm* c, const Plan& plan, const void* sendbuf, void* recvbuf, int dtype, int op) {
+  if (plan.steps.empty()) return XMPI_OK;
+  if (plan.temp_bytes > c->temp_bytes) {
+    if (c->temp) XMPI_HIP(hipFree(c->temp));
+    c->temp = nullptr;
+    c->temp_bytes = 0;
+    XMPI_HIP(hipMalloc(&c->temp, plan.temp_bytes));
+    c->temp_bytes = plan.temp_bytes;
+  }
+  Exec ex(c, plan, sendbuf, recvbuf, dtype, op);
+  int rc = ex.run();
+  if (rc != XMPI_OK) {
+    c->ctl->set_abort(rc);
+    // leave no work behind that still references pooled events
+    (void)hipDeviceSynchronize();
+  }
+  return rc;
+}
+
+// ---- tagged point-to-point --------------------------------------------------------------------
+
+namespace {
+
+struct P2PStream {
+  hipStream_t s = nullptr;
+};
+
+hipStream_t p2p_stream_get(xmpi_comm* c) {
+  std::lock_guard<std::mutex> g(c->p2p_mu);
+  if (!c->p2p_streams.empty()) {
+    hipStream_t s = c->p2p_streams.back();
+    c->p2p_streams.pop_back();
+    return s;
+  }
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  return s;
+}
+
+void p2p_stream_put(xmpi_comm* c, hipStream_t s) {
+  std::lock_guard<std::mutex> g(c->p2p_mu);
+  c->p2p_streams.push_back(s);
+}
+
+struct TagGuard {
+  xmpi_comm* c;
+  std::set<std::pair<int, int>>* reg;
+  std::pair<int, int> key;
+  bool held = false;
+  TagGuard(xmpi_comm* comm, std::set<std::pair<int, int>>* r, int peer, int tag) : c(comm), reg(r), key(peer, tag) {
+    std::lock_guard<std::mutex> g(c->p2p_mu);
+    held = reg->insert(key).second;
+  }
+  ~TagGuard() {
+    if (held) {
+      std::lock_guard<std::mutex> g(c->p2p_mu);
+      reg->erase(key);
+    }
+  }
+};
+
+struct StreamLease {
+  xmpi_comm* c;
+  hipStream_t s;
+  explicit StreamLease(xmpi_comm* comm) : c(comm), s(p2p_stream_get(comm)) {}
+  ~StreamLease() {
+    if (s) p2p_stream_put(c, s);
+  }
+};
+
+bool timed_out(xmpi_comm* c, double t0) { return c->timeout_s > 0 && now_seconds() - t0 > (double)c->timeout_s; }
+
+}  // namespace
+
+int p2p_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, int tag) {
+  // {dest,tag} unique among concurrent sends (mpi.go:121-125; the reference panics at
+  // network.go:469, here it is an error code the Go shim turns into mpi.TagExists)
+  TagGuard tg(c, &c->send_tags, dest, tag);
+  if (!tg.held) {
+    set_last_error("tag " + std::to_string(tag) + " already in use sending to " + std::to_string(dest));
+    return XMPI_ERR_TAG_EXISTS;
+  }
+  StreamLease lease(c);
+  if (!lease.s) return hip_fail(hipGetLastError(), "hipStreamCreate", __FILE__, __LINE__);
+  const bool dev_src = bytes == 0 || is_device_pointer(buf);
+  const double t0 = now_seconds();
+  Backoff bo;
+
+  // claim a mail entry of the ordered pair (me -> dest)
+  MailEntry* m = nullptr;
+  int entry = -1;
+  while (!m) {
+    for (int e = 0; e < kMailEntries && !m; e++) {
+      MailEntry* cand = c->ctl->mail(c->rank, dest, e);
+      uint32_t expect = MAIL_FREE;
+      if (cand->state.compare_exchange_strong(expect, MAIL_CLAIMED, std::memory_order_acq_rel)) {
+        m = cand;
+        entry = e;
+      }
+    }
+    if (m) break;
+    if (c->ctl->aborted()) return XMPI_ERR_PEER;
+    if (timed_out(c, t0)) {
+      set_last_error("send: no free mail entry towards rank " + std::to_string(dest));
+      return XMPI_ERR_TIMEOUT;
+    }
+    bo.pause();
+  }
+  m->tag = tag;
+  m->dtype = dtype;
+  m->bytes = bytes;
+  m->status.store(XMPI_OK, std::memory_order_relaxed);
+  m->state.store(MAIL_POSTED, std::memory_order_release);
+
+  const size_t slot = c->p2p_slot_bytes;
+  const uint64_t npieces = (bytes + slot - 1) / slot;
+  const uint64_t depth = (uint64_t)c->p2p_depth;
+  std::deque<hipEvent_t> inflight;
+  uint64_t issued = 0, published = 0;
+  int rc = XMPI_OK;
+  void* stage = nullptr;
+  if (!dev_src && npieces > 0) {  // host payload: bounce through this rank's HBM
+    if (hipMalloc(&stage, std::min<size_t>(bytes, depth * slot)) != hipSuccess)
+      rc = hip_fail(hipGetLastError(), "hipMalloc(stage)", __FILE__, __LINE__);
+  }
+  bo.n = 0;
+  double tp = now_seconds();
+  while (rc == XMPI_OK && published < npieces) {
+    bool progressed = false;
+    if (issued < npieces) {
+      const uint64_t tail = m->pipe.tail.v.load(std::memory_order_acquire);
+      if (issued - tail < depth) {
+        const size_t off = (size_t)issued * slot, n = std::min(slot, bytes - off);
+        char* dst = c->peer_window[dest] + c->p2p_slot_off(c->rank, entry, issued);
+        hipError_t e;
+        if (dev_src) {
+          e = hipMemcpyAsync(dst, (const char*)buf + off, n, hipMemcpyDeviceToDevice, lease.s);
+        } else {
+          char* st = (char*)stage + (size_t)(issued % depth) * slot;
+          e = hipMemcpyAsync(st, (const char*)buf + off, n, hipMemcpyHostToDevice, lease.s);
+          if (e == hipSuccess) e = hipMemcpyAsync(dst, st, n, hipMemcpyDeviceToDevice, lease.s);
+        }
+        hipEvent_t ev = (e == hipSuccess) ? ev_get(c, false) : nullptr;
+        if (e == hipSuccess && ev) e = hipEventRecord(ev, lease.s);
+        if (e != hipSuccess || !ev) {
+          rc = hip_fail(e, "p2p send copy", __FILE__, __LINE__);
+          break;
+        }
+        inflight.push_back(ev);
+        issued++;
+        progressed = true;
+      }
+    }
+    while (!inflight.empty()) {
+      hipError_t e = hipEventQuery(inflight.front());
+      if (e == hipErrorNotReady) {
+        (void)hipGetLastError();
+        break;
+      }
+      if (e != hipSuccess) {
+        rc = hip_fail(e, "hipEventQuery", __FILE__, __LINE__);
+        break;
+      }
+      ev_put(c, inflight.front(), false);
+      inflight.pop_front();
+      m->pipe.head.v.store(++published, std::memory_order_release);
+      progressed = true;
+    }
+    if (progressed) {
+      tp = now_seconds();
+      bo.n = 0;
+      continue;
+    }
+    if (m->state.load(std::memory_order_acquire) == MAIL_DONE) break;  // receiver gave up (truncate...)
+    if (c->ctl->aborted()) rc = XMPI_ERR_PEER;
+    else if (c->timeout_s > 0 && now_seconds() - tp > (double)c->timeout_s) {
+      set_last_error("send to rank " + std::to_string(dest) + " tag " + std::to_string(tag) + ": no matching receive");
+      rc = XMPI_ERR_TIMEOUT;
+    }
+    bo.pause();
+  }
+  if (!inflight.empty()) {
+    (void)hipStreamSynchronize(lease.s);
+    while (!inflight.empty()) {
+      ev_put(c, inflight.front(), false);
+      inflight.pop_front();
+    }
+  }
+  // rendezvous: wait for the receiver's verdict (network.go:569 waits for the ack message)
+  tp = now_seconds();
+  bo.n = 0;
+  while (rc == XMPI_OK && m->state.load(std::memory_order_acquire) != MAIL_DONE) {
+    if (c->ctl->aborted()) rc = XMPI_ERR_PEER;
+    else if (c->timeout_s > 0 && now_seconds() - tp > (double)c->timeout_s) {
+      set_last_error("send to rank " + std::to_string(dest) + " tag " + std::to_string(tag) + ": no matching receive");
+      rc = XMPI_ERR_TIMEOUT;
+    }
+    bo.pause();
+  }
+  if (stage) (void)hipFree(stage);
+  if (rc == XMPI_OK) {
+    rc = m->status.load(std::memory_order_acquire);
+    m->pipe.head.v.store(0, std::memory_order_relaxed);
+    m->pipe.tail.v.store(0, std::memory_order_relaxed);
+    m->state.store(MAIL_FREE, std::memory_order_release);
+  } else {
+    c->ctl->set_abort(rc);  // the entry is in an unknown state: the job cannot continue
+  }
+  return rc;
+}
+
+int p2p_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int tag, size_t* got_bytes) {
+  TagGuard tg(c, &c->recv_tags, src, tag);
+  if (!tg.held) {
+    set_last_error("tag " + std::to_string(tag) + " already in use receiving from " + std::to_string(src));
+    return XMPI_ERR_TAG_EXISTS;
+  }
+  StreamLease lease(c);
+  if (!lease.s) return hip_fail(hipGetLastError(), "hipStreamCreate", __FILE__, __LINE__);
+  double t0 = now_seconds();
+  Backoff bo;
+  MailEntry* m = nullptr;
+  int entry = -1;
+  while (!m) {
+    for (int e = 0; e < kMailEntries && !m; e++) {
+      MailEntry* cand = c->ctl->mail(src, c->rank, e);
+      if (cand->state.load(std::memory_order_acquire) == MAIL_POSTED && cand->tag == tag) {
+        uint32_t expect = MAIL_POSTED;
+        if (cand->state.compare_exchange_strong(expect, MAIL_MATCHED, std::memory_order_acq_rel)) {
+          m = cand;
+          entry = e;
+        }
+      }
+    }
+    if (m) break;
+    if (c->ctl->aborted()) return XMPI_ERR_PEER;
+    if (timed_out(c, t0)) {
+      set_last_error("receive from rank " + std::to_string(src) + " tag " + std::to_string(tag) + ": no matching send");
+      return XMPI_ERR_TIMEOUT;
+    }
+    bo.pause();
+  }
+  const size_t bytes = m->bytes;
+  if (got_bytes) *got_bytes = bytes;
+  int verdict = XMPI_OK;
+  if (m->dtype != dtype) {
+    set_last_error("receive: dtype differs from the sender's");
+    verdict = XMPI_ERR_ARG;
+  } else if (bytes > cap_bytes) {
+    set_last_error("receive: message of " + std::to_string(bytes) + " bytes does not fit " + std::to_string(cap_bytes));
+    verdict = XMPI_ERR_TRUNCATE;
+  }
+  if (verdict != XMPI_OK) {
+    m->status.store(verdict, std::memory_order_release);
+    m->state.store(MAIL_DONE, std::memory_order_release);
+    return verdict;
+  }
+  const bool dev_dst = bytes == 0 || is_device_pointer(buf);
+  const size_t slot = c->p2p_slot_bytes;
+  const uint64_t npieces = (bytes + slot - 1) / slot;
+  std::deque<hipEvent_t> inflight;
+  uint64_t issued = 0, drained = 0;
+  int rc = XMPI_OK;
+  double tp = now_seconds();
+  bo.n = 0;
+  while (rc == XMPI_OK && drained < npieces) {
+    bool progressed = false;
+    if (issued < npieces && m->pipe.head.v.load(std::memory_order_acquire) > issued) {
+      const size_t off = (size_t)issued * slot, n = std::min(slot, bytes - off);
+      const char* from = c->window + c->p2p_slot_off(src, entry, issued);
+      hipError_t e = hipMemcpyAsync((char*)buf + off, from, n, dev_dst ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                                    lease.s);
+      hipEvent_t ev = (e == hipSuccess) ? ev_get(c, false) : nullptr;
+      if (e == hipSuccess && ev) e = hipEventRecord(ev, lease.s);
+      if (e != hipSuccess || !ev) {
+        rc = hip_fail(e, "p2p recv copy", __FILE__, __LINE__);
+        break;
+      }
+      inflight.push_back(ev);
+      issued++;
+      progressed = true;
+    }
+    while (!inflight.empty()) {
+      hipError_t e = hipEventQuery(inflight.front());
+      if (e == hipErrorNotReady) {
+        (void)hipGetLastError();
+        break;
+      }
+      if (e != hipSuccess) {
+        rc = hip_fail(e, "hipEventQuery", __FILE__, __LINE__);
+        break;
+      }
+      ev_put(c, inflight.front(), false);
+      inflight.pop_front();
+      m->pipe.tail.v.store(++drained, std::memory_order_release);
+      progressed = true;
+    }
+    if (progressed) {
+      tp = now_seconds();
+      bo.n = 0;
+      continue;
+    }
+    if (c->ctl->aborted()) rc = XMPI_ERR_PEER;
+    else if (c->timeout_s > 0 && now_seconds() - tp > (double)c->timeout_s) {
+      set_last_error("receive: sender stalled");
+      rc = XMPI_ERR_TIMEOUT;
+    }
+    bo.pause();
+  }
+  if (!inflight.empty()) {
+    (void)hipStreamSynchronize(lease.s);
+    while (!inflight.empty()) {
+      ev_put(c, inflight.front(), false);
+      inflight.pop_front();
+    }
+  }
+  if (rc != XMPI_OK) {
+    c->ctl->set_abort(rc);
+    return rc;
+  }
+  m->status.store(XMPI_OK, std::memory_order_release);
+  m->state.store(MAIL_DONE, std::memory_order_release);  // the ack (network.go:616-624)
+  return XMPI_OK;
+}
+
+}  // namespace xmpi

@@ -1,0 +1,35 @@
+// kernels.h -- internal launch API of the gfx950 kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace xmpi {
+
+constexpr int kMaxReduceSrcs = 16;
+
+// dst[i] = a[i] op b[i]; dst may alias a and/or b exactly (same address), never partially.
+hipError_t launch_reduce2(void* dst, const void* a, const void* b, size_t count, int dtype, int op,
+                          hipStream_t stream);
+// dst[i] = ((s0[i] op s1[i]) op s2[i]) ... left to right.
+hipError_t launch_reduce_n(void* dst, const void* const* srcs, int nsrc, size_t count, int dtype,
+                           int op, hipStream_t stream);
+// streaming copy (local HBM -> local HBM, or local HBM -> peer HBM over xGMI)
+hipError_t launch_copy(void* dst, const void* src, size_t bytes, hipStream_t stream);
+
+// *d_out += number of differing bytes (d_out: 8-byte device word, caller zeroes it)
+hipError_t launch_count_mismatch(const void* a, const void* b, size_t bytes, uint64_t* d_out,
+                                 hipStream_t stream);
+// *d_out += sum of LE u32 words + trailing bytes
+hipError_t launch_checksum(const void* buf, size_t bytes, uint64_t* d_out, hipStream_t stream);
+// d_out[0] = bits of max|a-b| (as u64 of a non-negative double), d_out[1] = sum|b| (double),
+// d_out[2] = NaN-mismatch count (u64); caller zeroes the 24 bytes
+hipError_t launch_diff_stats(const void* a, const void* b, size_t count, int dtype, void* d_out,
+                             hipStream_t stream);
+hipError_t launch_fill(void* buf, size_t count, int dtype, int pattern, uint64_t seed,
+                       hipStream_t stream);
+// one lane: system-scope release store of `value` to *flag (host-registered or device memory)
+hipError_t launch_signal(uint64_t* flag, uint64_t value, hipStream_t stream);
+
+}  // namespace xmpi

@@ -1,0 +1,655 @@
+// kernels.hip -- gfx950 (CDNA4, wave64) kernels of the collectives hot path.
+//
+// The reference has no kernels at all (it is pure Go).  These replace what a
+// reference user does on the host after exchanging buffers with Send/Receive
+// (examples/helloworld/helloworld.go:53-81): the elementwise combine of two (ring / halving
+// step) or N (full-mesh step) rank buffers, the copy out of a receive window, and the
+// bytes.Equal / floats.Equal checks of examples/bounce/bounce.go:105,133.
+//
+// All of them are HBM-bound streaming kernels (1 flop per 12 bytes for an f32 add), so the
+// design rules are the memory ones: 16 B per lane per access (global_load_dwordx4, 1 KiB per
+// wave instruction), every load of an unrolled tile issued before the first use, <=64 VGPRs
+// so 8 waves/SIMD stay resident, grids capped at 8 blocks/CU with a grid-stride loop.  No MFMA
+// (nothing here is a contraction) and no LDS in the streaming kernels (no cross-lane reuse);
+// LDS + wavefront shuffles are used where a cross-lane reduction really exists: the
+// verification kernels at the bottom.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace xmpi {
+namespace {
+
+constexpr int kBlock = 256;      // 4 waves: one per SIMD
+constexpr int kUnroll = 4;       // 16-byte packets per lane per operand in flight
+constexpr int kMaxBlocks = 2048; // 256 CUs x 8 resident blocks
+
+enum { DT_U8 = 0, DT_I32 = 1, DT_I64 = 2, DT_F16 = 3, DT_F32 = 4, DT_F64 = 5, DT_BF16 = 6 };
+enum { OP_SUM = 0, OP_PROD = 1, OP_MIN = 2, OP_MAX = 3 };
+
+struct bf16_t {
+  uint16_t bits;
+};
+
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+// 16-byte packet: a native vector (not HIP's pack_t struct) so it always lives in 4 VGPRs
+typedef unsigned int pack_t __attribute__((ext_vector_type(4)));
+
+// ---- scalar combine: one rounding per operation, min/max spelled as in oracle/xmpi_oracle.c ---
+
+template <typename T, int OP>
+__device__ __forceinline__ T combine(T a, T b) {
+  if constexpr (OP == OP_SUM) return a + b;
+  else if constexpr (OP == OP_PROD) return a * b;
+  else if constexpr (OP == OP_MIN) return (b < a) ? b : a;
+  else return (a < b) ? b : a;
+}
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+template <int OP>
+__device__ __forceinline__ bf16_t combine_bf16(bf16_t a, bf16_t b) {
+  float x = bf16_to_f32(a.bits), y = bf16_to_f32(b.bits);
+  if constexpr (OP == OP_SUM) return bf16_t{f32_to_bf16(x + y)};
+  else if constexpr (OP == OP_PROD) return bf16_t{f32_to_bf16(x * y)};
+  else if constexpr (OP == OP_MIN) return (y < x) ? b : a;
+  else return (x < y) ? b : a;
+}
+
+// wrapping integer arithmetic (Go semantics) without signed-overflow UB
+template <int OP>
+__device__ __forceinline__ int32_t combine_i32(int32_t a, int32_t b) {
+  if constexpr (OP == OP_SUM) return (int32_t)((uint32_t)a + (uint32_t)b);
+  else if constexpr (OP == OP_PROD) return (int32_t)((uint32_t)a * (uint32_t)b);
+  else return combine<int32_t, OP>(a, b);
+}
+template <int OP>
+__device__ __forceinline__ int64_t combine_i64(int64_t a, int64_t b) {
+  if constexpr (OP == OP_SUM) return (int64_t)((uint64_t)a + (uint64_t)b);
+  else if constexpr (OP == OP_PROD) return (int64_t)((uint64_t)a * (uint64_t)b);
+  else return combine<int64_t, OP>(a, b);
+}
+
+template <typename T, int OP>
+__device__ __forceinline__ T combine_any(T a, T b) {
+  if constexpr (sizeof(T) == 2 && !__is_same(T, _Float16)) return combine_bf16<OP>(a, b);
+  else if constexpr (__is_same(T, int32_t)) return combine_i32<OP>(a, b);
+  else if constexpr (__is_same(T, int64_t)) return combine_i64<OP>(a, b);
+  else if constexpr (__is_same(T, uint8_t)) {
+    if constexpr (OP == OP_SUM) return (uint8_t)(a + b);
+    else if constexpr (OP == OP_PROD) return (uint8_t)(a * b);
+    else return combine<uint8_t, OP>(a, b);
+  } else return combine<T, OP>(a, b);
+}
+
+// ---- 16-byte packet combine ------------------------------------------------------------------
+
+template <typename T, int OP>
+__device__ __forceinline__ pack_t combine16(pack_t a, pack_t b) {
+  constexpr int N = 16 / sizeof(T);
+  if constexpr (__is_same(T, _Float16) && (OP == OP_SUM || OP == OP_PROD)) {
+    // packed halves: v_pk_add_f16 / v_pk_mul_f16, 2 elements per VALU lane-op
+    union { pack_t u; half2_t h[4]; } x, y, r;
+    x.u = a; y.u = b;
+#pragma unroll
+    for (int i = 0; i < 4; i++) r.h[i] = (OP == OP_SUM) ? (x.h[i] + y.h[i]) : (x.h[i] * y.h[i]);
+    return r.u;
+  } else {
+    union { pack_t u; T e[N]; } x, y, r;
+    x.u = a; y.u = b;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.e[i] = combine_any<T, OP>(x.e[i], y.e[i]);
+    return r.u;
+  }
+}
+
+// ---- dst = a op b  (the per-chunk reduction of every ring / halving step) --------------------
+// Lane l of block B touches packets  base + k*256 + l  (k < kUnroll): each wave instruction
+// covers one contiguous KiB; 2 x kUnroll loads are in flight before the first VALU op.
+
+template <typename T, int OP>
+__global__ __launch_bounds__(kBlock) void reduce2_kernel(T* dst, const T* a, const T* b,
+                                                         size_t npack, size_t count) {
+  const pack_t* pa = reinterpret_cast<const pack_t*>(a);
+  const pack_t* pb = reinterpret_cast<const pack_t*>(b);
+  pack_t* pd = reinterpret_cast<pack_t*>(dst);
+  constexpr size_t kTile = (size_t)kBlock * kUnroll;
+  const size_t stride = (size_t)gridDim.x * kTile;
+  // wave w of the block owns kUnroll consecutive KiB: lane l reads packets first + k*64, so the
+  // k-th access is the same address register + an immediate offset of k KiB
+  const size_t lane_off = (size_t)(threadIdx.x >> 6) * (64 * kUnroll) + (threadIdx.x & 63);
+  for (size_t base = (size_t)blockIdx.x * kTile; base < npack; base += stride) {
+    const size_t first = base + lane_off;
+    if (base + kTile <= npack) {  // full tile: every load issued before the first use
+      pack_t va[kUnroll], vb[kUnroll];
+#pragma unroll
+      for (int k = 0; k < kUnroll; k++) {
+        va[k] = pa[first + k * 64];
+        vb[k] = pb[first + k * 64];
+      }
+#pragma unroll
+      for (int k = 0; k < kUnroll; k++) pd[first + k * 64] = combine16<T, OP>(va[k], vb[k]);
+    } else {  // last, partial tile of the buffer
+      for (int k = 0; k < kUnroll; k++) {
+        const size_t i = first + k * 64;
+        if (i < npack) pd[i] = combine16<T, OP>(pa[i], pb[i]);
+      }
+    }
+  }
+  // ragged tail (< 16 bytes): the first lanes of block 0
+  constexpr size_t N = 16 / sizeof(T);
+  const size_t done = npack * N;
+  if (blockIdx.x == 0 && done + threadIdx.x < count) {
+    const size_t i = done + threadIdx.x;
+    dst[i] = combine_any<T, OP>(a[i], b[i]);
+  }
+}
+
+// any alignment: one element per lane per iteration (correctness path for odd offsets)
+template <typename T, int OP>
+__global__ __launch_bounds__(kBlock) void reduce2_elem_kernel(T* dst, const T* a, const T* b,
+                                                              size_t count) {
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride)
+    dst[i] = combine_any<T, OP>(a[i], b[i]);
+}
+
+// ---- dst = ((s0 op s1) op s2) ...  strictly left to right (full-mesh step, rank order) -------
+
+struct SrcPtrs {
+  const void* p[kMaxReduceSrcs];
+};
+
+template <typename T, int OP, int NSRC>
+__global__ __launch_bounds__(kBlock) void reduce_n_kernel(T* dst, SrcPtrs srcs, int nsrc_rt,
+                                                          size_t npack, size_t count) {
+  const int nsrc = (NSRC > 0) ? NSRC : nsrc_rt;
+  pack_t* pd = reinterpret_cast<pack_t*>(dst);
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < npack; i += stride) {
+    if constexpr (NSRC > 0) {
+      pack_t v[NSRC];
+#pragma unroll
+      for (int s = 0; s < NSRC; s++) v[s] = reinterpret_cast<const pack_t*>(srcs.p[s])[i];
+      pack_t acc = v[0];
+#pragma unroll
+      for (int s = 1; s < NSRC; s++) acc = combine16<T, OP>(acc, v[s]);
+      pd[i] = acc;
+    } else {
+      pack_t acc = reinterpret_cast<const pack_t*>(srcs.p[0])[i];
+      for (int s = 1; s < nsrc; s++)
+        acc = combine16<T, OP>(acc, reinterpret_cast<const pack_t*>(srcs.p[s])[i]);
+      pd[i] = acc;
+    }
+  }
+  constexpr size_t N = 16 / sizeof(T);
+  const size_t done = npack * N;
+  if (blockIdx.x == 0 && done + threadIdx.x < count) {
+    const size_t i = done + threadIdx.x;
+    T acc = reinterpret_cast<const T*>(srcs.p[0])[i];
+    for (int s = 1; s < nsrc; s++) acc = combine_any<T, OP>(acc, reinterpret_cast<const T*>(srcs.p[s])[i]);
+    dst[i] = acc;
+  }
+}
+
+// ---- streaming copy --------------------------------------------------------------------------
+
+__global__ __launch_bounds__(kBlock) void copy16_kernel(pack_t* dst, const pack_t* src, size_t npack,
+                                                        size_t bytes) {
+  constexpr size_t kTile = (size_t)kBlock * kUnroll;
+  const size_t stride = (size_t)gridDim.x * kTile;
+  const size_t lane_off = (size_t)(threadIdx.x >> 6) * (64 * kUnroll) + (threadIdx.x & 63);
+  for (size_t base = (size_t)blockIdx.x * kTile; base < npack; base += stride) {
+    const size_t first = base + lane_off;
+    if (base + kTile <= npack) {
+      pack_t v[kUnroll];
+#pragma unroll
+      for (int k = 0; k < kUnroll; k++) v[k] = src[first + k * 64];
+#pragma unroll
+      for (int k = 0; k < kUnroll; k++) dst[first + k * 64] = v[k];
+    } else {
+      for (int k = 0; k < kUnroll; k++) {
+        const size_t i = first + k * 64;
+        if (i < npack) dst[i] = src[i];
+      }
+    }
+  }
+  const size_t done = npack * 16;
+  if (blockIdx.x == 0 && done + threadIdx.x < bytes) {
+    const size_t i = done + threadIdx.x;
+    reinterpret_cast<uint8_t*>(dst)[i] = reinterpret_cast<const uint8_t*>(src)[i];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void copy1_kernel(uint8_t* dst, const uint8_t* src, size_t bytes) {
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < bytes; i += stride) dst[i] = src[i];
+}
+
+// ---- verification kernels: wavefront __shfl_down + LDS block reduction -----------------------
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    double o = __shfl_down(v, off, 64);
+    v = (o > v) ? o : v;
+  }
+  return v;
+}
+
+// block-wide sum of one u64 per lane; result valid in thread 0
+__device__ __forceinline__ uint64_t block_sum_u64(uint64_t v, uint64_t* lds /*[kBlock/64]*/) {
+  v = wave_sum_u64(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) lds[wave] = v;
+  __syncthreads();
+  uint64_t r = 0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; w++) r += lds[w];
+  }
+  __syncthreads();
+  return r;
+}
+
+__device__ __forceinline__ uint32_t diff_bytes_u32(uint32_t x, uint32_t y) {
+  uint32_t d = x ^ y;  // a byte differs iff any of its bits is set
+  d |= d >> 4;
+  d |= d >> 2;
+  d |= d >> 1;
+  return __popc(d & 0x01010101u);
+}
+
+__global__ __launch_bounds__(kBlock) void count_mismatch_kernel(const uint8_t* a, const uint8_t* b,
+                                                                size_t bytes, int vec_ok,
+                                                                unsigned long long* out) {
+  __shared__ uint64_t lds[kBlock / 64];
+  uint64_t n = 0;
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  size_t done = 0;
+  if (vec_ok) {
+    const size_t npack = bytes / 16;
+    const pack_t* pa = reinterpret_cast<const pack_t*>(a);
+    const pack_t* pb = reinterpret_cast<const pack_t*>(b);
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < npack; i += stride) {
+      const pack_t x = pa[i], y = pb[i];
+      n += diff_bytes_u32(x.x, y.x) + diff_bytes_u32(x.y, y.y) + diff_bytes_u32(x.z, y.z) +
+           diff_bytes_u32(x.w, y.w);
+    }
+    done = npack * 16;
+  }
+  for (size_t i = done + (size_t)blockIdx.x * kBlock + threadIdx.x; i < bytes; i += stride)
+    n += (a[i] != b[i]);
+  const uint64_t tot = block_sum_u64(n, lds);
+  if (threadIdx.x == 0 && tot) atomicAdd(out, (unsigned long long)tot);
+}
+
+__global__ __launch_bounds__(kBlock) void checksum_kernel(const uint8_t* buf, size_t bytes, int vec_ok,
+                                                          unsigned long long* out) {
+  __shared__ uint64_t lds[kBlock / 64];
+  uint64_t s = 0;
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  const size_t nword = bytes / 4;
+  size_t wdone = 0;
+  if (vec_ok) {
+    const size_t npack = bytes / 16;
+    const pack_t* p = reinterpret_cast<const pack_t*>(buf);
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < npack; i += stride) {
+      const pack_t v = p[i];
+      s += (uint64_t)v.x + v.y + v.z + v.w;
+    }
+    wdone = npack * 4;
+  }
+  for (size_t w = wdone + (size_t)blockIdx.x * kBlock + threadIdx.x; w < nword; w += stride) {
+    const uint8_t* q = buf + 4 * w;  // byte loads: any alignment
+    s += (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+  }
+  for (size_t i = 4 * nword + (size_t)blockIdx.x * kBlock + threadIdx.x; i < bytes; i += stride)
+    s += buf[i];
+  const uint64_t tot = block_sum_u64(s, lds);
+  if (threadIdx.x == 0 && tot) atomicAdd(out, (unsigned long long)tot);
+}
+
+template <typename T>
+__device__ __forceinline__ double as_double(T v) {
+  if constexpr (sizeof(T) == 2 && !__is_same(T, _Float16)) return (double)bf16_to_f32(v.bits);
+  else return (double)v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void diff_stats_kernel(const T* a, const T* b, size_t count,
+                                                            unsigned long long* out_max,
+                                                            double* out_sum,
+                                                            unsigned long long* out_nan) {
+  __shared__ double lds_max[kBlock / 64];
+  __shared__ double lds_sum[kBlock / 64];
+  __shared__ uint64_t lds_nan[kBlock / 64];
+  double mx = 0.0, sb = 0.0;
+  uint64_t nn = 0;
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride) {
+    const double x = as_double(a[i]), y = as_double(b[i]);
+    const bool nx = (x != x), ny = (y != y);
+    if (nx || ny) {
+      nn += (nx != ny);
+    } else {
+      const double d = fabs(x - y);
+      mx = (d > mx) ? d : mx;
+      sb += fabs(y);
+    }
+  }
+  mx = wave_max_f64(mx);
+  sb = wave_sum_f64(sb);
+  nn = wave_sum_u64(nn);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    lds_max[wave] = mx;
+    lds_sum[wave] = sb;
+    lds_nan[wave] = nn;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m = 0.0, s = 0.0;
+    uint64_t n = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; w++) {
+      m = (lds_max[w] > m) ? lds_max[w] : m;
+      s += lds_sum[w];
+      n += lds_nan[w];
+    }
+    // non-negative doubles order like their bit patterns
+    atomicMax(out_max, (unsigned long long)__double_as_longlong(m));
+    atomicAdd(out_sum, s);
+    if (n) atomicAdd(out_nan, (unsigned long long)n);
+  }
+}
+
+// ---- deterministic inputs: mirrors oracle_fill (oracle/xmpi_oracle.c) bit for bit ------------
+
+__device__ __forceinline__ uint64_t hash64(uint64_t seed, uint64_t i) {
+  uint64_t z = seed * 0xD1342543DE82EF95ULL + i * 0x9E3779B97F4A7C15ULL + 0x2545F4914F6CDD1DULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+
+// value of element i as a double exactly representable in the target type
+__device__ __forceinline__ double pattern_real(int dtype, int pattern, uint64_t seed, uint64_t i) {
+  const uint64_t h = hash64(seed, i);
+  switch (pattern) {
+    case 0:
+      if (dtype == DT_F64) return (double)(h >> 11) * 0x1p-53;
+      if (dtype == DT_F32) return (double)(h >> 40) * 0x1p-24;
+      if (dtype == DT_F16) return (double)(h & 63u) * 0x1p-6;
+      return (double)(h & 15u) * 0x1p-4;
+    case 1:
+      if (dtype == DT_F16) return (double)(i & 63u) * 0x1p-6 + (double)(seed & 7u);
+      if (dtype == DT_BF16) return (double)(i & 15u) * 0x1p-4 + (double)(seed & 7u);
+      return (double)(i % 251u) * 0x1p-8 + (double)(seed & 0xFFu);
+    case 2:
+      return (double)((seed & 0xFFu) + 1u);
+    default: {
+      const double m = (double)((h >> 40) & 0xFFu) * 0x1p-8 - 0.5;
+      const int sh = (int)((h >> 8) & 7u) - 4;
+      return ldexp(m, sh);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void fill_kernel(void* buf, size_t count, int dtype, int pattern,
+                                                      uint64_t seed) {
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride) {
+    switch (dtype) {
+      case DT_U8: {
+        uint8_t v = (pattern == 1)   ? (uint8_t)(seed * 31u + i)
+                    : (pattern == 2) ? (uint8_t)(seed + 1u)
+                                     : (uint8_t)(hash64(seed, i) >> 56);
+        reinterpret_cast<uint8_t*>(buf)[i] = v;
+        break;
+      }
+      case DT_I32: {
+        int32_t v = (pattern == 1)   ? (int32_t)(((uint32_t)seed << 24) | ((uint32_t)i & 0xFFFFFFu))
+                    : (pattern == 2) ? (int32_t)(seed + 1u)
+                                     : (int32_t)(uint32_t)(hash64(seed, i) >> 32);
+        reinterpret_cast<int32_t*>(buf)[i] = v;
+        break;
+      }
+      case DT_I64: {
+        int64_t v = (pattern == 1)   ? (int64_t)((seed << 40) | (uint64_t)i)
+                    : (pattern == 2) ? (int64_t)(seed + 1u)
+                                     : (int64_t)hash64(seed, i);
+        reinterpret_cast<int64_t*>(buf)[i] = v;
+        break;
+      }
+      case DT_F16:  // exactly representable => both conversions are exact
+        reinterpret_cast<_Float16*>(buf)[i] = (_Float16)(float)pattern_real(dtype, pattern, seed, i);
+        break;
+      case DT_BF16:
+        reinterpret_cast<uint16_t*>(buf)[i] = f32_to_bf16((float)pattern_real(dtype, pattern, seed, i));
+        break;
+      case DT_F32:
+        reinterpret_cast<float*>(buf)[i] = (float)pattern_real(dtype, pattern, seed, i);
+        break;
+      default:
+        reinterpret_cast<double*>(buf)[i] = pattern_real(dtype, pattern, seed, i);
+        break;
+    }
+  }
+}
+
+// ---- cross-process completion flag -----------------------------------------------------------
+
+__global__ void signal_kernel(uint64_t* flag, uint64_t value) {
+  // everything earlier on this stream has completed (stream order); publish system-wide
+  __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ---- launch helpers --------------------------------------------------------------------------
+
+inline int grid_for(size_t work_items, size_t per_block) {
+  size_t g = (work_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > (size_t)kMaxBlocks) g = kMaxBlocks;
+  return (int)g;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <typename T, int OP>
+hipError_t reduce2_typed(void* dst, const void* a, const void* b, size_t count, hipStream_t s) {
+  if (count == 0) return hipSuccess;
+  if (aligned16(dst) && aligned16(a) && aligned16(b)) {
+    constexpr size_t N = 16 / sizeof(T);
+    const size_t npack = count / N;
+    const int grid = grid_for(npack, (size_t)kBlock * kUnroll);
+    hipLaunchKernelGGL((reduce2_kernel<T, OP>), dim3(grid), dim3(kBlock), 0, s, (T*)dst, (const T*)a,
+                       (const T*)b, npack, count);
+  } else {
+    const int grid = grid_for(count, kBlock);
+    hipLaunchKernelGGL((reduce2_elem_kernel<T, OP>), dim3(grid), dim3(kBlock), 0, s, (T*)dst,
+                       (const T*)a, (const T*)b, count);
+  }
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t reduce2_op(void* dst, const void* a, const void* b, size_t count, int op, hipStream_t s) {
+  switch (op) {
+    case OP_SUM: return reduce2_typed<T, OP_SUM>(dst, a, b, count, s);
+    case OP_PROD: return reduce2_typed<T, OP_PROD>(dst, a, b, count, s);
+    case OP_MIN: return reduce2_typed<T, OP_MIN>(dst, a, b, count, s);
+    case OP_MAX: return reduce2_typed<T, OP_MAX>(dst, a, b, count, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+template <typename T, int OP>
+hipError_t reduce_n_typed(void* dst, const SrcPtrs& srcs, int nsrc, size_t count, hipStream_t s) {
+  constexpr size_t N = 16 / sizeof(T);
+  const size_t npack = count / N;
+  const int grid = grid_for(npack, kBlock);
+#define XMPI_RN(NS)                                                                              \
+  case NS:                                                                                       \
+    hipLaunchKernelGGL((reduce_n_kernel<T, OP, NS>), dim3(grid), dim3(kBlock), 0, s, (T*)dst, srcs, \
+                       nsrc, npack, count);                                                      \
+    break;
+  switch (nsrc) {
+    XMPI_RN(2) XMPI_RN(3) XMPI_RN(4) XMPI_RN(5) XMPI_RN(6) XMPI_RN(7) XMPI_RN(8)
+    default:
+      hipLaunchKernelGGL((reduce_n_kernel<T, OP, 0>), dim3(grid), dim3(kBlock), 0, s, (T*)dst, srcs,
+                         nsrc, npack, count);
+      break;
+  }
+#undef XMPI_RN
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t reduce_n_op(void* dst, const SrcPtrs& srcs, int nsrc, size_t count, int op, hipStream_t s) {
+  switch (op) {
+    case OP_SUM: return reduce_n_typed<T, OP_SUM>(dst, srcs, nsrc, count, s);
+    case OP_PROD: return reduce_n_typed<T, OP_PROD>(dst, srcs, nsrc, count, s);
+    case OP_MIN: return reduce_n_typed<T, OP_MIN>(dst, srcs, nsrc, count, s);
+    case OP_MAX: return reduce_n_typed<T, OP_MAX>(dst, srcs, nsrc, count, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace
+
+hipError_t launch_reduce2(void* dst, const void* a, const void* b, size_t count, int dtype, int op,
+                          hipStream_t s) {
+  switch (dtype) {
+    case DT_U8: return reduce2_op<uint8_t>(dst, a, b, count, op, s);
+    case DT_I32: return reduce2_op<int32_t>(dst, a, b, count, op, s);
+    case DT_I64: return reduce2_op<int64_t>(dst, a, b, count, op, s);
+    case DT_F16: return reduce2_op<_Float16>(dst, a, b, count, op, s);
+    case DT_F32: return reduce2_op<float>(dst, a, b, count, op, s);
+    case DT_F64: return reduce2_op<double>(dst, a, b, count, op, s);
+    case DT_BF16: return reduce2_op<bf16_t>(dst, a, b, count, op, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_reduce_n(void* dst, const void* const* srcs, int nsrc, size_t count, int dtype,
+                           int op, hipStream_t s) {
+  if (nsrc < 1 || nsrc > kMaxReduceSrcs) return hipErrorInvalidValue;
+  if (count == 0) return hipSuccess;
+  if (nsrc == 1) {
+    static const size_t es[] = {1, 4, 8, 2, 4, 8, 2};
+    if (dtype < 0 || dtype > DT_BF16) return hipErrorInvalidValue;
+    return launch_copy(dst, srcs[0], count * es[dtype], s);
+  }
+  bool ok = aligned16(dst);
+  SrcPtrs p;
+  for (int i = 0; i < kMaxReduceSrcs; i++) p.p[i] = (i < nsrc) ? srcs[i] : nullptr;
+  for (int i = 0; i < nsrc; i++) ok = ok && aligned16(srcs[i]);
+  if (!ok) {  // odd alignment: chain the element kernel (same left-to-right order)
+    hipError_t e = launch_reduce2(dst, srcs[0], srcs[1], count, dtype, op, s);
+    for (int i = 2; i < nsrc && e == hipSuccess; i++) e = launch_reduce2(dst, dst, srcs[i], count, dtype, op, s);
+    return e;
+  }
+  switch (dtype) {
+    case DT_U8: return reduce_n_op<uint8_t>(dst, p, nsrc, count, op, s);
+    case DT_I32: return reduce_n_op<int32_t>(dst, p, nsrc, count, op, s);
+    case DT_I64: return reduce_n_op<int64_t>(dst, p, nsrc, count, op, s);
+    case DT_F16: return reduce_n_op<_Float16>(dst, p, nsrc, count, op, s);
+    case DT_F32: return reduce_n_op<float>(dst, p, nsrc, count, op, s);
+    case DT_F64: return reduce_n_op<double>(dst, p, nsrc, count, op, s);
+    case DT_BF16: return reduce_n_op<bf16_t>(dst, p, nsrc, count, op, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_copy(void* dst, const void* src, size_t bytes, hipStream_t s) {
+  if (bytes == 0 || dst == src) return hipSuccess;
+  if (aligned16(dst) && aligned16(src)) {
+    const size_t npack = bytes / 16;
+    const int grid = grid_for(npack, (size_t)kBlock * kUnroll);
+    hipLaunchKernelGGL(copy16_kernel, dim3(grid), dim3(kBlock), 0, s, (pack_t*)dst, (const pack_t*)src,
+                       npack, bytes);
+  } else {
+    hipLaunchKernelGGL(copy1_kernel, dim3(grid_for(bytes, kBlock)), dim3(kBlock), 0, s, (uint8_t*)dst,
+                       (const uint8_t*)src, bytes);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_count_mismatch(const void* a, const void* b, size_t bytes, uint64_t* d_out,
+                                 hipStream_t s) {
+  if (bytes == 0) return hipSuccess;
+  const int vec_ok = aligned16(a) && aligned16(b);
+  hipLaunchKernelGGL(count_mismatch_kernel, dim3(grid_for(bytes / 16 + 1, kBlock * 4)), dim3(kBlock), 0,
+                     s, (const uint8_t*)a, (const uint8_t*)b, bytes, vec_ok, (unsigned long long*)d_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_checksum(const void* buf, size_t bytes, uint64_t* d_out, hipStream_t s) {
+  if (bytes == 0) return hipSuccess;
+  const int vec_ok = aligned16(buf);
+  hipLaunchKernelGGL(checksum_kernel, dim3(grid_for(bytes / 16 + 1, kBlock * 4)), dim3(kBlock), 0, s,
+                     (const uint8_t*)buf, bytes, vec_ok, (unsigned long long*)d_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_diff_stats(const void* a, const void* b, size_t count, int dtype, void* d_out,
+                             hipStream_t s) {
+  if (count == 0) return hipSuccess;
+  unsigned long long* o_max = (unsigned long long*)d_out;
+  double* o_sum = (double*)d_out + 1;
+  unsigned long long* o_nan = (unsigned long long*)d_out + 2;
+  const dim3 grid(grid_for(count, kBlock * 8)), block(kBlock);
+  switch (dtype) {
+    case DT_F16:
+      hipLaunchKernelGGL(diff_stats_kernel<_Float16>, grid, block, 0, s, (const _Float16*)a,
+                         (const _Float16*)b, count, o_max, o_sum, o_nan);
+      break;
+    case DT_BF16:
+      hipLaunchKernelGGL(diff_stats_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)a,
+                         (const bf16_t*)b, count, o_max, o_sum, o_nan);
+      break;
+    case DT_F32:
+      hipLaunchKernelGGL(diff_stats_kernel<float>, grid, block, 0, s, (const float*)a, (const float*)b,
+                         count, o_max, o_sum, o_nan);
+      break;
+    case DT_F64:
+      hipLaunchKernelGGL(diff_stats_kernel<double>, grid, block, 0, s, (const double*)a,
+                         (const double*)b, count, o_max, o_sum, o_nan);
+      break;
+    default:
+      return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_fill(void* buf, size_t count, int dtype, int pattern, uint64_t seed, hipStream_t s) {
+  if (count == 0) return hipSuccess;
+  if (dtype < 0 || dtype > DT_BF16 || pattern < 0 || pattern > 3) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(count, kBlock * 4)), dim3(kBlock), 0, s, buf, count,
+                     dtype, pattern, seed);
+  return hipGetLastError();
+}
+
+hipError_t launch_signal(uint64_t* flag, uint64_t value, hipStream_t s) {
+  hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(1), 0, s, flag, value);
+  return hipGetLastError();
+}
+
+}  // namespace xmpi

@@ -1,0 +1,66 @@
+"""Launch N rank processes (one per GPU when the box has N, otherwise sharing device 0) and wait."""
+import json
+import os
+import subprocess
+import sys
+import threading
+import uuid
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_ranks(scenario: str, size: int, args: dict | None = None, timeout: float = 300.0, env: dict | None = None):
+    key = f"t{os.getpid()}-{uuid.uuid4().hex[:8]}"
+    e = dict(os.environ)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    e.setdefault("XMPI_TIMEOUT_S", "60")
+    e.update(env or {})
+    procs = []
+    for r in range(size):
+        cmd = [sys.executable, os.path.join(ROOT, "tests", "rank_worker.py"), scenario, str(r), str(size), key,
+               json.dumps(args or {})]
+        procs.append(subprocess.Popen(cmd, cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [None] * size
+
+    def wait(i):
+        try:
+            outs[i], _ = procs[i].communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            procs[i].kill()
+            outs[i] = (procs[i].communicate()[0] or "") + "\n[harness] killed after timeout"
+
+    ts = [threading.Thread(target=wait, args=(i,)) for i in range(size)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    failed = [i for i, p in enumerate(procs) if p.returncode != 0]
+    if failed:
+        msg = "\n".join(f"--- rank {i} (exit {procs[i].returncode}) ---\n{outs[i]}" for i in range(size))
+        raise AssertionError(f"scenario {scenario} size {size}: ranks {failed} failed\n{msg}")
+    return outs
+
+
+def run_threads(scenario: str, size: int, args: dict | None = None):
+    """All ranks as threads of THIS process (pid-equal peers share pointers instead of hipIpc)."""
+    from mpi_amd import xmpi
+    from tests import scenarios
+    key = f"th{os.getpid()}-{uuid.uuid4().hex[:8]}"
+    errors = []
+
+    def body(r):
+        try:
+            comm = xmpi.Comm(r, size, (args or {}).get("device", -1), key)
+            scenarios.SCENARIOS[scenario](comm, args or {})
+            comm.barrier()
+            comm.finalize()
+        except BaseException as e:  # noqa: BLE001
+            import traceback
+            errors.append((r, traceback.format_exc()))
+
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(size)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, "\n".join(f"rank {r}:\n{tb}" for r, tb in errors)

@@ -1,0 +1,426 @@
+"""Multi-rank GPU scenarios.  Each function runs on ONE rank (a process or a thread) against the
+C ABI through mpi_amd.xmpi and checks its own results against the CPU oracle.  On the 1-GPU
+test box all ranks share device 0 (functional test of the real multi-process hipIpc path)."""
+from __future__ import annotations
+
+import threading
+
+import numpy as np
+
+from mpi_amd import xmpi
+from oracle import oracle
+
+FLOATS = (xmpi.F16, xmpi.F32, xmpi.F64, xmpi.BF16)
+# per-element tolerance factor on sum_i |x_i| when the summation order differs from rank order
+TOL = {xmpi.F32: 1e-6, xmpi.F64: 2e-15, xmpi.F16: 2.0 ** -10, xmpi.BF16: 2.0 ** -7}
+
+
+def check_reduced(got: np.ndarray, ins, dtype: int, op: int, exact: bool, what: str):
+    want = oracle.reduce_ranks(ins, dtype, op)
+    if exact or dtype not in FLOATS or op in (xmpi.MIN, xmpi.MAX):
+        bad = oracle.count_mismatch(got, want)
+        assert bad == 0, f"{what}: {bad} bytes differ from the rank-order oracle"
+        return
+    g, w = oracle.as_float64(got, dtype), oracle.as_float64(want, dtype)
+    if op == xmpi.SUM:
+        scale = np.sum([np.abs(oracle.as_float64(x, dtype)) for x in ins], axis=0)
+    else:
+        scale = np.abs(w)
+    n = len(ins)
+    # f32/f64: BASELINE.md bound (two orderings, each within (N-1)*eps*sum|x|, N <= 8);
+    # 16-bit floats round every partial sum to 11 / 8 bits: (N-1) * 2 * eps
+    bound = TOL[dtype] * scale * (max(1, n - 1) if dtype in (xmpi.F16, xmpi.BF16) else 1.0)
+    err = np.abs(g - w)
+    worst = int(np.argmax(err - bound))
+    assert np.all(err <= bound), f"{what}: |delta|={err[worst]:.3e} > bound {bound[worst]:.3e} at {worst}"
+
+
+def allreduce_case(comm, dtype, count, algo, op=xmpi.SUM, pattern=xmpi.PAT_UNIFORM, inplace=False, seed0=1000,
+                   exact=None):
+    rank, size = comm.rank(), comm.size()
+    es = xmpi.DTYPE_SIZE[dtype]
+    send = comm.alloc(count * es)
+    recv = send if inplace else comm.alloc(count * es)
+    comm.fill(send, count, dtype, pattern, seed0 + rank)
+    ins = [oracle.fill(count, dtype, pattern, seed0 + r) for r in range(size)]
+    mine = send.download(xmpi.NUMPY_DTYPE[dtype], count)
+    assert mine.tobytes() == ins[rank].tobytes(), "device fill differs from oracle fill"
+    if not inplace:
+        comm.memset(recv, 0xA5, count * es)
+    comm.allreduce(send, recv, count, dtype, op, algo)
+    got = recv.download(xmpi.NUMPY_DTYPE[dtype], count)
+    if exact is None:
+        # rank-order algorithms and exactly-summable inputs must be bit-identical
+        exact = algo == xmpi.ALGO_DIRECT or size <= 2 or pattern in (xmpi.PAT_CONST,) or (
+            dtype in (xmpi.F16, xmpi.BF16) and pattern in (xmpi.PAT_UNIFORM, xmpi.PAT_INDEX) and op == xmpi.SUM)
+    check_reduced(got, ins, dtype, op, exact,
+                  f"allreduce {xmpi.DTYPE_NAME[dtype]} n={count} algo={algo} op={op} pat={pattern} inplace={inplace}")
+    if not inplace:
+        again = send.download(xmpi.NUMPY_DTYPE[dtype], count)
+        assert again.tobytes() == ins[rank].tobytes(), "sendbuf was modified"
+        recv.free()
+    send.free()
+
+
+def sc_allreduce_small(comm, args):
+    counts = args.get("counts", [0, 1, 3, 17, 1000, 4099, 65536 + 5])
+    for dtype in args.get("dtypes", [xmpi.F32, xmpi.I64, xmpi.F16, xmpi.F64, xmpi.I32, xmpi.U8, xmpi.BF16]):
+        for algo in (xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_DIRECT, xmpi.ALGO_AUTO):
+            for count in counts:
+                allreduce_case(comm, dtype, count, algo)
+    # other operators, signed data, in place
+    for op in (xmpi.PROD, xmpi.MIN, xmpi.MAX):
+        for dtype in (xmpi.F32, xmpi.I32, xmpi.F16):
+            # a float product in another order may underflow differently: compare it only where the
+            # fold is in rank order (DIRECT, bit-exact)
+            if not (op == xmpi.PROD and dtype in FLOATS):
+                allreduce_case(comm, dtype, 3001, xmpi.ALGO_RING, op=op, pattern=xmpi.PAT_SIGNED)
+            allreduce_case(comm, dtype, 3001, xmpi.ALGO_DIRECT, op=op, pattern=xmpi.PAT_SIGNED)
+    for algo in (xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_DIRECT):
+        allreduce_case(comm, xmpi.F32, 100003, algo, inplace=True)
+        allreduce_case(comm, xmpi.F32, 100003, algo, pattern=xmpi.PAT_SIGNED)
+        allreduce_case(comm, xmpi.F64, 50001, algo, pattern=xmpi.PAT_SIGNED)
+        allreduce_case(comm, xmpi.I64, 4097, algo, pattern=xmpi.PAT_CONST)  # x_r = r+1 -> N(N+1)/2
+    # known answer: x_r[i] = r + 1  =>  every element N(N+1)/2
+    n = comm.size()
+    buf = comm.alloc(4 * 1024)
+    comm.fill(buf, 1024, xmpi.F32, xmpi.PAT_CONST, comm.rank())
+    comm.allreduce(buf, buf, 1024, xmpi.F32, xmpi.SUM, xmpi.ALGO_RING)
+    assert np.all(buf.download(np.float32, 1024) == np.float32(n * (n + 1) / 2))
+    buf.free()
+
+
+def sc_allreduce_medium(comm, args):
+    """multi-piece, multi-channel pipelines (several MiB per rank)"""
+    for piece in (0, 64 << 10):
+        comm.set_param("piece_bytes", piece)
+        for channels in (1, 4):
+            comm.set_param("channels", channels)
+            for algo in (xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_DIRECT):
+                allreduce_case(comm, xmpi.F32, (3 << 20) + 7, algo)
+                allreduce_case(comm, xmpi.F16, (2 << 20) + 3, algo)
+    comm.set_param("piece_bytes", 0)
+    comm.set_param("channels", 4)
+    for engine in (1, 0):
+        comm.set_param("copy_engine", engine)
+        allreduce_case(comm, xmpi.I64, (1 << 20) + 1, xmpi.ALGO_RING)
+        allreduce_case(comm, xmpi.F32, (4 << 20) + 5, xmpi.ALGO_DIRECT, pattern=xmpi.PAT_SIGNED)
+
+
+def allgather_case(comm, dtype, count, algo, inplace=False):
+    rank, size = comm.rank(), comm.size()
+    es = xmpi.DTYPE_SIZE[dtype]
+    recv = comm.alloc(count * es * size)
+    comm.memset(recv, 0x5A, count * es * size)
+    if inplace:
+        send_ptr = recv.at(rank * count * es)
+        comm.fill(send_ptr, count, dtype, xmpi.PAT_INDEX, rank)
+        send = None
+    else:
+        send = comm.alloc(count * es)
+        comm.fill(send, count, dtype, xmpi.PAT_INDEX, rank)
+        send_ptr = send.ptr
+    comm.allgather(send_ptr, recv, count, dtype, algo)
+    got = recv.download(xmpi.NUMPY_DTYPE[dtype], count * size)
+    want = oracle.allgather([oracle.fill(count, dtype, xmpi.PAT_INDEX, r) for r in range(size)], dtype)
+    assert got.tobytes() == want.tobytes(), f"allgather {xmpi.DTYPE_NAME[dtype]} n={count} algo={algo} inplace={inplace}"
+    recv.free()
+    if send:
+        send.free()
+
+
+def sc_allgather(comm, args):
+    for dtype in (xmpi.I64, xmpi.U8, xmpi.F32):
+        for algo in (xmpi.ALGO_RING, xmpi.ALGO_DIRECT, xmpi.ALGO_AUTO):
+            for count in (0, 1, 5, 1000, 4099, (1 << 20) + 3):
+                allgather_case(comm, dtype, count, algo)
+    allgather_case(comm, xmpi.I64, 70001, xmpi.ALGO_RING, inplace=True)
+    allgather_case(comm, xmpi.I64, 70001, xmpi.ALGO_DIRECT, inplace=True)
+
+
+def sc_bcast_reduce(comm, args):
+    rank, size = comm.rank(), comm.size()
+    for root in sorted({0, size - 1, size // 2}):
+        for dtype, count in ((xmpi.U8, 1), (xmpi.I64, 4099), (xmpi.F32, (1 << 20) + 9), (xmpi.F16, 0)):
+            es = xmpi.DTYPE_SIZE[dtype]
+            buf = comm.alloc(count * es)
+            comm.fill(buf, count, dtype, xmpi.PAT_UNIFORM, 40 + rank)
+            comm.bcast(buf, count, dtype, root)
+            got = buf.download(xmpi.NUMPY_DTYPE[dtype], count)
+            want = oracle.fill(count, dtype, xmpi.PAT_UNIFORM, 40 + root)
+            assert got.tobytes() == want.tobytes(), f"bcast root={root} {xmpi.DTYPE_NAME[dtype]} n={count}"
+            buf.free()
+        for algo in (xmpi.ALGO_TREE, xmpi.ALGO_DIRECT):
+            for dtype, count, pat in ((xmpi.F32, 100003, xmpi.PAT_SIGNED), (xmpi.I64, 4099, xmpi.PAT_UNIFORM),
+                                      (xmpi.F16, 5001, xmpi.PAT_UNIFORM), (xmpi.F64, 1, xmpi.PAT_SIGNED)):
+                es = xmpi.DTYPE_SIZE[dtype]
+                send = comm.alloc(count * es)
+                recv = comm.alloc(count * es)
+                comm.fill(send, count, dtype, pat, 70 + rank)
+                comm.reduce(send, recv, count, dtype, xmpi.SUM, root, algo)
+                if rank == root:
+                    ins = [oracle.fill(count, dtype, pat, 70 + r) for r in range(size)]
+                    got = recv.download(xmpi.NUMPY_DTYPE[dtype], count)
+                    exact = algo == xmpi.ALGO_DIRECT or size <= 2 or (dtype == xmpi.F16 and pat == xmpi.PAT_UNIFORM)
+                    check_reduced(got, ins, dtype, xmpi.SUM, exact, f"reduce root={root} algo={algo}")
+                send.free()
+                recv.free()
+    # host-resident buffers go through the same collectives (staged through HBM)
+    x = oracle.fill(1000, xmpi.F32, xmpi.PAT_UNIFORM, 5 + rank)
+    out = np.zeros_like(x)
+    comm.allreduce(x, out, 1000, xmpi.F32, xmpi.SUM, xmpi.ALGO_DIRECT)
+    want = oracle.reduce_ranks([oracle.fill(1000, xmpi.F32, xmpi.PAT_UNIFORM, 5 + r) for r in range(size)], xmpi.F32, 0)
+    assert out.tobytes() == want.tobytes()
+
+
+# ---- point to point ------------------------------------------------------------------------------
+
+BOUNCE_LENGTHS = [0, 1, 10, 100, 1000, 10**4, 10**5, 10**6, 10**7]  # examples/bounce/bounce.go:33
+
+
+def sc_bounce(comm, args):
+    """examples/bounce/bounce.go:83-137: even rank sends to rank+1, odd rank echoes; the even rank
+    checks the echo is bit-identical (bytes.Equal / floats.Equal)."""
+    rank, size = comm.rank(), comm.size()
+    assert size % 2 == 0
+    even = rank % 2 == 0
+    peer = rank + 1 if even else rank - 1
+    maxlen = BOUNCE_LENGTHS[-1]
+    msg = comm.alloc(maxlen)
+    rcv = comm.alloc(maxlen)
+    comm.fill(msg, maxlen, xmpi.U8, xmpi.PAT_UNIFORM, 1 + rank)
+    for length in BOUNCE_LENGTHS:
+        for dtype, count in ((xmpi.U8, length), (xmpi.F64, length // 8)):
+            nbytes = count * xmpi.DTYPE_SIZE[dtype]
+            comm.memset(rcv, 0, maxlen)  # bounce.go:110-112: no false positives from the previous round
+            if even:
+                comm.send(msg, count, dtype, peer, 0)
+                got = comm.recv(rcv, count, dtype, peer, 0)
+                assert got == count
+                assert comm.count_mismatch(msg, rcv, nbytes) == 0, f"echo of {nbytes} bytes differs"
+            else:
+                got = comm.recv(rcv, count, dtype, peer, 0)
+                assert got == count
+                comm.send(rcv, count, dtype, peer, 0)
+    # BASELINE cfg 2: 1 MiB float32 ping-pong, bit-exact
+    n = 262144
+    comm.fill(msg, n, xmpi.F32, xmpi.PAT_UNIFORM, 1)
+    for _ in range(5):
+        comm.memset(rcv, 0, n * 4)
+        if even:
+            comm.send(msg, n, xmpi.F32, peer, 3)
+            comm.recv(rcv, n, xmpi.F32, peer, 3)
+            assert comm.count_mismatch(msg, rcv, n * 4) == 0
+        else:
+            comm.recv(rcv, n, xmpi.F32, peer, 3)
+            comm.send(rcv, n, xmpi.F32, peer, 3)
+
+
+def sc_helloworld(comm, args):
+    """examples/helloworld/helloworld.go:53-81: every rank concurrently sends a string to every rank
+    (itself included) with tag 0 and receives one from every rank."""
+    rank, size = comm.rank(), comm.size()
+    errors = []
+
+    def text(dst, src):
+        return (f"\"I'm just node {src} talking to myself\"" if dst == src else f"\"Hello node {dst}, I'm node {src}\"").encode()
+
+    def sender(i):
+        try:
+            s = np.frombuffer(text(i, rank), dtype=np.uint8).copy()
+            comm.send(s, s.size, xmpi.U8, i, 0)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    def receiver(i):
+        try:
+            buf = np.zeros(256, dtype=np.uint8)
+            got = comm.recv(buf, 256, xmpi.U8, i, 0)
+            assert buf[:got].tobytes() == text(rank, i), (buf[:got].tobytes(), text(rank, i))
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=sender, args=(i,)) for i in range(size)]
+    ts += [threading.Thread(target=receiver, args=(i,)) for i in range(size)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+
+
+def sc_p2p_semantics(comm, args):
+    rank, size = comm.rank(), comm.size()
+    assert size >= 2
+    if rank > 1:
+        comm.barrier()
+        return
+    peer = 1 - rank
+    n = 300000  # spans several window slots only with small slots; still multi-piece-safe
+    a = comm.alloc(n * 4)
+    b = comm.alloc(n * 4)
+    # concurrent sends with distinct tags, received in the opposite order (mpi.go:121-125)
+    errors = []
+    if rank == 0:
+        comm.fill(a, n, xmpi.F32, xmpi.PAT_UNIFORM, 11)
+        comm.fill(b, n, xmpi.I32, xmpi.PAT_UNIFORM, 12)
+
+        def snd(buf, dt, tag):
+            try:
+                comm.send(buf, n, dt, peer, tag)
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+
+        ts = [threading.Thread(target=snd, args=(a, xmpi.F32, 7)), threading.Thread(target=snd, args=(b, xmpi.I32, 8))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errors, errors
+    else:
+        comm.recv(b, n, xmpi.I32, peer, 8)
+        comm.recv(a, n, xmpi.F32, peer, 7)
+        assert a.download(np.float32, n).tobytes() == oracle.fill(n, xmpi.F32, 0, 11).tobytes()
+        assert b.download(np.int32, n).tobytes() == oracle.fill(n, xmpi.I32, 0, 12).tobytes()
+    # receive buffer larger than the message: count reported; smaller: XMPI_ERR_TRUNCATE on both sides
+    if rank == 0:
+        comm.send(a, 10, xmpi.F32, peer, 1)
+        try:
+            comm.send(a, 100, xmpi.F32, peer, 2)
+            raise AssertionError("truncated send must fail")
+        except xmpi.XmpiError as e:
+            assert e.code == xmpi.ERR_TRUNCATE
+    else:
+        assert comm.recv(b, 1000, xmpi.F32, peer, 1) == 10
+        try:
+            comm.recv(b, 50, xmpi.F32, peer, 2)
+            raise AssertionError("truncated receive must fail")
+        except xmpi.XmpiError as e:
+            assert e.code == xmpi.ERR_TRUNCATE
+    # duplicate {peer, tag} among concurrent calls -> TagExists (the reference panics, network.go:469)
+    if rank == 0:
+        got = []
+
+        def blocked():
+            try:
+                comm.send(a, 4, xmpi.F32, peer, 99)
+            except Exception as e:  # noqa: BLE001
+                got.append(e)
+
+        t = threading.Thread(target=blocked)
+        t.start()
+        import time
+        time.sleep(0.3)  # the first send is now waiting for its receiver
+        try:
+            comm.send(a, 4, xmpi.F32, peer, 99)
+            raise AssertionError("duplicate tag must fail")
+        except xmpi.XmpiError as e:
+            assert e.code == xmpi.ERR_TAG_EXISTS
+        comm.send(a, 1, xmpi.U8, peer, 100)  # release the peer
+        t.join()
+        assert not got, got
+    else:
+        comm.recv(b, 1, xmpi.U8, peer, 100)
+        comm.recv(b, 4, xmpi.F32, peer, 99)
+    # host-resident payloads on either side
+    if rank == 0:
+        h = oracle.fill(5000, xmpi.F64, 0, 3)
+        comm.send(h, 5000, xmpi.F64, peer, 5)
+    else:
+        h = np.zeros(5000, dtype=np.float64)
+        comm.recv(h, 5000, xmpi.F64, peer, 5)
+        assert h.tobytes() == oracle.fill(5000, xmpi.F64, 0, 3).tobytes()
+    a.free()
+    b.free()
+    comm.barrier()
+
+
+def sc_fullsize(comm, args):
+    """BASELINE.json configs at full size, verified on the device (size-independent properties)."""
+    rank, size = comm.rank(), comm.size()
+    which = args["which"]
+    if which == "cfg3":  # allgather int64 16 MiB / rank, bit-exact positions
+        count = 2097152
+        send = comm.alloc(count * 8)
+        recv = comm.alloc(count * 8 * size)
+        want = comm.alloc(count * 8 * size)
+        comm.fill(send, count, xmpi.I64, xmpi.PAT_INDEX, rank)
+        for r in range(size):
+            comm.fill(want.at(r * count * 8), count, xmpi.I64, xmpi.PAT_INDEX, r)
+        for algo in (xmpi.ALGO_RING, xmpi.ALGO_DIRECT):
+            comm.memset(recv, 0, count * 8 * size)
+            comm.allgather(send, recv, count, xmpi.I64, algo)
+            assert comm.count_mismatch(recv, want, count * 8 * size) == 0
+        # spot-check against the CPU oracle as well: x[i] = (r << 40) | i
+        for r in (0, size - 1):
+            got = recv.download(np.int64, 1024, byte_offset=(r * count + count - 1024) * 8)
+            assert np.array_equal(got, (np.int64(r) << 40) | np.arange(count - 1024, count, dtype=np.int64))
+        return
+    if which == "cfg4":  # allreduce-sum f32 256 MiB
+        count, dtype = args.get("count", 67108864), xmpi.F32
+    else:  # cfg5: fp16, exactly summable inputs (k/64) -> every algorithm bit-identical
+        count, dtype = args.get("count", 536870912), xmpi.F16
+    es = xmpi.DTYPE_SIZE[dtype]
+    send = comm.alloc(count * es)
+    ref = comm.alloc(count * es)
+    out = comm.alloc(count * es)
+    seed0 = 1000 if which == "cfg4" else 2000
+    comm.fill(send, count, dtype, xmpi.PAT_UNIFORM, seed0 + rank)
+    # rank-order result (DIRECT) is the on-device reference; check windows of it against the CPU oracle
+    comm.allreduce(send, ref, count, dtype, xmpi.SUM, xmpi.ALGO_DIRECT)
+    for off in (0, count // 3, count - 65536):
+        off = off // 8 * 8
+        ins = []
+        for r in range(size):  # regenerate the same window of every rank's input on the CPU
+            ins.append(oracle_fill_window(dtype, seed0 + r, off, 65536))
+        mine = send.download(xmpi.NUMPY_DTYPE[dtype], 65536, byte_offset=off * es)
+        assert mine.tobytes() == ins[rank].tobytes(), "device fill window differs from the oracle's"
+        want = oracle.reduce_ranks(ins, dtype, xmpi.SUM)
+        got = ref.download(xmpi.NUMPY_DTYPE[dtype], 65536, byte_offset=off * es)
+        assert got.tobytes() == want.tobytes(), f"{which}: DIRECT differs from the rank-order oracle at {off}"
+    for algo in (xmpi.ALGO_RING, xmpi.ALGO_RHD):
+        comm.memset(out, 0, count * es)
+        comm.allreduce(send, out, count, dtype, xmpi.SUM, algo)
+        if dtype == xmpi.F16:
+            assert comm.count_mismatch(out, ref, count * es) == 0, f"{which} algo {algo}: not bit-identical"
+        else:
+            mx, sb, nn = comm.diff_stats(out, ref, count, dtype)
+            # inputs in [0,1): sum_i|x_i| <= N, so |delta| <= 1e-6 * N is the BASELINE.md bound
+            assert nn == 0 and mx <= 1e-6 * size, f"{which} algo {algo}: max|delta| {mx}"
+            s1, s2 = comm.checksum(out, count * es), comm.checksum(ref, count * es)
+            assert s1 != 0 and s2 != 0
+    # idempotence of the data path: the same call again gives the same bits
+    comm.allreduce(send, out, count, dtype, xmpi.SUM, xmpi.ALGO_DIRECT)
+    assert comm.count_mismatch(out, ref, count * es) == 0
+
+
+def np_hash(seed: int, idx: np.ndarray) -> np.ndarray:
+    """numpy restatement of oracle_hash (cross-checked against the C one in tests/test_oracle.py)"""
+    u = np.uint64
+    with np.errstate(over="ignore"):
+        z = u(seed) * u(0xD1342543DE82EF95) + idx.astype(np.uint64) * u(0x9E3779B97F4A7C15) + u(0x2545F4914F6CDD1D)
+        z = (z ^ (z >> u(30))) * u(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> u(27))) * u(0x94D049BB133111EB)
+        return z ^ (z >> u(31))
+
+
+def oracle_fill_window(dtype, seed, start, n):
+    """elements [start, start+n) of oracle_fill(..., PAT_UNIFORM, seed) without generating the prefix"""
+    h = np_hash(seed, np.arange(start, start + n, dtype=np.uint64))
+    if dtype == xmpi.F32:
+        return ((h >> np.uint64(40)).astype(np.float64) * 2.0 ** -24).astype(np.float32)
+    if dtype == xmpi.F16:
+        return ((h & np.uint64(63)).astype(np.float64) / 64.0).astype(np.float16)
+    raise NotImplementedError
+
+
+SCENARIOS = {
+    "allreduce_small": sc_allreduce_small,
+    "allreduce_medium": sc_allreduce_medium,
+    "allgather": sc_allgather,
+    "bcast_reduce": sc_bcast_reduce,
+    "bounce": sc_bounce,
+    "helloworld": sc_helloworld,
+    "p2p_semantics": sc_p2p_semantics,
+    "fullsize": sc_fullsize,
+}

@@ -1,0 +1,81 @@
+"""Multi-rank parity tests on real hardware.  One process per rank (the production path: hipIpc
+windows + shared control block); on a 1-GPU box the ranks share device 0, on an N-GPU box rank i
+uses GPU i % ndev.  Every rank checks its own result against the CPU oracle (tests/scenarios.py)."""
+import pytest
+
+from tests.gpu_harness import run_ranks, run_threads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("size", [2, 4, 8])
+def test_allreduce_small(size):
+    run_ranks("allreduce_small", size, timeout=600)
+
+
+@pytest.mark.parametrize("size", [3, 5])
+def test_allreduce_odd_world(size):
+    run_ranks("allreduce_small", size, {"counts": [1, 1000, 4099], "dtypes": [4, 2, 3]}, timeout=600)
+
+
+@pytest.mark.parametrize("size", [2, 8])
+def test_allreduce_pipelined(size):
+    run_ranks("allreduce_medium", size, timeout=600)
+
+
+def test_allreduce_tiny_slots():
+    """4 KiB slots and a 2-deep FIFO force heavy slot reuse and back-pressure"""
+    run_ranks("allreduce_medium", 4, timeout=600,
+              env={"XMPI_SLOT_BYTES": "65536", "XMPI_FIFO_DEPTH": "2", "XMPI_P2P_SLOT_BYTES": "8192"})
+
+
+@pytest.mark.parametrize("size", [2, 4, 8])
+def test_allgather(size):
+    run_ranks("allgather", size, timeout=600)
+
+
+@pytest.mark.parametrize("size", [2, 4, 7])
+def test_bcast_reduce(size):
+    run_ranks("bcast_reduce", size, timeout=600)
+
+
+@pytest.mark.parametrize("size", [2, 4])
+def test_bounce(size):
+    """examples/bounce/bounce.go at its own message lengths + BASELINE cfg 2 (1 MiB f32)"""
+    run_ranks("bounce", size, timeout=600)
+
+
+def test_bounce_small_p2p_slots():
+    run_ranks("bounce", 2, timeout=600, env={"XMPI_P2P_SLOT_BYTES": "8192"})
+
+
+@pytest.mark.parametrize("size", [1, 2, 4])
+def test_helloworld(size):
+    """examples/helloworld/helloworld.go: BASELINE cfg 1 (all-to-all strings incl. self-send)"""
+    run_ranks("helloworld", size, timeout=300)
+
+
+def test_p2p_semantics():
+    run_ranks("p2p_semantics", 2, timeout=300, env={"XMPI_P2P_SLOT_BYTES": "65536"})
+
+
+def test_ranks_as_threads():
+    """ranks hosted by threads of one process share window pointers instead of hipIpc handles"""
+    run_threads("allreduce_small", 4, {"counts": [1, 4099], "dtypes": [4, 2]})
+    run_threads("helloworld", 3)
+
+
+def test_cfg3_allgather_int64_full():
+    """BASELINE cfg 3: allgather int64, 16 MiB per rank, 4 ranks, bit-exact"""
+    run_ranks("fullsize", 4, {"which": "cfg3"}, timeout=600)
+
+
+def test_cfg4_allreduce_f32_full():
+    """BASELINE cfg 4 (headline): allreduce-sum f32 256 MiB, 8 ranks"""
+    run_ranks("fullsize", 8, {"which": "cfg4"}, timeout=900)
+
+
+def test_cfg5_allreduce_f16_large():
+    """BASELINE cfg 5: fp16 allreduce, ring vs recursive halving, exactly-summable inputs.
+    256 MiB per rank here (8 ranks share one GPU on the test box); bench.py runs the 1 GiB size."""
+    run_ranks("fullsize", 8, {"which": "cfg5", "count": 134217728}, timeout=900)

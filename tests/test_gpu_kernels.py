@@ -1,0 +1,151 @@
+"""Parity of the HIP kernels with the CPU oracle, through the C ABI, on one MI355X.
+Bit-exact for every dtype and operator (a two-operand combine has no ordering freedom; the
+N-way fold is strictly left to right like the oracle's)."""
+import numpy as np
+import pytest
+
+from mpi_amd import xmpi
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+ALL_DTYPES = [xmpi.U8, xmpi.I32, xmpi.I64, xmpi.F16, xmpi.F32, xmpi.F64, xmpi.BF16]
+OPS = [xmpi.SUM, xmpi.PROD, xmpi.MIN, xmpi.MAX]
+
+
+@pytest.fixture(scope="module")
+def comm():
+    import os
+    import uuid
+    c = xmpi.Comm(0, 1, 0, f"k{os.getpid()}-{uuid.uuid4().hex[:6]}")
+    yield c
+    c.finalize()
+
+
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
+@pytest.mark.parametrize("pattern", [xmpi.PAT_UNIFORM, xmpi.PAT_INDEX, xmpi.PAT_CONST, xmpi.PAT_SIGNED])
+def test_fill_matches_oracle(comm, dtype, pattern):
+    n = 70001
+    buf = comm.alloc(n * xmpi.DTYPE_SIZE[dtype])
+    comm.fill(buf, n, dtype, pattern, 12345)
+    got = buf.download(xmpi.NUMPY_DTYPE[dtype], n)
+    want = oracle.fill(n, dtype, pattern, 12345)
+    assert got.tobytes() == want.tobytes()
+    buf.free()
+
+
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
+@pytest.mark.parametrize("op", OPS)
+def test_reduce2_bit_exact(comm, dtype, op):
+    es = xmpi.DTYPE_SIZE[dtype]
+    for count in (0, 1, 2, 15, 16, 17, 1023, 4096, 65536 + 3, (1 << 20) + 11):
+        for pattern in (xmpi.PAT_UNIFORM, xmpi.PAT_SIGNED):
+            a = oracle.fill(count, dtype, pattern, 7)
+            b = oracle.fill(count, dtype, pattern, 8)
+            da, db, dd = comm.alloc(count * es + 16), comm.alloc(count * es + 16), comm.alloc(count * es + 16)
+            da.upload(a)
+            db.upload(b)
+            comm.memset(dd, 0xEE, count * es + 16)
+            comm.reduce_local(dd, da, db, count, dtype, op)
+            got = dd.download(xmpi.NUMPY_DTYPE[dtype], count)
+            want = oracle.reduce2(a, b, dtype, op)
+            assert got.tobytes() == want.tobytes(), (xmpi.DTYPE_NAME[dtype], op, count, pattern)
+            guard = dd.download(np.uint8, 16, byte_offset=count * es)
+            assert np.all(guard == 0xEE), "kernel wrote past the end"
+            for x in (da, db, dd):
+                x.free()
+
+
+@pytest.mark.parametrize("dtype", [xmpi.F32, xmpi.F16, xmpi.U8, xmpi.I64])
+def test_reduce2_unaligned_and_inplace(comm, dtype):
+    """chunk boundaries can fall on any element: odd byte offsets take the element path"""
+    es = xmpi.DTYPE_SIZE[dtype]
+    count = 10007
+    a = oracle.fill(count + 8, dtype, xmpi.PAT_SIGNED, 1)
+    b = oracle.fill(count + 8, dtype, xmpi.PAT_SIGNED, 2)
+    da, db = comm.alloc((count + 8) * es), comm.alloc((count + 8) * es)
+    for off in (1, 3):
+        da.upload(a)
+        db.upload(b)
+        comm.reduce_local(da.at(off * es), da.at(off * es), db.at(off * es), count, dtype, xmpi.SUM)  # dst == a
+        got = da.download(xmpi.NUMPY_DTYPE[dtype], count + 8)
+        want = a.copy()
+        want[off:off + count] = oracle.reduce2(a[off:off + count], b[off:off + count], dtype, xmpi.SUM)
+        assert got.tobytes() == want.tobytes()
+    da.free()
+    db.free()
+
+
+@pytest.mark.parametrize("dtype", [xmpi.F32, xmpi.F16, xmpi.F64, xmpi.I32, xmpi.BF16])
+@pytest.mark.parametrize("nsrc", [1, 2, 3, 5, 8, 12])
+def test_reduce_n_is_left_to_right(comm, dtype, nsrc):
+    es = xmpi.DTYPE_SIZE[dtype]
+    for count in (1, 1000, 65536 + 7):
+        ins = [oracle.fill(count, dtype, xmpi.PAT_SIGNED, 100 + r) for r in range(nsrc)]
+        bufs = [comm.alloc(count * es).upload(x) for x in ins]
+        dst = comm.alloc(count * es)
+        for op in (xmpi.SUM, xmpi.MAX):
+            comm.reduce_local_n(dst, bufs, count, dtype, op)
+            got = dst.download(xmpi.NUMPY_DTYPE[dtype], count)
+            want = oracle.reduce_ranks(ins, dtype, op)
+            assert got.tobytes() == want.tobytes(), (xmpi.DTYPE_NAME[dtype], nsrc, count, op)
+        for x in bufs + [dst]:
+            x.free()
+
+
+def test_copy_and_verify_kernels(comm):
+    n = (3 << 20) + 13
+    a = oracle.fill(n, xmpi.U8, xmpi.PAT_UNIFORM, 5)
+    da, db = comm.alloc(n), comm.alloc(n)
+    da.upload(a)
+    comm.memset(db, 0, n)
+    comm.copy_local(db, da, n)
+    assert db.download(np.uint8, n).tobytes() == a.tobytes()
+    assert comm.count_mismatch(da, db, n) == 0
+    assert comm.checksum(da, n) == oracle.checksum(a)
+    # flip a few bytes: the LDS/shuffle reduction must count exactly those
+    b = a.copy()
+    idx = [0, 1, 17, 4096, n // 2, n - 1]
+    for i in idx:
+        b[i] ^= 0x40
+    db.upload(b)
+    assert comm.count_mismatch(da, db, n) == len(idx) == oracle.count_mismatch(a, b)
+    # unaligned views
+    assert comm.count_mismatch(da.at(1), db.at(1), n - 1) == len(idx) - 1
+    assert comm.checksum(da.at(3), n - 3) == oracle.checksum(a[3:])
+    comm.copy_local(db.at(5), da.at(2), 1001)
+    assert db.download(np.uint8, 1001, byte_offset=5).tobytes() == a[2:1003].tobytes()
+    da.free()
+    db.free()
+
+
+@pytest.mark.parametrize("dtype", [xmpi.F32, xmpi.F16, xmpi.F64, xmpi.BF16])
+def test_diff_stats(comm, dtype):
+    n = 200003
+    es = xmpi.DTYPE_SIZE[dtype]
+    a = oracle.fill(n, dtype, xmpi.PAT_SIGNED, 1)
+    b = oracle.fill(n, dtype, xmpi.PAT_SIGNED, 2)
+    da, db = comm.alloc(n * es).upload(a), comm.alloc(n * es).upload(b)
+    mx, sb, nn = comm.diff_stats(da, db, n, dtype)
+    wmx, wsb, wnn = oracle.diff_stats(a, b, dtype)
+    assert mx == wmx and nn == wnn == 0
+    assert abs(sb - wsb) <= 1e-9 * wsb  # the sum's association differs
+    da.free()
+    db.free()
+
+
+def test_send_to_self_needs_no_peer(comm):
+    """size-1 communicator: collectives degenerate to the local copy kernel"""
+    n = 100001
+    a = oracle.fill(n, xmpi.F32, 0, 9)
+    da, db = comm.alloc(n * 4).upload(a), comm.alloc(n * 4)
+    comm.allreduce(da, db, n, xmpi.F32, xmpi.SUM, xmpi.ALGO_RING)
+    assert db.download(np.float32, n).tobytes() == a.tobytes()
+    comm.allgather(da, db, n, xmpi.F32)
+    assert db.download(np.float32, n).tobytes() == a.tobytes()
+    comm.bcast(da, n, xmpi.F32, 0)
+    comm.reduce(da, db, n, xmpi.F32, xmpi.SUM, 0)
+    assert db.download(np.float32, n).tobytes() == a.tobytes()
+    assert comm.rank() == 0 and comm.size() == 1
+    da.free()
+    db.free()

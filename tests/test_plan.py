@@ -1,0 +1,152 @@
+"""Host-logic tests of the collective schedules (no GPU): every rank's step table, as emitted by
+libxmpi.so (xmpi_plan_dump), is executed by tests/plan_sim.py over bounded FIFOs under a random
+schedule and compared with the rank-order oracle."""
+import numpy as np
+import pytest
+
+from mpi_amd import xmpi
+from oracle import oracle
+from tests import plan_sim
+
+SIZES = [1, 2, 3, 4, 5, 8]
+
+
+def _inputs(n, count, dtype_code, seed0=1000, pattern=oracle.lib and 0):
+    return [oracle.fill(count, dtype_code, 0, seed0 + r) for r in range(n)]
+
+
+@pytest.mark.parametrize("algo", [xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_DIRECT])
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("count,piece", [(1, 4), (7, 4), (64, 4), (1000, 16), (4099, 64), (65536, 1024)])
+def test_allreduce_i64_exact(algo, n, count, piece):
+    ins = _inputs(n, count, oracle.I64)
+    want = oracle.reduce_ranks(ins, oracle.I64, oracle.SUM)
+    for channels in (1, 4):
+        plans = plan_sim.get_plans(xmpi.COLL_ALLREDUCE, algo, n, 0, count, 8, channels, piece)
+        for depth in (2, 8):
+            got = plan_sim.simulate(plans, ins, count, np.int64, xmpi.SUM, depth, seed=count + n)
+            for r in range(n):
+                assert np.array_equal(got[r], want), f"rank {r}"
+
+
+@pytest.mark.parametrize("algo", [xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_DIRECT])
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_allreduce_inplace(algo, n):
+    count = 3001
+    ins = _inputs(n, count, oracle.I64)
+    want = oracle.reduce_ranks(ins, oracle.I64, oracle.SUM)
+    plans = plan_sim.get_plans(xmpi.COLL_ALLREDUCE, algo, n, 0, count, 8, 4, 128)
+    got = plan_sim.simulate(plans, ins, count, np.int64, xmpi.SUM, 2, seed=7, inplace=True)
+    for r in range(n):
+        assert np.array_equal(got[r], want)
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 8])
+def test_allreduce_direct_is_rank_order_f32(n):
+    """DIRECT folds in rank order: bit-identical to the oracle for floats too."""
+    count = 2053
+    ins = [oracle.fill(count, oracle.F32, 3, 50 + r) for r in range(n)]  # signed, mixed binades
+    want = oracle.reduce_ranks(ins, oracle.F32, oracle.SUM)
+    plans = plan_sim.get_plans(xmpi.COLL_ALLREDUCE, xmpi.ALGO_DIRECT, n, 0, count, 4, 1, 256)
+    got = plan_sim.simulate(plans, ins, count, np.float32, xmpi.SUM, 4, seed=3)
+    for r in range(n):
+        assert got[r].tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("n", [2, 4, 8])
+@pytest.mark.parametrize("algo", [xmpi.ALGO_RING, xmpi.ALGO_RHD])
+def test_allreduce_f32_tolerance(n, algo):
+    """Ring / halving change the summation order: |delta| <= 1e-6 * sum_i |x_i| (BASELINE.md cfg 4)."""
+    count = 4096
+    ins = [oracle.fill(count, oracle.F32, 0, 1000 + r) for r in range(n)]
+    want = oracle.reduce_ranks(ins, oracle.F32, oracle.SUM).astype(np.float64)
+    bound = 1e-6 * np.sum([np.abs(x.astype(np.float64)) for x in ins], axis=0)
+    plans = plan_sim.get_plans(xmpi.COLL_ALLREDUCE, algo, n, 0, count, 4, 4, 128)
+    got = plan_sim.simulate(plans, ins, count, np.float32, xmpi.SUM, 4, seed=11)
+    for r in range(n):
+        assert np.all(np.abs(got[r].astype(np.float64) - want) <= bound)
+
+
+@pytest.mark.parametrize("algo", [xmpi.ALGO_RING, xmpi.ALGO_DIRECT])
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("count,piece", [(1, 2), (5, 2), (1000, 64), (4099, 256)])
+def test_allgather_exact(algo, n, count, piece):
+    ins = [oracle.fill(count, oracle.I64, 1, r) for r in range(n)]  # (r << 40) | i  (BASELINE cfg 3)
+    want = oracle.allgather(ins, oracle.I64)
+    for channels in (1, 4):
+        plans = plan_sim.get_plans(xmpi.COLL_ALLGATHER, algo, n, 0, count, 8, channels, piece)
+        got = plan_sim.simulate(plans, ins, count * n, np.int64, xmpi.SUM, 2, seed=n)
+        for r in range(n):
+            assert np.array_equal(got[r], want)
+        got = plan_sim.simulate(plans, ins, count * n, np.int64, xmpi.SUM, 3, seed=n, inplace=True,
+                                send_shift_bytes=count * 8)
+        for r in range(n):
+            assert np.array_equal(got[r], want)
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("root", [0, 1, -1])
+def test_bcast_tree(n, root):
+    root = root % n
+    count = 777
+    ins = [oracle.fill(count, oracle.I32, 0, 10 + r) for r in range(n)]
+    plans = plan_sim.get_plans(xmpi.COLL_BCAST, xmpi.ALGO_TREE, n, root, count, 4, 1, 64)
+    got = plan_sim.simulate(plans, ins, count, np.int32, xmpi.SUM, 2, seed=5, inplace=True)
+    for r in range(n):
+        assert np.array_equal(got[r], ins[root])
+
+
+@pytest.mark.parametrize("algo", [xmpi.ALGO_TREE, xmpi.ALGO_DIRECT])
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("root", [0, -1])
+def test_reduce_to_root(algo, n, root):
+    root = root % n
+    count = 1500
+    ins = [oracle.fill(count, oracle.I64, 0, 77 + r) for r in range(n)]
+    want = oracle.reduce_ranks(ins, oracle.I64, oracle.SUM)
+    plans = plan_sim.get_plans(xmpi.COLL_REDUCE, algo, n, root, count, 8, 1, 128)
+    got = plan_sim.simulate(plans, ins, count, np.int64, xmpi.SUM, 2, seed=9)
+    assert np.array_equal(got[root], want)
+
+
+def test_reduce_direct_is_rank_order_f32():
+    n, count = 8, 1025
+    ins = [oracle.fill(count, oracle.F32, 3, 5 + r) for r in range(n)]
+    want = oracle.reduce_ranks(ins, oracle.F32, oracle.SUM)
+    plans = plan_sim.get_plans(xmpi.COLL_REDUCE, xmpi.ALGO_DIRECT, n, 3, count, 4, 1, 64)
+    got = plan_sim.simulate(plans, ins, count, np.float32, xmpi.SUM, 2, seed=1)
+    assert got[3].tobytes() == want.tobytes()
+
+
+def test_min_max_prod_through_ring():
+    n, count = 4, 513
+    ins = [oracle.fill(count, oracle.I32, 0, 900 + r) for r in range(n)]
+    for op in (oracle.MIN, oracle.MAX, oracle.PROD):
+        want = oracle.reduce_ranks(ins, oracle.I32, op)
+        plans = plan_sim.get_plans(xmpi.COLL_ALLREDUCE, xmpi.ALGO_RING, n, 0, count, 4, 2, 32)
+        got = plan_sim.simulate(plans, ins, count, np.int32, op, 2, seed=op)
+        for r in range(n):
+            assert np.array_equal(got[r], want)
+
+
+def test_headline_plan_shape():
+    """BASELINE cfg 4: 256 MiB f32, 8 ranks, ring, 4 channels: 14 steps per channel, every rank sends and
+    receives 2*(N-1)/N*S bytes, over 4 distinct neighbours in each direction."""
+    n, count = 8, 64 << 20
+    text = xmpi.plan_text(xmpi.COLL_ALLREDUCE, xmpi.ALGO_RING, n, 3, 0, count, 4, 4, (2 << 20) // 4)
+    plan = plan_sim.parse_plan(text)
+    sent = sum(s.nbytes for s in plan.steps if s.kind == 0)
+    recvd = sum(s.nbytes for s in plan.steps if s.kind in (1, 2))
+    assert sent == recvd == 2 * (n - 1) * (count * 4) // n
+    assert len({s.peer for s in plan.steps if s.kind == 0}) == 4
+    assert len({s.peer for s in plan.steps if s.kind in (1, 2)}) == 4
+    assert max(s.nbytes for s in plan.steps) <= 2 << 20
+
+
+def test_ring_channels_use_distinct_links():
+    """Channel strides 1, 7, 3, 5 of an 8-rank mesh: 4 different out-neighbours per rank."""
+    for r in range(8):
+        text = xmpi.plan_text(xmpi.COLL_ALLREDUCE, xmpi.ALGO_RING, 8, r, 0, 1 << 22, 4, 4, 1 << 16)
+        plan = plan_sim.parse_plan(text)
+        nxt = {s.peer for s in plan.steps if s.kind == 0}
+        assert nxt == {(r + d) % 8 for d in (1, 7, 3, 5)}
