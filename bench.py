@@ -1,0 +1,380 @@
+#!/usr/bin/env python3
+"""bench.py -- allreduce bandwidth of the xmpi hot path (BASELINE.json metric), one JSON line.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json config 4, the one the metric is quoted on): allreduce-sum of 256 MiB of
+float32 per rank over 8 ranks.  The job always has 8 ranks; they are spread over the N GPUs the
+run was given (N = 8: one rank per MI355X, the north-star layout; N = 4 / 2 / 1: 2 / 4 / 8 ranks
+share each GPU, hosted as threads of the per-GPU process and talking through the same HBM windows,
+pipes and kernels -- peer copies between co-located ranks stay inside one HBM instead of crossing
+xGMI).  Total work is fixed as N grows, so "scaling" is "strong".  A step = one allreduce; inputs
+are generated on the device before the timed region (nothing crosses PCIe while timing).
+
+value = aggregate algorithm bandwidth = ranks x S / t  (GB = 1e9 B; every rank ends up with S
+reduced bytes), with t = max over ranks of the barrier-bracketed time of K steps / K.  The plain
+nccl-tests figures are alongside: algbw = S / t and busbw = algbw x 2(R-1)/R.
+
+roofline: the dominant kernel of the path is the per-piece reduction reduce2_kernel<float,SUM>
+(HBM-bound: 12 algorithmic bytes per output element); its launches inside the timed region are
+bracketed by HIP events on the stream they run on (libxmpi's profiling hooks).
+
+cpu_baseline (N = 1, rank 0 only): the reference path -- mpi.Network over loopback TCP with gob
+framing -- restated in C++ (oracle/refpath.cpp, "kind": "port": the image has no Go toolchain),
+8 OS processes on the host cores, composing the allreduce the way a reference user would.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from mpi_amd import xmpi  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s
+XGMI_LINK_GBPS = 153.0   # per-link peak (bidirectional), task statement
+ALGO_NAME = {xmpi.ALGO_RING: "ring", xmpi.ALGO_RHD: "rhd", xmpi.ALGO_DIRECT: "direct"}
+DT = {"f32": xmpi.F32, "f16": xmpi.F16, "f64": xmpi.F64, "bf16": xmpi.BF16, "i64": xmpi.I64}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--ranks", type=int, default=0, help="total ranks (default 8 when it divides by --gpus)")
+    ap.add_argument("--size-mib", type=float, default=256.0, help="bytes per rank")
+    ap.add_argument("--dtype", default="f32", choices=sorted(DT))
+    ap.add_argument("--algo", default="auto", choices=["auto", "ring", "rhd", "direct"])
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed sweeps after the timed region")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU reference-path baseline")
+    ap.add_argument("--cpu-count", type=int, default=1 << 20, help="elements per rank of the CPU sample")
+    return ap.parse_args()
+
+
+class Job:
+    """Everything the rank threads of this process share."""
+
+    def __init__(self, args):
+        self.args = args
+        self.world_procs = int(os.environ.get("WORLD_SIZE", "1"))
+        self.proc_rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        n = args.gpus
+        if self.world_procs > 1 and self.world_procs != n:
+            raise SystemExit(f"--gpus {n} but WORLD_SIZE={self.world_procs}")
+        self.ranks = args.ranks or (8 if 8 % n == 0 else n)
+        if self.ranks % n:
+            raise SystemExit("--ranks must be a multiple of --gpus")
+        self.single_process = self.world_procs == 1
+        # one process per GPU under torchrun; a lone process hosts every rank (and drives every GPU)
+        self.procs = self.world_procs
+        self.ranks_per_proc = self.ranks // self.procs
+        port = os.environ.get("MASTER_PORT", "0")
+        self.key = f"bench-{port}-{os.getppid() if self.procs > 1 else os.getpid()}"
+        self.result = {}
+        self.errors = []
+        self.lock = threading.Lock()
+
+    def device_of(self, grank: int) -> int:
+        if "XMPI_BENCH_DEVICE" in os.environ:  # rehearsal of the multi-process launch on a 1-GPU box
+            return int(os.environ["XMPI_BENCH_DEVICE"])
+        if self.procs > 1:
+            return self.local_rank
+        return grank * self.args.gpus // self.ranks  # lone process: ranks spread over the visible GPUs
+
+    def my_ranks(self):
+        base = self.proc_rank * self.ranks_per_proc
+        return list(range(base, base + self.ranks_per_proc))
+
+
+def all_max(comm, value: float) -> float:
+    a = np.array([value], dtype=np.float64)
+    out = np.zeros(1, dtype=np.float64)
+    comm.allreduce(a, out, 1, xmpi.F64, xmpi.MAX, xmpi.ALGO_DIRECT)
+    return float(out[0])
+
+
+def timed(comm, fn, iters: int) -> float:
+    """barrier + device sync on both sides; max over ranks of the per-iteration time"""
+    comm.barrier()
+    comm.sync()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    comm.sync()
+    comm.barrier()
+    return all_max(comm, (time.perf_counter() - t0) / iters)
+
+
+def check_window(comm, send, recv, count, dtype, seed0, off, n):
+    """the result window [off, off+n) against the rank-order CPU oracle"""
+    from oracle import oracle
+    from tests.scenarios import oracle_fill_window
+    ins = [oracle_fill_window(dtype, seed0 + r, off, n) for r in range(comm.size())]
+    want = oracle.reduce_ranks(ins, dtype, oracle.SUM)
+    got = recv.download(xmpi.NUMPY_DTYPE[dtype], n, byte_offset=off * xmpi.DTYPE_SIZE[dtype])
+    if dtype == xmpi.F16:
+        return got.tobytes() == want.tobytes(), 0.0
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    bound = 1e-6 * np.sum([np.abs(x.astype(np.float64)) for x in ins], axis=0)
+    return bool(np.all(err <= bound)), float(err.max())
+
+
+def rank_main(job: Job, grank: int):
+    a = job.args
+    dtype = DT[a.dtype]
+    es = xmpi.DTYPE_SIZE[dtype]
+    count = int(a.size_mib * (1 << 20)) // es
+    nbytes = count * es
+    comm = xmpi.Comm(grank, job.ranks, job.device_of(grank), job.key)
+    R = comm.size()
+    lead = grank == 0
+    seed0 = 1000 if dtype != xmpi.F16 else 2000
+    send, recv = comm.alloc(nbytes), comm.alloc(nbytes)
+    comm.fill(send, count, dtype, xmpi.PAT_UNIFORM, seed0 + grank)
+    comm.memset(recv, 0, nbytes)
+
+    def run(algo, cnt=count, s=send, r=recv, dt=dtype):
+        comm.allreduce(s, r, cnt, dt, xmpi.SUM, algo)
+
+    # ---- untimed: pick the schedule (all ranks see the same max-over-ranks times) -----------------
+    tune = []
+    if a.algo == "auto":
+        cands = []
+        if R > 1:
+            maxch = max(1, comm.get_param("ring_channels_max"))
+            for ch in sorted({1, 2, min(4, maxch)}):
+                for eng in (0, 1):
+                    cands.append((xmpi.ALGO_RING, ch, eng))
+            for eng in (0, 1):
+                cands.append((xmpi.ALGO_DIRECT, 1, eng))
+                if R & (R - 1) == 0:
+                    cands.append((xmpi.ALGO_RHD, 1, eng))
+        else:
+            cands = [(xmpi.ALGO_RING, 1, 0)]
+        for algo, ch, eng in cands:
+            comm.set_param("channels", ch)
+            comm.set_param("copy_engine", eng)
+            run(algo)
+            t = timed(comm, lambda: run(algo), 2)
+            tune.append({"algo": ALGO_NAME[algo], "channels": ch, "copy_engine": eng, "ms": t * 1e3,
+                         "algbw_GBps": nbytes / t / 1e9})
+        best = min(tune, key=lambda x: x["ms"])
+        best_ring = min((x for x in tune if x["algo"] == "ring"), key=lambda x: x["ms"])
+        algo = {v: k for k, v in ALGO_NAME.items()}[best["algo"]]
+        comm.set_param("channels", best["channels"])
+        comm.set_param("copy_engine", best["copy_engine"])
+    else:
+        algo = {v: k for k, v in ALGO_NAME.items()}[a.algo]
+        best = {"algo": a.algo, "channels": comm.get_param("channels"), "copy_engine": comm.get_param("copy_engine")}
+        best_ring = None
+
+    # ---- warmup + parity of the chosen schedule against the oracle --------------------------------
+    for _ in range(max(1, a.warmup)):
+        run(algo)
+    parity = {"checked": False}
+    if dtype in (xmpi.F32, xmpi.F16) and count >= 1 << 16:
+        oks, worst = [], 0.0
+        for off in (0, (count // 3) // 8 * 8, count - 65536):
+            ok, err = check_window(comm, send, recv, count, dtype, seed0, off, 65536)
+            oks.append(ok)
+            worst = max(worst, err)
+        parity = {"checked": True, "ok": all(oks), "max_abs_err": worst,
+                  "rule": "bit-exact" if dtype == xmpi.F16 else "|delta| <= 1e-6 * sum_i|x_i| vs rank-order oracle"}
+        if not all(oks):
+            raise AssertionError(f"rank {grank}: allreduce result differs from the oracle: {parity}")
+
+    # ---- timed region: exactly K steps ----------------------------------------------------------------
+    comm.prof_reset()
+    comm.prof_enable(True)
+    t_step = timed(comm, lambda: run(algo), a.steps)
+    comm.prof_enable(False)
+    prof = {k: comm.prof_get(k) for k in (xmpi.PROF_REDUCE2, xmpi.PROF_REDUCEN, xmpi.PROF_COPY, xmpi.PROF_PEER)}
+
+    out = {"t_step": t_step, "prof": prof, "tune": tune, "best": best, "best_ring": best_ring, "parity": parity,
+           "algo": algo, "nbytes": nbytes, "count": count}
+
+    # ---- untimed extras: what the next round needs to tune blind multi-GPU runs -----------------------
+    extras = {}
+    if not a.no_extras and R > 1:
+        extras["algos_at_size"] = {}
+        for al in (xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_DIRECT):
+            if al == xmpi.ALGO_RHD and R & (R - 1):
+                continue
+            run(al)
+            t = timed(comm, lambda: run(al), 3)
+            extras["algos_at_size"][ALGO_NAME[al]] = {"ms": t * 1e3, "algbw_GBps": nbytes / t / 1e9,
+                                                      "busbw_GBps": nbytes / t / 1e9 * 2 * (R - 1) / R}
+        sweep = []
+        sz = 1 << 10
+        while sz <= min(nbytes, 1 << 30):
+            cnt = sz // es
+            row = {"bytes": sz}
+            for al in (xmpi.ALGO_RING, xmpi.ALGO_DIRECT):
+                run(al, cnt)
+                t = timed(comm, lambda: run(al, cnt), 5 if sz <= (16 << 20) else 2)
+                row[ALGO_NAME[al] + "_us"] = t * 1e6
+                row[ALGO_NAME[al] + "_busbw_GBps"] = sz / t / 1e9 * 2 * (R - 1) / R
+            sweep.append(row)
+            sz *= 4
+        extras["size_sweep"] = sweep
+        # BASELINE cfg 2: 1 MiB float32 ping-pong between ranks 0 and 1 (half round trip)
+        n1 = 262144
+        if grank in (0, 1):
+            peer = 1 - grank
+            iters = 50
+            for w in range(5 + iters):
+                if w == 5:
+                    t0 = time.perf_counter()
+                if grank == 0:
+                    comm.send(send, n1, xmpi.F32, peer, 3)
+                    comm.recv(recv, n1, xmpi.F32, peer, 3)
+                else:
+                    comm.recv(recv, n1, xmpi.F32, peer, 3)
+                    comm.send(recv, n1, xmpi.F32, peer, 3)
+            half = (time.perf_counter() - t0) / iters / 2
+            extras["bounce_1MiB_f32"] = {"half_round_trip_us": half * 1e6, "GBps": n1 * 4 / half / 1e9}
+        comm.barrier()
+        # BASELINE cfg 3 shape: allgather int64, 16 MiB per rank
+        cnt3 = min(2097152, nbytes // 8 // R)
+        if cnt3 > 0:
+            t = timed(comm, lambda: comm.allgather(send, recv, cnt3, xmpi.I64, xmpi.ALGO_RING), 3)
+            extras["allgather_i64"] = {"bytes_per_rank": cnt3 * 8, "ms": t * 1e3,
+                                       "busbw_GBps": cnt3 * 8 * R / t / 1e9 * (R - 1) / R}
+        # link probe between rank 0 and the first rank living on another GPU (xGMI), both engines
+        dev0 = job.device_of(0)
+        other = next((r for r in range(R) if (r * a.gpus // R if job.procs == 1 else r // job.ranks_per_proc) != 0), None)
+        if other is not None and a.gpus > 1:
+            probe = {}
+            for eng, name in ((0, "hipMemcpyAsync"), (1, "copy_kernel")):
+                comm.barrier()
+                if grank == 0:
+                    probe[name + "_write_GBps"] = comm.link_probe(other, 64 << 20, eng, 10, 0)
+                    probe[name + "_read_GBps"] = comm.link_probe(other, 64 << 20, eng, 10, 1)
+                comm.barrier()
+                if grank in (0, other):  # both directions at once
+                    peer = other if grank == 0 else 0
+                    v = comm.link_probe(peer, 64 << 20, eng, 10, 0)
+                    if grank == 0:
+                        probe[name + "_bidir_each_GBps"] = v
+                comm.barrier()
+            extras["xgmi_link_probe"] = {"between_ranks": [0, other], **probe}
+            del dev0
+    out["extras"] = extras
+    with job.lock:
+        job.result[grank] = out
+    comm.barrier()
+    send.free()
+    recv.free()
+    comm.finalize()
+    _ = lead
+
+
+def cpu_baseline(ranks: int, count: int):
+    """oracle/refpath_bin: the reference's TCP+gob path, `ranks` processes on localhost"""
+    binp = os.path.join(ROOT, "oracle", "refpath_bin")
+    if not os.path.exists(binp):
+        return None
+    base = 21000 + (os.getpid() % 20000)
+    ports = [f":{base + i}" for i in range(ranks)]
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([binp, "allreduce_f32", "-mpi-addr", p, "-mpi-alladdr", ",".join(ports), str(count), "3"],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for p in ports]
+    rows = []
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        if p.returncode != 0:
+            return {"error": out[-300:]}
+        rows.append(json.loads(out.strip().split("\n")[-1]))
+    wall = time.perf_counter() - t0
+    t = max(r["mean_s"] for r in rows)
+    s = count * 4
+    return {"value": ranks * s / t / 1e9, "unit": "GB/s", "cores": os.cpu_count(), "kind": "port",
+            "algbw_GBps": s / t / 1e9, "ranks": ranks, "seconds_per_allreduce": t, "wall_s": wall,
+            "sample": f"allreduce-sum f32, {s >> 20} MiB per rank, {ranks} ranks (one OS process each, unpinned), "
+                      f"3 repetitions; loopback TCP + gob framing, all-to-all exchange + rank-order host sum "
+                      f"(oracle/refpath.cpp restating network.go:518-625; no Go toolchain in the image)"}
+
+
+def main():
+    args = parse_args()
+    job = Job(args)
+    threads = [threading.Thread(target=_guard, args=(job, g)) for g in job.my_ranks()]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if job.errors:
+        for g, tb in job.errors:
+            sys.stderr.write(f"[bench] rank {g} failed:\n{tb}\n")
+        sys.exit(1)
+    if 0 not in job.result:
+        return  # not the process hosting rank 0
+    r0 = job.result[0]
+    R, S, t = job.ranks, r0["nbytes"], r0["t_step"]
+    algbw = S / t / 1e9
+    busbw = algbw * 2 * (R - 1) / R
+    n2, ms2, b2 = r0["prof"][xmpi.PROF_REDUCE2]
+    nn, msn, bn = r0["prof"][xmpi.PROF_REDUCEN]
+    if ms2 >= msn and n2:
+        kname, launches, ms, by = "reduce2_kernel<float,SUM> (dst = a + slot)", n2, ms2, b2
+    elif nn:
+        kname, launches, ms, by = "reduce_n_kernel<float,SUM,N> (rank-order fold)", nn, msn, bn
+    else:
+        nc, msc, bc = r0["prof"][xmpi.PROF_COPY]
+        kname, launches, ms, by = "copy16_kernel", nc, msc, bc
+    achieved = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+            "launches": launches, "avg_launch_us": (ms * 1e3 / launches) if launches else None,
+            "algorithmic_bytes_per_launch": (by / launches) if launches else None,
+            "note": "live HIP events on the kernel's own stream inside the timed region (rank 0's launches); "
+                    "12 B per output element (2 reads + 1 write); traffic (PMC) not collected in this run"}
+    line = {
+        "metric": "allreduce_sum_f32_256MiB aggregate algbw (ranks x S / t)" if (args.dtype == "f32" and args.size_mib == 256)
+        else f"allreduce_sum_{args.dtype}_{args.size_mib:g}MiB aggregate algbw (ranks x S / t)",
+        "value": R * algbw, "unit": "GB/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": t * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"BASELINE cfg 4: allreduce-sum {args.dtype} {args.size_mib:g} MiB/rank, {R} ranks",
+                   "ranks": R, "ranks_per_gpu": R // args.gpus, "bytes_per_rank": S,
+                   "algo": r0["best"]["algo"], "channels": r0["best"]["channels"],
+                   "copy_engine": "copy_kernel" if r0["best"]["copy_engine"] else "hipMemcpyAsync",
+                   "transport": "xGMI peer copies" if args.gpus == R else
+                   ("intra-HBM copies between co-located ranks" if args.gpus == 1 else "mixed intra-HBM / xGMI")},
+        "algbw_GBps": algbw, "busbw_GBps": busbw,
+        "xgmi": {"per_link_peak_GBps": XGMI_LINK_GBPS, "busbw_frac_of_link_peak": busbw / XGMI_LINK_GBPS,
+                 "meaningful": args.gpus == R},
+        "roofline": roof, "parity": r0["parity"], "autotune": r0["tune"], "ring_best": r0["best_ring"],
+        "extras": r0["extras"],
+    }
+    if args.gpus == 1 and not args.no_cpu and job.proc_rank == 0:
+        line["cpu_baseline"] = cpu_baseline(R, args.cpu_count)
+    else:
+        line["cpu_baseline"] = None
+    print(json.dumps(line))
+    sys.stdout.flush()
+
+
+def _guard(job, g):
+    try:
+        rank_main(job, g)
+    except BaseException:  # noqa: BLE001
+        import traceback
+        with job.lock:
+            job.errors.append((g, traceback.format_exc()))
+
+
+if __name__ == "__main__":
+    main()

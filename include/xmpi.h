@@ -179,6 +179,12 @@ int xmpi_prof_reset(xmpi_comm* comm);
 int xmpi_prof_get(xmpi_comm* comm, int kind, uint64_t* launches, double* total_ms,
                   uint64_t* bytes);
 
+/* Link diagnostic: times `iters` back-to-back copies of `bytes` between this rank's window and the
+ * peer's (direction 0 = write to the peer, 1 = read from the peer; engine as "copy_engine").  The
+ * peer must not be inside a collective; call it on both ranks of a pair for the bidirectional rate. */
+int xmpi_link_probe(xmpi_comm* comm, int peer, size_t bytes, int engine, int iters, int direction,
+                    double* gbps);
+
 /* Schedule introspection (host logic only, no GPU needed): writes the step table the executor
  * would run for (coll, algo, size, rank, count) as text into out; returns needed length. */
 int xmpi_plan_dump(int coll, int algo, int size, int rank, int root, size_t count,

@@ -96,6 +96,10 @@ def build_oracle(force: bool = False) -> list[str]:
         if force or _newer(out, [ref, os.path.join(odir, "gob_codec.h")]):
             _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", ref, "-o", out, "-lpthread"])
         outs.append(out)
+        out = os.path.join(odir, "refpath_bin")
+        if force or _newer(out, [ref, os.path.join(odir, "gob_codec.h")]):
+            _run(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-DREFPATH_MAIN", ref, "-o", out, "-lpthread"])
+        outs.append(out)
     return outs
 
 

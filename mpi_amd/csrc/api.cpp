@@ -4,7 +4,9 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <vector>
 
 #include "comm.h"
 #include "kernels.h"
@@ -53,6 +55,47 @@ static size_t choose_piece(const xmpi_comm* c, size_t bytes_per_rank_chunk) {
   size_t p = 64u << 10;
   while (p * 4 < bytes_per_rank_chunk && p < c->slot_bytes) p <<= 1;
   return std::min(p, c->slot_bytes);
+}
+
+// A process may host several ranks (threads); each peer window is mapped once per process and
+// shared by them (hipIpcOpenMemHandle on an already-open handle is not portable behaviour).
+struct IpcMapping {
+  int owner_pid;
+  uint64_t owner_addr;
+  void* ptr;
+  int refs;
+};
+static std::mutex g_ipc_mu;
+static std::vector<IpcMapping> g_ipc_map;
+
+static hipError_t ipc_open_shared(int owner_pid, uint64_t owner_addr, const void* handle_bytes, void** out) {
+  std::lock_guard<std::mutex> g(g_ipc_mu);
+  for (IpcMapping& m : g_ipc_map)
+    if (m.owner_pid == owner_pid && m.owner_addr == owner_addr) {
+      m.refs++;
+      *out = m.ptr;
+      return hipSuccess;
+    }
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle_bytes, sizeof h);
+  void* ptr = nullptr;
+  hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+  if (e != hipSuccess) return e;
+  g_ipc_map.push_back({owner_pid, owner_addr, ptr, 1});
+  *out = ptr;
+  return hipSuccess;
+}
+
+static void ipc_close_shared(void* ptr) {
+  std::lock_guard<std::mutex> g(g_ipc_mu);
+  for (size_t i = 0; i < g_ipc_map.size(); i++)
+    if (g_ipc_map[i].ptr == ptr) {
+      if (--g_ipc_map[i].refs == 0) {
+        (void)hipIpcCloseMemHandle(ptr);
+        g_ipc_map.erase(g_ipc_map.begin() + (long)i);
+      }
+      return;
+    }
 }
 
 static int collective(xmpi_comm* c, int coll, int algo, int root, const void* sendbuf, void* recvbuf, size_t count,
@@ -264,10 +307,8 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
         (void)hipGetLastError();
       }
     } else {
-      hipIpcMemHandle_t h;
-      memcpy(&h, pi->ipc_handle, sizeof h);
       void* ptr = nullptr;
-      e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+      e = ipc_open_shared(pi->pid, pi->window_addr, pi->ipc_handle, &ptr);
       if (e != hipSuccess) {
         hip_fail(e, "hipIpcOpenMemHandle", __FILE__, __LINE__);
         return fail(XMPI_ERR_HIP);
@@ -306,7 +347,7 @@ int xmpi_finalize(xmpi_comm* c) {
   // nobody may still be writing into a window that is about to be unmapped
   if (!c->ctl->aborted()) (void)c->ctl->barrier(c->timeout_s > 0 ? (double)c->timeout_s : 3600.0);
   for (int p = 0; p < c->size; p++) {
-    if (c->peer_opened[p]) (void)hipIpcCloseMemHandle(c->peer_window[p]);
+    if (c->peer_opened[p]) ipc_close_shared(c->peer_window[p]);
     if (c->send_stream[p]) (void)hipStreamDestroy(c->send_stream[p]);
     if (c->recv_stream[p]) (void)hipStreamDestroy(c->recv_stream[p]);
   }
@@ -588,6 +629,41 @@ int xmpi_prof_get(xmpi_comm* c, int kind, uint64_t* launches, double* total_ms, 
   if (launches) *launches = c->prof[kind].launches;
   if (total_ms) *total_ms = c->prof[kind].total_ms;
   if (bytes) *bytes = c->prof[kind].bytes;
+  return XMPI_OK;
+}
+
+int xmpi_link_probe(xmpi_comm* c, int peer, size_t bytes, int engine, int iters, int direction, double* gbps) {
+  XMPI_ENTER(c);
+  if (peer < 0 || peer >= c->size || iters < 1 || !gbps) return XMPI_ERR_ARG;
+  std::lock_guard<std::mutex> g(c->coll_mu);
+  // the FIFO slots this rank owns in the peer's window (idle between collectives) are the remote
+  // end; the slots the peer owns in this rank's window are the local end
+  const size_t span = (size_t)c->lanes * c->fifo_depth * c->slot_bytes;
+  bytes = std::min(bytes, span);
+  char* remote = c->peer_window[peer] + c->coll_slot_off(c->rank, 0, 0);
+  char* local = c->window + c->coll_slot_off(peer, 0, 0);
+  char* dst = direction == 0 ? remote : local;  // 0 = write to the peer, 1 = read from the peer
+  char* src = direction == 0 ? local : remote;
+  hipStream_t s = c->send_stream[peer] ? c->send_stream[peer] : c->local_stream;
+  hipEvent_t a = ev_get(c, true), b = ev_get(c, true);
+  if (!a || !b) return XMPI_ERR_HIP;
+  for (int w = 0; w < 2; w++) {
+    if (engine == 1) XMPI_HIP(launch_copy(dst, src, bytes, s));
+    else XMPI_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+  }
+  XMPI_HIP(hipStreamSynchronize(s));
+  XMPI_HIP(hipEventRecord(a, s));
+  for (int i = 0; i < iters; i++) {
+    if (engine == 1) XMPI_HIP(launch_copy(dst, src, bytes, s));
+    else XMPI_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+  }
+  XMPI_HIP(hipEventRecord(b, s));
+  XMPI_HIP(hipStreamSynchronize(s));
+  float ms = 0.f;
+  XMPI_HIP(hipEventElapsedTime(&ms, a, b));
+  ev_put(c, a, true);
+  ev_put(c, b, true);
+  *gbps = ms > 0 ? (double)bytes * iters / (ms * 1e-3) / 1e9 : 0.0;
   return XMPI_OK;
 }
 

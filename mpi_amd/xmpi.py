@@ -66,6 +66,7 @@ SYMBOLS = [
     ("xmpi_prof_enable", _I, [_P, _I]),
     ("xmpi_prof_reset", _I, [_P]),
     ("xmpi_prof_get", _I, [_P, _I, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    ("xmpi_link_probe", _I, [_P, _I, _Z, _I, _I, _I, C.POINTER(C.c_double)]),
     ("xmpi_plan_dump", _I, [_I, _I, _I, _I, _I, _Z, _Z, _I, _Z, C.c_char_p, _Z]),
     ("xmpi_dtype_size", _Z, [_I]),
 ]
@@ -260,6 +261,11 @@ class Comm:
 
     def get_param(self, name: str) -> int:
         return lib().xmpi_get_param(self.handle, name.encode())
+
+    def link_probe(self, peer: int, nbytes: int, engine: int, iters: int = 10, direction: int = 0) -> float:
+        out = C.c_double(0)
+        _check(lib().xmpi_link_probe(self.handle, peer, nbytes, engine, iters, direction, C.byref(out)), "link_probe")
+        return out.value
 
     def prof_enable(self, on: bool = True) -> None:
         _check(lib().xmpi_prof_enable(self.handle, 1 if on else 0), "prof_enable")
