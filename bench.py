@@ -82,6 +82,11 @@ class Job:
         self.ranks_per_proc = self.ranks // self.procs
         port = os.environ.get("MASTER_PORT", "0")
         self.key = f"bench-{port}-{os.getppid() if self.procs > 1 else os.getpid()}"
+        # ranks sharing a GPU have no link to pipeline against: large pieces (one launch per chunk)
+        # keep every kernel at full-chip bandwidth; one rank per GPU keeps the library defaults
+        if self.ranks // n >= 4:
+            os.environ.setdefault("XMPI_SLOT_BYTES", str(32 << 20))
+            os.environ.setdefault("XMPI_FIFO_DEPTH", "4")
         self.result = {}
         self.errors = []
         self.lock = threading.Lock()
@@ -163,21 +168,27 @@ def rank_main(job: Job, grank: int):
                     cands.append((xmpi.ALGO_RHD, 1, eng))
         else:
             cands = [(xmpi.ALGO_RING, 1, 0)]
+        slot = comm.get_param("slot_bytes")
+        pieces = sorted({0, slot}) if R > 1 else [0]  # 0 = library heuristic (~4 pieces per chunk)
         for algo, ch, eng in cands:
-            comm.set_param("channels", ch)
-            comm.set_param("copy_engine", eng)
-            run(algo)
-            t = timed(comm, lambda: run(algo), 2)
-            tune.append({"algo": ALGO_NAME[algo], "channels": ch, "copy_engine": eng, "ms": t * 1e3,
-                         "algbw_GBps": nbytes / t / 1e9})
+            for pc in pieces:
+                comm.set_param("channels", ch)
+                comm.set_param("copy_engine", eng)
+                comm.set_param("piece_bytes", pc)
+                run(algo)
+                t = timed(comm, lambda: run(algo), 2)
+                tune.append({"algo": ALGO_NAME[algo], "channels": ch, "copy_engine": eng, "piece_bytes": pc,
+                             "ms": t * 1e3, "algbw_GBps": nbytes / t / 1e9})
         best = min(tune, key=lambda x: x["ms"])
         best_ring = min((x for x in tune if x["algo"] == "ring"), key=lambda x: x["ms"])
         algo = {v: k for k, v in ALGO_NAME.items()}[best["algo"]]
         comm.set_param("channels", best["channels"])
         comm.set_param("copy_engine", best["copy_engine"])
+        comm.set_param("piece_bytes", best["piece_bytes"])
     else:
         algo = {v: k for k, v in ALGO_NAME.items()}[a.algo]
-        best = {"algo": a.algo, "channels": comm.get_param("channels"), "copy_engine": comm.get_param("copy_engine")}
+        best = {"algo": a.algo, "channels": comm.get_param("channels"), "copy_engine": comm.get_param("copy_engine"),
+                "piece_bytes": comm.get_param("piece_bytes")}
         best_ring = None
 
     # ---- warmup + parity of the chosen schedule against the oracle --------------------------------
@@ -197,13 +208,32 @@ def rank_main(job: Job, grank: int):
 
     # ---- timed region: exactly K steps ----------------------------------------------------------------
     comm.prof_reset()
+    comm.set_param("prof_every", 4)  # bracket every 4th launch: event markers cost stream bubbles
     comm.prof_enable(True)
     t_step = timed(comm, lambda: run(algo), a.steps)
     comm.prof_enable(False)
     prof = {k: comm.prof_get(k) for k in (xmpi.PROF_REDUCE2, xmpi.PROF_REDUCEN, xmpi.PROF_COPY, xmpi.PROF_PEER)}
 
+    # the same kernel with the GPU to itself (rank 0 only, everybody else parked at a barrier):
+    # one ring-step chunk (S / R) per launch
+    iso = None
+    comm.barrier()
+    if lead and R > 1:
+        chunk = max(1, count // R)
+        comm.prof_reset()
+        comm.prof_enable(True)
+        for _ in range(20):
+            comm.reduce_local(recv, send, send.at(chunk * es), chunk, dtype, xmpi.SUM)
+        n_i, ms_i, by_i = comm.prof_get(xmpi.PROF_REDUCE2)
+        comm.prof_enable(False)
+        iso = {"kernel": "reduce2_kernel (one ring-step chunk, GPU otherwise idle)", "bytes_per_launch": by_i / n_i,
+               "avg_launch_us": ms_i * 1e3 / n_i, "achieved": by_i / (ms_i * 1e-3) / 1e9, "unit": "GB/s",
+               "frac": by_i / (ms_i * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    comm.barrier()
+
     out = {"t_step": t_step, "prof": prof, "tune": tune, "best": best, "best_ring": best_ring, "parity": parity,
-           "algo": algo, "nbytes": nbytes, "count": count}
+           "algo": algo, "nbytes": nbytes, "count": count, "iso": iso,
+           "shared_stream": comm.get_param("shared_stream"), "slot_bytes": comm.get_param("slot_bytes")}
 
     # ---- untimed extras: what the next round needs to tune blind multi-GPU runs -----------------------
     extras = {}
@@ -351,12 +381,14 @@ def main():
                    "ranks": R, "ranks_per_gpu": R // args.gpus, "bytes_per_rank": S,
                    "algo": r0["best"]["algo"], "channels": r0["best"]["channels"],
                    "copy_engine": "copy_kernel" if r0["best"]["copy_engine"] else "hipMemcpyAsync",
+                   "piece_bytes": r0["best"].get("piece_bytes", 0), "slot_bytes": r0["slot_bytes"],
+                   "shared_stream": bool(r0["shared_stream"]),
                    "transport": "xGMI peer copies" if args.gpus == R else
                    ("intra-HBM copies between co-located ranks" if args.gpus == 1 else "mixed intra-HBM / xGMI")},
         "algbw_GBps": algbw, "busbw_GBps": busbw,
         "xgmi": {"per_link_peak_GBps": XGMI_LINK_GBPS, "busbw_frac_of_link_peak": busbw / XGMI_LINK_GBPS,
                  "meaningful": args.gpus == R},
-        "roofline": roof, "parity": r0["parity"], "autotune": r0["tune"], "ring_best": r0["best_ring"],
+        "roofline": roof, "roofline_isolated": r0["iso"], "parity": r0["parity"], "autotune": r0["tune"], "ring_best": r0["best_ring"],
         "extras": r0["extras"],
     }
     if args.gpus == 1 and not args.no_cpu and job.proc_rank == 0:

@@ -98,6 +98,18 @@ static void ipc_close_shared(void* ptr) {
     }
 }
 
+static hipStream_t shared_stream_for(int device) {
+  static std::mutex mu;
+  static std::vector<std::pair<int, hipStream_t>> streams;
+  std::lock_guard<std::mutex> g(mu);
+  for (auto& kv : streams)
+    if (kv.first == device) return kv.second;
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  streams.push_back({device, s});
+  return s;
+}
+
 static int collective(xmpi_comm* c, int coll, int algo, int root, const void* sendbuf, void* recvbuf, size_t count,
                       int dtype, int op) {
   const size_t es = xmpi_dtype_size((xmpi_dtype)dtype);
@@ -227,7 +239,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   CtlConfig cfg;
   cfg.lanes = (int32_t)std::min<long>(kMaxLanes, std::max<long>(1, env_long("XMPI_LANES", 2)));
   cfg.fifo_depth = (int32_t)std::min<long>(64, std::max<long>(2, env_long("XMPI_FIFO_DEPTH", 8)));
-  cfg.slot_bytes = (uint64_t)std::max<long>(4096, env_long("XMPI_SLOT_BYTES", 4l << 20)) / 256 * 256;
+  cfg.slot_bytes = (uint64_t)std::max<long>(4096, env_long("XMPI_SLOT_BYTES", 8l << 20)) / 256 * 256;
   cfg.p2p_depth = (int32_t)std::min<long>(16, std::max<long>(2, env_long("XMPI_P2P_DEPTH", 2)));
   cfg.p2p_slot_bytes = (uint64_t)std::max<long>(4096, env_long("XMPI_P2P_SLOT_BYTES", 4l << 20)) / 256 * 256;
   const double timeout = (double)env_long("XMPI_TIMEOUT_S", 60);
@@ -255,6 +267,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   c->channels = env_long("XMPI_CHANNELS", 4);
   c->piece_bytes = env_long("XMPI_PIECE_BYTES", 0);
   c->copy_engine = env_long("XMPI_COPY_ENGINE", 0);
+  c->dep_mode = env_long("XMPI_DEP_MODE", 0) ? 1 : 0;
   c->coll_region_bytes = (size_t)size * c->lanes * c->fifo_depth * c->slot_bytes;
   c->window_bytes = c->coll_region_bytes + (size_t)size * kMailEntries * c->p2p_depth * c->p2p_slot_bytes;
 
@@ -317,16 +330,40 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
       c->peer_opened[p] = true;
     }
   }
-  for (int p = 0; p < size; p++) {
-    if (p == rank) continue;
-    if (hipStreamCreateWithFlags(&c->send_stream[p], hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->recv_stream[p], hipStreamNonBlocking) != hipSuccess) {
+  // Ranks hosted by threads of one process on one GPU share a single in-order stream: HBM is their
+  // only shared resource, so concurrent streams would only make every kernel slower, while one
+  // stream lets each kernel run at full-chip bandwidth (and needs no cross-stream events).
+  bool colocated = false;
+  for (int p = 0; p < size; p++)
+    if (p != rank && ctl->info(p)->pid == mypid && ctl->info(p)->device == device) {
+      colocated = true;
+      c->peer_coloc[p] = true;
+    }
+  const long shared_env = env_long("XMPI_SHARED_STREAM", -1);
+  c->shared_stream = shared_env < 0 ? colocated : shared_env != 0;
+  if (c->shared_stream) {
+    hipStream_t s = shared_stream_for(device);
+    if (!s) {
+      hip_fail(hipGetLastError(), "hipStreamCreate(shared)", __FILE__, __LINE__);
+      return fail(XMPI_ERR_HIP);
+    }
+    for (int p = 0; p < size; p++) c->send_stream[p] = c->recv_stream[p] = (p == rank) ? nullptr : s;
+    c->local_stream = s;
+  } else {
+    for (int p = 0; p < size; p++) {
+      if (p == rank) continue;
+      if (hipStreamCreateWithFlags(&c->send_stream[p], hipStreamNonBlocking) != hipSuccess ||
+          hipStreamCreateWithFlags(&c->recv_stream[p], hipStreamNonBlocking) != hipSuccess) {
+        hip_fail(hipGetLastError(), "hipStreamCreate", __FILE__, __LINE__);
+        return fail(XMPI_ERR_HIP);
+      }
+    }
+    if (hipStreamCreateWithFlags(&c->local_stream, hipStreamNonBlocking) != hipSuccess) {
       hip_fail(hipGetLastError(), "hipStreamCreate", __FILE__, __LINE__);
       return fail(XMPI_ERR_HIP);
     }
   }
-  if (hipStreamCreateWithFlags(&c->local_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipMalloc((void**)&c->dev_words, 4 * sizeof(uint64_t)) != hipSuccess) {
+  if (hipMalloc((void**)&c->dev_words, 4 * sizeof(uint64_t)) != hipSuccess) {
     hip_fail(hipGetLastError(), "hipStreamCreate/hipMalloc", __FILE__, __LINE__);
     return fail(XMPI_ERR_HIP);
   }
@@ -348,10 +385,11 @@ int xmpi_finalize(xmpi_comm* c) {
   if (!c->ctl->aborted()) (void)c->ctl->barrier(c->timeout_s > 0 ? (double)c->timeout_s : 3600.0);
   for (int p = 0; p < c->size; p++) {
     if (c->peer_opened[p]) ipc_close_shared(c->peer_window[p]);
+    if (c->shared_stream) continue;  // the per-device shared stream outlives communicators
     if (c->send_stream[p]) (void)hipStreamDestroy(c->send_stream[p]);
     if (c->recv_stream[p]) (void)hipStreamDestroy(c->recv_stream[p]);
   }
-  if (c->local_stream) (void)hipStreamDestroy(c->local_stream);
+  if (c->local_stream && !c->shared_stream) (void)hipStreamDestroy(c->local_stream);
   for (hipStream_t s : c->p2p_streams) (void)hipStreamDestroy(s);
   for (hipEvent_t e : c->ev_free) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev_timed_free) (void)hipEventDestroy(e);
@@ -588,6 +626,8 @@ int xmpi_set_param(xmpi_comm* c, const char* name, long value) {
   else if (n == "piece_bytes") c->piece_bytes = std::max<long>(0, value);
   else if (n == "copy_engine") c->copy_engine = value ? 1 : 0;
   else if (n == "timeout_s") c->timeout_s = value;
+  else if (n == "dep_mode") c->dep_mode = value ? 1 : 0;
+  else if (n == "prof_every") c->prof_every = std::max<long>(1, value);
   else return XMPI_ERR_ARG;
   return XMPI_OK;
 }
@@ -599,6 +639,8 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
   if (n == "piece_bytes") return c->piece_bytes;
   if (n == "copy_engine") return c->copy_engine;
   if (n == "timeout_s") return c->timeout_s;
+  if (n == "dep_mode") return c->dep_mode;
+  if (n == "shared_stream") return c->shared_stream ? 1 : 0;
   if (n == "lanes") return c->lanes;
   if (n == "fifo_depth") return c->fifo_depth;
   if (n == "slot_bytes") return (long)c->slot_bytes;

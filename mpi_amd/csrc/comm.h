@@ -61,6 +61,10 @@ struct xmpi_comm {
   hipStream_t send_stream[xmpi::kMaxRanks] = {nullptr};
   hipStream_t recv_stream[xmpi::kMaxRanks] = {nullptr};
   hipStream_t local_stream = nullptr;
+  bool shared_stream = false;  // all of the above alias one per-device stream (co-located ranks)
+  bool peer_coloc[xmpi::kMaxRanks] = {false};  // peer is a thread of this process on this GPU
+  long prof_every = 1;  // profile every k-th launch (events cost stream bubbles)
+  uint64_t prof_seq = 0;
 
   // per collective pipe: slots issued / consumed so far (monotonic across operations)
   uint64_t sent[xmpi::kMaxRanks][xmpi::kMaxLanes] = {{0}};
@@ -74,6 +78,7 @@ struct xmpi_comm {
   long piece_bytes = 0;  // 0 = choose per operation
   long copy_engine = 0;  // 0 = hipMemcpyAsync (SDMA / runtime blit), 1 = xmpi copy kernel
   long timeout_s = 60;
+  long dep_mode = 0;  // 0 = chain same-rank dependencies with stream events, 1 = wait on the host
 
   // scratch
   void* temp = nullptr;

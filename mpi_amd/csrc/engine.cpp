@@ -51,6 +51,16 @@ bool is_device_pointer(const void* p) {
 
 namespace {
 
+// Ranks hosted by threads of one process enqueue onto one stream: serialise each step's enqueue so a
+// profiled launch is bracketed by ITS events only.
+std::mutex g_shared_stream_mu;
+struct SharedStreamLock {
+  std::unique_lock<std::mutex> l;
+  explicit SharedStreamLock(const xmpi_comm* c) {
+    if (c->shared_stream) l = std::unique_lock<std::mutex>(g_shared_stream_mu);
+  }
+};
+
 struct InFlight {
   int step;
   hipEvent_t done;
@@ -87,6 +97,8 @@ struct Exec {
   std::vector<std::deque<char>> unreleased;  // per (peer, lane): popped slots not yet released
   size_t remaining;
   double last_progress;
+  bool eager_used = false;
+  std::vector<InFlight> prof_pending;  // sampled eager steps: timed after the final sync
 
   Exec(xmpi_comm* comm, const Plan& p, const void* sb, void* rb, int dt, int o)
       : c(comm), plan(p), dtype(dt), op(o), N(comm->size), L(comm->lanes) {
@@ -121,16 +133,20 @@ struct Exec {
     return c->local_stream;
   }
 
+  // dep_mode 0: a step may be enqueued once its dependencies are enqueued (chained with
+  // hipStreamWaitEvent); dep_mode 1: only once they have completed (no stream ever waits on
+  // another, so streams sharing a hardware queue cannot stall each other)
   bool deps_issued(const Step& s) const {
+    const uint8_t need = c->dep_mode == 1 ? 2 : 1;
     for (int d = 0; d < s.ndeps; d++)
-      if (state[(size_t)s.deps[d]] == 0) return false;
+      if (state[(size_t)s.deps[d]] < need) return false;
     return true;
   }
 
   int chain_deps(const Step& s, int sid) {
     for (int d = 0; d < s.ndeps; d++) {
       const int j = s.deps[d];
-      if (state[(size_t)j] == 1 && stream_of[(size_t)j] != sid && ev[(size_t)j])
+      if (state[(size_t)j] == 1 && stream(stream_of[(size_t)j]) != stream(sid) && ev[(size_t)j])
         XMPI_HIP(hipStreamWaitEvent(stream(sid), ev[(size_t)j], 0));
     }
     return XMPI_OK;
@@ -141,7 +157,7 @@ struct Exec {
     f->start = nullptr;
     f->prof_kind = prof_kind;
     f->prof_bytes = prof_bytes;
-    if (c->prof_on && prof_kind >= 0) {
+    if (c->prof_on && prof_kind >= 0 && (c->prof_seq++ % (uint64_t)std::max<long>(1, c->prof_every)) == 0) {
       f->start = ev_get(c, true);
       if (!f->start) return XMPI_ERR_HIP;
       XMPI_HIP(hipEventRecord(f->start, stream(sid)));
@@ -149,8 +165,25 @@ struct Exec {
     return XMPI_OK;
   }
 
-  int end_op(int i, int sid, InFlight* f) {
+  // eager = the consumer of this step's effect runs on the SAME in-order stream (ranks hosted by
+  // one process on one GPU): stream order already guarantees what the completion event would, so
+  // the counters are published at enqueue time and no event is recorded at all.
+  int end_op(int i, int sid, InFlight* f, bool eager) {
     const bool timed = f->start != nullptr;
+    if (eager) {
+      if (timed) {
+        f->done = ev_get(c, true);
+        if (!f->done) return XMPI_ERR_HIP;
+        XMPI_HIP(hipEventRecord(f->done, stream(sid)));
+        prof_pending.push_back(*f);
+      }
+      eager_used = true;
+      stream_of[(size_t)i] = sid;
+      state[(size_t)i] = 2;
+      remaining--;
+      publish(plan.steps[(size_t)i], i);
+      return XMPI_OK;
+    }
     f->done = ev_get(c, timed);
     if (!f->done) return XMPI_ERR_HIP;
     XMPI_HIP(hipEventRecord(f->done, stream(sid)));
@@ -160,6 +193,8 @@ struct Exec {
     fl[(size_t)sid].push_back(*f);
     return XMPI_OK;
   }
+
+  bool coloc(int peer) const { return c->shared_stream && c->peer_coloc[peer]; }
 
   void release_slot(int peer, int lane, uint64_t seq) {
     std::deque<char>& u = unreleased[(size_t)peer * L + lane];
@@ -172,8 +207,7 @@ struct Exec {
     c->ctl->pipe(peer, c->rank, lane)->tail.v.store(base, std::memory_order_release);
   }
 
-  int complete(const InFlight& f) {
-    const Step& s = plan.steps[(size_t)f.step];
+  int account(const InFlight& f) {
     if (f.start) {
       float ms = 0.f;
       XMPI_HIP(hipEventElapsedTime(&ms, f.start, f.done));
@@ -184,9 +218,11 @@ struct Exec {
       ev_put(c, f.start, true);
     }
     ev_put(c, f.done, f.start != nullptr);
-    ev[(size_t)f.step] = nullptr;
-    state[(size_t)f.step] = 2;
-    remaining--;
+    return XMPI_OK;
+  }
+
+  // make the effect of a finished (or stream-ordered) step visible to the peer
+  void publish(const Step& s, int step) {
     switch (s.kind) {
       case STEP_SEND: {
         const uint64_t h = ++c->sent_done[s.peer][s.lane];
@@ -195,7 +231,7 @@ struct Exec {
       }
       case STEP_RECV_REDUCE:
       case STEP_RECV_COPY:
-        release_slot(s.peer, s.lane, slot_seq[(size_t)f.step]);
+        release_slot(s.peer, s.lane, slot_seq[(size_t)step]);
         break;
       case STEP_REDUCE_N:
         for (int k = 0; k < s.nsrcs; k++)
@@ -207,6 +243,15 @@ struct Exec {
       default:
         break;
     }
+  }
+
+  int complete(const InFlight& f) {
+    int rc = account(f);
+    if (rc) return rc;
+    ev[(size_t)f.step] = nullptr;
+    state[(size_t)f.step] = 2;
+    remaining--;
+    publish(plan.steps[(size_t)f.step], f.step);
     return XMPI_OK;
   }
 
@@ -222,14 +267,15 @@ struct Exec {
     int rc = chain_deps(s, sid);
     if (rc) return rc;
     InFlight f;
+    SharedStreamLock lk(c);  // [start marker, launch, done marker] stay contiguous on a shared stream
     rc = begin_op(i, sid, &f, PROF_PEER, s.bytes);
     if (rc) return rc;
     char* dst = c->peer_window[s.peer] + c->coll_slot_off(c->rank, s.lane, seq);
     rc = peer_copy(c, dst, bufs[s.src_buf] + s.src_off, s.bytes, stream(sid));
     if (rc) return rc;
-    rc = end_op(i, sid, &f);
-    if (rc) return rc;
     c->sent[s.peer][s.lane] = seq + 1;
+    rc = end_op(i, sid, &f, coloc(s.peer));
+    if (rc) return rc;
     return 1;
   }
 
@@ -253,6 +299,7 @@ struct Exec {
     int rc = chain_deps(s, sid);
     if (rc) return rc;
     InFlight f;
+    SharedStreamLock lk(c);  // [start marker, launch, done marker] stay contiguous on a shared stream
     if (s.kind == STEP_RECV_REDUCE) {
       rc = begin_op(i, sid, &f, PROF_REDUCE2, 3 * s.bytes);
       if (rc) return rc;
@@ -263,7 +310,7 @@ struct Exec {
       if (rc) return rc;
       XMPI_HIP(launch_copy(bufs[s.dst_buf] + s.dst_off, slot, s.bytes, stream(sid)));
     }
-    return end_op(i, sid, &f) ? XMPI_ERR_HIP : 1;
+    return end_op(i, sid, &f, coloc(s.peer)) ? XMPI_ERR_HIP : 1;
   }
 
   int try_local(int i) {
@@ -277,6 +324,7 @@ struct Exec {
     int rc = chain_deps(s, sid);
     if (rc) return rc;
     InFlight f;
+    SharedStreamLock lk(c);  // [start marker, launch, done marker] stay contiguous on a shared stream
     if (s.kind == STEP_REDUCE_N) {
       const void* srcs[kMaxSrcs];
       for (int k = 0; k < s.nsrcs; k++)
@@ -291,7 +339,11 @@ struct Exec {
       char* dst = bufs[s.dst_buf] + s.dst_off;
       if (src != dst) XMPI_HIP(launch_copy(dst, src, s.bytes, stream(sid)));
     }
-    return end_op(i, sid, &f) ? XMPI_ERR_HIP : 1;
+    bool eager = c->shared_stream;
+    if (s.kind == STEP_REDUCE_N)
+      for (int k = 0; k < s.nsrcs; k++)
+        if (s.srcs[k] >= 0 && !coloc(plan.steps[(size_t)s.srcs[k]].peer)) eager = false;
+    return end_op(i, sid, &f, eager) ? XMPI_ERR_HIP : 1;
   }
 
   int run() {
@@ -353,6 +405,18 @@ struct Exec {
         return XMPI_ERR_TIMEOUT;
       }
       bo.pause();
+    }
+    if (eager_used) {  // the call is blocking: this rank's stream-ordered work must have finished
+      hipEvent_t fin = ev_get(c, false);
+      if (!fin) return XMPI_ERR_HIP;
+      XMPI_HIP(hipEventRecord(fin, c->local_stream));
+      XMPI_HIP(hipEventSynchronize(fin));
+      ev_put(c, fin, false);
+      for (const InFlight& f : prof_pending) {
+        int rc = account(f);
+        if (rc) return rc;
+      }
+      prof_pending.clear();
     }
     return XMPI_OK;
   }
