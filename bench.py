@@ -110,16 +110,21 @@ def all_max(comm, value: float) -> float:
     return float(out[0])
 
 
-def timed(comm, fn, iters: int) -> float:
+def timed(comm, fn, iters: int, prof: bool = False) -> float:
     """barrier + device sync on both sides; max over ranks of the per-iteration time"""
     comm.barrier()
     comm.sync()
+    if prof:
+        comm.prof_enable(True)
     t0 = time.perf_counter()
     for _ in range(iters):
         fn()
     comm.sync()
     comm.barrier()
-    return all_max(comm, (time.perf_counter() - t0) / iters)
+    dt = (time.perf_counter() - t0) / iters
+    if prof:
+        comm.prof_enable(False)
+    return all_max(comm, dt)
 
 
 def check_window(comm, send, recv, count, dtype, seed0, off, n):
@@ -208,10 +213,8 @@ def rank_main(job: Job, grank: int):
 
     # ---- timed region: exactly K steps ----------------------------------------------------------------
     comm.prof_reset()
-    comm.set_param("prof_every", 4)  # bracket every 4th launch: event markers cost stream bubbles
-    comm.prof_enable(True)
-    t_step = timed(comm, lambda: run(algo), a.steps)
-    comm.prof_enable(False)
+    comm.set_param("prof_every", 1)  # every launch carries its own begin/end events (hipExtLaunchKernelGGL)
+    t_step = timed(comm, lambda: run(algo), a.steps, prof=True)
     prof = {k: comm.prof_get(k) for k in (xmpi.PROF_REDUCE2, xmpi.PROF_REDUCEN, xmpi.PROF_COPY, xmpi.PROF_PEER)}
 
     # the same kernel with the GPU to itself (rank 0 only, everybody else parked at a barrier):

@@ -118,6 +118,11 @@ int xmpi_send(xmpi_comm* comm, const void* buf, size_t count, xmpi_dtype dtype, 
 int xmpi_recv(xmpi_comm* comm, void* buf, size_t capacity, xmpi_dtype dtype, int src, int tag,
               size_t* got);
 
+/* Blocks until a message {src, tag} has been posted and reports its element count and dtype without
+ * consuming it.  Lets a binding size the destination the way the reference's in-place gob decode
+ * re-slices / re-allocates the caller's slice (network.go:594-601, bounce.go:89,94). */
+int xmpi_probe(xmpi_comm* comm, int src, int tag, size_t* count, xmpi_dtype* dtype);
+
 /* ---- collectives (absent from the reference: mpi.go:130 is a commented-out stub, mpi.go:69-71
  *      an unused probe variable; defined here in the reference's delegate style) -------------- */
 

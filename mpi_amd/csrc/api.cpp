@@ -476,6 +476,19 @@ int xmpi_recv(xmpi_comm* c, void* buf, size_t capacity, xmpi_dtype dtype, int sr
   return rc;
 }
 
+int xmpi_probe(xmpi_comm* c, int src, int tag, size_t* count, xmpi_dtype* dtype) {
+  XMPI_ENTER(c);
+  if (src < 0 || src >= c->size) return XMPI_ERR_ARG;
+  size_t bytes = 0;
+  int dt = 0;
+  int rc = p2p_probe(c, src, tag, &bytes, &dt);
+  if (rc != XMPI_OK) return rc;
+  const size_t es = xmpi_dtype_size((xmpi_dtype)dt);
+  if (count) *count = es ? bytes / es : 0;
+  if (dtype) *dtype = (xmpi_dtype)dt;
+  return XMPI_OK;
+}
+
 int xmpi_bcast(xmpi_comm* c, void* buf, size_t count, xmpi_dtype dtype, int root, int algo) {
   XMPI_ENTER(c);
   return collective(c, COLL_BCAST, algo, root, buf, buf, count, (int)dtype, XMPI_SUM);
@@ -506,18 +519,18 @@ int xmpi_allgather(xmpi_comm* c, const void* sendbuf, void* recvbuf, size_t coun
 
 // ---- local kernels -----------------------------------------------------------------------------
 
-static int timed_launch(xmpi_comm* c, int kind, size_t bytes, hipError_t (*launch)(void*), void* ctx) {
+static int timed_launch(xmpi_comm* c, int kind, size_t bytes, hipError_t (*launch)(void*, hipEvent_t, hipEvent_t),
+                        void* ctx) {
   hipStream_t s = c->local_stream;
   if (!c->prof_on) {
-    XMPI_HIP(launch(ctx));
+    XMPI_HIP(launch(ctx, nullptr, nullptr));
     XMPI_HIP(hipStreamSynchronize(s));
     return XMPI_OK;
   }
+  // the events ride on the dispatch itself: they carry the kernel's own begin / end timestamps
   hipEvent_t a = ev_get(c, true), b = ev_get(c, true);
   if (!a || !b) return XMPI_ERR_HIP;
-  XMPI_HIP(hipEventRecord(a, s));
-  XMPI_HIP(launch(ctx));
-  XMPI_HIP(hipEventRecord(b, s));
+  XMPI_HIP(launch(ctx, a, b));
   XMPI_HIP(hipStreamSynchronize(s));
   float ms = 0.f;
   XMPI_HIP(hipEventElapsedTime(&ms, a, b));
@@ -535,9 +548,9 @@ int xmpi_reduce_local(xmpi_comm* c, void* dst, const void* a, const void* b, siz
   if (!es || op < 0 || op >= XMPI_OP_COUNT) return XMPI_ERR_ARG;
   struct Ctx { xmpi_comm* c; void* dst; const void *a, *b; size_t n; int dt, op; } ctx{c, dst, a, b, count, (int)dtype, (int)op};
   return timed_launch(c, PROF_REDUCE2, 3 * count * es,
-                      [](void* p) {
+                      [](void* p, hipEvent_t es, hipEvent_t ee) {
                         Ctx* x = (Ctx*)p;
-                        return launch_reduce2(x->dst, x->a, x->b, x->n, x->dt, x->op, x->c->local_stream);
+                        return launch_reduce2(x->dst, x->a, x->b, x->n, x->dt, x->op, x->c->local_stream, es, ee);
                       },
                       &ctx);
 }
@@ -549,9 +562,9 @@ int xmpi_reduce_local_n(xmpi_comm* c, void* dst, const void* const* srcs, int ns
   if (!es || op < 0 || op >= XMPI_OP_COUNT || nsrc < 1 || nsrc > kMaxReduceSrcs) return XMPI_ERR_ARG;
   struct Ctx { xmpi_comm* c; void* dst; const void* const* s; int ns; size_t n; int dt, op; } ctx{c, dst, srcs, nsrc, count, (int)dtype, (int)op};
   return timed_launch(c, PROF_REDUCEN, (size_t)(nsrc + 1) * count * es,
-                      [](void* p) {
+                      [](void* p, hipEvent_t es, hipEvent_t ee) {
                         Ctx* x = (Ctx*)p;
-                        return launch_reduce_n(x->dst, x->s, x->ns, x->n, x->dt, x->op, x->c->local_stream);
+                        return launch_reduce_n(x->dst, x->s, x->ns, x->n, x->dt, x->op, x->c->local_stream, es, ee);
                       },
                       &ctx);
 }
@@ -560,9 +573,9 @@ int xmpi_copy_local(xmpi_comm* c, void* dst, const void* src, size_t bytes) {
   XMPI_ENTER(c);
   struct Ctx { xmpi_comm* c; void* dst; const void* src; size_t n; } ctx{c, dst, src, bytes};
   return timed_launch(c, PROF_COPY, 2 * bytes,
-                      [](void* p) {
+                      [](void* p, hipEvent_t es, hipEvent_t ee) {
                         Ctx* x = (Ctx*)p;
-                        return launch_copy(x->dst, x->src, x->n, x->c->local_stream);
+                        return launch_copy(x->dst, x->src, x->n, x->c->local_stream, es, ee);
                       },
                       &ctx);
 }

@@ -64,7 +64,7 @@ struct xmpi_comm {
   bool shared_stream = false;  // all of the above alias one per-device stream (co-located ranks)
   bool peer_coloc[xmpi::kMaxRanks] = {false};  // peer is a thread of this process on this GPU
   long prof_every = 1;  // profile every k-th launch (events cost stream bubbles)
-  uint64_t prof_seq = 0;
+  uint64_t prof_seq[xmpi::PROF_KINDS] = {0};
 
   // per collective pipe: slots issued / consumed so far (monotonic across operations)
   uint64_t sent[xmpi::kMaxRanks][xmpi::kMaxLanes] = {{0}};
@@ -105,6 +105,7 @@ namespace xmpi {
 int run_plan(xmpi_comm* c, const Plan& plan, const void* sendbuf, void* recvbuf, int dtype, int op);
 int p2p_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, int tag);
 int p2p_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int tag, size_t* got_bytes);
+int p2p_probe(xmpi_comm* c, int src, int tag, size_t* bytes, int* dtype);
 hipEvent_t ev_get(xmpi_comm* c, bool timed);
 void ev_put(xmpi_comm* c, hipEvent_t e, bool timed);
 bool is_device_pointer(const void* p);

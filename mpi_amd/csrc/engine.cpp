@@ -63,17 +63,19 @@ struct SharedStreamLock {
 
 struct InFlight {
   int step;
-  hipEvent_t done;
-  hipEvent_t start;  // only when profiling
+  hipEvent_t done;         // completion tracking (not needed for stream-ordered steps)
+  hipEvent_t start, stop;  // only for profiled launches: attached to the dispatch itself
   int prof_kind;
   size_t prof_bytes;
 };
 
-int peer_copy(xmpi_comm* c, void* dst, const void* src, size_t bytes, hipStream_t s) {
+int peer_copy(xmpi_comm* c, void* dst, const void* src, size_t bytes, hipStream_t s, hipEvent_t es, hipEvent_t ee) {
   if (c->copy_engine == 1) {
-    XMPI_HIP(launch_copy(dst, src, bytes, s));
+    XMPI_HIP(launch_copy(dst, src, bytes, s, es, ee));
   } else {
+    if (es) XMPI_HIP(hipEventRecord(es, s));
     XMPI_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+    if (ee) XMPI_HIP(hipEventRecord(ee, s));
   }
   return XMPI_OK;
 }
@@ -152,15 +154,16 @@ struct Exec {
     return XMPI_OK;
   }
 
-  int begin_op(int i, int sid, InFlight* f, int prof_kind, size_t prof_bytes) {
+  int begin_op(int i, InFlight* f, int prof_kind, size_t prof_bytes) {
     f->step = i;
-    f->start = nullptr;
+    f->done = f->start = f->stop = nullptr;
     f->prof_kind = prof_kind;
     f->prof_bytes = prof_bytes;
-    if (c->prof_on && prof_kind >= 0 && (c->prof_seq++ % (uint64_t)std::max<long>(1, c->prof_every)) == 0) {
+    if (c->prof_on && prof_kind >= 0 &&
+        (c->prof_seq[prof_kind]++ % (uint64_t)std::max<long>(1, c->prof_every)) == 0) {
       f->start = ev_get(c, true);
-      if (!f->start) return XMPI_ERR_HIP;
-      XMPI_HIP(hipEventRecord(f->start, stream(sid)));
+      f->stop = ev_get(c, true);
+      if (!f->start || !f->stop) return XMPI_ERR_HIP;
     }
     return XMPI_OK;
   }
@@ -169,26 +172,19 @@ struct Exec {
   // one process on one GPU): stream order already guarantees what the completion event would, so
   // the counters are published at enqueue time and no event is recorded at all.
   int end_op(int i, int sid, InFlight* f, bool eager) {
-    const bool timed = f->start != nullptr;
+    stream_of[(size_t)i] = sid;
     if (eager) {
-      if (timed) {
-        f->done = ev_get(c, true);
-        if (!f->done) return XMPI_ERR_HIP;
-        XMPI_HIP(hipEventRecord(f->done, stream(sid)));
-        prof_pending.push_back(*f);
-      }
+      if (f->start) prof_pending.push_back(*f);
       eager_used = true;
-      stream_of[(size_t)i] = sid;
       state[(size_t)i] = 2;
       remaining--;
       publish(plan.steps[(size_t)i], i);
       return XMPI_OK;
     }
-    f->done = ev_get(c, timed);
+    f->done = ev_get(c, false);
     if (!f->done) return XMPI_ERR_HIP;
     XMPI_HIP(hipEventRecord(f->done, stream(sid)));
     ev[(size_t)i] = f->done;
-    stream_of[(size_t)i] = sid;
     state[(size_t)i] = 1;
     fl[(size_t)sid].push_back(*f);
     return XMPI_OK;
@@ -210,14 +206,15 @@ struct Exec {
   int account(const InFlight& f) {
     if (f.start) {
       float ms = 0.f;
-      XMPI_HIP(hipEventElapsedTime(&ms, f.start, f.done));
+      XMPI_HIP(hipEventElapsedTime(&ms, f.start, f.stop));
       ProfCounter& pc = c->prof[f.prof_kind];
       pc.launches++;
       pc.total_ms += ms;
       pc.bytes += f.prof_bytes;
       ev_put(c, f.start, true);
+      ev_put(c, f.stop, true);
     }
-    ev_put(c, f.done, f.start != nullptr);
+    if (f.done) ev_put(c, f.done, false);
     return XMPI_OK;
   }
 
@@ -268,10 +265,10 @@ struct Exec {
     if (rc) return rc;
     InFlight f;
     SharedStreamLock lk(c);  // [start marker, launch, done marker] stay contiguous on a shared stream
-    rc = begin_op(i, sid, &f, PROF_PEER, s.bytes);
+    rc = begin_op(i, &f, PROF_PEER, s.bytes);
     if (rc) return rc;
     char* dst = c->peer_window[s.peer] + c->coll_slot_off(c->rank, s.lane, seq);
-    rc = peer_copy(c, dst, bufs[s.src_buf] + s.src_off, s.bytes, stream(sid));
+    rc = peer_copy(c, dst, bufs[s.src_buf] + s.src_off, s.bytes, stream(sid), f.start, f.stop);
     if (rc) return rc;
     c->sent[s.peer][s.lane] = seq + 1;
     rc = end_op(i, sid, &f, coloc(s.peer));
@@ -301,14 +298,14 @@ struct Exec {
     InFlight f;
     SharedStreamLock lk(c);  // [start marker, launch, done marker] stay contiguous on a shared stream
     if (s.kind == STEP_RECV_REDUCE) {
-      rc = begin_op(i, sid, &f, PROF_REDUCE2, 3 * s.bytes);
+      rc = begin_op(i, &f, PROF_REDUCE2, 3 * s.bytes);
       if (rc) return rc;
       XMPI_HIP(launch_reduce2(bufs[s.dst_buf] + s.dst_off, bufs[s.src_buf] + s.src_off, slot, s.bytes / es, dtype,
-                              op, stream(sid)));
+                              op, stream(sid), f.start, f.stop));
     } else {
-      rc = begin_op(i, sid, &f, PROF_COPY, 2 * s.bytes);
+      rc = begin_op(i, &f, PROF_COPY, 2 * s.bytes);
       if (rc) return rc;
-      XMPI_HIP(launch_copy(bufs[s.dst_buf] + s.dst_off, slot, s.bytes, stream(sid)));
+      XMPI_HIP(launch_copy(bufs[s.dst_buf] + s.dst_off, slot, s.bytes, stream(sid), f.start, f.stop));
     }
     return end_op(i, sid, &f, coloc(s.peer)) ? XMPI_ERR_HIP : 1;
   }
@@ -329,15 +326,16 @@ struct Exec {
       const void* srcs[kMaxSrcs];
       for (int k = 0; k < s.nsrcs; k++)
         srcs[k] = (s.srcs[k] < 0) ? (const void*)(bufs[s.src_buf] + s.src_off) : (const void*)slot_ptr[(size_t)s.srcs[k]];
-      rc = begin_op(i, sid, &f, PROF_REDUCEN, (size_t)(s.nsrcs + 1) * s.bytes);
+      rc = begin_op(i, &f, PROF_REDUCEN, (size_t)(s.nsrcs + 1) * s.bytes);
       if (rc) return rc;
-      XMPI_HIP(launch_reduce_n(bufs[s.dst_buf] + s.dst_off, srcs, s.nsrcs, s.bytes / es, dtype, op, stream(sid)));
+      XMPI_HIP(launch_reduce_n(bufs[s.dst_buf] + s.dst_off, srcs, s.nsrcs, s.bytes / es, dtype, op, stream(sid),
+                               f.start, f.stop));
     } else {
-      rc = begin_op(i, sid, &f, PROF_COPY, 2 * s.bytes);
+      rc = begin_op(i, &f, PROF_COPY, 2 * s.bytes);
       if (rc) return rc;
       const char* src = bufs[s.src_buf] + s.src_off;
       char* dst = bufs[s.dst_buf] + s.dst_off;
-      if (src != dst) XMPI_HIP(launch_copy(dst, src, s.bytes, stream(sid)));
+      XMPI_HIP(launch_copy(dst, src, s.bytes, stream(sid), f.start, f.stop));
     }
     bool eager = c->shared_stream;
     if (s.kind == STEP_REDUCE_N)
@@ -633,6 +631,29 @@ int p2p_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, i
     c->ctl->set_abort(rc);  // the entry is in an unknown state: the job cannot continue
   }
   return rc;
+}
+
+// Wait for a message {src, tag} to be posted and report its size without consuming it (lets a
+// host-language binding size the destination the way gob's in-place decode does, network.go:597).
+int p2p_probe(xmpi_comm* c, int src, int tag, size_t* bytes, int* dtype) {
+  const double t0 = now_seconds();
+  Backoff bo;
+  for (;;) {
+    for (int e = 0; e < kMailEntries; e++) {
+      MailEntry* m = c->ctl->mail(src, c->rank, e);
+      if (m->state.load(std::memory_order_acquire) == MAIL_POSTED && m->tag == tag) {
+        if (bytes) *bytes = m->bytes;
+        if (dtype) *dtype = m->dtype;
+        return XMPI_OK;
+      }
+    }
+    if (c->ctl->aborted()) return XMPI_ERR_PEER;
+    if (timed_out(c, t0)) {
+      set_last_error("probe from rank " + std::to_string(src) + " tag " + std::to_string(tag) + ": no matching send");
+      return XMPI_ERR_TIMEOUT;
+    }
+    bo.pause();
+  }
 }
 
 int p2p_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int tag, size_t* got_bytes) {

@@ -10,13 +10,17 @@ namespace xmpi {
 constexpr int kMaxReduceSrcs = 16;
 
 // dst[i] = a[i] op b[i]; dst may alias a and/or b exactly (same address), never partially.
+// ev_start / ev_stop (optional, timing-enabled events): attached to the dispatch itself
+// (hipExtLaunchKernelGGL), i.e. they carry the kernel's own begin / end timestamps.
 hipError_t launch_reduce2(void* dst, const void* a, const void* b, size_t count, int dtype, int op,
-                          hipStream_t stream);
+                          hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // dst[i] = ((s0[i] op s1[i]) op s2[i]) ... left to right.
 hipError_t launch_reduce_n(void* dst, const void* const* srcs, int nsrc, size_t count, int dtype,
-                           int op, hipStream_t stream);
+                           int op, hipStream_t stream, hipEvent_t ev_start = nullptr,
+                           hipEvent_t ev_stop = nullptr);
 // streaming copy (local HBM -> local HBM, or local HBM -> peer HBM over xGMI)
-hipError_t launch_copy(void* dst, const void* src, size_t bytes, hipStream_t stream);
+hipError_t launch_copy(void* dst, const void* src, size_t bytes, hipStream_t stream,
+                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
 // *d_out += number of differing bytes (d_out: 8-byte device word, caller zeroes it)
 hipError_t launch_count_mismatch(const void* a, const void* b, size_t bytes, uint64_t* d_out,

@@ -14,6 +14,7 @@
 // LDS + wavefront shuffles are used where a cross-lane reduction really exists: the
 // verification kernels at the bottom.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "kernels.h"
 
@@ -463,6 +464,13 @@ __global__ void signal_kernel(uint64_t* flag, uint64_t value) {
 
 // ---- launch helpers --------------------------------------------------------------------------
 
+// plain launch, or a launch that carries its own begin / end events
+#define XMPI_LAUNCH(kern, grid, block, stream, es, ee, ...)                                  \
+  do {                                                                                       \
+    if ((es) || (ee)) hipExtLaunchKernelGGL(kern, grid, block, 0, stream, es, ee, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__);                      \
+  } while (0)
+
 inline int grid_for(size_t work_items, size_t per_block) {
   size_t g = (work_items + per_block - 1) / per_block;
   if (g < 1) g = 1;
@@ -473,48 +481,51 @@ inline int grid_for(size_t work_items, size_t per_block) {
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <typename T, int OP>
-hipError_t reduce2_typed(void* dst, const void* a, const void* b, size_t count, hipStream_t s) {
+hipError_t reduce2_typed(void* dst, const void* a, const void* b, size_t count, hipStream_t s, hipEvent_t es,
+                         hipEvent_t ee) {
   if (count == 0) return hipSuccess;
   if (aligned16(dst) && aligned16(a) && aligned16(b)) {
     constexpr size_t N = 16 / sizeof(T);
     const size_t npack = count / N;
     const int grid = grid_for(npack, (size_t)kBlock * kUnroll);
-    hipLaunchKernelGGL((reduce2_kernel<T, OP>), dim3(grid), dim3(kBlock), 0, s, (T*)dst, (const T*)a,
-                       (const T*)b, npack, count);
+    XMPI_LAUNCH((reduce2_kernel<T, OP>), dim3(grid), dim3(kBlock), s, es, ee, (T*)dst, (const T*)a, (const T*)b,
+                npack, count);
   } else {
     const int grid = grid_for(count, kBlock);
-    hipLaunchKernelGGL((reduce2_elem_kernel<T, OP>), dim3(grid), dim3(kBlock), 0, s, (T*)dst,
-                       (const T*)a, (const T*)b, count);
+    XMPI_LAUNCH((reduce2_elem_kernel<T, OP>), dim3(grid), dim3(kBlock), s, es, ee, (T*)dst, (const T*)a,
+                (const T*)b, count);
   }
   return hipGetLastError();
 }
 
 template <typename T>
-hipError_t reduce2_op(void* dst, const void* a, const void* b, size_t count, int op, hipStream_t s) {
+hipError_t reduce2_op(void* dst, const void* a, const void* b, size_t count, int op, hipStream_t s, hipEvent_t es,
+                      hipEvent_t ee) {
   switch (op) {
-    case OP_SUM: return reduce2_typed<T, OP_SUM>(dst, a, b, count, s);
-    case OP_PROD: return reduce2_typed<T, OP_PROD>(dst, a, b, count, s);
-    case OP_MIN: return reduce2_typed<T, OP_MIN>(dst, a, b, count, s);
-    case OP_MAX: return reduce2_typed<T, OP_MAX>(dst, a, b, count, s);
+    case OP_SUM: return reduce2_typed<T, OP_SUM>(dst, a, b, count, s, es, ee);
+    case OP_PROD: return reduce2_typed<T, OP_PROD>(dst, a, b, count, s, es, ee);
+    case OP_MIN: return reduce2_typed<T, OP_MIN>(dst, a, b, count, s, es, ee);
+    case OP_MAX: return reduce2_typed<T, OP_MAX>(dst, a, b, count, s, es, ee);
     default: return hipErrorInvalidValue;
   }
 }
 
 template <typename T, int OP>
-hipError_t reduce_n_typed(void* dst, const SrcPtrs& srcs, int nsrc, size_t count, hipStream_t s) {
+hipError_t reduce_n_typed(void* dst, const SrcPtrs& srcs, int nsrc, size_t count, hipStream_t s, hipEvent_t es,
+                          hipEvent_t ee) {
   constexpr size_t N = 16 / sizeof(T);
   const size_t npack = count / N;
   const int grid = grid_for(npack, kBlock);
-#define XMPI_RN(NS)                                                                              \
-  case NS:                                                                                       \
-    hipLaunchKernelGGL((reduce_n_kernel<T, OP, NS>), dim3(grid), dim3(kBlock), 0, s, (T*)dst, srcs, \
-                       nsrc, npack, count);                                                      \
+#define XMPI_RN(NS)                                                                                        \
+  case NS:                                                                                                 \
+    XMPI_LAUNCH((reduce_n_kernel<T, OP, NS>), dim3(grid), dim3(kBlock), s, es, ee, (T*)dst, srcs, nsrc, npack, \
+                count);                                                                                    \
     break;
   switch (nsrc) {
     XMPI_RN(2) XMPI_RN(3) XMPI_RN(4) XMPI_RN(5) XMPI_RN(6) XMPI_RN(7) XMPI_RN(8)
     default:
-      hipLaunchKernelGGL((reduce_n_kernel<T, OP, 0>), dim3(grid), dim3(kBlock), 0, s, (T*)dst, srcs,
-                         nsrc, npack, count);
+      XMPI_LAUNCH((reduce_n_kernel<T, OP, 0>), dim3(grid), dim3(kBlock), s, es, ee, (T*)dst, srcs, nsrc, npack,
+                  count);
       break;
   }
 #undef XMPI_RN
@@ -522,12 +533,13 @@ hipError_t reduce_n_typed(void* dst, const SrcPtrs& srcs, int nsrc, size_t count
 }
 
 template <typename T>
-hipError_t reduce_n_op(void* dst, const SrcPtrs& srcs, int nsrc, size_t count, int op, hipStream_t s) {
+hipError_t reduce_n_op(void* dst, const SrcPtrs& srcs, int nsrc, size_t count, int op, hipStream_t s, hipEvent_t es,
+                       hipEvent_t ee) {
   switch (op) {
-    case OP_SUM: return reduce_n_typed<T, OP_SUM>(dst, srcs, nsrc, count, s);
-    case OP_PROD: return reduce_n_typed<T, OP_PROD>(dst, srcs, nsrc, count, s);
-    case OP_MIN: return reduce_n_typed<T, OP_MIN>(dst, srcs, nsrc, count, s);
-    case OP_MAX: return reduce_n_typed<T, OP_MAX>(dst, srcs, nsrc, count, s);
+    case OP_SUM: return reduce_n_typed<T, OP_SUM>(dst, srcs, nsrc, count, s, es, ee);
+    case OP_PROD: return reduce_n_typed<T, OP_PROD>(dst, srcs, nsrc, count, s, es, ee);
+    case OP_MIN: return reduce_n_typed<T, OP_MIN>(dst, srcs, nsrc, count, s, es, ee);
+    case OP_MAX: return reduce_n_typed<T, OP_MAX>(dst, srcs, nsrc, count, s, es, ee);
     default: return hipErrorInvalidValue;
   }
 }
@@ -535,59 +547,63 @@ hipError_t reduce_n_op(void* dst, const SrcPtrs& srcs, int nsrc, size_t count, i
 }  // namespace
 
 hipError_t launch_reduce2(void* dst, const void* a, const void* b, size_t count, int dtype, int op,
-                          hipStream_t s) {
+                          hipStream_t s, hipEvent_t es, hipEvent_t ee) {
   switch (dtype) {
-    case DT_U8: return reduce2_op<uint8_t>(dst, a, b, count, op, s);
-    case DT_I32: return reduce2_op<int32_t>(dst, a, b, count, op, s);
-    case DT_I64: return reduce2_op<int64_t>(dst, a, b, count, op, s);
-    case DT_F16: return reduce2_op<_Float16>(dst, a, b, count, op, s);
-    case DT_F32: return reduce2_op<float>(dst, a, b, count, op, s);
-    case DT_F64: return reduce2_op<double>(dst, a, b, count, op, s);
-    case DT_BF16: return reduce2_op<bf16_t>(dst, a, b, count, op, s);
+    case DT_U8: return reduce2_op<uint8_t>(dst, a, b, count, op, s, es, ee);
+    case DT_I32: return reduce2_op<int32_t>(dst, a, b, count, op, s, es, ee);
+    case DT_I64: return reduce2_op<int64_t>(dst, a, b, count, op, s, es, ee);
+    case DT_F16: return reduce2_op<_Float16>(dst, a, b, count, op, s, es, ee);
+    case DT_F32: return reduce2_op<float>(dst, a, b, count, op, s, es, ee);
+    case DT_F64: return reduce2_op<double>(dst, a, b, count, op, s, es, ee);
+    case DT_BF16: return reduce2_op<bf16_t>(dst, a, b, count, op, s, es, ee);
     default: return hipErrorInvalidValue;
   }
 }
 
 hipError_t launch_reduce_n(void* dst, const void* const* srcs, int nsrc, size_t count, int dtype,
-                           int op, hipStream_t s) {
+                           int op, hipStream_t s, hipEvent_t es, hipEvent_t ee) {
   if (nsrc < 1 || nsrc > kMaxReduceSrcs) return hipErrorInvalidValue;
   if (count == 0) return hipSuccess;
   if (nsrc == 1) {
-    static const size_t es[] = {1, 4, 8, 2, 4, 8, 2};
+    static const size_t esz[] = {1, 4, 8, 2, 4, 8, 2};
     if (dtype < 0 || dtype > DT_BF16) return hipErrorInvalidValue;
-    return launch_copy(dst, srcs[0], count * es[dtype], s);
+    return launch_copy(dst, srcs[0], count * esz[dtype], s, es, ee);
   }
   bool ok = aligned16(dst);
   SrcPtrs p;
   for (int i = 0; i < kMaxReduceSrcs; i++) p.p[i] = (i < nsrc) ? srcs[i] : nullptr;
   for (int i = 0; i < nsrc; i++) ok = ok && aligned16(srcs[i]);
   if (!ok) {  // odd alignment: chain the element kernel (same left-to-right order)
-    hipError_t e = launch_reduce2(dst, srcs[0], srcs[1], count, dtype, op, s);
-    for (int i = 2; i < nsrc && e == hipSuccess; i++) e = launch_reduce2(dst, dst, srcs[i], count, dtype, op, s);
+    hipError_t e = launch_reduce2(dst, srcs[0], srcs[1], count, dtype, op, s, es, nsrc == 2 ? ee : nullptr);
+    for (int i = 2; i < nsrc && e == hipSuccess; i++)
+      e = launch_reduce2(dst, dst, srcs[i], count, dtype, op, s, nullptr, i == nsrc - 1 ? ee : nullptr);
     return e;
   }
   switch (dtype) {
-    case DT_U8: return reduce_n_op<uint8_t>(dst, p, nsrc, count, op, s);
-    case DT_I32: return reduce_n_op<int32_t>(dst, p, nsrc, count, op, s);
-    case DT_I64: return reduce_n_op<int64_t>(dst, p, nsrc, count, op, s);
-    case DT_F16: return reduce_n_op<_Float16>(dst, p, nsrc, count, op, s);
-    case DT_F32: return reduce_n_op<float>(dst, p, nsrc, count, op, s);
-    case DT_F64: return reduce_n_op<double>(dst, p, nsrc, count, op, s);
-    case DT_BF16: return reduce_n_op<bf16_t>(dst, p, nsrc, count, op, s);
+    case DT_U8: return reduce_n_op<uint8_t>(dst, p, nsrc, count, op, s, es, ee);
+    case DT_I32: return reduce_n_op<int32_t>(dst, p, nsrc, count, op, s, es, ee);
+    case DT_I64: return reduce_n_op<int64_t>(dst, p, nsrc, count, op, s, es, ee);
+    case DT_F16: return reduce_n_op<_Float16>(dst, p, nsrc, count, op, s, es, ee);
+    case DT_F32: return reduce_n_op<float>(dst, p, nsrc, count, op, s, es, ee);
+    case DT_F64: return reduce_n_op<double>(dst, p, nsrc, count, op, s, es, ee);
+    case DT_BF16: return reduce_n_op<bf16_t>(dst, p, nsrc, count, op, s, es, ee);
     default: return hipErrorInvalidValue;
   }
 }
 
-hipError_t launch_copy(void* dst, const void* src, size_t bytes, hipStream_t s) {
-  if (bytes == 0 || dst == src) return hipSuccess;
+hipError_t launch_copy(void* dst, const void* src, size_t bytes, hipStream_t s, hipEvent_t es, hipEvent_t ee) {
+  if (bytes == 0 || dst == src) {  // nothing to launch: still honour the events
+    if (es) (void)hipEventRecord(es, s);
+    if (ee) (void)hipEventRecord(ee, s);
+    return hipSuccess;
+  }
   if (aligned16(dst) && aligned16(src)) {
     const size_t npack = bytes / 16;
     const int grid = grid_for(npack, (size_t)kBlock * kUnroll);
-    hipLaunchKernelGGL(copy16_kernel, dim3(grid), dim3(kBlock), 0, s, (pack_t*)dst, (const pack_t*)src,
-                       npack, bytes);
+    XMPI_LAUNCH(copy16_kernel, dim3(grid), dim3(kBlock), s, es, ee, (pack_t*)dst, (const pack_t*)src, npack, bytes);
   } else {
-    hipLaunchKernelGGL(copy1_kernel, dim3(grid_for(bytes, kBlock)), dim3(kBlock), 0, s, (uint8_t*)dst,
-                       (const uint8_t*)src, bytes);
+    XMPI_LAUNCH(copy1_kernel, dim3(grid_for(bytes, kBlock)), dim3(kBlock), s, es, ee, (uint8_t*)dst,
+                (const uint8_t*)src, bytes);
   }
   return hipGetLastError();
 }

@@ -50,6 +50,7 @@ SYMBOLS = [
     ("xmpi_sync", _I, [_P]),
     ("xmpi_send", _I, [_P, _P, _Z, _I, _I, _I]),
     ("xmpi_recv", _I, [_P, _P, _Z, _I, _I, _I, C.POINTER(_Z)]),
+    ("xmpi_probe", _I, [_P, _I, _I, C.POINTER(_Z), C.POINTER(_I)]),
     ("xmpi_bcast", _I, [_P, _P, _Z, _I, _I, _I]),
     ("xmpi_reduce", _I, [_P, _P, _P, _Z, _I, _I, _I, _I]),
     ("xmpi_allreduce", _I, [_P, _P, _P, _Z, _I, _I, _I]),
@@ -200,6 +201,12 @@ class Comm:
         got = _Z(0)
         _check(lib().xmpi_recv(self.handle, _ptr(buf), capacity, dtype, src, tag, C.byref(got)), "xmpi_recv")
         return got.value
+
+    def probe(self, src: int, tag: int):
+        """(count, dtype) of the message {src, tag} once it has been posted; does not consume it."""
+        n, dt = _Z(0), _I(0)
+        _check(lib().xmpi_probe(self.handle, src, tag, C.byref(n), C.byref(dt)), "xmpi_probe")
+        return n.value, dt.value
 
     # -- collectives ---------------------------------------------------------------------------
     def barrier(self) -> None:

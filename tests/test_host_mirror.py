@@ -1,0 +1,64 @@
+"""The C++ mirror of the reference's Go package (mpi_amd/host/mpi.hpp): host logic on the CPU, and the
+reference's two example programs on the GPU through the launcher."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "mpi_amd", "bin")
+
+
+def test_host_api_semantics(tmp_path):
+    exe = str(tmp_path / "host_api_check")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I",
+                           os.path.join(ROOT, "mpi_amd", "host"), os.path.join(ROOT, "tests", "host_api_check.cpp"),
+                           "-o", exe, "-L", os.path.join(ROOT, "mpi_amd"), "-lxmpi_host", "-lxmpi",
+                           "-Wl,-rpath," + os.path.join(ROOT, "mpi_amd"), "-lpthread"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
+
+
+def test_launcher_contract(tmp_path):
+    """xmpirun passes -mpi-addr / -mpi-alladdr exactly like gompirun.go:46-51,77 and propagates the
+    worst exit status (the reference drops it, gompirun.go:89)."""
+    script = tmp_path / "probe.sh"
+    script.write_text("#!/bin/sh\necho \"$@ dev=$XMPI_DEVICE job=$XMPI_JOB\"\ncase \"$*\" in *'-mpi-addr :6001'*) exit 3;; esac\nexit 0\n")
+    script.chmod(0o755)
+    r = subprocess.run([os.path.join(BIN, "xmpirun"), "3", str(script), "extra"], capture_output=True, text=True,
+                       timeout=60, env={**os.environ, "XMPI_NGPUS": "2"})
+    assert r.returncode == 3
+    lines = sorted(r.stdout.strip().split("\n"))
+    assert len(lines) == 3
+    for i, ln in enumerate(lines):
+        assert ln.startswith(f"extra -mpi-addr :600{i} -mpi-alladdr :6000,:6001,:6002 dev={i % 2} job=x")
+    assert len({ln.split("job=")[1] for ln in lines}) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 2, 4])
+def test_helloworld_program(n):
+    """BASELINE config 1: same text as examples/helloworld/helloworld.go:51,59-62,78"""
+    r = subprocess.run([os.path.join(BIN, "xmpirun"), str(n), os.path.join(BIN, "helloworld")], capture_output=True,
+                       text=True, timeout=300, env={**os.environ, "XMPI_BASEPORT": str(6100 + 10 * n)})
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().split("\n")
+    for rank in range(n):
+        assert f"Hello world, I'm node {rank} in a land with {n} nodes" in lines
+        for src in range(n):
+            msg = f"\"I'm just node {rank} talking to myself\"" if src == rank else f"\"Hello node {rank}, I'm node {src}\""
+            assert f"I, node {rank}, received a message: {msg}" in lines
+    assert len(lines) == n + n * n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [[], ["--host"]])
+def test_bounce_program(mode):
+    """BASELINE config 2 / examples/bounce/bounce.go: lossless echo at every message length"""
+    r = subprocess.run([os.path.join(BIN, "xmpirun"), "2", os.path.join(BIN, "bounce"), *mode], capture_output=True,
+                       text=True, timeout=600, env={**os.environ, "XMPI_BASEPORT": "6200"})
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Number of nodes =  2" in r.stdout
+    assert "Average byte trip time in µs between node 0 and 1: [" in r.stdout
+    assert "Average float64 trip time in µs between node 0 and 1: [" in r.stdout
+    assert "message not the same" not in r.stderr
