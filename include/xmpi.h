@@ -190,6 +190,11 @@ int xmpi_prof_get(xmpi_comm* comm, int kind, uint64_t* launches, double* total_m
 int xmpi_link_probe(xmpi_comm* comm, int peer, size_t bytes, int engine, int iters, int direction,
                     double* gbps);
 
+/* Host-only self-test of the control plane shared by the ranks of a job (no GPU call): every rank
+ * of `size` calls it with the same key; exercises join, barriers, pipe counters and the mail-entry
+ * states for `rounds` rounds.  Used by the CPU test-suite with plain OS processes. */
+int xmpi_ctl_selftest(const char* job_key, int rank, int size, int rounds);
+
 /* Schedule introspection (host logic only, no GPU needed): writes the step table the executor
  * would run for (coll, algo, size, rank, count) as text into out; returns needed length. */
 int xmpi_plan_dump(int coll, int algo, int size, int rank, int root, size_t count,

@@ -268,6 +268,8 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   c->piece_bytes = env_long("XMPI_PIECE_BYTES", 0);
   c->copy_engine = env_long("XMPI_COPY_ENGINE", 0);
   c->dep_mode = env_long("XMPI_DEP_MODE", 0) ? 1 : 0;
+  if (getenv("XMPI_KERNEL_MODE")) set_kernel_mode((int)env_long("XMPI_KERNEL_MODE", -1));
+  if (getenv("XMPI_GRID_CAP")) set_grid_cap((int)env_long("XMPI_GRID_CAP", 2048));
   c->coll_region_bytes = (size_t)size * c->lanes * c->fifo_depth * c->slot_bytes;
   c->window_bytes = c->coll_region_bytes + (size_t)size * kMailEntries * c->p2p_depth * c->p2p_slot_bytes;
 
@@ -641,6 +643,8 @@ int xmpi_set_param(xmpi_comm* c, const char* name, long value) {
   else if (n == "timeout_s") c->timeout_s = value;
   else if (n == "dep_mode") c->dep_mode = value ? 1 : 0;
   else if (n == "prof_every") c->prof_every = std::max<long>(1, value);
+  else if (n == "kernel_mode") set_kernel_mode((int)value);  // process-wide
+  else if (n == "grid_cap") set_grid_cap((int)value);        // process-wide
   else return XMPI_ERR_ARG;
   return XMPI_OK;
 }
@@ -654,6 +658,7 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
   if (n == "timeout_s") return c->timeout_s;
   if (n == "dep_mode") return c->dep_mode;
   if (n == "shared_stream") return c->shared_stream ? 1 : 0;
+  if (n == "kernel_mode") return get_kernel_mode();
   if (n == "lanes") return c->lanes;
   if (n == "fifo_depth") return c->fifo_depth;
   if (n == "slot_bytes") return (long)c->slot_bytes;
@@ -720,6 +725,68 @@ int xmpi_link_probe(xmpi_comm* c, int peer, size_t bytes, int engine, int iters,
   ev_put(c, b, true);
   *gbps = ms > 0 ? (double)bytes * iters / (ms * 1e-3) / 1e9 : 0.0;
   return XMPI_OK;
+}
+
+// Host-only exercise of the control plane (no HIP call): join, barriers, a token passed round the
+// ring through the pipe counters and a mail-entry handshake with the next rank.  Lets the N > 1
+// bootstrap / rendezvous logic be tested with plain OS processes on a machine without a GPU.
+int xmpi_ctl_selftest(const char* job_key, int rank, int size, int rounds) {
+  CtlConfig cfg{2, 8, 8u << 20, 2, 4u << 20};
+  std::string err;
+  Ctl* ctl = nullptr;
+  int rc = Ctl::join(job_key ? job_key : "selftest", rank, size, cfg, 30.0, &ctl, &err);
+  if (rc != XMPI_OK) {
+    set_last_error("ctl selftest: " + err);
+    return rc;
+  }
+  auto wait_for = [&](auto pred) {
+    const double t0 = now_seconds();
+    Backoff bo;
+    while (!pred()) {
+      if (ctl->aborted()) return XMPI_ERR_PEER;
+      if (now_seconds() - t0 > 30.0) return XMPI_ERR_TIMEOUT;
+      bo.pause();
+    }
+    return XMPI_OK;
+  };
+  const int next = (rank + 1) % size, prev = (rank + size - 1) % size;
+  for (int k = 1; k <= rounds && rc == XMPI_OK; k++) {
+    rc = ctl->barrier(30.0);
+    if (rc != XMPI_OK || size == 1) continue;
+    // token round the ring through the head counters
+    if (rank == 0) {
+      ctl->pipe(0, next, 0)->head.v.store((uint64_t)k, std::memory_order_release);
+      rc = wait_for([&] { return ctl->pipe(prev, 0, 0)->head.v.load(std::memory_order_acquire) == (uint64_t)k; });
+    } else {
+      rc = wait_for([&] { return ctl->pipe(prev, rank, 0)->head.v.load(std::memory_order_acquire) == (uint64_t)k; });
+      ctl->pipe(rank, next, 0)->head.v.store((uint64_t)k, std::memory_order_release);
+    }
+    if (rc != XMPI_OK) break;
+    // tagged rendezvous with the next rank (the states of a Send / Receive pair, without payload)
+    MailEntry* out = ctl->mail(rank, next, k % kMailEntries);
+    uint32_t expect = MAIL_FREE;
+    if (!out->state.compare_exchange_strong(expect, MAIL_CLAIMED)) {
+      rc = XMPI_ERR_STATE;
+      break;
+    }
+    out->tag = k;
+    out->bytes = (uint64_t)k * 10u + (uint64_t)rank;
+    out->state.store(MAIL_POSTED, std::memory_order_release);
+    MailEntry* in = ctl->mail(prev, rank, k % kMailEntries);
+    rc = wait_for([&] { return in->state.load(std::memory_order_acquire) == MAIL_POSTED && in->tag == k; });
+    if (rc != XMPI_OK) break;
+    if (in->bytes != (uint64_t)k * 10u + (uint64_t)prev) {
+      rc = XMPI_ERR_STATE;
+      break;
+    }
+    in->state.store(MAIL_DONE, std::memory_order_release);
+    rc = wait_for([&] { return out->state.load(std::memory_order_acquire) == MAIL_DONE; });
+    out->state.store(MAIL_FREE, std::memory_order_release);
+  }
+  if (rc != XMPI_OK) ctl->set_abort(rc);
+  else rc = ctl->barrier(30.0);
+  delete ctl;
+  return rc;
 }
 
 int xmpi_plan_dump(int coll, int algo, int size, int rank, int root, size_t count, size_t elem_size, int channels,

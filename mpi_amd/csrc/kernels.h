@@ -33,6 +33,12 @@ hipError_t launch_diff_stats(const void* a, const void* b, size_t count, int dty
                              hipStream_t stream);
 hipError_t launch_fill(void* buf, size_t count, int dtype, int pattern, uint64_t seed,
                        hipStream_t stream);
+// cache policy of the streaming kernels: -1 = chosen per launch by size, 0 plain, 1 nt loads+stores,
+// 2 nt loads only; grid cap in blocks (0 = one tile per block)
+void set_kernel_mode(int mode);
+int get_kernel_mode();
+void set_grid_cap(int cap);
+
 // one lane: system-scope release store of `value` to *flag (host-registered or device memory)
 hipError_t launch_signal(uint64_t* flag, uint64_t value, hipStream_t stream);
 

@@ -110,11 +110,28 @@ __device__ __forceinline__ pack_t combine16(pack_t a, pack_t b) {
   }
 }
 
+// ---- cache policy of the streaming accesses ----------------------------------------------------
+// MODE 0: plain loads and stores.  MODE 1: non-temporal loads and stores.  MODE 2: non-temporal
+// loads, plain stores.  Data that is touched once should not displace lines in L2 / the Infinity
+// Cache: measured on MI355X at 256 MiB operands (beyond the 256 MiB Infinity Cache) nt loads take
+// reduce2<f32> from 5.45 to 6.6-6.8 TB/s; which mode wins at a given size is a launch-time choice
+// (set_kernel_mode / XMPI_KERNEL_MODE), the arithmetic is identical in all three.
+template <int MODE>
+__device__ __forceinline__ pack_t ldp(const pack_t* p) {
+  if constexpr (MODE != 0) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <int MODE>
+__device__ __forceinline__ void stp(pack_t* p, pack_t v) {
+  if constexpr (MODE == 1) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
 // ---- dst = a op b  (the per-chunk reduction of every ring / halving step) --------------------
 // Lane l of block B touches packets  base + k*256 + l  (k < kUnroll): each wave instruction
 // covers one contiguous KiB; 2 x kUnroll loads are in flight before the first VALU op.
 
-template <typename T, int OP>
+template <typename T, int OP, int MODE>
 __global__ __launch_bounds__(kBlock) void reduce2_kernel(T* dst, const T* a, const T* b,
                                                          size_t npack, size_t count) {
   const pack_t* pa = reinterpret_cast<const pack_t*>(a);
@@ -131,11 +148,11 @@ __global__ __launch_bounds__(kBlock) void reduce2_kernel(T* dst, const T* a, con
       pack_t va[kUnroll], vb[kUnroll];
 #pragma unroll
       for (int k = 0; k < kUnroll; k++) {
-        va[k] = pa[first + k * 64];
-        vb[k] = pb[first + k * 64];
+        va[k] = ldp<MODE>(pa + first + k * 64);
+        vb[k] = ldp<MODE>(pb + first + k * 64);
       }
 #pragma unroll
-      for (int k = 0; k < kUnroll; k++) pd[first + k * 64] = combine16<T, OP>(va[k], vb[k]);
+      for (int k = 0; k < kUnroll; k++) stp<MODE>(pd + first + k * 64, combine16<T, OP>(va[k], vb[k]));
     } else {  // last, partial tile of the buffer
       for (int k = 0; k < kUnroll; k++) {
         const size_t i = first + k * 64;
@@ -167,7 +184,7 @@ struct SrcPtrs {
   const void* p[kMaxReduceSrcs];
 };
 
-template <typename T, int OP, int NSRC>
+template <typename T, int OP, int NSRC, int MODE>
 __global__ __launch_bounds__(kBlock) void reduce_n_kernel(T* dst, SrcPtrs srcs, int nsrc_rt,
                                                           size_t npack, size_t count) {
   const int nsrc = (NSRC > 0) ? NSRC : nsrc_rt;
@@ -177,11 +194,11 @@ __global__ __launch_bounds__(kBlock) void reduce_n_kernel(T* dst, SrcPtrs srcs, 
     if constexpr (NSRC > 0) {
       pack_t v[NSRC];
 #pragma unroll
-      for (int s = 0; s < NSRC; s++) v[s] = reinterpret_cast<const pack_t*>(srcs.p[s])[i];
+      for (int s = 0; s < NSRC; s++) v[s] = ldp<MODE>(reinterpret_cast<const pack_t*>(srcs.p[s]) + i);
       pack_t acc = v[0];
 #pragma unroll
       for (int s = 1; s < NSRC; s++) acc = combine16<T, OP>(acc, v[s]);
-      pd[i] = acc;
+      stp<MODE>(pd + i, acc);
     } else {
       pack_t acc = reinterpret_cast<const pack_t*>(srcs.p[0])[i];
       for (int s = 1; s < nsrc; s++)
@@ -201,6 +218,7 @@ __global__ __launch_bounds__(kBlock) void reduce_n_kernel(T* dst, SrcPtrs srcs, 
 
 // ---- streaming copy --------------------------------------------------------------------------
 
+template <int MODE>
 __global__ __launch_bounds__(kBlock) void copy16_kernel(pack_t* dst, const pack_t* src, size_t npack,
                                                         size_t bytes) {
   constexpr size_t kTile = (size_t)kBlock * kUnroll;
@@ -211,9 +229,9 @@ __global__ __launch_bounds__(kBlock) void copy16_kernel(pack_t* dst, const pack_
     if (base + kTile <= npack) {
       pack_t v[kUnroll];
 #pragma unroll
-      for (int k = 0; k < kUnroll; k++) v[k] = src[first + k * 64];
+      for (int k = 0; k < kUnroll; k++) v[k] = ldp<MODE>(src + first + k * 64);
 #pragma unroll
-      for (int k = 0; k < kUnroll; k++) dst[first + k * 64] = v[k];
+      for (int k = 0; k < kUnroll; k++) stp<MODE>(dst + first + k * 64, v[k]);
     } else {
       for (int k = 0; k < kUnroll; k++) {
         const size_t i = first + k * 64;
@@ -471,10 +489,21 @@ __global__ void signal_kernel(uint64_t* flag, uint64_t value) {
     else hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__);                      \
   } while (0)
 
+int g_kernel_mode = -1;   // -1 = by size, else forced 0 / 1 / 2
+int g_grid_cap = kMaxBlocks;  // 0 = one tile per block
+
+inline int kernel_mode_for(size_t traffic_bytes) {
+  if (g_kernel_mode >= 0) return g_kernel_mode;
+  // a launch whose traffic exceeds what the caches can hold streams through them: keep its loads
+  // from displacing anything (nt); small launches are served from L2 / Infinity Cache as they are
+  return traffic_bytes >= (size_t)(48u << 20) ? 2 : 0;
+}
+
 inline int grid_for(size_t work_items, size_t per_block) {
   size_t g = (work_items + per_block - 1) / per_block;
   if (g < 1) g = 1;
-  if (g > (size_t)kMaxBlocks) g = kMaxBlocks;
+  if (g_grid_cap > 0 && g > (size_t)g_grid_cap) g = (size_t)g_grid_cap;
+  if (g > 0x7fffffffu) g = 0x7fffffffu;
   return (int)g;
 }
 
@@ -488,8 +517,16 @@ hipError_t reduce2_typed(void* dst, const void* a, const void* b, size_t count, 
     constexpr size_t N = 16 / sizeof(T);
     const size_t npack = count / N;
     const int grid = grid_for(npack, (size_t)kBlock * kUnroll);
-    XMPI_LAUNCH((reduce2_kernel<T, OP>), dim3(grid), dim3(kBlock), s, es, ee, (T*)dst, (const T*)a, (const T*)b,
-                npack, count);
+    const int mode = kernel_mode_for(3 * count * sizeof(T));
+    if (mode == 1)
+      XMPI_LAUNCH((reduce2_kernel<T, OP, 1>), dim3(grid), dim3(kBlock), s, es, ee, (T*)dst, (const T*)a, (const T*)b,
+                  npack, count);
+    else if (mode == 2)
+      XMPI_LAUNCH((reduce2_kernel<T, OP, 2>), dim3(grid), dim3(kBlock), s, es, ee, (T*)dst, (const T*)a, (const T*)b,
+                  npack, count);
+    else
+      XMPI_LAUNCH((reduce2_kernel<T, OP, 0>), dim3(grid), dim3(kBlock), s, es, ee, (T*)dst, (const T*)a, (const T*)b,
+                  npack, count);
   } else {
     const int grid = grid_for(count, kBlock);
     XMPI_LAUNCH((reduce2_elem_kernel<T, OP>), dim3(grid), dim3(kBlock), s, es, ee, (T*)dst, (const T*)a,
@@ -516,15 +553,20 @@ hipError_t reduce_n_typed(void* dst, const SrcPtrs& srcs, int nsrc, size_t count
   constexpr size_t N = 16 / sizeof(T);
   const size_t npack = count / N;
   const int grid = grid_for(npack, kBlock);
-#define XMPI_RN(NS)                                                                                        \
-  case NS:                                                                                                 \
-    XMPI_LAUNCH((reduce_n_kernel<T, OP, NS>), dim3(grid), dim3(kBlock), s, es, ee, (T*)dst, srcs, nsrc, npack, \
-                count);                                                                                    \
+  const int mode = kernel_mode_for((size_t)(nsrc + 1) * count * sizeof(T));
+#define XMPI_RN(NS)                                                                                            \
+  case NS:                                                                                                     \
+    if (mode != 0)                                                                                             \
+      XMPI_LAUNCH((reduce_n_kernel<T, OP, NS, 2>), dim3(grid), dim3(kBlock), s, es, ee, (T*)dst, srcs, nsrc, npack, \
+                  count);                                                                                      \
+    else                                                                                                       \
+      XMPI_LAUNCH((reduce_n_kernel<T, OP, NS, 0>), dim3(grid), dim3(kBlock), s, es, ee, (T*)dst, srcs, nsrc, npack, \
+                  count);                                                                                      \
     break;
   switch (nsrc) {
     XMPI_RN(2) XMPI_RN(3) XMPI_RN(4) XMPI_RN(5) XMPI_RN(6) XMPI_RN(7) XMPI_RN(8)
     default:
-      XMPI_LAUNCH((reduce_n_kernel<T, OP, 0>), dim3(grid), dim3(kBlock), s, es, ee, (T*)dst, srcs, nsrc, npack,
+      XMPI_LAUNCH((reduce_n_kernel<T, OP, 0, 0>), dim3(grid), dim3(kBlock), s, es, ee, (T*)dst, srcs, nsrc, npack,
                   count);
       break;
   }
@@ -600,7 +642,13 @@ hipError_t launch_copy(void* dst, const void* src, size_t bytes, hipStream_t s, 
   if (aligned16(dst) && aligned16(src)) {
     const size_t npack = bytes / 16;
     const int grid = grid_for(npack, (size_t)kBlock * kUnroll);
-    XMPI_LAUNCH(copy16_kernel, dim3(grid), dim3(kBlock), s, es, ee, (pack_t*)dst, (const pack_t*)src, npack, bytes);
+    const int mode = kernel_mode_for(2 * bytes);
+    if (mode == 1)
+      XMPI_LAUNCH(copy16_kernel<1>, dim3(grid), dim3(kBlock), s, es, ee, (pack_t*)dst, (const pack_t*)src, npack, bytes);
+    else if (mode == 2)
+      XMPI_LAUNCH(copy16_kernel<2>, dim3(grid), dim3(kBlock), s, es, ee, (pack_t*)dst, (const pack_t*)src, npack, bytes);
+    else
+      XMPI_LAUNCH(copy16_kernel<0>, dim3(grid), dim3(kBlock), s, es, ee, (pack_t*)dst, (const pack_t*)src, npack, bytes);
   } else {
     XMPI_LAUNCH(copy1_kernel, dim3(grid_for(bytes, kBlock)), dim3(kBlock), s, es, ee, (uint8_t*)dst,
                 (const uint8_t*)src, bytes);
@@ -662,6 +710,10 @@ hipError_t launch_fill(void* buf, size_t count, int dtype, int pattern, uint64_t
                      dtype, pattern, seed);
   return hipGetLastError();
 }
+
+void set_kernel_mode(int mode) { g_kernel_mode = (mode < 0 || mode > 2) ? -1 : mode; }
+int get_kernel_mode() { return g_kernel_mode; }
+void set_grid_cap(int cap) { g_grid_cap = cap < 0 ? kMaxBlocks : cap; }
 
 hipError_t launch_signal(uint64_t* flag, uint64_t value, hipStream_t s) {
   hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(1), 0, s, flag, value);

@@ -448,7 +448,8 @@ int build_plan(const PlanParams& p, Plan* out) {
   int algo = p.algo;
   switch (p.coll) {
     case COLL_ALLREDUCE:
-      if (algo == XMPI_ALGO_AUTO) algo = XMPI_ALGO_RING;
+      // a full xGMI mesh: the one-hop schedule keeps all N-1 links busy and folds in rank order
+      if (algo == XMPI_ALGO_AUTO) algo = XMPI_ALGO_DIRECT;
       if (algo == XMPI_ALGO_RHD && !is_pow2(p.size)) algo = XMPI_ALGO_RING;
       if (p.size == 1) {
         b.local_copy(BUF_SEND, 0, BUF_RECV, 0, p.count);
@@ -463,7 +464,7 @@ int build_plan(const PlanParams& p, Plan* out) {
       }
       break;
     case COLL_ALLGATHER:
-      if (algo == XMPI_ALGO_AUTO) algo = XMPI_ALGO_RING;
+      if (algo == XMPI_ALGO_AUTO) algo = XMPI_ALGO_DIRECT;
       b.send_shift = (size_t)p.rank * p.count * p.elem_size;
       if (algo == XMPI_ALGO_RING) build_allgather_ring(b);
       else if (algo == XMPI_ALGO_DIRECT) build_allgather_direct(b);

@@ -68,6 +68,7 @@ SYMBOLS = [
     ("xmpi_prof_reset", _I, [_P]),
     ("xmpi_prof_get", _I, [_P, _I, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     ("xmpi_link_probe", _I, [_P, _I, _Z, _I, _I, _I, C.POINTER(C.c_double)]),
+    ("xmpi_ctl_selftest", _I, [C.c_char_p, _I, _I, _I]),
     ("xmpi_plan_dump", _I, [_I, _I, _I, _I, _I, _Z, _Z, _I, _Z, C.c_char_p, _Z]),
     ("xmpi_dtype_size", _Z, [_I]),
 ]
