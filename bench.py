@@ -87,6 +87,10 @@ class Job:
         if self.ranks // n >= 4:
             os.environ.setdefault("XMPI_SLOT_BYTES", str(32 << 20))
             os.environ.setdefault("XMPI_FIFO_DEPTH", "4")
+        if self.ranks // n == 1:
+            # one rank per GPU drives up to 7 peer links at once, each on its own stream: give the HIP
+            # runtime more hardware queues than its default of 4 so those streams do not serialise
+            os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         self.result = {}
         self.errors = []
         self.lock = threading.Lock()
@@ -197,23 +201,42 @@ def rank_main(job: Job, grank: int):
         best_ring = None
 
     # ---- warmup + parity of the chosen schedule against the oracle --------------------------------
-    for _ in range(max(1, a.warmup)):
-        run(algo)
-    parity = {"checked": False}
-    if dtype in (xmpi.F32, xmpi.F16) and count >= 1 << 16:
-        oks, worst = [], 0.0
-        for off in (0, (count // 3) // 8 * 8, count - 65536):
-            ok, err = check_window(comm, send, recv, count, dtype, seed0, off, 65536)
-            oks.append(ok)
-            worst = max(worst, err)
-        parity = {"checked": True, "ok": all(oks), "max_abs_err": worst,
-                  "rule": "bit-exact" if dtype == xmpi.F16 else "|delta| <= 1e-6 * sum_i|x_i| vs rank-order oracle"}
-        if not all(oks):
-            raise AssertionError(f"rank {grank}: allreduce result differs from the oracle: {parity}")
+    # Candidates in order of measured speed; the first whose result matches the oracle ON EVERY RANK is
+    # used (a schedule that is fast but wrong on this machine is reported, never timed).
+    by_name = {v: k for k, v in ALGO_NAME.items()}
+    order = sorted(tune, key=lambda x: x["ms"]) if tune else [best]
+    parity, parity_failures, chosen = {"checked": False}, [], None
+    for cand in order[:6]:
+        algo = by_name[cand["algo"]]
+        comm.set_param("channels", cand["channels"])
+        comm.set_param("copy_engine", cand["copy_engine"])
+        comm.set_param("piece_bytes", cand.get("piece_bytes", 0))
+        comm.memset(recv, 0, nbytes)
+        for _ in range(max(1, a.warmup)):
+            run(algo)
+        info = {"checked": False}
+        ok_here = True
+        if dtype in (xmpi.F32, xmpi.F16) and count >= 1 << 16:
+            oks, worst = [], 0.0
+            for off in (0, (count // 3) // 8 * 8, count - 65536):
+                ok, err = check_window(comm, send, recv, count, dtype, seed0, off, 65536)
+                oks.append(ok)
+                worst = max(worst, err)
+            ok_here = all(oks)
+            info = {"checked": True, "ok": ok_here, "max_abs_err": worst,
+                    "rule": "bit-exact" if dtype == xmpi.F16 else "|delta| <= 1e-6 * sum_i|x_i| vs rank-order oracle"}
+        if all_max(comm, 0.0 if ok_here else 1.0) == 0.0:
+            parity, chosen, best = info, cand, cand
+            break
+        parity_failures.append({"candidate": cand, "rank": grank, "local": info})
+    if chosen is None:
+        raise AssertionError(f"rank {grank}: no schedule reproduces the oracle: {parity_failures}")
 
     # ---- timed region: exactly K steps ----------------------------------------------------------------
     comm.prof_reset()
-    comm.set_param("prof_every", 1)  # every launch carries its own begin/end events (hipExtLaunchKernelGGL)
+    # every 4th launch of a kind carries its own begin/end events (hipExtLaunchKernelGGL): the events are
+    # exact per dispatch whatever runs around them, and sampling keeps their cost out of `value`
+    comm.set_param("prof_every", 4)
     t_step = timed(comm, lambda: run(algo), a.steps, prof=True)
     prof = {k: comm.prof_get(k) for k in (xmpi.PROF_REDUCE2, xmpi.PROF_REDUCEN, xmpi.PROF_COPY, xmpi.PROF_PEER)}
 
@@ -225,8 +248,10 @@ def rank_main(job: Job, grank: int):
         chunk = max(1, count // R)
         comm.prof_reset()
         comm.prof_enable(True)
-        for _ in range(20):
-            comm.reduce_local(recv, send, send.at(chunk * es), chunk, dtype, xmpi.SUM)
+        for j in range(24):  # walk the chunks: operands are cold, as they are inside the collective
+            k = j % R
+            comm.reduce_local(recv.at(k * chunk * es), send.at(k * chunk * es), send.at(((k + 1) % R) * chunk * es),
+                              chunk, dtype, xmpi.SUM)
         n_i, ms_i, by_i = comm.prof_get(xmpi.PROF_REDUCE2)
         comm.prof_enable(False)
         iso = {"kernel": "reduce2_kernel (one ring-step chunk, GPU otherwise idle)", "bytes_per_launch": by_i / n_i,
@@ -235,7 +260,7 @@ def rank_main(job: Job, grank: int):
     comm.barrier()
 
     out = {"t_step": t_step, "prof": prof, "tune": tune, "best": best, "best_ring": best_ring, "parity": parity,
-           "algo": algo, "nbytes": nbytes, "count": count, "iso": iso,
+           "algo": algo, "nbytes": nbytes, "count": count, "iso": iso, "parity_failures": parity_failures,
            "shared_stream": comm.get_param("shared_stream"), "slot_bytes": comm.get_param("slot_bytes")}
 
     # ---- untimed extras: what the next round needs to tune blind multi-GPU runs -----------------------
@@ -342,6 +367,7 @@ def cpu_baseline(ranks: int, count: int):
 
 def main():
     args = parse_args()
+    sys.setswitchinterval(1e-4)  # rank threads hand the GIL over quickly between their (GIL-free) C calls
     job = Job(args)
     threads = [threading.Thread(target=_guard, args=(job, g)) for g in job.my_ranks()]
     for t in threads:
@@ -391,7 +417,7 @@ def main():
         "algbw_GBps": algbw, "busbw_GBps": busbw,
         "xgmi": {"per_link_peak_GBps": XGMI_LINK_GBPS, "busbw_frac_of_link_peak": busbw / XGMI_LINK_GBPS,
                  "meaningful": args.gpus == R},
-        "roofline": roof, "roofline_isolated": r0["iso"], "parity": r0["parity"], "autotune": r0["tune"], "ring_best": r0["best_ring"],
+        "roofline": roof, "roofline_isolated": r0["iso"], "parity": r0["parity"], "parity_failures": r0["parity_failures"], "autotune": r0["tune"], "ring_best": r0["best_ring"],
         "extras": r0["extras"],
     }
     if args.gpus == 1 and not args.no_cpu and job.proc_rank == 0:
