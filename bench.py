@@ -310,6 +310,25 @@ def rank_main(job: Job, grank: int):
             t = timed(comm, lambda: comm.allgather(send, recv, cnt3, xmpi.I64, xmpi.ALGO_RING), 3)
             extras["allgather_i64"] = {"bytes_per_rank": cnt3 * 8, "ms": t * 1e3,
                                        "busbw_GBps": cnt3 * 8 * R / t / 1e9 * (R - 1) / R}
+        # BASELINE cfg 5: allreduce-sum fp16, 1 GiB per rank, ring vs recursive halving (exactly summable
+        # inputs k/64: both must be bit-identical to the rank-order result)
+        if dtype == xmpi.F32 and nbytes >= (256 << 20):
+            n5 = (1 << 30) // 2
+            s5, r5, ref5 = comm.alloc(n5 * 2), comm.alloc(n5 * 2), comm.alloc(n5 * 2)
+            comm.fill(s5, n5, xmpi.F16, xmpi.PAT_UNIFORM, 2000 + grank)
+            comm.allreduce(s5, ref5, n5, xmpi.F16, xmpi.SUM, xmpi.ALGO_DIRECT)
+            cfg5 = {"bytes_per_rank": n5 * 2}
+            for al in (xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_DIRECT):
+                if al == xmpi.ALGO_RHD and R & (R - 1):
+                    continue
+                comm.allreduce(s5, r5, n5, xmpi.F16, xmpi.SUM, al)
+                same = comm.count_mismatch(r5, ref5, n5 * 2) == 0
+                t = timed(comm, lambda: comm.allreduce(s5, r5, n5, xmpi.F16, xmpi.SUM, al), 2)
+                cfg5[ALGO_NAME[al]] = {"ms": t * 1e3, "algbw_GBps": n5 * 2 / t / 1e9,
+                                       "busbw_GBps": n5 * 2 / t / 1e9 * 2 * (R - 1) / R, "bit_identical_to_rank_order": same}
+            extras["cfg5_allreduce_f16_1GiB"] = cfg5
+            for b in (s5, r5, ref5):
+                b.free()
         # link probe between rank 0 and the first rank living on another GPU (xGMI), both engines
         dev0 = job.device_of(0)
         other = next((r for r in range(R) if (r * a.gpus // R if job.procs == 1 else r // job.ranks_per_proc) != 0), None)
@@ -394,12 +413,27 @@ def main():
         nc, msc, bc = r0["prof"][xmpi.PROF_COPY]
         kname, launches, ms, by = "copy16_kernel", nc, msc, bc
     achieved = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    # HBM traffic per launch comes from separate rocprofv3 --pmc passes (committed under profiles/); it is
+    # attached only when this run launched the same kernel on the same number of bytes
+    traffic, traffic_src = None, "PMC counters are collected in separate rocprofv3 passes (profiles/); none matches this launch size"
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        stem = kname.split("<")[0].split(" ")[0]
+        for row in pmc["rows"]:
+            if row["kernel"].startswith(stem) and launches and abs(row["traffic_bytes_per_launch"] / (by / launches) - 1) < 0.01:
+                traffic = row["traffic_bytes_per_launch"]
+                traffic_src = "profiles/pmc_traffic.json (" + row["kernel"] + ", " + row["schedule"] + "): " + pmc["source"]
+                break
+    except (OSError, ValueError, KeyError):
+        pass
     roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
             "launches": launches, "avg_launch_us": (ms * 1e3 / launches) if launches else None,
             "algorithmic_bytes_per_launch": (by / launches) if launches else None,
             "note": "live HIP events on the kernel's own stream inside the timed region (rank 0's launches); "
-                    "12 B per output element (2 reads + 1 write); traffic (PMC) not collected in this run"}
+                    "algorithmic bytes: 12 B per output element for reduce2 (2 reads + 1 write), (N+1) x 4 B for the "
+                    "N-way fold; every 4th launch of the kind carries events attached to its dispatch"}
     line = {
         "metric": "allreduce_sum_f32_256MiB aggregate algbw (ranks x S / t)" if (args.dtype == "f32" and args.size_mib == 256)
         else f"allreduce_sum_{args.dtype}_{args.size_mib:g}MiB aggregate algbw (ranks x S / t)",

@@ -268,6 +268,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   c->piece_bytes = env_long("XMPI_PIECE_BYTES", 0);
   c->copy_engine = env_long("XMPI_COPY_ENGINE", 0);
   c->dep_mode = env_long("XMPI_DEP_MODE", 0) ? 1 : 0;
+  c->batch_copies = env_long("XMPI_BATCH_COPIES", 1) ? 1 : 0;
   if (getenv("XMPI_KERNEL_MODE")) set_kernel_mode((int)env_long("XMPI_KERNEL_MODE", -1));
   if (getenv("XMPI_GRID_CAP")) set_grid_cap((int)env_long("XMPI_GRID_CAP", 2048));
   c->coll_region_bytes = (size_t)size * c->lanes * c->fifo_depth * c->slot_bytes;
@@ -350,8 +351,13 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
       return fail(XMPI_ERR_HIP);
     }
     for (int p = 0; p < size; p++) c->send_stream[p] = c->recv_stream[p] = (p == rank) ? nullptr : s;
-    c->local_stream = s;
+    c->local_stream = c->batch_send_stream = c->batch_recv_stream = s;
   } else {
+    if (hipStreamCreateWithFlags(&c->batch_send_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->batch_recv_stream, hipStreamNonBlocking) != hipSuccess) {
+      hip_fail(hipGetLastError(), "hipStreamCreate", __FILE__, __LINE__);
+      return fail(XMPI_ERR_HIP);
+    }
     for (int p = 0; p < size; p++) {
       if (p == rank) continue;
       if (hipStreamCreateWithFlags(&c->send_stream[p], hipStreamNonBlocking) != hipSuccess ||
@@ -392,6 +398,10 @@ int xmpi_finalize(xmpi_comm* c) {
     if (c->recv_stream[p]) (void)hipStreamDestroy(c->recv_stream[p]);
   }
   if (c->local_stream && !c->shared_stream) (void)hipStreamDestroy(c->local_stream);
+  if (!c->shared_stream) {
+    if (c->batch_send_stream) (void)hipStreamDestroy(c->batch_send_stream);
+    if (c->batch_recv_stream) (void)hipStreamDestroy(c->batch_recv_stream);
+  }
   for (hipStream_t s : c->p2p_streams) (void)hipStreamDestroy(s);
   for (hipEvent_t e : c->ev_free) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev_timed_free) (void)hipEventDestroy(e);
@@ -643,6 +653,7 @@ int xmpi_set_param(xmpi_comm* c, const char* name, long value) {
   else if (n == "timeout_s") c->timeout_s = value;
   else if (n == "dep_mode") c->dep_mode = value ? 1 : 0;
   else if (n == "prof_every") c->prof_every = std::max<long>(1, value);
+  else if (n == "batch_copies") c->batch_copies = value ? 1 : 0;
   else if (n == "kernel_mode") set_kernel_mode((int)value);  // process-wide
   else if (n == "grid_cap") set_grid_cap((int)value);        // process-wide
   else return XMPI_ERR_ARG;
@@ -659,6 +670,8 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
   if (n == "dep_mode") return c->dep_mode;
   if (n == "shared_stream") return c->shared_stream ? 1 : 0;
   if (n == "kernel_mode") return get_kernel_mode();
+  if (n == "last_run_us") return (long)c->last_run_us;
+  if (n == "last_sync_us") return (long)c->last_sync_us;
   if (n == "lanes") return c->lanes;
   if (n == "fifo_depth") return c->fifo_depth;
   if (n == "slot_bytes") return (long)c->slot_bytes;

@@ -61,6 +61,8 @@ struct xmpi_comm {
   hipStream_t send_stream[xmpi::kMaxRanks] = {nullptr};
   hipStream_t recv_stream[xmpi::kMaxRanks] = {nullptr};
   hipStream_t local_stream = nullptr;
+  hipStream_t batch_send_stream = nullptr, batch_recv_stream = nullptr;  // multi-destination copy launches
+  long batch_copies = 1;  // with the copy kernel: all ready SENDs (RECV_COPYs) go out in one launch
   bool shared_stream = false;  // all of the above alias one per-device stream (co-located ranks)
   bool peer_coloc[xmpi::kMaxRanks] = {false};  // peer is a thread of this process on this GPU
   long prof_every = 1;  // profile every k-th launch (events cost stream bubbles)
@@ -78,6 +80,7 @@ struct xmpi_comm {
   long piece_bytes = 0;  // 0 = choose per operation
   long copy_engine = 0;  // 0 = hipMemcpyAsync (SDMA / runtime blit), 1 = xmpi copy kernel
   long timeout_s = 60;
+  double last_run_us = 0, last_sync_us = 0;  // timing of the most recent collective (diagnostic)
   long dep_mode = 0;  // 0 = chain same-rank dependencies with stream events, 1 = wait on the host
 
   // scratch

@@ -67,6 +67,7 @@ struct InFlight {
   hipEvent_t start, stop;  // only for profiled launches: attached to the dispatch itself
   int prof_kind;
   size_t prof_bytes;
+  std::vector<int> more;   // further steps completed by the same launch (batched copies)
 };
 
 int peer_copy(xmpi_comm* c, void* dst, const void* src, size_t bytes, hipStream_t s, hipEvent_t es, hipEvent_t ee) {
@@ -97,6 +98,7 @@ struct Exec {
   std::vector<uint64_t> slot_seq;
   std::vector<std::deque<InFlight>> fl;  // per stream, completion is in issue order
   std::vector<std::deque<char>> unreleased;  // per (peer, lane): popped slots not yet released
+  std::vector<std::deque<char>> unpublished;  // per (peer, lane): pushed slots whose head is not yet out
   size_t remaining;
   double last_progress;
   bool eager_used = false;
@@ -116,8 +118,9 @@ struct Exec {
     stream_of.assign(n, -1);
     slot_ptr.assign(n, nullptr);
     slot_seq.assign(n, 0);
-    fl.resize((size_t)2 * N + 1);
+    fl.resize((size_t)2 * N + 3);
     unreleased.resize((size_t)N * L);
+    unpublished.resize((size_t)N * L);
     remaining = n;
     for (size_t i = 0; i < n; i++) {
       const Step& s = p.steps[i];
@@ -132,6 +135,8 @@ struct Exec {
   hipStream_t stream(int sid) const {
     if (sid < N) return c->send_stream[sid];
     if (sid < 2 * N) return c->recv_stream[sid - N];
+    if (sid == 2 * N + 1) return c->batch_send_stream;
+    if (sid == 2 * N + 2) return c->batch_recv_stream;
     return c->local_stream;
   }
 
@@ -173,12 +178,18 @@ struct Exec {
   // the counters are published at enqueue time and no event is recorded at all.
   int end_op(int i, int sid, InFlight* f, bool eager) {
     stream_of[(size_t)i] = sid;
+    for (int j : f->more) stream_of[(size_t)j] = sid;
     if (eager) {
       if (f->start) prof_pending.push_back(*f);
       eager_used = true;
       state[(size_t)i] = 2;
       remaining--;
       publish(plan.steps[(size_t)i], i);
+      for (int j : f->more) {
+        state[(size_t)j] = 2;
+        remaining--;
+        publish(plan.steps[(size_t)j], j);
+      }
       return XMPI_OK;
     }
     f->done = ev_get(c, false);
@@ -186,6 +197,10 @@ struct Exec {
     XMPI_HIP(hipEventRecord(f->done, stream(sid)));
     ev[(size_t)i] = f->done;
     state[(size_t)i] = 1;
+    for (int j : f->more) {
+      ev[(size_t)j] = f->done;
+      state[(size_t)j] = 1;
+    }
     fl[(size_t)sid].push_back(*f);
     return XMPI_OK;
   }
@@ -222,8 +237,16 @@ struct Exec {
   void publish(const Step& s, int step) {
     switch (s.kind) {
       case STEP_SEND: {
-        const uint64_t h = ++c->sent_done[s.peer][s.lane];
-        c->ctl->pipe(c->rank, s.peer, s.lane)->head.v.store(h, std::memory_order_release);
+        // pushes of one pipe may complete out of order (batched and single launches run on different
+        // streams): head only advances over a gap-free prefix of filled slots
+        std::deque<char>& u = unpublished[(size_t)s.peer * L + s.lane];
+        uint64_t& base = c->sent_done[s.peer][s.lane];
+        u[(size_t)(slot_seq[(size_t)step] - base)] = 1;
+        while (!u.empty() && u.front()) {
+          u.pop_front();
+          base++;
+        }
+        c->ctl->pipe(c->rank, s.peer, s.lane)->head.v.store(base, std::memory_order_release);
         break;
       }
       case STEP_RECV_REDUCE:
@@ -249,7 +272,95 @@ struct Exec {
     state[(size_t)f.step] = 2;
     remaining--;
     publish(plan.steps[(size_t)f.step], f.step);
+    for (int j : f.more) {
+      ev[(size_t)j] = nullptr;
+      state[(size_t)j] = 2;
+      remaining--;
+      publish(plan.steps[(size_t)j], j);
+    }
     return XMPI_OK;
+  }
+
+  // ---- batched copies: every SEND (or RECV_COPY) that is ready right now goes out in ONE launch ----
+  bool send_ready(int i) const {
+    const Step& s = plan.steps[(size_t)i];
+    if (!deps_issued(s) || s.bytes > c->slot_bytes) return false;
+    const uint64_t tail = c->ctl->pipe(c->rank, s.peer, s.lane)->tail.v.load(std::memory_order_acquire);
+    return c->sent[s.peer][s.lane] - tail < (uint64_t)c->fifo_depth;
+  }
+
+  bool recv_copy_ready(int i) const {
+    const Step& s = plan.steps[(size_t)i];
+    if (s.kind != STEP_RECV_COPY || !deps_issued(s)) return false;
+    return c->ctl->pipe(s.peer, c->rank, s.lane)->head.v.load(std::memory_order_acquire) > c->recvd[s.peer][s.lane];
+  }
+
+  int issue_batch(const std::vector<int>& steps, bool sends) {
+    void* dst[kMaxBatch];
+    const void* src[kMaxBatch];
+    size_t bytes[kMaxBatch];
+    const int n = (int)steps.size();
+    const int sid = sends ? 2 * N + 1 : 2 * N + 2;
+    size_t total = 0;
+    bool eager = c->shared_stream;
+    for (int k = 0; k < n; k++) {
+      const int i = steps[(size_t)k];
+      const Step& s = plan.steps[(size_t)i];
+      int rc = chain_deps(s, sid);
+      if (rc) return rc;
+      if (sends) {
+        const uint64_t seq = c->sent[s.peer][s.lane];
+        dst[k] = c->peer_window[s.peer] + c->coll_slot_off(c->rank, s.lane, seq);
+        src[k] = bufs[s.src_buf] + s.src_off;
+        c->sent[s.peer][s.lane] = seq + 1;
+        slot_seq[(size_t)i] = seq;
+        unpublished[(size_t)s.peer * L + s.lane].push_back(0);
+      } else {
+        const uint64_t seq = c->recvd[s.peer][s.lane];
+        char* slot = c->window + c->coll_slot_off(s.peer, s.lane, seq);
+        slot_ptr[(size_t)i] = slot;
+        slot_seq[(size_t)i] = seq;
+        c->recvd[s.peer][s.lane] = seq + 1;
+        unreleased[(size_t)s.peer * L + s.lane].push_back(0);
+        dst[k] = bufs[s.dst_buf] + s.dst_off;
+        src[k] = slot;
+      }
+      bytes[k] = s.bytes;
+      total += s.bytes;
+      if (!coloc(s.peer)) eager = false;
+    }
+    InFlight f;
+    SharedStreamLock lk(c);
+    int rc = begin_op(steps[0], &f, sends ? PROF_PEER : PROF_COPY, sends ? total : 2 * total);
+    if (rc) return rc;
+    for (int k = 1; k < n; k++) f.more.push_back(steps[(size_t)k]);
+    XMPI_HIP(launch_copy_batch(dst, src, bytes, n, stream(sid), f.start, f.stop));
+    return end_op(steps[0], sid, &f, eager);
+  }
+
+  // returns the number of steps issued (0 = nothing to batch), <0 on error
+  int try_batches() {
+    if (c->copy_engine != 1 || !c->batch_copies) return 0;
+    int issued = 0;
+    for (int pass = 0; pass < 2; pass++) {
+      const bool sends = pass == 0;
+      std::vector<std::deque<int>>& qs = sends ? sq : rq;
+      for (;;) {
+        std::vector<int> ready;
+        std::vector<std::deque<int>*> from;
+        for (auto& q : qs)
+          if (!q.empty() && (int)ready.size() < kMaxBatch && (sends ? send_ready(q.front()) : recv_copy_ready(q.front()))) {
+            ready.push_back(q.front());
+            from.push_back(&q);
+          }
+        if (ready.size() < 2) break;  // a single step takes the ordinary path
+        int rc = issue_batch(ready, sends);
+        if (rc) return rc;
+        for (auto* q : from) q->pop_front();
+        issued += (int)ready.size();
+      }
+    }
+    return issued;
   }
 
   // returns 1 if issued, 0 if not ready, <0 on error
@@ -271,6 +382,8 @@ struct Exec {
     rc = peer_copy(c, dst, bufs[s.src_buf] + s.src_off, s.bytes, stream(sid), f.start, f.stop);
     if (rc) return rc;
     c->sent[s.peer][s.lane] = seq + 1;
+    slot_seq[(size_t)i] = seq;
+    unpublished[(size_t)s.peer * L + s.lane].push_back(0);
     rc = end_op(i, sid, &f, coloc(s.peer));
     if (rc) return rc;
     return 1;
@@ -348,6 +461,11 @@ struct Exec {
     Backoff bo;
     while (remaining > 0) {
       bool progressed = false;
+      {
+        const int nb = try_batches();
+        if (nb < 0) return nb;
+        progressed = nb > 0;
+      }
       for (auto& q : sq)
         while (!q.empty()) {
           int r = try_send(q.front());
@@ -408,7 +526,9 @@ struct Exec {
       hipEvent_t fin = ev_get(c, false);
       if (!fin) return XMPI_ERR_HIP;
       XMPI_HIP(hipEventRecord(fin, c->local_stream));
+      const double ts = now_seconds();
       XMPI_HIP(hipEventSynchronize(fin));
+      c->last_sync_us = (now_seconds() - ts) * 1e6;
       ev_put(c, fin, false);
       for (const InFlight& f : prof_pending) {
         int rc = account(f);
@@ -431,8 +551,11 @@ int run_plan(xmpi_comm* c, const Plan& plan, const void* sendbuf, void* recvbuf,
     XMPI_HIP(hipMalloc(&c->temp, plan.temp_bytes));
     c->temp_bytes = plan.temp_bytes;
   }
+  const double t0 = now_seconds();
   Exec ex(c, plan, sendbuf, recvbuf, dtype, op);
+  c->last_sync_us = 0;
   int rc = ex.run();
+  c->last_run_us = (now_seconds() - t0) * 1e6;
   if (rc != XMPI_OK) {
     c->ctl->set_abort(rc);
     // leave no work behind that still references pooled events

@@ -22,6 +22,12 @@ hipError_t launch_reduce_n(void* dst, const void* const* srcs, int nsrc, size_t 
 hipError_t launch_copy(void* dst, const void* src, size_t bytes, hipStream_t stream,
                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
+// n <= kMaxBatch independent copies in one launch (a piece pushed to every peer / every peer's slot
+// drained at once); falls back to one launch per copy for odd alignments
+constexpr int kMaxBatch = 16;
+hipError_t launch_copy_batch(void* const* dst, const void* const* src, const size_t* bytes, int n,
+                             hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+
 // *d_out += number of differing bytes (d_out: 8-byte device word, caller zeroes it)
 hipError_t launch_count_mismatch(const void* a, const void* b, size_t bytes, uint64_t* d_out,
                                  hipStream_t stream);

@@ -246,6 +246,46 @@ __global__ __launch_bounds__(kBlock) void copy16_kernel(pack_t* dst, const pack_
   }
 }
 
+// Several independent copies in ONE launch: blockIdx.y picks the copy, blockIdx.x strides over its
+// tiles.  This is how a rank pushes a piece to all of its peers at once (each destination is a
+// different xGMI link, all driven from one grid) and how it drains the slots of all peers at once.
+struct CopyBatch {
+  void* dst[kMaxBatch];
+  const void* src[kMaxBatch];
+  size_t bytes[kMaxBatch];
+};
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void copy_batch_kernel(CopyBatch b) {
+  const int j = blockIdx.y;
+  pack_t* dst = reinterpret_cast<pack_t*>(b.dst[j]);
+  const pack_t* src = reinterpret_cast<const pack_t*>(b.src[j]);
+  const size_t bytes = b.bytes[j], npack = bytes / 16;
+  constexpr size_t kTile = (size_t)kBlock * kUnroll;
+  const size_t stride = (size_t)gridDim.x * kTile;
+  const size_t lane_off = (size_t)(threadIdx.x >> 6) * (64 * kUnroll) + (threadIdx.x & 63);
+  for (size_t base = (size_t)blockIdx.x * kTile; base < npack; base += stride) {
+    const size_t first = base + lane_off;
+    if (base + kTile <= npack) {
+      pack_t v[kUnroll];
+#pragma unroll
+      for (int k = 0; k < kUnroll; k++) v[k] = ldp<MODE>(src + first + k * 64);
+#pragma unroll
+      for (int k = 0; k < kUnroll; k++) stp<MODE>(dst + first + k * 64, v[k]);
+    } else {
+      for (int k = 0; k < kUnroll; k++) {
+        const size_t i = first + k * 64;
+        if (i < npack) dst[i] = src[i];
+      }
+    }
+  }
+  const size_t done = npack * 16;
+  if (blockIdx.x == 0 && done + threadIdx.x < bytes) {
+    const size_t i = done + threadIdx.x;
+    reinterpret_cast<uint8_t*>(dst)[i] = reinterpret_cast<const uint8_t*>(src)[i];
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void copy1_kernel(uint8_t* dst, const uint8_t* src, size_t bytes) {
   const size_t stride = (size_t)gridDim.x * kBlock;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < bytes; i += stride) dst[i] = src[i];
@@ -653,6 +693,42 @@ hipError_t launch_copy(void* dst, const void* src, size_t bytes, hipStream_t s, 
     XMPI_LAUNCH(copy1_kernel, dim3(grid_for(bytes, kBlock)), dim3(kBlock), s, es, ee, (uint8_t*)dst,
                 (const uint8_t*)src, bytes);
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_copy_batch(void* const* dst, const void* const* src, const size_t* bytes, int n, hipStream_t s,
+                             hipEvent_t es, hipEvent_t ee) {
+  if (n < 1 || n > kMaxBatch) return hipErrorInvalidValue;
+  CopyBatch b;
+  size_t maxb = 0, total = 0;
+  bool ok = true;
+  for (int i = 0; i < n; i++) {
+    b.dst[i] = dst[i];
+    b.src[i] = src[i];
+    b.bytes[i] = bytes[i];
+    maxb = bytes[i] > maxb ? bytes[i] : maxb;
+    total += bytes[i];
+    ok = ok && aligned16(dst[i]) && aligned16(src[i]);
+  }
+  if (!ok || n == 1) {  // odd alignment: one launch per copy, the events span the group
+    for (int i = 0; i < n; i++) {
+      hipError_t e = launch_copy(dst[i], src[i], bytes[i], s, i == 0 ? es : nullptr, i == n - 1 ? ee : nullptr);
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  }
+  if (maxb == 0) {
+    if (es) (void)hipEventRecord(es, s);
+    if (ee) (void)hipEventRecord(ee, s);
+    return hipSuccess;
+  }
+  int gx = grid_for(maxb / 16 + 1, (size_t)kBlock * kUnroll);
+  const int cap = g_grid_cap > 0 ? (g_grid_cap + n - 1) / n : 0;
+  if (cap > 0 && gx > cap) gx = cap;
+  const int mode = kernel_mode_for(2 * total);
+  if (mode == 1) XMPI_LAUNCH(copy_batch_kernel<1>, dim3(gx, n), dim3(kBlock), s, es, ee, b);
+  else if (mode == 2) XMPI_LAUNCH(copy_batch_kernel<2>, dim3(gx, n), dim3(kBlock), s, es, ee, b);
+  else XMPI_LAUNCH(copy_batch_kernel<0>, dim3(gx, n), dim3(kBlock), s, es, ee, b);
   return hipGetLastError();
 }
 

@@ -51,6 +51,8 @@ def run_threads(scenario: str, size: int, args: dict | None = None):
     def body(r):
         try:
             comm = xmpi.Comm(r, size, (args or {}).get("device", -1), key)
+            for k, v in (args or {}).get("params", {}).items():
+                comm.set_param(k, v)
             scenarios.SCENARIOS[scenario](comm, args or {})
             comm.barrier()
             comm.finalize()

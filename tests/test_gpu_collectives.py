@@ -29,6 +29,21 @@ def test_allreduce_tiny_slots():
               env={"XMPI_SLOT_BYTES": "65536", "XMPI_FIFO_DEPTH": "2", "XMPI_P2P_SLOT_BYTES": "8192"})
 
 
+@pytest.mark.parametrize("size", [2, 8])
+def test_copy_kernel_transport_and_batched_copies(size):
+    """peer pushes by the copy kernel; all ready pushes / slot drains of a rank go out in one launch"""
+    env = {"XMPI_COPY_ENGINE": "1", "XMPI_BATCH_COPIES": "1"}
+    run_ranks("allreduce_small", size, {"counts": [1, 4099, 65536 + 5], "dtypes": [4, 2, 3]}, timeout=600, env=env)
+    run_ranks("allgather", size, timeout=600, env=env)
+    run_ranks("bcast_reduce", size, timeout=600, env=env)
+    run_ranks("allreduce_medium", size, timeout=600, env={**env, "XMPI_SLOT_BYTES": "262144", "XMPI_FIFO_DEPTH": "3"})
+
+
+def test_copy_kernel_transport_threads():
+    run_threads("allreduce_small", 4, {"counts": [1, 4099, 300001], "dtypes": [4, 2], "params": {"copy_engine": 1}})
+    run_threads("allgather", 3, {"params": {"copy_engine": 1}})
+
+
 @pytest.mark.parametrize("size", [2, 4, 8])
 def test_allgather(size):
     run_ranks("allgather", size, timeout=600)
