@@ -434,6 +434,14 @@ def main():
             "note": "live HIP events on the kernel's own stream inside the timed region (rank 0's launches); "
                     "algorithmic bytes: 12 B per output element for reduce2 (2 reads + 1 write), (N+1) x 4 B for the "
                     "N-way fold; every 4th launch of the kind carries events attached to its dispatch"}
+    # the other kernels of the timed region (same per-dispatch events): slot drains and peer pushes
+    others = {}
+    for kind, label, factor in ((xmpi.PROF_COPY, "copy-out of receive slots (copy16 / copy_batch)", 1.0),
+                                (xmpi.PROF_PEER, "peer pushes (copy_batch / hipMemcpyAsync), payload bytes x2 = read + write", 2.0)):
+        n_k, ms_k, by_k = r0["prof"][kind]
+        if n_k and ms_k > 0:
+            others[label] = {"launches": n_k, "avg_launch_us": ms_k * 1e3 / n_k, "bytes_per_launch": factor * by_k / n_k,
+                             "GBps": factor * by_k / (ms_k * 1e-3) / 1e9, "frac_of_hbm_peak": factor * by_k / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBPS}
     line = {
         "metric": "allreduce_sum_f32_256MiB aggregate algbw (ranks x S / t)" if (args.dtype == "f32" and args.size_mib == 256)
         else f"allreduce_sum_{args.dtype}_{args.size_mib:g}MiB aggregate algbw (ranks x S / t)",
@@ -451,7 +459,7 @@ def main():
         "algbw_GBps": algbw, "busbw_GBps": busbw,
         "xgmi": {"per_link_peak_GBps": XGMI_LINK_GBPS, "busbw_frac_of_link_peak": busbw / XGMI_LINK_GBPS,
                  "meaningful": args.gpus == R},
-        "roofline": roof, "roofline_isolated": r0["iso"], "parity": r0["parity"], "parity_failures": r0["parity_failures"], "autotune": r0["tune"], "ring_best": r0["best_ring"],
+        "roofline": roof, "roofline_isolated": r0["iso"], "other_kernels": others, "parity": r0["parity"], "parity_failures": r0["parity_failures"], "autotune": r0["tune"], "ring_best": r0["best_ring"],
         "extras": r0["extras"],
     }
     if args.gpus == 1 and not args.no_cpu and job.proc_rank == 0:

@@ -270,7 +270,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   c->dep_mode = env_long("XMPI_DEP_MODE", 0) ? 1 : 0;
   c->batch_copies = env_long("XMPI_BATCH_COPIES", 1) ? 1 : 0;
   if (getenv("XMPI_KERNEL_MODE")) set_kernel_mode((int)env_long("XMPI_KERNEL_MODE", -1));
-  if (getenv("XMPI_GRID_CAP")) set_grid_cap((int)env_long("XMPI_GRID_CAP", 2048));
+  if (getenv("XMPI_GRID_CAP")) set_grid_cap((int)env_long("XMPI_GRID_CAP", 0));
   c->coll_region_bytes = (size_t)size * c->lanes * c->fifo_depth * c->slot_bytes;
   c->window_bytes = c->coll_region_bytes + (size_t)size * kMailEntries * c->p2p_depth * c->p2p_slot_bytes;
 

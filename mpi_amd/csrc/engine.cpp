@@ -681,7 +681,8 @@ int p2p_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, i
         char* dst = c->peer_window[dest] + c->p2p_slot_off(c->rank, entry, issued);
         hipError_t e;
         if (dev_src) {
-          e = hipMemcpyAsync(dst, (const char*)buf + off, n, hipMemcpyDeviceToDevice, lease.s);
+          e = c->copy_engine == 1 ? launch_copy(dst, (const char*)buf + off, n, lease.s)
+                                  : hipMemcpyAsync(dst, (const char*)buf + off, n, hipMemcpyDeviceToDevice, lease.s);
         } else {
           char* st = (char*)stage + (size_t)(issued % depth) * slot;
           e = hipMemcpyAsync(st, (const char*)buf + off, n, hipMemcpyHostToDevice, lease.s);
@@ -838,8 +839,10 @@ int p2p_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int 
     if (issued < npieces && m->pipe.head.v.load(std::memory_order_acquire) > issued) {
       const size_t off = (size_t)issued * slot, n = std::min(slot, bytes - off);
       const char* from = c->window + c->p2p_slot_off(src, entry, issued);
-      hipError_t e = hipMemcpyAsync((char*)buf + off, from, n, dev_dst ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
-                                    lease.s);
+      hipError_t e = (dev_dst && c->copy_engine == 1)
+                         ? launch_copy((char*)buf + off, from, n, lease.s)
+                         : hipMemcpyAsync((char*)buf + off, from, n,
+                                          dev_dst ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, lease.s);
       hipEvent_t ev = (e == hipSuccess) ? ev_get(c, false) : nullptr;
       if (e == hipSuccess && ev) e = hipEventRecord(ev, lease.s);
       if (e != hipSuccess || !ev) {

@@ -36,6 +36,7 @@ def test_copy_kernel_transport_and_batched_copies(size):
     run_ranks("allreduce_small", size, {"counts": [1, 4099, 65536 + 5], "dtypes": [4, 2, 3]}, timeout=600, env=env)
     run_ranks("allgather", size, timeout=600, env=env)
     run_ranks("bcast_reduce", size, timeout=600, env=env)
+    run_ranks("bounce", 2, timeout=600, env=env)
     run_ranks("allreduce_medium", size, timeout=600, env={**env, "XMPI_SLOT_BYTES": "262144", "XMPI_FIFO_DEPTH": "3"})
 
 
