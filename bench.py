@@ -58,7 +58,8 @@ def parse_args():
     ap.add_argument("--algo", default="auto", choices=["auto", "ring", "rhd", "direct"])
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed sweeps after the timed region")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU reference-path baseline")
-    ap.add_argument("--cpu-count", type=int, default=1 << 20, help="elements per rank of the CPU sample")
+    ap.add_argument("--cpu-count", type=int, default=16 << 20,
+                    help="float32 elements per rank of the CPU sample (64 MiB: ~10-30 CPU-seconds over 8 processes)")
     return ap.parse_args()
 
 
@@ -167,8 +168,8 @@ def rank_main(job: Job, grank: int):
     if a.algo == "auto":
         cands = []
         if R > 1:
-            maxch = max(1, comm.get_param("ring_channels_max"))
-            for ch in sorted({1, 2, min(4, maxch)}):
+            nch = max(1, comm.get_param("ring_channels"))  # N-2 edge-disjoint directed rings on an even mesh
+            for ch in sorted({k for k in (1, 2, 4, nch) if k <= nch}):
                 for eng in (0, 1):
                     cands.append((xmpi.ALGO_RING, ch, eng))
             for eng in (0, 1):
@@ -266,14 +267,26 @@ def rank_main(job: Job, grank: int):
     # ---- untimed extras: what the next round needs to tune blind multi-GPU runs -----------------------
     extras = {}
     if not a.no_extras and R > 1:
+        def apply(cand):
+            comm.set_param("channels", cand["channels"])
+            comm.set_param("copy_engine", cand["copy_engine"])
+            comm.set_param("piece_bytes", cand.get("piece_bytes", 0))
+
         extras["algos_at_size"] = {}
         for al in (xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_DIRECT):
             if al == xmpi.ALGO_RHD and R & (R - 1):
                 continue
+            mine = [x for x in tune if x["algo"] == ALGO_NAME[al]]
+            cand = min(mine, key=lambda x: x["ms"]) if mine else best
+            apply(cand)  # each algorithm with ITS best tuned settings
             run(al)
             t = timed(comm, lambda: run(al), 3)
             extras["algos_at_size"][ALGO_NAME[al]] = {"ms": t * 1e3, "algbw_GBps": nbytes / t / 1e9,
-                                                      "busbw_GBps": nbytes / t / 1e9 * 2 * (R - 1) / R}
+                                                      "busbw_GBps": nbytes / t / 1e9 * 2 * (R - 1) / R,
+                                                      "channels": cand["channels"], "copy_engine": cand["copy_engine"],
+                                                      "piece_bytes": cand.get("piece_bytes", 0)}
+        apply(best)
+        comm.set_param("piece_bytes", 0)  # the size sweep lets the library pick the piece size per message
         sweep = []
         sz = 1 << 10
         while sz <= min(nbytes, 1 << 30):

@@ -131,11 +131,11 @@ static int collective(xmpi_comm* c, int coll, int algo, int root, const void* se
   pp.root = root;
   pp.count = count;
   pp.elem_size = es;
-  pp.channels = (int)c->channels;
+  pp.channels = c->channels > 0 ? (int)c->channels : ring_channel_count(c->size);  // 0 = every link
   pp.lanes = c->lanes;
   const size_t total = count * es;
   size_t chunk = total;
-  if (coll == COLL_ALLREDUCE) chunk = total / (size_t)c->size / (size_t)std::max<long>(1, c->channels);
+  if (coll == COLL_ALLREDUCE) chunk = total / (size_t)c->size / (size_t)std::max(1, pp.channels);
   pp.piece_bytes = choose_piece(c, chunk);
   Plan plan;
   int rc = build_plan(pp, &plan);
@@ -264,7 +264,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   c->slot_bytes = g.slot_bytes;
   c->p2p_depth = g.p2p_depth;
   c->p2p_slot_bytes = g.p2p_slot_bytes;
-  c->channels = env_long("XMPI_CHANNELS", 4);
+  c->channels = env_long("XMPI_CHANNELS", 0);  // 0 = one ring channel per available link direction
   c->piece_bytes = env_long("XMPI_PIECE_BYTES", 0);
   c->copy_engine = env_long("XMPI_COPY_ENGINE", 0);
   c->dep_mode = env_long("XMPI_DEP_MODE", 0) ? 1 : 0;
@@ -647,7 +647,7 @@ int xmpi_set_param(xmpi_comm* c, const char* name, long value) {
   if (!c || c->finalized || !name) return XMPI_ERR_STATE;
   std::lock_guard<std::mutex> g(c->coll_mu);
   const std::string n = name;
-  if (n == "channels") c->channels = std::max<long>(1, value);
+  if (n == "channels") c->channels = std::max<long>(0, value);
   else if (n == "piece_bytes") c->piece_bytes = std::max<long>(0, value);
   else if (n == "copy_engine") c->copy_engine = value ? 1 : 0;
   else if (n == "timeout_s") c->timeout_s = value;
@@ -678,6 +678,7 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
   if (n == "p2p_slot_bytes") return (long)c->p2p_slot_bytes;
   if (n == "window_bytes") return (long)c->window_bytes;
   if (n == "ring_channels_max") return ring_channel_count(c->size) * c->lanes;
+  if (n == "ring_channels") return ring_channel_count(c->size);
   return -1;
 }
 

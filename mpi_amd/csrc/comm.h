@@ -76,7 +76,7 @@ struct xmpi_comm {
   uint64_t recvd_released[xmpi::kMaxRanks][xmpi::kMaxLanes] = {{0}};
 
   // tunables (xmpi_set_param)
-  long channels = 4;
+  long channels = 0;  // ring channels; 0 = all edge-disjoint directed rings of the mesh
   long piece_bytes = 0;  // 0 = choose per operation
   long copy_engine = 0;  // 0 = hipMemcpyAsync (SDMA / runtime blit), 1 = xmpi copy kernel
   long timeout_s = 60;

@@ -427,14 +427,41 @@ static std::vector<int> ring_strides(int size) {
   return strides;
 }
 
+// Even N >= 4: Walecki's decomposition of the complete graph K_N into N/2 - 1 edge-disjoint
+// Hamiltonian cycles (rank N-1 is the hub "infinity", the others are taken mod N-1):
+//     H_i = (N-1, i, i-1, i+1, i-2, i+2, ...),   i = 0 .. N/2 - 2
+// Each cycle is used in both directions, so N - 2 directed rings run at once and no two of them
+// share a link direction: at N = 8 that is 6 channels over 6 of the 7 xGMI links of every GPU
+// (the circulant strides 1, 7, 3, 5 reach only 4 channels over 2 links).  Odd N and N = 2 keep
+// the circulant strides coprime to N.
+static bool use_walecki(int size) { return size >= 4 && size % 2 == 0; }
+
 void ring_order(int size, int channel, std::vector<int>* order) {
+  order->resize((size_t)size);
+  if (use_walecki(size)) {
+    const int ncyc = size / 2 - 1, m = size - 1;
+    const int ch = channel % (2 * ncyc), i = ch / 2;
+    std::vector<int> seq;
+    seq.push_back(size - 1);
+    seq.push_back(i % m);
+    for (int k = 1; k < size / 2; k++) {
+      seq.push_back(((i - k) % m + m) % m);
+      seq.push_back((i + k) % m);
+    }
+    seq.resize((size_t)size);
+    if (ch % 2) std::reverse(seq.begin(), seq.end());  // the same links, the other direction
+    *order = seq;
+    return;
+  }
   const std::vector<int> strides = ring_strides(size);
   const int d = strides[(size_t)channel % strides.size()];
-  order->resize((size_t)size);
   for (int i = 0; i < size; i++) (*order)[(size_t)i] = (int)(((long)i * d) % size);
 }
 
-int ring_channel_count(int size) { return (int)ring_strides(size).size(); }
+int ring_channel_count(int size) {
+  if (use_walecki(size)) return size - 2;
+  return (int)ring_strides(size).size();
+}
 
 int build_plan(const PlanParams& p, Plan* out) {
   out->steps.clear();

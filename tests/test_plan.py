@@ -143,10 +143,27 @@ def test_headline_plan_shape():
     assert max(s.nbytes for s in plan.steps) <= 2 << 20
 
 
-def test_ring_channels_use_distinct_links():
-    """Channel strides 1, 7, 3, 5 of an 8-rank mesh: 4 different out-neighbours per rank."""
-    for r in range(8):
-        text = xmpi.plan_text(xmpi.COLL_ALLREDUCE, xmpi.ALGO_RING, 8, r, 0, 1 << 22, 4, 4, 1 << 16)
+@pytest.mark.parametrize("n", [4, 6, 8, 16])
+def test_ring_channels_use_distinct_links(n):
+    """Even N: the N-2 ring channels are the two directions of N/2-1 edge-disjoint Hamiltonian cycles
+    (Walecki): every rank sends to N-2 different peers and no directed link carries two channels."""
+    links = {}
+    for r in range(n):
+        text = xmpi.plan_text(xmpi.COLL_ALLREDUCE, xmpi.ALGO_RING, n, r, 0, n << 20, 4, n - 2, 1 << 16)
         plan = plan_sim.parse_plan(text)
+        assert plan.channels == n - 2
         nxt = {s.peer for s in plan.steps if s.kind == 0}
-        assert nxt == {(r + d) % 8 for d in (1, 7, 3, 5)}
+        prv = {s.peer for s in plan.steps if s.kind in (1, 2)}
+        assert len(nxt) == n - 2 and len(prv) == n - 2 and r not in nxt
+        for peer in nxt:
+            links[(r, peer)] = links.get((r, peer), 0) + 1
+    assert len(links) == n * (n - 2) and set(links.values()) == {1}
+    # both directions of every used link are used (bidirectional xGMI links fully loaded)
+    assert all((b, a) in links for (a, b) in links)
+
+
+def test_ring_channels_odd_world():
+    for r in range(5):
+        text = xmpi.plan_text(xmpi.COLL_ALLREDUCE, xmpi.ALGO_RING, 5, r, 0, 5 << 20, 4, 4, 1 << 16)
+        nxt = {s.peer for s in plan_sim.parse_plan(text).steps if s.kind == 0}
+        assert nxt == {(r + d) % 5 for d in (1, 2, 3, 4)}
