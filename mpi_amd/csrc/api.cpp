@@ -51,8 +51,14 @@ static int use_device(const xmpi_comm* c) {
 
 static size_t choose_piece(const xmpi_comm* c, size_t bytes_per_rank_chunk) {
   if (c->piece_bytes > 0) return std::min<size_t>((size_t)c->piece_bytes, c->slot_bytes);
-  // ~4 pieces per chunk so a chunk's transfer overlaps its reduction, within [64 KiB, slot]
-  size_t p = 64u << 10;
+  // ranks sharing one in-order stream have nothing to overlap: one launch per chunk
+  bool all_coloc = c->shared_stream;
+  for (int p = 0; p < c->size && all_coloc; p++)
+    if (p != c->rank && !c->peer_coloc[p]) all_coloc = false;
+  if (all_coloc) return c->slot_bytes;
+  // ~4 pieces per chunk so a chunk's transfer overlaps its reduction, but never below 1 MiB (a piece
+  // costs a launch and an event: ~10 us, i.e. ~0.5 MiB of link time), within [1 MiB, slot]
+  size_t p = 1u << 20;
   while (p * 4 < bytes_per_rank_chunk && p < c->slot_bytes) p <<= 1;
   return std::min(p, c->slot_bytes);
 }

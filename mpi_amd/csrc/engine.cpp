@@ -295,12 +295,21 @@ struct Exec {
     return c->ctl->pipe(s.peer, c->rank, s.lane)->head.v.load(std::memory_order_acquire) > c->recvd[s.peer][s.lane];
   }
 
-  int issue_batch(const std::vector<int>& steps, bool sends) {
+  bool recv_reduce_ready(int i) const {
+    const Step& s = plan.steps[(size_t)i];
+    if (s.kind != STEP_RECV_REDUCE || !deps_issued(s)) return false;
+    return c->ctl->pipe(s.peer, c->rank, s.lane)->head.v.load(std::memory_order_acquire) > c->recvd[s.peer][s.lane];
+  }
+
+  enum BatchKind { BATCH_SEND = 0, BATCH_RECV_COPY = 1, BATCH_RECV_REDUCE = 2 };
+
+  int issue_batch(const std::vector<int>& steps, int kind) {
     void* dst[kMaxBatch];
     const void* src[kMaxBatch];
-    size_t bytes[kMaxBatch];
+    const void* opa[kMaxBatch];
+    size_t bytes[kMaxBatch], counts[kMaxBatch];
     const int n = (int)steps.size();
-    const int sid = sends ? 2 * N + 1 : 2 * N + 2;
+    const int sid = kind == BATCH_SEND ? 2 * N + 1 : 2 * N + 2;
     size_t total = 0;
     bool eager = c->shared_stream;
     for (int k = 0; k < n; k++) {
@@ -308,7 +317,7 @@ struct Exec {
       const Step& s = plan.steps[(size_t)i];
       int rc = chain_deps(s, sid);
       if (rc) return rc;
-      if (sends) {
+      if (kind == BATCH_SEND) {
         const uint64_t seq = c->sent[s.peer][s.lane];
         dst[k] = c->peer_window[s.peer] + c->coll_slot_off(c->rank, s.lane, seq);
         src[k] = bufs[s.src_buf] + s.src_off;
@@ -324,37 +333,50 @@ struct Exec {
         unreleased[(size_t)s.peer * L + s.lane].push_back(0);
         dst[k] = bufs[s.dst_buf] + s.dst_off;
         src[k] = slot;
+        opa[k] = bufs[s.src_buf] + s.src_off;  // RECV_REDUCE: the local operand
       }
       bytes[k] = s.bytes;
+      counts[k] = s.bytes / es;
       total += s.bytes;
       if (!coloc(s.peer)) eager = false;
     }
     InFlight f;
     SharedStreamLock lk(c);
-    int rc = begin_op(steps[0], &f, sends ? PROF_PEER : PROF_COPY, sends ? total : 2 * total);
+    const int pk = kind == BATCH_SEND ? PROF_PEER : (kind == BATCH_RECV_COPY ? PROF_COPY : PROF_REDUCE2);
+    const size_t pb = kind == BATCH_SEND ? total : (kind == BATCH_RECV_COPY ? 2 * total : 3 * total);
+    int rc = begin_op(steps[0], &f, pk, pb);
     if (rc) return rc;
     for (int k = 1; k < n; k++) f.more.push_back(steps[(size_t)k]);
-    XMPI_HIP(launch_copy_batch(dst, src, bytes, n, stream(sid), f.start, f.stop));
+    if (kind == BATCH_RECV_REDUCE)
+      XMPI_HIP(launch_reduce2_batch(dst, opa, src, counts, n, dtype, op, stream(sid), f.start, f.stop));
+    else
+      XMPI_HIP(launch_copy_batch(dst, src, bytes, n, stream(sid), f.start, f.stop));
     return end_op(steps[0], sid, &f, eager);
   }
 
-  // returns the number of steps issued (0 = nothing to batch), <0 on error
+  // Everything of one kind that is ready right now goes out in ONE launch (all peers of a full-mesh
+  // step, all channels of a ring step).  Returns the number of steps issued, <0 on error.
   int try_batches() {
-    if (c->copy_engine != 1 || !c->batch_copies) return 0;
+    if (!c->batch_copies) return 0;
     int issued = 0;
-    for (int pass = 0; pass < 2; pass++) {
-      const bool sends = pass == 0;
-      std::vector<std::deque<int>>& qs = sends ? sq : rq;
+    for (int kind = 0; kind < 3; kind++) {
+      if (kind != BATCH_RECV_REDUCE && c->copy_engine != 1) continue;  // copies batch only as kernels
+      std::vector<std::deque<int>>& qs = kind == BATCH_SEND ? sq : rq;
       for (;;) {
         std::vector<int> ready;
         std::vector<std::deque<int>*> from;
-        for (auto& q : qs)
-          if (!q.empty() && (int)ready.size() < kMaxBatch && (sends ? send_ready(q.front()) : recv_copy_ready(q.front()))) {
-            ready.push_back(q.front());
+        for (auto& q : qs) {
+          if (q.empty() || (int)ready.size() >= kMaxBatch) continue;
+          const int i = q.front();
+          const bool ok = kind == BATCH_SEND ? send_ready(i)
+                                             : (kind == BATCH_RECV_COPY ? recv_copy_ready(i) : recv_reduce_ready(i));
+          if (ok) {
+            ready.push_back(i);
             from.push_back(&q);
           }
+        }
         if (ready.size() < 2) break;  // a single step takes the ordinary path
-        int rc = issue_batch(ready, sends);
+        int rc = issue_batch(ready, kind);
         if (rc) return rc;
         for (auto* q : from) q->pop_front();
         issued += (int)ready.size();

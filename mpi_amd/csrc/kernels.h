@@ -28,6 +28,11 @@ constexpr int kMaxBatch = 16;
 hipError_t launch_copy_batch(void* const* dst, const void* const* src, const size_t* bytes, int n,
                              hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
+// n <= kMaxBatch independent dst = a op b reductions in one launch (the ring channels of one step)
+hipError_t launch_reduce2_batch(void* const* dst, const void* const* a, const void* const* b,
+                                const size_t* counts, int n, int dtype, int op, hipStream_t stream,
+                                hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+
 // *d_out += number of differing bytes (d_out: 8-byte device word, caller zeroes it)
 hipError_t launch_count_mismatch(const void* a, const void* b, size_t bytes, uint64_t* d_out,
                                  hipStream_t stream);

@@ -169,6 +169,54 @@ __global__ __launch_bounds__(kBlock) void reduce2_kernel(T* dst, const T* a, con
   }
 }
 
+// Several independent reductions in ONE launch (the ring channels of one step): blockIdx.y picks the
+// segment.  Same tile body as reduce2_kernel.
+struct Reduce2Batch {
+  void* dst[kMaxBatch];
+  const void* a[kMaxBatch];
+  const void* b[kMaxBatch];
+  size_t count[kMaxBatch];
+};
+
+template <typename T, int OP, int MODE>
+__global__ __launch_bounds__(kBlock) void reduce2_batch_kernel(Reduce2Batch q) {
+  const int j = blockIdx.y;
+  T* dst = reinterpret_cast<T*>(q.dst[j]);
+  const T* a = reinterpret_cast<const T*>(q.a[j]);
+  const T* b = reinterpret_cast<const T*>(q.b[j]);
+  constexpr size_t N = 16 / sizeof(T);
+  const size_t count = q.count[j], npack = count / N;
+  const pack_t* pa = reinterpret_cast<const pack_t*>(a);
+  const pack_t* pb = reinterpret_cast<const pack_t*>(b);
+  pack_t* pd = reinterpret_cast<pack_t*>(dst);
+  constexpr size_t kTile = (size_t)kBlock * kUnroll;
+  const size_t stride = (size_t)gridDim.x * kTile;
+  const size_t lane_off = (size_t)(threadIdx.x >> 6) * (64 * kUnroll) + (threadIdx.x & 63);
+  for (size_t base = (size_t)blockIdx.x * kTile; base < npack; base += stride) {
+    const size_t first = base + lane_off;
+    if (base + kTile <= npack) {
+      pack_t va[kUnroll], vb[kUnroll];
+#pragma unroll
+      for (int k = 0; k < kUnroll; k++) {
+        va[k] = ldp<MODE>(pa + first + k * 64);
+        vb[k] = ldp<MODE>(pb + first + k * 64);
+      }
+#pragma unroll
+      for (int k = 0; k < kUnroll; k++) stp<MODE>(pd + first + k * 64, combine16<T, OP>(va[k], vb[k]));
+    } else {
+      for (int k = 0; k < kUnroll; k++) {
+        const size_t i = first + k * 64;
+        if (i < npack) pd[i] = combine16<T, OP>(pa[i], pb[i]);
+      }
+    }
+  }
+  const size_t done = npack * N;
+  if (blockIdx.x == 0 && done + threadIdx.x < count) {
+    const size_t i = done + threadIdx.x;
+    dst[i] = combine_any<T, OP>(a[i], b[i]);
+  }
+}
+
 // any alignment: one element per lane per iteration (correctness path for odd offsets)
 template <typename T, int OP>
 __global__ __launch_bounds__(kBlock) void reduce2_elem_kernel(T* dst, const T* a, const T* b,
@@ -696,6 +744,73 @@ hipError_t launch_copy(void* dst, const void* src, size_t bytes, hipStream_t s, 
                 (const uint8_t*)src, bytes);
   }
   return hipGetLastError();
+}
+
+namespace {
+template <typename T, int OP>
+hipError_t reduce2_batch_typed(const Reduce2Batch& q, int n, size_t maxcount, size_t total, hipStream_t s,
+                               hipEvent_t es, hipEvent_t ee) {
+  constexpr size_t N = 16 / sizeof(T);
+  int gx = grid_for(maxcount / N + 1, (size_t)kBlock * kUnroll);
+  const int cap = g_grid_cap > 0 ? (g_grid_cap + n - 1) / n : 0;
+  if (cap > 0 && gx > cap) gx = cap;
+  const int mode = kernel_mode_for(3 * total * sizeof(T));
+  if (mode == 1) XMPI_LAUNCH((reduce2_batch_kernel<T, OP, 1>), dim3(gx, n), dim3(kBlock), s, es, ee, q);
+  else if (mode == 2) XMPI_LAUNCH((reduce2_batch_kernel<T, OP, 2>), dim3(gx, n), dim3(kBlock), s, es, ee, q);
+  else XMPI_LAUNCH((reduce2_batch_kernel<T, OP, 0>), dim3(gx, n), dim3(kBlock), s, es, ee, q);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t reduce2_batch_op(const Reduce2Batch& q, int n, size_t maxcount, size_t total, int op, hipStream_t s,
+                            hipEvent_t es, hipEvent_t ee) {
+  switch (op) {
+    case OP_SUM: return reduce2_batch_typed<T, OP_SUM>(q, n, maxcount, total, s, es, ee);
+    case OP_PROD: return reduce2_batch_typed<T, OP_PROD>(q, n, maxcount, total, s, es, ee);
+    case OP_MIN: return reduce2_batch_typed<T, OP_MIN>(q, n, maxcount, total, s, es, ee);
+    case OP_MAX: return reduce2_batch_typed<T, OP_MAX>(q, n, maxcount, total, s, es, ee);
+    default: return hipErrorInvalidValue;
+  }
+}
+}  // namespace
+
+hipError_t launch_reduce2_batch(void* const* dst, const void* const* a, const void* const* b, const size_t* counts,
+                                int n, int dtype, int op, hipStream_t s, hipEvent_t es, hipEvent_t ee) {
+  if (n < 1 || n > kMaxBatch) return hipErrorInvalidValue;
+  Reduce2Batch q;
+  size_t maxc = 0, total = 0;
+  bool ok = true;
+  for (int i = 0; i < n; i++) {
+    q.dst[i] = dst[i];
+    q.a[i] = a[i];
+    q.b[i] = b[i];
+    q.count[i] = counts[i];
+    maxc = counts[i] > maxc ? counts[i] : maxc;
+    total += counts[i];
+    ok = ok && aligned16(dst[i]) && aligned16(a[i]) && aligned16(b[i]);
+  }
+  if (!ok || n == 1 || maxc == 0) {
+    for (int i = 0; i < n; i++) {
+      hipError_t e = launch_reduce2(dst[i], a[i], b[i], counts[i], dtype, op, s, i == 0 ? es : nullptr,
+                                    i == n - 1 ? ee : nullptr);
+      if (e != hipSuccess) return e;
+    }
+    if (maxc == 0) {  // nothing launched: still honour the events
+      if (es) (void)hipEventRecord(es, s);
+      if (ee) (void)hipEventRecord(ee, s);
+    }
+    return hipSuccess;
+  }
+  switch (dtype) {
+    case DT_U8: return reduce2_batch_op<uint8_t>(q, n, maxc, total, op, s, es, ee);
+    case DT_I32: return reduce2_batch_op<int32_t>(q, n, maxc, total, op, s, es, ee);
+    case DT_I64: return reduce2_batch_op<int64_t>(q, n, maxc, total, op, s, es, ee);
+    case DT_F16: return reduce2_batch_op<_Float16>(q, n, maxc, total, op, s, es, ee);
+    case DT_F32: return reduce2_batch_op<float>(q, n, maxc, total, op, s, es, ee);
+    case DT_F64: return reduce2_batch_op<double>(q, n, maxc, total, op, s, es, ee);
+    case DT_BF16: return reduce2_batch_op<bf16_t>(q, n, maxc, total, op, s, es, ee);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 hipError_t launch_copy_batch(void* const* dst, const void* const* src, const size_t* bytes, int n, hipStream_t s,
