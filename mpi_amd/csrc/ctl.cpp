@@ -1,6 +1,7 @@
 // ctl.cpp -- shared-memory control block (see ctl.h).  Host logic only, no HIP.
 #include "ctl.h"
 
+#include <dirent.h>
 #include <fcntl.h>
 #include <sched.h>
 #include <signal.h>
@@ -13,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "../../include/xmpi.h"
 
@@ -78,6 +80,31 @@ static std::string shm_name(const std::string& key) {
   return n;
 }
 
+// Control blocks of jobs that died without finalising (kill -9, a crash) would otherwise pile up in
+// /dev/shm: rank 0 of a new job removes every block of this user whose creator process is gone.
+static void reap_dead_blocks() {
+  const std::string prefix = "xmpi-" + std::to_string((unsigned)getuid()) + "-";
+  DIR* d = opendir("/dev/shm");
+  if (!d) return;
+  std::vector<std::string> dead;
+  while (dirent* ent = readdir(d)) {
+    const std::string fn = ent->d_name;
+    if (fn.compare(0, prefix.size(), prefix) != 0) continue;
+    const std::string path = "/dev/shm/" + fn;
+    int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) continue;
+    CtlHeader h;
+    const ssize_t got = pread(fd, &h, sizeof h, 0);
+    close(fd);
+    if (got != (ssize_t)sizeof h || h.magic.load(std::memory_order_relaxed) != kCtlMagic) continue;
+    const int cp = h.creator_pid;
+    const bool alive = (kill(cp, 0) == 0 || errno == EPERM) && proc_start_time(cp) == h.creator_start;
+    if (!alive) dead.push_back("/" + fn);
+  }
+  closedir(d);
+  for (const std::string& n : dead) shm_unlink(n.c_str());
+}
+
 int Ctl::join(const std::string& key, int rank, int size, const CtlConfig& cfg, double timeout_s, Ctl** out,
               std::string* err) {
   if (size < 1 || size > kMaxRanks || rank < 0 || rank >= size) {
@@ -91,6 +118,7 @@ int Ctl::join(const std::string& key, int rank, int size, const CtlConfig& cfg, 
   bool creator = false;
 
   if (rank == 0) {
+    reap_dead_blocks();
     shm_unlink(name.c_str());  // a stale block of a crashed job with the same key
     int fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
     if (fd < 0) {
