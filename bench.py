@@ -419,7 +419,8 @@ def main():
     n2, ms2, b2 = r0["prof"][xmpi.PROF_REDUCE2]
     nn, msn, bn = r0["prof"][xmpi.PROF_REDUCEN]
     if ms2 >= msn and n2:
-        kname, launches, ms, by = "reduce2_kernel<float,SUM> (dst = a + slot)", n2, ms2, b2
+        kname, launches, ms, by = ("reduce2_batch_kernel<float,SUM> (fused ring step: a + slot -> next rank's slot [+ local]) / "
+                                   "reduce2_kernel<float,SUM>"), n2, ms2, b2
     elif nn:
         kname, launches, ms, by = "reduce_n_kernel<float,SUM,N> (rank-order fold)", nn, msn, bn
     else:

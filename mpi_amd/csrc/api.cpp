@@ -143,6 +143,8 @@ static int collective(xmpi_comm* c, int coll, int algo, int root, const void* se
   size_t chunk = total;
   if (coll == COLL_ALLREDUCE) chunk = total / (size_t)c->size / (size_t)std::max(1, pp.channels);
   pp.piece_bytes = choose_piece(c, chunk);
+  pp.fuse = c->fuse_ring ? 1 : 0;
+  pp.fifo_depth = c->fifo_depth;
   Plan plan;
   int rc = build_plan(pp, &plan);
   if (rc != XMPI_OK) {
@@ -275,6 +277,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   c->copy_engine = env_long("XMPI_COPY_ENGINE", 0);
   c->dep_mode = env_long("XMPI_DEP_MODE", 0) ? 1 : 0;
   c->batch_copies = env_long("XMPI_BATCH_COPIES", 1) ? 1 : 0;
+  c->fuse_ring = env_long("XMPI_FUSE_RING", 1) ? 1 : 0;
   if (getenv("XMPI_KERNEL_MODE")) set_kernel_mode((int)env_long("XMPI_KERNEL_MODE", -1));
   if (getenv("XMPI_GRID_CAP")) set_grid_cap((int)env_long("XMPI_GRID_CAP", 0));
   c->coll_region_bytes = (size_t)size * c->lanes * c->fifo_depth * c->slot_bytes;
@@ -660,6 +663,7 @@ int xmpi_set_param(xmpi_comm* c, const char* name, long value) {
   else if (n == "dep_mode") c->dep_mode = value ? 1 : 0;
   else if (n == "prof_every") c->prof_every = std::max<long>(1, value);
   else if (n == "batch_copies") c->batch_copies = value ? 1 : 0;
+  else if (n == "fuse_ring") c->fuse_ring = value ? 1 : 0;
   else if (n == "kernel_mode") set_kernel_mode((int)value);  // process-wide
   else if (n == "grid_cap") set_grid_cap((int)value);        // process-wide
   else return XMPI_ERR_ARG;
@@ -822,6 +826,8 @@ int xmpi_plan_dump(int coll, int algo, int size, int rank, int root, size_t coun
   pp.channels = channels;
   pp.lanes = 2;
   pp.piece_bytes = piece_elems * elem_size;
+  pp.fuse = env_long("XMPI_FUSE_RING", 1) ? 1 : 0;
+  pp.fifo_depth = (int)env_long("XMPI_PLAN_FIFO_DEPTH", 8);
   Plan plan;
   int rc = build_plan(pp, &plan);
   if (rc != XMPI_OK) return rc;

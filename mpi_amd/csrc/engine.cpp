@@ -96,6 +96,7 @@ struct Exec {
   std::vector<int> stream_of;
   std::vector<char*> slot_ptr;          // RECV_*: the slot this step reads
   std::vector<uint64_t> slot_seq;
+  std::vector<uint64_t> out_seq;        // fused steps: sequence number of the slot they push
   std::vector<std::deque<InFlight>> fl;  // per stream, completion is in issue order
   std::vector<std::deque<char>> unreleased;  // per (peer, lane): popped slots not yet released
   std::vector<std::deque<char>> unpublished;  // per (peer, lane): pushed slots whose head is not yet out
@@ -118,6 +119,7 @@ struct Exec {
     stream_of.assign(n, -1);
     slot_ptr.assign(n, nullptr);
     slot_seq.assign(n, 0);
+    out_seq.assign(n, 0);
     fl.resize((size_t)2 * N + 3);
     unreleased.resize((size_t)N * L);
     unpublished.resize((size_t)N * L);
@@ -127,10 +129,15 @@ struct Exec {
       if (s.kind == STEP_SEND) sq[(size_t)s.peer * L + s.lane].push_back((int)i);
       else if (s.kind == STEP_RECV_REDUCE || s.kind == STEP_RECV_COPY || s.kind == STEP_RECV_HOLD)
         rq[(size_t)s.peer * L + s.lane].push_back((int)i);
-      else lq.push_back((int)i);
+      else if (is_fused(s)) {  // pops one pipe and pushes another: in FIFO order on both
+        rq[(size_t)s.peer * L + s.lane].push_back((int)i);
+        sq[(size_t)s.peer2 * L + s.lane2].push_back((int)i);
+      } else lq.push_back((int)i);
     }
     last_progress = now_seconds();
   }
+
+  static bool is_fused(const Step& s) { return s.kind == STEP_RECV_REDUCE_SEND || s.kind == STEP_RECV_COPY_SEND; }
 
   hipStream_t stream(int sid) const {
     if (sid < N) return c->send_stream[sid];
@@ -233,24 +240,32 @@ struct Exec {
     return XMPI_OK;
   }
 
+  // pushes of one pipe may complete out of order (batched and single launches run on different
+  // streams): head only advances over a gap-free prefix of filled slots
+  void publish_push(int peer, int lane, uint64_t seq) {
+    std::deque<char>& u = unpublished[(size_t)peer * L + lane];
+    uint64_t& base = c->sent_done[peer][lane];
+    u[(size_t)(seq - base)] = 1;
+    while (!u.empty() && u.front()) {
+      u.pop_front();
+      base++;
+    }
+    c->ctl->pipe(c->rank, peer, lane)->head.v.store(base, std::memory_order_release);
+  }
+
   // make the effect of a finished (or stream-ordered) step visible to the peer
   void publish(const Step& s, int step) {
     switch (s.kind) {
-      case STEP_SEND: {
-        // pushes of one pipe may complete out of order (batched and single launches run on different
-        // streams): head only advances over a gap-free prefix of filled slots
-        std::deque<char>& u = unpublished[(size_t)s.peer * L + s.lane];
-        uint64_t& base = c->sent_done[s.peer][s.lane];
-        u[(size_t)(slot_seq[(size_t)step] - base)] = 1;
-        while (!u.empty() && u.front()) {
-          u.pop_front();
-          base++;
-        }
-        c->ctl->pipe(c->rank, s.peer, s.lane)->head.v.store(base, std::memory_order_release);
+      case STEP_SEND:
+        publish_push(s.peer, s.lane, slot_seq[(size_t)step]);
         break;
-      }
       case STEP_RECV_REDUCE:
       case STEP_RECV_COPY:
+        release_slot(s.peer, s.lane, slot_seq[(size_t)step]);
+        break;
+      case STEP_RECV_REDUCE_SEND:
+      case STEP_RECV_COPY_SEND:
+        publish_push(s.peer2, s.lane2, out_seq[(size_t)step]);
         release_slot(s.peer, s.lane, slot_seq[(size_t)step]);
         break;
       case STEP_REDUCE_N:
@@ -281,104 +296,133 @@ struct Exec {
     return XMPI_OK;
   }
 
-  // ---- batched copies: every SEND (or RECV_COPY) that is ready right now goes out in ONE launch ----
-  bool send_ready(int i) const {
-    const Step& s = plan.steps[(size_t)i];
-    if (!deps_issued(s) || s.bytes > c->slot_bytes) return false;
-    const uint64_t tail = c->ctl->pipe(c->rank, s.peer, s.lane)->tail.v.load(std::memory_order_acquire);
-    return c->sent[s.peer][s.lane] - tail < (uint64_t)c->fifo_depth;
+  // ---- batched launches: everything of one kind that is ready right now goes out in ONE launch ------
+  enum BatchKind { BATCH_SEND = 0, BATCH_RECV_COPY, BATCH_RECV_REDUCE, BATCH_RRS, BATCH_RCS, BATCH_KINDS };
+
+  static int kind_of_batch(int bk) {
+    switch (bk) {
+      case BATCH_SEND: return STEP_SEND;
+      case BATCH_RECV_COPY: return STEP_RECV_COPY;
+      case BATCH_RECV_REDUCE: return STEP_RECV_REDUCE;
+      case BATCH_RRS: return STEP_RECV_REDUCE_SEND;
+      default: return STEP_RECV_COPY_SEND;
+    }
   }
 
-  bool recv_copy_ready(int i) const {
-    const Step& s = plan.steps[(size_t)i];
-    if (s.kind != STEP_RECV_COPY || !deps_issued(s)) return false;
+  bool can_pop(const Step& s) const {
     return c->ctl->pipe(s.peer, c->rank, s.lane)->head.v.load(std::memory_order_acquire) > c->recvd[s.peer][s.lane];
   }
-
-  bool recv_reduce_ready(int i) const {
-    const Step& s = plan.steps[(size_t)i];
-    if (s.kind != STEP_RECV_REDUCE || !deps_issued(s)) return false;
-    return c->ctl->pipe(s.peer, c->rank, s.lane)->head.v.load(std::memory_order_acquire) > c->recvd[s.peer][s.lane];
+  bool can_push(int peer, int lane) const {
+    const uint64_t tail = c->ctl->pipe(c->rank, peer, lane)->tail.v.load(std::memory_order_acquire);
+    return c->sent[peer][lane] - tail < (uint64_t)c->fifo_depth;
   }
 
-  enum BatchKind { BATCH_SEND = 0, BATCH_RECV_COPY = 1, BATCH_RECV_REDUCE = 2 };
+  // is step i (the front of a queue) of batch kind bk and ready to be launched right now?
+  bool batch_ready(int i, int bk) const {
+    const Step& s = plan.steps[(size_t)i];
+    if (s.kind != kind_of_batch(bk) || !deps_issued(s) || s.bytes > c->slot_bytes) return false;
+    switch (bk) {
+      case BATCH_SEND: return can_push(s.peer, s.lane);
+      case BATCH_RECV_COPY:
+      case BATCH_RECV_REDUCE: return can_pop(s);
+      default: {  // fused: next in line on BOTH of its pipes, data in, room out
+        const std::deque<int>& in = rq[(size_t)s.peer * L + s.lane];
+        const std::deque<int>& out = sq[(size_t)s.peer2 * L + s.lane2];
+        return !in.empty() && in.front() == i && !out.empty() && out.front() == i && can_pop(s) &&
+               can_push(s.peer2, s.lane2);
+      }
+    }
+  }
 
-  int issue_batch(const std::vector<int>& steps, int kind) {
-    void* dst[kMaxBatch];
-    const void* src[kMaxBatch];
-    const void* opa[kMaxBatch];
+  int issue_batch(const std::vector<int>& steps, int bk) {
+    void *dst[kMaxBatch], *dst2[kMaxBatch];
+    const void *src[kMaxBatch], *opa[kMaxBatch];
     size_t bytes[kMaxBatch], counts[kMaxBatch];
     const int n = (int)steps.size();
-    const int sid = kind == BATCH_SEND ? 2 * N + 1 : 2 * N + 2;
-    size_t total = 0;
+    const int sid = bk == BATCH_SEND ? 2 * N + 1 : 2 * N + 2;
+    size_t total = 0, written = 0;
     bool eager = c->shared_stream;
     for (int k = 0; k < n; k++) {
       const int i = steps[(size_t)k];
       const Step& s = plan.steps[(size_t)i];
       int rc = chain_deps(s, sid);
       if (rc) return rc;
-      if (kind == BATCH_SEND) {
-        const uint64_t seq = c->sent[s.peer][s.lane];
-        dst[k] = c->peer_window[s.peer] + c->coll_slot_off(c->rank, s.lane, seq);
-        src[k] = bufs[s.src_buf] + s.src_off;
-        c->sent[s.peer][s.lane] = seq + 1;
-        slot_seq[(size_t)i] = seq;
-        unpublished[(size_t)s.peer * L + s.lane].push_back(0);
-      } else {
+      dst[k] = dst2[k] = nullptr;
+      src[k] = opa[k] = nullptr;
+      if (bk != BATCH_SEND) {  // pop the incoming slot
         const uint64_t seq = c->recvd[s.peer][s.lane];
         char* slot = c->window + c->coll_slot_off(s.peer, s.lane, seq);
         slot_ptr[(size_t)i] = slot;
         slot_seq[(size_t)i] = seq;
         c->recvd[s.peer][s.lane] = seq + 1;
         unreleased[(size_t)s.peer * L + s.lane].push_back(0);
-        dst[k] = bufs[s.dst_buf] + s.dst_off;
         src[k] = slot;
-        opa[k] = bufs[s.src_buf] + s.src_off;  // RECV_REDUCE: the local operand
+        opa[k] = bufs[s.src_buf] + s.src_off;  // reductions: the local operand
+        if (bk != BATCH_RRS || s.keep_local) dst[k] = bufs[s.dst_buf] + s.dst_off;
+        if (!coloc(s.peer)) eager = false;
+      }
+      if (bk == BATCH_SEND || bk == BATCH_RRS || bk == BATCH_RCS) {  // claim the outgoing slot
+        const int peer = bk == BATCH_SEND ? s.peer : s.peer2, lane = bk == BATCH_SEND ? s.lane : s.lane2;
+        const uint64_t seq = c->sent[peer][lane];
+        char* remote = c->peer_window[peer] + c->coll_slot_off(c->rank, lane, seq);
+        c->sent[peer][lane] = seq + 1;
+        unpublished[(size_t)peer * L + lane].push_back(0);
+        if (bk == BATCH_SEND) {
+          slot_seq[(size_t)i] = seq;
+          dst[k] = remote;
+          src[k] = bufs[s.src_buf] + s.src_off;
+        } else {
+          out_seq[(size_t)i] = seq;
+          dst2[k] = remote;
+        }
+        if (!coloc(peer)) eager = false;
       }
       bytes[k] = s.bytes;
       counts[k] = s.bytes / es;
       total += s.bytes;
-      if (!coloc(s.peer)) eager = false;
+      written += s.bytes * (size_t)((dst[k] ? 1 : 0) + (dst2[k] ? 1 : 0));
     }
     InFlight f;
     SharedStreamLock lk(c);
-    const int pk = kind == BATCH_SEND ? PROF_PEER : (kind == BATCH_RECV_COPY ? PROF_COPY : PROF_REDUCE2);
-    const size_t pb = kind == BATCH_SEND ? total : (kind == BATCH_RECV_COPY ? 2 * total : 3 * total);
+    const bool reduce = bk == BATCH_RECV_REDUCE || bk == BATCH_RRS;
+    const int pk = bk == BATCH_SEND ? PROF_PEER : (reduce ? PROF_REDUCE2 : PROF_COPY);
+    const size_t pb = bk == BATCH_SEND ? total : (reduce ? 2 * total + written : total + written);
     int rc = begin_op(steps[0], &f, pk, pb);
     if (rc) return rc;
     for (int k = 1; k < n; k++) f.more.push_back(steps[(size_t)k]);
-    if (kind == BATCH_RECV_REDUCE)
-      XMPI_HIP(launch_reduce2_batch(dst, opa, src, counts, n, dtype, op, stream(sid), f.start, f.stop));
+    if (reduce)
+      XMPI_HIP(launch_reduce2_batch(dst, dst2, opa, src, counts, n, dtype, op, stream(sid), f.start, f.stop));
     else
-      XMPI_HIP(launch_copy_batch(dst, src, bytes, n, stream(sid), f.start, f.stop));
+      XMPI_HIP(launch_copy_batch(dst, dst2, src, bytes, n, stream(sid), f.start, f.stop));
     return end_op(steps[0], sid, &f, eager);
   }
 
-  // Everything of one kind that is ready right now goes out in ONE launch (all peers of a full-mesh
-  // step, all channels of a ring step).  Returns the number of steps issued, <0 on error.
+  // Returns the number of steps issued, <0 on error.  Plain sends and slot drains batch only when
+  // they are kernels (copy_engine 1) and at least two are ready; the fused ring steps exist only as
+  // kernels and always go through here, alone if need be.
   int try_batches() {
-    if (!c->batch_copies) return 0;
     int issued = 0;
-    for (int kind = 0; kind < 3; kind++) {
-      if (kind != BATCH_RECV_REDUCE && c->copy_engine != 1) continue;  // copies batch only as kernels
-      std::vector<std::deque<int>>& qs = kind == BATCH_SEND ? sq : rq;
+    for (int bk = 0; bk < BATCH_KINDS; bk++) {
+      const bool fused = bk == BATCH_RRS || bk == BATCH_RCS;
+      if (!fused && !c->batch_copies) continue;
+      if ((bk == BATCH_SEND || bk == BATCH_RECV_COPY) && c->copy_engine != 1) continue;
+      std::vector<std::deque<int>>& qs = bk == BATCH_SEND ? sq : rq;
+      const size_t max_group = c->batch_copies ? (size_t)kMaxBatch : 1;
       for (;;) {
         std::vector<int> ready;
-        std::vector<std::deque<int>*> from;
         for (auto& q : qs) {
-          if (q.empty() || (int)ready.size() >= kMaxBatch) continue;
-          const int i = q.front();
-          const bool ok = kind == BATCH_SEND ? send_ready(i)
-                                             : (kind == BATCH_RECV_COPY ? recv_copy_ready(i) : recv_reduce_ready(i));
-          if (ok) {
-            ready.push_back(i);
-            from.push_back(&q);
-          }
+          if (q.empty() || ready.size() >= max_group) continue;
+          if (batch_ready(q.front(), bk)) ready.push_back(q.front());
         }
-        if (ready.size() < 2) break;  // a single step takes the ordinary path
-        int rc = issue_batch(ready, kind);
+        if (ready.size() < (fused ? 1u : 2u)) break;  // a single plain step takes the ordinary path
+        int rc = issue_batch(ready, bk);
         if (rc) return rc;
-        for (auto* q : from) q->pop_front();
+        for (int i : ready) {
+          const Step& s = plan.steps[(size_t)i];
+          if (bk == BATCH_SEND) sq[(size_t)s.peer * L + s.lane].pop_front();
+          else rq[(size_t)s.peer * L + s.lane].pop_front();
+          if (fused) sq[(size_t)s.peer2 * L + s.lane2].pop_front();
+        }
         issued += (int)ready.size();
       }
     }
@@ -388,7 +432,7 @@ struct Exec {
   // returns 1 if issued, 0 if not ready, <0 on error
   int try_send(int i) {
     const Step& s = plan.steps[(size_t)i];
-    if (!deps_issued(s)) return 0;
+    if (is_fused(s) || !deps_issued(s)) return 0;  // fused steps are launched by try_batches
     const uint64_t seq = c->sent[s.peer][s.lane];
     const uint64_t tail = c->ctl->pipe(c->rank, s.peer, s.lane)->tail.v.load(std::memory_order_acquire);
     if (seq - tail >= (uint64_t)c->fifo_depth) return 0;
@@ -413,7 +457,7 @@ struct Exec {
 
   int try_recv(int i) {
     const Step& s = plan.steps[(size_t)i];
-    if (!deps_issued(s)) return 0;
+    if (is_fused(s) || !deps_issued(s)) return 0;  // fused steps are launched by try_batches
     const uint64_t seq = c->recvd[s.peer][s.lane];
     const uint64_t head = c->ctl->pipe(s.peer, c->rank, s.lane)->head.v.load(std::memory_order_acquire);
     if (head <= seq) return 0;

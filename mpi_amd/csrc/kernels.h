@@ -25,11 +25,13 @@ hipError_t launch_copy(void* dst, const void* src, size_t bytes, hipStream_t str
 // n <= kMaxBatch independent copies in one launch (a piece pushed to every peer / every peer's slot
 // drained at once); falls back to one launch per copy for odd alignments
 constexpr int kMaxBatch = 16;
-hipError_t launch_copy_batch(void* const* dst, const void* const* src, const size_t* bytes, int n,
-                             hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// dst2 (optional array; entries may be null): a second destination of each copy
+hipError_t launch_copy_batch(void* const* dst, void* const* dst2, const void* const* src, const size_t* bytes,
+                             int n, hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
 // n <= kMaxBatch independent dst = a op b reductions in one launch (the ring channels of one step)
-hipError_t launch_reduce2_batch(void* const* dst, const void* const* a, const void* const* b,
+// dst[i] may be null (result only forwarded) and dst2 (optional array) is a second destination
+hipError_t launch_reduce2_batch(void* const* dst, void* const* dst2, const void* const* a, const void* const* b,
                                 const size_t* counts, int n, int dtype, int op, hipStream_t stream,
                                 hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 

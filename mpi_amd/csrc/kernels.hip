@@ -170,9 +170,12 @@ __global__ __launch_bounds__(kBlock) void reduce2_kernel(T* dst, const T* a, con
 }
 
 // Several independent reductions in ONE launch (the ring channels of one step): blockIdx.y picks the
-// segment.  Same tile body as reduce2_kernel.
+// segment.  Same tile body as reduce2_kernel.  Each segment may store its result twice: dst is the
+// local copy (null for the partial sums of a fused ring step, which are only forwarded) and dst2 the
+// next rank's receive slot (xGMI write) -- receive-reduce-send in one pass over the data.
 struct Reduce2Batch {
   void* dst[kMaxBatch];
+  void* dst2[kMaxBatch];
   const void* a[kMaxBatch];
   const void* b[kMaxBatch];
   size_t count[kMaxBatch];
@@ -182,6 +185,7 @@ template <typename T, int OP, int MODE>
 __global__ __launch_bounds__(kBlock) void reduce2_batch_kernel(Reduce2Batch q) {
   const int j = blockIdx.y;
   T* dst = reinterpret_cast<T*>(q.dst[j]);
+  T* dst2 = reinterpret_cast<T*>(q.dst2[j]);
   const T* a = reinterpret_cast<const T*>(q.a[j]);
   const T* b = reinterpret_cast<const T*>(q.b[j]);
   constexpr size_t N = 16 / sizeof(T);
@@ -189,6 +193,7 @@ __global__ __launch_bounds__(kBlock) void reduce2_batch_kernel(Reduce2Batch q) {
   const pack_t* pa = reinterpret_cast<const pack_t*>(a);
   const pack_t* pb = reinterpret_cast<const pack_t*>(b);
   pack_t* pd = reinterpret_cast<pack_t*>(dst);
+  pack_t* pd2 = reinterpret_cast<pack_t*>(dst2);
   constexpr size_t kTile = (size_t)kBlock * kUnroll;
   const size_t stride = (size_t)gridDim.x * kTile;
   const size_t lane_off = (size_t)(threadIdx.x >> 6) * (64 * kUnroll) + (threadIdx.x & 63);
@@ -202,18 +207,32 @@ __global__ __launch_bounds__(kBlock) void reduce2_batch_kernel(Reduce2Batch q) {
         vb[k] = ldp<MODE>(pb + first + k * 64);
       }
 #pragma unroll
-      for (int k = 0; k < kUnroll; k++) stp<MODE>(pd + first + k * 64, combine16<T, OP>(va[k], vb[k]));
+      for (int k = 0; k < kUnroll; k++) va[k] = combine16<T, OP>(va[k], vb[k]);
+      if (pd) {
+#pragma unroll
+        for (int k = 0; k < kUnroll; k++) stp<MODE>(pd + first + k * 64, va[k]);
+      }
+      if (pd2) {
+#pragma unroll
+        for (int k = 0; k < kUnroll; k++) stp<MODE>(pd2 + first + k * 64, va[k]);
+      }
     } else {
       for (int k = 0; k < kUnroll; k++) {
         const size_t i = first + k * 64;
-        if (i < npack) pd[i] = combine16<T, OP>(pa[i], pb[i]);
+        if (i < npack) {
+          const pack_t v = combine16<T, OP>(pa[i], pb[i]);
+          if (pd) pd[i] = v;
+          if (pd2) pd2[i] = v;
+        }
       }
     }
   }
   const size_t done = npack * N;
   if (blockIdx.x == 0 && done + threadIdx.x < count) {
     const size_t i = done + threadIdx.x;
-    dst[i] = combine_any<T, OP>(a[i], b[i]);
+    const T v = combine_any<T, OP>(a[i], b[i]);
+    if (dst) dst[i] = v;
+    if (dst2) dst2[i] = v;
   }
 }
 
@@ -299,6 +318,7 @@ __global__ __launch_bounds__(kBlock) void copy16_kernel(pack_t* dst, const pack_
 // different xGMI link, all driven from one grid) and how it drains the slots of all peers at once.
 struct CopyBatch {
   void* dst[kMaxBatch];
+  void* dst2[kMaxBatch];  // optional second destination (receive-copy-send: store locally and forward)
   const void* src[kMaxBatch];
   size_t bytes[kMaxBatch];
 };
@@ -307,6 +327,7 @@ template <int MODE>
 __global__ __launch_bounds__(kBlock) void copy_batch_kernel(CopyBatch b) {
   const int j = blockIdx.y;
   pack_t* dst = reinterpret_cast<pack_t*>(b.dst[j]);
+  pack_t* dst2 = reinterpret_cast<pack_t*>(b.dst2[j]);
   const pack_t* src = reinterpret_cast<const pack_t*>(b.src[j]);
   const size_t bytes = b.bytes[j], npack = bytes / 16;
   constexpr size_t kTile = (size_t)kBlock * kUnroll;
@@ -320,17 +341,27 @@ __global__ __launch_bounds__(kBlock) void copy_batch_kernel(CopyBatch b) {
       for (int k = 0; k < kUnroll; k++) v[k] = ldp<MODE>(src + first + k * 64);
 #pragma unroll
       for (int k = 0; k < kUnroll; k++) stp<MODE>(dst + first + k * 64, v[k]);
+      if (dst2) {
+#pragma unroll
+        for (int k = 0; k < kUnroll; k++) stp<MODE>(dst2 + first + k * 64, v[k]);
+      }
     } else {
       for (int k = 0; k < kUnroll; k++) {
         const size_t i = first + k * 64;
-        if (i < npack) dst[i] = src[i];
+        if (i < npack) {
+          const pack_t v = src[i];
+          dst[i] = v;
+          if (dst2) dst2[i] = v;
+        }
       }
     }
   }
   const size_t done = npack * 16;
   if (blockIdx.x == 0 && done + threadIdx.x < bytes) {
     const size_t i = done + threadIdx.x;
-    reinterpret_cast<uint8_t*>(dst)[i] = reinterpret_cast<const uint8_t*>(src)[i];
+    const uint8_t v = reinterpret_cast<const uint8_t*>(src)[i];
+    reinterpret_cast<uint8_t*>(dst)[i] = v;
+    if (dst2) reinterpret_cast<uint8_t*>(dst2)[i] = v;
   }
 }
 
@@ -774,27 +805,35 @@ hipError_t reduce2_batch_op(const Reduce2Batch& q, int n, size_t maxcount, size_
 }
 }  // namespace
 
-hipError_t launch_reduce2_batch(void* const* dst, const void* const* a, const void* const* b, const size_t* counts,
-                                int n, int dtype, int op, hipStream_t s, hipEvent_t es, hipEvent_t ee) {
+hipError_t launch_reduce2_batch(void* const* dst, void* const* dst2, const void* const* a, const void* const* b,
+                                const size_t* counts, int n, int dtype, int op, hipStream_t s, hipEvent_t es,
+                                hipEvent_t ee) {
   if (n < 1 || n > kMaxBatch) return hipErrorInvalidValue;
   Reduce2Batch q;
   size_t maxc = 0, total = 0;
-  bool ok = true;
+  bool ok = true, fused = false;
   for (int i = 0; i < n; i++) {
     q.dst[i] = dst[i];
+    q.dst2[i] = dst2 ? dst2[i] : nullptr;
     q.a[i] = a[i];
     q.b[i] = b[i];
     q.count[i] = counts[i];
     maxc = counts[i] > maxc ? counts[i] : maxc;
     total += counts[i];
-    ok = ok && aligned16(dst[i]) && aligned16(a[i]) && aligned16(b[i]);
+    fused = fused || q.dst2[i] != nullptr || dst[i] == nullptr;
+    ok = ok && aligned16(dst[i]) && aligned16(q.dst2[i]) && aligned16(a[i]) && aligned16(b[i]);
   }
-  if (!ok || n == 1 || maxc == 0) {
-    for (int i = 0; i < n; i++) {
-      hipError_t e = launch_reduce2(dst[i], a[i], b[i], counts[i], dtype, op, s, i == 0 ? es : nullptr,
-                                    i == n - 1 ? ee : nullptr);
-      if (e != hipSuccess) return e;
-    }
+  if (!ok || (n == 1 && !fused) || maxc == 0) {  // odd alignment / nothing to fuse: plain launches
+    bool first = true;
+    for (int i = 0; i < n; i++)
+      for (int w = 0; w < 2; w++) {
+        void* d = w == 0 ? dst[i] : q.dst2[i];
+        if (!d) continue;
+        const bool last = (i == n - 1) && (w == 1 || !q.dst2[i]);
+        hipError_t e = launch_reduce2(d, a[i], b[i], counts[i], dtype, op, s, first ? es : nullptr, last ? ee : nullptr);
+        if (e != hipSuccess) return e;
+        first = false;
+      }
     if (maxc == 0) {  // nothing launched: still honour the events
       if (es) (void)hipEventRecord(es, s);
       if (ee) (void)hipEventRecord(ee, s);
@@ -813,25 +852,33 @@ hipError_t launch_reduce2_batch(void* const* dst, const void* const* a, const vo
   }
 }
 
-hipError_t launch_copy_batch(void* const* dst, const void* const* src, const size_t* bytes, int n, hipStream_t s,
-                             hipEvent_t es, hipEvent_t ee) {
+hipError_t launch_copy_batch(void* const* dst, void* const* dst2, const void* const* src, const size_t* bytes, int n,
+                             hipStream_t s, hipEvent_t es, hipEvent_t ee) {
   if (n < 1 || n > kMaxBatch) return hipErrorInvalidValue;
   CopyBatch b;
   size_t maxb = 0, total = 0;
-  bool ok = true;
+  bool ok = true, fused = false;
   for (int i = 0; i < n; i++) {
     b.dst[i] = dst[i];
+    b.dst2[i] = dst2 ? dst2[i] : nullptr;
     b.src[i] = src[i];
     b.bytes[i] = bytes[i];
     maxb = bytes[i] > maxb ? bytes[i] : maxb;
     total += bytes[i];
-    ok = ok && aligned16(dst[i]) && aligned16(src[i]);
+    fused = fused || b.dst2[i] != nullptr;
+    ok = ok && aligned16(dst[i]) && aligned16(b.dst2[i]) && aligned16(src[i]);
   }
-  if (!ok || n == 1) {  // odd alignment: one launch per copy, the events span the group
-    for (int i = 0; i < n; i++) {
-      hipError_t e = launch_copy(dst[i], src[i], bytes[i], s, i == 0 ? es : nullptr, i == n - 1 ? ee : nullptr);
-      if (e != hipSuccess) return e;
-    }
+  if (!ok || (n == 1 && !fused)) {  // odd alignment: one launch per copy, the events span the group
+    bool first = true;
+    for (int i = 0; i < n; i++)
+      for (int w = 0; w < 2; w++) {
+        void* d = w == 0 ? dst[i] : b.dst2[i];
+        if (!d) continue;
+        const bool last = (i == n - 1) && (w == 1 || !b.dst2[i]);
+        hipError_t e = launch_copy(d, src[i], bytes[i], s, first ? es : nullptr, last ? ee : nullptr);
+        if (e != hipSuccess) return e;
+        first = false;
+      }
     return hipSuccess;
   }
   if (maxb == 0) {

@@ -108,6 +108,19 @@ struct Builder {
     s.dst_buf = dst_buf; s.dst_off = dst_elem_off * es; s.bytes = count * es;
     return emit(s, false, true);
   }
+  int recv_reduce_send(int peer, int lane, int peer2, int lane2, int a_buf, int dst_buf, const Atom& a, bool keep) {
+    Step s;
+    s.kind = STEP_RECV_REDUCE_SEND; s.peer = peer; s.lane = lane; s.peer2 = peer2; s.lane2 = lane2;
+    s.src_buf = a_buf; s.src_off = a.off * es; s.dst_buf = dst_buf; s.dst_off = a.off * es;
+    s.bytes = a.count * es; s.keep_local = keep ? 1 : 0;
+    return emit(s, true, keep);
+  }
+  int recv_copy_send(int peer, int lane, int peer2, int lane2, int dst_buf, const Atom& a) {
+    Step s;
+    s.kind = STEP_RECV_COPY_SEND; s.peer = peer; s.lane = lane; s.peer2 = peer2; s.lane2 = lane2;
+    s.dst_buf = dst_buf; s.dst_off = a.off * es; s.bytes = a.count * es;
+    return emit(s, false, true);
+  }
   int recv_hold(int peer, int lane, size_t count) {
     Step s;
     s.kind = STEP_RECV_HOLD; s.peer = peer; s.lane = lane; s.bytes = count * es;
@@ -174,6 +187,65 @@ void build_allreduce_ring(Builder& b) {
     k.prev = ord[(size_t)((k.pos + N - 1) % N)];
     k.lane = (c / nstr) % std::max(1, P.lanes);
     k.cb = split_even(slice[(size_t)c], slice[(size_t)c + 1], N, al);
+  }
+  if (P.fuse && P.fifo_depth >= 2) {
+    // Fused ring: a chunk that arrives is combined and forwarded by ONE kernel (receive-reduce-send),
+    // partial sums are never stored locally; only the last reduce-scatter step keeps its result (the
+    // rank's final chunk) while already forwarding it as the first allgather hop; allgather hops
+    // store and forward in one kernel (receive-copy-send).  2N-1 launches per piece instead of 4(N-1).
+    //
+    // Emission order.  Hop h = 0 .. 2N-3 of piece p is "pop what prev pushed at hop h, push hop h+1".
+    // A fused step keeps its incoming slot until it can push, and all ranks run the same sequence, so
+    // a piece in flight occupies one slot of EVERY pipe of its ring: at most W = depth-1 pieces may be
+    // in flight or every pipe is full and nobody can push (a circular wait).  Steps are therefore
+    // emitted by the key (start(p) + h, h, p) with start(p) = max(p, start(p-W) + 2N-1): a sliding
+    // window of W pieces, each advancing one hop per time unit.  The same key orders the pushes and
+    // the pops of every pipe identically on both ends.  Full rate needs W >= 2N-1 (depth >= 2N);
+    // real messages have only a few pieces per chunk, so the window rarely binds.
+    // (tests/test_plan_property.py runs depths 1..5; depth 1 uses the unfused schedule.)
+    std::vector<std::vector<std::vector<Atom>>> pcs((size_t)C);  // [channel][chunk] -> pieces
+    size_t NP = 0;  // pieces per chunk (max over chunks)
+    for (int c = 0; c < C; c++) {
+      pcs[(size_t)c].resize((size_t)N);
+      for (int j = 0; j < N; j++) {
+        pcs[(size_t)c][(size_t)j] = pieces_of(ch[(size_t)c].cb[(size_t)j], ch[(size_t)c].cb[(size_t)j + 1], pe);
+        NP = std::max(NP, pcs[(size_t)c][(size_t)j].size());
+      }
+    }
+    const int H = 2 * N - 2;  // hops (pushes) per piece
+    const size_t W = (size_t)std::max(1, P.fifo_depth - 1);
+    std::vector<size_t> start(NP);
+    for (size_t p = 0; p < NP; p++) start[p] = p < W ? p : std::max(p, start[p - W] + (size_t)H + 1);
+    // ops: (time, hop, piece); hop -1 = the initial SEND (pushes hop 0), hop h >= 0 pops hop h
+    struct Op { size_t time; int hop; size_t piece; };
+    std::vector<Op> ops;
+    for (size_t p = 0; p < NP; p++) {
+      ops.push_back({start[p], -1, p});
+      for (int h = 0; h < H; h++) ops.push_back({start[p] + (size_t)h + 1, h, p});
+    }
+    std::sort(ops.begin(), ops.end(), [](const Op& x, const Op& y) {
+      if (x.time != y.time) return x.time < y.time;
+      if (x.hop != y.hop) return x.hop < y.hop;
+      return x.piece < y.piece;
+    });
+    for (const Op& o : ops)
+      for (int c = 0; c < C; c++) {
+        const Chan& k = ch[(size_t)c];
+        const int h = o.hop;
+        if (h < 0) {  // hop 0: the own chunk starts its journey
+          const std::vector<Atom>& v = pcs[(size_t)c][(size_t)k.pos];
+          if (o.piece < v.size()) b.send(k.next, k.lane, BUF_SEND, v[o.piece]);
+          continue;
+        }
+        // reduce-scatter hops 0..N-2 carry chunk (pos-h-1); allgather hops N-1..2N-3 chunk (pos-(h-(N-1)))
+        const int chunk = h < N - 1 ? ((k.pos - h - 1) % N + N) % N : ((k.pos - (h - (N - 1))) % N + N) % N;
+        const std::vector<Atom>& v = pcs[(size_t)c][(size_t)chunk];
+        if (o.piece >= v.size()) continue;
+        if (h < N - 1) b.recv_reduce_send(k.prev, k.lane, k.next, k.lane, BUF_SEND, BUF_RECV, v[o.piece], /*keep_local=*/h == N - 2);
+        else if (h < H - 1) b.recv_copy_send(k.prev, k.lane, k.next, k.lane, BUF_RECV, v[o.piece]);
+        else b.recv_copy(k.prev, k.lane, BUF_RECV, v[o.piece].off, v[o.piece].count);
+      }
+    return;
   }
   // reduce-scatter: step s sends chunk (pos-s), receives chunk (pos-s-1) and folds it in
   for (int s = 0; s < N - 1; s++) {
@@ -516,7 +588,8 @@ int build_plan(const PlanParams& p, Plan* out) {
 }
 
 std::string plan_to_text(const Plan& plan) {
-  static const char* kn[] = {"SEND", "RECV_REDUCE", "RECV_COPY", "RECV_HOLD", "REDUCE_N", "LOCAL_COPY"};
+  static const char* kn[] = {"SEND", "RECV_REDUCE", "RECV_COPY", "RECV_HOLD", "REDUCE_N", "LOCAL_COPY",
+                             "RECV_REDUCE_SEND", "RECV_COPY_SEND"};
   std::string out;
   char line[512];
   snprintf(line, sizeof line, "plan algo=%d channels=%d temp_bytes=%zu steps=%zu\n", plan.algo, plan.channels,
@@ -529,6 +602,7 @@ std::string plan_to_text(const Plan& plan) {
     for (int d = 0; d < s.ndeps; d++) n += snprintf(line + n, sizeof line - (size_t)n, "%s%d", d ? "," : "", s.deps[d]);
     n += snprintf(line + n, sizeof line - (size_t)n, " srcs=");
     for (int d = 0; d < s.nsrcs; d++) n += snprintf(line + n, sizeof line - (size_t)n, "%s%d", d ? "," : "", s.srcs[d]);
+    n += snprintf(line + n, sizeof line - (size_t)n, " peer2=%d lane2=%d keep=%d", s.peer2, s.lane2, s.keep_local);
     snprintf(line + n, sizeof line - (size_t)n, "\n");
     out += line;
   }

@@ -21,6 +21,9 @@ enum StepKind : int {
   STEP_RECV_HOLD = 3,    // wait for the slot and keep it for a later STEP_REDUCE_N
   STEP_REDUCE_N = 4,     // dst = fold over srcs[] in the given (rank) order; releases held slots
   STEP_LOCAL_COPY = 5,   // dst = src, both local
+  // fused ring primitives: pop pipe(peer -> me, lane) and push pipe(me -> peer2, lane2) in ONE kernel
+  STEP_RECV_REDUCE_SEND = 6,  // v = a op slot; next slot = v; dst = v too when keep_local
+  STEP_RECV_COPY_SEND = 7,    // dst = slot; next slot = slot
 };
 
 enum BufId : int { BUF_SEND = 0, BUF_RECV = 1, BUF_TEMP = 2 };
@@ -42,6 +45,9 @@ struct Step {
   int deps[kMaxDeps] = {0};  // earlier steps of THIS rank that must have completed
   int nsrcs = 0;
   int srcs[kMaxSrcs] = {0};  // STEP_REDUCE_N: index of a RECV_HOLD step, or -1 = the local operand
+  int peer2 = -1;            // fused steps: where the result is pushed
+  int lane2 = 0;
+  int keep_local = 0;        // STEP_RECV_REDUCE_SEND: also store the result in dst
 };
 
 struct PlanParams {
@@ -55,6 +61,8 @@ struct PlanParams {
   int channels = 1;      // ring channels (each a different Hamiltonian cycle of the mesh)
   int lanes = 2;         // FIFO lanes per ordered rank pair
   size_t piece_bytes = 1 << 20;  // max bytes per step (<= slot size)
+  int fuse = 1;                  // ring: receive-reduce-send / receive-copy-send in one kernel
+  int fifo_depth = 8;            // slots per pipe (bounds the pieces a fused ring keeps in flight)
 };
 
 struct Plan {

@@ -16,7 +16,8 @@ import numpy as np
 
 from mpi_amd import xmpi
 
-KINDS = {"SEND": 0, "RECV_REDUCE": 1, "RECV_COPY": 2, "RECV_HOLD": 3, "REDUCE_N": 4, "LOCAL_COPY": 5}
+KINDS = {"SEND": 0, "RECV_REDUCE": 1, "RECV_COPY": 2, "RECV_HOLD": 3, "REDUCE_N": 4, "LOCAL_COPY": 5,
+         "RECV_REDUCE_SEND": 6, "RECV_COPY_SEND": 7}
 
 
 @dataclass
@@ -31,6 +32,9 @@ class Step:
     nbytes: int
     deps: List[int]
     srcs: List[int]
+    peer2: int = -1
+    lane2: int = 0
+    keep: int = 0
 
 
 @dataclass
@@ -53,14 +57,25 @@ def parse_plan(text: str) -> Plan:
         deps = [int(x) for x in kv["deps"].split(",") if x]
         srcs = [int(x) for x in kv["srcs"].split(",") if x]
         plan.steps.append(Step(KINDS[tok[1]], int(kv["peer"]), int(kv["lane"]), int(sb), int(so), int(db), int(do),
-                               int(kv["bytes"]), deps, srcs))
+                               int(kv["bytes"]), deps, srcs, int(kv.get("peer2", -1)), int(kv.get("lane2", 0)),
+                               int(kv.get("keep", 0))))
     assert len(plan.steps) == int(hdr["steps"])
     return plan
 
 
-def get_plans(coll, algo, size, root, count, elem_size, channels, piece_elems) -> List[Plan]:
-    return [parse_plan(xmpi.plan_text(coll, algo, size, r, root, count, elem_size, channels, piece_elems))
-            for r in range(size)]
+def get_plans(coll, algo, size, root, count, elem_size, channels, piece_elems, fifo_depth: int = 2) -> List[Plan]:
+    """Step tables of every rank, built for pipes of `fifo_depth` slots (valid for any deeper FIFO)."""
+    import os
+    old = os.environ.get("XMPI_PLAN_FIFO_DEPTH")
+    os.environ["XMPI_PLAN_FIFO_DEPTH"] = str(fifo_depth)
+    try:
+        return [parse_plan(xmpi.plan_text(coll, algo, size, r, root, count, elem_size, channels, piece_elems))
+                for r in range(size)]
+    finally:
+        if old is None:
+            del os.environ["XMPI_PLAN_FIFO_DEPTH"]
+        else:
+            os.environ["XMPI_PLAN_FIFO_DEPTH"] = old
 
 
 def np_combine(a: np.ndarray, b: np.ndarray, op: int) -> np.ndarray:
@@ -111,6 +126,9 @@ def simulate(plans: List[Plan], sendbufs: List[np.ndarray], recv_elems: int, dty
                 sendq[r].setdefault((s.peer, s.lane), deque()).append(i)
             elif s.kind in (1, 2, 3):
                 recvq[r].setdefault((s.peer, s.lane), deque()).append(i)
+            elif s.kind in (6, 7):  # fused: pops one pipe and pushes another, in FIFO order on both
+                recvq[r].setdefault((s.peer, s.lane), deque()).append(i)
+                sendq[r].setdefault((s.peer2, s.lane2), deque()).append(i)
             else:
                 localq[r].append(i)
     remaining = sum(len(p.steps) for p in plans)
@@ -125,13 +143,18 @@ def simulate(plans: List[Plan], sendbufs: List[np.ndarray], recv_elems: int, dty
                 if q:
                     s = p.steps[q[0]]
                     key = (r, peer, lane)
-                    if deps_ok(r, s) and occupied.get(key, 0) < fifo_depth:
+                    if s.kind == 0 and deps_ok(r, s) and occupied.get(key, 0) < fifo_depth:
                         ready.append((r, q[0]))
             for (peer, lane), q in recvq[r].items():
                 if q:
                     s = p.steps[q[0]]
-                    if deps_ok(r, s) and pipes.get((peer, r, lane)):
-                        ready.append((r, q[0]))
+                    if not (deps_ok(r, s) and pipes.get((peer, r, lane))):
+                        continue
+                    if s.kind in (6, 7):  # must also be next in line on its outgoing pipe, with room there
+                        oq = sendq[r][(s.peer2, s.lane2)]
+                        if oq[0] != q[0] or occupied.get((r, s.peer2, s.lane2), 0) >= fifo_depth:
+                            continue
+                    ready.append((r, q[0]))
             for i in localq[r]:
                 s = p.steps[i]
                 if state[r][i] == 0 and deps_ok(r, s) and all(h < 0 or state[r][h] == 2 for h in s.srcs):
@@ -159,6 +182,23 @@ def simulate(plans: List[Plan], sendbufs: List[np.ndarray], recv_elems: int, dty
                 occupied[key] -= 1
             else:
                 held[r][i] = (key, data)
+        elif s.kind in (6, 7):
+            key = (s.peer, r, s.lane)
+            data = pipes[key].popleft()
+            assert data.size * es == s.nbytes
+            recvq[r][(s.peer, s.lane)].popleft()
+            sendq[r][(s.peer2, s.lane2)].popleft()
+            if s.kind == 6:
+                val = np_combine(view(r, s.src_buf, s.src_off, s.nbytes), data, op)
+                if s.keep:
+                    view(r, s.dst_buf, s.dst_off, s.nbytes)[:] = val
+            else:
+                val = data
+                view(r, s.dst_buf, s.dst_off, s.nbytes)[:] = val
+            occupied[key] -= 1
+            okey = (r, s.peer2, s.lane2)
+            pipes.setdefault(okey, deque()).append(np.array(val, copy=True))
+            occupied[okey] = occupied.get(okey, 0) + 1
         elif s.kind == 4:
             acc = None
             for h in s.srcs:

@@ -96,6 +96,15 @@ for algo in (xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_DIRECT):
                 bufs[s.dst_buf][s.dst_off // es:(s.dst_off + s.nbytes) // es] = x
             else:
                 held[i] = x
+        elif s.kind in (6, 7):                   # fused ring steps: pop, (reduce,) store?, forward
+            t = torch.empty(s.nbytes // es, dtype=torch.int64)
+            dist.recv(t, s.peer, tag=s.lane)
+            x = t.numpy()
+            if s.kind == 6:
+                x = bufs[s.src_buf][s.src_off // es:(s.src_off + s.nbytes) // es] + x
+            if s.kind == 7 or s.keep:
+                bufs[s.dst_buf][s.dst_off // es:(s.dst_off + s.nbytes) // es] = x
+            reqs.append(dist.isend(torch.from_numpy(x.copy()), s.peer2, tag=s.lane2))
         elif s.kind == 4:
             acc = None
             for h in s.srcs:

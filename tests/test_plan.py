@@ -135,12 +135,16 @@ def test_headline_plan_shape():
     n, count = 8, 64 << 20
     text = xmpi.plan_text(xmpi.COLL_ALLREDUCE, xmpi.ALGO_RING, n, 3, 0, count, 4, 4, (2 << 20) // 4)
     plan = plan_sim.parse_plan(text)
-    sent = sum(s.nbytes for s in plan.steps if s.kind == 0)
-    recvd = sum(s.nbytes for s in plan.steps if s.kind in (1, 2))
+    # kinds: 0 SEND, 1 RECV_REDUCE, 2 RECV_COPY, 6 RECV_REDUCE_SEND, 7 RECV_COPY_SEND (fused pop + push)
+    sent = sum(s.nbytes for s in plan.steps if s.kind in (0, 6, 7))
+    recvd = sum(s.nbytes for s in plan.steps if s.kind in (1, 2, 6, 7))
     assert sent == recvd == 2 * (n - 1) * (count * 4) // n
-    assert len({s.peer for s in plan.steps if s.kind == 0}) == 4
-    assert len({s.peer for s in plan.steps if s.kind in (1, 2)}) == 4
+    assert len({s.peer if s.kind == 0 else s.peer2 for s in plan.steps if s.kind in (0, 6, 7)}) == 4
+    assert len({s.peer for s in plan.steps if s.kind in (1, 2, 6, 7)}) == 4
     assert max(s.nbytes for s in plan.steps) <= 2 << 20
+    # fused ring: 2N-1 launches per piece instead of 4(N-1)
+    pieces = len([s for s in plan.steps if s.kind == 0])
+    assert len(plan.steps) == pieces * (2 * n - 1)
 
 
 @pytest.mark.parametrize("n", [4, 6, 8, 16])

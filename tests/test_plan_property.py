@@ -23,7 +23,7 @@ def test_any_schedule_matches_oracle(coll, n, count, piece, channels, depth, see
     algo = data.draw(st.sampled_from(ALGOS[coll]))
     root = data.draw(st.integers(0, n - 1))
     ins = [oracle.fill(count, oracle.I64, 0, seed + r) for r in range(n)]
-    plans = plan_sim.get_plans(coll, algo, n, root, count, 8, channels, piece)
+    plans = plan_sim.get_plans(coll, algo, n, root, count, 8, channels, piece, fifo_depth=depth)
     if coll == xmpi.COLL_ALLREDUCE:
         want = oracle.reduce_ranks(ins, oracle.I64, oracle.SUM)
         got = plan_sim.simulate(plans, ins, count, np.int64, xmpi.SUM, depth, seed=seed)
