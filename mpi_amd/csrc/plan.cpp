@@ -379,6 +379,47 @@ void build_allgather_ring(Builder& b) {
     k.prev = k.ord[(size_t)((k.pos + N - 1) % N)];
     k.lane = (c / nstr) % std::max(1, P.lanes);
   }
+  if (P.fuse && P.fifo_depth >= 2 && N > 1) {
+    // fused: a block piece that arrives is stored and forwarded by one kernel (receive-copy-send);
+    // same sliding-window emission order as the fused allreduce ring, with N-1 hops per piece
+    std::vector<std::vector<Atom>> pcs((size_t)C);
+    size_t NP = 0;
+    for (int c = 0; c < C; c++) {
+      pcs[(size_t)c] = pieces_of(slice[(size_t)c], slice[(size_t)c + 1], pe);
+      NP = std::max(NP, pcs[(size_t)c].size());
+    }
+    const int H = N - 1;
+    const size_t W = (size_t)std::max(1, P.fifo_depth - 1);
+    std::vector<size_t> start(NP);
+    for (size_t p = 0; p < NP; p++) start[p] = p < W ? p : std::max(p, start[p - W] + (size_t)H + 1);
+    struct Op { size_t time; int hop; size_t piece; };
+    std::vector<Op> ops;
+    for (size_t p = 0; p < NP; p++) {
+      ops.push_back({start[p], -1, p});
+      for (int h = 0; h < H; h++) ops.push_back({start[p] + (size_t)h + 1, h, p});
+    }
+    std::sort(ops.begin(), ops.end(), [](const Op& x, const Op& y) {
+      if (x.time != y.time) return x.time < y.time;
+      if (x.hop != y.hop) return x.hop < y.hop;
+      return x.piece < y.piece;
+    });
+    for (const Op& o : ops)
+      for (int c = 0; c < C; c++) {
+        const Chan& k = ch[(size_t)c];
+        if (o.piece >= pcs[(size_t)c].size()) continue;
+        const Atom& a = pcs[(size_t)c][o.piece];
+        if (o.hop < 0) {
+          b.send(k.next, k.lane, BUF_SEND, a);
+          continue;
+        }
+        const int br = k.ord[(size_t)(((k.pos - o.hop - 1) % N + N) % N)];  // whose block arrives at this hop
+        Atom dst = a;
+        dst.off += (size_t)br * P.count;
+        if (o.hop < H - 1) b.recv_copy_send(k.prev, k.lane, k.next, k.lane, BUF_RECV, dst);
+        else b.recv_copy(k.prev, k.lane, BUF_RECV, dst.off, dst.count);
+      }
+    return;
+  }
   for (int s = 0; s < N - 1; s++)
     for (int c = 0; c < C; c++) {
       const Chan& k = ch[(size_t)c];
