@@ -145,6 +145,7 @@ static int collective(xmpi_comm* c, int coll, int algo, int root, const void* se
   pp.piece_bytes = choose_piece(c, chunk);
   pp.fuse = c->fuse_ring ? 1 : 0;
   pp.fifo_depth = c->fifo_depth;
+  pp.oneshot_bytes = (size_t)std::max<long>(0, c->oneshot_bytes);
   Plan plan;
   int rc = build_plan(pp, &plan);
   if (rc != XMPI_OK) {
@@ -278,6 +279,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   c->dep_mode = env_long("XMPI_DEP_MODE", 0) ? 1 : 0;
   c->batch_copies = env_long("XMPI_BATCH_COPIES", 1) ? 1 : 0;
   c->fuse_ring = env_long("XMPI_FUSE_RING", 1) ? 1 : 0;
+  c->oneshot_bytes = std::max<long>(0, env_long("XMPI_ONESHOT_BYTES", 1 << 20));
   if (getenv("XMPI_KERNEL_MODE")) set_kernel_mode((int)env_long("XMPI_KERNEL_MODE", -1));
   if (getenv("XMPI_GRID_CAP")) set_grid_cap((int)env_long("XMPI_GRID_CAP", 0));
   c->coll_region_bytes = (size_t)size * c->lanes * c->fifo_depth * c->slot_bytes;
@@ -664,6 +666,7 @@ int xmpi_set_param(xmpi_comm* c, const char* name, long value) {
   else if (n == "prof_every") c->prof_every = std::max<long>(1, value);
   else if (n == "batch_copies") c->batch_copies = value ? 1 : 0;
   else if (n == "fuse_ring") c->fuse_ring = value ? 1 : 0;
+  else if (n == "oneshot_bytes") c->oneshot_bytes = std::max<long>(0, value);
   else if (n == "kernel_mode") set_kernel_mode((int)value);  // process-wide
   else if (n == "grid_cap") set_grid_cap((int)value);        // process-wide
   else return XMPI_ERR_ARG;
@@ -828,6 +831,7 @@ int xmpi_plan_dump(int coll, int algo, int size, int rank, int root, size_t coun
   pp.piece_bytes = piece_elems * elem_size;
   pp.fuse = env_long("XMPI_FUSE_RING", 1) ? 1 : 0;
   pp.fifo_depth = (int)env_long("XMPI_PLAN_FIFO_DEPTH", 8);
+  pp.oneshot_bytes = (size_t)std::max<long>(0, env_long("XMPI_ONESHOT_BYTES", 1 << 20));
   Plan plan;
   int rc = build_plan(pp, &plan);
   if (rc != XMPI_OK) return rc;

@@ -62,7 +62,8 @@ struct xmpi_comm {
   hipStream_t recv_stream[xmpi::kMaxRanks] = {nullptr};
   hipStream_t local_stream = nullptr;
   hipStream_t batch_send_stream = nullptr, batch_recv_stream = nullptr;  // multi-destination copy launches
-  long fuse_ring = 1;     // ring: receive-reduce-send / receive-copy-send as one kernel
+  long oneshot_bytes = 1 << 20;  // direct allreduce up to this size: push everything, fold locally
+  long fuse_ring = 1;    // ring: receive-reduce-send / receive-copy-send as one kernel
   long batch_copies = 1;  // with the copy kernel: all ready SENDs (RECV_COPYs) go out in one launch
   bool shared_stream = false;  // all of the above alias one per-device stream (co-located ranks)
   bool peer_coloc[xmpi::kMaxRanks] = {false};  // peer is a thread of this process on this GPU

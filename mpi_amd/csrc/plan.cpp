@@ -317,9 +317,31 @@ void build_allreduce_rhd(Builder& b) {
 
 // ---- allreduce: full-mesh one-hop reduce-scatter + allgather; rank-order fold ------------------
 
+// Small messages: one-shot.  Every rank pushes its WHOLE buffer to every peer (one batched launch
+// over all links) and folds the N buffers itself, in rank order: two stages instead of four, at the
+// price of (N-1)*S instead of 2(N-1)/N*S bytes per rank on the wire -- irrelevant below ~1 MiB.
+void build_allreduce_oneshot(Builder& b) {
+  const PlanParams& P = b.P;
+  const int N = P.size, r = P.rank;
+  const size_t pe = piece_elems_of(P);
+  const int L = std::max(1, P.lanes);
+  const std::vector<Atom> pcs = pieces_of(0, P.count, pe);
+  for (size_t p = 0; p < pcs.size(); p++)
+    for (int d = 1; d < N; d++) b.send((r + d) % N, (int)(p % (size_t)L), BUF_SEND, pcs[p]);
+  for (size_t p = 0; p < pcs.size(); p++) {
+    std::vector<int> srcs;
+    for (int q = 0; q < N; q++) srcs.push_back(q == r ? -1 : b.recv_hold(q, (int)(p % (size_t)L), pcs[p].count));
+    b.reduce_n(BUF_SEND, BUF_RECV, pcs[p], srcs);
+  }
+}
+
 void build_allreduce_direct(Builder& b) {
   const PlanParams& P = b.P;
   const int N = P.size, r = P.rank;
+  if (P.count * P.elem_size <= P.oneshot_bytes) {
+    build_allreduce_oneshot(b);
+    return;
+  }
   const size_t al = align_elems(P.elem_size), pe = piece_elems_of(P);
   const std::vector<size_t> cb = split_even(0, P.count, N, al);
   const std::vector<Atom> mine = pieces_of(cb[(size_t)r], cb[(size_t)r + 1], pe);

@@ -29,7 +29,7 @@ enum StepKind : int {
 enum BufId : int { BUF_SEND = 0, BUF_RECV = 1, BUF_TEMP = 2 };
 enum CollKind : int { COLL_ALLREDUCE = 0, COLL_ALLGATHER = 1, COLL_BCAST = 2, COLL_REDUCE = 3 };
 
-constexpr int kMaxDeps = 6;
+constexpr int kMaxDeps = 18;  // >= kMaxRanks + 2: a write may follow one read per peer (one-shot, in place)
 constexpr int kMaxSrcs = 16;
 
 struct Step {
@@ -63,6 +63,7 @@ struct PlanParams {
   size_t piece_bytes = 1 << 20;  // max bytes per step (<= slot size)
   int fuse = 1;                  // ring: receive-reduce-send / receive-copy-send in one kernel
   int fifo_depth = 8;            // slots per pipe (bounds the pieces a fused ring keeps in flight)
+  size_t oneshot_bytes = 1 << 20;  // direct allreduce: messages up to this size use the one-shot form
 };
 
 struct Plan {

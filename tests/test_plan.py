@@ -53,6 +53,34 @@ def test_allreduce_direct_is_rank_order_f32(n):
         assert got[r].tobytes() == want.tobytes()
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("count,piece", [(1, 4), (7, 4), (1000, 16), (4099, 64), (65536, 65536)])
+@pytest.mark.parametrize("inplace", [False, True])
+def test_allreduce_oneshot(n, count, piece, inplace):
+    """Small-message DIRECT: every rank pushes its whole buffer to every peer and folds all N in
+    rank order itself -- one exchange instead of two, still bit-identical to the oracle."""
+    ins = [oracle.fill(count, oracle.F32, 3, 70 + r) for r in range(n)]
+    want = oracle.reduce_ranks(ins, oracle.F32, oracle.SUM)
+    plans = plan_sim.get_plans(xmpi.COLL_ALLREDUCE, xmpi.ALGO_DIRECT, n, 0, count, 4, 1, piece,
+                               oneshot_bytes=1 << 20)
+    if n > 1:
+        kinds = {s.kind for s in plans[0].steps}
+        assert kinds == {0, 3, 4}, kinds  # SEND, RECV_HOLD, REDUCE_N only
+        assert sum(s.kind == 0 for s in plans[0].steps) == (n - 1) * -(-count // max(piece, 4))
+    for depth in (2, 8):
+        got = plan_sim.simulate(plans, ins, count, np.float32, xmpi.SUM, depth, seed=count + n, inplace=inplace)
+        for r in range(n):
+            assert got[r].tobytes() == want.tobytes(), f"rank {r}"
+
+
+def test_allreduce_oneshot_threshold():
+    """Above oneshot_bytes the two-phase form (reduce-scatter, then allgather) is used."""
+    big = plan_sim.get_plans(xmpi.COLL_ALLREDUCE, xmpi.ALGO_DIRECT, 4, 0, 4096, 4, 1, 4096, oneshot_bytes=4096)
+    small = plan_sim.get_plans(xmpi.COLL_ALLREDUCE, xmpi.ALGO_DIRECT, 4, 0, 1024, 4, 1, 4096, oneshot_bytes=4096)
+    assert 2 in {s.kind for s in big[0].steps}       # RECV_COPY of the allgather phase
+    assert 2 not in {s.kind for s in small[0].steps}
+
+
 @pytest.mark.parametrize("n", [2, 4, 8])
 @pytest.mark.parametrize("algo", [xmpi.ALGO_RING, xmpi.ALGO_RHD])
 def test_allreduce_f32_tolerance(n, algo):

@@ -23,7 +23,9 @@ def test_any_schedule_matches_oracle(coll, n, count, piece, channels, depth, see
     algo = data.draw(st.sampled_from(ALGOS[coll]))
     root = data.draw(st.integers(0, n - 1))
     ins = [oracle.fill(count, oracle.I64, 0, seed + r) for r in range(n)]
-    plans = plan_sim.get_plans(coll, algo, n, root, count, 8, channels, piece, fifo_depth=depth)
+    oneshot = data.draw(st.sampled_from([0, 4096, 1 << 20]))  # direct allreduce: two-phase / one-shot
+    plans = plan_sim.get_plans(coll, algo, n, root, count, 8, channels, piece, fifo_depth=depth,
+                               oneshot_bytes=oneshot)
     if coll == xmpi.COLL_ALLREDUCE:
         want = oracle.reduce_ranks(ins, oracle.I64, oracle.SUM)
         got = plan_sim.simulate(plans, ins, count, np.int64, xmpi.SUM, depth, seed=seed)
@@ -42,10 +44,12 @@ def test_any_schedule_matches_oracle(coll, n, count, piece, channels, depth, see
 
 
 @settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.too_slow])
-@given(n=st.integers(2, 8), count=st.integers(1, 2000), piece=st.integers(2, 500), seed=st.integers(0, 10 ** 6))
-def test_direct_fold_is_bitwise_rank_order_for_floats(n, count, piece, seed):
+@given(n=st.integers(2, 8), count=st.integers(1, 2000), piece=st.integers(2, 500), seed=st.integers(0, 10 ** 6),
+       oneshot=st.sampled_from([0, 2048, 1 << 20]))
+def test_direct_fold_is_bitwise_rank_order_for_floats(n, count, piece, seed, oneshot):
     ins = [oracle.fill(count, oracle.F32, 3, seed + r) for r in range(n)]
     want = oracle.reduce_ranks(ins, oracle.F32, oracle.SUM)
-    plans = plan_sim.get_plans(xmpi.COLL_ALLREDUCE, xmpi.ALGO_DIRECT, n, 0, count, 4, 1, piece)
+    plans = plan_sim.get_plans(xmpi.COLL_ALLREDUCE, xmpi.ALGO_DIRECT, n, 0, count, 4, 1, piece,
+                               oneshot_bytes=oneshot)
     got = plan_sim.simulate(plans, ins, count, np.float32, xmpi.SUM, 2, seed=seed)
     assert all(g.tobytes() == want.tobytes() for g in got)
