@@ -43,7 +43,7 @@ from mpi_amd import xmpi  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s
 XGMI_LINK_GBPS = 153.0   # per-link peak (bidirectional), task statement
-ALGO_NAME = {xmpi.ALGO_RING: "ring", xmpi.ALGO_RHD: "rhd", xmpi.ALGO_DIRECT: "direct"}
+ALGO_NAME = {xmpi.ALGO_RING: "ring", xmpi.ALGO_RHD: "rhd", xmpi.ALGO_DIRECT: "direct", xmpi.ALGO_ZCOPY: "zcopy"}
 DT = {"f32": xmpi.F32, "f16": xmpi.F16, "f64": xmpi.F64, "bf16": xmpi.BF16, "i64": xmpi.I64}
 
 
@@ -55,7 +55,7 @@ def parse_args():
     ap.add_argument("--ranks", type=int, default=0, help="total ranks (default 8 when it divides by --gpus)")
     ap.add_argument("--size-mib", type=float, default=256.0, help="bytes per rank")
     ap.add_argument("--dtype", default="f32", choices=sorted(DT))
-    ap.add_argument("--algo", default="auto", choices=["auto", "ring", "rhd", "direct"])
+    ap.add_argument("--algo", default="auto", choices=["auto", "ring", "rhd", "direct", "zcopy"])
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed sweeps after the timed region")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU reference-path baseline")
     ap.add_argument("--cpu-count", type=int, default=16 << 20,
@@ -180,8 +180,10 @@ def rank_main(job: Job, grank: int):
             cands = [(xmpi.ALGO_RING, 1, 0)]
         slot = comm.get_param("slot_bytes")
         pieces = sorted({0, slot}) if R > 1 else [0]  # 0 = library heuristic (~4 pieces per chunk)
+        if R > 1:
+            cands.append((xmpi.ALGO_ZCOPY, 1, 0))  # no staging: channels / engine / piece size do not apply
         for algo, ch, eng in cands:
-            for pc in pieces:
+            for pc in (pieces if algo != xmpi.ALGO_ZCOPY else [0]):
                 comm.set_param("channels", ch)
                 comm.set_param("copy_engine", eng)
                 comm.set_param("piece_bytes", pc)
@@ -224,7 +226,7 @@ def rank_main(job: Job, grank: int):
                 oks.append(ok)
                 worst = max(worst, err)
             ok_here = all(oks)
-            info = {"checked": True, "ok": ok_here, "max_abs_err": worst,
+            info = {"checked": True, "ok": ok_here, "max_abs_err": worst, "bit_identical": worst == 0.0 and ok_here,
                     "rule": "bit-exact" if dtype == xmpi.F16 else "|delta| <= 1e-6 * sum_i|x_i| vs rank-order oracle"}
         if all_max(comm, 0.0 if ok_here else 1.0) == 0.0:
             parity, chosen, best = info, cand, cand
@@ -237,9 +239,11 @@ def rank_main(job: Job, grank: int):
     comm.prof_reset()
     # every 4th launch of a kind carries its own begin/end events (hipExtLaunchKernelGGL): the events are
     # exact per dispatch whatever runs around them, and sampling keeps their cost out of `value`
-    comm.set_param("prof_every", 4)
+    # (a zero-copy step is ONE launch per rank: all of them carry events)
+    comm.set_param("prof_every", 1 if algo == xmpi.ALGO_ZCOPY else 4)
     t_step = timed(comm, lambda: run(algo), a.steps, prof=True)
-    prof = {k: comm.prof_get(k) for k in (xmpi.PROF_REDUCE2, xmpi.PROF_REDUCEN, xmpi.PROF_COPY, xmpi.PROF_PEER)}
+    prof = {k: comm.prof_get(k) for k in (xmpi.PROF_REDUCE2, xmpi.PROF_REDUCEN, xmpi.PROF_COPY, xmpi.PROF_PEER,
+                                          xmpi.PROF_ZCOPY)}
 
     # the same kernel with the GPU to itself (rank 0 only, everybody else parked at a barrier):
     # one ring-step chunk (S / R) per launch
@@ -249,13 +253,22 @@ def rank_main(job: Job, grank: int):
         chunk = max(1, count // R)
         comm.prof_reset()
         comm.prof_enable(True)
-        for j in range(24):  # walk the chunks: operands are cold, as they are inside the collective
-            k = j % R
-            comm.reduce_local(recv.at(k * chunk * es), send.at(k * chunk * es), send.at(((k + 1) % R) * chunk * es),
-                              chunk, dtype, xmpi.SUM)
-        n_i, ms_i, by_i = comm.prof_get(xmpi.PROF_REDUCE2)
+        comm.set_param("prof_every", 1)
+        if algo == xmpi.ALGO_ZCOPY:  # the same N-source, N-destination launch, all operands local
+            for j in range(12):
+                comm.reduce_local_multi([recv.at(((k + j) % R) * chunk * es) for k in range(R)],
+                                        [send.at(((k + j) % R) * chunk * es) for k in range(R)], chunk, dtype, xmpi.SUM)
+            n_i, ms_i, by_i = comm.prof_get(xmpi.PROF_ZCOPY)
+            iso_name = "reduce_n_multi_kernel (R local sources -> R local destinations, GPU otherwise idle)"
+        else:
+            for j in range(24):  # walk the chunks: operands are cold, as they are inside the collective
+                k = j % R
+                comm.reduce_local(recv.at(k * chunk * es), send.at(k * chunk * es), send.at(((k + 1) % R) * chunk * es),
+                                  chunk, dtype, xmpi.SUM)
+            n_i, ms_i, by_i = comm.prof_get(xmpi.PROF_REDUCE2)
+            iso_name = "reduce2_kernel (one ring-step chunk, GPU otherwise idle)"
         comm.prof_enable(False)
-        iso = {"kernel": "reduce2_kernel (one ring-step chunk, GPU otherwise idle)", "bytes_per_launch": by_i / n_i,
+        iso = {"kernel": iso_name, "bytes_per_launch": by_i / n_i,
                "avg_launch_us": ms_i * 1e3 / n_i, "achieved": by_i / (ms_i * 1e-3) / 1e9, "unit": "GB/s",
                "frac": by_i / (ms_i * 1e-3) / 1e9 / HBM_PEAK_GBPS}
     comm.barrier()
@@ -273,7 +286,7 @@ def rank_main(job: Job, grank: int):
             comm.set_param("piece_bytes", cand.get("piece_bytes", 0))
 
         extras["algos_at_size"] = {}
-        for al in (xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_DIRECT):
+        for al in (xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_DIRECT, xmpi.ALGO_ZCOPY):
             if al == xmpi.ALGO_RHD and R & (R - 1):
                 continue
             mine = [x for x in tune if x["algo"] == ALGO_NAME[al]]
@@ -292,7 +305,7 @@ def rank_main(job: Job, grank: int):
         while sz <= min(nbytes, 1 << 30):
             cnt = sz // es
             row = {"bytes": sz}
-            for al in (xmpi.ALGO_RING, xmpi.ALGO_DIRECT):
+            for al in (xmpi.ALGO_RING, xmpi.ALGO_DIRECT, xmpi.ALGO_ZCOPY):
                 run(al, cnt)
                 t = timed(comm, lambda: run(al, cnt), 5 if sz <= (16 << 20) else 2)
                 row[ALGO_NAME[al] + "_us"] = t * 1e6
@@ -320,9 +333,11 @@ def rank_main(job: Job, grank: int):
         # BASELINE cfg 3 shape: allgather int64, 16 MiB per rank
         cnt3 = min(2097152, nbytes // 8 // R)
         if cnt3 > 0:
-            t = timed(comm, lambda: comm.allgather(send, recv, cnt3, xmpi.I64, xmpi.ALGO_RING), 3)
-            extras["allgather_i64"] = {"bytes_per_rank": cnt3 * 8, "ms": t * 1e3,
-                                       "busbw_GBps": cnt3 * 8 * R / t / 1e9 * (R - 1) / R}
+            extras["allgather_i64"] = {"bytes_per_rank": cnt3 * 8}
+            for al in (xmpi.ALGO_RING, xmpi.ALGO_ZCOPY):
+                comm.allgather(send, recv, cnt3, xmpi.I64, al)
+                t = timed(comm, lambda: comm.allgather(send, recv, cnt3, xmpi.I64, al), 3)
+                extras["allgather_i64"][ALGO_NAME[al]] = {"ms": t * 1e3, "busbw_GBps": cnt3 * 8 * R / t / 1e9 * (R - 1) / R}
         # BASELINE cfg 5: allreduce-sum fp16, 1 GiB per rank, ring vs recursive halving (exactly summable
         # inputs k/64: both must be bit-identical to the rank-order result)
         if dtype == xmpi.F32 and nbytes >= (256 << 20):
@@ -331,7 +346,7 @@ def rank_main(job: Job, grank: int):
             comm.fill(s5, n5, xmpi.F16, xmpi.PAT_UNIFORM, 2000 + grank)
             comm.allreduce(s5, ref5, n5, xmpi.F16, xmpi.SUM, xmpi.ALGO_DIRECT)
             cfg5 = {"bytes_per_rank": n5 * 2}
-            for al in (xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_DIRECT):
+            for al in (xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_DIRECT, xmpi.ALGO_ZCOPY):
                 if al == xmpi.ALGO_RHD and R & (R - 1):
                     continue
                 comm.allreduce(s5, r5, n5, xmpi.F16, xmpi.SUM, al)
@@ -418,7 +433,11 @@ def main():
     busbw = algbw * 2 * (R - 1) / R
     n2, ms2, b2 = r0["prof"][xmpi.PROF_REDUCE2]
     nn, msn, bn = r0["prof"][xmpi.PROF_REDUCEN]
-    if ms2 >= msn and n2:
+    nz, msz, bz = r0["prof"][xmpi.PROF_ZCOPY]
+    if nz and msz >= max(ms2, msn):
+        kname, launches, ms, by = (f"reduce_n_multi_kernel<float,SUM,{R}> (zero-copy allreduce: folds chunk j of the {R} send "
+                                   f"buffers in rank order, stores it into the {R} receive buffers)"), nz, msz, bz
+    elif ms2 >= msn and n2:
         kname, launches, ms, by = ("reduce2_batch_kernel<float,SUM> (fused ring step: a + slot -> next rank's slot [+ local]) / "
                                    "reduce2_kernel<float,SUM>"), n2, ms2, b2
     elif nn:
@@ -447,7 +466,8 @@ def main():
             "algorithmic_bytes_per_launch": (by / launches) if launches else None,
             "note": "live HIP events on the kernel's own stream inside the timed region (rank 0's launches); "
                     "algorithmic bytes: 12 B per output element for reduce2 (2 reads + 1 write), (N+1) x 4 B for the "
-                    "N-way fold; every 4th launch of the kind carries events attached to its dispatch"}
+                    "N-way fold, 2N x 4 B for the zero-copy fold (N reads + N writes); sampled launches carry events "
+                    "attached to their dispatch (every launch for zero-copy, every 4th otherwise)"}
     # the other kernels of the timed region (same per-dispatch events): slot drains and peer pushes
     others = {}
     for kind, label, factor in ((xmpi.PROF_COPY, "copy-out of receive slots (copy16 / copy_batch)", 1.0),

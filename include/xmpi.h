@@ -49,7 +49,9 @@ typedef enum {
   XMPI_ALGO_RHD = 2,    /* recursive halving (reduce-scatter) + doubling (allgather) */
   XMPI_ALGO_DIRECT = 3, /* full-mesh one-hop reduce-scatter + allgather; rank-order sum */
   XMPI_ALGO_TREE = 4,   /* binary tree (bcast / reduce)                              */
-  XMPI_ALGO_COUNT = 5
+  XMPI_ALGO_ZCOPY = 5,  /* zero-copy: one kernel folds straight out of the peers' registered
+                           buffers (rank order) and stores straight into them; no staging  */
+  XMPI_ALGO_COUNT = 6
 } xmpi_algo;
 
 /* error codes */
@@ -94,8 +96,18 @@ const char* xmpi_version(void);
 
 /* ---- HBM buffers ------------------------------------------------------------------------ */
 
+/* HBM of this rank's device.  Buffers from xmpi_malloc are REGISTERED: peers may map them
+ * (hipIpc) so the zero-copy collectives can read and write them in place over xGMI.  The
+ * reference has no counterpart (its payloads are Go values, network.go:539); the Go shim wraps
+ * these in its DeviceBuffer type. */
 void* xmpi_malloc(xmpi_comm* comm, size_t bytes);
 int xmpi_free(xmpi_comm* comm, void* dptr);
+/* Register / forget device memory that was NOT allocated by xmpi_malloc (e.g. a framework's
+ * allocator): [dptr, dptr+bytes) must lie inside one hipMalloc allocation of this rank's device.
+ * Deregister before that allocation is freed.  Unregistered buffers still work with every
+ * collective -- through the staged (window) path. */
+int xmpi_register(xmpi_comm* comm, void* dptr, size_t bytes);
+int xmpi_deregister(xmpi_comm* comm, void* dptr);
 /* Blocking copy between any two of {host, this rank's HBM}. */
 int xmpi_memcpy(xmpi_comm* comm, void* dst, const void* src, size_t bytes);
 int xmpi_memset(xmpi_comm* comm, void* dst, int byte, size_t bytes);
@@ -153,6 +165,11 @@ int xmpi_reduce_local_n(xmpi_comm* comm, void* dst, const void* const* srcs, int
                         size_t count, xmpi_dtype dtype, xmpi_op op);
 /* dst = src through the library's streaming copy kernel. */
 int xmpi_copy_local(xmpi_comm* comm, void* dst, const void* src, size_t bytes);
+/* The kernels of the zero-copy collectives, on local buffers: every dsts[k][i] = left-to-right fold
+ * of srcs[.][i] (one pass: nsrc reads + ndst writes per element), and dsts[k] = src. */
+int xmpi_reduce_local_multi(xmpi_comm* comm, void* const* dsts, int ndst, const void* const* srcs,
+                            int nsrc, size_t count, xmpi_dtype dtype, xmpi_op op);
+int xmpi_copy_local_multi(xmpi_comm* comm, void* const* dsts, int ndst, const void* src, size_t bytes);
 
 /* Verification kernels (LDS + wavefront-shuffle reductions; replace bytes.Equal /
  * floats.Equal of examples/bounce/bounce.go:105,133 for HBM-resident data). */
@@ -178,7 +195,7 @@ long xmpi_get_param(const xmpi_comm* comm, const char* name);
 
 /* Kernel profiling: when enabled every reduction / copy kernel launch is bracketed by HIP
  * events on the stream it runs on.  kind: 0 = reduce2, 1 = reduceN, 2 = copy kernel,
- * 3 = peer copy (hipMemcpyAsync or kernel push). */
+ * 3 = peer copy (hipMemcpyAsync or kernel push), 4 = zero-copy fold / multi-destination copy. */
 int xmpi_prof_enable(xmpi_comm* comm, int on);
 int xmpi_prof_reset(xmpi_comm* comm);
 int xmpi_prof_get(xmpi_comm* comm, int kind, uint64_t* launches, double* total_ms,
@@ -199,6 +216,10 @@ int xmpi_ctl_selftest(const char* job_key, int rank, int size, int rounds);
  * would run for (coll, algo, size, rank, count) as text into out; returns needed length. */
 int xmpi_plan_dump(int coll, int algo, int size, int rank, int root, size_t count,
                    size_t elem_size, int channels, size_t piece_elems, char* out, size_t cap);
+
+/* Chunk j of a count-element buffer cut for `size` ranks the way the zero-copy collectives cut it
+ * (16-byte aligned boundaries): element offset and length.  Host logic only. */
+int xmpi_zc_chunk(size_t count, size_t elem_size, int size, int j, size_t* elem_off, size_t* elem_cnt);
 
 size_t xmpi_dtype_size(xmpi_dtype dtype);
 

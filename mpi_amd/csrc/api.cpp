@@ -129,6 +129,15 @@ static int collective(xmpi_comm* c, int coll, int algo, int root, const void* se
     return XMPI_ERR_ARG;
   }
   std::lock_guard<std::mutex> g(c->coll_mu);
+  // Zero-copy first (zcopy.cpp): when every rank's buffers are registered HBM one kernel per rank does
+  // the whole collective in place.  Whether that holds is decided collectively, so either every rank
+  // returns from here or every rank goes on to the staged schedule below.
+  if (c->size > 1 && (algo == XMPI_ALGO_ZCOPY || (algo == XMPI_ALGO_AUTO && c->zero_copy))) {
+    bool done = false;
+    int zrc = zero_copy_collective(c, coll, root, sendbuf, recvbuf, count, dtype, op, &done);
+    if (zrc != XMPI_OK || done) return zrc;
+  }
+  if (algo == XMPI_ALGO_ZCOPY) algo = XMPI_ALGO_AUTO;
   PlanParams pp;
   pp.coll = coll;
   pp.algo = algo;
@@ -280,6 +289,8 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   c->batch_copies = env_long("XMPI_BATCH_COPIES", 1) ? 1 : 0;
   c->fuse_ring = env_long("XMPI_FUSE_RING", 1) ? 1 : 0;
   c->oneshot_bytes = std::max<long>(0, env_long("XMPI_ONESHOT_BYTES", 1 << 20));
+  c->zero_copy = env_long("XMPI_ZERO_COPY", 1) ? 1 : 0;
+  c->zc_bcast_push_bytes = std::max<long>(0, env_long("XMPI_ZC_BCAST_PUSH_BYTES", 256 << 10));
   if (getenv("XMPI_KERNEL_MODE")) set_kernel_mode((int)env_long("XMPI_KERNEL_MODE", -1));
   if (getenv("XMPI_GRID_CAP")) set_grid_cap((int)env_long("XMPI_GRID_CAP", 0));
   c->coll_region_bytes = (size_t)size * c->lanes * c->fifo_depth * c->slot_bytes;
@@ -402,6 +413,7 @@ int xmpi_finalize(xmpi_comm* c) {
   (void)hipDeviceSynchronize();
   // nobody may still be writing into a window that is about to be unmapped
   if (!c->ctl->aborted()) (void)c->ctl->barrier(c->timeout_s > 0 ? (double)c->timeout_s : 3600.0);
+  zc_close_peers(c);
   for (int p = 0; p < c->size; p++) {
     if (c->peer_opened[p]) ipc_close_shared(c->peer_window[p]);
     if (c->shared_stream) continue;  // the per-device shared stream outlives communicators
@@ -446,12 +458,45 @@ void* xmpi_malloc(xmpi_comm* c, size_t bytes) {
     hip_fail(hipGetLastError(), "hipMalloc", __FILE__, __LINE__);
     return nullptr;
   }
+  registry_add(p, bytes ? bytes : 1, c->device);
   return p;
 }
 
 int xmpi_free(xmpi_comm* c, void* p) {
   XMPI_ENTER(c);
-  if (p) XMPI_HIP(hipFree(p));
+  if (p) {
+    registry_remove(c, p);
+    XMPI_HIP(hipFree(p));
+  }
+  return XMPI_OK;
+}
+
+int xmpi_register(xmpi_comm* c, void* p, size_t bytes) {
+  XMPI_ENTER(c);
+  hipDeviceptr_t base = nullptr;
+  size_t size = 0;
+  if (!p || !is_device_pointer(p) || hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) != hipSuccess) {
+    (void)hipGetLastError();
+    set_last_error("register: not a device allocation");
+    return XMPI_ERR_ARG;
+  }
+  if ((char*)p + bytes > (char*)base + size) {
+    set_last_error("register: the range runs past its allocation");
+    return XMPI_ERR_ARG;
+  }
+  return registry_add((void*)base, size, c->device);
+}
+
+int xmpi_deregister(xmpi_comm* c, void* p) {
+  XMPI_ENTER(c);
+  hipDeviceptr_t base = nullptr;
+  size_t size = 0;
+  if (!p || hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) != hipSuccess) {
+    (void)hipGetLastError();
+    registry_remove(c, p);
+    return XMPI_OK;
+  }
+  registry_remove(c, (void*)base);
   return XMPI_OK;
 }
 
@@ -603,6 +648,41 @@ int xmpi_copy_local(xmpi_comm* c, void* dst, const void* src, size_t bytes) {
                       &ctx);
 }
 
+int xmpi_reduce_local_multi(xmpi_comm* c, void* const* dsts, int ndst, const void* const* srcs, int nsrc, size_t count,
+                            xmpi_dtype dtype, xmpi_op op) {
+  XMPI_ENTER(c);
+  const size_t es = xmpi_dtype_size(dtype);
+  if (!es || op < 0 || op >= XMPI_OP_COUNT || nsrc < 1 || nsrc > kMaxReduceSrcs || ndst < 1 || ndst > kMaxReduceSrcs)
+    return XMPI_ERR_ARG;
+  struct Ctx { xmpi_comm* c; void* const* d; int nd; const void* const* s; int ns; size_t n; int dt, op; }
+      ctx{c, dsts, ndst, srcs, nsrc, count, (int)dtype, (int)op};
+  return timed_launch(c, PROF_ZCOPY, (size_t)(nsrc + ndst) * count * es,
+                      [](void* p, hipEvent_t es, hipEvent_t ee) {
+                        Ctx* x = (Ctx*)p;
+                        return launch_reduce_n_multi(x->d, x->nd, x->s, x->ns, x->n, x->dt, x->op, x->c->local_stream,
+                                                     es, ee);
+                      },
+                      &ctx);
+}
+
+int xmpi_copy_local_multi(xmpi_comm* c, void* const* dsts, int ndst, const void* src, size_t bytes) {
+  XMPI_ENTER(c);
+  if (ndst < 1 || ndst > kMaxReduceSrcs) return XMPI_ERR_ARG;
+  struct Ctx { xmpi_comm* c; void* const* d; int nd; const void* src; size_t n; } ctx{c, dsts, ndst, src, bytes};
+  return timed_launch(c, PROF_ZCOPY, (size_t)(1 + ndst) * bytes,
+                      [](void* p, hipEvent_t es, hipEvent_t ee) {
+                        Ctx* x = (Ctx*)p;
+                        return launch_copy_multi(x->d, x->nd, x->src, x->n, x->c->local_stream, es, ee);
+                      },
+                      &ctx);
+}
+
+int xmpi_zc_chunk(size_t count, size_t elem_size, int size, int j, size_t* elem_off, size_t* elem_cnt) {
+  if (!elem_off || !elem_cnt || size < 1 || j < 0 || j >= size || elem_size < 1) return XMPI_ERR_ARG;
+  zc_chunk(count, elem_size, size, j, elem_off, elem_cnt);
+  return XMPI_OK;
+}
+
 int xmpi_count_mismatch(xmpi_comm* c, const void* a, const void* b, size_t bytes, uint64_t* out) {
   XMPI_ENTER(c);
   if (!out) return XMPI_ERR_ARG;
@@ -667,6 +747,8 @@ int xmpi_set_param(xmpi_comm* c, const char* name, long value) {
   else if (n == "batch_copies") c->batch_copies = value ? 1 : 0;
   else if (n == "fuse_ring") c->fuse_ring = value ? 1 : 0;
   else if (n == "oneshot_bytes") c->oneshot_bytes = std::max<long>(0, value);
+  else if (n == "zero_copy") c->zero_copy = value ? 1 : 0;
+  else if (n == "zc_bcast_push_bytes") c->zc_bcast_push_bytes = std::max<long>(0, value);
   else if (n == "kernel_mode") set_kernel_mode((int)value);  // process-wide
   else if (n == "grid_cap") set_grid_cap((int)value);        // process-wide
   else return XMPI_ERR_ARG;
@@ -681,6 +763,8 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
   if (n == "copy_engine") return c->copy_engine;
   if (n == "timeout_s") return c->timeout_s;
   if (n == "dep_mode") return c->dep_mode;
+  if (n == "zero_copy") return c->zero_copy;
+  if (n == "zc_seq") return (long)c->zc_seq;
   if (n == "shared_stream") return c->shared_stream ? 1 : 0;
   if (n == "kernel_mode") return get_kernel_mode();
   if (n == "last_run_us") return (long)c->last_run_us;
@@ -820,7 +904,7 @@ int xmpi_plan_dump(int coll, int algo, int size, int rank, int root, size_t coun
                    size_t piece_elems, char* out, size_t cap) {
   PlanParams pp;
   pp.coll = coll;
-  pp.algo = algo;
+  pp.algo = (algo == XMPI_ALGO_ZCOPY) ? (int)XMPI_ALGO_AUTO : algo;  // the staged schedule zero-copy falls back to
   pp.size = size;
   pp.rank = rank;
   pp.root = root;

@@ -30,7 +30,7 @@ struct ProfCounter {
   uint64_t bytes = 0;
 };
 
-enum ProfKind { PROF_REDUCE2 = 0, PROF_REDUCEN = 1, PROF_COPY = 2, PROF_PEER = 3, PROF_KINDS = 4 };
+enum ProfKind { PROF_REDUCE2 = 0, PROF_REDUCEN = 1, PROF_COPY = 2, PROF_PEER = 3, PROF_ZCOPY = 4, PROF_KINDS = 5 };
 
 }  // namespace xmpi
 
@@ -62,6 +62,12 @@ struct xmpi_comm {
   hipStream_t recv_stream[xmpi::kMaxRanks] = {nullptr};
   hipStream_t local_stream = nullptr;
   hipStream_t batch_send_stream = nullptr, batch_recv_stream = nullptr;  // multi-destination copy launches
+  // zero-copy collectives (zcopy.cpp): registered user buffers are read / written in place by peers
+  long zero_copy = 1;            // AUTO may choose the zero-copy path (all buffers registered HBM)
+  long zc_bcast_push_bytes = 256 << 10;  // bcast up to this size: root pushes to everyone; above: scatter + allgather
+  uint64_t zc_seq = 0;           // zero-copy attempts so far (same on every rank)
+  std::set<std::pair<uint64_t, uint64_t>> zc_announced;  // {base, gen} already published on this communicator
+  uint64_t zc_retired_seen[xmpi::kMaxRanks] = {0};       // how far each peer's retire log has been processed
   long oneshot_bytes = 1 << 20;  // direct allreduce up to this size: push everything, fold locally
   long fuse_ring = 1;    // ring: receive-reduce-send / receive-copy-send as one kernel
   long batch_copies = 1;  // with the copy kernel: all ready SENDs (RECV_COPYs) go out in one launch
@@ -111,6 +117,13 @@ int run_plan(xmpi_comm* c, const Plan& plan, const void* sendbuf, void* recvbuf,
 int p2p_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, int tag);
 int p2p_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int tag, size_t* got_bytes);
 int p2p_probe(xmpi_comm* c, int src, int tag, size_t* bytes, int* dtype);
+// zcopy.cpp.  *done = false: some rank's buffers are not registered HBM -- every rank saw that and
+// the caller runs the staged schedule instead (no rank is left behind: the decision is collective).
+int zero_copy_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void* recvbuf, size_t count,
+                         int dtype, int op, bool* done);
+int registry_add(void* base, size_t bytes, int device);
+void registry_remove(xmpi_comm* c, void* base);
+void zc_close_peers(const xmpi_comm* c);
 hipEvent_t ev_get(xmpi_comm* c, bool timed);
 void ev_put(xmpi_comm* c, hipEvent_t e, bool timed);
 bool is_device_pointer(const void* p);

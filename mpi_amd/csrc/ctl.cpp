@@ -70,6 +70,8 @@ size_t Ctl::layout_bytes(int size) {
   b += sizeof(RankInfo) * (size_t)size;
   b += sizeof(PipeCtl) * (size_t)size * size * kMaxLanes;
   b += sizeof(MailEntry) * (size_t)size * size * kMailEntries;
+  b += sizeof(BufDesc) * (size_t)size * 2;
+  b += sizeof(RetireLog) * (size_t)size;
   return (b + 4095) / 4096 * 4096;
 }
 
@@ -140,7 +142,7 @@ int Ctl::join(const std::string& key, int rank, int size, const CtlConfig& cfg, 
     }
     memset(base, 0, bytes);  // every counter, state and flag starts at zero
     CtlHeader* h = new (base) CtlHeader;
-    h->version = 1;
+    h->version = 2;
     h->size = size;
     h->total_bytes = bytes;
     h->creator_pid = (int32_t)getpid();
@@ -191,7 +193,7 @@ int Ctl::join(const std::string& key, int rank, int size, const CtlConfig& cfg, 
         const int cp = h->creator_pid;
         const bool alive = (kill(cp, 0) == 0 || errno == EPERM) && proc_start_time(cp) == h->creator_start;
         ok = alive && h->size == size && h->total_bytes == bytes && h->abort_code.load() == 0 &&
-             h->version == 1;
+             h->version == 2;
       }
       if (ok) {
         base = m;
@@ -218,6 +220,10 @@ int Ctl::join(const std::string& key, int rank, int size, const CtlConfig& cfg, 
   c->pipes_ = reinterpret_cast<PipeCtl*>(p);
   p += sizeof(PipeCtl) * (size_t)size * size * kMaxLanes;
   c->mail_ = reinterpret_cast<MailEntry*>(p);
+  p += sizeof(MailEntry) * (size_t)size * size * kMailEntries;
+  c->desc_ = reinterpret_cast<BufDesc*>(p);
+  p += sizeof(BufDesc) * (size_t)size * 2;
+  c->retire_ = reinterpret_cast<RetireLog*>(p);
 
   RankInfo* me = c->info(rank);
   if (me->state.load() != 0) {  // two processes claim the same rank

@@ -54,6 +54,35 @@ struct alignas(64) RankInfo {
   char busid[32];
 };
 
+// What a rank tells its peers about the user buffers of one zero-copy collective: enough for a
+// peer to map them (hipIpc) and address the same bytes.  Two descriptors per rank, used alternately
+// (a rank may publish the next collective's while a slower peer still reads the current one).
+struct BufRef {
+  uint64_t base;    // allocation base VA in the owner's process (0 = no buffer)
+  uint64_t gen;     // owner's registration number of that allocation (a re-used VA gets a new one)
+  uint64_t offset;  // of the user pointer inside the allocation
+  uint64_t bytes;   // of the allocation
+  uint8_t handle[64];
+};
+
+struct alignas(64) BufDesc {
+  std::atomic<uint64_t> seq;  // which zero-copy collective of this communicator the content belongs to
+  int32_t ok;     // 1 = both buffers are registered HBM of this rank's device
+  int32_t fresh;  // 1 = an allocation named here was not announced on this communicator before
+  std::atomic<int32_t> verdict;  // after mapping the peers' buffers: 1 = all mapped, -1 = failed
+  int32_t reserved;
+  BufRef send, recv;
+};
+
+// Registered allocations a rank has freed since the job began (their `gen`s, in order).  A peer that
+// mapped one must unmap it before it maps anything new of that rank: the runtime may hand the same
+// hipIpc handle to a later allocation, and a mapping of the dead one would shadow it.
+constexpr int kRetireRing = 512;
+struct alignas(64) RetireLog {
+  std::atomic<uint64_t> count;  // entries ever appended; entry k lives in gen[k % kRetireRing]
+  uint64_t gen[kRetireRing];
+};
+
 struct CtlConfig {
   int32_t lanes;        // FIFO lanes per ordered pair for collectives
   int32_t fifo_depth;   // slots per collective pipe
@@ -89,6 +118,8 @@ class Ctl {
   RankInfo* info(int r) { return &ranks_[r]; }
   PipeCtl* pipe(int src, int dst, int lane) { return &pipes_[((size_t)src * size_ + dst) * kMaxLanes + lane]; }
   MailEntry* mail(int src, int dst, int e) { return &mail_[((size_t)src * size_ + dst) * kMailEntries + e]; }
+  BufDesc* desc(int r, uint64_t seq) { return &desc_[(size_t)r * 2 + (size_t)(seq & 1)]; }
+  RetireLog* retired(int r) { return &retire_[r]; }
   void* base() const { return base_; }
   size_t bytes() const { return bytes_; }
 
@@ -115,6 +146,8 @@ class Ctl {
   RankInfo* ranks_ = nullptr;
   PipeCtl* pipes_ = nullptr;
   MailEntry* mail_ = nullptr;
+  BufDesc* desc_ = nullptr;
+  RetireLog* retire_ = nullptr;
   bool creator_ = false;
 };
 

@@ -35,6 +35,16 @@ hipError_t launch_reduce2_batch(void* const* dst, void* const* dst2, const void*
                                 const size_t* counts, int n, int dtype, int op, hipStream_t stream,
                                 hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
+// The zero-copy collective kernels.  Every dsts[k][i] = left-to-right fold of srcs[.][i]: one pass,
+// nsrc reads + ndst writes per element; sources and destinations may be local HBM or peers' buffers
+// (reads / writes over xGMI).  dsts[k] may alias srcs[j] exactly.  nsrc, ndst <= kMaxReduceSrcs.
+hipError_t launch_reduce_n_multi(void* const* dsts, int ndst, const void* const* srcs, int nsrc, size_t count,
+                                 int dtype, int op, hipStream_t stream, hipEvent_t ev_start = nullptr,
+                                 hipEvent_t ev_stop = nullptr);
+// every dsts[k] = src (one read, ndst writes); entries equal to src are skipped
+hipError_t launch_copy_multi(void* const* dsts, int ndst, const void* src, size_t bytes, hipStream_t stream,
+                             hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+
 // *d_out += number of differing bytes (d_out: 8-byte device word, caller zeroes it)
 hipError_t launch_count_mismatch(const void* a, const void* b, size_t bytes, uint64_t* d_out,
                                  hipStream_t stream);

@@ -283,6 +283,104 @@ __global__ __launch_bounds__(kBlock) void reduce_n_kernel(T* dst, SrcPtrs srcs, 
   }
 }
 
+// ---- zero-copy collective kernels: fold N rank buffers once, store the result M times ----------
+// The sources are the ranks' own send buffers (one local, the others read over xGMI), the
+// destinations the ranks' receive buffers (one local, the others written over xGMI): rank j runs
+// this on chunk j, which is the whole allreduce for that chunk -- N reads + N writes per element and
+// no staging copy anywhere.  Same lane reads element i of every source before it stores element i
+// anywhere, so a destination may alias a source (in-place collectives).
+
+struct MultiPtrs {
+  const void* src[kMaxReduceSrcs];
+  void* dst[kMaxReduceSrcs];
+};
+
+template <typename T, int OP, int NSRC, int MODE>
+__global__ __launch_bounds__(kBlock) void reduce_n_multi_kernel(MultiPtrs q, int nsrc_rt, int ndst,
+                                                                size_t npack, size_t count) {
+  const int nsrc = (NSRC > 0) ? NSRC : nsrc_rt;
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < npack; i += stride) {
+    pack_t acc;
+    if constexpr (NSRC > 0) {
+      pack_t v[NSRC];
+#pragma unroll
+      for (int s = 0; s < NSRC; s++) v[s] = ldp<MODE>(reinterpret_cast<const pack_t*>(q.src[s]) + i);
+      acc = v[0];
+#pragma unroll
+      for (int s = 1; s < NSRC; s++) acc = combine16<T, OP>(acc, v[s]);
+    } else {
+      acc = reinterpret_cast<const pack_t*>(q.src[0])[i];
+      for (int s = 1; s < nsrc; s++) acc = combine16<T, OP>(acc, reinterpret_cast<const pack_t*>(q.src[s])[i]);
+    }
+    for (int k = 0; k < ndst; k++) reinterpret_cast<pack_t*>(q.dst[k])[i] = acc;
+  }
+  constexpr size_t N = 16 / sizeof(T);
+  const size_t done = npack * N;
+  if (blockIdx.x == 0 && done + threadIdx.x < count) {
+    const size_t i = done + threadIdx.x;
+    T acc = reinterpret_cast<const T*>(q.src[0])[i];
+    for (int s = 1; s < nsrc; s++) acc = combine_any<T, OP>(acc, reinterpret_cast<const T*>(q.src[s])[i]);
+    for (int k = 0; k < ndst; k++) reinterpret_cast<T*>(q.dst[k])[i] = acc;
+  }
+}
+
+// any alignment: one element per lane per iteration
+template <typename T, int OP>
+__global__ __launch_bounds__(kBlock) void reduce_n_multi_elem_kernel(MultiPtrs q, int nsrc, int ndst, size_t count) {
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride) {
+    T acc = reinterpret_cast<const T*>(q.src[0])[i];
+    for (int s = 1; s < nsrc; s++) acc = combine_any<T, OP>(acc, reinterpret_cast<const T*>(q.src[s])[i]);
+    for (int k = 0; k < ndst; k++) reinterpret_cast<T*>(q.dst[k])[i] = acc;
+  }
+}
+
+// every dst[k] = src[0]: one read, ndst writes (allgather / bcast push to all peers at once)
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void copy_multi_kernel(MultiPtrs q, int ndst, size_t npack, size_t bytes) {
+  const pack_t* src = reinterpret_cast<const pack_t*>(q.src[0]);
+  constexpr size_t kTile = (size_t)kBlock * kUnroll;
+  const size_t stride = (size_t)gridDim.x * kTile;
+  const size_t lane_off = (size_t)(threadIdx.x >> 6) * (64 * kUnroll) + (threadIdx.x & 63);
+  for (size_t base = (size_t)blockIdx.x * kTile; base < npack; base += stride) {
+    const size_t first = base + lane_off;
+    if (base + kTile <= npack) {
+      pack_t v[kUnroll];
+#pragma unroll
+      for (int k = 0; k < kUnroll; k++) v[k] = ldp<MODE>(src + first + k * 64);
+      for (int d = 0; d < ndst; d++) {
+        pack_t* pd = reinterpret_cast<pack_t*>(q.dst[d]);
+#pragma unroll
+        for (int k = 0; k < kUnroll; k++) pd[first + k * 64] = v[k];
+      }
+    } else {
+      for (int k = 0; k < kUnroll; k++) {
+        const size_t i = first + k * 64;
+        if (i < npack) {
+          const pack_t v = src[i];
+          for (int d = 0; d < ndst; d++) reinterpret_cast<pack_t*>(q.dst[d])[i] = v;
+        }
+      }
+    }
+  }
+  const size_t done = npack * 16;
+  if (blockIdx.x == 0 && done + threadIdx.x < bytes) {
+    const size_t i = done + threadIdx.x;
+    const uint8_t v = reinterpret_cast<const uint8_t*>(src)[i];
+    for (int d = 0; d < ndst; d++) reinterpret_cast<uint8_t*>(q.dst[d])[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void copy_multi_elem_kernel(MultiPtrs q, int ndst, size_t bytes) {
+  const uint8_t* src = reinterpret_cast<const uint8_t*>(q.src[0]);
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < bytes; i += stride) {
+    const uint8_t v = src[i];
+    for (int d = 0; d < ndst; d++) reinterpret_cast<uint8_t*>(q.dst[d])[i] = v;
+  }
+}
+
 // ---- streaming copy --------------------------------------------------------------------------
 
 template <int MODE>
@@ -736,11 +834,9 @@ hipError_t launch_reduce_n(void* dst, const void* const* srcs, int nsrc, size_t 
   SrcPtrs p;
   for (int i = 0; i < kMaxReduceSrcs; i++) p.p[i] = (i < nsrc) ? srcs[i] : nullptr;
   for (int i = 0; i < nsrc; i++) ok = ok && aligned16(srcs[i]);
-  if (!ok) {  // odd alignment: chain the element kernel (same left-to-right order)
-    hipError_t e = launch_reduce2(dst, srcs[0], srcs[1], count, dtype, op, s, es, nsrc == 2 ? ee : nullptr);
-    for (int i = 2; i < nsrc && e == hipSuccess; i++)
-      e = launch_reduce2(dst, dst, srcs[i], count, dtype, op, s, nullptr, i == nsrc - 1 ? ee : nullptr);
-    return e;
+  if (!ok) {  // odd alignment: the element kernel (same left-to-right order; dst may alias any source)
+    void* d1[1] = {dst};
+    return launch_reduce_n_multi(d1, 1, srcs, nsrc, count, dtype, op, s, es, ee);
   }
   switch (dtype) {
     case DT_U8: return reduce_n_op<uint8_t>(dst, p, nsrc, count, op, s, es, ee);
@@ -893,6 +989,109 @@ hipError_t launch_copy_batch(void* const* dst, void* const* dst2, const void* co
   if (mode == 1) XMPI_LAUNCH(copy_batch_kernel<1>, dim3(gx, n), dim3(kBlock), s, es, ee, b);
   else if (mode == 2) XMPI_LAUNCH(copy_batch_kernel<2>, dim3(gx, n), dim3(kBlock), s, es, ee, b);
   else XMPI_LAUNCH(copy_batch_kernel<0>, dim3(gx, n), dim3(kBlock), s, es, ee, b);
+  return hipGetLastError();
+}
+
+namespace {
+template <typename T, int OP>
+hipError_t reduce_n_multi_typed(const MultiPtrs& q, int nsrc, int ndst, size_t count, bool vec, hipStream_t s,
+                                hipEvent_t es, hipEvent_t ee) {
+  if (!vec) {
+    XMPI_LAUNCH((reduce_n_multi_elem_kernel<T, OP>), dim3(grid_for(count, kBlock)), dim3(kBlock), s, es, ee, q, nsrc,
+                ndst, count);
+    return hipGetLastError();
+  }
+  constexpr size_t N = 16 / sizeof(T);
+  const size_t npack = count / N;
+  const int grid = grid_for(npack, kBlock);
+  const int mode = kernel_mode_for((size_t)(nsrc + ndst) * count * sizeof(T));
+#define XMPI_RNM(NS)                                                                                              \
+  case NS:                                                                                                        \
+    if (mode != 0)                                                                                                \
+      XMPI_LAUNCH((reduce_n_multi_kernel<T, OP, NS, 2>), dim3(grid), dim3(kBlock), s, es, ee, q, nsrc, ndst, npack, \
+                  count);                                                                                         \
+    else                                                                                                          \
+      XMPI_LAUNCH((reduce_n_multi_kernel<T, OP, NS, 0>), dim3(grid), dim3(kBlock), s, es, ee, q, nsrc, ndst, npack, \
+                  count);                                                                                         \
+    break;
+  switch (nsrc) {
+    XMPI_RNM(1) XMPI_RNM(2) XMPI_RNM(3) XMPI_RNM(4) XMPI_RNM(5) XMPI_RNM(6) XMPI_RNM(7) XMPI_RNM(8)
+    default:
+      XMPI_LAUNCH((reduce_n_multi_kernel<T, OP, 0, 0>), dim3(grid), dim3(kBlock), s, es, ee, q, nsrc, ndst, npack,
+                  count);
+      break;
+  }
+#undef XMPI_RNM
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t reduce_n_multi_op(const MultiPtrs& q, int nsrc, int ndst, size_t count, bool vec, int op, hipStream_t s,
+                             hipEvent_t es, hipEvent_t ee) {
+  switch (op) {
+    case OP_SUM: return reduce_n_multi_typed<T, OP_SUM>(q, nsrc, ndst, count, vec, s, es, ee);
+    case OP_PROD: return reduce_n_multi_typed<T, OP_PROD>(q, nsrc, ndst, count, vec, s, es, ee);
+    case OP_MIN: return reduce_n_multi_typed<T, OP_MIN>(q, nsrc, ndst, count, vec, s, es, ee);
+    case OP_MAX: return reduce_n_multi_typed<T, OP_MAX>(q, nsrc, ndst, count, vec, s, es, ee);
+    default: return hipErrorInvalidValue;
+  }
+}
+}  // namespace
+
+hipError_t launch_reduce_n_multi(void* const* dsts, int ndst, const void* const* srcs, int nsrc, size_t count,
+                                 int dtype, int op, hipStream_t s, hipEvent_t es, hipEvent_t ee) {
+  if (nsrc < 1 || nsrc > kMaxReduceSrcs || ndst < 0 || ndst > kMaxReduceSrcs) return hipErrorInvalidValue;
+  if (count == 0 || ndst == 0) {
+    if (es) (void)hipEventRecord(es, s);
+    if (ee) (void)hipEventRecord(ee, s);
+    return hipSuccess;
+  }
+  MultiPtrs q;
+  bool vec = true;
+  for (int i = 0; i < kMaxReduceSrcs; i++) {
+    q.src[i] = (i < nsrc) ? srcs[i] : nullptr;
+    q.dst[i] = (i < ndst) ? dsts[i] : nullptr;
+    vec = vec && aligned16(q.src[i]) && aligned16(q.dst[i]);
+  }
+  switch (dtype) {
+    case DT_U8: return reduce_n_multi_op<uint8_t>(q, nsrc, ndst, count, vec, op, s, es, ee);
+    case DT_I32: return reduce_n_multi_op<int32_t>(q, nsrc, ndst, count, vec, op, s, es, ee);
+    case DT_I64: return reduce_n_multi_op<int64_t>(q, nsrc, ndst, count, vec, op, s, es, ee);
+    case DT_F16: return reduce_n_multi_op<_Float16>(q, nsrc, ndst, count, vec, op, s, es, ee);
+    case DT_F32: return reduce_n_multi_op<float>(q, nsrc, ndst, count, vec, op, s, es, ee);
+    case DT_F64: return reduce_n_multi_op<double>(q, nsrc, ndst, count, vec, op, s, es, ee);
+    case DT_BF16: return reduce_n_multi_op<bf16_t>(q, nsrc, ndst, count, vec, op, s, es, ee);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_copy_multi(void* const* dsts, int ndst, const void* src, size_t bytes, hipStream_t s,
+                             hipEvent_t es, hipEvent_t ee) {
+  if (ndst < 0 || ndst > kMaxReduceSrcs) return hipErrorInvalidValue;
+  MultiPtrs q;
+  for (int i = 0; i < kMaxReduceSrcs; i++) q.src[i] = q.dst[i] = nullptr;
+  q.src[0] = src;
+  int n = 0;
+  bool vec = aligned16(src);
+  for (int i = 0; i < ndst; i++)
+    if (dsts[i] != src) {  // in-place entry: nothing to move
+      q.dst[n++] = dsts[i];
+      vec = vec && aligned16(dsts[i]);
+    }
+  if (bytes == 0 || n == 0) {
+    if (es) (void)hipEventRecord(es, s);
+    if (ee) (void)hipEventRecord(ee, s);
+    return hipSuccess;
+  }
+  if (!vec) {
+    XMPI_LAUNCH(copy_multi_elem_kernel, dim3(grid_for(bytes, kBlock)), dim3(kBlock), s, es, ee, q, n, bytes);
+    return hipGetLastError();
+  }
+  const size_t npack = bytes / 16;
+  const int grid = grid_for(npack + 1, (size_t)kBlock * kUnroll);
+  const int mode = kernel_mode_for((size_t)(1 + n) * bytes);
+  if (mode != 0) XMPI_LAUNCH(copy_multi_kernel<2>, dim3(grid), dim3(kBlock), s, es, ee, q, n, npack, bytes);
+  else XMPI_LAUNCH(copy_multi_kernel<0>, dim3(grid), dim3(kBlock), s, es, ee, q, n, npack, bytes);
   return hipGetLastError();
 }
 

@@ -672,4 +672,11 @@ std::string plan_to_text(const Plan& plan) {
   return out;
 }
 
+void zc_chunk(size_t count, size_t elem_size, int size, int j, size_t* elem_off, size_t* elem_cnt) {
+  const std::vector<size_t> b = split_even(0, count, std::max(1, size), align_elems(std::max<size_t>(1, elem_size)));
+  const size_t k = (size_t)std::min(std::max(j, 0), std::max(1, size) - 1);
+  *elem_off = b[k];
+  *elem_cnt = b[k + 1] - b[k];
+}
+
 }  // namespace xmpi

@@ -84,4 +84,8 @@ void ring_order(int size, int channel, std::vector<int>* order);
 
 std::string plan_to_text(const Plan& plan);
 
+// Chunk j of a count-element buffer cut for `size` ranks with 16-byte aligned boundaries (the cut of
+// the zero-copy collectives: rank j folds / forwards chunk j): element offset and length.
+void zc_chunk(size_t count, size_t elem_size, int size, int j, size_t* elem_off, size_t* elem_cnt);
+
 }  // namespace xmpi

@@ -17,10 +17,10 @@ LIB_PATH = os.path.join(_HERE, "libxmpi.so")
 # enums of include/xmpi.h
 U8, I32, I64, F16, F32, F64, BF16 = range(7)
 SUM, PROD, MIN, MAX = range(4)
-ALGO_AUTO, ALGO_RING, ALGO_RHD, ALGO_DIRECT, ALGO_TREE = range(5)
+ALGO_AUTO, ALGO_RING, ALGO_RHD, ALGO_DIRECT, ALGO_TREE, ALGO_ZCOPY = range(6)
 COLL_ALLREDUCE, COLL_ALLGATHER, COLL_BCAST, COLL_REDUCE = range(4)
 PAT_UNIFORM, PAT_INDEX, PAT_CONST, PAT_SIGNED = range(4)
-PROF_REDUCE2, PROF_REDUCEN, PROF_COPY, PROF_PEER = range(4)
+PROF_REDUCE2, PROF_REDUCEN, PROF_COPY, PROF_PEER, PROF_ZCOPY = range(5)
 
 OK = 0
 ERR_ARG, ERR_HIP, ERR_BOOTSTRAP, ERR_TIMEOUT, ERR_TAG_EXISTS, ERR_TRUNCATE = -1, -2, -3, -4, -5, -6
@@ -71,6 +71,11 @@ SYMBOLS = [
     ("xmpi_ctl_selftest", _I, [C.c_char_p, _I, _I, _I]),
     ("xmpi_plan_dump", _I, [_I, _I, _I, _I, _I, _Z, _Z, _I, _Z, C.c_char_p, _Z]),
     ("xmpi_dtype_size", _Z, [_I]),
+    ("xmpi_register", _I, [_P, _P, _Z]),
+    ("xmpi_deregister", _I, [_P, _P]),
+    ("xmpi_reduce_local_multi", _I, [_P, C.POINTER(_P), _I, C.POINTER(_P), _I, _Z, _I, _I]),
+    ("xmpi_copy_local_multi", _I, [_P, C.POINTER(_P), _I, _P, _Z]),
+    ("xmpi_zc_chunk", _I, [_Z, _Z, _I, _I, C.POINTER(_Z), C.POINTER(_Z)]),
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -115,6 +120,15 @@ def plan_text(coll: int, algo: int, size: int, rank: int, root: int, count: int,
     buf = C.create_string_buffer(n + 1)
     L.xmpi_plan_dump(coll, algo, size, rank, root, count, elem_size, channels, piece_elems, buf, n + 1)
     return buf.value.decode()
+
+
+def zc_chunk(count: int, elem_size: int, size: int, j: int):
+    """(element offset, element count) of the chunk rank j folds / forwards in a zero-copy collective."""
+    off, cnt = _Z(0), _Z(0)
+    rc = lib().xmpi_zc_chunk(count, elem_size, size, j, C.byref(off), C.byref(cnt))
+    if rc != OK:
+        raise XmpiError(rc, "xmpi_zc_chunk")
+    return off.value, cnt.value
 
 
 class DeviceBuffer:
@@ -235,6 +249,24 @@ class Comm:
 
     def copy_local(self, dst, src, nbytes: int) -> None:
         _check(lib().xmpi_copy_local(self.handle, _ptr(dst), _ptr(src), nbytes), "copy_local")
+
+    def reduce_local_multi(self, dsts: Sequence, srcs: Sequence, count: int, dtype: int, op: int = SUM) -> None:
+        """Every dsts[k] = left-to-right fold of srcs (the zero-copy allreduce kernel, on local buffers)."""
+        d = (_P * len(dsts))(*[_ptr(x) for x in dsts])
+        s = (_P * len(srcs))(*[_ptr(x) for x in srcs])
+        _check(lib().xmpi_reduce_local_multi(self.handle, d, len(dsts), s, len(srcs), count, dtype, op),
+               "reduce_local_multi")
+
+    def copy_local_multi(self, dsts: Sequence, src, nbytes: int) -> None:
+        d = (_P * len(dsts))(*[_ptr(x) for x in dsts])
+        _check(lib().xmpi_copy_local_multi(self.handle, d, len(dsts), _ptr(src), nbytes), "copy_local_multi")
+
+    def register(self, ptr, nbytes: int) -> None:
+        """Make device memory that did not come from alloc() reachable by the zero-copy collectives."""
+        _check(lib().xmpi_register(self.handle, _ptr(ptr), nbytes), "xmpi_register")
+
+    def deregister(self, ptr) -> None:
+        _check(lib().xmpi_deregister(self.handle, _ptr(ptr)), "xmpi_deregister")
 
     def count_mismatch(self, a, b, nbytes: int) -> int:
         out = C.c_uint64(0)

@@ -21,7 +21,10 @@ def check_reduced(got: np.ndarray, ins, dtype: int, op: int, exact: bool, what: 
         return
     if exact or dtype not in FLOATS or op in (xmpi.MIN, xmpi.MAX):
         bad = oracle.count_mismatch(got, want)
-        assert bad == 0, f"{what}: {bad} bytes differ from the rank-order oracle"
+        if bad:
+            idx = np.nonzero(got.view(np.uint8).reshape(got.size, -1) != want.view(np.uint8).reshape(want.size, -1))[0]
+            raise AssertionError(f"{what}: {bad} bytes differ from the rank-order oracle; elements {idx.min()}..{idx.max()} "
+                                 f"of {got.size} ({np.unique(idx).size} elements), e.g. got {got[idx[0]]!r} want {want[idx[0]]!r}")
         return
     g, w = oracle.as_float64(got, dtype), oracle.as_float64(want, dtype)
     if op == xmpi.SUM:
@@ -53,7 +56,7 @@ def allreduce_case(comm, dtype, count, algo, op=xmpi.SUM, pattern=xmpi.PAT_UNIFO
     got = recv.download(xmpi.NUMPY_DTYPE[dtype], count)
     if exact is None:
         # rank-order algorithms and exactly-summable inputs must be bit-identical
-        exact = algo == xmpi.ALGO_DIRECT or size <= 2 or pattern in (xmpi.PAT_CONST,) or (
+        exact = algo in (xmpi.ALGO_DIRECT, xmpi.ALGO_ZCOPY, xmpi.ALGO_AUTO) or size <= 2 or pattern in (xmpi.PAT_CONST,) or (
             dtype in (xmpi.F16, xmpi.BF16) and pattern in (xmpi.PAT_UNIFORM, xmpi.PAT_INDEX) and op == xmpi.SUM)
     check_reduced(got, ins, dtype, op, exact,
                   f"allreduce {xmpi.DTYPE_NAME[dtype]} n={count} algo={algo} op={op} pat={pattern} inplace={inplace}")
@@ -145,13 +148,14 @@ def sc_bcast_reduce(comm, args):
     for root in sorted({0, size - 1, size // 2}):
         for dtype, count in ((xmpi.U8, 1), (xmpi.I64, 4099), (xmpi.F32, (1 << 20) + 9), (xmpi.F16, 0)):
             es = xmpi.DTYPE_SIZE[dtype]
-            buf = comm.alloc(count * es)
-            comm.fill(buf, count, dtype, xmpi.PAT_UNIFORM, 40 + rank)
-            comm.bcast(buf, count, dtype, root)
-            got = buf.download(xmpi.NUMPY_DTYPE[dtype], count)
-            want = oracle.fill(count, dtype, xmpi.PAT_UNIFORM, 40 + root)
-            assert got.tobytes() == want.tobytes(), f"bcast root={root} {xmpi.DTYPE_NAME[dtype]} n={count}"
-            buf.free()
+            for algo in (xmpi.ALGO_TREE, xmpi.ALGO_AUTO):
+                buf = comm.alloc(count * es)
+                comm.fill(buf, count, dtype, xmpi.PAT_UNIFORM, 40 + rank)
+                comm.bcast(buf, count, dtype, root, algo)
+                got = buf.download(xmpi.NUMPY_DTYPE[dtype], count)
+                want = oracle.fill(count, dtype, xmpi.PAT_UNIFORM, 40 + root)
+                assert got.tobytes() == want.tobytes(), f"bcast root={root} {xmpi.DTYPE_NAME[dtype]} n={count} algo={algo}"
+                buf.free()
         for algo in (xmpi.ALGO_TREE, xmpi.ALGO_DIRECT):
             for dtype, count, pat in ((xmpi.F32, 100003, xmpi.PAT_SIGNED), (xmpi.I64, 4099, xmpi.PAT_UNIFORM),
                                       (xmpi.F16, 5001, xmpi.PAT_UNIFORM), (xmpi.F64, 1, xmpi.PAT_SIGNED)):
@@ -173,6 +177,106 @@ def sc_bcast_reduce(comm, args):
     comm.allreduce(x, out, 1000, xmpi.F32, xmpi.SUM, xmpi.ALGO_DIRECT)
     want = oracle.reduce_ranks([oracle.fill(1000, xmpi.F32, xmpi.PAT_UNIFORM, 5 + r) for r in range(size)], xmpi.F32, 0)
     assert out.tobytes() == want.tobytes()
+
+
+def _zc_launches(comm) -> int:
+    return comm.prof_get(xmpi.PROF_ZCOPY)[0]
+
+
+def sc_zero_copy(comm, args):
+    """Zero-copy collectives (zcopy.cpp): kernels read and write the peers' registered buffers in place.
+    Rank-order fold => every result is bit-identical to the oracle, for every dtype and operator."""
+    rank, size = comm.rank(), comm.size()
+    Z = xmpi.ALGO_ZCOPY
+    comm.prof_enable(True)
+    comm.set_param("prof_every", 1)
+    before = _zc_launches(comm)
+    for dtype in (xmpi.F32, xmpi.I64, xmpi.F16, xmpi.F64, xmpi.I32, xmpi.U8, xmpi.BF16):
+        for count in args.get("counts", [0, 1, 3, 17, 1000, 4099, 65536 + 5]):
+            allreduce_case(comm, dtype, count, Z, exact=True)
+    allreduce_case(comm, xmpi.F32, (3 << 20) + 7, Z, pattern=xmpi.PAT_SIGNED, exact=True)
+    allreduce_case(comm, xmpi.F32, (3 << 20) + 7, xmpi.ALGO_AUTO, pattern=xmpi.PAT_SIGNED, inplace=True, exact=True)
+    for op in (xmpi.PROD, xmpi.MIN, xmpi.MAX):
+        for dtype in (xmpi.F32, xmpi.I32, xmpi.F16, xmpi.BF16):
+            allreduce_case(comm, dtype, 3001, Z, op=op, pattern=xmpi.PAT_SIGNED, exact=True)
+    allreduce_case(comm, xmpi.F64, 50001, Z, pattern=xmpi.PAT_SIGNED, inplace=True, exact=True)
+    # the big allreduce gave every rank a chunk: the zero-copy kernel ran here (not a silent fallback)
+    assert _zc_launches(comm) > before, "zero-copy path did not run"
+
+    # buffers at odd element offsets: the element-wise kernel, still in place in the peers' memory
+    for dtype, count in ((xmpi.F32, 10007), (xmpi.F16, 4099), (xmpi.U8, 1001)):
+        es = xmpi.DTYPE_SIZE[dtype]
+        send, recv = comm.alloc((count + 3) * es), comm.alloc((count + 3) * es)
+        comm.fill(send.at(es), count, dtype, xmpi.PAT_SIGNED, 300 + rank)
+        comm.allreduce(send.at(es), recv.at(2 * es), count, dtype, xmpi.SUM, Z)
+        ins = [oracle.fill(count, dtype, xmpi.PAT_SIGNED, 300 + r) for r in range(size)]
+        got = recv.download(xmpi.NUMPY_DTYPE[dtype], count, byte_offset=2 * es)
+        check_reduced(got, ins, dtype, xmpi.SUM, True, f"zero-copy unaligned {xmpi.DTYPE_NAME[dtype]}")
+        send.free()
+        recv.free()
+
+    for dtype in (xmpi.I64, xmpi.U8, xmpi.F32):
+        for count in (0, 1, 5, 1000, 4099, (1 << 20) + 3):
+            allgather_case(comm, dtype, count, Z)
+    allgather_case(comm, xmpi.I64, 70001, Z, inplace=True)
+
+    for push_bytes in (256 << 10, 0):  # root pushes to everyone / scatter + allgather of the chunks
+        comm.set_param("zc_bcast_push_bytes", push_bytes)
+        for root in sorted({0, size - 1, size // 2}):
+            for dtype, count in ((xmpi.U8, 1), (xmpi.U8, 37), (xmpi.I64, 4099), (xmpi.F32, (1 << 20) + 9), (xmpi.F16, 0)):
+                es = xmpi.DTYPE_SIZE[dtype]
+                buf = comm.alloc(count * es)
+                comm.fill(buf, count, dtype, xmpi.PAT_UNIFORM, 40 + rank)
+                comm.bcast(buf, count, dtype, root, Z)
+                got = buf.download(xmpi.NUMPY_DTYPE[dtype], count)
+                want = oracle.fill(count, dtype, xmpi.PAT_UNIFORM, 40 + root)
+                assert got.tobytes() == want.tobytes(), f"zero-copy bcast root={root} {xmpi.DTYPE_NAME[dtype]} n={count}"
+                buf.free()
+    comm.set_param("zc_bcast_push_bytes", 256 << 10)
+
+    for root in sorted({0, size - 1, size // 2}):
+        for dtype, count, pat in ((xmpi.F32, 100003, xmpi.PAT_SIGNED), (xmpi.I64, 4099, xmpi.PAT_UNIFORM),
+                                  (xmpi.F16, 5001, xmpi.PAT_SIGNED), (xmpi.F64, 1, xmpi.PAT_SIGNED)):
+            for inplace_root in (False, True):
+                es = xmpi.DTYPE_SIZE[dtype]
+                send = comm.alloc(count * es)
+                recv = send if (inplace_root and rank == root) else comm.alloc(count * es)
+                comm.fill(send, count, dtype, pat, 70 + rank)
+                comm.reduce(send, recv if rank == root else None, count, dtype, xmpi.SUM, root, Z)
+                if rank == root:
+                    ins = [oracle.fill(count, dtype, pat, 70 + r) for r in range(size)]
+                    got = recv.download(xmpi.NUMPY_DTYPE[dtype], count)
+                    check_reduced(got, ins, dtype, xmpi.SUM, True,
+                                  f"zero-copy reduce root={root} {xmpi.DTYPE_NAME[dtype]} n={count} inplace={inplace_root}")
+                if recv is not send:
+                    recv.free()
+                send.free()
+
+    # buffers the peers cannot map: every rank falls back to the staged schedule, together
+    n0 = _zc_launches(comm)
+    x = oracle.fill(1000, xmpi.F32, xmpi.PAT_UNIFORM, 5 + rank)
+    out = np.zeros_like(x)
+    comm.allreduce(x, out, 1000, xmpi.F32, xmpi.SUM, Z)  # host memory
+    want = oracle.reduce_ranks([oracle.fill(1000, xmpi.F32, xmpi.PAT_UNIFORM, 5 + r) for r in range(size)], xmpi.F32, 0)
+    assert out.tobytes() == want.tobytes()
+    count = 20011
+    send, recv = comm.alloc(count * 4), comm.alloc(count * 4)
+    comm.fill(send, count, xmpi.F32, xmpi.PAT_SIGNED, 900 + rank)
+    ins = [oracle.fill(count, xmpi.F32, xmpi.PAT_SIGNED, 900 + r) for r in range(size)]
+    if rank == size - 1:
+        comm.deregister(recv)  # one rank's buffer is not registered: nobody may take the zero-copy path
+    comm.allreduce(send, recv, count, xmpi.F32, xmpi.SUM, Z)
+    check_reduced(recv.download(np.float32, count), ins, xmpi.F32, xmpi.SUM, True, "fallback (unregistered)")
+    assert _zc_launches(comm) == n0, "zero-copy kernel ran although a peer's buffer was not registered"
+    if rank == size - 1:
+        comm.register(recv, count * 4)
+    comm.memset(recv, 0, count * 4)
+    comm.allreduce(send, recv, count, xmpi.F32, xmpi.SUM, Z)
+    check_reduced(recv.download(np.float32, count), ins, xmpi.F32, xmpi.SUM, True, "re-registered")
+    assert _zc_launches(comm) > n0 or xmpi.zc_chunk(count, 4, size, rank)[1] == 0
+    send.free()
+    recv.free()
+    comm.prof_enable(False)
 
 
 # ---- point to point ------------------------------------------------------------------------------
@@ -349,7 +453,7 @@ def sc_fullsize(comm, args):
         comm.fill(send, count, xmpi.I64, xmpi.PAT_INDEX, rank)
         for r in range(size):
             comm.fill(want.at(r * count * 8), count, xmpi.I64, xmpi.PAT_INDEX, r)
-        for algo in (xmpi.ALGO_RING, xmpi.ALGO_DIRECT):
+        for algo in (xmpi.ALGO_RING, xmpi.ALGO_DIRECT, xmpi.ALGO_ZCOPY):
             comm.memset(recv, 0, count * 8 * size)
             comm.allgather(send, recv, count, xmpi.I64, algo)
             assert comm.count_mismatch(recv, want, count * 8 * size) == 0
@@ -394,6 +498,15 @@ def sc_fullsize(comm, args):
     # idempotence of the data path: the same call again gives the same bits
     comm.allreduce(send, out, count, dtype, xmpi.SUM, xmpi.ALGO_DIRECT)
     assert comm.count_mismatch(out, ref, count * es) == 0
+    # zero-copy folds in rank order too: bit-identical to DIRECT (hence to the oracle), f32 included;
+    # AUTO picks it for registered buffers; in place it must not read what a peer already overwrote
+    for algo in (xmpi.ALGO_ZCOPY, xmpi.ALGO_AUTO):
+        comm.memset(out, 0, count * es)
+        comm.allreduce(send, out, count, dtype, xmpi.SUM, algo)
+        assert comm.count_mismatch(out, ref, count * es) == 0, f"{which} algo {algo}: not bit-identical to rank order"
+    comm.copy_local(out, send, count * es)
+    comm.allreduce(out, out, count, dtype, xmpi.SUM, xmpi.ALGO_ZCOPY)
+    assert comm.count_mismatch(out, ref, count * es) == 0, f"{which}: in-place zero-copy differs"
 
 
 def np_hash(seed: int, idx: np.ndarray) -> np.ndarray:
@@ -425,4 +538,5 @@ SCENARIOS = {
     "helloworld": sc_helloworld,
     "p2p_semantics": sc_p2p_semantics,
     "fullsize": sc_fullsize,
+    "zero_copy": sc_zero_copy,
 }

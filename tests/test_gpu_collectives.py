@@ -55,6 +55,23 @@ def test_bcast_reduce(size):
     run_ranks("bcast_reduce", size, timeout=600)
 
 
+@pytest.mark.parametrize("size", [2, 3, 8])
+def test_zero_copy_processes(size):
+    """zero-copy collectives between processes: the peers' user buffers are mapped through hipIpc and
+    read / written in place; every result bit-identical to the rank-order oracle"""
+    run_ranks("zero_copy", size, timeout=600)
+
+
+def test_zero_copy_threads():
+    """ranks hosted by threads of one process use each other's pointers directly"""
+    run_threads("zero_copy", 4, {"counts": [1, 17, 4099, 65536 + 5]})
+
+
+def test_zero_copy_disabled_by_param():
+    """XMPI_ZERO_COPY=0: AUTO keeps to the staged schedules"""
+    run_ranks("allreduce_small", 2, {"counts": [1, 4099], "dtypes": [4]}, timeout=300, env={"XMPI_ZERO_COPY": "0"})
+
+
 @pytest.mark.parametrize("size", [2, 4])
 def test_bounce(size):
     """examples/bounce/bounce.go at its own message lengths + BASELINE cfg 2 (1 MiB f32)"""

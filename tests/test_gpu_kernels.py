@@ -93,6 +93,65 @@ def test_reduce_n_is_left_to_right(comm, dtype, nsrc):
             x.free()
 
 
+@pytest.mark.parametrize("dtype", [xmpi.F32, xmpi.F16, xmpi.I64, xmpi.BF16, xmpi.U8])
+@pytest.mark.parametrize("nsrc,ndst", [(1, 1), (2, 2), (3, 1), (4, 4), (8, 8), (8, 1), (5, 7), (12, 3)])
+def test_reduce_n_multi_fold_once_store_many(comm, dtype, nsrc, ndst):
+    """the zero-copy allreduce kernel: every destination gets the left-to-right fold; a destination may be
+    one of the sources (in place); odd offsets take the element path"""
+    es = xmpi.DTYPE_SIZE[dtype]
+    for count, shift in ((1, 0), (1000, 0), (65536 + 7, 0), (10007, 1)):
+        ins = [oracle.fill(count, dtype, xmpi.PAT_SIGNED, 100 + r) for r in range(nsrc)]
+        bufs = [comm.alloc((count + 2) * es) for _ in ins]
+        for b, x in zip(bufs, ins):
+            b.upload(x, byte_offset=shift * es)
+        outs = [comm.alloc((count + 2) * es + 16) for _ in range(ndst - 1)]
+        for o in outs:
+            comm.memset(o, 0xEE, (count + 2) * es + 16)
+        inplace = bufs[min(1, nsrc - 1)]  # the last destination aliases a source
+        for op in (xmpi.SUM, xmpi.MIN):
+            bufs[min(1, nsrc - 1)].upload(ins[min(1, nsrc - 1)], byte_offset=shift * es)
+            dsts = [o.at(shift * es) for o in outs] + [inplace.at(shift * es)]
+            comm.reduce_local_multi(dsts, [b.at(shift * es) for b in bufs], count, dtype, op)
+            want = oracle.reduce_ranks(ins, dtype, op)
+            for o in outs + [inplace]:
+                got = o.download(xmpi.NUMPY_DTYPE[dtype], count, byte_offset=shift * es)
+                assert got.tobytes() == want.tobytes(), (xmpi.DTYPE_NAME[dtype], nsrc, ndst, count, op)
+            for o in outs:
+                guard = o.download(np.uint8, 16, byte_offset=(shift + count) * es)
+                assert np.all(guard == 0xEE), "kernel wrote past the end"
+        for x in bufs + outs:
+            x.free()
+
+
+@pytest.mark.parametrize("ndst", [1, 2, 7, 15])
+def test_copy_multi(comm, ndst):
+    for n, shift in ((1, 0), (4099, 0), ((3 << 20) + 13, 0), (100001, 3)):
+        a = oracle.fill(n + 8, xmpi.U8, xmpi.PAT_UNIFORM, 5)
+        src = comm.alloc(n + 8).upload(a)
+        outs = [comm.alloc(n + 24) for _ in range(ndst)]
+        for o in outs:
+            comm.memset(o, 0xEE, n + 24)
+        # the source itself may be listed (in-place allgather block): it is skipped
+        comm.copy_local_multi([o.at(shift) for o in outs] + [src.at(shift)], src.at(shift), n)
+        for o in outs:
+            got = o.download(np.uint8, n + 24)
+            assert got[shift:shift + n].tobytes() == a[shift:shift + n].tobytes()
+            assert np.all(got[:shift] == 0xEE) and np.all(got[shift + n:] == 0xEE)
+        assert src.download(np.uint8, n + 8).tobytes() == a.tobytes()
+        for x in outs + [src]:
+            x.free()
+
+
+def test_zc_chunk_partition():
+    for count, es, size in ((0, 4, 8), (1, 4, 8), (67108864, 4, 8), (4099, 8, 3), (1001, 1, 5), (17, 2, 16)):
+        pos = 0
+        for j in range(size):
+            off, cnt = xmpi.zc_chunk(count, es, size, j)
+            assert off == pos and (off * es) % 16 == 0 or cnt == 0
+            pos = off + cnt
+        assert pos == count
+
+
 def test_copy_and_verify_kernels(comm):
     n = (3 << 20) + 13
     a = oracle.fill(n, xmpi.U8, xmpi.PAT_UNIFORM, 5)

@@ -73,6 +73,28 @@ def test_allreduce_oneshot(n, count, piece, inplace):
             assert got[r].tobytes() == want.tobytes(), f"rank {r}"
 
 
+@pytest.mark.parametrize("size", [1, 2, 3, 8, 16])
+@pytest.mark.parametrize("count,es", [(0, 4), (1, 4), (67108864, 4), (4099, 8), (1001, 1), (17, 2), (536870912, 2)])
+def test_zero_copy_chunks_partition_the_buffer(size, count, es):
+    """zero-copy collectives: rank j folds / forwards chunk j; the chunks tile [0, count) in rank order,
+    every boundary 16-byte aligned, and a numpy fold over them reproduces the oracle"""
+    pos = 0
+    for j in range(size):
+        off, cnt = xmpi.zc_chunk(count, es, size, j)
+        assert off == pos
+        assert cnt == 0 or (off * es) % 16 == 0
+        pos = off + cnt
+    assert pos == count
+    if count and count <= 5000 and es in (4, 8):
+        code = oracle.F32 if es == 4 else oracle.F64
+        ins = [oracle.fill(count, code, 3, 11 + r) for r in range(size)]
+        out = np.zeros_like(ins[0])
+        for j in range(size):  # what rank j's kernel computes
+            off, cnt = xmpi.zc_chunk(count, es, size, j)
+            out[off:off + cnt] = oracle.reduce_ranks([x[off:off + cnt] for x in ins], code, oracle.SUM)
+        assert out.tobytes() == oracle.reduce_ranks(ins, code, oracle.SUM).tobytes()
+
+
 def test_allreduce_oneshot_threshold():
     """Above oneshot_bytes the two-phase form (reduce-scatter, then allgather) is used."""
     big = plan_sim.get_plans(xmpi.COLL_ALLREDUCE, xmpi.ALGO_DIRECT, 4, 0, 4096, 4, 1, 4096, oneshot_bytes=4096)
