@@ -115,15 +115,20 @@ def all_max(comm, value: float) -> float:
     return float(out[0])
 
 
-def timed(comm, fn, iters: int, prof: bool = False) -> float:
-    """barrier + device sync on both sides; max over ranks of the per-iteration time"""
+def timed(comm, fn, iters: int, prof: bool = False, batch=None) -> float:
+    """barrier + device sync on both sides; max over ranks of the per-iteration time.  batch(iters), when
+    given, runs all the iterations inside one native call (xmpi_allreduce_repeat) instead of fn() x iters:
+    the rank threads of this process then do not queue for the interpreter lock between steps."""
     comm.barrier()
     comm.sync()
     if prof:
         comm.prof_enable(True)
     t0 = time.perf_counter()
-    for _ in range(iters):
-        fn()
+    if batch is not None:
+        batch(iters)
+    else:
+        for _ in range(iters):
+            fn()
     comm.sync()
     comm.barrier()
     dt = (time.perf_counter() - t0) / iters
@@ -163,6 +168,9 @@ def rank_main(job: Job, grank: int):
     def run(algo, cnt=count, s=send, r=recv, dt=dtype):
         comm.allreduce(s, r, cnt, dt, xmpi.SUM, algo)
 
+    def run_n(algo, iters):
+        comm.allreduce_repeat(send, recv, count, dtype, xmpi.SUM, algo, iters)
+
     # ---- untimed: pick the schedule (all ranks see the same max-over-ranks times) -----------------
     tune = []
     if a.algo == "auto":
@@ -188,7 +196,7 @@ def rank_main(job: Job, grank: int):
                 comm.set_param("copy_engine", eng)
                 comm.set_param("piece_bytes", pc)
                 run(algo)
-                t = timed(comm, lambda: run(algo), 2)
+                t = timed(comm, None, 2, batch=lambda k: run_n(algo, k))
                 tune.append({"algo": ALGO_NAME[algo], "channels": ch, "copy_engine": eng, "piece_bytes": pc,
                              "ms": t * 1e3, "algbw_GBps": nbytes / t / 1e9})
         best = min(tune, key=lambda x: x["ms"])
@@ -239,9 +247,9 @@ def rank_main(job: Job, grank: int):
     comm.prof_reset()
     # every 4th launch of a kind carries its own begin/end events (hipExtLaunchKernelGGL): the events are
     # exact per dispatch whatever runs around them, and sampling keeps their cost out of `value`
-    # (a zero-copy step is ONE launch per rank: all of them carry events)
-    comm.set_param("prof_every", 1 if algo == xmpi.ALGO_ZCOPY else 4)
-    t_step = timed(comm, lambda: run(algo), a.steps, prof=True)
+    # (a zero-copy step is ONE launch per GPU process: every 2nd carries events)
+    comm.set_param("prof_every", 2 if algo == xmpi.ALGO_ZCOPY else 4)
+    t_step = timed(comm, None, a.steps, prof=True, batch=lambda k: run_n(algo, k))
     prof = {k: comm.prof_get(k) for k in (xmpi.PROF_REDUCE2, xmpi.PROF_REDUCEN, xmpi.PROF_COPY, xmpi.PROF_PEER,
                                           xmpi.PROF_ZCOPY)}
 
@@ -255,9 +263,16 @@ def rank_main(job: Job, grank: int):
         comm.prof_enable(True)
         comm.set_param("prof_every", 1)
         if algo == xmpi.ALGO_ZCOPY:  # the same N-source, N-destination launch, all operands local
-            for j in range(12):
-                comm.reduce_local_multi([recv.at(((k + j) % R) * chunk * es) for k in range(R)],
-                                        [send.at(((k + j) % R) * chunk * es) for k in range(R)], chunk, dtype, xmpi.SUM)
+            nz, _, bz = prof[xmpi.PROF_ZCOPY]
+            per = int(bz / nz / (2 * R * es)) if nz else chunk  # elements one launch of the timed region folded
+            zs = [comm.alloc(per * es) for _ in range(R)]
+            zd = [comm.alloc(per * es) for _ in range(R)]
+            for k, b in enumerate(zs):
+                comm.fill(b, per, dtype, xmpi.PAT_UNIFORM, 77 + k)
+            for j in range(6):
+                comm.reduce_local_multi(zd, zs, per, dtype, xmpi.SUM)
+            for b in zs + zd:
+                b.free()
             n_i, ms_i, by_i = comm.prof_get(xmpi.PROF_ZCOPY)
             iso_name = "reduce_n_multi_kernel (R local sources -> R local destinations, GPU otherwise idle)"
         else:
@@ -467,7 +482,7 @@ def main():
             "note": "live HIP events on the kernel's own stream inside the timed region (rank 0's launches); "
                     "algorithmic bytes: 12 B per output element for reduce2 (2 reads + 1 write), (N+1) x 4 B for the "
                     "N-way fold, 2N x 4 B for the zero-copy fold (N reads + N writes); sampled launches carry events "
-                    "attached to their dispatch (every launch for zero-copy, every 4th otherwise)"}
+                    "attached to their dispatch (every 2nd launch for zero-copy, every 4th otherwise)"}
     # the other kernels of the timed region (same per-dispatch events): slot drains and peer pushes
     others = {}
     for kind, label, factor in ((xmpi.PROF_COPY, "copy-out of receive slots (copy16 / copy_batch)", 1.0),

@@ -136,22 +136,34 @@ int xmpi_recv(xmpi_comm* comm, void* buf, size_t capacity, xmpi_dtype dtype, int
 int xmpi_probe(xmpi_comm* comm, int src, int tag, size_t* count, xmpi_dtype* dtype);
 
 /* ---- collectives (absent from the reference: mpi.go:130 is a commented-out stub, mpi.go:69-71
- *      an unused probe variable; defined here in the reference's delegate style) -------------- */
+ *      an unused probe variable; defined here in the reference's delegate style) --------------
+ * Called by every rank, in the same order, with the same count / dtype / op / root / algo.
+ * Blocking: the buffers must be complete when the call is made and may be reused when it returns.
+ * ZCOPY (and AUTO, when every rank's buffers are registered HBM -- xmpi_malloc / xmpi_register):
+ * the peers' buffers are read and written in place by one kernel per rank; floating-point folds
+ * are in rank order 0..N-1.  Buffers the peers cannot map (host memory, unregistered device
+ * memory) send every rank to the staged schedules through the HBM receive windows. */
 
-/* root's buffer replicated to every rank, bit-exact.  algo: TREE (binary tree) | AUTO. */
+/* root's buffer replicated to every rank, bit-exact.  algo: TREE (binary tree) | ZCOPY | AUTO. */
 int xmpi_bcast(xmpi_comm* comm, void* buf, size_t count, xmpi_dtype dtype, int root, int algo);
 
-/* recvbuf (significant at root only) = op over ranks of sendbuf.  algo: TREE | DIRECT | AUTO. */
+/* recvbuf (significant at root only) = op over ranks of sendbuf.  algo: TREE | DIRECT | ZCOPY | AUTO. */
 int xmpi_reduce(xmpi_comm* comm, const void* sendbuf, void* recvbuf, size_t count,
                 xmpi_dtype dtype, xmpi_op op, int root, int algo);
 
 /* recvbuf = op over ranks of sendbuf, on every rank (sendbuf == recvbuf allowed).
- * algo: RING | RHD | DIRECT | AUTO.  DIRECT sums in rank order 0..N-1 (bit-identical to the
- * reference-user composition "gather everything, add on the host in rank order"). */
+ * algo: RING | RHD | DIRECT | ZCOPY | AUTO.  DIRECT and ZCOPY sum in rank order 0..N-1 (bit-identical
+ * to the reference-user composition "gather everything, add on the host in rank order"). */
 int xmpi_allreduce(xmpi_comm* comm, const void* sendbuf, void* recvbuf, size_t count,
                    xmpi_dtype dtype, xmpi_op op, int algo);
 
-/* recvbuf[r*count : (r+1)*count] = rank r's sendbuf, bit-exact.  algo: RING | DIRECT | AUTO. */
+/* The same allreduce `iters` times back to back: the step loop of a benchmark without per-call
+ * host-language overhead (bench.py hosts several ranks as Python threads, which would otherwise
+ * queue for the interpreter lock between steps; a Go or C++ caller has no such cost). */
+int xmpi_allreduce_repeat(xmpi_comm* comm, const void* sendbuf, void* recvbuf, size_t count,
+                          xmpi_dtype dtype, xmpi_op op, int algo, int iters);
+
+/* recvbuf[r*count : (r+1)*count] = rank r's sendbuf, bit-exact.  algo: RING | DIRECT | ZCOPY | AUTO. */
 int xmpi_allgather(xmpi_comm* comm, const void* sendbuf, void* recvbuf, size_t count,
                    xmpi_dtype dtype, int algo);
 

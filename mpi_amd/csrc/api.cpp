@@ -291,6 +291,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   c->oneshot_bytes = std::max<long>(0, env_long("XMPI_ONESHOT_BYTES", 1 << 20));
   c->zero_copy = env_long("XMPI_ZERO_COPY", 1) ? 1 : 0;
   c->zc_bcast_push_bytes = std::max<long>(0, env_long("XMPI_ZC_BCAST_PUSH_BYTES", 256 << 10));
+  c->zc_group_launch = env_long("XMPI_ZC_GROUP_LAUNCH", 1) ? 1 : 0;
   if (getenv("XMPI_KERNEL_MODE")) set_kernel_mode((int)env_long("XMPI_KERNEL_MODE", -1));
   if (getenv("XMPI_GRID_CAP")) set_grid_cap((int)env_long("XMPI_GRID_CAP", 0));
   c->coll_region_bytes = (size_t)size * c->lanes * c->fifo_depth * c->slot_bytes;
@@ -585,6 +586,16 @@ int xmpi_allgather(xmpi_comm* c, const void* sendbuf, void* recvbuf, size_t coun
   return collective(c, COLL_ALLGATHER, algo, 0, sendbuf, recvbuf, count, (int)dtype, XMPI_SUM);
 }
 
+int xmpi_allreduce_repeat(xmpi_comm* c, const void* sendbuf, void* recvbuf, size_t count, xmpi_dtype dtype, xmpi_op op,
+                          int algo, int iters) {
+  XMPI_ENTER(c);
+  for (int i = 0; i < iters; i++) {
+    const int rc = collective(c, COLL_ALLREDUCE, algo, 0, sendbuf, recvbuf, count, (int)dtype, (int)op);
+    if (rc != XMPI_OK) return rc;
+  }
+  return XMPI_OK;
+}
+
 // ---- local kernels -----------------------------------------------------------------------------
 
 static int timed_launch(xmpi_comm* c, int kind, size_t bytes, hipError_t (*launch)(void*, hipEvent_t, hipEvent_t),
@@ -749,6 +760,7 @@ int xmpi_set_param(xmpi_comm* c, const char* name, long value) {
   else if (n == "oneshot_bytes") c->oneshot_bytes = std::max<long>(0, value);
   else if (n == "zero_copy") c->zero_copy = value ? 1 : 0;
   else if (n == "zc_bcast_push_bytes") c->zc_bcast_push_bytes = std::max<long>(0, value);
+  else if (n == "zc_group_launch") c->zc_group_launch = value ? 1 : 0;
   else if (n == "kernel_mode") set_kernel_mode((int)value);  // process-wide
   else if (n == "grid_cap") set_grid_cap((int)value);        // process-wide
   else return XMPI_ERR_ARG;

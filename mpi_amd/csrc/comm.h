@@ -65,7 +65,8 @@ struct xmpi_comm {
   // zero-copy collectives (zcopy.cpp): registered user buffers are read / written in place by peers
   long zero_copy = 1;            // AUTO may choose the zero-copy path (all buffers registered HBM)
   long zc_bcast_push_bytes = 256 << 10;  // bcast up to this size: root pushes to everyone; above: scatter + allgather
-  uint64_t zc_seq = 0;           // zero-copy attempts so far (same on every rank)
+  long zc_group_launch = 1;      // co-located ranks (threads on one GPU): the lowest folds all their chunks in one launch
+  uint64_t zc_seq = 0;          // zero-copy attempts so far (same on every rank)
   std::set<std::pair<uint64_t, uint64_t>> zc_announced;  // {base, gen} already published on this communicator
   uint64_t zc_retired_seen[xmpi::kMaxRanks] = {0};       // how far each peer's retire log has been processed
   long oneshot_bytes = 1 << 20;  // direct allreduce up to this size: push everything, fold locally

@@ -295,6 +295,9 @@ struct MultiPtrs {
   void* dst[kMaxReduceSrcs];
 };
 
+// The destination loop is unrolled over the maximum with a uniform guard, so all destination pointers
+// sit in SGPRs before the loop (a runtime-indexed kernarg array costs a scalar load + wait per store).
+// Result data is written once and not read again by this GPU: non-temporal stores (MODE != 0).
 template <typename T, int OP, int NSRC, int MODE>
 __global__ __launch_bounds__(kBlock) void reduce_n_multi_kernel(MultiPtrs q, int nsrc_rt, int ndst,
                                                                 size_t npack, size_t count) {
@@ -313,7 +316,9 @@ __global__ __launch_bounds__(kBlock) void reduce_n_multi_kernel(MultiPtrs q, int
       acc = reinterpret_cast<const pack_t*>(q.src[0])[i];
       for (int s = 1; s < nsrc; s++) acc = combine16<T, OP>(acc, reinterpret_cast<const pack_t*>(q.src[s])[i]);
     }
-    for (int k = 0; k < ndst; k++) reinterpret_cast<pack_t*>(q.dst[k])[i] = acc;
+#pragma unroll
+    for (int k = 0; k < kMaxReduceSrcs; k++)
+      if (k < ndst) stp<(MODE != 0) ? 1 : 0>(reinterpret_cast<pack_t*>(q.dst[k]) + i, acc);
   }
   constexpr size_t N = 16 / sizeof(T);
   const size_t done = npack * N;
@@ -349,11 +354,13 @@ __global__ __launch_bounds__(kBlock) void copy_multi_kernel(MultiPtrs q, int nds
       pack_t v[kUnroll];
 #pragma unroll
       for (int k = 0; k < kUnroll; k++) v[k] = ldp<MODE>(src + first + k * 64);
-      for (int d = 0; d < ndst; d++) {
-        pack_t* pd = reinterpret_cast<pack_t*>(q.dst[d]);
 #pragma unroll
-        for (int k = 0; k < kUnroll; k++) pd[first + k * 64] = v[k];
-      }
+      for (int d = 0; d < kMaxReduceSrcs; d++)
+        if (d < ndst) {
+          pack_t* pd = reinterpret_cast<pack_t*>(q.dst[d]);
+#pragma unroll
+          for (int k = 0; k < kUnroll; k++) stp<(MODE != 0) ? 1 : 0>(pd + first + k * 64, v[k]);
+        }
     } else {
       for (int k = 0; k < kUnroll; k++) {
         const size_t i = first + k * 64;

@@ -139,7 +139,15 @@ struct Launcher {
     hipEvent_t fin = ev_get(c, false);
     if (!fin) return XMPI_ERR_HIP;
     XMPI_HIP(hipEventRecord(fin, c->local_stream));
-    XMPI_HIP(hipEventSynchronize(fin));
+    // poll instead of hipEventSynchronize: its wake-up latency is a visible share of a small collective
+    Backoff bo;
+    for (;;) {
+      const hipError_t e = hipEventQuery(fin);
+      if (e == hipSuccess) break;
+      if (e != hipErrorNotReady) return hip_fail(e, "hipEventQuery", __FILE__, __LINE__);
+      (void)hipGetLastError();
+      bo.pause();
+    }
     ev_put(c, fin, false);
     if (start) {
       float ms = 0.f;
@@ -322,9 +330,19 @@ static int zc_run(xmpi_comm* c, int coll, int root, const void* sendbuf, void* r
   hipStream_t s = c->local_stream;
   Launcher L(c);
   if (coll == COLL_ALLREDUCE || coll == COLL_REDUCE) {
-    size_t off = 0, cnt = 0;
-    zc_chunk(count, es, N, me, &off, &cnt);
-    if (cnt > 0) {
+    // Ranks hosted by threads of this process on this GPU share one stream and one HBM: their chunks
+    // are adjacent, so the lowest of them folds the whole run in ONE launch (the others only take part
+    // in the barriers) instead of one launch each queueing behind the same runtime lock.
+    int lo = me, hi = me;  // the maximal run of consecutive co-located ranks around me
+    if (c->zc_group_launch) {
+      while (lo > 0 && c->peer_coloc[lo - 1]) lo--;
+      while (hi + 1 < N && c->peer_coloc[hi + 1]) hi++;
+    }
+    size_t off = 0, cnt = 0, off_hi = 0, cnt_hi = 0;
+    zc_chunk(count, es, N, lo, &off, &cnt);
+    zc_chunk(count, es, N, hi, &off_hi, &cnt_hi);
+    cnt = off_hi + cnt_hi - off;
+    if (me == lo && cnt > 0) {
       const void* srcs[kMaxRanks];
       void* dsts[kMaxRanks];
       for (int p = 0; p < N; p++) srcs[p] = psend[p] + off * es;

@@ -71,6 +71,7 @@ SYMBOLS = [
     ("xmpi_ctl_selftest", _I, [C.c_char_p, _I, _I, _I]),
     ("xmpi_plan_dump", _I, [_I, _I, _I, _I, _I, _Z, _Z, _I, _Z, C.c_char_p, _Z]),
     ("xmpi_dtype_size", _Z, [_I]),
+    ("xmpi_allreduce_repeat", _I, [_P, _P, _P, _Z, _I, _I, _I, _I]),
     ("xmpi_register", _I, [_P, _P, _Z]),
     ("xmpi_deregister", _I, [_P, _P]),
     ("xmpi_reduce_local_multi", _I, [_P, C.POINTER(_P), _I, C.POINTER(_P), _I, _Z, _I, _I]),
@@ -235,6 +236,11 @@ class Comm:
 
     def allreduce(self, send, recv, count: int, dtype: int, op: int = SUM, algo: int = ALGO_AUTO) -> None:
         _check(lib().xmpi_allreduce(self.handle, _ptr(send), _ptr(recv), count, dtype, op, algo), "xmpi_allreduce")
+
+    def allreduce_repeat(self, send, recv, count: int, dtype: int, op: int, algo: int, iters: int) -> None:
+        """`iters` back-to-back allreduces inside one call (a benchmark's step loop without the interpreter)."""
+        _check(lib().xmpi_allreduce_repeat(self.handle, _ptr(send), _ptr(recv), count, dtype, op, algo, iters),
+               "xmpi_allreduce_repeat")
 
     def allgather(self, send, recv, count: int, dtype: int, algo: int = ALGO_AUTO) -> None:
         _check(lib().xmpi_allgather(self.handle, _ptr(send), _ptr(recv), count, dtype, algo), "xmpi_allgather")

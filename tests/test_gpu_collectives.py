@@ -65,6 +65,8 @@ def test_zero_copy_processes(size):
 def test_zero_copy_threads():
     """ranks hosted by threads of one process use each other's pointers directly"""
     run_threads("zero_copy", 4, {"counts": [1, 17, 4099, 65536 + 5]})
+    # ... and by default the lowest of them folds everybody's chunks in one launch; without that:
+    run_threads("zero_copy", 3, {"counts": [1, 4099], "params": {"zc_group_launch": 0}})
 
 
 def test_zero_copy_disabled_by_param():
