@@ -97,7 +97,11 @@ const char* xmpi_version(void);
 /* ---- HBM buffers ------------------------------------------------------------------------ */
 
 /* HBM of this rank's device.  Buffers from xmpi_malloc are REGISTERED: peers may map them
- * (hipIpc) so the zero-copy collectives can read and write them in place over xGMI.  The
+ * (hipIpc) so the zero-copy collectives can read and write them in place over xGMI.  They are
+ * 256-byte aligned blocks of a few large arenas that stay allocated (and mapped by the peers)
+ * until the process's last communicator is finalised: allocating and freeing costs no runtime
+ * call and no re-mapping (XMPI_ARENA_MIN_BYTES / XMPI_ARENA_MAX_BYTES, default 64 MiB / 1 GiB;
+ * a larger request gets an arena of its own).  xmpi_free takes the pointer xmpi_malloc returned.  The
  * reference has no counterpart (its payloads are Go values, network.go:539); the Go shim wraps
  * these in its DeviceBuffer type. */
 void* xmpi_malloc(xmpi_comm* comm, size_t bytes);
@@ -105,7 +109,8 @@ int xmpi_free(xmpi_comm* comm, void* dptr);
 /* Register / forget device memory that was NOT allocated by xmpi_malloc (e.g. a framework's
  * allocator): [dptr, dptr+bytes) must lie inside one hipMalloc allocation of this rank's device.
  * Deregister before that allocation is freed.  Unregistered buffers still work with every
- * collective -- through the staged (window) path. */
+ * collective -- through the staged (window) path.  Memory of xmpi_malloc is registered as it is
+ * (register: no-op, deregister: XMPI_ERR_ARG). */
 int xmpi_register(xmpi_comm* comm, void* dptr, size_t bytes);
 int xmpi_deregister(xmpi_comm* comm, void* dptr);
 /* Blocking copy between any two of {host, this rank's HBM}. */

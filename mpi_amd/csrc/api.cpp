@@ -403,6 +403,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
     set_last_error("xmpi_init: barrier failed");
     return fail(rc);
   }
+  heap_comm_created();
   *out = c;
   return XMPI_OK;
 }
@@ -433,6 +434,7 @@ int xmpi_finalize(xmpi_comm* c) {
   if (c->window) (void)hipFree(c->window);
   if (c->temp) (void)hipFree(c->temp);
   if (c->dev_words) (void)hipFree(c->dev_words);
+  heap_comm_destroyed(c);  // last communicator of the process: empty arenas go back to the device
   c->ctl->info(c->rank)->state.store(3, std::memory_order_release);
   delete c->ctl;
   c->ctl = nullptr;
@@ -454,20 +456,16 @@ int xmpi_barrier(xmpi_comm* c) {
 
 void* xmpi_malloc(xmpi_comm* c, size_t bytes) {
   if (!c || c->finalized || use_device(c) != XMPI_OK) return nullptr;
-  void* p = nullptr;
-  if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
-    hip_fail(hipGetLastError(), "hipMalloc", __FILE__, __LINE__);
-    return nullptr;
-  }
-  registry_add(p, bytes ? bytes : 1, c->device);
+  void* p = heap_alloc(c->device, bytes);  // a block of a registered arena (heap.cpp)
+  if (!p) hip_fail(hipGetLastError(), "hipMalloc(arena)", __FILE__, __LINE__);
   return p;
 }
 
 int xmpi_free(xmpi_comm* c, void* p) {
   XMPI_ENTER(c);
-  if (p) {
-    registry_remove(c, p);
-    XMPI_HIP(hipFree(p));
+  if (p && !heap_free(p)) {
+    set_last_error("free: not a live buffer of xmpi_malloc");
+    return XMPI_ERR_ARG;
   }
   return XMPI_OK;
 }
@@ -485,11 +483,16 @@ int xmpi_register(xmpi_comm* c, void* p, size_t bytes) {
     set_last_error("register: the range runs past its allocation");
     return XMPI_ERR_ARG;
   }
+  if (heap_owns(p)) return XMPI_OK;  // memory of xmpi_malloc is registered as it is
   return registry_add((void*)base, size, c->device);
 }
 
 int xmpi_deregister(xmpi_comm* c, void* p) {
   XMPI_ENTER(c);
+  if (heap_owns(p)) {
+    set_last_error("deregister: memory of xmpi_malloc stays registered until xmpi_free");
+    return XMPI_ERR_ARG;
+  }
   hipDeviceptr_t base = nullptr;
   size_t size = 0;
   if (!p || hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) != hipSuccess) {
@@ -776,7 +779,14 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
   if (n == "timeout_s") return c->timeout_s;
   if (n == "dep_mode") return c->dep_mode;
   if (n == "zero_copy") return c->zero_copy;
+  if (n == "heap_arenas" || n == "heap_reserved" || n == "heap_in_use") {
+    size_t a = 0, r = 0, u = 0;
+    heap_stats(c->device, &a, &r, &u);
+    return (long)(n == "heap_arenas" ? a : n == "heap_reserved" ? r : u);
+  }
   if (n == "zc_seq") return (long)c->zc_seq;
+  if (n == "zc_fallbacks_unregistered") return (long)c->zc_fallbacks_unregistered;
+  if (n == "zc_fallbacks_unmappable") return (long)c->zc_fallbacks_unmappable;
   if (n == "shared_stream") return c->shared_stream ? 1 : 0;
   if (n == "kernel_mode") return get_kernel_mode();
   if (n == "last_run_us") return (long)c->last_run_us;

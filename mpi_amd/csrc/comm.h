@@ -66,6 +66,7 @@ struct xmpi_comm {
   long zero_copy = 1;            // AUTO may choose the zero-copy path (all buffers registered HBM)
   long zc_bcast_push_bytes = 256 << 10;  // bcast up to this size: root pushes to everyone; above: scatter + allgather
   long zc_group_launch = 1;      // co-located ranks (threads on one GPU): the lowest folds all their chunks in one launch
+  uint64_t zc_fallbacks_unregistered = 0, zc_fallbacks_unmappable = 0;  // zero-copy attempts that went staged, by reason
   uint64_t zc_seq = 0;          // zero-copy attempts so far (same on every rank)
   std::set<std::pair<uint64_t, uint64_t>> zc_announced;  // {base, gen} already published on this communicator
   uint64_t zc_retired_seen[xmpi::kMaxRanks] = {0};       // how far each peer's retire log has been processed
@@ -125,6 +126,13 @@ int zero_copy_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, 
 int registry_add(void* base, size_t bytes, int device);
 void registry_remove(xmpi_comm* c, void* base);
 void zc_close_peers(const xmpi_comm* c);
+// heap.cpp: xmpi_malloc carves buffers out of long-lived registered arenas
+void* heap_alloc(int device, size_t bytes);
+bool heap_free(void* p);
+bool heap_owns(const void* p);
+void heap_comm_created();
+void heap_comm_destroyed(xmpi_comm* c);
+void heap_stats(int device, size_t* arenas, size_t* reserved, size_t* in_use);
 hipEvent_t ev_get(xmpi_comm* c, bool timed);
 void ev_put(xmpi_comm* c, hipEvent_t e, bool timed);
 bool is_device_pointer(const void* p);

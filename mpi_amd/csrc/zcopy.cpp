@@ -21,9 +21,12 @@
 // Synchronisation is host-side through the control block: publish buffer descriptors -> barrier
 // (everyone's input is ready, everyone's output may be overwritten) -> kernel -> barrier (all
 // remote reads of my input and writes of my output have completed).
+#include <dirent.h>
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -119,6 +122,15 @@ bool fill_ref(xmpi_comm* c, const void* p, size_t need, BufRef* ref, bool* fresh
 }
 
 double tmo(const xmpi_comm* c) { return c->timeout_s > 0 ? (double)c->timeout_s : 3600.0; }
+
+int count_open_fds() {
+  int n = 0;
+  if (DIR* d = opendir("/proc/self/fd")) {
+    while (readdir(d)) n++;
+    closedir(d);
+  }
+  return n;
+}
 
 // launch + wait; a sampled launch carries its own begin / end events (kind PROF_ZCOPY)
 struct Launcher {
@@ -285,7 +297,10 @@ static int zc_run(xmpi_comm* c, int coll, int root, const void* sendbuf, void* r
     all_ok = all_ok && d->ok == 1;
     any_fresh = any_fresh || d->fresh == 1;
   }
-  if (!all_ok) return XMPI_OK;  // staged path, on every rank
+  if (!all_ok) {  // staged path, on every rank
+    c->zc_fallbacks_unregistered++;
+    return XMPI_OK;
+  }
 
   // 3. map the peers' buffers (cached per allocation)
   const int mypid = (int)getpid();
@@ -306,9 +321,18 @@ static int zc_run(xmpi_comm* c, int coll, int root, const void* sendbuf, void* r
       continue;
     }
     void *bs = nullptr, *br = nullptr;
-    if (map_peer(pid, d->send, &bs) != hipSuccess) mapped = false;
-    if (mapped && d->recv.base == d->send.base && d->recv.gen == d->send.gen) br = bs;
-    else if (mapped && map_peer(pid, d->recv, &br) != hipSuccess) mapped = false;
+    hipError_t me_err = map_peer(pid, d->send, &bs);
+    if (me_err == hipSuccess) {
+      if (d->recv.base == d->send.base && d->recv.gen == d->send.gen) br = bs;
+      else me_err = map_peer(pid, d->recv, &br);
+    }
+    if (me_err != hipSuccess) {
+      mapped = false;
+      static std::atomic<int> said{0};
+      if (said.fetch_add(1) < 3)  // a mapping failure costs the zero-copy path: say why, a few times
+        fprintf(stderr, "xmpi: rank %d cannot map a buffer of rank %d (pid %d): %s; %zu mappings open, %d fds open\n",
+                me, p, pid, hipGetErrorString(me_err), g_maps.size(), count_open_fds());
+    }
     if (mapped) {
       psend[p] = (char*)bs + d->send.offset;
       precv[p] = (char*)br + d->recv.offset;
@@ -319,7 +343,10 @@ static int zc_run(xmpi_comm* c, int coll, int root, const void* sendbuf, void* r
     rc = c->ctl->barrier(tmo(c));
     if (rc != XMPI_OK) return rc;
     for (int p = 0; p < N; p++)
-      if (c->ctl->desc(p, seq)->verdict.load(std::memory_order_acquire) != 1) return XMPI_OK;  // staged, everywhere
+      if (c->ctl->desc(p, seq)->verdict.load(std::memory_order_acquire) != 1) {  // staged, everywhere
+        c->zc_fallbacks_unmappable++;
+        return XMPI_OK;
+      }
   } else if (!mapped) {
     set_last_error("zero-copy collective: a peer buffer that was mapped before can no longer be mapped");
     c->ctl->set_abort(XMPI_ERR_HIP);

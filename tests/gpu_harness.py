@@ -37,6 +37,10 @@ def run_ranks(scenario: str, size: int, args: dict | None = None, timeout: float
     failed = [i for i, p in enumerate(procs) if p.returncode != 0]
     if failed:
         msg = "\n".join(f"--- rank {i} (exit {procs[i].returncode}) ---\n{outs[i]}" for i in range(size))
+        dump = os.path.join(ROOT, "gpurun_out")  # survives the GPU box: post-mortem of intermittent failures
+        if os.path.isdir(dump):
+            with open(os.path.join(dump, f"fail_{scenario}_{size}_{key}.log"), "w") as f:
+                f.write(msg)
         raise AssertionError(f"scenario {scenario} size {size}: ranks {failed} failed\n{msg}")
     return outs
 

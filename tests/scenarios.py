@@ -183,6 +183,11 @@ def _zc_launches(comm) -> int:
     return comm.prof_get(xmpi.PROF_ZCOPY)[0]
 
 
+def _zc_why(comm) -> str:
+    return (f"zero-copy attempts {comm.get_param('zc_seq')}, went staged: {comm.get_param('zc_fallbacks_unregistered')} "
+            f"(a buffer not registered / not exportable), {comm.get_param('zc_fallbacks_unmappable')} (a peer could not map)")
+
+
 def sc_zero_copy(comm, args):
     """Zero-copy collectives (zcopy.cpp): kernels read and write the peers' registered buffers in place.
     Rank-order fold => every result is bit-identical to the oracle, for every dtype and operator."""
@@ -202,7 +207,8 @@ def sc_zero_copy(comm, args):
     allreduce_case(comm, xmpi.F64, 50001, Z, pattern=xmpi.PAT_SIGNED, inplace=True, exact=True)
     # the big allreduce gave every rank a chunk: the zero-copy kernel ran here (not a silent fallback)
     # (rank 0 always launches; ranks hosted by threads of its process leave their chunks to it)
-    assert rank != 0 or _zc_launches(comm) > before, "zero-copy path did not run"
+    assert rank != 0 or _zc_launches(comm) > before, "zero-copy path did not run: " + _zc_why(comm)
+    assert comm.get_param("zc_fallbacks_unregistered") == 0 and comm.get_param("zc_fallbacks_unmappable") == 0, _zc_why(comm)
 
     # buffers at odd element offsets: the element-wise kernel, still in place in the peers' memory
     for dtype, count in ((xmpi.F32, 10007), (xmpi.F16, 4099), (xmpi.U8, 1001)):
@@ -260,23 +266,48 @@ def sc_zero_copy(comm, args):
     comm.allreduce(x, out, 1000, xmpi.F32, xmpi.SUM, Z)  # host memory
     want = oracle.reduce_ranks([oracle.fill(1000, xmpi.F32, xmpi.PAT_UNIFORM, 5 + r) for r in range(size)], xmpi.F32, 0)
     assert out.tobytes() == want.tobytes()
+    # device memory from another allocator (here: plain hipMalloc) on ONE rank: staged until it is registered,
+    # zero-copy while it is, staged again after deregistration
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
     count = 20011
-    send, recv = comm.alloc(count * 4), comm.alloc(count * 4)
+    send, mine = comm.alloc(count * 4), comm.alloc(count * 4)
+    foreign = ctypes.c_void_p(0)
+    if rank == size - 1:
+        comm.sync()  # (selects this rank's device on this thread)
+        assert hip.hipMalloc(ctypes.byref(foreign), ctypes.c_size_t(count * 4)) == 0
+    recv_ptr = foreign.value if rank == size - 1 else mine.ptr
     comm.fill(send, count, xmpi.F32, xmpi.PAT_SIGNED, 900 + rank)
     ins = [oracle.fill(count, xmpi.F32, xmpi.PAT_SIGNED, 900 + r) for r in range(size)]
+
+    def result():
+        out = np.empty(count, dtype=np.float32)
+        xmpi._check(xmpi.lib().xmpi_memcpy(comm.handle, out.ctypes.data, recv_ptr, count * 4), "download")
+        return out
+
+    staged0 = comm.get_param("zc_fallbacks_unregistered")
+    for phase in ("unregistered", "registered", "deregistered"):
+        if rank == size - 1 and phase == "registered":
+            comm.register(recv_ptr, count * 4)
+        if rank == size - 1 and phase == "deregistered":
+            comm.deregister(recv_ptr)
+        comm.memset(recv_ptr, 0, count * 4)
+        before = _zc_launches(comm)
+        comm.allreduce(send, recv_ptr, count, xmpi.F32, xmpi.SUM, Z)
+        check_reduced(result(), ins, xmpi.F32, xmpi.SUM, True, f"foreign buffer, {phase}")
+        if phase == "registered":
+            assert rank != 0 or _zc_launches(comm) > before, _zc_why(comm)
+        else:
+            assert _zc_launches(comm) == before, "zero-copy kernel ran although a peer's buffer was not registered"
+    assert comm.get_param("zc_fallbacks_unregistered") == staged0 + 2, _zc_why(comm)
+    assert comm.get_param("zc_fallbacks_unmappable") == 0, _zc_why(comm)
+    # buffers of xmpi_malloc are blocks of long-lived arenas: nothing was mapped per call
+    assert comm.get_param("heap_arenas") <= 8, comm.get_param("heap_arenas")
+    comm.barrier()
     if rank == size - 1:
-        comm.deregister(recv)  # one rank's buffer is not registered: nobody may take the zero-copy path
-    comm.allreduce(send, recv, count, xmpi.F32, xmpi.SUM, Z)
-    check_reduced(recv.download(np.float32, count), ins, xmpi.F32, xmpi.SUM, True, "fallback (unregistered)")
-    assert _zc_launches(comm) == n0, "zero-copy kernel ran although a peer's buffer was not registered"
-    if rank == size - 1:
-        comm.register(recv, count * 4)
-    comm.memset(recv, 0, count * 4)
-    comm.allreduce(send, recv, count, xmpi.F32, xmpi.SUM, Z)
-    check_reduced(recv.download(np.float32, count), ins, xmpi.F32, xmpi.SUM, True, "re-registered")
-    assert rank != 0 or _zc_launches(comm) > n0
+        assert hip.hipFree(foreign) == 0
     send.free()
-    recv.free()
+    mine.free()
     comm.prof_enable(False)
 
 

@@ -142,6 +142,40 @@ def test_copy_multi(comm, ndst):
             x.free()
 
 
+def test_malloc_carves_blocks_out_of_arenas(comm):
+    """xmpi_malloc: 256-byte aligned blocks of a few long-lived arenas; freed blocks coalesce and are reused"""
+    a0, r0, u0 = (comm.get_param(k) for k in ("heap_arenas", "heap_reserved", "heap_in_use"))
+    bufs = [comm.alloc(n) for n in (1, 255, 256, 257, 4096, 1 << 20, 3 << 20)]
+    assert all(b.ptr % 256 == 0 for b in bufs)
+    spans = sorted((b.ptr, b.ptr + max(1, b.nbytes)) for b in bufs)
+    assert all(spans[i][1] <= spans[i + 1][0] for i in range(len(spans) - 1)), "blocks overlap"
+    assert comm.get_param("heap_in_use") >= u0 + sum(b.nbytes for b in bufs)
+    for i, b in enumerate(bufs):  # blocks are usable device memory
+        comm.memset(b, i + 1, b.nbytes)
+    for i, b in enumerate(bufs):
+        assert np.all(b.download(np.uint8, b.nbytes) == i + 1)
+    first = bufs[0].ptr
+    r1 = comm.get_param("heap_reserved")
+    assert r1 >= r0
+    for b in bufs[::2] + bufs[1::2]:  # free out of order: neighbours merge
+        b.free()
+    assert comm.get_param("heap_in_use") == u0
+    big = comm.alloc(4 << 20)  # fits where the seven blocks were, once they have coalesced
+    assert comm.get_param("heap_reserved") == r1, "a new arena was reserved although the freed blocks had room"
+    again = comm.alloc(1)
+    assert again.ptr != big.ptr
+    big.free()
+    again.free()
+    assert comm.get_param("heap_arenas") >= max(1, a0) and first % 256 == 0
+    # a buffer larger than any arena gets one of its own
+    huge = comm.alloc((1 << 30) + 4096)
+    comm.memset(huge.at(1 << 30), 7, 4096)
+    assert np.all(huge.download(np.uint8, 4096, byte_offset=1 << 30) == 7)
+    huge.free()
+    # not the start of a live block
+    assert xmpi.lib().xmpi_free(comm.handle, first + 17) == xmpi.ERR_ARG
+
+
 def test_zc_chunk_partition():
     for count, es, size in ((0, 4, 8), (1, 4, 8), (67108864, 4, 8), (4099, 8, 3), (1001, 1, 5), (17, 2, 16)):
         pos = 0
