@@ -16,9 +16,13 @@ value = aggregate algorithm bandwidth = ranks x S / t  (GB = 1e9 B; every rank e
 reduced bytes), with t = max over ranks of the barrier-bracketed time of K steps / K.  The plain
 nccl-tests figures are alongside: algbw = S / t and busbw = algbw x 2(R-1)/R.
 
-roofline: the dominant kernel of the path is the per-piece reduction reduce2_kernel<float,SUM>
-(HBM-bound: 12 algorithmic bytes per output element); its launches inside the timed region are
-bracketed by HIP events on the stream they run on (libxmpi's profiling hooks).
+roofline: the dominant kernel of the timed region -- reduce_n_multi_kernel<float,SUM,8> on the zero-copy
+path (folds chunk j of the 8 send buffers in rank order and stores it into the 8 receive buffers:
+8 reads + 8 writes = 64 algorithmic bytes per f32 element), reduce2 / reduce_n on the staged schedules.
+Sampled launches inside the timed region carry HIP events attached to their dispatch (libxmpi's
+profiling hooks), on the stream the kernel runs on.  Before timing, the schedule is auto-tuned
+(zero-copy vs ring / halving / direct and their knobs) and only a candidate whose result matches the
+rank-order oracle on every rank is timed.
 
 cpu_baseline (N = 1, rank 0 only): the reference path -- mpi.Network over loopback TCP with gob
 framing -- restated in C++ (oracle/refpath.cpp, "kind": "port": the image has no Go toolchain),

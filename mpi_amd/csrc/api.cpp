@@ -292,6 +292,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   c->zero_copy = env_long("XMPI_ZERO_COPY", 1) ? 1 : 0;
   c->zc_bcast_push_bytes = std::max<long>(0, env_long("XMPI_ZC_BCAST_PUSH_BYTES", 256 << 10));
   c->zc_group_launch = env_long("XMPI_ZC_GROUP_LAUNCH", 1) ? 1 : 0;
+  c->p2p_direct_bytes = env_long("XMPI_P2P_DIRECT_BYTES", 4096);
   if (getenv("XMPI_KERNEL_MODE")) set_kernel_mode((int)env_long("XMPI_KERNEL_MODE", -1));
   if (getenv("XMPI_GRID_CAP")) set_grid_cap((int)env_long("XMPI_GRID_CAP", 0));
   c->coll_region_bytes = (size_t)size * c->lanes * c->fifo_depth * c->slot_bytes;
@@ -764,6 +765,7 @@ int xmpi_set_param(xmpi_comm* c, const char* name, long value) {
   else if (n == "zero_copy") c->zero_copy = value ? 1 : 0;
   else if (n == "zc_bcast_push_bytes") c->zc_bcast_push_bytes = std::max<long>(0, value);
   else if (n == "zc_group_launch") c->zc_group_launch = value ? 1 : 0;
+  else if (n == "p2p_direct_bytes") c->p2p_direct_bytes = value;  // < 0: always through the mail slots
   else if (n == "kernel_mode") set_kernel_mode((int)value);  // process-wide
   else if (n == "grid_cap") set_grid_cap((int)value);        // process-wide
   else return XMPI_ERR_ARG;
@@ -784,6 +786,9 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
     heap_stats(c->device, &a, &r, &u);
     return (long)(n == "heap_arenas" ? a : n == "heap_reserved" ? r : u);
   }
+  if (n == "p2p_direct_bytes") return c->p2p_direct_bytes;
+  if (n == "p2p_direct_count") return (long)c->p2p_direct_count;
+  if (n == "p2p_staged_count") return (long)c->p2p_staged_count;
   if (n == "zc_seq") return (long)c->zc_seq;
   if (n == "zc_fallbacks_unregistered") return (long)c->zc_fallbacks_unregistered;
   if (n == "zc_fallbacks_unmappable") return (long)c->zc_fallbacks_unmappable;

@@ -69,7 +69,10 @@ struct xmpi_comm {
   uint64_t zc_fallbacks_unregistered = 0, zc_fallbacks_unmappable = 0;  // zero-copy attempts that went staged, by reason
   uint64_t zc_seq = 0;          // zero-copy attempts so far (same on every rank)
   std::set<std::pair<uint64_t, uint64_t>> zc_announced;  // {base, gen} already published on this communicator
-  uint64_t zc_retired_seen[xmpi::kMaxRanks] = {0};       // how far each peer's retire log has been processed
+  std::mutex zc_mu;              // guards zc_retired_seen (collectives and p2p calls process the retire logs)
+  long p2p_direct_bytes = 4096;  // messages from a registered buffer at least this long: the receiver pulls them directly
+  uint64_t p2p_direct_count = 0, p2p_staged_count = 0;  // receives served each way (diagnostic)
+  uint64_t zc_retired_seen[xmpi::kMaxRanks] = {0};      // how far each peer's retire log has been processed
   long oneshot_bytes = 1 << 20;  // direct allreduce up to this size: push everything, fold locally
   long fuse_ring = 1;    // ring: receive-reduce-send / receive-copy-send as one kernel
   long batch_copies = 1;  // with the copy kernel: all ready SENDs (RECV_COPYs) go out in one launch
@@ -126,6 +129,8 @@ int zero_copy_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, 
 int registry_add(void* base, size_t bytes, int device);
 void registry_remove(xmpi_comm* c, void* base);
 void zc_close_peers(const xmpi_comm* c);
+bool zc_export(xmpi_comm* c, const void* p, size_t need, BufRef* ref);
+bool zc_import(xmpi_comm* c, int peer, const BufRef& ref, void** out);
 // heap.cpp: xmpi_malloc carves buffers out of long-lived registered arenas
 void* heap_alloc(int device, size_t bytes);
 bool heap_free(void* p);

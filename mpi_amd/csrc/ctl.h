@@ -33,14 +33,33 @@ struct PipeCtl {
 
 enum MailState : uint32_t { MAIL_FREE = 0, MAIL_CLAIMED = 1, MAIL_POSTED = 2, MAIL_MATCHED = 3, MAIL_DONE = 4 };
 
+// Where a registered buffer lives: enough for a peer to map it (hipIpc) and address the same bytes.
+struct BufRef {
+  uint64_t base;    // allocation base VA in the owner's process (0 = no buffer)
+  uint64_t gen;     // owner's registration number of that allocation (a re-used VA gets a new one)
+  uint64_t offset;  // of the user pointer inside the allocation
+  uint64_t bytes;   // of the allocation
+  uint8_t handle[64];
+};
+
+// how the payload of a message travels
+enum MailDirect : int32_t {
+  DIRECT_NONE = 0,      // through the mail slots of the receiver's window (two copies, pipelined)
+  DIRECT_OFFERED = 1,   // the sender's buffer is registered: `src` says where it is
+  DIRECT_ACCEPTED = 2,  // the receiver copies straight out of it (one copy, one xGMI crossing)
+  DIRECT_DECLINED = 3,  // the receiver cannot (host destination, mapping failed): sender uses the slots
+};
+
 struct alignas(64) MailEntry {
   std::atomic<uint32_t> state;
   int32_t tag;
   int32_t dtype;
   std::atomic<int32_t> status;  // receiver's verdict (XMPI_OK / XMPI_ERR_TRUNCATE / ...)
   uint64_t bytes;
-  char pad[40];
+  std::atomic<int32_t> direct;  // MailDirect
+  char pad[36];
   PipeCtl pipe;
+  BufRef src;
 };
 
 struct alignas(64) RankInfo {
@@ -54,17 +73,9 @@ struct alignas(64) RankInfo {
   char busid[32];
 };
 
-// What a rank tells its peers about the user buffers of one zero-copy collective: enough for a
-// peer to map them (hipIpc) and address the same bytes.  Two descriptors per rank, used alternately
-// (a rank may publish the next collective's while a slower peer still reads the current one).
-struct BufRef {
-  uint64_t base;    // allocation base VA in the owner's process (0 = no buffer)
-  uint64_t gen;     // owner's registration number of that allocation (a re-used VA gets a new one)
-  uint64_t offset;  // of the user pointer inside the allocation
-  uint64_t bytes;   // of the allocation
-  uint8_t handle[64];
-};
-
+// What a rank tells its peers about the user buffers of one zero-copy collective.  Two descriptors
+// per rank, used alternately (a rank may publish the next collective's while a slower peer still
+// reads the current one).
 struct alignas(64) BufDesc {
   std::atomic<uint64_t> seq;  // which zero-copy collective of this communicator the content belongs to
   int32_t ok;     // 1 = both buffers are registered HBM of this rank's device

@@ -723,21 +723,46 @@ int p2p_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, i
   m->dtype = dtype;
   m->bytes = bytes;
   m->status.store(XMPI_OK, std::memory_order_relaxed);
+  // A registered source (xmpi_malloc / xmpi_register) is offered to the receiver, which then copies
+  // straight out of it: one pass over the data and one xGMI crossing instead of slot-in + slot-out.
+  const bool offered = dev_src && c->p2p_direct_bytes >= 0 && bytes >= (size_t)std::max<long>(1, c->p2p_direct_bytes) &&
+                       zc_export(c, buf, bytes, &m->src);
+  m->direct.store(offered ? DIRECT_OFFERED : DIRECT_NONE, std::memory_order_relaxed);
   m->state.store(MAIL_POSTED, std::memory_order_release);
 
+  int rc = XMPI_OK;
+  double tp = now_seconds();
+  if (offered) {  // rendezvous first: the matching receive decides how the payload travels
+    bo.n = 0;
+    while (m->direct.load(std::memory_order_acquire) == DIRECT_OFFERED &&
+           m->state.load(std::memory_order_acquire) != MAIL_DONE) {
+      if (c->ctl->aborted()) {
+        rc = XMPI_ERR_PEER;
+        break;
+      }
+      if (c->timeout_s > 0 && now_seconds() - tp > (double)c->timeout_s) {
+        set_last_error("send to rank " + std::to_string(dest) + " tag " + std::to_string(tag) + ": no matching receive");
+        rc = XMPI_ERR_TIMEOUT;
+        break;
+      }
+      bo.pause();
+    }
+  }
+  const bool push = rc == XMPI_OK && m->direct.load(std::memory_order_acquire) != DIRECT_ACCEPTED &&
+                    m->state.load(std::memory_order_acquire) != MAIL_DONE;
+
   const size_t slot = c->p2p_slot_bytes;
-  const uint64_t npieces = (bytes + slot - 1) / slot;
+  const uint64_t npieces = push ? (bytes + slot - 1) / slot : 0;
   const uint64_t depth = (uint64_t)c->p2p_depth;
   std::deque<hipEvent_t> inflight;
   uint64_t issued = 0, published = 0;
-  int rc = XMPI_OK;
   void* stage = nullptr;
   if (!dev_src && npieces > 0) {  // host payload: bounce through this rank's HBM
     if (hipMalloc(&stage, std::min<size_t>(bytes, depth * slot)) != hipSuccess)
       rc = hip_fail(hipGetLastError(), "hipMalloc(stage)", __FILE__, __LINE__);
   }
   bo.n = 0;
-  double tp = now_seconds();
+  tp = now_seconds();
   while (rc == XMPI_OK && published < npieces) {
     bool progressed = false;
     if (issued < npieces) {
@@ -893,12 +918,48 @@ int p2p_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int 
     return verdict;
   }
   const bool dev_dst = bytes == 0 || is_device_pointer(buf);
+  int rc = XMPI_OK;
+  double tp = now_seconds();
+  if (m->direct.load(std::memory_order_acquire) == DIRECT_OFFERED) {
+    // the sender's buffer is registered: copy straight out of it (mapped once per allocation)
+    void* from = nullptr;
+    if (dev_dst && zc_import(c, src, m->src, &from)) {
+      m->direct.store(DIRECT_ACCEPTED, std::memory_order_release);
+      hipError_t e = c->copy_engine == 1 ? launch_copy(buf, from, bytes, lease.s)
+                                         : hipMemcpyAsync(buf, from, bytes, hipMemcpyDeviceToDevice, lease.s);
+      hipEvent_t ev = (e == hipSuccess) ? ev_get(c, false) : nullptr;
+      if (e == hipSuccess && ev) e = hipEventRecord(ev, lease.s);
+      if (e != hipSuccess || !ev) rc = hip_fail(e, "p2p direct copy", __FILE__, __LINE__);
+      bo.n = 0;
+      while (rc == XMPI_OK) {
+        e = hipEventQuery(ev);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) {
+          rc = hip_fail(e, "hipEventQuery", __FILE__, __LINE__);
+          break;
+        }
+        (void)hipGetLastError();
+        if (c->ctl->aborted()) rc = XMPI_ERR_PEER;
+        bo.pause();
+      }
+      if (ev) ev_put(c, ev, false);
+      if (rc != XMPI_OK) {
+        c->ctl->set_abort(rc);
+        return rc;
+      }
+      __atomic_fetch_add(&c->p2p_direct_count, 1, __ATOMIC_RELAXED);
+      m->status.store(XMPI_OK, std::memory_order_release);
+      m->state.store(MAIL_DONE, std::memory_order_release);  // the ack (network.go:616-624)
+      return XMPI_OK;
+    }
+    m->direct.store(DIRECT_DECLINED, std::memory_order_release);  // host destination / not mappable: use the slots
+  }
+  __atomic_fetch_add(&c->p2p_staged_count, 1, __ATOMIC_RELAXED);
   const size_t slot = c->p2p_slot_bytes;
   const uint64_t npieces = (bytes + slot - 1) / slot;
   std::deque<hipEvent_t> inflight;
   uint64_t issued = 0, drained = 0;
-  int rc = XMPI_OK;
-  double tp = now_seconds();
+  tp = now_seconds();
   bo.n = 0;
   while (rc == XMPI_OK && drained < npieces) {
     bool progressed = false;

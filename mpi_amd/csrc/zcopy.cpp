@@ -211,6 +211,7 @@ namespace {
 // unmap what the peers have freed since this rank last looked (before anything new is mapped)
 void drop_retired(xmpi_comm* c) {
   const int mypid = (int)getpid();
+  std::lock_guard<std::mutex> gz(c->zc_mu);  // collectives and point-to-point calls both come here
   for (int p = 0; p < c->size; p++) {
     const int pid = c->ctl->info(p)->pid;
     if (p == c->rank || pid == mypid) continue;
@@ -238,6 +239,33 @@ void drop_retired(xmpi_comm* c) {
   (void)hipGetLastError();
 }
 }  // namespace
+
+// point-to-point rendezvous (engine.cpp): where `p` lives, for the peer to copy straight out of it
+bool zc_export(xmpi_comm* c, const void* p, size_t need, BufRef* ref) {
+  memset(ref, 0, sizeof *ref);
+  Alloc al;
+  if (!p || !registry_lookup(p, need, c->device, &al)) return false;
+  ref->base = al.base;
+  ref->gen = al.gen;
+  ref->offset = (uint64_t)(uintptr_t)p - al.base;
+  ref->bytes = al.bytes;
+  memcpy(ref->handle, &al.handle, sizeof al.handle);
+  return true;
+}
+
+// ... and the peer's side: a pointer to the same bytes in this process (mapping cached per allocation)
+bool zc_import(xmpi_comm* c, int peer, const BufRef& ref, void** out) {
+  const int pid = c->ctl->info(peer)->pid;
+  if (pid == (int)getpid()) {  // a thread of this process (or this rank itself)
+    *out = (void*)(uintptr_t)(ref.base + ref.offset);
+    return true;
+  }
+  drop_retired(c);
+  void* base = nullptr;
+  if (map_peer(pid, ref, &base) != hipSuccess) return false;
+  *out = (char*)base + ref.offset;
+  return true;
+}
 
 void zc_close_peers(const xmpi_comm* c) {
   const int mypid = (int)getpid();

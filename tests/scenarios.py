@@ -352,6 +352,13 @@ def sc_bounce(comm, args):
         else:
             comm.recv(rcv, n, xmpi.F32, peer, 3)
             comm.send(rcv, n, xmpi.F32, peer, 3)
+    # registered buffers of >= p2p_direct_bytes were pulled straight out of the sender's HBM (one copy);
+    # shorter ones, or everything when p2p_direct_bytes < 0, went through the mail slots
+    direct, staged = comm.get_param("p2p_direct_count"), comm.get_param("p2p_staged_count")
+    if comm.get_param("p2p_direct_bytes") >= 0:
+        assert direct >= 2 * 4 + 5 and staged >= 2 * 3, (direct, staged)
+    else:
+        assert direct == 0 and staged > 0, (direct, staged)
 
 
 def sc_helloworld(comm, args):

@@ -81,7 +81,13 @@ def test_bounce(size):
 
 
 def test_bounce_small_p2p_slots():
-    run_ranks("bounce", 2, timeout=600, env={"XMPI_P2P_SLOT_BYTES": "8192"})
+    """everything through 8 KiB mail slots (the path of unregistered / host buffers): heavy slot reuse"""
+    run_ranks("bounce", 2, timeout=600, env={"XMPI_P2P_SLOT_BYTES": "8192", "XMPI_P2P_DIRECT_BYTES": "-1"})
+
+
+def test_bounce_threads():
+    """ranks as threads of one process: the receiver reads the sender's buffer through its own pointer"""
+    run_threads("bounce", 2)
 
 
 @pytest.mark.parametrize("size", [1, 2, 4])
@@ -90,8 +96,9 @@ def test_helloworld(size):
     run_ranks("helloworld", size, timeout=300)
 
 
-def test_p2p_semantics():
-    run_ranks("p2p_semantics", 2, timeout=300, env={"XMPI_P2P_SLOT_BYTES": "65536"})
+@pytest.mark.parametrize("direct", ["4096", "-1"])
+def test_p2p_semantics(direct):
+    run_ranks("p2p_semantics", 2, timeout=300, env={"XMPI_P2P_SLOT_BYTES": "65536", "XMPI_P2P_DIRECT_BYTES": direct})
 
 
 def test_ranks_as_threads():
