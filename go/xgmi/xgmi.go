@@ -216,6 +216,21 @@ func (b *Backend) Send(data interface{}, destination, tag int) error {
 	return status(C.xmpi_send(b.comm, p, C.size_t(len(raw)), C.xmpi_dtype(U8), C.int(destination), C.int(tag)), "mpi send")
 }
 
+// SendNoWait and Wait are the pair sketched in the comment block of mpi.go:132-152: SendNoWait
+// returns once the payload has left `data` (numeric slices and DeviceBuffers only), Wait blocks
+// until `destination` confirmed the message with `tag` and frees the {destination, tag} pair.
+func (b *Backend) SendNoWait(data interface{}, destination, tag int) error {
+	p, n, dt, ok := view(data)
+	if !ok {
+		return errPayload
+	}
+	return status(C.xmpi_send_nowait(b.comm, p, C.size_t(n), C.xmpi_dtype(dt), C.int(destination), C.int(tag)), "mpi send")
+}
+
+func (b *Backend) Wait(destination, tag int) error {
+	return status(C.xmpi_wait(b.comm, C.int(destination), C.int(tag)), "mpi wait")
+}
+
 func (b *Backend) probe(source, tag int) (int, error) {
 	var n C.size_t
 	var dt C.xmpi_dtype

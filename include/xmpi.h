@@ -133,6 +133,16 @@ int xmpi_sync(xmpi_comm* comm);
  * the mail slots of the receiver's window (slot-in by the sender, slot-out by the receiver). */
 int xmpi_send(xmpi_comm* comm, const void* buf, size_t count, xmpi_dtype dtype, int dest, int tag);
 
+/* The split of Send the reference's author sketched and left commented out (mpi.go:132-152):
+ * xmpi_send_nowait returns once the payload has left the caller's buffer (it may be modified at
+ * once) without waiting for the receiver -- the payload sits in the mail slots of the receiver's
+ * window; a message longer than those slots hold (p2p_depth x p2p_slot_bytes, 8 MiB) still needs
+ * the receive to drain them.  xmpi_wait blocks until the destination confirmed reception and
+ * frees the {dest, tag} pair for re-use, exactly as the sketched Wait(destination, tag). */
+int xmpi_send_nowait(xmpi_comm* comm, const void* buf, size_t count, xmpi_dtype dtype, int dest,
+                     int tag);
+int xmpi_wait(xmpi_comm* comm, int dest, int tag);
+
 /* Replaces mpi.Receive -> (*Network).Receive + receiveReader (mpi.go:157-159,
  * network.go:575-625).  `capacity` is the room in `buf` (elements); `*got` (optional) is the
  * element count of the message.  The dtype must match the sender's. */

@@ -536,6 +536,22 @@ int xmpi_send(xmpi_comm* c, const void* buf, size_t count, xmpi_dtype dtype, int
   return p2p_send(c, buf, count * es, (int)dtype, dest, tag);
 }
 
+int xmpi_send_nowait(xmpi_comm* c, const void* buf, size_t count, xmpi_dtype dtype, int dest, int tag) {
+  XMPI_ENTER(c);
+  const size_t es = xmpi_dtype_size(dtype);
+  if (!es || dest < 0 || dest >= c->size || (count && !buf)) {
+    set_last_error("send: bad dtype / destination / buffer");
+    return XMPI_ERR_ARG;
+  }
+  return p2p_send(c, buf, count * es, (int)dtype, dest, tag, /*wait_ack=*/false);
+}
+
+int xmpi_wait(xmpi_comm* c, int dest, int tag) {
+  XMPI_ENTER(c);
+  if (dest < 0 || dest >= c->size) return XMPI_ERR_ARG;
+  return p2p_wait(c, dest, tag);
+}
+
 int xmpi_recv(xmpi_comm* c, void* buf, size_t capacity, xmpi_dtype dtype, int src, int tag, size_t* got) {
   XMPI_ENTER(c);
   const size_t es = xmpi_dtype_size(dtype);

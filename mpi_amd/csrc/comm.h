@@ -3,6 +3,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <deque>
+#include <map>
 #include <mutex>
 #include <set>
 #include <string>
@@ -113,13 +114,15 @@ struct xmpi_comm {
   std::mutex coll_mu;  // collectives are serialised per communicator
   std::mutex p2p_mu;   // guards the tag registries and the p2p stream pool
   std::set<std::pair<int, int>> send_tags, recv_tags;  // active {peer, tag} (network.go:448-497)
+  std::map<std::pair<int, int>, xmpi::MailEntry*> pending_sends;  // xmpi_send_nowait awaiting xmpi_wait
   std::vector<hipStream_t> p2p_streams;
   bool finalized = false;
 };
 
 namespace xmpi {
 int run_plan(xmpi_comm* c, const Plan& plan, const void* sendbuf, void* recvbuf, int dtype, int op);
-int p2p_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, int tag);
+int p2p_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, int tag, bool wait_ack = true);
+int p2p_wait(xmpi_comm* c, int dest, int tag);
 int p2p_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int tag, size_t* got_bytes);
 int p2p_probe(xmpi_comm* c, int src, int tag, size_t* bytes, int* dtype);
 // zcopy.cpp.  *done = false: some rank's buffers are not registered HBM -- every rank saw that and

@@ -683,9 +683,36 @@ struct StreamLease {
 
 bool timed_out(xmpi_comm* c, double t0) { return c->timeout_s > 0 && now_seconds() - t0 > (double)c->timeout_s; }
 
+// rendezvous: wait for the receiver's verdict (network.go:569 waits for the ack message), free the entry
+int await_ack(xmpi_comm* c, MailEntry* m, int dest, int tag) {
+  int rc = XMPI_OK;
+  const double tp = now_seconds();
+  Backoff bo;
+  while (rc == XMPI_OK && m->state.load(std::memory_order_acquire) != MAIL_DONE) {
+    if (c->ctl->aborted()) rc = XMPI_ERR_PEER;
+    else if (c->timeout_s > 0 && now_seconds() - tp > (double)c->timeout_s) {
+      set_last_error("send to rank " + std::to_string(dest) + " tag " + std::to_string(tag) + ": no matching receive");
+      rc = XMPI_ERR_TIMEOUT;
+    }
+    bo.pause();
+  }
+  if (rc == XMPI_OK) {
+    rc = m->status.load(std::memory_order_acquire);
+    m->pipe.head.v.store(0, std::memory_order_relaxed);
+    m->pipe.tail.v.store(0, std::memory_order_relaxed);
+    m->state.store(MAIL_FREE, std::memory_order_release);
+  } else {
+    c->ctl->set_abort(rc);  // the entry is in an unknown state: the job cannot continue
+  }
+  return rc;
+}
+
 }  // namespace
 
-int p2p_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, int tag) {
+// wait_ack = false is the reference author's intended Send (commented out at mpi.go:132-152): return
+// once the payload has left the caller's buffer; p2p_wait() later collects the receiver's confirmation
+// and frees the {dest, tag} pair.
+int p2p_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, int tag, bool wait_ack) {
   // {dest,tag} unique among concurrent sends (mpi.go:121-125; the reference panics at
   // network.go:469, here it is an error code the Go shim turns into mpi.TagExists)
   TagGuard tg(c, &c->send_tags, dest, tag);
@@ -725,7 +752,7 @@ int p2p_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, i
   m->status.store(XMPI_OK, std::memory_order_relaxed);
   // A registered source (xmpi_malloc / xmpi_register) is offered to the receiver, which then copies
   // straight out of it: one pass over the data and one xGMI crossing instead of slot-in + slot-out.
-  const bool offered = dev_src && c->p2p_direct_bytes >= 0 && bytes >= (size_t)std::max<long>(1, c->p2p_direct_bytes) &&
+  const bool offered = wait_ack && dev_src && c->p2p_direct_bytes >= 0 && bytes >= (size_t)std::max<long>(1, c->p2p_direct_bytes) &&
                        zc_export(c, buf, bytes, &m->src);
   m->direct.store(offered ? DIRECT_OFFERED : DIRECT_NONE, std::memory_order_relaxed);
   m->state.store(MAIL_POSTED, std::memory_order_release);
@@ -825,26 +852,35 @@ int p2p_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, i
       inflight.pop_front();
     }
   }
-  // rendezvous: wait for the receiver's verdict (network.go:569 waits for the ack message)
-  tp = now_seconds();
-  bo.n = 0;
-  while (rc == XMPI_OK && m->state.load(std::memory_order_acquire) != MAIL_DONE) {
-    if (c->ctl->aborted()) rc = XMPI_ERR_PEER;
-    else if (c->timeout_s > 0 && now_seconds() - tp > (double)c->timeout_s) {
-      set_last_error("send to rank " + std::to_string(dest) + " tag " + std::to_string(tag) + ": no matching receive");
-      rc = XMPI_ERR_TIMEOUT;
-    }
-    bo.pause();
-  }
   if (stage) (void)hipFree(stage);
-  if (rc == XMPI_OK) {
-    rc = m->status.load(std::memory_order_acquire);
-    m->pipe.head.v.store(0, std::memory_order_relaxed);
-    m->pipe.tail.v.store(0, std::memory_order_relaxed);
-    m->state.store(MAIL_FREE, std::memory_order_release);
-  } else {
+  if (rc != XMPI_OK) {
     c->ctl->set_abort(rc);  // the entry is in an unknown state: the job cannot continue
+    return rc;
   }
+  if (!wait_ack) {  // the payload sits in the receiver's window: the caller's buffer is free again
+    std::lock_guard<std::mutex> g(c->p2p_mu);
+    c->pending_sends[{dest, tag}] = m;
+    tg.held = false;  // {dest, tag} stays reserved until p2p_wait
+    return XMPI_OK;
+  }
+  return await_ack(c, m, dest, tag);
+}
+
+int p2p_wait(xmpi_comm* c, int dest, int tag) {
+  MailEntry* m = nullptr;
+  {
+    std::lock_guard<std::mutex> g(c->p2p_mu);
+    auto it = c->pending_sends.find({dest, tag});
+    if (it == c->pending_sends.end()) {
+      set_last_error("wait: no send to rank " + std::to_string(dest) + " with tag " + std::to_string(tag) + " is outstanding");
+      return XMPI_ERR_ARG;
+    }
+    m = it->second;
+    c->pending_sends.erase(it);
+  }
+  const int rc = await_ack(c, m, dest, tag);
+  std::lock_guard<std::mutex> g(c->p2p_mu);
+  c->send_tags.erase({dest, tag});
   return rc;
 }
 

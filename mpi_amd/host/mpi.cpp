@@ -186,6 +186,12 @@ Error XGMI::Send(const Data& d, int destination, int tag) {
   return from_code(xmpi_send(comm_, d.ptr, d.count, d.dtype, destination, tag), "mpi send");
 }
 
+Error XGMI::SendNoWait(const Data& d, int destination, int tag) {
+  return from_code(xmpi_send_nowait(comm_, d.ptr, d.count, d.dtype, destination, tag), "mpi send");
+}
+
+Error XGMI::Wait(int destination, int tag) { return from_code(xmpi_wait(comm_, destination, tag), "mpi wait"); }
+
 Error XGMI::Receive(Data d, int source, int tag) {
   if (d.resize) {  // decode into *[]T: size the container to the incoming message first
     size_t n = 0;

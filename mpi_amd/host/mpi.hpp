@@ -165,6 +165,12 @@ class XGMI : public Interface, public Collective {
   Error Allgather(const Data& send, Data recv) override;
   Error Barrier() override;
 
+  // The Send / Wait pair the reference sketches in a comment (mpi.go:132-152): SendNoWait returns once
+  // the payload has left `data`; Wait blocks until `destination` confirmed the message with `tag` and
+  // frees the {destination, tag} pair.
+  Error SendNoWait(const Data& data, int destination, int tag);
+  Error Wait(int destination, int tag);
+
   // HBM buffers of this rank (device-resident payloads are the hot path)
   void* Malloc(size_t bytes);
   void Free(void* p);

@@ -72,6 +72,8 @@ SYMBOLS = [
     ("xmpi_plan_dump", _I, [_I, _I, _I, _I, _I, _Z, _Z, _I, _Z, C.c_char_p, _Z]),
     ("xmpi_dtype_size", _Z, [_I]),
     ("xmpi_allreduce_repeat", _I, [_P, _P, _P, _Z, _I, _I, _I, _I]),
+    ("xmpi_send_nowait", _I, [_P, _P, _Z, _I, _I, _I]),
+    ("xmpi_wait", _I, [_P, _I, _I]),
     ("xmpi_register", _I, [_P, _P, _Z]),
     ("xmpi_deregister", _I, [_P, _P]),
     ("xmpi_reduce_local_multi", _I, [_P, C.POINTER(_P), _I, C.POINTER(_P), _I, _Z, _I, _I]),
@@ -212,6 +214,13 @@ class Comm:
 
     def send(self, buf, count: int, dtype: int, dest: int, tag: int) -> None:
         _check(lib().xmpi_send(self.handle, _ptr(buf), count, dtype, dest, tag), "xmpi_send")
+
+    def send_nowait(self, buf, count: int, dtype: int, dest: int, tag: int) -> None:
+        """Returns once the payload has left `buf`; wait(dest, tag) collects the receiver's confirmation."""
+        _check(lib().xmpi_send_nowait(self.handle, _ptr(buf), count, dtype, dest, tag), "xmpi_send_nowait")
+
+    def wait(self, dest: int, tag: int) -> None:
+        _check(lib().xmpi_wait(self.handle, dest, tag), "xmpi_wait")
 
     def recv(self, buf, capacity: int, dtype: int, src: int, tag: int) -> int:
         got = _Z(0)

@@ -475,6 +475,43 @@ def sc_p2p_semantics(comm, args):
         h = np.zeros(5000, dtype=np.float64)
         comm.recv(h, 5000, xmpi.F64, peer, 5)
         assert h.tobytes() == oracle.fill(5000, xmpi.F64, 0, 3).tobytes()
+    # Send without waiting for the receiver + Wait (the reference author's sketched API, mpi.go:132-152):
+    # the send returns while the receiver is still busy elsewhere, the buffer may be overwritten at once,
+    # the pair {dest, tag} stays taken until wait() has collected the confirmation
+    import time
+    k = 30000  # 120 KB: fits the entry's two 64 KiB slots of test_p2p_semantics, so nothing has to be drained first
+    want = oracle.fill(k, xmpi.F32, xmpi.PAT_SIGNED, 21)
+    if rank == 0:
+        comm.fill(a, k, xmpi.F32, xmpi.PAT_SIGNED, 21)
+        t0 = time.perf_counter()
+        comm.send_nowait(a, k, xmpi.F32, peer, 31)
+        assert time.perf_counter() - t0 < 0.4, "send_nowait waited for the receiver"
+        comm.memset(a, 0xFF, k * 4)  # the payload no longer lives here
+        try:
+            comm.send_nowait(a, 1, xmpi.F32, peer, 31)
+            raise AssertionError("the pair {dest, tag} must stay reserved until wait()")
+        except xmpi.XmpiError as e:
+            assert e.code == xmpi.ERR_TAG_EXISTS
+        hsrc = oracle.fill(1000, xmpi.I64, 0, 22)
+        comm.send_nowait(hsrc, 1000, xmpi.I64, peer, 32)  # host payload
+        hsrc[:] = 0
+        comm.wait(peer, 31)
+        comm.wait(peer, 32)
+        try:
+            comm.wait(peer, 31)
+            raise AssertionError("nothing is outstanding any more")
+        except xmpi.XmpiError as e:
+            assert e.code == xmpi.ERR_ARG
+        comm.send_nowait(a, 0, xmpi.F32, peer, 31)  # the pair is free again; empty message
+        comm.wait(peer, 31)
+    else:
+        time.sleep(0.5)
+        assert comm.recv(b, k, xmpi.F32, peer, 31) == k
+        assert b.download(np.float32, k).tobytes() == want.tobytes()
+        hd = np.zeros(1000, dtype=np.int64)
+        comm.recv(hd, 1000, xmpi.I64, peer, 32)
+        assert hd.tobytes() == oracle.fill(1000, xmpi.I64, 0, 22).tobytes()
+        assert comm.recv(b, 0, xmpi.F32, peer, 31) == 0
     a.free()
     b.free()
     comm.barrier()

@@ -118,6 +118,25 @@ for algo in (xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_DIRECT):
     want = oracle.reduce_ranks([oracle.fill(count, oracle.I64, 0, 1000 + q) for q in range(size)], oracle.I64, oracle.SUM)
     assert np.array_equal(recv, want), f"algo {algo} rank {rank}"
     dist.barrier()
+
+# The zero-copy allreduce's data flow (zcopy.cpp) with gloo standing in for the xGMI loads and stores:
+# rank j "reads" chunk j of every rank's send buffer (gather to j), folds in rank order, and "writes"
+# the result into chunk j of every rank's receive buffer (broadcast from j).  Floats: bit-exact.
+for count, es, code, npdt, tdt in ((4099, 4, oracle.F32, np.float32, torch.float32), (17, 8, oracle.F64, np.float64, torch.float64)):
+    send = oracle.fill(count, code, 3, 500 + rank)
+    recv = np.zeros(count, dtype=npdt)
+    for j in range(size):
+        off, cnt = xmpi.zc_chunk(count, es, size, j)
+        mine = torch.from_numpy(send[off:off + cnt].copy())
+        parts = [torch.empty(cnt, dtype=tdt) for _ in range(size)] if rank == j else None
+        dist.gather(mine, parts, dst=j)
+        out = torch.empty(cnt, dtype=tdt)
+        if rank == j:
+            out = torch.from_numpy(oracle.reduce_ranks([p.numpy() for p in parts], code, oracle.SUM).copy())
+        dist.broadcast(out, src=j)
+        recv[off:off + cnt] = out.numpy()
+    want = oracle.reduce_ranks([oracle.fill(count, code, 3, 500 + q) for q in range(size)], code, oracle.SUM)
+    assert recv.tobytes() == want.tobytes(), f"zero-copy flow, rank {rank}"
 dist.destroy_process_group()
 print("ok")
 """ % ROOT
