@@ -332,6 +332,31 @@ def rank_main(job: Job, grank: int):
             sweep.append(row)
             sz *= 4
         extras["size_sweep"] = sweep
+        # the same message at 2 and 4 ranks (BASELINE.json quotes the metric at 1/2/4/8 ranks): smaller
+        # communicators among the first ranks of this job, the others wait at the barrier
+        if job.procs == 1:
+            by_ranks = {}
+            for r2 in (2, 4):
+                if r2 >= R:
+                    continue
+                comm.barrier()
+                if grank < r2:
+                    sub = xmpi.Comm(grank, r2, job.device_of(grank), f"{job.key}-r{r2}")
+                    s2, d2 = sub.alloc(nbytes), sub.alloc(nbytes)
+                    sub.fill(s2, count, dtype, xmpi.PAT_UNIFORM, seed0 + grank)
+                    row = {}
+                    for al in (xmpi.ALGO_ZCOPY, xmpi.ALGO_RING):
+                        sub.allreduce(s2, d2, count, dtype, xmpi.SUM, al)
+                        t = timed(sub, None, 3, batch=lambda k: sub.allreduce_repeat(s2, d2, count, dtype, xmpi.SUM, al, k))
+                        row[ALGO_NAME[al]] = {"ms": t * 1e3, "algbw_GBps": nbytes / t / 1e9,
+                                              "busbw_GBps": nbytes / t / 1e9 * 2 * (r2 - 1) / r2}
+                    if grank == 0:
+                        by_ranks[str(r2)] = row
+                    s2.free()
+                    d2.free()
+                    sub.finalize()
+                comm.barrier()
+            extras["allreduce_at_fewer_ranks"] = by_ranks
         # BASELINE cfg 2: 1 MiB float32 ping-pong between ranks 0 and 1 (half round trip)
         n1 = 262144
         if grank in (0, 1):

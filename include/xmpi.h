@@ -252,6 +252,11 @@ int xmpi_plan_dump(int coll, int algo, int size, int rank, int root, size_t coun
  * (16-byte aligned boundaries): element offset and length.  Host logic only. */
 int xmpi_zc_chunk(size_t count, size_t elem_size, int size, int j, size_t* elem_off, size_t* elem_cnt);
 
+/* Host-only self-test of xmpi_malloc's block bookkeeping (no GPU call): `rounds` random allocate /
+ * free operations on a synthetic arena; 0 = blocks never overlapped, stayed aligned and coalesced
+ * back into one free block, otherwise the number of the failed check. */
+int xmpi_heap_selftest(uint64_t seed, int rounds);
+
 size_t xmpi_dtype_size(xmpi_dtype dtype);
 
 #ifdef __cplusplus

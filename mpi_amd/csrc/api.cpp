@@ -708,6 +708,8 @@ int xmpi_copy_local_multi(xmpi_comm* c, void* const* dsts, int ndst, const void*
                       &ctx);
 }
 
+int xmpi_heap_selftest(uint64_t seed, int rounds) { return heap_selftest(seed, rounds); }
+
 int xmpi_zc_chunk(size_t count, size_t elem_size, int size, int j, size_t* elem_off, size_t* elem_cnt) {
   if (!elem_off || !elem_cnt || size < 1 || j < 0 || j >= size || elem_size < 1) return XMPI_ERR_ARG;
   zc_chunk(count, elem_size, size, j, elem_off, elem_cnt);

@@ -141,6 +141,7 @@ bool heap_owns(const void* p);
 void heap_comm_created();
 void heap_comm_destroyed(xmpi_comm* c);
 void heap_stats(int device, size_t* arenas, size_t* reserved, size_t* in_use);
+int heap_selftest(uint64_t seed, int rounds);
 hipEvent_t ev_get(xmpi_comm* c, bool timed);
 void ev_put(xmpi_comm* c, hipEvent_t e, bool timed);
 bool is_device_pointer(const void* p);

@@ -108,31 +108,36 @@ void* heap_alloc(int device, size_t bytes) {
   return take(a, need);
 }
 
+namespace {
+// give a live block back to its arena, merging it with free neighbours
+bool release_block(Arena* a, char* p) {
+  const size_t off = (size_t)(p - a->base);
+  auto u = a->used_blocks.find(off);
+  if (u == a->used_blocks.end()) return false;  // not the start of a live block
+  size_t lo = off, len = u->second;
+  a->used_blocks.erase(u);
+  auto next = a->free_blocks.lower_bound(lo);
+  if (next != a->free_blocks.end() && next->first == lo + len) {  // merge with the block after
+    len += next->second;
+    next = a->free_blocks.erase(next);
+  }
+  if (next != a->free_blocks.begin()) {  // ... and with the block before
+    auto prev = std::prev(next);
+    if (prev->first + prev->second == lo) {
+      lo = prev->first;
+      len += prev->second;
+      a->free_blocks.erase(prev);
+    }
+  }
+  a->free_blocks[lo] = len;
+  return true;
+}
+}  // namespace
+
 bool heap_free(void* p) {
   std::lock_guard<std::mutex> g(g_heap_mu);
-  for (Arena* a : g_arenas) {
-    if ((char*)p < a->base || (char*)p >= a->base + a->bytes) continue;
-    const size_t off = (size_t)((char*)p - a->base);
-    auto u = a->used_blocks.find(off);
-    if (u == a->used_blocks.end()) return false;  // not the start of a live block
-    size_t lo = off, len = u->second;
-    a->used_blocks.erase(u);
-    auto next = a->free_blocks.lower_bound(lo);
-    if (next != a->free_blocks.end() && next->first == lo + len) {  // merge with the block after
-      len += next->second;
-      next = a->free_blocks.erase(next);
-    }
-    if (next != a->free_blocks.begin()) {  // ... and with the block before
-      auto prev = std::prev(next);
-      if (prev->first + prev->second == lo) {
-        lo = prev->first;
-        len += prev->second;
-        a->free_blocks.erase(prev);
-      }
-    }
-    a->free_blocks[lo] = len;
-    return true;
-  }
+  for (Arena* a : g_arenas)
+    if ((char*)p >= a->base && (char*)p < a->base + a->bytes) return release_block(a, (char*)p);
   return false;
 }
 
@@ -141,6 +146,52 @@ bool heap_owns(const void* p) {
   for (Arena* a : g_arenas)
     if ((const char*)p >= a->base && (const char*)p < a->base + a->bytes) return true;
   return false;
+}
+
+// Host-only exercise of the block bookkeeping (no HIP call): random allocate / free traffic on one
+// synthetic arena; blocks must never overlap, stay 256-byte aligned, and everything must coalesce back
+// into a single free block.  Returns 0, or the number of the check that failed.
+int heap_selftest(uint64_t seed, int rounds) {
+  Arena a;
+  a.base = (char*)(uintptr_t)0x10000000;  // never dereferenced
+  a.bytes = 64u << 20;
+  a.free_blocks[0] = a.bytes;
+  std::vector<std::pair<char*, size_t>> live;
+  auto rnd = [&seed]() {
+    seed = seed * 6364136223846793005ull + 1442695040888963407ull;
+    return (uint32_t)(seed >> 33);
+  };
+  auto release = [&a](char* p) -> bool { return release_block(&a, p); };
+  for (int r = 0; r < rounds; r++) {
+    if (live.empty() || rnd() % 3 != 0) {
+      const size_t want = (rnd() % 7 == 0) ? (size_t)(rnd() % (4u << 20)) + 1 : (size_t)(rnd() % 5000) + 1;
+      const size_t need = (want + kGranule - 1) / kGranule * kGranule;
+      char* p = (char*)take(&a, need);
+      if (!p) continue;  // full: fine
+      if (((uintptr_t)p & (kGranule - 1)) != 0) return 1;
+      for (auto& b : live)
+        if (p < b.first + b.second && b.first < p + need) return 2;  // overlap
+      live.push_back({p, need});
+    } else {
+      const size_t i = rnd() % live.size();
+      if (!release(live[i].first)) return 3;
+      if (release(live[i].first)) return 4;  // double free must be refused
+      live.erase(live.begin() + (long)i);
+    }
+    size_t used = 0, freeb = 0;
+    for (auto& kv : a.used_blocks) used += kv.second;
+    for (auto& kv : a.free_blocks) freeb += kv.second;
+    if (used + freeb != a.bytes) return 5;  // bytes leaked or counted twice
+    size_t prev_end = (size_t)-1;
+    for (auto& kv : a.free_blocks) {  // neighbours must have been merged
+      if (kv.first == prev_end) return 6;
+      prev_end = kv.first + kv.second;
+    }
+  }
+  for (auto& b : live)
+    if (!release(b.first)) return 7;
+  if (a.free_blocks.size() != 1 || a.free_blocks.begin()->first != 0 || a.free_blocks.begin()->second != a.bytes) return 8;
+  return 0;
 }
 
 // diagnostics: arenas / bytes reserved / bytes in use on `device`

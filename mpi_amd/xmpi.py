@@ -72,6 +72,7 @@ SYMBOLS = [
     ("xmpi_plan_dump", _I, [_I, _I, _I, _I, _I, _Z, _Z, _I, _Z, C.c_char_p, _Z]),
     ("xmpi_dtype_size", _Z, [_I]),
     ("xmpi_allreduce_repeat", _I, [_P, _P, _P, _Z, _I, _I, _I, _I]),
+    ("xmpi_heap_selftest", _I, [C.c_uint64, _I]),
     ("xmpi_send_nowait", _I, [_P, _P, _Z, _I, _I, _I]),
     ("xmpi_wait", _I, [_P, _I, _I]),
     ("xmpi_register", _I, [_P, _P, _Z]),

@@ -62,6 +62,33 @@ __global__ __launch_bounds__(BLOCK) void k_fold(Ptrs q, size_t npack) {
   }
 }
 
+// XCD-contiguous mapping: workgroups are dealt round-robin to the 8 XCDs, so block b runs on XCD b % 8;
+// give every XCD one contiguous eighth of the buffer instead of every 8th tile
+template <int BLOCK, int U, int NTL, int NTS>
+__global__ __launch_bounds__(BLOCK) void k_fold_xcd(Ptrs q, size_t npack) {
+  constexpr size_t kTile = (size_t)BLOCK * U;
+  const size_t lane_off = (size_t)(threadIdx.x >> 6) * (64 * U) + (threadIdx.x & 63);
+  const size_t per = gridDim.x / 8;
+  const size_t tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
+  const size_t base = tile * kTile;
+  if (blockIdx.x >= per * 8 || base + kTile > npack) return;
+  const size_t first = base + lane_off;
+  f4 v[R][U];
+#pragma unroll
+  for (int s = 0; s < R; s++)
+#pragma unroll
+    for (int k = 0; k < U; k++) v[s][k] = ld<NTL>(q.s[s] + first + k * 64);
+#pragma unroll
+  for (int k = 0; k < U; k++) {
+#pragma unroll
+    for (int s = 1; s < R; s++) v[0][k] = v[0][k] + v[s][k];
+  }
+#pragma unroll
+  for (int d = 0; d < R; d++)
+#pragma unroll
+    for (int k = 0; k < U; k++) st<NTS>(q.d[d] + first + k * 64, v[0][k]);
+}
+
 // two halves of the sources at a time (half the registers of the full prefetch at the same U)
 template <int BLOCK, int U, int NTL, int NTS>
 __global__ __launch_bounds__(BLOCK) void k_fold_split(Ptrs q, size_t npack) {
@@ -148,6 +175,8 @@ int main(int argc, char** argv) {
     run("U1 ntl", k_fold<256, 1, 1, 0>, 256, 1, 0, reps);
     run("U1 plain", k_fold<256, 1, 0, 0>, 256, 1, 0, reps);
     run("U1 ntl nts", k_fold<256, 1, 1, 1>, 256, 1, 0, reps);
+    run("U1 ntl nts xcd-contig", k_fold_xcd<256, 1, 1, 1>, 256, 1, 0, reps);
+    run("U4 ntl nts xcd-contig", k_fold_xcd<256, 4, 1, 1>, 256, 4, 0, reps);
     run("U2 ntl", k_fold<256, 2, 1, 0>, 256, 2, 0, reps);
     run("U2 ntl nts", k_fold<256, 2, 1, 1>, 256, 2, 0, reps);
     run("U4 ntl", k_fold<256, 4, 1, 0>, 256, 4, 0, reps);

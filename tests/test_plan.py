@@ -95,6 +95,13 @@ def test_zero_copy_chunks_partition_the_buffer(size, count, es):
         assert out.tobytes() == oracle.reduce_ranks(ins, code, oracle.SUM).tobytes()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 12345])
+def test_malloc_block_bookkeeping(seed):
+    """xmpi_malloc's arena allocator (heap.cpp), host logic only: random allocate / free traffic never yields
+    overlapping or misaligned blocks, refuses double frees and coalesces back into one free block"""
+    assert xmpi.lib().xmpi_heap_selftest(seed, 20000) == 0
+
+
 def test_allreduce_oneshot_threshold():
     """Above oneshot_bytes the two-phase form (reduce-scatter, then allgather) is used."""
     big = plan_sim.get_plans(xmpi.COLL_ALLREDUCE, xmpi.ALGO_DIRECT, 4, 0, 4096, 4, 1, 4096, oneshot_bytes=4096)
