@@ -176,6 +176,26 @@ int xmpi_reduce(xmpi_comm* comm, const void* sendbuf, void* recvbuf, size_t coun
 int xmpi_allreduce(xmpi_comm* comm, const void* sendbuf, void* recvbuf, size_t count,
                    xmpi_dtype dtype, xmpi_op op, int algo);
 
+/* Non-blocking forms: the call returns at once with a request; one worker per communicator runs the
+ * operations in the order they were issued (every rank must issue them in the same order, as with
+ * the blocking calls; a blocking collective or xmpi_barrier issued later runs after them).  The
+ * buffers belong to the operation until xmpi_request_wait returned.  This is the overlap of
+ * communication with the caller's own work that the reference's sketched Send / Wait pair was after
+ * (mpi.go:132-152), for the collectives. */
+typedef struct xmpi_request xmpi_request;
+int xmpi_iallreduce(xmpi_comm* comm, const void* sendbuf, void* recvbuf, size_t count,
+                    xmpi_dtype dtype, xmpi_op op, int algo, xmpi_request** req);
+int xmpi_iallgather(xmpi_comm* comm, const void* sendbuf, void* recvbuf, size_t count,
+                    xmpi_dtype dtype, int algo, xmpi_request** req);
+int xmpi_ibcast(xmpi_comm* comm, void* buf, size_t count, xmpi_dtype dtype, int root, int algo,
+                xmpi_request** req);
+int xmpi_ireduce(xmpi_comm* comm, const void* sendbuf, void* recvbuf, size_t count,
+                 xmpi_dtype dtype, xmpi_op op, int root, int algo, xmpi_request** req);
+/* *done = 1 once the operation has completed (xmpi_request_wait will not block). */
+int xmpi_request_test(xmpi_request* req, int* done);
+/* Blocks until the operation completed, returns ITS status and frees the request. */
+int xmpi_request_wait(xmpi_request* req);
+
 /* The same allreduce `iters` times back to back: the step loop of a benchmark without per-call
  * host-language overhead (bench.py hosts several ranks as Python threads, which would otherwise
  * queue for the interpreter lock between steps; a Go or C++ caller has no such cost). */

@@ -116,8 +116,75 @@ static hipStream_t shared_stream_for(int device) {
   return s;
 }
 
+// ---- non-blocking collectives: an ordered worker per communicator --------------------------------
+static thread_local bool t_in_worker = false;
+
+static void worker_main(xmpi_comm* c) {
+  t_in_worker = true;
+  (void)hipSetDevice(c->device);
+  for (;;) {
+    std::pair<std::function<int()>, xmpi_request*> job;
+    {
+      std::unique_lock<std::mutex> l(c->wq_mu);
+      c->wq_cv.wait(l, [c] { return c->wq_stop || !c->wq.empty(); });
+      if (c->wq.empty()) return;  // stop requested and nothing left to run
+      job = std::move(c->wq.front());
+      c->wq.pop_front();
+    }
+    g_last_error.clear();
+    const int rc = job.first();
+    {
+      std::lock_guard<std::mutex> l(job.second->mu);
+      job.second->rc = rc;
+      job.second->err = g_last_error;
+      job.second->done = true;
+      job.second->cv.notify_all();  // under the lock: the waiter frees the request as soon as it sees `done`
+    }
+    {
+      std::lock_guard<std::mutex> l(c->wq_mu);
+      c->wq_busy--;
+    }
+    c->wq_cv.notify_all();
+  }
+}
+
+static xmpi_request* submit(xmpi_comm* c, std::function<int()> fn) {
+  xmpi_request* r = new xmpi_request;
+  {
+    std::lock_guard<std::mutex> l(c->wq_mu);
+    if (!c->worker_started) {
+      c->worker = std::thread(worker_main, c);
+      c->worker_started = true;
+    }
+    c->wq.emplace_back(std::move(fn), r);
+    c->wq_busy++;
+  }
+  c->wq_cv.notify_all();
+  return r;
+}
+
+// a blocking collective issued after non-blocking ones runs after them (same order on every rank)
+static void drain_worker(xmpi_comm* c) {
+  if (t_in_worker || !c->worker_started) return;
+  std::unique_lock<std::mutex> l(c->wq_mu);
+  c->wq_cv.wait(l, [c] { return c->wq_busy == 0; });
+}
+
+static void stop_worker(xmpi_comm* c) {
+  if (!c->worker_started) return;
+  drain_worker(c);
+  {
+    std::lock_guard<std::mutex> l(c->wq_mu);
+    c->wq_stop = true;
+  }
+  c->wq_cv.notify_all();
+  c->worker.join();
+  c->worker_started = false;
+}
+
 static int collective(xmpi_comm* c, int coll, int algo, int root, const void* sendbuf, void* recvbuf, size_t count,
                       int dtype, int op) {
+  drain_worker(c);
   const size_t es = xmpi_dtype_size((xmpi_dtype)dtype);
   if (es == 0 || op < 0 || op >= XMPI_OP_COUNT || root < 0 || root >= c->size || algo < 0 || algo >= XMPI_ALGO_COUNT) {
     set_last_error("bad dtype / op / root / algo");
@@ -412,6 +479,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
 int xmpi_finalize(xmpi_comm* c) {
   if (!c) return XMPI_ERR_STATE;
   if (c->finalized) return XMPI_OK;
+  stop_worker(c);  // outstanding non-blocking collectives complete first
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   // nobody may still be writing into a window that is about to be unmapped
@@ -450,6 +518,7 @@ int xmpi_device(const xmpi_comm* c) { return (c && !c->finalized) ? c->device : 
 
 int xmpi_barrier(xmpi_comm* c) {
   XMPI_ENTER(c);
+  drain_worker(c);
   int rc = c->ctl->barrier(c->timeout_s > 0 ? (double)c->timeout_s : 3600.0);
   if (rc != XMPI_OK) set_last_error("barrier: a peer did not arrive");
   return rc;
@@ -604,6 +673,57 @@ int xmpi_allreduce(xmpi_comm* c, const void* sendbuf, void* recvbuf, size_t coun
 int xmpi_allgather(xmpi_comm* c, const void* sendbuf, void* recvbuf, size_t count, xmpi_dtype dtype, int algo) {
   XMPI_ENTER(c);
   return collective(c, COLL_ALLGATHER, algo, 0, sendbuf, recvbuf, count, (int)dtype, XMPI_SUM);
+}
+
+int xmpi_iallreduce(xmpi_comm* c, const void* sendbuf, void* recvbuf, size_t count, xmpi_dtype dtype, xmpi_op op, int algo,
+                    xmpi_request** req) {
+  XMPI_ENTER(c);
+  if (!req) return XMPI_ERR_ARG;
+  *req = submit(c, [=] { return xmpi_allreduce(c, sendbuf, recvbuf, count, dtype, op, algo); });
+  return XMPI_OK;
+}
+
+int xmpi_iallgather(xmpi_comm* c, const void* sendbuf, void* recvbuf, size_t count, xmpi_dtype dtype, int algo,
+                    xmpi_request** req) {
+  XMPI_ENTER(c);
+  if (!req) return XMPI_ERR_ARG;
+  *req = submit(c, [=] { return xmpi_allgather(c, sendbuf, recvbuf, count, dtype, algo); });
+  return XMPI_OK;
+}
+
+int xmpi_ibcast(xmpi_comm* c, void* buf, size_t count, xmpi_dtype dtype, int root, int algo, xmpi_request** req) {
+  XMPI_ENTER(c);
+  if (!req) return XMPI_ERR_ARG;
+  *req = submit(c, [=] { return xmpi_bcast(c, buf, count, dtype, root, algo); });
+  return XMPI_OK;
+}
+
+int xmpi_ireduce(xmpi_comm* c, const void* sendbuf, void* recvbuf, size_t count, xmpi_dtype dtype, xmpi_op op, int root,
+                 int algo, xmpi_request** req) {
+  XMPI_ENTER(c);
+  if (!req) return XMPI_ERR_ARG;
+  *req = submit(c, [=] { return xmpi_reduce(c, sendbuf, recvbuf, count, dtype, op, root, algo); });
+  return XMPI_OK;
+}
+
+int xmpi_request_test(xmpi_request* r, int* done) {
+  if (!r || !done) return XMPI_ERR_ARG;
+  std::lock_guard<std::mutex> l(r->mu);
+  *done = r->done ? 1 : 0;
+  return XMPI_OK;
+}
+
+int xmpi_request_wait(xmpi_request* r) {
+  if (!r) return XMPI_ERR_ARG;
+  int rc;
+  {
+    std::unique_lock<std::mutex> l(r->mu);
+    r->cv.wait(l, [r] { return r->done; });
+    rc = r->rc;
+    if (rc != XMPI_OK) set_last_error(r->err);
+  }
+  delete r;
+  return rc;
 }
 
 int xmpi_allreduce_repeat(xmpi_comm* c, const void* sendbuf, void* recvbuf, size_t count, xmpi_dtype dtype, xmpi_op op,

@@ -2,8 +2,11 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <condition_variable>
 #include <deque>
+#include <functional>
 #include <map>
+#include <thread>
 #include <mutex>
 #include <set>
 #include <string>
@@ -34,6 +37,15 @@ struct ProfCounter {
 enum ProfKind { PROF_REDUCE2 = 0, PROF_REDUCEN = 1, PROF_COPY = 2, PROF_PEER = 3, PROF_ZCOPY = 4, PROF_KINDS = 5 };
 
 }  // namespace xmpi
+
+// a non-blocking collective in flight (xmpi_iallreduce ...): completed by the communicator's worker
+struct xmpi_request {
+  std::mutex mu;
+  std::condition_variable cv;
+  bool done = false;
+  int rc = 0;
+  std::string err;  // the worker's error text, handed to the thread that waits
+};
 
 struct xmpi_comm {
   int rank = 0, size = 0, device = 0;
@@ -116,6 +128,15 @@ struct xmpi_comm {
   std::set<std::pair<int, int>> send_tags, recv_tags;  // active {peer, tag} (network.go:448-497)
   std::map<std::pair<int, int>, xmpi::MailEntry*> pending_sends;  // xmpi_send_nowait awaiting xmpi_wait
   std::vector<hipStream_t> p2p_streams;
+
+  // non-blocking collectives: one worker per communicator runs them in the order they were issued
+  // (every rank issues them in the same order, as with the blocking ones)
+  std::thread worker;
+  std::mutex wq_mu;
+  std::condition_variable wq_cv;
+  std::deque<std::pair<std::function<int()>, xmpi_request*>> wq;
+  size_t wq_busy = 0;  // queued + running
+  bool wq_stop = false, worker_started = false;
   bool finalized = false;
 };
 

@@ -73,6 +73,12 @@ SYMBOLS = [
     ("xmpi_dtype_size", _Z, [_I]),
     ("xmpi_allreduce_repeat", _I, [_P, _P, _P, _Z, _I, _I, _I, _I]),
     ("xmpi_heap_selftest", _I, [C.c_uint64, _I]),
+    ("xmpi_iallreduce", _I, [_P, _P, _P, _Z, _I, _I, _I, C.POINTER(_P)]),
+    ("xmpi_iallgather", _I, [_P, _P, _P, _Z, _I, _I, C.POINTER(_P)]),
+    ("xmpi_ibcast", _I, [_P, _P, _Z, _I, _I, _I, C.POINTER(_P)]),
+    ("xmpi_ireduce", _I, [_P, _P, _P, _Z, _I, _I, _I, _I, C.POINTER(_P)]),
+    ("xmpi_request_test", _I, [_P, C.POINTER(_I)]),
+    ("xmpi_request_wait", _I, [_P]),
     ("xmpi_send_nowait", _I, [_P, _P, _Z, _I, _I, _I]),
     ("xmpi_wait", _I, [_P, _I, _I]),
     ("xmpi_register", _I, [_P, _P, _Z]),
@@ -246,6 +252,38 @@ class Comm:
 
     def allreduce(self, send, recv, count: int, dtype: int, op: int = SUM, algo: int = ALGO_AUTO) -> None:
         _check(lib().xmpi_allreduce(self.handle, _ptr(send), _ptr(recv), count, dtype, op, algo), "xmpi_allreduce")
+
+    # non-blocking forms: return a request handle; request_wait() returns when the operation has completed
+    def iallreduce(self, send, recv, count: int, dtype: int, op: int = SUM, algo: int = ALGO_AUTO) -> int:
+        r = _P()
+        _check(lib().xmpi_iallreduce(self.handle, _ptr(send), _ptr(recv), count, dtype, op, algo, C.byref(r)), "xmpi_iallreduce")
+        return r.value
+
+    def iallgather(self, send, recv, count: int, dtype: int, algo: int = ALGO_AUTO) -> int:
+        r = _P()
+        _check(lib().xmpi_iallgather(self.handle, _ptr(send), _ptr(recv), count, dtype, algo, C.byref(r)), "xmpi_iallgather")
+        return r.value
+
+    def ibcast(self, buf, count: int, dtype: int, root: int, algo: int = ALGO_AUTO) -> int:
+        r = _P()
+        _check(lib().xmpi_ibcast(self.handle, _ptr(buf), count, dtype, root, algo, C.byref(r)), "xmpi_ibcast")
+        return r.value
+
+    def ireduce(self, send, recv, count: int, dtype: int, op: int, root: int, algo: int = ALGO_AUTO) -> int:
+        r = _P()
+        _check(lib().xmpi_ireduce(self.handle, _ptr(send), _ptr(recv), count, dtype, op, root, algo, C.byref(r)),
+               "xmpi_ireduce")
+        return r.value
+
+    @staticmethod
+    def request_test(req: int) -> bool:
+        d = _I(0)
+        _check(lib().xmpi_request_test(req, C.byref(d)), "xmpi_request_test")
+        return bool(d.value)
+
+    @staticmethod
+    def request_wait(req: int) -> None:
+        _check(lib().xmpi_request_wait(req), "xmpi_request_wait")
 
     def allreduce_repeat(self, send, recv, count: int, dtype: int, op: int, algo: int, iters: int) -> None:
         """`iters` back-to-back allreduces inside one call (a benchmark's step loop without the interpreter)."""

@@ -311,6 +311,63 @@ def sc_zero_copy(comm, args):
     comm.prof_enable(False)
 
 
+def sc_nonblocking(comm, args):
+    """Non-blocking collectives: issued back to back, completed by the communicator's worker in issue order
+    while the caller does its own work; results identical to the blocking forms."""
+    rank, size = comm.rank(), comm.size()
+    n = args.get("count", 300007)
+    ops = []
+    for k, (dtype, algo) in enumerate(((xmpi.F32, xmpi.ALGO_AUTO), (xmpi.I64, xmpi.ALGO_RING), (xmpi.F16, xmpi.ALGO_DIRECT))):
+        es = xmpi.DTYPE_SIZE[dtype]
+        s, r = comm.alloc(n * es), comm.alloc(n * es)
+        comm.fill(s, n, dtype, xmpi.PAT_SIGNED if dtype != xmpi.I64 else xmpi.PAT_UNIFORM, 600 + 10 * k + rank)
+        ops.append((dtype, algo, s, r, k))
+    reqs = [comm.iallreduce(s, r, n, dtype, xmpi.SUM, algo) for dtype, algo, s, r, _ in ops]
+    gs, gr = comm.alloc(n * 8), comm.alloc(n * 8 * size)
+    comm.fill(gs, n, xmpi.I64, xmpi.PAT_INDEX, rank)
+    reqs.append(comm.iallgather(gs, gr, n, xmpi.I64))
+    b = comm.alloc(n * 4)
+    comm.fill(b, n, xmpi.F32, xmpi.PAT_UNIFORM, 640 + rank)
+    reqs.append(comm.ibcast(b, n, xmpi.F32, size - 1))
+    # the caller's own work overlaps with all of that
+    x, y, z = comm.alloc(n * 4), comm.alloc(n * 4), comm.alloc(n * 4)
+    comm.fill(x, n, xmpi.F32, xmpi.PAT_UNIFORM, 1)
+    comm.fill(y, n, xmpi.F32, xmpi.PAT_UNIFORM, 2)
+    for _ in range(5):
+        comm.reduce_local(z, x, y, n, xmpi.F32, xmpi.SUM)
+    assert z.download(np.float32, n).tobytes() == oracle.reduce2(oracle.fill(n, xmpi.F32, 0, 1), oracle.fill(n, xmpi.F32, 0, 2),
+                                                                  xmpi.F32, xmpi.SUM).tobytes()
+    for q in reversed(reqs):  # completion order is the issue order, whatever order they are waited for in
+        comm.request_wait(q)
+    for dtype, algo, s, r, k in ops:
+        pat = xmpi.PAT_SIGNED if dtype != xmpi.I64 else xmpi.PAT_UNIFORM
+        ins = [oracle.fill(n, dtype, pat, 600 + 10 * k + q) for q in range(size)]
+        exact = algo != xmpi.ALGO_RING or dtype == xmpi.I64
+        check_reduced(r.download(xmpi.NUMPY_DTYPE[dtype], n), ins, dtype, xmpi.SUM, exact, f"iallreduce {k}")
+    want = oracle.allgather([oracle.fill(n, xmpi.I64, xmpi.PAT_INDEX, q) for q in range(size)], xmpi.I64)
+    assert gr.download(np.int64, n * size).tobytes() == want.tobytes()
+    assert b.download(np.float32, n).tobytes() == oracle.fill(n, xmpi.F32, xmpi.PAT_UNIFORM, 640 + size - 1).tobytes()
+    # a blocking collective issued while a non-blocking one is in flight runs after it, on every rank
+    dtype, algo, s, r, k = ops[0]
+    q1 = comm.iallreduce(s, r, n, dtype, xmpi.MAX, xmpi.ALGO_AUTO)
+    comm.allreduce(r, z, n, dtype, xmpi.SUM, xmpi.ALGO_AUTO)  # consumes the result of q1
+    assert comm.request_test(q1)
+    comm.request_wait(q1)
+    ins = [oracle.fill(n, dtype, xmpi.PAT_SIGNED, 600 + q) for q in range(size)]
+    mx = oracle.reduce_ranks(ins, dtype, xmpi.MAX)
+    check_reduced(z.download(np.float32, n), [mx] * size, dtype, xmpi.SUM, True, "blocking after non-blocking")
+    # the operation's own status comes back from wait
+    bad = comm.iallreduce(s, r, n, 99, xmpi.SUM, xmpi.ALGO_AUTO)
+    try:
+        comm.request_wait(bad)
+        raise AssertionError("a bad dtype must be reported by request_wait")
+    except xmpi.XmpiError as e:
+        assert e.code == xmpi.ERR_ARG
+    comm.barrier()
+    for buf in [gs, gr, b, x, y, z] + [o[2] for o in ops] + [o[3] for o in ops]:
+        buf.free()
+
+
 # ---- point to point ------------------------------------------------------------------------------
 
 BOUNCE_LENGTHS = [0, 1, 10, 100, 1000, 10**4, 10**5, 10**6, 10**7]  # examples/bounce/bounce.go:33
@@ -615,4 +672,5 @@ SCENARIOS = {
     "p2p_semantics": sc_p2p_semantics,
     "fullsize": sc_fullsize,
     "zero_copy": sc_zero_copy,
+    "nonblocking": sc_nonblocking,
 }

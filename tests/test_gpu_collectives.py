@@ -74,6 +74,15 @@ def test_zero_copy_disabled_by_param():
     run_ranks("allreduce_small", 2, {"counts": [1, 4099], "dtypes": [4]}, timeout=300, env={"XMPI_ZERO_COPY": "0"})
 
 
+@pytest.mark.parametrize("size", [2, 5])
+def test_nonblocking_collectives(size):
+    run_ranks("nonblocking", size, timeout=300)
+
+
+def test_nonblocking_collectives_threads():
+    run_threads("nonblocking", 3, {"count": 50021})
+
+
 @pytest.mark.parametrize("size", [2, 4])
 def test_bounce(size):
     """examples/bounce/bounce.go at its own message lengths + BASELINE cfg 2 (1 MiB f32)"""
