@@ -62,6 +62,9 @@ def parse_args():
     ap.add_argument("--algo", default="auto", choices=["auto", "ring", "rhd", "direct", "zcopy"])
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed sweeps after the timed region")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU reference-path baseline")
+    ap.add_argument("--probe", action="store_true",
+                    help="(internal) a short zero-copy allreduce in a job of its own; the exit status is the verdict")
+    ap.add_argument("--no-probe", action="store_true", help="skip the zero-copy probe before a multi-GPU run")
     ap.add_argument("--cpu-count", type=int, default=16 << 20,
                     help="float32 elements per rank of the CPU sample (64 MiB: ~10-30 CPU-seconds over 8 processes)")
     return ap.parse_args()
@@ -86,7 +89,8 @@ class Job:
         self.procs = self.world_procs
         self.ranks_per_proc = self.ranks // self.procs
         port = os.environ.get("MASTER_PORT", "0")
-        self.key = f"bench-{port}-{os.getppid() if self.procs > 1 else os.getpid()}"
+        self.key = os.environ.get("XMPI_BENCH_KEY") or f"bench-{port}-{os.getppid() if self.procs > 1 else os.getpid()}"
+        self.zero_copy_ok = True
         # ranks sharing a GPU have no link to pipeline against: large pieces (one launch per chunk)
         # keep every kernel at full-chip bandwidth; one rank per GPU keeps the library defaults
         if self.ranks // n >= 4:
@@ -165,6 +169,11 @@ def rank_main(job: Job, grank: int):
     R = comm.size()
     lead = grank == 0
     seed0 = 1000 if dtype != xmpi.F16 else 2000
+    # every process probed the zero-copy path in a job of its own (multi-GPU runs): one veto keeps all staged
+    zc_ok = all_max(comm, 0.0 if job.zero_copy_ok else 1.0) == 0.0
+    if not zc_ok:
+        comm.set_param("zero_copy", 0)
+    ZC = (xmpi.ALGO_ZCOPY,) if zc_ok else ()
     send, recv = comm.alloc(nbytes), comm.alloc(nbytes)
     comm.fill(send, count, dtype, xmpi.PAT_UNIFORM, seed0 + grank)
     comm.memset(recv, 0, nbytes)
@@ -192,7 +201,7 @@ def rank_main(job: Job, grank: int):
             cands = [(xmpi.ALGO_RING, 1, 0)]
         slot = comm.get_param("slot_bytes")
         pieces = sorted({0, slot}) if R > 1 else [0]  # 0 = library heuristic (~4 pieces per chunk)
-        if R > 1:
+        if R > 1 and zc_ok:
             cands.append((xmpi.ALGO_ZCOPY, 1, 0))  # no staging: channels / engine / piece size do not apply
         for algo, ch, eng in cands:
             for pc in (pieces if algo != xmpi.ALGO_ZCOPY else [0]):
@@ -210,8 +219,9 @@ def rank_main(job: Job, grank: int):
         comm.set_param("copy_engine", best["copy_engine"])
         comm.set_param("piece_bytes", best["piece_bytes"])
     else:
-        algo = {v: k for k, v in ALGO_NAME.items()}[a.algo]
-        best = {"algo": a.algo, "channels": comm.get_param("channels"), "copy_engine": comm.get_param("copy_engine"),
+        forced = a.algo if (a.algo != "zcopy" or zc_ok) else "ring"
+        algo = {v: k for k, v in ALGO_NAME.items()}[forced]
+        best = {"algo": forced, "channels": comm.get_param("channels"), "copy_engine": comm.get_param("copy_engine"),
                 "piece_bytes": comm.get_param("piece_bytes")}
         best_ring = None
 
@@ -294,7 +304,8 @@ def rank_main(job: Job, grank: int):
 
     out = {"t_step": t_step, "prof": prof, "tune": tune, "best": best, "best_ring": best_ring, "parity": parity,
            "algo": algo, "nbytes": nbytes, "count": count, "iso": iso, "parity_failures": parity_failures,
-           "shared_stream": comm.get_param("shared_stream"), "slot_bytes": comm.get_param("slot_bytes")}
+           "shared_stream": comm.get_param("shared_stream"), "slot_bytes": comm.get_param("slot_bytes"),
+           "zero_copy_probe": "ok" if zc_ok else "failed: staged schedules only"}
 
     # ---- untimed extras: what the next round needs to tune blind multi-GPU runs -----------------------
     extras = {}
@@ -305,7 +316,7 @@ def rank_main(job: Job, grank: int):
             comm.set_param("piece_bytes", cand.get("piece_bytes", 0))
 
         extras["algos_at_size"] = {}
-        for al in (xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_DIRECT, xmpi.ALGO_ZCOPY):
+        for al in (xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_DIRECT) + ZC:
             if al == xmpi.ALGO_RHD and R & (R - 1):
                 continue
             mine = [x for x in tune if x["algo"] == ALGO_NAME[al]]
@@ -324,7 +335,7 @@ def rank_main(job: Job, grank: int):
         while sz <= min(nbytes, 1 << 30):
             cnt = sz // es
             row = {"bytes": sz}
-            for al in (xmpi.ALGO_RING, xmpi.ALGO_DIRECT, xmpi.ALGO_ZCOPY):
+            for al in (xmpi.ALGO_RING, xmpi.ALGO_DIRECT) + ZC:
                 run(al, cnt)
                 t = timed(comm, lambda: run(al, cnt), 5 if sz <= (16 << 20) else 2)
                 row[ALGO_NAME[al] + "_us"] = t * 1e6
@@ -345,7 +356,7 @@ def rank_main(job: Job, grank: int):
                     s2, d2 = sub.alloc(nbytes), sub.alloc(nbytes)
                     sub.fill(s2, count, dtype, xmpi.PAT_UNIFORM, seed0 + grank)
                     row = {}
-                    for al in (xmpi.ALGO_ZCOPY, xmpi.ALGO_RING):
+                    for al in ZC + (xmpi.ALGO_RING,):
                         sub.allreduce(s2, d2, count, dtype, xmpi.SUM, al)
                         t = timed(sub, None, 3, batch=lambda k: sub.allreduce_repeat(s2, d2, count, dtype, xmpi.SUM, al, k))
                         row[ALGO_NAME[al]] = {"ms": t * 1e3, "algbw_GBps": nbytes / t / 1e9,
@@ -378,7 +389,7 @@ def rank_main(job: Job, grank: int):
         cnt3 = min(2097152, nbytes // 8 // R)
         if cnt3 > 0:
             extras["allgather_i64"] = {"bytes_per_rank": cnt3 * 8}
-            for al in (xmpi.ALGO_RING, xmpi.ALGO_ZCOPY):
+            for al in (xmpi.ALGO_RING,) + ZC:
                 comm.allgather(send, recv, cnt3, xmpi.I64, al)
                 t = timed(comm, lambda: comm.allgather(send, recv, cnt3, xmpi.I64, al), 3)
                 extras["allgather_i64"][ALGO_NAME[al]] = {"ms": t * 1e3, "busbw_GBps": cnt3 * 8 * R / t / 1e9 * (R - 1) / R}
@@ -390,7 +401,7 @@ def rank_main(job: Job, grank: int):
             comm.fill(s5, n5, xmpi.F16, xmpi.PAT_UNIFORM, 2000 + grank)
             comm.allreduce(s5, ref5, n5, xmpi.F16, xmpi.SUM, xmpi.ALGO_DIRECT)
             cfg5 = {"bytes_per_rank": n5 * 2}
-            for al in (xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_DIRECT, xmpi.ALGO_ZCOPY):
+            for al in (xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_DIRECT) + ZC:
                 if al == xmpi.ALGO_RHD and R & (R - 1):
                     continue
                 comm.allreduce(s5, r5, n5, xmpi.F16, xmpi.SUM, al)
@@ -456,10 +467,61 @@ def cpu_baseline(ranks: int, count: int):
                       f"(oracle/refpath.cpp restating network.go:518-625; no Go toolchain in the image)"}
 
 
+def probe_rank(job: Job, grank: int):
+    """--probe: one zero-copy allreduce of 16 MiB per rank, checked bit for bit against the oracle"""
+    from oracle import oracle
+    if os.environ.get("XMPI_BENCH_FAIL_PROBE"):  # rehearsal of the fallback
+        raise AssertionError("probe failure forced by XMPI_BENCH_FAIL_PROBE")
+    comm = xmpi.Comm(grank, job.ranks, job.device_of(grank), job.key)
+    count = 4 << 20
+    send, recv = comm.alloc(count * 4), comm.alloc(count * 4)
+    comm.fill(send, count, xmpi.F32, xmpi.PAT_SIGNED, 4000 + grank)
+    comm.memset(recv, 0, count * 4)
+    for _ in range(3):
+        comm.allreduce(send, recv, count, xmpi.F32, xmpi.SUM, xmpi.ALGO_ZCOPY)
+    went_staged = comm.get_param("zc_fallbacks_unregistered") + comm.get_param("zc_fallbacks_unmappable")
+    off = (count // 3) // 8 * 8
+    ins = [oracle.fill(count, xmpi.F32, xmpi.PAT_SIGNED, 4000 + r)[off:off + 65536] for r in range(job.ranks)]
+    got = recv.download(np.float32, 65536, byte_offset=off * 4)
+    ok = went_staged == 0 and got.tobytes() == oracle.reduce_ranks(ins, xmpi.F32, oracle.SUM).tobytes()
+    comm.barrier()
+    comm.finalize()
+    if not ok:
+        raise AssertionError(f"rank {grank}: zero-copy probe failed (staged fallbacks: {went_staged})")
+
+
+def probe_zero_copy(job: Job) -> bool:
+    """The zero-copy kernels load and store through xGMI-mapped peer memory.  On a node this code has not run
+    on before, try that in a job of its own (child processes): if it faults, hangs or gives wrong bits, this
+    run keeps to the staged schedules instead of dying without a result."""
+    env = dict(os.environ, XMPI_BENCH_KEY=job.key + "-probe", XMPI_TIMEOUT_S="30")
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(job.args.gpus), "--ranks", str(job.ranks), "--probe"]
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=150)
+    except subprocess.TimeoutExpired:
+        sys.stderr.write("[bench] zero-copy probe timed out: keeping to the staged schedules\n")
+        return False
+    if p.returncode != 0:
+        sys.stderr.write(f"[bench] zero-copy probe failed (exit {p.returncode}): keeping to the staged schedules\n"
+                         f"{(p.stdout or '')[-1500:]}\n")
+    return p.returncode == 0
+
+
 def main():
     args = parse_args()
     sys.setswitchinterval(1e-4)  # rank threads hand the GIL over quickly between their (GIL-free) C calls
     job = Job(args)
+    if args.probe:
+        threads = [threading.Thread(target=_guard, args=(job, g, probe_rank)) for g in job.my_ranks()]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for g, tb in job.errors:
+            sys.stderr.write(f"[probe] rank {g}:\n{tb}\n")
+        sys.exit(1 if job.errors else 0)
+    if (args.gpus > 1 or job.procs > 1) and not args.no_probe:
+        job.zero_copy_ok = probe_zero_copy(job)
     threads = [threading.Thread(target=_guard, args=(job, g)) for g in job.my_ranks()]
     for t in threads:
         t.start()
@@ -537,6 +599,7 @@ def main():
         "algbw_GBps": algbw, "busbw_GBps": busbw,
         "xgmi": {"per_link_peak_GBps": XGMI_LINK_GBPS, "busbw_frac_of_link_peak": busbw / XGMI_LINK_GBPS,
                  "meaningful": args.gpus == R},
+        "zero_copy_probe": r0["zero_copy_probe"] if (args.gpus > 1 or job.procs > 1) and not args.no_probe else "not run (1 GPU)",
         "roofline": roof, "roofline_isolated": r0["iso"], "other_kernels": others, "parity": r0["parity"], "parity_failures": r0["parity_failures"], "autotune": r0["tune"], "ring_best": r0["best_ring"],
         "extras": r0["extras"],
     }
@@ -548,9 +611,9 @@ def main():
     sys.stdout.flush()
 
 
-def _guard(job, g):
+def _guard(job, g, fn=None):
     try:
-        rank_main(job, g)
+        (fn or rank_main)(job, g)
     except BaseException:  # noqa: BLE001
         import traceback
         with job.lock:
