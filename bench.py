@@ -384,6 +384,25 @@ def rank_main(job: Job, grank: int):
                     comm.send(recv, n1, xmpi.F32, peer, 3)
             half = (time.perf_counter() - t0) / iters / 2
             extras["bounce_1MiB_f32"] = {"half_round_trip_us": half * 1e6, "GBps": n1 * 4 / half / 1e9}
+            # the reference's own sweep (examples/bounce/bounce.go:33: message lengths 0 ... 1e7 bytes, 10 repetitions,
+            # bounce.go:140-151 prints the mean round trip per length)
+            sweep_b = []
+            for length in (0, 1, 10, 100, 1000, 10**4, 10**5, 10**6, 10**7):
+                if length > nbytes:
+                    break
+                reps = 10
+                for w in range(2 + reps):
+                    if w == 2:
+                        t0 = time.perf_counter()
+                    if grank == 0:
+                        comm.send(send, length, xmpi.U8, peer, 4)
+                        comm.recv(recv, length, xmpi.U8, peer, 4)
+                    else:
+                        comm.recv(recv, length, xmpi.U8, peer, 4)
+                        comm.send(recv, length, xmpi.U8, peer, 4)
+                rt = (time.perf_counter() - t0) / reps
+                sweep_b.append({"bytes": length, "round_trip_us": rt * 1e6, "GBps": 2 * length / rt / 1e9})
+            extras["bounce_sweep_u8"] = sweep_b
         comm.barrier()
         # BASELINE cfg 3 shape: allgather int64, 16 MiB per rank
         cnt3 = min(2097152, nbytes // 8 // R)
@@ -465,6 +484,24 @@ def cpu_baseline(ranks: int, count: int):
             "sample": f"allreduce-sum f32, {s >> 20} MiB per rank, {ranks} ranks (one OS process each, unpinned), "
                       f"3 repetitions; loopback TCP + gob framing, all-to-all exchange + rank-order host sum "
                       f"(oracle/refpath.cpp restating network.go:518-625; no Go toolchain in the image)"}
+
+
+def cpu_bounce():
+    """oracle/refpath_bin bounce: the reference's ping-pong (bounce.go:83-151) over loopback TCP + gob, 2 processes"""
+    binp = os.path.join(ROOT, "oracle", "refpath_bin")
+    if not os.path.exists(binp):
+        return None
+    base = 23000 + (os.getpid() % 20000)
+    ports = [f":{base}", f":{base + 1}"]
+    procs = [subprocess.Popen([binp, "bounce", "-mpi-addr", p, "-mpi-alladdr", ",".join(ports), "10000000", "10"],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for p in ports]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    if any(p.returncode != 0 for p in procs):
+        return {"error": outs[0][-300:]}
+    row = json.loads(outs[0].strip().split("\n")[-1])
+    lens = (0, 1, 10, 100, 1000, 10**4, 10**5, 10**6, 10**7)
+    return [{"bytes": n, "round_trip_us": us, "GBps": 2 * n / (us * 1e-6) / 1e9 if us > 0 else 0.0}
+            for n, us in zip(lens, row["bytes_us"])]
 
 
 def probe_rank(job: Job, grank: int):
@@ -605,6 +642,8 @@ def main():
     }
     if args.gpus == 1 and not args.no_cpu and job.proc_rank == 0:
         line["cpu_baseline"] = cpu_baseline(R, args.cpu_count)
+        if isinstance(line.get("extras"), dict) and "bounce_sweep_u8" in line["extras"]:
+            line["extras"]["cpu_reference_bounce_u8"] = cpu_bounce()  # same lengths, the reference path on the host
     else:
         line["cpu_baseline"] = None
     print(json.dumps(line))

@@ -127,10 +127,11 @@ int xmpi_sync(xmpi_comm* comm);
  * consumed the message (network.go:569).  {dest,tag} must be unique among concurrent sends
  * (mpi.go:121-125) -> XMPI_ERR_TAG_EXISTS otherwise.  dest == own rank is allowed
  * (network.go:545-548) when a concurrent xmpi_recv is posted from another thread.
- * A message of >= p2p_direct_bytes (4 KiB) from a registered buffer (xmpi_malloc / xmpi_register) is
- * not pushed at all: the matching receive copies it straight out of the sender's HBM (one pass, one
- * xGMI crossing).  Shorter messages, host buffers and unregistered device memory travel through
- * the mail slots of the receiver's window (slot-in by the sender, slot-out by the receiver). */
+ * A non-empty message from a registered buffer (xmpi_malloc / xmpi_register; p2p_direct_bytes = 1 is
+ * the smallest such message, < 0 turns this off) is not pushed at all: the matching receive copies it
+ * straight out of the sender's HBM (one pass, one xGMI crossing).  Host buffers and unregistered
+ * device memory travel through the mail slots of the receiver's window (slot-in by the sender,
+ * slot-out by the receiver). */
 int xmpi_send(xmpi_comm* comm, const void* buf, size_t count, xmpi_dtype dtype, int dest, int tag);
 
 /* The split of Send the reference's author sketched and left commented out (mpi.go:132-152):

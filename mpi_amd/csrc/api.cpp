@@ -359,7 +359,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   c->zero_copy = env_long("XMPI_ZERO_COPY", 1) ? 1 : 0;
   c->zc_bcast_push_bytes = std::max<long>(0, env_long("XMPI_ZC_BCAST_PUSH_BYTES", 256 << 10));
   c->zc_group_launch = env_long("XMPI_ZC_GROUP_LAUNCH", 1) ? 1 : 0;
-  c->p2p_direct_bytes = env_long("XMPI_P2P_DIRECT_BYTES", 4096);
+  c->p2p_direct_bytes = env_long("XMPI_P2P_DIRECT_BYTES", 1);
   if (getenv("XMPI_KERNEL_MODE")) set_kernel_mode((int)env_long("XMPI_KERNEL_MODE", -1));
   if (getenv("XMPI_GRID_CAP")) set_grid_cap((int)env_long("XMPI_GRID_CAP", 0));
   c->coll_region_bytes = (size_t)size * c->lanes * c->fifo_depth * c->slot_bytes;

@@ -412,10 +412,10 @@ def sc_bounce(comm, args):
     # registered buffers of >= p2p_direct_bytes were pulled straight out of the sender's HBM (one copy);
     # shorter ones, or everything when p2p_direct_bytes < 0, went through the mail slots
     direct, staged = comm.get_param("p2p_direct_count"), comm.get_param("p2p_staged_count")
-    if comm.get_param("p2p_direct_bytes") >= 0:
-        assert direct >= 2 * 4 + 5 and staged >= 2 * 3, (direct, staged)
-    else:
-        assert direct == 0 and staged > 0, (direct, staged)
+    thr = comm.get_param("p2p_direct_bytes")
+    sizes = [c * xmpi.DTYPE_SIZE[d] for length in BOUNCE_LENGTHS for d, c in ((xmpi.U8, length), (xmpi.F64, length // 8))]
+    want_direct = 0 if thr < 0 else sum(1 for b in sizes if b >= max(1, thr)) + 5
+    assert direct == want_direct and staged == len(sizes) + 5 - want_direct, (direct, staged, want_direct)
 
 
 def sc_helloworld(comm, args):

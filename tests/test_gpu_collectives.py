@@ -105,7 +105,7 @@ def test_helloworld(size):
     run_ranks("helloworld", size, timeout=300)
 
 
-@pytest.mark.parametrize("direct", ["4096", "-1"])
+@pytest.mark.parametrize("direct", ["1", "4096", "-1"])
 def test_p2p_semantics(direct):
     run_ranks("p2p_semantics", 2, timeout=300, env={"XMPI_P2P_SLOT_BYTES": "65536", "XMPI_P2P_DIRECT_BYTES": direct})
 
