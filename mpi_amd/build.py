@@ -64,7 +64,8 @@ def build_host(force: bool = False) -> list[str]:
                   "-L", os.path.dirname(LIB), "-lxmpi", "-Wl,-rpath,$ORIGIN", "-lpthread"])
         outs.append(HOSTLIB)
         for name, src in (("helloworld", os.path.join(ROOT, "examples", "helloworld.cpp")),
-                          ("bounce", os.path.join(ROOT, "examples", "bounce.cpp"))):
+                          ("bounce", os.path.join(ROOT, "examples", "bounce.cpp")),
+                          ("allreduce", os.path.join(ROOT, "examples", "allreduce.cpp"))):
             if os.path.exists(src):
                 out = os.path.join(BIN, name)
                 if force or _newer(out, [src, HOSTLIB] + deps):

@@ -62,3 +62,14 @@ def test_bounce_program(mode):
     assert "Average byte trip time in µs between node 0 and 1: [" in r.stdout
     assert "Average float64 trip time in µs between node 0 and 1: [" in r.stdout
     assert "message not the same" not in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,elems", [(2, 1 << 20), (4, 100003), (8, 4099)])
+def test_allreduce_program(n, elems):
+    """examples/allreduce.cpp: the collectives through the C++ mirror's package-level functions, launched like a
+    reference program (xmpirun = gompirun); the program checks every result against its closed form"""
+    r = subprocess.run([os.path.join(BIN, "xmpirun"), str(n), os.path.join(BIN, "allreduce"), str(elems)],
+                       capture_output=True, text=True, timeout=300, env={**os.environ, "XMPI_BASEPORT": str(6300 + 10 * n)})
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"allreduce of {elems} float32 over {n} nodes" in r.stdout and "every result exact" in r.stdout
