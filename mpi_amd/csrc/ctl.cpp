@@ -142,7 +142,7 @@ int Ctl::join(const std::string& key, int rank, int size, const CtlConfig& cfg, 
     }
     memset(base, 0, bytes);  // every counter, state and flag starts at zero
     CtlHeader* h = new (base) CtlHeader;
-    h->version = 2;
+    h->version = kCtlVersion;
     h->size = size;
     h->total_bytes = bytes;
     h->creator_pid = (int32_t)getpid();
@@ -193,7 +193,7 @@ int Ctl::join(const std::string& key, int rank, int size, const CtlConfig& cfg, 
         const int cp = h->creator_pid;
         const bool alive = (kill(cp, 0) == 0 || errno == EPERM) && proc_start_time(cp) == h->creator_start;
         ok = alive && h->size == size && h->total_bytes == bytes && h->abort_code.load() == 0 &&
-             h->version == 2;
+             h->version == kCtlVersion;
       }
       if (ok) {
         base = m;

@@ -18,6 +18,7 @@ constexpr int kMaxRanks = 16;
 constexpr int kMaxLanes = 4;
 constexpr int kMailEntries = 4;  // concurrent messages per ordered rank pair
 constexpr uint64_t kCtlMagic = 0x584D504943544C31ull;  // "XMPICTL1"
+constexpr uint32_t kCtlVersion = 4;  // layout of the block: bump with every change of the structs below
 
 struct alignas(64) Counter {
   std::atomic<uint64_t> v;
