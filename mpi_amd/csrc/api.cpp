@@ -1047,17 +1047,58 @@ int xmpi_ctl_selftest(const char* job_key, int rank, int size, int rounds) {
     }
     out->tag = k;
     out->bytes = (uint64_t)k * 10u + (uint64_t)rank;
+    memset(&out->src, 0, sizeof out->src);  // the direct-pull offer of a registered payload travels with the header
+    out->src.base = 0x1000u * (uint64_t)(rank + 1);
+    out->src.gen = (uint64_t)k;
+    out->src.offset = (uint64_t)rank;
+    out->direct.store(DIRECT_OFFERED, std::memory_order_relaxed);
     out->state.store(MAIL_POSTED, std::memory_order_release);
     MailEntry* in = ctl->mail(prev, rank, k % kMailEntries);
     rc = wait_for([&] { return in->state.load(std::memory_order_acquire) == MAIL_POSTED && in->tag == k; });
     if (rc != XMPI_OK) break;
-    if (in->bytes != (uint64_t)k * 10u + (uint64_t)prev) {
+    if (in->bytes != (uint64_t)k * 10u + (uint64_t)prev || in->direct.load(std::memory_order_acquire) != DIRECT_OFFERED ||
+        in->src.base != 0x1000u * (uint64_t)(prev + 1) || in->src.gen != (uint64_t)k || in->src.offset != (uint64_t)prev) {
       rc = XMPI_ERR_STATE;
       break;
     }
+    in->direct.store(k % 2 ? DIRECT_ACCEPTED : DIRECT_DECLINED, std::memory_order_release);
     in->state.store(MAIL_DONE, std::memory_order_release);
     rc = wait_for([&] { return out->state.load(std::memory_order_acquire) == MAIL_DONE; });
+    if (rc == XMPI_OK && out->direct.load(std::memory_order_acquire) != (k % 2 ? DIRECT_ACCEPTED : DIRECT_DECLINED))
+      rc = XMPI_ERR_STATE;
     out->state.store(MAIL_FREE, std::memory_order_release);
+    if (rc != XMPI_OK) break;
+    // zero-copy collective k: descriptors are double-buffered by sequence parity; everybody reads
+    // everybody's after the barrier, a rank that freed buffers says so in its retire log
+    BufDesc* mine = ctl->desc(rank, (uint64_t)k);
+    mine->ok = 1;
+    mine->fresh = (k + rank) % 3 == 0;
+    mine->send.base = 0x100000u * (uint64_t)(rank + 1) + (uint64_t)k;
+    mine->send.gen = (uint64_t)k * 100u + (uint64_t)rank;
+    mine->recv = mine->send;
+    mine->recv.offset = 64u * (uint64_t)k;
+    for (size_t b = 0; b < sizeof mine->send.handle; b++) mine->send.handle[b] = (uint8_t)(b + (size_t)rank + (size_t)k);
+    mine->seq.store((uint64_t)k, std::memory_order_release);
+    RetireLog* log = ctl->retired(rank);
+    for (int j = 0; j < rank + 1; j++) {  // rank r retires r+1 allocations per round
+      const uint64_t n = log->count.load(std::memory_order_relaxed);
+      log->gen[n % kRetireRing] = ((uint64_t)rank << 32) | n;
+      log->count.store(n + 1, std::memory_order_release);
+    }
+    rc = ctl->barrier(30.0);
+    if (rc != XMPI_OK) break;
+    for (int p = 0; p < size && rc == XMPI_OK; p++) {
+      const BufDesc* d = ctl->desc(p, (uint64_t)k);
+      const RetireLog* lp = ctl->retired(p);
+      const uint64_t n = lp->count.load(std::memory_order_acquire);
+      bool good = d->seq.load(std::memory_order_acquire) == (uint64_t)k && d->ok == 1 && d->fresh == ((k + p) % 3 == 0) &&
+                  d->send.base == 0x100000u * (uint64_t)(p + 1) + (uint64_t)k &&
+                  d->send.gen == (uint64_t)k * 100u + (uint64_t)p && d->recv.offset == 64u * (uint64_t)k &&
+                  d->send.handle[5] == (uint8_t)(5 + p + k) && n == (uint64_t)k * (uint64_t)(p + 1);
+      for (uint64_t j = n > (uint64_t)kRetireRing ? n - kRetireRing : 0; j < n && good; j++)
+        good = lp->gen[j % kRetireRing] == (((uint64_t)p << 32) | j);
+      if (!good) rc = XMPI_ERR_STATE;
+    }
   }
   if (rc != XMPI_OK) ctl->set_abort(rc);
   else rc = ctl->barrier(30.0);
