@@ -1,6 +1,6 @@
 // allreduce -- what a user of the reference would write once `//func AllReduce() {}` (mpi.go:130) is
 // filled in: the package-level collectives of the C++ mirror of package mpi, on HBM buffers and on
-// plain host slices, plus the non-blocking form through the C ABI.  Every result is checked against
+// plain host slices, plus the non-blocking form.  Every result is checked against
 // its closed form, so the exit status is the verdict.
 //   xmpirun N allreduce [elements]
 #include <chrono>
@@ -52,11 +52,10 @@ int main(int argc, char** argv) {
   if (mpi::Error err = mpi::Allreduce(mpi::Slice(x), mpi::Into(&host_out))) return fail("allreduce(host)", err);
   check_sum(host_out, "allreduce(host)");
 
-  // 3. non-blocking, through the C ABI the Go shim binds; the caller is free until Wait
+  // 3. non-blocking: the caller is free to do its own work until WaitRequest
   xmpi_request* req = nullptr;
-  if (xmpi_iallreduce(gpu->Handle(), send, recv, n, XMPI_F32, XMPI_MAX, XMPI_ALGO_AUTO, &req) != XMPI_OK)
-    return fail("iallreduce", mpi::Error(XMPI_ERR_STATE, xmpi_last_error()));
-  if (xmpi_request_wait(req) != XMPI_OK) return fail("wait", mpi::Error(XMPI_ERR_STATE, xmpi_last_error()));
+  if (mpi::Error err = gpu->IAllreduce(mpi::Span(send, n), mpi::Span(recv, n), XMPI_MAX, &req)) return fail("iallreduce", err);
+  if (mpi::Error err = gpu->WaitRequest(req)) return fail("wait", err);
   if (mpi::Error err = gpu->Memcpy(got.data(), recv, n * sizeof(float))) return fail("download", err);
   for (size_t i = 0; i < n; i++)
     if (got[i] != (float)size + (float)(i % 7) && bad++ < 3) fprintf(stderr, "node %d: max[%zu] = %g\n", rank, i, got[i]);

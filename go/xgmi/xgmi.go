@@ -357,7 +357,34 @@ func (b *Backend) Allgather(send, recv interface{}) error {
 // Barrier is a host-side rendezvous of all ranks.
 func (b *Backend) Barrier() error { return status(C.xmpi_barrier(b.comm), "mpi barrier") }
 
-// Malloc allocates `count` elements of HBM on this rank's GPU.
+// IAllreduce starts an allreduce on DeviceBuffers and returns at once; the error arrives on the
+// channel when the operation has completed (non-blocking collectives run in issue order on the
+// communicator's worker: issue them in the same order on every rank).  Device buffers only: C keeps
+// the pointers after the call returns, which cgo forbids for Go memory.
+func (b *Backend) IAllreduce(send, recv DeviceBuffer, op int) <-chan error {
+	done := make(chan error, 1)
+	var req *C.xmpi_request
+	rc := C.xmpi_iallreduce(b.comm, send.Ptr, recv.Ptr, C.size_t(send.Count), C.xmpi_dtype(send.Type), C.xmpi_op(op),
+		C.int(b.Algo), &req)
+	if err := status(rc, "mpi iallreduce"); err != nil {
+		done <- err
+		return done
+	}
+	go func() { done <- status(C.xmpi_request_wait(req), "mpi iallreduce") }()
+	return done
+}
+
+// Register makes device memory that did not come from Malloc (another allocator's) reachable by the
+// zero-copy collectives and the direct point-to-point path; Deregister before freeing it.
+func (b *Backend) Register(ptr unsafe.Pointer, bytes int) error {
+	return status(C.xmpi_register(b.comm, ptr, C.size_t(bytes)), "mpi register")
+}
+func (b *Backend) Deregister(ptr unsafe.Pointer) error {
+	return status(C.xmpi_deregister(b.comm, ptr), "mpi deregister")
+}
+
+// Malloc allocates `count` elements of HBM on this rank's GPU: a block of an arena every peer maps
+// once, so collectives and Send / Receive on it move the bytes GPU to GPU in one pass.
 func (b *Backend) Malloc(count int, dt DType) DeviceBuffer {
 	bytes := C.size_t(count) * C.xmpi_dtype_size(C.xmpi_dtype(dt))
 	return DeviceBuffer{Ptr: C.xmpi_malloc(b.comm, bytes), Count: count, Type: dt}

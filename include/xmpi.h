@@ -260,8 +260,9 @@ int xmpi_link_probe(xmpi_comm* comm, int peer, size_t bytes, int engine, int ite
                     double* gbps);
 
 /* Host-only self-test of the control plane shared by the ranks of a job (no GPU call): every rank
- * of `size` calls it with the same key; exercises join, barriers, pipe counters and the mail-entry
- * states for `rounds` rounds.  Used by the CPU test-suite with plain OS processes. */
+ * of `size` calls it with the same key; exercises join, barriers, pipe counters, the mail-entry
+ * states (with the direct-pull offer), the zero-copy buffer descriptors and the retire logs for
+ * `rounds` rounds.  Used by the CPU test-suite with plain OS processes. */
 int xmpi_ctl_selftest(const char* job_key, int rank, int size, int rounds);
 
 /* Schedule introspection (host logic only, no GPU needed): writes the step table the executor

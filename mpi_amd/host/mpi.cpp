@@ -224,6 +224,16 @@ Error XGMI::Allgather(const Data& send, Data recv) {
 
 Error XGMI::Barrier() { return from_code(xmpi_barrier(comm_), "mpi barrier"); }
 
+Error XGMI::IAllreduce(const Data& send, Data recv, xmpi_op op, xmpi_request** req) {
+  if (recv.resize) recv.resize(recv.owner, send.count, &recv);
+  return from_code(xmpi_iallreduce(comm_, send.ptr, recv.ptr, send.count, send.dtype, op, Algo, req), "mpi iallreduce");
+}
+
+Error XGMI::WaitRequest(xmpi_request* req) { return from_code(xmpi_request_wait(req), "mpi wait"); }
+
+Error XGMI::RegisterBuffer(void* p, size_t bytes) { return from_code(xmpi_register(comm_, p, bytes), "mpi register"); }
+Error XGMI::DeregisterBuffer(void* p) { return from_code(xmpi_deregister(comm_, p), "mpi deregister"); }
+
 void* XGMI::Malloc(size_t bytes) { return xmpi_malloc(comm_, bytes); }
 void XGMI::Free(void* p) { xmpi_free(comm_, p); }
 Error XGMI::Memcpy(void* dst, const void* src, size_t bytes) { return from_code(xmpi_memcpy(comm_, dst, src, bytes), "mpi memcpy"); }

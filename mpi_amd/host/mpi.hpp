@@ -171,6 +171,16 @@ class XGMI : public Interface, public Collective {
   Error SendNoWait(const Data& data, int destination, int tag);
   Error Wait(int destination, int tag);
 
+  // Non-blocking allreduce: returns at once, WaitRequest blocks until it completed (operations issued
+  // this way run in issue order on the communicator's worker; the buffers belong to the operation until then).
+  Error IAllreduce(const Data& send, Data recv, xmpi_op op, xmpi_request** req);
+  Error WaitRequest(xmpi_request* req);
+
+  // Device memory from another allocator joins the zero-copy paths with RegisterBuffer (Malloc'd memory
+  // is registered as it is); DeregisterBuffer before it is freed.
+  Error RegisterBuffer(void* p, size_t bytes);
+  Error DeregisterBuffer(void* p);
+
   // HBM buffers of this rank (device-resident payloads are the hot path)
   void* Malloc(size_t bytes);
   void Free(void* p);
