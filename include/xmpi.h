@@ -2,7 +2,7 @@
  * xmpi.h -- C ABI of the MI355X-native message-passing / collectives library.
  *
  * This header is the drop-in boundary: it is what a cgo shim (see INTEGRATION.md and
- * go/mpi/xgmi.go) binds to put an xGMI/HIP backend behind btracey/mpi's Go API.  Every
+ * go/xgmi/xgmi.go) binds to put an xGMI/HIP backend behind btracey/mpi's Go API.  Every
  * entry point names the reference interface it replaces (file:line are relative to the
  * reference repository root).
  *
@@ -10,8 +10,9 @@
  *   - plain C: opaque handle, raw pointers, sizes in ELEMENTS of `dtype` unless stated;
  *   - every function returns 0 (XMPI_OK) or a negative xmpi error code; HIP failures are
  *     mapped to XMPI_ERR_HIP and the HIP error text is kept for xmpi_last_error();
- *   - all calls are blocking (reference: mpi.go:47-48) and may be called from any OS thread
- *     (cgo moves goroutines between threads; each entry point re-selects the comm's device);
+ *   - calls are blocking (reference: mpi.go:47-48) except xmpi_send_nowait and the xmpi_i*
+ *     collectives, and may be made from any OS thread (cgo moves goroutines between threads; each
+ *     entry point re-selects the comm's device);
  *   - buffers may be device pointers (HBM, the hot path) or host pointers (staged by HIP);
  *   - one communicator == one rank == one process == one MI355X.
  */

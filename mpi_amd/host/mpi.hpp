@@ -2,7 +2,7 @@
 //
 // The reference is compiled Go; this image has no Go toolchain, so the host side above the C ABI
 // (include/xmpi.h) is written in C++ with the reference's names, argument meaning and error
-// behaviour.  The Go binding a maintainer would add is in go/mpi/ and INTEGRATION.md.
+// behaviour.  The Go binding a maintainer would add is in go/xgmi/ and INTEGRATION.md.
 //
 //   reference (Go)                                   here (C++)
 //   mpi.Register(mpi.Interface)      mpi.go:61-67    mpi::Register(Interface*)   (2nd call throws: Go panics)
