@@ -47,7 +47,9 @@ from mpi_amd import xmpi  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s
 XGMI_LINK_GBPS = 153.0   # per-link peak (bidirectional), task statement
-ALGO_NAME = {xmpi.ALGO_RING: "ring", xmpi.ALGO_RHD: "rhd", xmpi.ALGO_DIRECT: "direct", xmpi.ALGO_ZCOPY: "zcopy"}
+ALGO_NAME = {xmpi.ALGO_RING: "ring", xmpi.ALGO_RHD: "rhd", xmpi.ALGO_DIRECT: "direct", xmpi.ALGO_ZCOPY: "zcopy",
+             xmpi.ALGO_ZPUSH: "zpush"}
+ZC_ALGOS = (xmpi.ALGO_ZCOPY, xmpi.ALGO_ZPUSH)
 DT = {"f32": xmpi.F32, "f16": xmpi.F16, "f64": xmpi.F64, "bf16": xmpi.BF16, "i64": xmpi.I64}
 
 
@@ -59,7 +61,7 @@ def parse_args():
     ap.add_argument("--ranks", type=int, default=0, help="total ranks (default 8 when it divides by --gpus)")
     ap.add_argument("--size-mib", type=float, default=256.0, help="bytes per rank")
     ap.add_argument("--dtype", default="f32", choices=sorted(DT))
-    ap.add_argument("--algo", default="auto", choices=["auto", "ring", "rhd", "direct", "zcopy"])
+    ap.add_argument("--algo", default="auto", choices=["auto", "ring", "rhd", "direct", "zcopy", "zpush"])
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed sweeps after the timed region")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU reference-path baseline")
     ap.add_argument("--probe", action="store_true",
@@ -203,8 +205,9 @@ def rank_main(job: Job, grank: int):
         pieces = sorted({0, slot}) if R > 1 else [0]  # 0 = library heuristic (~4 pieces per chunk)
         if R > 1 and zc_ok:
             cands.append((xmpi.ALGO_ZCOPY, 1, 0))  # no staging: channels / engine / piece size do not apply
+            cands.append((xmpi.ALGO_ZPUSH, 1, 0))  # ... the variant that only writes over xGMI (3 kernels)
         for algo, ch, eng in cands:
-            for pc in (pieces if algo != xmpi.ALGO_ZCOPY else [0]):
+            for pc in (pieces if algo not in ZC_ALGOS else [0]):
                 comm.set_param("channels", ch)
                 comm.set_param("copy_engine", eng)
                 comm.set_param("piece_bytes", pc)
@@ -219,7 +222,7 @@ def rank_main(job: Job, grank: int):
         comm.set_param("copy_engine", best["copy_engine"])
         comm.set_param("piece_bytes", best["piece_bytes"])
     else:
-        forced = a.algo if (a.algo != "zcopy" or zc_ok) else "ring"
+        forced = a.algo if (a.algo not in ("zcopy", "zpush") or zc_ok) else "ring"
         algo = {v: k for k, v in ALGO_NAME.items()}[forced]
         best = {"algo": forced, "channels": comm.get_param("channels"), "copy_engine": comm.get_param("copy_engine"),
                 "piece_bytes": comm.get_param("piece_bytes")}
@@ -262,7 +265,7 @@ def rank_main(job: Job, grank: int):
     # every 4th launch of a kind carries its own begin/end events (hipExtLaunchKernelGGL): the events are
     # exact per dispatch whatever runs around them, and sampling keeps their cost out of `value`
     # (a zero-copy step is ONE launch per GPU process: every 2nd carries events)
-    comm.set_param("prof_every", 2 if algo == xmpi.ALGO_ZCOPY else 4)
+    comm.set_param("prof_every", 2 if algo == xmpi.ALGO_ZCOPY else (1 if algo == xmpi.ALGO_ZPUSH else 4))
     t_step = timed(comm, None, a.steps, prof=True, batch=lambda k: run_n(algo, k))
     prof = {k: comm.prof_get(k) for k in (xmpi.PROF_REDUCE2, xmpi.PROF_REDUCEN, xmpi.PROF_COPY, xmpi.PROF_PEER,
                                           xmpi.PROF_ZCOPY)}
@@ -316,7 +319,7 @@ def rank_main(job: Job, grank: int):
             comm.set_param("piece_bytes", cand.get("piece_bytes", 0))
 
         extras["algos_at_size"] = {}
-        for al in (xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_DIRECT) + ZC:
+        for al in (xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_DIRECT) + (ZC_ALGOS if zc_ok else ()):
             if al == xmpi.ALGO_RHD and R & (R - 1):
                 continue
             mine = [x for x in tune if x["algo"] == ALGO_NAME[al]]
@@ -577,7 +580,11 @@ def main():
     n2, ms2, b2 = r0["prof"][xmpi.PROF_REDUCE2]
     nn, msn, bn = r0["prof"][xmpi.PROF_REDUCEN]
     nz, msz, bz = r0["prof"][xmpi.PROF_ZCOPY]
-    if nz and msz >= max(ms2, msn):
+    if nz and msz >= max(ms2, msn) and r0["best"]["algo"] == "zpush":
+        kname, launches, ms, by = ("zero-copy push pipeline: copy_batch_kernel (contributions into the peers' receive buffers) + "
+                                   f"reduce_n_multi_kernel<float,SUM,{R}> (local rank-order fold) + copy_multi_kernel (results to "
+                                   "all peers); bytes and time summed over the three"), nz, msz, bz
+    elif nz and msz >= max(ms2, msn):
         kname, launches, ms, by = (f"reduce_n_multi_kernel<float,SUM,{R}> (zero-copy allreduce: folds chunk j of the {R} send "
                                    f"buffers in rank order, stores it into the {R} receive buffers)"), nz, msz, bz
     elif ms2 >= msn and n2:

@@ -52,7 +52,11 @@ typedef enum {
   XMPI_ALGO_TREE = 4,   /* binary tree (bcast / reduce)                              */
   XMPI_ALGO_ZCOPY = 5,  /* zero-copy: one kernel folds straight out of the peers' registered
                            buffers (rank order) and stores straight into them; no staging  */
-  XMPI_ALGO_COUNT = 6
+  XMPI_ALGO_ZPUSH = 6,  /* zero-copy allreduce that only WRITES over xGMI: contributions are pushed
+                           into the peers' receive buffers, folded locally (rank order), results
+                           pushed back; 3 kernels; out-of-place, count divisible by ranks x 16 B,
+                           otherwise (and for the other collectives) the same as ZCOPY       */
+  XMPI_ALGO_COUNT = 7
 } xmpi_algo;
 
 /* error codes */

@@ -199,12 +199,13 @@ static int collective(xmpi_comm* c, int coll, int algo, int root, const void* se
   // Zero-copy first (zcopy.cpp): when every rank's buffers are registered HBM one kernel per rank does
   // the whole collective in place.  Whether that holds is decided collectively, so either every rank
   // returns from here or every rank goes on to the staged schedule below.
-  if (c->size > 1 && (algo == XMPI_ALGO_ZCOPY || (algo == XMPI_ALGO_AUTO && c->zero_copy))) {
+  const bool zc_algo = algo == XMPI_ALGO_ZCOPY || algo == XMPI_ALGO_ZPUSH;
+  if (c->size > 1 && (zc_algo || (algo == XMPI_ALGO_AUTO && c->zero_copy))) {
     bool done = false;
-    int zrc = zero_copy_collective(c, coll, root, sendbuf, recvbuf, count, dtype, op, &done);
+    int zrc = zero_copy_collective(c, coll, root, sendbuf, recvbuf, count, dtype, op, algo == XMPI_ALGO_ZPUSH, &done);
     if (zrc != XMPI_OK || done) return zrc;
   }
-  if (algo == XMPI_ALGO_ZCOPY) algo = XMPI_ALGO_AUTO;
+  if (zc_algo) algo = XMPI_ALGO_AUTO;
   PlanParams pp;
   pp.coll = coll;
   pp.algo = algo;
@@ -1110,7 +1111,7 @@ int xmpi_plan_dump(int coll, int algo, int size, int rank, int root, size_t coun
                    size_t piece_elems, char* out, size_t cap) {
   PlanParams pp;
   pp.coll = coll;
-  pp.algo = (algo == XMPI_ALGO_ZCOPY) ? (int)XMPI_ALGO_AUTO : algo;  // the staged schedule zero-copy falls back to
+  pp.algo = (algo == XMPI_ALGO_ZCOPY || algo == XMPI_ALGO_ZPUSH) ? (int)XMPI_ALGO_AUTO : algo;  // the staged fallback
   pp.size = size;
   pp.rank = rank;
   pp.root = root;

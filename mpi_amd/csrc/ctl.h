@@ -82,7 +82,7 @@ struct alignas(64) BufDesc {
   int32_t ok;     // 1 = both buffers are registered HBM of this rank's device
   int32_t fresh;  // 1 = an allocation named here was not announced on this communicator before
   std::atomic<int32_t> verdict;  // after mapping the peers' buffers: 1 = all mapped, -1 = failed
-  int32_t reserved;
+  int32_t in_place;  // 1 = send and receive buffer are the same memory on this rank
   BufRef send, recv;
 };
 

@@ -286,7 +286,7 @@ void zc_close_peers(const xmpi_comm* c) {
 }
 
 static int zc_run(xmpi_comm* c, int coll, int root, const void* sendbuf, void* recvbuf, size_t count, int dtype,
-                  int op, bool* done) {
+                  int op, bool push, bool* done) {
   *done = false;
   const int N = c->size, me = c->rank;
   const size_t es = xmpi_dtype_size((xmpi_dtype)dtype);
@@ -303,6 +303,7 @@ static int zc_run(xmpi_comm* c, int coll, int root, const void* sendbuf, void* r
   else mine->recv = mine->send;
   mine->ok = ok ? 1 : 0;
   mine->fresh = fresh ? 1 : 0;
+  mine->in_place = (sendbuf == recvbuf) ? 1 : 0;
   mine->verdict.store(0, std::memory_order_relaxed);
   mine->seq.store(seq, std::memory_order_release);
   int rc = c->ctl->barrier(tmo(c));
@@ -314,7 +315,7 @@ static int zc_run(xmpi_comm* c, int coll, int root, const void* sendbuf, void* r
   drop_retired(c);
 
   // 2. every rank reads the same descriptors and reaches the same decision
-  bool all_ok = true, any_fresh = false;
+  bool all_ok = true, any_fresh = false, any_in_place = false;
   for (int p = 0; p < N; p++) {
     BufDesc* d = c->ctl->desc(p, seq);
     if (d->seq.load(std::memory_order_acquire) != seq) {
@@ -324,6 +325,7 @@ static int zc_run(xmpi_comm* c, int coll, int root, const void* sendbuf, void* r
     }
     all_ok = all_ok && d->ok == 1;
     any_fresh = any_fresh || d->fresh == 1;
+    any_in_place = any_in_place || d->in_place == 1;
   }
   if (!all_ok) {  // staged path, on every rank
     c->zc_fallbacks_unregistered++;
@@ -384,7 +386,60 @@ static int zc_run(xmpi_comm* c, int coll, int root, const void* sendbuf, void* r
   // 4. the data movement: one kernel (bcast of a large buffer: two, with a barrier in between)
   hipStream_t s = c->local_stream;
   Launcher L(c);
-  if (coll == COLL_ALLREDUCE || coll == COLL_REDUCE) {
+  const size_t al = std::max<size_t>(1, 16 / es);
+  const bool use_push = push && coll == COLL_ALLREDUCE && !any_in_place && N > 1 && count % ((size_t)N * al) == 0;
+  if (use_push) {
+    // Write-only variant (XMPI_ALGO_ZPUSH): nothing is READ over xGMI.  The receive buffer of rank q is
+    // its own staging area -- region p (p != q) receives rank p's contribution to chunk q, region q is
+    // where q folds them (rank order) -- and then every rank pushes its folded chunk to everybody.
+    // Three kernels and two more barriers than the read-based form, the same bytes on the wire, all of
+    // them posted writes.  Needs out-of-place buffers and equal chunks; otherwise the read-based form runs.
+    const size_t C = count / (size_t)N, cb = C * es;
+    {  // 1. my contribution to chunk q -> region `me` of rank q's receive buffer
+      void* dst[kMaxBatch];
+      const void* src[kMaxBatch];
+      size_t bytes[kMaxBatch];
+      int n = 0;
+      for (int d = 1; d < N; d++) {
+        const int q = (me + d) % N;
+        dst[n] = precv[q] + (size_t)me * cb;
+        src[n] = psend[me] + (size_t)q * cb;
+        bytes[n] = cb;
+        if (++n == kMaxBatch || d == N - 1) {
+          rc = L.begin(2 * (size_t)n * cb);
+          if (rc) return rc;
+          XMPI_HIP(launch_copy_batch(dst, nullptr, src, bytes, n, s, L.start, L.stop));
+          rc = L.finish();
+          if (rc) return rc;
+          n = 0;
+        }
+      }
+    }
+    rc = c->ctl->barrier(tmo(c));  // every contribution to my chunk has landed in my receive buffer
+    if (rc != XMPI_OK) return rc;
+    {  // 2. fold chunk `me` in rank order: all operands are local now
+      const void* srcs[kMaxRanks];
+      for (int p = 0; p < N; p++) srcs[p] = (p == me) ? psend[me] + (size_t)me * cb : precv[me] + (size_t)p * cb;
+      void* d1[1] = {precv[me] + (size_t)me * cb};
+      rc = L.begin((size_t)(N + 1) * cb);
+      if (rc) return rc;
+      XMPI_HIP(launch_reduce_n_multi(d1, 1, srcs, N, C, dtype, op, s, L.start, L.stop));
+      rc = L.finish();
+      if (rc) return rc;
+    }
+    rc = c->ctl->barrier(tmo(c));  // nobody still reads the staging regions my result is about to overwrite
+    if (rc != XMPI_OK) return rc;
+    {  // 3. my folded chunk -> region `me` of everybody's receive buffer
+      void* dsts[kMaxRanks];
+      int nd = 0;
+      for (int d = 1; d < N; d++) dsts[nd++] = precv[(me + d) % N] + (size_t)me * cb;
+      rc = L.begin((size_t)(1 + nd) * cb);
+      if (rc) return rc;
+      XMPI_HIP(launch_copy_multi(dsts, nd, precv[me] + (size_t)me * cb, cb, s, L.start, L.stop));
+      rc = L.finish();
+      if (rc) return rc;
+    }
+  } else if (coll == COLL_ALLREDUCE || coll == COLL_REDUCE) {
     // Ranks hosted by threads of this process on this GPU share one stream and one HBM: their chunks
     // are adjacent, so the lowest of them folds the whole run in ONE launch (the others only take part
     // in the barriers) instead of one launch each queueing behind the same runtime lock.
@@ -498,8 +553,8 @@ static int zc_run(xmpi_comm* c, int coll, int root, const void* sendbuf, void* r
 }
 
 int zero_copy_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void* recvbuf, size_t count,
-                         int dtype, int op, bool* done) {
-  const int rc = zc_run(c, coll, root, sendbuf, recvbuf, count, dtype, op, done);
+                         int dtype, int op, bool push, bool* done) {
+  const int rc = zc_run(c, coll, root, sendbuf, recvbuf, count, dtype, op, push, done);
   if (rc != XMPI_OK) c->ctl->set_abort(rc);  // peers waiting in a barrier stop waiting
   return rc;
 }

@@ -205,6 +205,14 @@ def sc_zero_copy(comm, args):
         for dtype in (xmpi.F32, xmpi.I32, xmpi.F16, xmpi.BF16):
             allreduce_case(comm, dtype, 3001, Z, op=op, pattern=xmpi.PAT_SIGNED, exact=True)
     allreduce_case(comm, xmpi.F64, 50001, Z, pattern=xmpi.PAT_SIGNED, inplace=True, exact=True)
+    # the write-only variant (contributions pushed into the peers' receive buffers, folded locally, results pushed
+    # back): equal chunks and out-of-place buffers take it, anything else runs the read-based form; same bits
+    ZP = xmpi.ALGO_ZPUSH
+    for dtype, count in ((xmpi.F32, 4 * size * 1024), (xmpi.F16, 8 * size * 4099), (xmpi.I64, 2 * size * 3), (xmpi.F64, 2 * size * 50001),
+                         (xmpi.BF16, 8 * size), (xmpi.F32, 100003), (xmpi.U8, 16 * size * 7 + 5)):
+        allreduce_case(comm, dtype, count, ZP, pattern=xmpi.PAT_SIGNED, exact=True)
+    allreduce_case(comm, xmpi.F32, 4 * size * 65536, ZP, op=xmpi.MAX, pattern=xmpi.PAT_SIGNED, exact=True)
+    allreduce_case(comm, xmpi.F32, 4 * size * 1024, ZP, pattern=xmpi.PAT_SIGNED, inplace=True, exact=True)
     # the big allreduce gave every rank a chunk: the zero-copy kernel ran here (not a silent fallback)
     # (rank 0 always launches; ranks hosted by threads of its process leave their chunks to it)
     assert rank != 0 or _zc_launches(comm) > before, "zero-copy path did not run: " + _zc_why(comm)
