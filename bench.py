@@ -468,8 +468,10 @@ def cpu_baseline(ranks: int, count: int):
     binp = os.path.join(ROOT, "oracle", "refpath_bin")
     if not os.path.exists(binp):
         return None
+    import resource
     base = 21000 + (os.getpid() % 20000)
     ports = [f":{base + i}" for i in range(ranks)]
+    ru0 = resource.getrusage(resource.RUSAGE_CHILDREN)
     t0 = time.perf_counter()
     procs = [subprocess.Popen([binp, "allreduce_f32", "-mpi-addr", p, "-mpi-alladdr", ",".join(ports), str(count), "3"],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for p in ports]
@@ -480,9 +482,15 @@ def cpu_baseline(ranks: int, count: int):
             return {"error": out[-300:]}
         rows.append(json.loads(out.strip().split("\n")[-1]))
     wall = time.perf_counter() - t0
+    ru1 = resource.getrusage(resource.RUSAGE_CHILDREN)
+    cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
     t = max(r["mean_s"] for r in rows)
     s = count * 4
-    return {"value": ranks * s / t / 1e9, "unit": "GB/s", "cores": os.cpu_count(), "kind": "port",
+    # `cores`: what the sample actually kept busy (CPU seconds of the rank processes / wall seconds); the
+    # processes are not pinned and have 2 x ranks threads each (one per concurrent Send / Receive, as the
+    # reference's goroutines), most of them blocked on their sockets at any moment
+    return {"value": ranks * s / t / 1e9, "unit": "GB/s", "cores": round(max(1.0, cpu_s / wall), 1), "kind": "port",
+            "host_cores": os.cpu_count(), "threads": ranks * 2 * ranks, "cpu_seconds": cpu_s,
             "algbw_GBps": s / t / 1e9, "ranks": ranks, "seconds_per_allreduce": t, "wall_s": wall,
             "sample": f"allreduce-sum f32, {s >> 20} MiB per rank, {ranks} ranks (one OS process each, unpinned), "
                       f"3 repetitions; loopback TCP + gob framing, all-to-all exchange + rank-order host sum "

@@ -59,6 +59,17 @@ def test_mismatched_world_size_is_refused(monkeypatch):
         _job(m, 4, world=2, monkeypatch=monkeypatch)
 
 
+def test_cpu_baseline_reports_what_it_used():
+    m = _bench()
+    r = m.cpu_baseline(4, 1 << 16)
+    if r is None:
+        pytest.skip("oracle/refpath_bin not built")
+    assert "error" not in r, r
+    assert r["kind"] == "port" and r["unit"] == "GB/s" and r["value"] > 0
+    assert 1.0 <= r["cores"] <= r["host_cores"] and r["threads"] == 4 * 2 * 4  # busy cores measured, not the host's count
+    assert "4 ranks" in r["sample"]
+
+
 def test_cpu_reference_bounce_runs_the_reference_lengths():
     m = _bench()
     rows = m.cpu_bounce()
