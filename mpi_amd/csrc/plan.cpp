@@ -494,6 +494,42 @@ void build_bcast_tree(Builder& b) {
   }
 }
 
+// Full-mesh broadcast: the root scatters chunk j to rank j (every link of the root carries S/N), then
+// every rank forwards its chunk to the ranks that lack it (every link carries S/N once more) -- two
+// hops instead of the tree's log2 N, and 1/N of the bytes per link.
+void build_bcast_direct(Builder& b) {
+  const PlanParams& P = b.P;
+  const int N = P.size, r = P.rank, R = P.root;
+  const size_t al = align_elems(P.elem_size), pe = piece_elems_of(P);
+  const int L = std::max(1, P.lanes);
+  const std::vector<size_t> cb = split_even(0, P.count, N, al);
+  auto chunk = [&](int j) { return pieces_of(cb[(size_t)j], cb[(size_t)j + 1], pe); };
+  if (r == R) {
+    for (int d = 1; d < N; d++) {  // scatter
+      const int j = (R + d) % N;
+      const std::vector<Atom> pcs = chunk(j);
+      for (size_t p = 0; p < pcs.size(); p++) b.send(j, (int)(p % (size_t)L), BUF_RECV, pcs[p]);
+    }
+    const std::vector<Atom> mine = chunk(R);  // the root's own chunk goes to everybody
+    for (size_t p = 0; p < mine.size(); p++)
+      for (int d = 1; d < N; d++) b.send((R + d) % N, (int)(p % (size_t)L), BUF_RECV, mine[p]);
+    return;
+  }
+  const std::vector<Atom> mine = chunk(r);
+  for (size_t p = 0; p < mine.size(); p++) {  // my chunk arrives from the root and goes on to the others
+    b.recv_copy(R, (int)(p % (size_t)L), BUF_RECV, mine[p].off, mine[p].count);
+    for (int d = 1; d < N; d++) {
+      const int q = (r + d) % N;
+      if (q != R) b.send(q, (int)(p % (size_t)L), BUF_RECV, mine[p]);
+    }
+  }
+  for (int d = 1; d < N; d++) {  // everybody else's chunk, from its owner (the root's from the root)
+    const int q = (r + N - d) % N;
+    const std::vector<Atom> pcs = chunk(q);
+    for (size_t p = 0; p < pcs.size(); p++) b.recv_copy(q, (int)(p % (size_t)L), BUF_RECV, pcs[p].off, pcs[p].count);
+  }
+}
+
 // ---- reduce to root ----------------------------------------------------------------------------
 
 void build_reduce_tree(Builder& b) {
@@ -528,9 +564,46 @@ void build_reduce_tree(Builder& b) {
   }
 }
 
+// Large messages: reduce-scatter over the full mesh (rank j folds chunk j of everybody, in rank order),
+// then the folded chunks are gathered at the root: every link carries S/N instead of the root's links
+// carrying S each, and the fold is spread over all ranks.
+void build_reduce_scatter_gather(Builder& b) {
+  const PlanParams& P = b.P;
+  const int N = P.size, r = P.rank, R = P.root;
+  const size_t al = align_elems(P.elem_size), pe = piece_elems_of(P);
+  const int L = std::max(1, P.lanes);
+  const std::vector<size_t> cb = split_even(0, P.count, N, al);
+  auto chunk = [&](int j) { return pieces_of(cb[(size_t)j], cb[(size_t)j + 1], pe); };
+  const int acc = (r == R) ? BUF_RECV : BUF_TEMP;
+  if (r != R) b.plan->temp_bytes = P.count * P.elem_size;
+  for (int d = 1; d < N; d++) {  // my contribution to everybody else's chunk
+    const int j = (r + d) % N;
+    const std::vector<Atom> pcs = chunk(j);
+    for (size_t p = 0; p < pcs.size(); p++) b.send(j, (int)(p % (size_t)L), BUF_SEND, pcs[p]);
+  }
+  const std::vector<Atom> mine = chunk(r);
+  for (size_t p = 0; p < mine.size(); p++) {  // fold my chunk, hand it to the root
+    const int lane = (int)(p % (size_t)L);
+    std::vector<int> srcs;
+    for (int q = 0; q < N; q++) srcs.push_back(q == r ? -1 : b.recv_hold(q, lane, mine[p].count));
+    b.reduce_n(BUF_SEND, acc, mine[p], srcs);
+    if (r != R) b.send(R, lane, BUF_TEMP, mine[p]);
+  }
+  if (r == R)
+    for (int d = 1; d < N; d++) {
+      const int j = (r + N - d) % N;
+      const std::vector<Atom> pcs = chunk(j);
+      for (size_t p = 0; p < pcs.size(); p++) b.recv_copy(j, (int)(p % (size_t)L), BUF_RECV, pcs[p].off, pcs[p].count);
+    }
+}
+
 void build_reduce_direct(Builder& b) {
   const PlanParams& P = b.P;
   const int N = P.size, r = P.rank;
+  if (N > 2 && P.count * P.elem_size > P.oneshot_bytes) {
+    build_reduce_scatter_gather(b);
+    return;
+  }
   const size_t pe = piece_elems_of(P);
   const int L = std::max(1, P.lanes);
   const std::vector<Atom> pcs = pieces_of(0, P.count, pe);
@@ -633,12 +706,16 @@ int build_plan(const PlanParams& p, Plan* out) {
       else return XMPI_ERR_UNSUPPORTED;
       break;
     case COLL_BCAST:
-      if (algo == XMPI_ALGO_AUTO) algo = XMPI_ALGO_TREE;
-      if (algo != XMPI_ALGO_TREE) return XMPI_ERR_UNSUPPORTED;
-      build_bcast_tree(b);
+      // small: the tree's log2 N latency-bound hops; large: scatter + allgather over the whole mesh
+      if (algo == XMPI_ALGO_AUTO)
+        algo = (p.size > 2 && p.count * p.elem_size > p.oneshot_bytes) ? XMPI_ALGO_DIRECT : XMPI_ALGO_TREE;
+      if (algo == XMPI_ALGO_TREE) build_bcast_tree(b);
+      else if (algo == XMPI_ALGO_DIRECT) build_bcast_direct(b);
+      else return XMPI_ERR_UNSUPPORTED;
       break;
     case COLL_REDUCE:
-      if (algo == XMPI_ALGO_AUTO) algo = XMPI_ALGO_TREE;
+      if (algo == XMPI_ALGO_AUTO)
+        algo = (p.size > 2 && p.count * p.elem_size > p.oneshot_bytes) ? XMPI_ALGO_DIRECT : XMPI_ALGO_TREE;
       if (algo == XMPI_ALGO_TREE) build_reduce_tree(b);
       else if (algo == XMPI_ALGO_DIRECT) build_reduce_direct(b);
       else return XMPI_ERR_UNSUPPORTED;

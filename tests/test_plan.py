@@ -141,38 +141,53 @@ def test_allgather_exact(algo, n, count, piece):
             assert np.array_equal(got[r], want)
 
 
+@pytest.mark.parametrize("algo", [xmpi.ALGO_TREE, xmpi.ALGO_DIRECT, xmpi.ALGO_AUTO])
 @pytest.mark.parametrize("n", SIZES)
 @pytest.mark.parametrize("root", [0, 1, -1])
-def test_bcast_tree(n, root):
+def test_bcast(algo, n, root):
+    """binary tree, and the full-mesh form (root scatters chunk j to rank j, every rank forwards its chunk)"""
     root = root % n
-    count = 777
-    ins = [oracle.fill(count, oracle.I32, 0, 10 + r) for r in range(n)]
-    plans = plan_sim.get_plans(xmpi.COLL_BCAST, xmpi.ALGO_TREE, n, root, count, 4, 1, 64)
-    got = plan_sim.simulate(plans, ins, count, np.int32, xmpi.SUM, 2, seed=5, inplace=True)
-    for r in range(n):
-        assert np.array_equal(got[r], ins[root])
+    for count, piece in ((777, 64), (5, 64), (4099, 16)):
+        ins = [oracle.fill(count, oracle.I32, 0, 10 + r) for r in range(n)]
+        plans = plan_sim.get_plans(xmpi.COLL_BCAST, algo, n, root, count, 4, 1, piece)
+        for depth in (1, 2, 8):
+            got = plan_sim.simulate(plans, ins, count, np.int32, xmpi.SUM, depth, seed=5 + depth, inplace=True)
+            for r in range(n):
+                assert np.array_equal(got[r], ins[root])
+    if algo == xmpi.ALGO_DIRECT and n > 2:  # two hops: nobody receives anything that travelled further
+        p = plans[(root + 1) % n]
+        assert {s.kind for s in p.steps} <= {0, 2}
 
 
-@pytest.mark.parametrize("algo", [xmpi.ALGO_TREE, xmpi.ALGO_DIRECT])
+@pytest.mark.parametrize("algo", [xmpi.ALGO_TREE, xmpi.ALGO_DIRECT, xmpi.ALGO_AUTO])
 @pytest.mark.parametrize("n", SIZES)
 @pytest.mark.parametrize("root", [0, -1])
-def test_reduce_to_root(algo, n, root):
+@pytest.mark.parametrize("oneshot", [0, 1 << 20])  # DIRECT: reduce-scatter + gather above, everything-to-root below
+def test_reduce_to_root(algo, n, root, oneshot):
     root = root % n
-    count = 1500
-    ins = [oracle.fill(count, oracle.I64, 0, 77 + r) for r in range(n)]
-    want = oracle.reduce_ranks(ins, oracle.I64, oracle.SUM)
-    plans = plan_sim.get_plans(xmpi.COLL_REDUCE, algo, n, root, count, 8, 1, 128)
-    got = plan_sim.simulate(plans, ins, count, np.int64, xmpi.SUM, 2, seed=9)
-    assert np.array_equal(got[root], want)
+    for count, piece in ((1500, 128), (3, 128), (4099, 16)):
+        ins = [oracle.fill(count, oracle.I64, 0, 77 + r) for r in range(n)]
+        want = oracle.reduce_ranks(ins, oracle.I64, oracle.SUM)
+        plans = plan_sim.get_plans(xmpi.COLL_REDUCE, algo, n, root, count, 8, 1, piece, oneshot_bytes=oneshot)
+        for depth in (1, 2, 8):
+            got = plan_sim.simulate(plans, ins, count, np.int64, xmpi.SUM, depth, seed=9 + depth)
+            assert np.array_equal(got[root], want)
+        # the root's buffers may be one and the same
+        got = plan_sim.simulate(plans, ins, count, np.int64, xmpi.SUM, 2, seed=4, inplace=True)
+        assert np.array_equal(got[root], want)
 
 
-def test_reduce_direct_is_rank_order_f32():
+@pytest.mark.parametrize("oneshot", [0, 1 << 20])
+def test_reduce_direct_is_rank_order_f32(oneshot):
     n, count = 8, 1025
     ins = [oracle.fill(count, oracle.F32, 3, 5 + r) for r in range(n)]
     want = oracle.reduce_ranks(ins, oracle.F32, oracle.SUM)
-    plans = plan_sim.get_plans(xmpi.COLL_REDUCE, xmpi.ALGO_DIRECT, n, 3, count, 4, 1, 64)
+    plans = plan_sim.get_plans(xmpi.COLL_REDUCE, xmpi.ALGO_DIRECT, n, 3, count, 4, 1, 64, oneshot_bytes=oneshot)
     got = plan_sim.simulate(plans, ins, count, np.float32, xmpi.SUM, 2, seed=1)
     assert got[3].tobytes() == want.tobytes()
+    if oneshot == 0:  # the fold is spread over the ranks: the root folds one chunk only
+        folds = [s for s in plans[3].steps if s.kind == 4]
+        assert sum(s.nbytes for s in folds) <= (count // n + 16) * 4
 
 
 def test_min_max_prod_through_ring():

@@ -12,8 +12,8 @@ from tests import plan_sim
 
 ALGOS = {xmpi.COLL_ALLREDUCE: [xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_DIRECT, xmpi.ALGO_AUTO],
          xmpi.COLL_ALLGATHER: [xmpi.ALGO_RING, xmpi.ALGO_DIRECT],
-         xmpi.COLL_BCAST: [xmpi.ALGO_TREE],
-         xmpi.COLL_REDUCE: [xmpi.ALGO_TREE, xmpi.ALGO_DIRECT]}
+         xmpi.COLL_BCAST: [xmpi.ALGO_TREE, xmpi.ALGO_DIRECT, xmpi.ALGO_AUTO],
+         xmpi.COLL_REDUCE: [xmpi.ALGO_TREE, xmpi.ALGO_DIRECT, xmpi.ALGO_AUTO]}
 
 
 @settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.too_slow])
