@@ -147,10 +147,10 @@ def test_allgather_exact(algo, n, count, piece):
 def test_bcast(algo, n, root):
     """binary tree, and the full-mesh form (root scatters chunk j to rank j, every rank forwards its chunk)"""
     root = root % n
-    for count, piece in ((777, 64), (5, 64), (4099, 16)):
+    for count, piece in ((777, 64), (5, 64), (2053, 32)):
         ins = [oracle.fill(count, oracle.I32, 0, 10 + r) for r in range(n)]
         plans = plan_sim.get_plans(xmpi.COLL_BCAST, algo, n, root, count, 4, 1, piece)
-        for depth in (1, 2, 8):
+        for depth in (1, 4):
             got = plan_sim.simulate(plans, ins, count, np.int32, xmpi.SUM, depth, seed=5 + depth, inplace=True)
             for r in range(n):
                 assert np.array_equal(got[r], ins[root])
@@ -165,11 +165,11 @@ def test_bcast(algo, n, root):
 @pytest.mark.parametrize("oneshot", [0, 1 << 20])  # DIRECT: reduce-scatter + gather above, everything-to-root below
 def test_reduce_to_root(algo, n, root, oneshot):
     root = root % n
-    for count, piece in ((1500, 128), (3, 128), (4099, 16)):
+    for count, piece in ((1500, 128), (3, 128), (2053, 32)):
         ins = [oracle.fill(count, oracle.I64, 0, 77 + r) for r in range(n)]
         want = oracle.reduce_ranks(ins, oracle.I64, oracle.SUM)
         plans = plan_sim.get_plans(xmpi.COLL_REDUCE, algo, n, root, count, 8, 1, piece, oneshot_bytes=oneshot)
-        for depth in (1, 2, 8):
+        for depth in (1, 4):
             got = plan_sim.simulate(plans, ins, count, np.int64, xmpi.SUM, depth, seed=9 + depth)
             assert np.array_equal(got[root], want)
         # the root's buffers may be one and the same
