@@ -12,9 +12,9 @@ pipes and kernels -- peer copies between co-located ranks stay inside one HBM in
 xGMI).  Total work is fixed as N grows, so "scaling" is "strong".  A step = one allreduce; inputs
 are generated on the device before the timed region (nothing crosses PCIe while timing).
 
-value = aggregate algorithm bandwidth = ranks x S / t  (GB = 1e9 B; every rank ends up with S
-reduced bytes), with t = max over ranks of the barrier-bracketed time of K steps / K.  The plain
-nccl-tests figures are alongside: algbw = S / t and busbw = algbw x 2(R-1)/R.
+value = algbw = S / t, the nccl-tests convention BASELINE.json's metric names (S = bytes per rank, GB = 1e9 B),
+with t = max over ranks of the barrier-bracketed time of K steps / K; busbw = algbw x 2(R-1)/R is alongside,
+and `busbw_table` holds busbw against message size at 1 / 2 / 4 / 8 ranks (the other half of the metric).
 
 roofline: the dominant kernel of the timed region -- reduce_n_multi_kernel<float,SUM,8> on the zero-copy
 path (folds chunk j of the 8 send buffers in rank order and stores it into the 8 receive buffers:
@@ -67,8 +67,9 @@ def parse_args():
     ap.add_argument("--probe", action="store_true",
                     help="(internal) a short zero-copy allreduce in a job of its own; the exit status is the verdict")
     ap.add_argument("--no-probe", action="store_true", help="skip the zero-copy probe before a multi-GPU run")
-    ap.add_argument("--cpu-count", type=int, default=16 << 20,
-                    help="float32 elements per rank of the CPU sample (64 MiB: ~10-30 CPU-seconds over 8 processes)")
+    ap.add_argument("--cpu-count", type=int, default=0,
+                    help="float32 elements per rank of the CPU sample (default: the workload's own size, 256 MiB per rank)")
+    ap.add_argument("--cpu-reps", type=int, default=2, help="repetitions of the CPU sample")
     return ap.parse_args()
 
 
@@ -305,7 +306,12 @@ def rank_main(job: Job, grank: int):
                "frac": by_i / (ms_i * 1e-3) / 1e9 / HBM_PEAK_GBPS}
     comm.barrier()
 
-    out = {"t_step": t_step, "prof": prof, "tune": tune, "best": best, "best_ring": best_ring, "parity": parity,
+    # what the bytes actually cross: only ranks on DIFFERENT devices talk over xGMI (a multi-process rehearsal on
+    # one GPU does not, whatever --gpus says)
+    ndev_used = len({job.device_of(r) for r in range(R)})
+    transport = ("xGMI (one rank per GPU)" if ndev_used == R else
+                 "intra-HBM (all ranks share one GPU)" if ndev_used == 1 else f"mixed: {R} ranks on {ndev_used} GPUs (intra-HBM + xGMI)")
+    out = {"transport": transport, "devices": ndev_used, "dsync": comm.get_param("dsync"), "t_step": t_step, "prof": prof, "tune": tune, "best": best, "best_ring": best_ring, "parity": parity,
            "algo": algo, "nbytes": nbytes, "count": count, "iso": iso, "parity_failures": parity_failures,
            "shared_stream": comm.get_param("shared_stream"), "slot_bytes": comm.get_param("slot_bytes"),
            "zero_copy_probe": "ok" if zc_ok else "failed: staged schedules only"}
@@ -346,31 +352,49 @@ def rank_main(job: Job, grank: int):
             sweep.append(row)
             sz *= 4
         extras["size_sweep"] = sweep
-        # the same message at 2 and 4 ranks (BASELINE.json quotes the metric at 1/2/4/8 ranks): smaller
-        # communicators among the first ranks of this job, the others wait at the barrier
-        if job.procs == 1:
-            by_ranks = {}
-            for r2 in (2, 4):
-                if r2 >= R:
-                    continue
-                comm.barrier()
-                if grank < r2:
-                    sub = xmpi.Comm(grank, r2, job.device_of(grank), f"{job.key}-r{r2}")
-                    s2, d2 = sub.alloc(nbytes), sub.alloc(nbytes)
+        # BASELINE.json's metric: busbw against message size at 1 / 2 / 4 / 8 ranks.  Smaller communicators among the
+        # first ranks of this job (the others wait at the barrier); the schedule is the library's own choice (AUTO).
+        # One rank: an allreduce is a copy, busbw is defined 0, algbw is the figure.  cfg 3 rides along at 4 ranks.
+        table = []
+        sizes = []
+        sz = 1 << 10
+        while sz <= min(nbytes, 1 << 30):
+            sizes.append(sz)
+            sz *= 4
+        for r2 in (1, 2, 4, R):
+            if r2 > R:
+                continue
+            comm.barrier()
+            if grank < r2:
+                sub = comm if r2 == R else xmpi.Comm(grank, r2, job.device_of(grank), f"{job.key}-r{r2}")
+                s2, d2 = (send, recv) if r2 == R else (sub.alloc(nbytes), sub.alloc(nbytes))
+                if r2 != R:
                     sub.fill(s2, count, dtype, xmpi.PAT_UNIFORM, seed0 + grank)
-                    row = {}
-                    for al in ZC + (xmpi.ALGO_RING,):
-                        sub.allreduce(s2, d2, count, dtype, xmpi.SUM, al)
-                        t = timed(sub, None, 3, batch=lambda k: sub.allreduce_repeat(s2, d2, count, dtype, xmpi.SUM, al, k))
-                        row[ALGO_NAME[al]] = {"ms": t * 1e3, "algbw_GBps": nbytes / t / 1e9,
-                                              "busbw_GBps": nbytes / t / 1e9 * 2 * (r2 - 1) / r2}
+                for b in sizes:
+                    cnt = b // es
+                    sub.allreduce(s2, d2, cnt, dtype, xmpi.SUM, xmpi.ALGO_AUTO)
+                    it = 20 if b <= (1 << 20) else (5 if b <= (64 << 20) else 3)
+                    t = timed(sub, None, it, batch=lambda k, c=cnt: sub.allreduce_repeat(s2, d2, c, dtype, xmpi.SUM, xmpi.ALGO_AUTO, k))
                     if grank == 0:
-                        by_ranks[str(r2)] = row
+                        table.append({"ranks": r2, "bytes": b, "us": t * 1e6, "algbw_GBps": b / t / 1e9,
+                                      "busbw_GBps": b / t / 1e9 * 2 * (r2 - 1) / r2})
+                if r2 == 4:  # BASELINE cfg 3: allgather int64, 16 MiB per rank, 4 ranks
+                    cnt3 = min(2097152, nbytes // 8 // 4)
+                    row3 = {"ranks": 4, "bytes_per_rank": cnt3 * 8}
+                    for al in (xmpi.ALGO_AUTO, xmpi.ALGO_RING):
+                        sub.allgather(s2, d2, cnt3, xmpi.I64, al)
+                        t = timed(sub, lambda: sub.allgather(s2, d2, cnt3, xmpi.I64, al), 5)
+                        row3["auto" if al == xmpi.ALGO_AUTO else "ring"] = {
+                            "ms": t * 1e3, "algbw_GBps": cnt3 * 8 * 4 / t / 1e9, "busbw_GBps": cnt3 * 8 * 4 / t / 1e9 * 3 / 4}
+                    if grank == 0:
+                        extras["cfg3_allgather_i64_16MiB_4ranks"] = row3
+                if r2 != R:
                     s2.free()
                     d2.free()
                     sub.finalize()
-                comm.barrier()
-            extras["allreduce_at_fewer_ranks"] = by_ranks
+            comm.barrier()
+        extras["busbw_table"] = {"schedule": "AUTO (the library's choice)", "unit_note": "GB = 1e9 B; busbw = algbw x 2(R-1)/R; 1 rank: busbw is 0 by definition, algbw is a device copy",
+                                 "rows": table}
         # BASELINE cfg 2: 1 MiB float32 ping-pong between ranks 0 and 1 (half round trip)
         n1 = 262144
         if grank in (0, 1):
@@ -407,31 +431,30 @@ def rank_main(job: Job, grank: int):
                 sweep_b.append({"bytes": length, "round_trip_us": rt * 1e6, "GBps": 2 * length / rt / 1e9})
             extras["bounce_sweep_u8"] = sweep_b
         comm.barrier()
-        # BASELINE cfg 3 shape: allgather int64, 16 MiB per rank
-        cnt3 = min(2097152, nbytes // 8 // R)
-        if cnt3 > 0:
-            extras["allgather_i64"] = {"bytes_per_rank": cnt3 * 8}
-            for al in (xmpi.ALGO_RING,) + ZC:
-                comm.allgather(send, recv, cnt3, xmpi.I64, al)
-                t = timed(comm, lambda: comm.allgather(send, recv, cnt3, xmpi.I64, al), 3)
-                extras["allgather_i64"][ALGO_NAME[al]] = {"ms": t * 1e3, "busbw_GBps": cnt3 * 8 * R / t / 1e9 * (R - 1) / R}
-        # BASELINE cfg 5: allreduce-sum fp16, 1 GiB per rank, ring vs recursive halving (exactly summable
-        # inputs k/64: both must be bit-identical to the rank-order result)
+        # BASELINE cfg 5: allreduce-sum fp16 up to 1 GiB per rank, recursive halving vs ring (and the library's own
+        # choice) over sizes 1 MiB ... 1 GiB; exactly summable inputs k/64: every schedule must be bit-identical to
+        # the rank-order result.  >= 5 timed iterations per point.
         if dtype == xmpi.F32 and nbytes >= (256 << 20):
             n5 = (1 << 30) // 2
             s5, r5, ref5 = comm.alloc(n5 * 2), comm.alloc(n5 * 2), comm.alloc(n5 * 2)
             comm.fill(s5, n5, xmpi.F16, xmpi.PAT_UNIFORM, 2000 + grank)
-            comm.allreduce(s5, ref5, n5, xmpi.F16, xmpi.SUM, xmpi.ALGO_DIRECT)
-            cfg5 = {"bytes_per_rank": n5 * 2}
-            for al in (xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_DIRECT) + ZC:
-                if al == xmpi.ALGO_RHD and R & (R - 1):
-                    continue
-                comm.allreduce(s5, r5, n5, xmpi.F16, xmpi.SUM, al)
-                same = comm.count_mismatch(r5, ref5, n5 * 2) == 0
-                t = timed(comm, lambda: comm.allreduce(s5, r5, n5, xmpi.F16, xmpi.SUM, al), 2)
-                cfg5[ALGO_NAME[al]] = {"ms": t * 1e3, "algbw_GBps": n5 * 2 / t / 1e9,
-                                       "busbw_GBps": n5 * 2 / t / 1e9 * 2 * (R - 1) / R, "bit_identical_to_rank_order": same}
-            extras["cfg5_allreduce_f16_1GiB"] = cfg5
+            rows5 = []
+            b5 = 1 << 20
+            while b5 <= (1 << 30):
+                c5 = b5 // 2
+                comm.allreduce(s5, ref5, c5, xmpi.F16, xmpi.SUM, xmpi.ALGO_DIRECT)
+                row = {"bytes": b5}
+                for al, name in ((xmpi.ALGO_RING, "ring"), (xmpi.ALGO_RHD, "rhd"), (xmpi.ALGO_AUTO, "auto")):
+                    if al == xmpi.ALGO_RHD and R & (R - 1):
+                        continue
+                    comm.allreduce(s5, r5, c5, xmpi.F16, xmpi.SUM, al)
+                    same = comm.count_mismatch(r5, ref5, b5) == 0
+                    t = timed(comm, None, 5, batch=lambda k, a5=al, cc=c5: comm.allreduce_repeat(s5, r5, cc, xmpi.F16, xmpi.SUM, a5, k))
+                    row[name] = {"ms": t * 1e3, "algbw_GBps": b5 / t / 1e9, "busbw_GBps": b5 / t / 1e9 * 2 * (R - 1) / R,
+                                 "bit_identical_to_rank_order": same}
+                rows5.append(row)
+                b5 *= 4
+            extras["cfg5_allreduce_f16_sweep"] = {"ranks": R, "iterations": 5, "rows": rows5}
             for b in (s5, r5, ref5):
                 b.free()
         # link probe between rank 0 and the first rank living on another GPU (xGMI), both engines
@@ -463,7 +486,7 @@ def rank_main(job: Job, grank: int):
     _ = lead
 
 
-def cpu_baseline(ranks: int, count: int):
+def cpu_baseline(ranks: int, count: int, reps: int = 2):
     """oracle/refpath_bin: the reference's TCP+gob path, `ranks` processes on localhost"""
     binp = os.path.join(ROOT, "oracle", "refpath_bin")
     if not os.path.exists(binp):
@@ -473,11 +496,11 @@ def cpu_baseline(ranks: int, count: int):
     ports = [f":{base + i}" for i in range(ranks)]
     ru0 = resource.getrusage(resource.RUSAGE_CHILDREN)
     t0 = time.perf_counter()
-    procs = [subprocess.Popen([binp, "allreduce_f32", "-mpi-addr", p, "-mpi-alladdr", ",".join(ports), str(count), "3"],
+    procs = [subprocess.Popen([binp, "allreduce_f32", "-mpi-addr", p, "-mpi-alladdr", ",".join(ports), str(count), str(reps)],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for p in ports]
     rows = []
     for p in procs:
-        out, _ = p.communicate(timeout=600)
+        out, _ = p.communicate(timeout=900)
         if p.returncode != 0:
             return {"error": out[-300:]}
         rows.append(json.loads(out.strip().split("\n")[-1]))
@@ -486,15 +509,38 @@ def cpu_baseline(ranks: int, count: int):
     cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
     t = max(r["mean_s"] for r in rows)
     s = count * 4
-    # `cores`: what the sample actually kept busy (CPU seconds of the rank processes / wall seconds); the
-    # processes are not pinned and have 2 x ranks threads each (one per concurrent Send / Receive, as the
-    # reference's goroutines), most of them blocked on their sockets at any moment
-    return {"value": ranks * s / t / 1e9, "unit": "GB/s", "cores": round(max(1.0, cpu_s / wall), 1), "kind": "port",
+    # value: the same figure as the line's `value` -- algbw = S / t.  `cores`: what the sample actually kept busy
+    # (CPU seconds of the rank processes / wall seconds); the processes are not pinned and have 2 x ranks threads
+    # each (one per concurrent Send / Receive, as the reference's goroutines), most of them blocked on their sockets
+    return {"value": s / t / 1e9, "unit": "GB/s", "cores": round(max(1.0, cpu_s / wall), 1), "kind": "port",
             "host_cores": os.cpu_count(), "threads": ranks * 2 * ranks, "cpu_seconds": cpu_s,
-            "algbw_GBps": s / t / 1e9, "ranks": ranks, "seconds_per_allreduce": t, "wall_s": wall,
+            "busbw_GBps": s / t / 1e9 * 2 * (ranks - 1) / ranks, "ranks": ranks, "seconds_per_allreduce": t, "wall_s": wall,
             "sample": f"allreduce-sum f32, {s >> 20} MiB per rank, {ranks} ranks (one OS process each, unpinned), "
-                      f"3 repetitions; loopback TCP + gob framing, all-to-all exchange + rank-order host sum "
+                      f"{reps} repetitions; loopback TCP + gob framing, all-to-all exchange + rank-order host sum "
                       f"(oracle/refpath.cpp restating network.go:518-625; no Go toolchain in the image)"}
+
+
+def multiprocess_sweep(ranks: int):
+    """examples/coll_sweep through the launcher: ONE OS PROCESS PER RANK (the production layout), all on this box's
+    GPU(s).  Processes meet on the device (flag words in HBM) -- the figure the rank-threads of this bench cannot give."""
+    run = os.path.join(ROOT, "mpi_amd", "bin", "xmpirun")
+    prog = os.path.join(ROOT, "mpi_amd", "bin", "coll_sweep")
+    if not (os.path.exists(run) and os.path.exists(prog)):
+        return None
+    env = dict(os.environ, XMPI_TIMEOUT_S="60", XMPI_BASEPORT=str(7000 + os.getpid() % 1000 * 16))
+    env.pop("XMPI_SLOT_BYTES", None)
+    env.pop("XMPI_FIFO_DEPTH", None)
+    try:
+        p = subprocess.run([run, str(ranks), prog, str(16 << 20), "200"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        return {"error": "timed out"}
+    if p.returncode != 0:
+        return {"error": (p.stderr or p.stdout)[-400:]}
+    try:
+        return json.loads(p.stdout.strip().split("\n")[-1])
+    except ValueError:
+        return {"error": p.stdout[-400:]}
 
 
 def cpu_bounce():
@@ -619,7 +665,7 @@ def main():
     except (OSError, ValueError, KeyError):
         pass
     roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_from_profile": True, "traffic_source": traffic_src,
             "launches": launches, "avg_launch_us": (ms * 1e3 / launches) if launches else None,
             "algorithmic_bytes_per_launch": (by / launches) if launches else None,
             "note": "live HIP events on the kernel's own stream inside the timed region (rank 0's launches); "
@@ -635,9 +681,8 @@ def main():
             others[label] = {"launches": n_k, "avg_launch_us": ms_k * 1e3 / n_k, "bytes_per_launch": factor * by_k / n_k,
                              "GBps": factor * by_k / (ms_k * 1e-3) / 1e9, "frac_of_hbm_peak": factor * by_k / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBPS}
     line = {
-        "metric": "allreduce_sum_f32_256MiB aggregate algbw (ranks x S / t)" if (args.dtype == "f32" and args.size_mib == 256)
-        else f"allreduce_sum_{args.dtype}_{args.size_mib:g}MiB aggregate algbw (ranks x S / t)",
-        "value": R * algbw, "unit": "GB/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "metric": f"allreduce_sum_{args.dtype}_{args.size_mib:g}MiB algbw",
+        "value": algbw, "unit": "GB/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": t * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"BASELINE cfg 4: allreduce-sum {args.dtype} {args.size_mib:g} MiB/rank, {R} ranks",
@@ -646,17 +691,18 @@ def main():
                    "copy_engine": "copy_kernel" if r0["best"]["copy_engine"] else "hipMemcpyAsync",
                    "piece_bytes": r0["best"].get("piece_bytes", 0), "slot_bytes": r0["slot_bytes"],
                    "shared_stream": bool(r0["shared_stream"]),
-                   "transport": "xGMI peer copies" if args.gpus == R else
-                   ("intra-HBM copies between co-located ranks" if args.gpus == 1 else "mixed intra-HBM / xGMI")},
-        "algbw_GBps": algbw, "busbw_GBps": busbw,
+                   "transport": r0["transport"]},
+        "algbw_GBps": algbw, "busbw_GBps": busbw, "ranks_meet": "on the device (dsync)" if r0["dsync"] == 1 else "on the host (control block)",
         "xgmi": {"per_link_peak_GBps": XGMI_LINK_GBPS, "busbw_frac_of_link_peak": busbw / XGMI_LINK_GBPS,
-                 "meaningful": args.gpus == R},
+                 "meaningful": r0["devices"] == R},
         "zero_copy_probe": r0["zero_copy_probe"] if (args.gpus > 1 or job.procs > 1) and not args.no_probe else "not run (1 GPU)",
         "roofline": roof, "roofline_isolated": r0["iso"], "other_kernels": others, "parity": r0["parity"], "parity_failures": r0["parity_failures"], "autotune": r0["tune"], "ring_best": r0["best_ring"],
         "extras": r0["extras"],
     }
     if args.gpus == 1 and not args.no_cpu and job.proc_rank == 0:
-        line["cpu_baseline"] = cpu_baseline(R, args.cpu_count)
+        line["cpu_baseline"] = cpu_baseline(R, args.cpu_count or r0["count"], args.cpu_reps)
+        if not args.no_extras and isinstance(line.get("extras"), dict):
+            line["extras"]["multiprocess_sweep"] = multiprocess_sweep(R)
         if isinstance(line.get("extras"), dict) and "bounce_sweep_u8" in line["extras"]:
             line["extras"]["cpu_reference_bounce_u8"] = cpu_bounce()  # same lengths, the reference path on the host
     else:

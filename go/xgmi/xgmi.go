@@ -132,7 +132,8 @@ func (b *Backend) Init() error {
 		}
 	}
 	if b.Timeout > 0 {
-		os.Setenv("XMPI_TIMEOUT_S", strconv.Itoa(int(b.Timeout.Seconds()+0.999)))
+		// -mpi-inittimeout bounds Init only (network.go:223-234,307-312); Send / Receive block for as long as it takes
+		os.Setenv("XMPI_INIT_TIMEOUT_S", strconv.Itoa(int(b.Timeout.Seconds()+0.999)))
 	}
 	ckey := C.CString(key)
 	defer C.free(unsafe.Pointer(ckey))

@@ -164,10 +164,13 @@ int xmpi_probe(xmpi_comm* comm, int src, int tag, size_t* count, xmpi_dtype* dty
  *      an unused probe variable; defined here in the reference's delegate style) --------------
  * Called by every rank, in the same order, with the same count / dtype / op / root / algo.
  * Blocking: the buffers must be complete when the call is made and may be reused when it returns.
- * ZCOPY (and AUTO, when every rank's buffers are registered HBM -- xmpi_malloc / xmpi_register):
- * the peers' buffers are read and written in place by one kernel per rank; floating-point folds
- * are in rank order 0..N-1.  Buffers the peers cannot map (host memory, unregistered device
- * memory) send every rank to the staged schedules through the HBM receive windows. */
+ * ZCOPY and AUTO: the peers' buffers are read and written in place by ONE kernel per rank; floating-point
+ * folds are in rank order 0..N-1.  With one process per GPU the ranks meet inside that kernel (flag words
+ * in HBM; see the stream-ordered forms below -- the blocking call enqueues on the communicator's stream
+ * and waits), and a buffer the peers cannot map (host memory, unregistered device memory) is stood in for
+ * by a registered block (one local copy each way).  Ranks sharing a process and a GPU meet through the
+ * control block instead, and there unregistered buffers send every rank to the staged schedules
+ * (RING / RHD / DIRECT / TREE through the HBM receive windows), which any rank can also ask for by name. */
 
 /* root's buffer replicated to every rank, bit-exact.  algo: TREE (binary tree) | ZCOPY | AUTO. */
 int xmpi_bcast(xmpi_comm* comm, void* buf, size_t count, xmpi_dtype dtype, int root, int algo);
@@ -201,6 +204,33 @@ int xmpi_ireduce(xmpi_comm* comm, const void* sendbuf, void* recvbuf, size_t cou
 int xmpi_request_test(xmpi_request* req, int* done);
 /* Blocks until the operation completed, returns ITS status and frees the request. */
 int xmpi_request_wait(xmpi_request* req);
+
+/* Stream-ordered forms.  The collective is ENQUEUED on `stream` (a hipStream_t passed as void*; NULL = the
+ * communicator's own stream) and the call returns without waiting for any peer: like a kernel launch, it runs
+ * after the work already on that stream, and work enqueued after it sees its result; the buffers belong to
+ * the operation until the stream has passed it.  One kernel per rank is the whole collective -- it exchanges
+ * "my buffers are ready / here they are" and "I am done" with the peers through flag words in HBM (written
+ * over xGMI), no host thread polls anything (mpi_amd/csrc/dsync.cpp).  This is the
+ * overlap the reference's author sketched for Send / Wait (mpi.go:132-152), on HIP streams.
+ * Every rank must enqueue the same collectives in the same order (per communicator, whatever the streams).
+ * Buffers must be device memory; memory that is not registered (xmpi_malloc / xmpi_register) is copied
+ * through a registered block on the same stream.  The layout this is for is one process per GPU; ranks that
+ * share a process AND a GPU (bench.py on a 1-GPU box) meet on the host instead (the call then waits).
+ * A failure inside the kernel (a peer that never arrives within XMPI_TIMEOUT_S, an aborted job) is reported by
+ * the next xmpi_stream_sync or blocking collective. */
+int xmpi_allreduce_on_stream(xmpi_comm* comm, const void* sendbuf, void* recvbuf, size_t count,
+                             xmpi_dtype dtype, xmpi_op op, void* stream);
+int xmpi_allgather_on_stream(xmpi_comm* comm, const void* sendbuf, void* recvbuf, size_t count,
+                             xmpi_dtype dtype, void* stream);
+int xmpi_bcast_on_stream(xmpi_comm* comm, void* buf, size_t count, xmpi_dtype dtype, int root, void* stream);
+int xmpi_reduce_on_stream(xmpi_comm* comm, const void* sendbuf, void* recvbuf, size_t count,
+                          xmpi_dtype dtype, xmpi_op op, int root, void* stream);
+/* Streams for callers without a HIP binding of their own (the cgo shim, ctypes): a non-blocking hipStream_t of
+ * the communicator's device; xmpi_stream_sync waits for everything enqueued on it (NULL = the communicator's
+ * own stream) and returns the status of the collectives that ran on it. */
+void* xmpi_stream_create(xmpi_comm* comm);
+int xmpi_stream_destroy(xmpi_comm* comm, void* stream);
+int xmpi_stream_sync(xmpi_comm* comm, void* stream);
 
 /* The same allreduce `iters` times back to back: the step loop of a benchmark without per-call
  * host-language overhead (bench.py hosts several ranks as Python threads, which would otherwise

@@ -9,6 +9,8 @@
 """
 from __future__ import annotations
 
+import hashlib
+import json
 import os
 import shutil
 import subprocess
@@ -24,29 +26,86 @@ HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wextra"]
 
-LIB_SOURCES = ["kernels.hip", "engine.cpp", "api.cpp", "ctl.cpp", "plan.cpp", "zcopy.cpp", "heap.cpp"]
+LIB_SOURCES = ["kernels.hip", "engine.cpp", "api.cpp", "ctl.cpp", "plan.cpp", "zcopy.cpp", "heap.cpp", "dsync.cpp"]
 LIB_HEADERS = ["kernels.h", "comm.h", "ctl.h", "plan.h", os.path.join("..", "..", "include", "xmpi.h")]
 
 
+MANIFEST = os.path.join(ROOT, "mpi_amd", ".build_manifest.json")
+OBJDIR = os.path.join(ROOT, "mpi_amd", "csrc", "obj")
+
+
+def _digest(paths: list[str], extra: str = "") -> str:
+    """Content hash of the files (and the command line): what a target was built FROM.  Targets are rebuilt when
+    this differs from what the manifest beside them recorded -- never by mtimes, which a fresh checkout, a copy to
+    the GPU box or `touch` make meaningless (a stale binary must not be able to pass for a current one)."""
+    h = hashlib.sha256(extra.encode())
+    for q in paths:
+        h.update(os.path.basename(q).encode())
+        if os.path.exists(q):
+            with open(q, "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
+def _manifest() -> dict:
+    try:
+        with open(MANIFEST) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def _stale(target: str, digest: str) -> bool:
+    return not os.path.exists(target) or _manifest().get(os.path.relpath(target, ROOT)) != digest
+
+
+def _record(target: str, digest: str) -> None:
+    m = _manifest()
+    m[os.path.relpath(target, ROOT)] = digest
+    tmp = MANIFEST + f".{os.getpid()}.tmp"
+    with open(tmp, "w") as f:
+        json.dump(m, f, indent=1, sort_keys=True)
+    os.replace(tmp, MANIFEST)
+
+
 def _newer(target: str, deps: list[str]) -> bool:
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+    """`target` is missing or was built from other contents than `deps` have now"""
+    return _stale(target, _digest(deps))
 
 
-def _run(cmd: list[str]) -> None:
+def _run(cmd: list[str], target: str | None = None, deps: list[str] | None = None) -> None:
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(" ".join(cmd) + "\n" + r.stdout + r.stderr)
         raise RuntimeError("build failed: " + cmd[0])
+    if target is not None:
+        _record(target, _digest(deps or []))
 
 
 def build_lib(force: bool = False) -> str:
-    srcs = [os.path.join(CSRC, s) for s in LIB_SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in LIB_HEADERS]
-    if force or _newer(LIB, deps):
-        _run([HIPCC, f"--offload-arch={ARCH}", *CXXFLAGS, "-shared", *srcs, "-o", LIB, "-lpthread", "-lrt"])
+    """One object per source (kernels.hip alone takes over a minute), then the link."""
+    os.makedirs(OBJDIR, exist_ok=True)
+    headers = [os.path.join(CSRC, h) for h in LIB_HEADERS]
+    flags = [f"--offload-arch={ARCH}", *CXXFLAGS]
+    objs, jobs = [], []
+    for src in LIB_SOURCES:
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        d = _digest([path] + headers, " ".join(flags))
+        if force or _stale(obj, d):
+            jobs.append((subprocess.Popen([HIPCC, *flags, "-c", path, "-o", obj], stdout=subprocess.PIPE,
+                                          stderr=subprocess.STDOUT, text=True), obj, d, src))
+    for proc, obj, d, src in jobs:  # the compilations run side by side
+        out, _ = proc.communicate()
+        if proc.returncode != 0:
+            sys.stderr.write(f"hipcc {src}:\n{out}")
+            raise RuntimeError("build failed: hipcc " + src)
+        _record(obj, d)
+    link = _digest(objs, "link")
+    if force or jobs or _stale(LIB, link):
+        _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB, "-lpthread", "-lrt"])
+        _record(LIB, _digest(objs, "link"))
     return LIB
 
 
@@ -61,22 +120,24 @@ def build_host(force: bool = False) -> list[str]:
         deps = [mpi_cpp, os.path.join(host_dir, "mpi.hpp"), os.path.join(ROOT, "include", "xmpi.h")]
         if force or _newer(HOSTLIB, deps):
             _run(["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-shared", *inc, mpi_cpp, "-o", HOSTLIB,
-                  "-L", os.path.dirname(LIB), "-lxmpi", "-Wl,-rpath,$ORIGIN", "-lpthread"])
+                  "-L", os.path.dirname(LIB), "-lxmpi", "-Wl,-rpath,$ORIGIN", "-lpthread"], HOSTLIB, deps)
         outs.append(HOSTLIB)
         for name, src in (("helloworld", os.path.join(ROOT, "examples", "helloworld.cpp")),
                           ("bounce", os.path.join(ROOT, "examples", "bounce.cpp")),
-                          ("allreduce", os.path.join(ROOT, "examples", "allreduce.cpp"))):
+                          ("allreduce", os.path.join(ROOT, "examples", "allreduce.cpp")),
+                          ("coll_sweep", os.path.join(ROOT, "examples", "coll_sweep.cpp"))):
             if os.path.exists(src):
                 out = os.path.join(BIN, name)
-                if force or _newer(out, [src, HOSTLIB] + deps):
+                if force or _newer(out, [src] + deps):
                     _run(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", *inc, src, "-o", out, "-L",
-                          os.path.dirname(LIB), "-lxmpi_host", "-lxmpi", "-Wl,-rpath,$ORIGIN/..", "-lpthread"])
+                          os.path.dirname(LIB), "-lxmpi_host", "-lxmpi", "-Wl,-rpath,$ORIGIN/..", "-lpthread"],
+                         out, [src] + deps)
                 outs.append(out)
     launcher = os.path.join(ROOT, "launcher", "xmpirun.cpp")
     if os.path.exists(launcher):
         out = os.path.join(BIN, "xmpirun")
         if force or _newer(out, [launcher]):
-            _run(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", launcher, "-o", out])
+            _run(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", launcher, "-o", out], out, [launcher])
         outs.append(out)
     return outs
 
@@ -89,17 +150,19 @@ def build_oracle(force: bool = False) -> list[str]:
     out = os.path.join(odir, "liboracle.so")
     if force or _newer(out, [src, os.path.join(odir, "xmpi_oracle.h")]):
         _run(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wall",
-              "-Wextra", src, "-o", out, "-lm"])
+              "-Wextra", src, "-o", out, "-lm"], out, [src, os.path.join(odir, "xmpi_oracle.h")])
     outs.append(out)
     ref = os.path.join(odir, "refpath.cpp")
     if os.path.exists(ref):
         out = os.path.join(odir, "librefpath.so")
         if force or _newer(out, [ref, os.path.join(odir, "gob_codec.h")]):
-            _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", ref, "-o", out, "-lpthread"])
+            _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", ref, "-o", out, "-lpthread"],
+                 out, [ref, os.path.join(odir, "gob_codec.h")])
         outs.append(out)
         out = os.path.join(odir, "refpath_bin")
         if force or _newer(out, [ref, os.path.join(odir, "gob_codec.h")]):
-            _run(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-DREFPATH_MAIN", ref, "-o", out, "-lpthread"])
+            _run(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-DREFPATH_MAIN", ref, "-o", out, "-lpthread"],
+                 out, [ref, os.path.join(odir, "gob_codec.h")])
         outs.append(out)
     return outs
 

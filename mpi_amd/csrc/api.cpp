@@ -1,7 +1,9 @@
 // api.cpp -- the extern "C" entry points of include/xmpi.h.  Compiled by hipcc as host code.
+#include <signal.h>
 #include <unistd.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -49,6 +51,9 @@ static int use_device(const xmpi_comm* c) {
     if (_rc) return _rc;                       \
   } while (0)
 
+// no-progress limit of a steady-state wait: XMPI_TIMEOUT_S, or for ever
+static double wait_limit(const xmpi_comm* c) { return c->timeout_s > 0 ? (double)c->timeout_s : 1e18; }
+
 static size_t choose_piece(const xmpi_comm* c, size_t bytes_per_rank_chunk) {
   if (c->piece_bytes > 0) return std::min<size_t>((size_t)c->piece_bytes, c->slot_bytes);
   // ranks sharing one in-order stream have nothing to overlap: one launch per chunk
@@ -63,45 +68,155 @@ static size_t choose_piece(const xmpi_comm* c, size_t bytes_per_rank_chunk) {
   return std::min(p, c->slot_bytes);
 }
 
-// A process may host several ranks (threads); each peer window is mapped once per process and
-// shared by them (hipIpcOpenMemHandle on an already-open handle is not portable behaviour).
+// ---- windows and their mappings outlive communicators (shared with dsync.cpp) -----------------------------------------------
+// Measured on MI355X / ROCm 7.2: memory that was exported with hipIpcGetMemHandle and mapped by another process
+// is NOT given back by hipFree + hipIpcCloseMemHandle while both processes live -- 8 ranks that create and
+// finalise a communicator in a loop lost 10 GiB of HBM per lifetime (8 windows of 1.25 GiB) and ran out after 27.
+// So nothing of that kind is freed or unmapped per communicator any more: a finalised communicator's window (and
+// flag page) goes into a per-process pool and the next communicator of that size takes it from there; a peer's
+// mapping of it stays open and is found again by {owner pid, address, handle}.  This also removes the one moment
+// where a stray write could meet an unmapped page ("the round-1 fault").
 struct IpcMapping {
   int owner_pid;
   uint64_t owner_addr;
+  uint8_t handle[64];
   void* ptr;
   int refs;
 };
 static std::mutex g_ipc_mu;
 static std::vector<IpcMapping> g_ipc_map;
 
-static hipError_t ipc_open_shared(int owner_pid, uint64_t owner_addr, const void* handle_bytes, void** out) {
+hipError_t ipc_open_shared(int owner_pid, uint64_t owner_addr, const void* handle_bytes, void** out) {
   std::lock_guard<std::mutex> g(g_ipc_mu);
-  for (IpcMapping& m : g_ipc_map)
-    if (m.owner_pid == owner_pid && m.owner_addr == owner_addr) {
+  for (size_t i = 0; i < g_ipc_map.size(); i++) {
+    IpcMapping& m = g_ipc_map[i];
+    if (m.owner_pid != owner_pid || m.owner_addr != owner_addr) continue;
+    if (memcmp(m.handle, handle_bytes, sizeof(hipIpcMemHandle_t)) == 0) {
       m.refs++;
       *out = m.ptr;
       return hipSuccess;
     }
+    if (m.refs == 0) {  // the owner has put another allocation at that address: the old mapping is dead
+      (void)hipIpcCloseMemHandle(m.ptr);
+      (void)hipGetLastError();
+      g_ipc_map.erase(g_ipc_map.begin() + (long)i);
+    }
+    break;
+  }
   hipIpcMemHandle_t h;
   memcpy(&h, handle_bytes, sizeof h);
   void* ptr = nullptr;
   hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
   if (e != hipSuccess) return e;
-  g_ipc_map.push_back({owner_pid, owner_addr, ptr, 1});
+  IpcMapping m;
+  m.owner_pid = owner_pid;
+  m.owner_addr = owner_addr;
+  memset(m.handle, 0, sizeof m.handle);
+  memcpy(m.handle, handle_bytes, sizeof h);
+  m.ptr = ptr;
+  m.refs = 1;
+  g_ipc_map.push_back(m);
   *out = ptr;
   return hipSuccess;
 }
 
-static void ipc_close_shared(void* ptr) {
+// the mapping stays open (see above); mappings of processes that no longer exist are closed
+void ipc_close_shared(void* ptr) {
   std::lock_guard<std::mutex> g(g_ipc_mu);
-  for (size_t i = 0; i < g_ipc_map.size(); i++)
-    if (g_ipc_map[i].ptr == ptr) {
-      if (--g_ipc_map[i].refs == 0) {
-        (void)hipIpcCloseMemHandle(ptr);
-        g_ipc_map.erase(g_ipc_map.begin() + (long)i);
-      }
-      return;
+  for (IpcMapping& m : g_ipc_map)
+    if (m.ptr == ptr && m.refs > 0) {
+      m.refs--;
+      break;
     }
+  for (size_t i = 0; i < g_ipc_map.size();) {
+    IpcMapping& m = g_ipc_map[i];
+    if (m.refs == 0 && kill(m.owner_pid, 0) != 0 && errno == ESRCH) {
+      (void)hipIpcCloseMemHandle(m.ptr);
+      (void)hipGetLastError();
+      g_ipc_map.erase(g_ipc_map.begin() + (long)i);
+    } else {
+      i++;
+    }
+  }
+}
+
+struct PooledBlock {
+  int device;
+  size_t bytes;
+  int kind;  // 0 = window (hipMalloc), 1 = flag page (uncached)
+  void* ptr;
+  bool in_use;
+  bool have_handle;
+  hipIpcMemHandle_t handle;
+};
+static std::mutex g_pool_mu;
+static std::vector<PooledBlock> g_pool;
+
+// HBM that peers map: taken from the pool of blocks earlier communicators of this process left behind, or
+// allocated (kind 1: uncached / fine-grained, for flag words polled by kernels)
+void* pool_acquire(int device, size_t bytes, int kind) {
+  std::lock_guard<std::mutex> g(g_pool_mu);
+  for (PooledBlock& b : g_pool)
+    if (!b.in_use && b.device == device && b.bytes == bytes && b.kind == kind) {
+      b.in_use = true;
+      return b.ptr;
+    }
+  void* p = nullptr;
+  hipError_t e;
+  if (kind == 1) {
+    e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+    }
+  } else {
+    e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {  // memory is tight: give idle blocks of other sizes back first
+      (void)hipGetLastError();
+      for (size_t i = 0; i < g_pool.size();)
+        if (!g_pool[i].in_use && g_pool[i].device == device) {
+          (void)hipFree(g_pool[i].ptr);
+          g_pool.erase(g_pool.begin() + (long)i);
+        } else {
+          i++;
+        }
+      e = hipMalloc(&p, bytes);
+    }
+  }
+  if (e != hipSuccess) return nullptr;
+  PooledBlock nb;
+  memset(&nb, 0, sizeof nb);
+  nb.device = device;
+  nb.bytes = bytes;
+  nb.kind = kind;
+  nb.ptr = p;
+  nb.in_use = true;
+  g_pool.push_back(nb);
+  return p;
+}
+
+// The hipIpc handle of a pooled block: exported ONCE, so that a peer recognises the block when a later
+// communicator offers it again and keeps using the mapping it has (closing and re-opening mappings while other
+// processes do the same is what fails with "invalid device pointer" on this stack).
+hipError_t pool_handle(void* ptr, void* handle_out) {
+  std::lock_guard<std::mutex> g(g_pool_mu);
+  for (PooledBlock& b : g_pool)
+    if (b.ptr == ptr) {
+      if (!b.have_handle) {
+        hipError_t e = hipIpcGetMemHandle(&b.handle, ptr);
+        if (e != hipSuccess) return e;
+        b.have_handle = true;
+      }
+      memcpy(handle_out, &b.handle, sizeof b.handle);
+      return hipSuccess;
+    }
+  return hipErrorInvalidValue;
+}
+
+void pool_release(void* ptr) {
+  std::lock_guard<std::mutex> g(g_pool_mu);
+  for (PooledBlock& b : g_pool)
+    if (b.ptr == ptr) b.in_use = false;
 }
 
 static hipStream_t shared_stream_for(int device) {
@@ -200,6 +315,12 @@ static int collective(xmpi_comm* c, int coll, int algo, int root, const void* se
   // the whole collective in place.  Whether that holds is decided collectively, so either every rank
   // returns from here or every rank goes on to the staged schedule below.
   const bool zc_algo = algo == XMPI_ALGO_ZCOPY || algo == XMPI_ALGO_ZPUSH;
+  // One process per GPU (the production layout): the ranks meet on the device (dsync.cpp) -- one kernel per
+  // rank, enqueued on this communicator's stream, no host barrier.  Whether this path is taken depends on the
+  // job's layout and the arguments only, so every rank decides alike; buffers the peers cannot map are stood in
+  // for by registered arena blocks inside.
+  if (dsync_usable(c) && (algo == XMPI_ALGO_ZCOPY || (algo == XMPI_ALGO_AUTO && c->zero_copy)))
+    return dsync_collective(c, coll, root, sendbuf, recvbuf, count, dtype, op, c->local_stream, /*blocking=*/true);
   if (c->size > 1 && (zc_algo || (algo == XMPI_ALGO_AUTO && c->zero_copy))) {
     bool done = false;
     int zrc = zero_copy_collective(c, coll, root, sendbuf, recvbuf, count, dtype, op, algo == XMPI_ALGO_ZPUSH, &done);
@@ -328,7 +449,11 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   cfg.slot_bytes = (uint64_t)std::max<long>(4096, env_long("XMPI_SLOT_BYTES", 8l << 20)) / 256 * 256;
   cfg.p2p_depth = (int32_t)std::min<long>(16, std::max<long>(2, env_long("XMPI_P2P_DEPTH", 2)));
   cfg.p2p_slot_bytes = (uint64_t)std::max<long>(4096, env_long("XMPI_P2P_SLOT_BYTES", 4l << 20)) / 256 * 256;
-  const double timeout = (double)env_long("XMPI_TIMEOUT_S", 60);
+  // Two different clocks.  XMPI_INIT_TIMEOUT_S (default 60) bounds the bootstrap only -- the reference's
+  // -mpi-inittimeout (network.go:223-234,307-312).  XMPI_TIMEOUT_S is the no-progress limit of Send / Receive and
+  // the collectives afterwards: default 0 = wait for ever, as the reference's blocking calls do (a receiver may
+  // compute for minutes before it posts its Receive); tests set it so a bug shows up as an error, not a hang.
+  const double timeout = (double)env_long("XMPI_INIT_TIMEOUT_S", 60);
 
   std::string key = (job_key && *job_key) ? job_key : "default";
   std::string err;
@@ -343,7 +468,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   c->size = size;
   c->device = device;
   c->ctl = ctl;
-  c->timeout_s = (long)timeout;
+  c->timeout_s = std::max<long>(0, env_long("XMPI_TIMEOUT_S", 0));
   const CtlConfig& g = ctl->cfg();  // rank 0's values are the job's
   c->lanes = g.lanes;
   c->fifo_depth = g.fifo_depth;
@@ -372,7 +497,8 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
     delete c;
     return code;
   };
-  if (hipMalloc((void**)&c->window, c->window_bytes) != hipSuccess) {
+  c->window = (char*)pool_acquire(device, c->window_bytes, 0);
+  if (!c->window) {
     hip_fail(hipGetLastError(), "hipMalloc(window)", __FILE__, __LINE__);
     return fail(XMPI_ERR_NOMEM);
   }
@@ -383,7 +509,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   (void)hipDeviceGetPCIBusId(me->busid, (int)sizeof me->busid, device);
   if (size > 1) {
     hipIpcMemHandle_t h;
-    e = hipIpcGetMemHandle(&h, c->window);
+    e = pool_handle(c->window, &h);
     if (e != hipSuccess) {
       hip_fail(e, "hipIpcGetMemHandle", __FILE__, __LINE__);
       return fail(XMPI_ERR_HIP);
@@ -391,6 +517,9 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
     static_assert(sizeof(h) <= sizeof(me->ipc_handle), "ipc handle size");
     memcpy(me->ipc_handle, &h, sizeof h);
   }
+  c->dsync = env_long("XMPI_DSYNC", 1) ? 1 : 0;
+  c->dsync_grid_cap = std::max<long>(0, env_long("XMPI_DSYNC_GRID", 0));
+  (void)dsync_prepare(c);  // this rank's flag page (device-synchronised collectives), published with the window
   me->state.store(2, std::memory_order_release);
   rc = ctl->wait_all_state(2, timeout > 0 ? timeout : 3600.0);
   if (rc != XMPI_OK) {
@@ -463,6 +592,9 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
       return fail(XMPI_ERR_HIP);
     }
   }
+  rc = dsync_connect(c);
+  if (rc != XMPI_OK) return fail(rc);
+  c->dsync_unroll = env_long("XMPI_DSYNC_UNROLL", c->dsync_sharers > 1 ? 1 : 2);
   if (hipMalloc((void**)&c->dev_words, 4 * sizeof(uint64_t)) != hipSuccess) {
     hip_fail(hipGetLastError(), "hipStreamCreate/hipMalloc", __FILE__, __LINE__);
     return fail(XMPI_ERR_HIP);
@@ -484,8 +616,13 @@ int xmpi_finalize(xmpi_comm* c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   // nobody may still be writing into a window that is about to be unmapped
-  if (!c->ctl->aborted()) (void)c->ctl->barrier(c->timeout_s > 0 ? (double)c->timeout_s : 3600.0);
+  if (!c->ctl->aborted()) {
+    Backoff bo;
+    arm(bo, c);
+    (void)c->ctl->barrier(wait_limit(c), &bo);
+  }
   zc_close_peers(c);
+  dsync_finalize(c);
   for (int p = 0; p < c->size; p++) {
     if (c->peer_opened[p]) ipc_close_shared(c->peer_window[p]);
     if (c->shared_stream) continue;  // the per-device shared stream outlives communicators
@@ -500,9 +637,10 @@ int xmpi_finalize(xmpi_comm* c) {
   for (hipStream_t s : c->p2p_streams) (void)hipStreamDestroy(s);
   for (hipEvent_t e : c->ev_free) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev_timed_free) (void)hipEventDestroy(e);
-  if (!c->ctl->aborted()) (void)c->ctl->barrier(c->timeout_s > 0 ? (double)c->timeout_s : 3600.0);
-  if (c->window) (void)hipFree(c->window);
+  if (!c->ctl->aborted()) (void)c->ctl->barrier(wait_limit(c));
+  if (c->window) pool_release(c->window);  // exported memory is never given back by the runtime: the next communicator reuses it
   if (c->temp) (void)hipFree(c->temp);
+  if (c->host_stage) (void)hipFree(c->host_stage);
   if (c->dev_words) (void)hipFree(c->dev_words);
   heap_comm_destroyed(c);  // last communicator of the process: empty arenas go back to the device
   c->ctl->info(c->rank)->state.store(3, std::memory_order_release);
@@ -520,7 +658,10 @@ int xmpi_device(const xmpi_comm* c) { return (c && !c->finalized) ? c->device : 
 int xmpi_barrier(xmpi_comm* c) {
   XMPI_ENTER(c);
   drain_worker(c);
-  int rc = c->ctl->barrier(c->timeout_s > 0 ? (double)c->timeout_s : 3600.0);
+  dsync_service(c);
+  Backoff bo;
+  arm(bo, c);
+  int rc = c->ctl->barrier(wait_limit(c), &bo);
   if (rc != XMPI_OK) set_last_error("barrier: a peer did not arrive");
   return rc;
 }
@@ -674,6 +815,103 @@ int xmpi_allreduce(xmpi_comm* c, const void* sendbuf, void* recvbuf, size_t coun
 int xmpi_allgather(xmpi_comm* c, const void* sendbuf, void* recvbuf, size_t count, xmpi_dtype dtype, int algo) {
   XMPI_ENTER(c);
   return collective(c, COLL_ALLGATHER, algo, 0, sendbuf, recvbuf, count, (int)dtype, XMPI_SUM);
+}
+
+// ---- stream-ordered forms --------------------------------------------------------------------------
+static int on_stream(xmpi_comm* c, int coll, int root, const void* sendbuf, void* recvbuf, size_t count, int dtype, int op,
+                     void* stream) {
+  const size_t es = xmpi_dtype_size((xmpi_dtype)dtype);
+  if (es == 0 || op < 0 || op >= XMPI_OP_COUNT || root < 0 || root >= c->size) {
+    set_last_error("bad dtype / op / root");
+    return XMPI_ERR_ARG;
+  }
+  if (count == 0) return XMPI_OK;
+  if (!sendbuf || !recvbuf) {
+    set_last_error("null buffer");
+    return XMPI_ERR_ARG;
+  }
+  drain_worker(c);
+  std::lock_guard<std::mutex> g(c->coll_mu);
+  hipStream_t s = stream ? (hipStream_t)stream : c->local_stream;
+  if (c->size == 1) {  // a job of one: the result is the input
+    if (coll != COLL_BCAST && sendbuf != recvbuf) XMPI_HIP(hipMemcpyAsync(recvbuf, sendbuf, count * es, hipMemcpyDefault, s));
+    return XMPI_OK;
+  }
+  if (!dsync_usable(c)) {
+    // ranks sharing a (process, GPU) pair meet on the host (see dsync.cpp): order the call after the stream's
+    // work, run it blocking.  Correct, but the host waits -- the layout this API is for is one process per GPU.
+    XMPI_HIP(hipStreamSynchronize(s));
+    bool done = false;
+    int rc = zero_copy_collective(c, coll, root, sendbuf, recvbuf, count, dtype, op, false, &done);
+    if (rc != XMPI_OK || done) return rc;
+    set_last_error("stream-ordered collectives need buffers of xmpi_malloc / xmpi_register when ranks share a process and a GPU");
+    return XMPI_ERR_UNSUPPORTED;
+  }
+  return dsync_collective(c, coll, root, sendbuf, recvbuf, count, dtype, op, s, /*blocking=*/false);
+}
+
+int xmpi_allreduce_on_stream(xmpi_comm* c, const void* sendbuf, void* recvbuf, size_t count, xmpi_dtype dtype, xmpi_op op,
+                             void* stream) {
+  XMPI_ENTER(c);
+  return on_stream(c, COLL_ALLREDUCE, 0, sendbuf, recvbuf, count, (int)dtype, (int)op, stream);
+}
+
+int xmpi_allgather_on_stream(xmpi_comm* c, const void* sendbuf, void* recvbuf, size_t count, xmpi_dtype dtype, void* stream) {
+  XMPI_ENTER(c);
+  return on_stream(c, COLL_ALLGATHER, 0, sendbuf, recvbuf, count, (int)dtype, XMPI_SUM, stream);
+}
+
+int xmpi_bcast_on_stream(xmpi_comm* c, void* buf, size_t count, xmpi_dtype dtype, int root, void* stream) {
+  XMPI_ENTER(c);
+  return on_stream(c, COLL_BCAST, root, buf, buf, count, (int)dtype, XMPI_SUM, stream);
+}
+
+int xmpi_reduce_on_stream(xmpi_comm* c, const void* sendbuf, void* recvbuf, size_t count, xmpi_dtype dtype, xmpi_op op,
+                          int root, void* stream) {
+  XMPI_ENTER(c);
+  void* rb = recvbuf ? recvbuf : const_cast<void*>(sendbuf);
+  if (c->rank == root && !recvbuf) {
+    set_last_error("reduce: root needs a receive buffer");
+    return XMPI_ERR_ARG;
+  }
+  return on_stream(c, COLL_REDUCE, root, sendbuf, rb, count, (int)dtype, (int)op, stream);
+}
+
+void* xmpi_stream_create(xmpi_comm* c) {
+  if (!c || c->finalized || use_device(c) != XMPI_OK) return nullptr;
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+    hip_fail(hipGetLastError(), "hipStreamCreate", __FILE__, __LINE__);
+    return nullptr;
+  }
+  return (void*)s;
+}
+
+int xmpi_stream_destroy(xmpi_comm* c, void* stream) {
+  XMPI_ENTER(c);
+  if (stream) XMPI_HIP(hipStreamDestroy((hipStream_t)stream));
+  return XMPI_OK;
+}
+
+int xmpi_stream_sync(xmpi_comm* c, void* stream) {
+  XMPI_ENTER(c);
+  hipStream_t s = stream ? (hipStream_t)stream : c->local_stream;
+  // poll, serving the peers meanwhile: a peer may be waiting for this rank to map a buffer it just registered
+  hipEvent_t fin = ev_get(c, false);
+  if (!fin) return XMPI_ERR_HIP;
+  XMPI_HIP(hipEventRecord(fin, s));
+  Backoff bo;
+  arm(bo, c);
+  for (;;) {
+    const hipError_t e = hipEventQuery(fin);
+    if (e == hipSuccess) break;
+    if (e != hipErrorNotReady) return hip_fail(e, "hipEventQuery", __FILE__, __LINE__);
+    (void)hipGetLastError();
+    bo.pause();
+  }
+  ev_put(c, fin, false);
+  std::lock_guard<std::mutex> g(c->coll_mu);
+  return dsync_check(c);
 }
 
 int xmpi_iallreduce(xmpi_comm* c, const void* sendbuf, void* recvbuf, size_t count, xmpi_dtype dtype, xmpi_op op, int algo,
@@ -905,6 +1143,9 @@ int xmpi_set_param(xmpi_comm* c, const char* name, long value) {
   else if (n == "zc_bcast_push_bytes") c->zc_bcast_push_bytes = std::max<long>(0, value);
   else if (n == "zc_group_launch") c->zc_group_launch = value ? 1 : 0;
   else if (n == "p2p_direct_bytes") c->p2p_direct_bytes = value;  // < 0: always through the mail slots
+  else if (n == "dsync") c->dsync = value ? 1 : 0;
+  else if (n == "dsync_grid") c->dsync_grid_cap = std::max<long>(0, value);
+  else if (n == "dsync_unroll") c->dsync_unroll = std::max<long>(1, std::min<long>(2, value));
   else if (n == "kernel_mode") set_kernel_mode((int)value);  // process-wide
   else if (n == "grid_cap") set_grid_cap((int)value);        // process-wide
   else return XMPI_ERR_ARG;
@@ -925,7 +1166,18 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
     heap_stats(c->device, &a, &r, &u);
     return (long)(n == "heap_arenas" ? a : n == "heap_reserved" ? r : u);
   }
+  if (n == "hbm_free_mib" || n == "hbm_total_mib") {  // of this rank's GPU, as the runtime reports it
+    size_t fr = 0, tot = 0;
+    if (hipSetDevice(c->device) != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) return -1;
+    return (long)((n == "hbm_free_mib" ? fr : tot) >> 20);
+  }
   if (n == "p2p_direct_bytes") return c->p2p_direct_bytes;
+  if (n == "dsync") return dsync_usable(c) ? 1 : 0;
+  if (n == "dsync_epoch") return (long)c->dsync_epoch;
+  if (n == "dsync_launches") return (long)c->dsync_launches;
+  if (n == "dsync_bounced") return (long)c->dsync_bounced;
+  if (n == "dsync_sharers") return c->dsync_sharers;
+  if (n == "dsync_unroll") return c->dsync_unroll;
   if (n == "p2p_direct_count") return (long)c->p2p_direct_count;
   if (n == "p2p_staged_count") return (long)c->p2p_staged_count;
   if (n == "zc_seq") return (long)c->zc_seq;

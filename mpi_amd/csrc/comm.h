@@ -15,6 +15,7 @@
 
 #include "../../include/xmpi.h"
 #include "ctl.h"
+#include "kernels.h"
 #include "plan.h"
 
 namespace xmpi {
@@ -94,6 +95,34 @@ struct xmpi_comm {
   long prof_every = 1;  // profile every k-th launch (events cost stream bubbles)
   uint64_t prof_seq[xmpi::PROF_KINDS] = {0};
 
+  // device-synchronised collectives (dsync.cpp): ranks meet through flag words in HBM, the host only enqueues
+  long dsync = 1;                // AUTO / ZCOPY may take the device-synchronised path (XMPI_DSYNC)
+  bool dsync_ok = false;         // ... and this job can: every rank has a flag page, no two ranks share a (process, GPU)
+  xmpi::DsyncPage* dpage = nullptr;                       // this rank's flag page (uncached HBM)
+  xmpi::DsyncPage* peer_page[xmpi::kMaxRanks] = {nullptr};  // everybody's, as addressable from here
+  bool peer_page_opened[xmpi::kMaxRanks] = {false};
+  hipStream_t dsync_copy_stream = nullptr;  // host -> translation table updates
+  const int32_t* dsync_abort_dev = nullptr;  // the job's abort flag as the GPU reads it
+  bool dsync_ctl_registered = false;
+  uint32_t* dsync_status = nullptr;          // pinned host word a kernel writes its first failure to ...
+  uint32_t* dsync_status_dev = nullptr;      // ... and its device address
+  int dsync_sharers = 1;         // ranks of this job on this rank's GPU (bounds the grid: their kernels spin together)
+  long dsync_grid_cap = 0;       // blocks per kernel; 0 = 1024 / sharers
+  long dsync_unroll = 1;         // 16-byte packets per lane per source in flight (2 = deeper, for links)
+  uint64_t dsync_epoch = 0;      // kernels launched so far: the same number on every rank
+  uint64_t dsync_launches = 0, dsync_bounced = 0;  // diagnostics: kernels; buffers stood in for by arena blocks
+  xmpi::DsyncEntry dsync_table[xmpi::kMaxRanks][xmpi::kDsyncArenas];  // host copy of dpage->table
+  uint64_t dsync_seen[xmpi::kMaxRanks] = {0};         // published entries of each peer processed so far
+  uint64_t dsync_slot_gen[xmpi::kDsyncArenas] = {0};  // my registrations the peers hold, by table slot
+  uint64_t dsync_slot_pub[xmpi::kDsyncArenas] = {0};  // ... published as entry number (1-based)
+  uint64_t dsync_slot_used[xmpi::kDsyncArenas] = {0};  // ... last used by epoch
+  std::mutex dsync_mu;           // dsync_service may be entered from any thread of the rank
+  struct DsyncDeferred {
+    hipEvent_t done;
+    std::vector<void*> bufs;
+  };
+  std::vector<DsyncDeferred> dsync_deferred;  // arena blocks lent to collectives still on a stream
+
   // per collective pipe: slots issued / consumed so far (monotonic across operations)
   uint64_t sent[xmpi::kMaxRanks][xmpi::kMaxLanes] = {{0}};
   uint64_t recvd[xmpi::kMaxRanks][xmpi::kMaxLanes] = {{0}};
@@ -105,7 +134,7 @@ struct xmpi_comm {
   long channels = 0;  // ring channels; 0 = all edge-disjoint directed rings of the mesh
   long piece_bytes = 0;  // 0 = choose per operation
   long copy_engine = 0;  // 0 = hipMemcpyAsync (SDMA / runtime blit), 1 = xmpi copy kernel
-  long timeout_s = 60;
+  long timeout_s = 0;  // no-progress limit of steady-state waits in seconds; 0 = for ever (the reference blocks indefinitely)
   double last_run_us = 0, last_sync_us = 0;  // timing of the most recent collective (diagnostic)
   long dep_mode = 0;  // 0 = chain same-rank dependencies with stream events, 1 = wait on the host
 
@@ -155,6 +184,30 @@ void registry_remove(xmpi_comm* c, void* base);
 void zc_close_peers(const xmpi_comm* c);
 bool zc_export(xmpi_comm* c, const void* p, size_t need, BufRef* ref);
 bool zc_import(xmpi_comm* c, int peer, const BufRef& ref, void** out);
+bool registry_alive(uint64_t gen);
+// api.cpp: blocks that peers map (windows, flag pages) and the mappings of the peers' blocks are kept per
+// process across communicators (exported memory is not given back by the runtime while the processes live)
+hipError_t ipc_open_shared(int owner_pid, uint64_t owner_addr, const void* handle_bytes, void** out);
+void ipc_close_shared(void* ptr);
+void* pool_acquire(int device, size_t bytes, int kind);
+void pool_release(void* ptr);
+hipError_t pool_handle(void* ptr, void* handle_out);
+// dsync.cpp
+int dsync_prepare(xmpi_comm* c);
+int dsync_connect(xmpi_comm* c);
+void dsync_finalize(xmpi_comm* c);
+void dsync_service(xmpi_comm* c);
+bool dsync_usable(const xmpi_comm* c);
+int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void* recvbuf, size_t count, int dtype,
+                     int op, hipStream_t stream, bool blocking);
+int dsync_check(xmpi_comm* c);
+// a rank that waits keeps serving its peers
+inline void arm(Backoff& bo, xmpi_comm* c) {
+  if (c->dsync_ok) {
+    bo.idle = [](void* p) { dsync_service((xmpi_comm*)p); };
+    bo.idle_arg = c;
+  }
+}
 // heap.cpp: xmpi_malloc carves buffers out of long-lived registered arenas
 void* heap_alloc(int device, size_t bytes);
 bool heap_free(void* p);

@@ -28,6 +28,7 @@ double now_seconds() {
 
 void Backoff::pause() {
   n++;
+  if (idle && (n & 255u) == 0) idle(idle_arg);
   if (n < 4096) {
 #if defined(__x86_64__)
     __builtin_ia32_pause();
@@ -72,6 +73,8 @@ size_t Ctl::layout_bytes(int size) {
   b += sizeof(MailEntry) * (size_t)size * size * kMailEntries;
   b += sizeof(BufDesc) * (size_t)size * 2;
   b += sizeof(RetireLog) * (size_t)size;
+  b += sizeof(PubTable) * (size_t)size;
+  b += 64 * (size_t)size * size;  // acked[reader][owner]
   return (b + 4095) / 4096 * 4096;
 }
 
@@ -121,7 +124,25 @@ int Ctl::join(const std::string& key, int rank, int size, const CtlConfig& cfg, 
 
   if (rank == 0) {
     reap_dead_blocks();
-    shm_unlink(name.c_str());  // a stale block of a crashed job with the same key
+    // A block of this name whose creator is still running belongs to a LIVE job using the same key (two jobs
+    // started with the default key, say): taking the name away from it would split that job.  Refuse instead.
+    {
+      int fd = shm_open(name.c_str(), O_RDONLY, 0600);
+      if (fd >= 0) {
+        CtlHeader h;
+        const ssize_t got = pread(fd, &h, sizeof h, 0);
+        close(fd);
+        if (got == (ssize_t)sizeof h && h.magic.load(std::memory_order_relaxed) == kCtlMagic) {
+          const int cp = h.creator_pid;
+          const bool alive = (kill(cp, 0) == 0 || errno == EPERM) && proc_start_time(cp) == h.creator_start;
+          if (alive && h.abort_code.load(std::memory_order_relaxed) == 0) {
+            *err = "job key already in use by a running job (pid " + std::to_string(cp) + "): " + name;
+            return XMPI_ERR_BOOTSTRAP;
+          }
+        }
+      }
+    }
+    shm_unlink(name.c_str());  // a stale block of a crashed (or aborted) job with the same key
     int fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
     if (fd < 0) {
       *err = "shm_open(create " + name + "): " + strerror(errno);
@@ -224,11 +245,18 @@ int Ctl::join(const std::string& key, int rank, int size, const CtlConfig& cfg, 
   c->desc_ = reinterpret_cast<BufDesc*>(p);
   p += sizeof(BufDesc) * (size_t)size * 2;
   c->retire_ = reinterpret_cast<RetireLog*>(p);
+  p += sizeof(RetireLog) * (size_t)size;
+  c->pub_ = reinterpret_cast<PubTable*>(p);
+  p += sizeof(PubTable) * (size_t)size;
+  c->acked_ = reinterpret_cast<std::atomic<uint64_t>*>(p);
 
   RankInfo* me = c->info(rank);
-  if (me->state.load() != 0) {  // two processes claim the same rank
+  int32_t unclaimed = 0;
+  if (!me->state.compare_exchange_strong(unclaimed, -1, std::memory_order_acq_rel)) {
+    // Two processes claim the same rank: this one never joined, so it must not touch the block (the
+    // other claimant's job may be perfectly healthy) -- it only reports the clash.
     *err = "rank " + std::to_string(rank) + " already joined " + name;
-    c->set_abort(XMPI_ERR_BOOTSTRAP);
+    c->creator_ = false;
     delete c;
     return XMPI_ERR_BOOTSTRAP;
   }
@@ -277,7 +305,7 @@ int Ctl::wait_all_state(int state, double timeout_s) {
   }
 }
 
-int Ctl::barrier(double timeout_s) {
+int Ctl::barrier(double timeout_s, Backoff* ext) {
   if (size_ == 1) return XMPI_OK;
   const uint32_t gen = hdr_->bar_gen.load(std::memory_order_acquire);
   const uint32_t arrived = hdr_->bar_count.fetch_add(1, std::memory_order_acq_rel) + 1;
@@ -287,7 +315,8 @@ int Ctl::barrier(double timeout_s) {
     return XMPI_OK;
   }
   const double t0 = now_seconds();
-  Backoff bo;
+  Backoff own;
+  Backoff& bo = ext ? *ext : own;
   while (hdr_->bar_gen.load(std::memory_order_acquire) == gen) {
     if (aborted()) return XMPI_ERR_PEER;
     if (now_seconds() - t0 > timeout_s) return XMPI_ERR_TIMEOUT;

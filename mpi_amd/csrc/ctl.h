@@ -18,7 +18,7 @@ constexpr int kMaxRanks = 16;
 constexpr int kMaxLanes = 4;
 constexpr int kMailEntries = 4;  // concurrent messages per ordered rank pair
 constexpr uint64_t kCtlMagic = 0x584D504943544C31ull;  // "XMPICTL1"
-constexpr uint32_t kCtlVersion = 4;  // layout of the block: bump with every change of the structs below
+constexpr uint32_t kCtlVersion = 5;  // layout of the block: bump with every change of the structs below
 
 struct alignas(64) Counter {
   std::atomic<uint64_t> v;
@@ -72,6 +72,8 @@ struct alignas(64) RankInfo {
   uint64_t window_bytes;
   uint8_t ipc_handle[64];  // hipIpcMemHandle_t of the window
   char busid[32];
+  uint64_t flag_addr;       // this rank's flag page (uncached HBM; device-synchronised collectives), 0 = none
+  uint8_t flag_handle[64];  // its hipIpcMemHandle_t
 };
 
 // What a rank tells its peers about the user buffers of one zero-copy collective.  Two descriptors
@@ -95,6 +97,25 @@ struct alignas(64) RetireLog {
   uint64_t gen[kRetireRing];
 };
 
+// Device-synchronised collectives (dsync.cpp): what a rank has registered for its peers to map, in
+// registration order.  A peer maps entry k (hipIpc), adds {gen -> its mapping} to the translation table its
+// kernels read, and then says so in `acked`: a rank uses a buffer in a device-synchronised collective only
+// once every peer has acknowledged the allocation it lives in, so no kernel ever meets an address it cannot
+// translate.  Entries are only appended; count - min(acked) <= kPubRing.
+constexpr int kPubRing = 64;
+struct PubEntry {
+  uint64_t gen;    // owner's registration number (same numbering as BufRef.gen / the retire log)
+  uint64_t base;   // allocation base VA in the owner's process
+  uint64_t bytes;
+  uint64_t reserved;
+  uint8_t handle[64];  // hipIpcMemHandle_t
+};
+struct alignas(64) PubTable {
+  std::atomic<uint64_t> count;  // entries ever published; entry k lives in e[k % kPubRing]
+  char pad[56];
+  PubEntry e[kPubRing];
+};
+
 struct CtlConfig {
   int32_t lanes;        // FIFO lanes per ordered pair for collectives
   int32_t fifo_depth;   // slots per collective pipe
@@ -116,6 +137,15 @@ struct alignas(64) CtlHeader {
   alignas(64) std::atomic<uint32_t> bar_gen;
 };
 
+// polite spin: pause a while, then yield the core (ranks may outnumber cores)
+struct Backoff {
+  unsigned n = 0;
+  // called now and then while waiting: a rank that blocks still serves its peers (maps the buffers they
+  // registered and acknowledges them -- dsync.cpp), so nobody waits on somebody who is waiting
+  void (*idle)(void*) = nullptr;
+  void* idle_arg = nullptr;
+  void pause();
+};
 class Ctl {
  public:
   // Joins (rank 0: creates) the block named after `key`.  Returns 0 or a negative xmpi code.
@@ -132,12 +162,15 @@ class Ctl {
   MailEntry* mail(int src, int dst, int e) { return &mail_[((size_t)src * size_ + dst) * kMailEntries + e]; }
   BufDesc* desc(int r, uint64_t seq) { return &desc_[(size_t)r * 2 + (size_t)(seq & 1)]; }
   RetireLog* retired(int r) { return &retire_[r]; }
+  PubTable* published(int r) { return &pub_[r]; }
+  // how many of rank `owner`'s published entries rank `reader` has mapped (written by `reader` only)
+  std::atomic<uint64_t>* acked(int reader, int owner) { return &acked_[((size_t)reader * size_ + owner) * 8]; }
   void* base() const { return base_; }
   size_t bytes() const { return bytes_; }
 
   // all ranks reach `state` (RankInfo.state >= state) or timeout / abort
   int wait_all_state(int state, double timeout_s);
-  int barrier(double timeout_s);
+  int barrier(double timeout_s, Backoff* bo = nullptr);
   void set_abort(int code) {
     int32_t z = 0;
     hdr_->abort_code.compare_exchange_strong(z, code);
@@ -160,14 +193,11 @@ class Ctl {
   MailEntry* mail_ = nullptr;
   BufDesc* desc_ = nullptr;
   RetireLog* retire_ = nullptr;
+  PubTable* pub_ = nullptr;
+  std::atomic<uint64_t>* acked_ = nullptr;  // [reader][owner], one cache line each
   bool creator_ = false;
 };
 
-// polite spin: pause a while, then yield the core (ranks may outnumber cores)
-struct Backoff {
-  unsigned n = 0;
-  void pause();
-};
 double now_seconds();
 
 }  // namespace xmpi

@@ -1,0 +1,544 @@
+// dsync.cpp -- device-synchronised, stream-ordered collectives.
+//
+// The zero-copy collectives of zcopy.cpp meet on the HOST: two or three barriers through the shared control
+// block around every kernel.  Here the ranks meet on the DEVICE: each rank owns a flag page in its HBM
+// (uncached, mapped by every peer), and one kernel per rank (kernels.hip `dsync_fold_kernel`) announces this
+// rank's buffers to the peers, waits for theirs, moves the data straight between the user buffers over xGMI
+// and exchanges "done" before it ends.  The host only enqueues that kernel on a stream -- its own for the
+// blocking calls (xmpi_allreduce ...), the caller's for xmpi_*_on_stream -- and never polls a peer: what the
+// reference does with a message + ack over a net.Conn per Send (network.go:562-571) is two 8-byte stores
+// over a link here.
+//
+// What still needs the host, rarely: a kernel can only address a peer's buffer through a mapping (hipIpc)
+// this process has opened.  Every rank therefore PUBLISHES the allocations it registers (control block,
+// PubTable), every peer maps them the next time it is inside the library (`dsync_service`, also called from
+// every wait loop), writes {slot -> mapping} into the translation table its kernels read, and acknowledges.
+// A rank uses a buffer in a device-synchronised collective only after all peers acknowledged the allocation
+// it lives in: in steady state (buffers allocated once, reused) nothing of this runs.
+//
+// Applies when no two ranks share a (process, GPU) pair -- the production layout, one process per MI355X.
+// Ranks hosted by threads of one process on one GPU (bench.py on a single-GPU box) keep the host-synchronised
+// path: they share one in-order stream, and a kernel that waits for a kernel queued behind it never ends.
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstring>
+
+#include "comm.h"
+#include "kernels.h"
+
+namespace xmpi {
+
+static_assert(kDsyncRanks == kMaxRanks, "dsync tables are sized by kMaxRanks");
+static_assert(sizeof(DsyncPage) <= 65536, "flag page");
+constexpr size_t kPageBytes = 65536;
+
+namespace {
+
+double wait_limit(const xmpi_comm* c) { return c->timeout_s > 0 ? (double)c->timeout_s : 1e18; }
+
+void idle_hook(void* arg) { dsync_service((xmpi_comm*)arg); }
+
+// host -> device table of this rank (a few dozen bytes, on the rare occasions a peer registers something)
+int push_table_entry(xmpi_comm* c, int owner, int slot) {
+  const DsyncEntry* src = &c->dsync_table[owner][slot];
+  DsyncEntry* dst = &c->dpage->table[owner][slot];
+  XMPI_HIP(hipMemcpyAsync(dst, src, sizeof *src, hipMemcpyHostToDevice, c->dsync_copy_stream));
+  XMPI_HIP(hipStreamSynchronize(c->dsync_copy_stream));
+  return XMPI_OK;
+}
+
+}  // namespace
+
+// Called by xmpi_init before this rank's RankInfo is published (state 2).
+int dsync_prepare(xmpi_comm* c) {
+  RankInfo* me = c->ctl->info(c->rank);
+  me->flag_addr = 0;
+  if (c->size < 2 || !c->dsync) return XMPI_OK;
+  // uncached HBM: the page is polled by this GPU and written by the others; it must never sit in an L2.
+  // (From the per-process pool: exported memory outlives communicators -- api.cpp.)
+  void* page = pool_acquire(c->device, kPageBytes, 1);
+  if (!page) {
+    (void)hipGetLastError();
+    return XMPI_OK;  // no such memory here: every rank sees flag_addr == 0 and keeps to the host-synchronised path
+  }
+  if (hipMemset(page, 0, kPageBytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    (void)hipGetLastError();
+    pool_release(page);
+    return XMPI_OK;
+  }
+  hipIpcMemHandle_t h;
+  if (pool_handle(page, &h) != hipSuccess) {
+    (void)hipGetLastError();
+    pool_release(page);
+    return XMPI_OK;
+  }
+  c->dpage = (DsyncPage*)page;
+  static_assert(sizeof h <= sizeof me->flag_handle, "ipc handle size");
+  memcpy(me->flag_handle, &h, sizeof h);
+  me->flag_addr = (uint64_t)(uintptr_t)page;
+  return XMPI_OK;
+}
+
+// Called by xmpi_init once every rank's RankInfo is visible.  Decides -- identically on every rank --
+// whether the job can synchronise on the device, and maps the peers' pages.
+int dsync_connect(xmpi_comm* c) {
+  c->dsync_ok = false;
+  if (c->size < 2) return XMPI_OK;
+  const int N = c->size, mypid = (int)getpid();
+  bool usable = true;
+  int sharers = 0;
+  for (int p = 0; p < N; p++) {
+    const RankInfo* a = c->ctl->info(p);
+    if (a->flag_addr == 0) usable = false;
+    if (strncmp(a->busid, c->ctl->info(c->rank)->busid, sizeof a->busid) == 0) sharers++;
+    for (int q = p + 1; q < N; q++) {
+      const RankInfo* b = c->ctl->info(q);
+      if (a->pid == b->pid && a->device == b->device) usable = false;  // two ranks on one stream: see the header
+    }
+  }
+  if (!usable) return XMPI_OK;
+  for (int p = 0; p < N; p++) {
+    RankInfo* pi = c->ctl->info(p);
+    if (p == c->rank) {
+      c->peer_page[p] = c->dpage;
+    } else if (pi->pid == mypid) {  // a thread of this process on another GPU (peer access is enabled by xmpi_init)
+      c->peer_page[p] = (DsyncPage*)(uintptr_t)pi->flag_addr;
+    } else {
+      void* ptr = nullptr;
+      hipError_t e = ipc_open_shared(pi->pid, pi->flag_addr, pi->flag_handle, &ptr);
+      if (e != hipSuccess) return hip_fail(e, "hipIpcOpenMemHandle(flag page)", __FILE__, __LINE__);
+      c->peer_page[p] = (DsyncPage*)ptr;
+      c->peer_page_opened[p] = true;
+    }
+  }
+  XMPI_HIP(hipStreamCreateWithFlags(&c->dsync_copy_stream, hipStreamNonBlocking));
+  // the job's abort flag, readable by the GPU: a kernel that waits for a dead peer gives up
+  if (hipHostRegister(c->ctl->base(), 4096, hipHostRegisterMapped) == hipSuccess) {
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, &c->ctl->header()->abort_code, 0) == hipSuccess) c->dsync_abort_dev = (const int32_t*)dev;
+    c->dsync_ctl_registered = true;
+  }
+  (void)hipGetLastError();
+  if (hipHostMalloc((void**)&c->dsync_status, 64, hipHostMallocMapped) == hipSuccess) {
+    *c->dsync_status = 0;
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, c->dsync_status, 0) == hipSuccess) c->dsync_status_dev = (uint32_t*)dev;
+  }
+  (void)hipGetLastError();
+  // Every block of the kernel spins until the peers' kernels have started: the kernels of all ranks on this GPU
+  // must be resident at once, in at most half of its 8192 wave slots (4 waves per block).
+  c->dsync_sharers = std::max(1, sharers);
+  memset(c->dsync_table, 0, sizeof c->dsync_table);
+  c->dsync_ok = true;
+  return XMPI_OK;
+}
+
+void dsync_finalize(xmpi_comm* c) {
+  for (int p = 0; p < c->size; p++)
+    if (c->peer_page_opened[p]) ipc_close_shared(c->peer_page[p]);
+  if (c->dsync_ctl_registered) (void)hipHostUnregister(c->ctl->base());
+  if (c->dsync_status) (void)hipHostFree(c->dsync_status);
+  if (c->dsync_copy_stream) (void)hipStreamDestroy(c->dsync_copy_stream);
+  for (auto& b : c->dsync_deferred) {
+    (void)hipEventDestroy(b.done);
+    for (void* p : b.bufs) (void)heap_free(p);
+  }
+  c->dsync_deferred.clear();
+  if (c->dpage) pool_release(c->dpage);
+  c->dpage = nullptr;
+  (void)hipGetLastError();
+}
+
+// Map what the peers have published since this rank last looked, and acknowledge.  Cheap when there is nothing
+// to do (one load per peer); safe to call from any thread of the rank (a second caller just skips).
+void dsync_service(xmpi_comm* c) {
+  if (!c->dsync_ok) return;
+  std::unique_lock<std::mutex> l(c->dsync_mu, std::try_to_lock);
+  if (!l.owns_lock()) return;
+  const int mypid = (int)getpid();
+  for (int p = 0; p < c->size; p++) {
+    if (p == c->rank) continue;
+    PubTable* pt = c->ctl->published(p);
+    const uint64_t n = pt->count.load(std::memory_order_acquire);
+    uint64_t k = c->dsync_seen[p];
+    if (k == n) continue;
+    (void)hipSetDevice(c->device);  // may be the first HIP call of this thread (a wait loop of Send / Receive)
+    for (; k < n; k++) {
+      const PubEntry& e = pt->e[k % kPubRing];
+      const int slot = (int)(e.reserved & 0xff);
+      DsyncEntry ent;
+      memset(&ent, 0, sizeof ent);
+      ent.gen = e.gen;
+      ent.bytes = e.bytes;
+      if (c->ctl->info(p)->pid == mypid) {
+        ent.base = e.base;  // same address space
+      } else {
+        BufRef ref;
+        memset(&ref, 0, sizeof ref);
+        ref.base = e.base;
+        ref.gen = e.gen;
+        ref.bytes = e.bytes;
+        memcpy(ref.handle, e.handle, sizeof ref.handle);
+        void* mapped = nullptr;
+        if (zc_import(c, p, ref, &mapped)) ent.base = (uint64_t)(uintptr_t)mapped;
+        else ent.gen = 0;  // cannot be mapped here: a kernel that meets it reports DSYNC_UNMAPPED
+      }
+      if (slot >= 0 && slot < kDsyncArenas) {
+        c->dsync_table[p][slot] = ent;
+        (void)push_table_entry(c, p, slot);
+      }
+    }
+    c->dsync_seen[p] = n;
+    c->ctl->acked(c->rank, p)->store(n, std::memory_order_release);
+  }
+}
+
+namespace {
+
+// the slot of my translation-table row that holds registration `gen`; publishes it if need be.
+// *pub_index = how many published entries a peer must have processed to know it.
+int publish(xmpi_comm* c, const BufRef& ref, int* slot_out, uint64_t* pub_index) {
+  for (int s = 0; s < kDsyncArenas; s++)
+    if (c->dsync_slot_gen[s] == ref.gen) {
+      c->dsync_slot_used[s] = c->dsync_epoch + 1;
+      *slot_out = s;
+      *pub_index = c->dsync_slot_pub[s];
+      return XMPI_OK;
+    }
+  int slot = -1;
+  for (int s = 0; s < kDsyncArenas && slot < 0; s++)
+    if (c->dsync_slot_gen[s] == 0) slot = s;
+  if (slot < 0)  // slots of registrations that have been freed / deregistered since are free again
+    for (int s = 0; s < kDsyncArenas; s++)
+      if (!registry_alive(c->dsync_slot_gen[s])) {
+        c->dsync_slot_gen[s] = 0;
+        if (slot < 0) slot = s;
+      }
+  if (slot < 0) {
+    // all slots hold live registrations: re-use the one that has not been used for longest.  Collectives in
+    // flight may still name it -- let them finish first (this is rare: > 32 registered allocations in use).
+    XMPI_HIP(hipDeviceSynchronize());
+    slot = 0;
+    for (int s = 1; s < kDsyncArenas; s++)
+      if (c->dsync_slot_used[s] < c->dsync_slot_used[slot]) slot = s;
+  }
+  PubTable* pt = c->ctl->published(c->rank);
+  const uint64_t n = pt->count.load(std::memory_order_relaxed);
+  // the ring must not overwrite an entry a peer has not read yet
+  Backoff bo;
+  bo.idle = idle_hook;
+  bo.idle_arg = c;
+  const double t0 = now_seconds();
+  for (;;) {
+    uint64_t lo = n;
+    for (int p = 0; p < c->size; p++)
+      if (p != c->rank) lo = std::min(lo, c->ctl->acked(p, c->rank)->load(std::memory_order_acquire));
+    if (n - lo < (uint64_t)kPubRing) break;
+    if (c->ctl->aborted()) return XMPI_ERR_PEER;
+    if (now_seconds() - t0 > wait_limit(c)) return XMPI_ERR_TIMEOUT;
+    dsync_service(c);
+    bo.pause();
+  }
+  PubEntry& e = pt->e[n % kPubRing];
+  e.gen = ref.gen;
+  e.base = ref.base;
+  e.bytes = ref.bytes;
+  e.reserved = (uint64_t)slot;
+  memcpy(e.handle, ref.handle, sizeof e.handle);
+  pt->count.store(n + 1, std::memory_order_release);
+  c->dsync_slot_gen[slot] = ref.gen;
+  c->dsync_slot_pub[slot] = n + 1;
+  c->dsync_slot_used[slot] = c->dsync_epoch + 1;
+  *slot_out = slot;
+  *pub_index = n + 1;
+  return XMPI_OK;
+}
+
+int await_acks(xmpi_comm* c, uint64_t pub_index) {
+  Backoff bo;
+  bo.idle = idle_hook;
+  bo.idle_arg = c;
+  const double t0 = now_seconds();
+  for (;;) {
+    bool all = true;
+    for (int p = 0; p < c->size && all; p++)
+      if (p != c->rank && c->ctl->acked(p, c->rank)->load(std::memory_order_acquire) < pub_index) all = false;
+    if (all) return XMPI_OK;
+    if (c->ctl->aborted()) {
+      set_last_error("a peer rank aborted the job");
+      return XMPI_ERR_PEER;
+    }
+    if (now_seconds() - t0 > wait_limit(c)) {
+      set_last_error("a peer did not map a newly registered buffer (is it inside the library at all?)");
+      return XMPI_ERR_TIMEOUT;
+    }
+    dsync_service(c);
+    bo.pause();
+  }
+}
+
+// buffers lent to collectives on a stream (bounce copies of unregistered memory): given back once the
+// stream has passed them
+void reap_deferred(xmpi_comm* c, bool wait) {
+  for (size_t i = 0; i < c->dsync_deferred.size();) {
+    auto& b = c->dsync_deferred[i];
+    hipError_t e = wait ? hipEventSynchronize(b.done) : hipEventQuery(b.done);
+    if (e == hipErrorNotReady) {
+      (void)hipGetLastError();
+      i++;
+      continue;
+    }
+    (void)hipEventDestroy(b.done);
+    for (void* p : b.bufs) (void)heap_free(p);
+    c->dsync_deferred.erase(c->dsync_deferred.begin() + (long)i);
+  }
+}
+
+struct Resolved {
+  const void* send = nullptr;
+  void* recv = nullptr;
+  BufRef sref, rref;
+  void* tmp_send = nullptr;  // registered stand-ins of buffers the peers cannot map
+  void* tmp_recv = nullptr;
+};
+
+}  // namespace
+
+bool dsync_usable(const xmpi_comm* c) { return c->dsync_ok && c->dsync && c->size > 1; }
+
+int dsync_grid(const xmpi_comm* c, size_t packets_per_segment, int nseg, int unroll) {
+  // blocks of all ranks on this GPU fit in half of its wave slots (256 CUs x 32 waves, 4 waves per block)
+  long cap = c->dsync_grid_cap > 0 ? c->dsync_grid_cap : 1024 / c->dsync_sharers;
+  cap = std::max<long>(1, cap / std::max(1, nseg));
+  const size_t per_block = (size_t)256 * (size_t)std::max(1, unroll);
+  const size_t want = (packets_per_segment + per_block - 1) / per_block;
+  return (int)std::max<size_t>(1, std::min<size_t>(want, (size_t)cap));
+}
+
+// One device-synchronised collective, enqueued on `stream`.  blocking: wait for it (the xmpi_allreduce family);
+// otherwise return once it is enqueued (xmpi_*_on_stream).  Every rank of the job takes this path for the same
+// calls (the decision depends on the communicator and the arguments only), so the epochs agree.
+int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void* recvbuf, size_t count, int dtype,
+                     int op, hipStream_t stream, bool blocking) {
+  const int N = c->size, me = c->rank;
+  const size_t es = xmpi_dtype_size((xmpi_dtype)dtype);
+  const size_t send_bytes = count * es;
+  const size_t recv_bytes = (coll == COLL_ALLGATHER) ? send_bytes * (size_t)N : send_bytes;
+  const bool recv_significant = (coll != COLL_REDUCE) || me == root;
+  if (!stream) stream = c->local_stream;
+  dsync_service(c);
+  reap_deferred(c, false);
+
+  // 1. buffers the peers can map.  Anything else -- host memory, device memory that was never registered --
+  //    is stood in for by a block of a registered arena (one local copy in, one out); the collective itself is
+  //    the same zero-copy exchange.
+  Resolved r;
+  r.send = sendbuf;
+  r.recv = recv_significant ? recvbuf : const_cast<void*>(sendbuf);
+  const bool in_place = sendbuf == recvbuf;
+  std::vector<void*> lent;
+  auto fail = [&](int rc) {
+    for (void* p : lent) (void)heap_free(p);
+    c->ctl->set_abort(rc);
+    return rc;
+  };
+  if (!zc_export(c, r.send, send_bytes, &r.sref)) {
+    r.tmp_send = heap_alloc(c->device, send_bytes);
+    if (!r.tmp_send) return fail(XMPI_ERR_NOMEM);
+    lent.push_back(r.tmp_send);
+    if (coll != COLL_BCAST || me == root)
+      XMPI_HIP(hipMemcpyAsync(r.tmp_send, sendbuf, send_bytes, hipMemcpyDefault, stream));
+    r.send = r.tmp_send;
+    if (!zc_export(c, r.send, send_bytes, &r.sref)) return fail(XMPI_ERR_HIP);
+    c->dsync_bounced++;
+  }
+  if (!recv_significant || (in_place && coll != COLL_ALLGATHER)) {
+    r.recv = const_cast<void*>(r.send);
+    r.rref = r.sref;
+  } else if (!zc_export(c, r.recv, recv_bytes, &r.rref)) {
+    r.tmp_recv = heap_alloc(c->device, recv_bytes);
+    if (!r.tmp_recv) return fail(XMPI_ERR_NOMEM);
+    lent.push_back(r.tmp_recv);
+    r.recv = r.tmp_recv;
+    if (!zc_export(c, r.recv, recv_bytes, &r.rref)) return fail(XMPI_ERR_HIP);
+    c->dsync_bounced++;
+  }
+
+  // 2. the peers know the allocations
+  int sslot = 0, rslot = 0;
+  uint64_t need = 0, pi = 0;
+  int rc = publish(c, r.sref, &sslot, &pi);
+  if (rc) return fail(rc);
+  need = std::max(need, pi);
+  rc = publish(c, r.rref, &rslot, &pi);
+  if (rc) return fail(rc);
+  need = std::max(need, pi);
+  rc = await_acks(c, need);
+  if (rc) return fail(rc);
+
+  // 3. the kernel(s)
+  DsyncArgs a;
+  memset(&a, 0, sizeof a);
+  for (int p = 0; p < N; p++) a.page[p] = c->peer_page[p];
+  a.me = me;
+  a.n = N;
+  a.send_gen = r.sref.gen;
+  a.send_off = r.sref.offset;
+  a.recv_gen = r.rref.gen;
+  a.recv_off = r.rref.offset;
+  a.my_send = r.send;
+  a.my_recv = r.recv;
+  a.abort_word = c->dsync_abort_dev;
+  a.status = c->dsync_status_dev;
+  a.spin_limit = c->timeout_s > 0 ? (uint64_t)c->timeout_s * 100000000ull : 0;  // wall_clock64 ticks at 100 MHz
+  const uint32_t everyone = N >= 32 ? 0xffffffffu : ((1u << N) - 1u);
+  const size_t al = std::max<size_t>(1, 16 / es);
+  const int unroll = (int)std::max<long>(1, std::min<long>(2, c->dsync_unroll));
+
+  hipEvent_t pstart = nullptr, pstop = nullptr;
+  const bool sampled = blocking && c->prof_on && (c->prof_seq[PROF_ZCOPY]++ % (uint64_t)std::max<long>(1, c->prof_every)) == 0;
+  size_t traffic = 0;
+  auto launch = [&](int nsrc, int kdtype, int kop, size_t packets) -> int {
+    a.epoch = ++c->dsync_epoch;
+    const int gx = a.nseg > 0 ? dsync_grid(c, packets, a.nseg, unroll) : 1;
+    if (sampled && !pstart) {
+      pstart = ev_get(c, true);
+      pstop = ev_get(c, true);
+      if (!pstart || !pstop) return XMPI_ERR_HIP;
+    }
+    XMPI_HIP(launch_dsync_fold(a, nsrc, kdtype, kop, gx, unroll, stream, sampled ? pstart : nullptr, sampled ? pstop : nullptr));
+    c->dsync_launches++;
+    return XMPI_OK;
+  };
+
+  if (coll == COLL_ALLREDUCE || coll == COLL_REDUCE) {
+    size_t off = 0, cnt = 0;
+    zc_chunk(count, es, N, me, &off, &cnt);
+    a.nseg = cnt > 0 ? 1 : 0;
+    a.seg[0].src_off = a.seg[0].dst_off = off * es;
+    a.seg[0].count = cnt;
+    a.seg[0].src_mask = everyone;
+    a.seg[0].dst_mask = coll == COLL_REDUCE ? (1u << root) : everyone;
+    traffic = (size_t)(N + (coll == COLL_REDUCE ? 1 : N)) * cnt * es;
+    rc = launch(N, dtype, op, cnt / al);
+  } else if (coll == COLL_ALLGATHER) {
+    a.nseg = 1;
+    a.seg[0].src_off = 0;
+    a.seg[0].dst_off = (size_t)me * send_bytes;
+    a.seg[0].count = send_bytes;
+    a.seg[0].src_mask = 1u << me;
+    a.seg[0].dst_mask = everyone;
+    traffic = (size_t)(1 + N) * send_bytes;
+    rc = launch(1, XMPI_U8, XMPI_SUM, send_bytes / 16);
+  } else {  // COLL_BCAST: `send` and `recv` are the same buffer on every rank
+    const bool push = N <= 2 || send_bytes <= (size_t)std::max<long>(0, c->zc_bcast_push_bytes);
+    if (push) {  // the root stores into every buffer; the others only take part in the rendezvous
+      a.nseg = me == root ? 1 : 0;
+      a.seg[0].count = send_bytes;
+      a.seg[0].src_mask = 1u << root;
+      a.seg[0].dst_mask = everyone & ~(1u << root);
+      traffic = me == root ? (size_t)N * send_bytes : 0;
+      rc = launch(1, XMPI_U8, XMPI_SUM, send_bytes / 16);
+    } else {
+      // the root scatters chunk j to rank j (one segment per destination, each over its own link), then every
+      // rank forwards its chunk to the others: each link carries S/N twice instead of the root's links carrying S
+      size_t maxp = 0;
+      if (me == root) {
+        for (int j = 0; j < N; j++) {
+          size_t off = 0, cnt = 0;
+          zc_chunk(count, es, N, j, &off, &cnt);
+          if (j == root || cnt == 0) continue;
+          DsyncSeg& g = a.seg[a.nseg++];
+          g.src_off = g.dst_off = off * es;
+          g.count = cnt * es;
+          g.src_mask = 1u << root;
+          g.dst_mask = 1u << j;
+          maxp = std::max(maxp, cnt * es / 16);
+          traffic += 2 * cnt * es;
+        }
+      }
+      rc = launch(1, XMPI_U8, XMPI_SUM, maxp);
+      if (rc == XMPI_OK) {
+        memset(a.seg, 0, sizeof a.seg);
+        size_t off = 0, cnt = 0;
+        zc_chunk(count, es, N, me, &off, &cnt);
+        a.nseg = cnt > 0 ? 1 : 0;
+        a.seg[0].src_off = a.seg[0].dst_off = off * es;
+        a.seg[0].count = cnt * es;
+        a.seg[0].src_mask = 1u << me;
+        a.seg[0].dst_mask = everyone & ~(1u << me) & ~(1u << root);
+        traffic += (size_t)(N - 1) * cnt * es;
+        rc = launch(1, XMPI_U8, XMPI_SUM, cnt * es / 16);
+      }
+    }
+  }
+  if (rc != XMPI_OK) return fail(rc);
+
+  // 4. results of a stand-in go home; stand-ins go back to the arena when the stream has passed them
+  if (r.tmp_recv) XMPI_HIP(hipMemcpyAsync(recvbuf, r.tmp_recv, recv_bytes, hipMemcpyDefault, stream));
+  else if (r.tmp_send && recv_significant && (in_place || coll == COLL_BCAST) && coll != COLL_ALLGATHER)
+    XMPI_HIP(hipMemcpyAsync(recvbuf, r.tmp_send, recv_bytes, hipMemcpyDefault, stream));
+  if (!blocking) {
+    if (!lent.empty()) {
+      xmpi_comm::DsyncDeferred d;
+      if (hipEventCreateWithFlags(&d.done, hipEventDisableTiming) != hipSuccess) return fail(XMPI_ERR_HIP);
+      XMPI_HIP(hipEventRecord(d.done, stream));
+      d.bufs = lent;
+      c->dsync_deferred.push_back(d);
+    }
+    return XMPI_OK;
+  }
+
+  // blocking call: wait for the stream (polling: the wake-up latency of hipStreamSynchronize is a visible share
+  // of a small collective), serving the peers meanwhile
+  hipEvent_t fin = ev_get(c, false);
+  if (!fin) return fail(XMPI_ERR_HIP);
+  XMPI_HIP(hipEventRecord(fin, stream));
+  Backoff bo;
+  bo.idle = idle_hook;
+  bo.idle_arg = c;
+  for (;;) {
+    const hipError_t e = hipEventQuery(fin);
+    if (e == hipSuccess) break;
+    if (e != hipErrorNotReady) return fail(hip_fail(e, "hipEventQuery", __FILE__, __LINE__));
+    (void)hipGetLastError();
+    bo.pause();
+  }
+  ev_put(c, fin, false);
+  for (void* p : lent) (void)heap_free(p);
+  lent.clear();
+  if (pstart) {
+    float ms = 0.f;
+    XMPI_HIP(hipEventElapsedTime(&ms, pstart, pstop));
+    ProfCounter& pc = c->prof[PROF_ZCOPY];
+    pc.launches++;
+    pc.total_ms += ms;
+    pc.bytes += traffic;
+    ev_put(c, pstart, true);
+    ev_put(c, pstop, true);
+  }
+  return dsync_check(c);
+}
+
+// the first failure a kernel of this rank reported since the last look (a wait that was cut short, a buffer
+// reference it could not translate); clears it
+int dsync_check(xmpi_comm* c) {
+  if (!c->dsync_status) return XMPI_OK;
+  const uint32_t st = __atomic_exchange_n(c->dsync_status, 0u, __ATOMIC_ACQ_REL);
+  if (st == DSYNC_OK) return XMPI_OK;
+  int rc = XMPI_ERR_PEER;
+  if (st == DSYNC_TIMEOUT) {
+    set_last_error("collective: a peer did not arrive within XMPI_TIMEOUT_S (kernel wait cut short)");
+    rc = XMPI_ERR_TIMEOUT;
+  } else if (st == DSYNC_UNMAPPED) {
+    set_last_error("collective: a peer's buffer is not mapped here (registration freed while in use?)");
+    rc = XMPI_ERR_STATE;
+  } else {
+    set_last_error("collective: the job was aborted while the kernel waited for a peer");
+  }
+  c->ctl->set_abort(rc);
+  return rc;
+}
+
+}  // namespace xmpi

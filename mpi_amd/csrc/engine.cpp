@@ -525,6 +525,7 @@ struct Exec {
 
   int run() {
     Backoff bo;
+    arm(bo, c);
     while (remaining > 0) {
       bool progressed = false;
       {
@@ -683,16 +684,32 @@ struct StreamLease {
 
 bool timed_out(xmpi_comm* c, double t0) { return c->timeout_s > 0 && now_seconds() - t0 > (double)c->timeout_s; }
 
+// A send that found no matching receive within XMPI_TIMEOUT_S takes its message back: the entry goes from POSTED to
+// FREE and the call returns XMPI_ERR_TIMEOUT with the job intact (the reference would block for ever,
+// network.go:569; a test harness prefers an error).  false = a receive matched it in the meantime: keep waiting.
+bool withdraw(MailEntry* m) {
+  uint32_t expect = MAIL_POSTED;
+  if (!m->state.compare_exchange_strong(expect, MAIL_CLAIMED, std::memory_order_acq_rel)) return false;
+  m->pipe.head.v.store(0, std::memory_order_relaxed);
+  m->pipe.tail.v.store(0, std::memory_order_relaxed);
+  m->state.store(MAIL_FREE, std::memory_order_release);
+  return true;
+}
+
 // rendezvous: wait for the receiver's verdict (network.go:569 waits for the ack message), free the entry
 int await_ack(xmpi_comm* c, MailEntry* m, int dest, int tag) {
   int rc = XMPI_OK;
-  const double tp = now_seconds();
+  double tp = now_seconds();
   Backoff bo;
+  arm(bo, c);
   while (rc == XMPI_OK && m->state.load(std::memory_order_acquire) != MAIL_DONE) {
     if (c->ctl->aborted()) rc = XMPI_ERR_PEER;
     else if (c->timeout_s > 0 && now_seconds() - tp > (double)c->timeout_s) {
-      set_last_error("send to rank " + std::to_string(dest) + " tag " + std::to_string(tag) + ": no matching receive");
-      rc = XMPI_ERR_TIMEOUT;
+      if (withdraw(m)) {
+        set_last_error("send to rank " + std::to_string(dest) + " tag " + std::to_string(tag) + ": no matching receive");
+        return XMPI_ERR_TIMEOUT;
+      }
+      tp = now_seconds();  // matched a moment ago: the receiver is copying
     }
     bo.pause();
   }
@@ -702,7 +719,7 @@ int await_ack(xmpi_comm* c, MailEntry* m, int dest, int tag) {
     m->pipe.tail.v.store(0, std::memory_order_relaxed);
     m->state.store(MAIL_FREE, std::memory_order_release);
   } else {
-    c->ctl->set_abort(rc);  // the entry is in an unknown state: the job cannot continue
+    c->ctl->set_abort(rc);  // a peer failed: the entry is in an unknown state
   }
   return rc;
 }
@@ -725,6 +742,7 @@ int p2p_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, i
   const bool dev_src = bytes == 0 || is_device_pointer(buf);
   const double t0 = now_seconds();
   Backoff bo;
+  arm(bo, c);
 
   // claim a mail entry of the ordered pair (me -> dest)
   MailEntry* m = nullptr;
@@ -768,9 +786,11 @@ int p2p_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, i
         break;
       }
       if (c->timeout_s > 0 && now_seconds() - tp > (double)c->timeout_s) {
-        set_last_error("send to rank " + std::to_string(dest) + " tag " + std::to_string(tag) + ": no matching receive");
-        rc = XMPI_ERR_TIMEOUT;
-        break;
+        if (withdraw(m)) {
+          set_last_error("send to rank " + std::to_string(dest) + " tag " + std::to_string(tag) + ": no matching receive");
+          return XMPI_ERR_TIMEOUT;  // nothing was pushed, the entry is free again, the job goes on
+        }
+        tp = now_seconds();
       }
       bo.pause();
     }
@@ -783,6 +803,7 @@ int p2p_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, i
   const uint64_t depth = (uint64_t)c->p2p_depth;
   std::deque<hipEvent_t> inflight;
   uint64_t issued = 0, published = 0;
+  bool withdrawn = false;
   void* stage = nullptr;
   if (!dev_src && npieces > 0) {  // host payload: bounce through this rank's HBM
     if (hipMalloc(&stage, std::min<size_t>(bytes, depth * slot)) != hipSuccess)
@@ -840,8 +861,12 @@ int p2p_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, i
     if (m->state.load(std::memory_order_acquire) == MAIL_DONE) break;  // receiver gave up (truncate...)
     if (c->ctl->aborted()) rc = XMPI_ERR_PEER;
     else if (c->timeout_s > 0 && now_seconds() - tp > (double)c->timeout_s) {
-      set_last_error("send to rank " + std::to_string(dest) + " tag " + std::to_string(tag) + ": no matching receive");
-      rc = XMPI_ERR_TIMEOUT;
+      if (inflight.empty() && withdraw(m)) {  // the slots are full and nobody drains them: take the message back
+        set_last_error("send to rank " + std::to_string(dest) + " tag " + std::to_string(tag) + ": no matching receive");
+        withdrawn = true;
+        break;
+      }
+      tp = now_seconds();
     }
     bo.pause();
   }
@@ -853,6 +878,7 @@ int p2p_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, i
     }
   }
   if (stage) (void)hipFree(stage);
+  if (withdrawn) return XMPI_ERR_TIMEOUT;
   if (rc != XMPI_OK) {
     c->ctl->set_abort(rc);  // the entry is in an unknown state: the job cannot continue
     return rc;
@@ -889,6 +915,7 @@ int p2p_wait(xmpi_comm* c, int dest, int tag) {
 int p2p_probe(xmpi_comm* c, int src, int tag, size_t* bytes, int* dtype) {
   const double t0 = now_seconds();
   Backoff bo;
+  arm(bo, c);
   for (;;) {
     for (int e = 0; e < kMailEntries; e++) {
       MailEntry* m = c->ctl->mail(src, c->rank, e);
@@ -917,6 +944,7 @@ int p2p_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int 
   if (!lease.s) return hip_fail(hipGetLastError(), "hipStreamCreate", __FILE__, __LINE__);
   double t0 = now_seconds();
   Backoff bo;
+  arm(bo, c);
   MailEntry* m = nullptr;
   int entry = -1;
   while (!m) {
@@ -925,6 +953,10 @@ int p2p_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int 
       if (cand->state.load(std::memory_order_acquire) == MAIL_POSTED && cand->tag == tag) {
         uint32_t expect = MAIL_POSTED;
         if (cand->state.compare_exchange_strong(expect, MAIL_MATCHED, std::memory_order_acq_rel)) {
+          if (cand->tag != tag) {  // withdrawn and re-posted with another tag between the look and the claim
+            cand->state.store(MAIL_POSTED, std::memory_order_release);
+            continue;
+          }
           m = cand;
           entry = e;
         }

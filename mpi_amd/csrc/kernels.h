@@ -62,6 +62,62 @@ void set_kernel_mode(int mode);
 int get_kernel_mode();
 void set_grid_cap(int cap);
 
+// ---- device-synchronised collectives (dsync.cpp) ------------------------------------------------
+// One kernel per rank IS the collective: it tells the peers (flag words in their HBM, written over xGMI)
+// that this rank's buffers are ready and where they are, waits until every peer said the same, moves the
+// data straight between the user buffers, and leaves only after every peer has finished reading this
+// rank's input and writing its output.  The host enqueues it on a stream and never polls.
+constexpr int kDsyncRanks = 16;   // = kMaxRanks of ctl.h
+constexpr int kDsyncArenas = 32;  // live allocations of one peer this rank can translate
+
+// written by ONE peer (slot p of rank q's page by rank p), read by the owner's kernels
+struct DsyncSlot {
+  uint64_t epoch;  // written last, system-scope release: the fields below belong to this collective
+  uint64_t send_gen, send_off, recv_gen, recv_off;  // the peer's buffers: registration number + byte offset
+  uint64_t pad[3];
+};
+struct DsyncEntry {  // a peer's registration number -> where this process mapped that allocation
+  uint64_t gen;      // 0 = free
+  uint64_t base, bytes, pad;
+};
+// One per rank, in that rank's HBM, allocated uncached (never held in an L2): polled by the owner, written by peers.
+struct DsyncPage {
+  DsyncSlot ready[kDsyncRanks];
+  uint64_t done[kDsyncRanks][8];  // 64 bytes apart
+  uint32_t ticket;                // blocks of the running kernel that have finished their stores
+  uint32_t pad[15];
+  DsyncEntry table[kDsyncRanks][kDsyncArenas];  // written by the host (between kernels), read by the kernels
+};
+
+// what a block of the kernel moves: the fold of the source ranks' buffers (rank order) -> the destination ranks'
+struct DsyncSeg {
+  uint64_t src_off, dst_off;  // byte offsets into the send / receive buffers
+  uint64_t count;             // elements
+  uint32_t src_mask, dst_mask;  // ranks whose SEND buffer is read / whose RECEIVE buffer is written
+};
+
+enum DsyncStatus : uint32_t { DSYNC_OK = 0, DSYNC_TIMEOUT = 1, DSYNC_ABORTED = 2, DSYNC_UNMAPPED = 3 };
+
+struct DsyncArgs {
+  DsyncPage* page[kDsyncRanks];  // [me]: own page, others: the peers' pages as mapped here
+  int32_t me, n;
+  uint64_t epoch;
+  uint64_t send_gen, send_off, recv_gen, recv_off;  // what this rank tells its peers
+  const void* my_send;
+  void* my_recv;
+  const int32_t* abort_word;  // host memory the GPU can read (the job's abort flag), may be null
+  uint32_t* status;           // host memory the GPU can write: first failure (DsyncStatus), may be null
+  uint64_t spin_limit;        // wall-clock ticks (100 MHz) a wait may last, 0 = for ever
+  int32_t nseg;               // gridDim.y; 0 = synchronise only
+  int32_t pad;
+  DsyncSeg seg[kDsyncRanks];
+};
+
+// grid_x blocks per segment (the caller bounds it: every block spins until the peers arrive, so the kernels of
+// all ranks sharing a GPU must be resident together); unroll = 16-byte packets per lane per source in flight
+hipError_t launch_dsync_fold(const DsyncArgs& a, int nsrc, int dtype, int op, int grid_x, int unroll, hipStream_t stream,
+                             hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+
 // one lane: system-scope release store of `value` to *flag (host-registered or device memory)
 hipError_t launch_signal(uint64_t* flag, uint64_t value, hipStream_t stream);
 

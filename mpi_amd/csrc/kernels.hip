@@ -9,7 +9,8 @@
 // All of them are HBM-bound streaming kernels (1 flop per 12 bytes for an f32 add), so the
 // design rules are the memory ones: 16 B per lane per access (global_load_dwordx4, 1 KiB per
 // wave instruction), every load of an unrolled tile issued before the first use, <=64 VGPRs
-// so 8 waves/SIMD stay resident, grids capped at 8 blocks/CU with a grid-stride loop.  No MFMA
+// so 8 waves/SIMD stay resident, one tile per block by default (the dispatcher balances the grid
+// over the XCDs; `grid_cap` > 0 bounds the grid and the kernels loop grid-stride).  No MFMA
 // (nothing here is a contraction) and no LDS in the streaming kernels (no cross-lane reuse);
 // LDS + wavefront shuffles are used where a cross-lane reduction really exists: the
 // verification kernels at the bottom.
@@ -23,7 +24,6 @@ namespace {
 
 constexpr int kBlock = 256;      // 4 waves: one per SIMD
 constexpr int kUnroll = 4;       // 16-byte packets per lane per operand in flight
-constexpr int kMaxBlocks = 2048; // 256 CUs x 8 resident blocks
 
 enum { DT_U8 = 0, DT_I32 = 1, DT_I64 = 2, DT_F16 = 3, DT_F32 = 4, DT_F64 = 5, DT_BF16 = 6 };
 enum { OP_SUM = 0, OP_PROD = 1, OP_MIN = 2, OP_MAX = 3 };
@@ -704,6 +704,212 @@ __global__ void signal_kernel(uint64_t* flag, uint64_t value) {
   __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ---- device-synchronised collective: rendezvous + data movement + completion in ONE kernel ------
+// (protocol and layout: kernels.h, dsync.cpp).  Prologue: block 0 writes {where my buffers are, epoch} into slot
+// `me` of every peer's flag page (system-scope release store over xGMI); every block waits until its own page
+// holds the peers' slots for this epoch (uncached HBM, polled with system-scope loads), acquires, and
+// translates the peers' buffer references into this process's mappings.  Body: the fold of reduce_n_multi_kernel.
+// Epilogue: every wave drains its stores, one lane per block releases at system scope and takes a ticket; the
+// block that takes the last ticket tells every peer "done" and waits until every peer said so: when the
+// kernel ends, nobody reads this rank's input or writes its output any more.
+
+__device__ __forceinline__ uint64_t ld_sys64(const uint64_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void st_sys64(uint64_t* p, uint64_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {  // the value is the same in every lane: keep it in SGPRs
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// Wait until *p >= want.  0 = it did; otherwise why not (the job was aborted / the wait outlasted spin_limit).
+__device__ uint32_t dsync_spin(const uint64_t* p, uint64_t want, const DsyncArgs& a) {
+  if (ld_sys64(p) >= want) return DSYNC_OK;
+  const uint64_t t0 = wall_clock64();
+  for (uint32_t k = 1;; k++) {
+    __builtin_amdgcn_s_sleep(1);
+    if (ld_sys64(p) >= want) return DSYNC_OK;
+    if ((k & 127u) == 0) {  // the expensive checks (a load over PCIe, the clock) now and then only
+      if (a.abort_word && __hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return DSYNC_ABORTED;
+      if (a.spin_limit && wall_clock64() - t0 > a.spin_limit) return DSYNC_TIMEOUT;
+    }
+  }
+}
+
+struct DsyncShared {
+  uint64_t send[kDsyncRanks], recv[kDsyncRanks];  // every rank's buffers as addressable from here
+  uint64_t src[kDsyncRanks], dst[kDsyncRanks];    // this block's segment: sources in rank order, destinations local first
+  int nsrc, ndst;
+  uint32_t fail, last;
+};
+
+__device__ uint64_t dsync_translate(const DsyncPage* mine, int peer, uint64_t gen, uint64_t off) {
+  for (int k = 0; k < kDsyncArenas; k++) {
+    const DsyncEntry* e = &mine->table[peer][k];
+    if (e->gen == gen && gen != 0) return (off <= e->bytes) ? e->base + off : 0;
+  }
+  return 0;
+}
+
+__device__ void dsync_begin(const DsyncArgs& a, DsyncShared& sh) {
+  const int t = threadIdx.x, me = a.me, n = a.n;
+  DsyncPage* mine = a.page[me];
+  if (t == 0) {
+    sh.fail = DSYNC_OK;
+    sh.send[me] = (uint64_t)(uintptr_t)a.my_send;
+    sh.recv[me] = (uint64_t)(uintptr_t)a.my_recv;
+  }
+  __syncthreads();
+  if (t < n && t != me) {
+    if (blockIdx.x == 0 && blockIdx.y == 0) {  // one block announces this rank
+      DsyncSlot* out = &a.page[t]->ready[me];
+      st_sys64(&out->send_gen, a.send_gen);
+      st_sys64(&out->send_off, a.send_off);
+      st_sys64(&out->recv_gen, a.recv_gen);
+      st_sys64(&out->recv_off, a.recv_off);
+      __hip_atomic_store(&out->epoch, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const DsyncSlot* in = &mine->ready[t];
+    uint32_t why = dsync_spin(&in->epoch, a.epoch, a);
+    if (why == DSYNC_OK) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+      const uint64_t s = dsync_translate(mine, t, ld_sys64(&in->send_gen), ld_sys64(&in->send_off));
+      const uint64_t r = dsync_translate(mine, t, ld_sys64(&in->recv_gen), ld_sys64(&in->recv_off));
+      sh.send[t] = s;
+      sh.recv[t] = r;
+      if (!s || !r) why = DSYNC_UNMAPPED;
+    }
+    if (why != DSYNC_OK) atomicMax(&sh.fail, why);
+  }
+  // every lane acquires: what the peers wrote before they announced themselves (their inputs) must not be
+  // served from a stale line of this CU's L1 / this XCD's L2
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  __syncthreads();
+}
+
+// true in the block that finished last (after it has exchanged "done" with every peer)
+__device__ void dsync_end(const DsyncArgs& a, DsyncShared& sh) {
+  const int t = threadIdx.x, me = a.me, n = a.n;
+  DsyncPage* mine = a.page[me];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left
+  __syncthreads();
+  if (t == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // ... and are visible system-wide (writes back this XCD's L2)
+    const uint32_t total = gridDim.x * gridDim.y;
+    sh.last = (__hip_atomic_fetch_add(&mine->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == total - 1) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!sh.last) return;
+  if (t == 0) __hip_atomic_store(&mine->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint32_t why = DSYNC_OK;
+  if (t < n && t != me) {
+    __hip_atomic_store(&a.page[t]->done[me][0], a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (sh.fail == DSYNC_OK) why = dsync_spin(&mine->done[t][0], a.epoch, a);
+    if (why != DSYNC_OK) atomicMax(&sh.fail, why);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  __syncthreads();
+  if (t == 0 && sh.fail != DSYNC_OK && a.status) __hip_atomic_store(a.status, sh.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// NSRC > 0: the number of sources is a compile-time constant and all their loads are issued before the first
+// use (U packets per lane per source: U x NSRC 16-byte loads in flight -- remote loads over xGMI are round
+// trips, so the deeper variant is for links); NSRC == 0: any number, one load at a time.
+template <typename T, int OP, int NSRC, int U>
+__global__ __launch_bounds__(kBlock) void dsync_fold_kernel(DsyncArgs a) {
+  __shared__ DsyncShared sh;
+  dsync_begin(a, sh);
+  if (sh.fail == DSYNC_OK && a.nseg > 0) {
+    const DsyncSeg& g = a.seg[blockIdx.y];
+    const int t = threadIdx.x, me = a.me, n = a.n;
+    if (t == 0) {  // this block's pointer lists
+      int ns = 0, nd = 0;
+      for (int r = 0; r < n; r++)
+        if (g.src_mask >> r & 1u) sh.src[ns++] = sh.send[r] + g.src_off;
+      for (int d = 0; d < n; d++) {
+        const int r = (me + d) % n;
+        if (g.dst_mask >> r & 1u) sh.dst[nd++] = sh.recv[r] + g.dst_off;
+      }
+      sh.nsrc = ns;
+      sh.ndst = nd;
+    }
+    __syncthreads();
+    const int nsrc = (NSRC > 0) ? NSRC : sh.nsrc, ndst = sh.ndst;
+    const size_t count = g.count;
+    uint64_t all = 0;
+    for (int k = 0; k < nsrc; k++) all |= sh.src[k];
+    for (int k = 0; k < ndst; k++) all |= sh.dst[k];
+    constexpr size_t N = 16 / sizeof(T);
+    if ((all & 15u) == 0) {
+      const size_t npack = count / N;
+      uint64_t dp[kDsyncRanks];
+#pragma unroll
+      for (int k = 0; k < kDsyncRanks; k++) dp[k] = uniform64(sh.dst[k < ndst ? k : 0]);
+      constexpr size_t kTile = (size_t)kBlock * U;
+      const size_t stride = (size_t)gridDim.x * kTile;
+      if constexpr (NSRC > 0) {
+        uint64_t sp[NSRC];
+#pragma unroll
+        for (int k = 0; k < NSRC; k++) sp[k] = uniform64(sh.src[k]);
+        for (size_t base = (size_t)blockIdx.x * kTile; base < npack; base += stride) {
+          if (base + kTile <= npack) {
+            pack_t v[U][NSRC];
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+              for (int k = 0; k < NSRC; k++)
+                v[u][k] = ldp<2>(reinterpret_cast<const pack_t*>(sp[k]) + base + (size_t)u * kBlock + t);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+              pack_t acc = v[u][0];
+#pragma unroll
+              for (int k = 1; k < NSRC; k++) acc = combine16<T, OP>(acc, v[u][k]);
+#pragma unroll
+              for (int k = 0; k < kDsyncRanks; k++)
+                if (k < ndst) stp<1>(reinterpret_cast<pack_t*>(dp[k]) + base + (size_t)u * kBlock + t, acc);
+            }
+          } else {
+            for (int u = 0; u < U; u++) {
+              const size_t i = base + (size_t)u * kBlock + t;
+              if (i >= npack) break;
+              pack_t acc = ldp<2>(reinterpret_cast<const pack_t*>(sp[0]) + i);
+#pragma unroll
+              for (int k = 1; k < NSRC; k++) acc = combine16<T, OP>(acc, ldp<2>(reinterpret_cast<const pack_t*>(sp[k]) + i));
+#pragma unroll
+              for (int k = 0; k < kDsyncRanks; k++)
+                if (k < ndst) stp<1>(reinterpret_cast<pack_t*>(dp[k]) + i, acc);
+            }
+          }
+        }
+      } else {
+        for (size_t i = (size_t)blockIdx.x * kBlock + t; i < npack; i += (size_t)gridDim.x * kBlock) {
+          pack_t acc = ldp<2>(reinterpret_cast<const pack_t*>(sh.src[0]) + i);
+          for (int k = 1; k < nsrc; k++) acc = combine16<T, OP>(acc, ldp<2>(reinterpret_cast<const pack_t*>(sh.src[k]) + i));
+#pragma unroll
+          for (int k = 0; k < kDsyncRanks; k++)
+            if (k < ndst) stp<1>(reinterpret_cast<pack_t*>(dp[k]) + i, acc);
+        }
+      }
+      const size_t done = npack * N;  // ragged tail (< 16 bytes): the first lanes of the segment's block 0
+      if (blockIdx.x == 0 && done + t < count) {
+        const size_t i = done + t;
+        T acc = reinterpret_cast<const T*>(sh.src[0])[i];
+        for (int k = 1; k < nsrc; k++) acc = combine_any<T, OP>(acc, reinterpret_cast<const T*>(sh.src[k])[i]);
+        for (int k = 0; k < ndst; k++) reinterpret_cast<T*>(sh.dst[k])[i] = acc;
+      }
+    } else {  // some buffer is not 16-byte aligned: one element per lane
+      for (size_t i = (size_t)blockIdx.x * kBlock + t; i < count; i += (size_t)gridDim.x * kBlock) {
+        T acc = reinterpret_cast<const T*>(sh.src[0])[i];
+        for (int k = 1; k < nsrc; k++) acc = combine_any<T, OP>(acc, reinterpret_cast<const T*>(sh.src[k])[i]);
+        for (int k = 0; k < ndst; k++) reinterpret_cast<T*>(sh.dst[k])[i] = acc;
+      }
+    }
+  }
+  dsync_end(a, sh);
+}
+
 // ---- launch helpers --------------------------------------------------------------------------
 
 // plain launch, or a launch that carries its own begin / end events
@@ -927,12 +1133,14 @@ hipError_t launch_reduce2_batch(void* const* dst, void* const* dst2, const void*
     ok = ok && aligned16(dst[i]) && aligned16(q.dst2[i]) && aligned16(a[i]) && aligned16(b[i]);
   }
   if (!ok || (n == 1 && !fused) || maxc == 0) {  // odd alignment / nothing to fuse: plain launches
+    // The local destination may alias an operand (in-place ring step: dst == a): the forwarded copy is
+    // computed FIRST, from the untouched operands, and the aliasing store comes last.
     bool first = true;
     for (int i = 0; i < n; i++)
       for (int w = 0; w < 2; w++) {
-        void* d = w == 0 ? dst[i] : q.dst2[i];
+        void* d = w == 0 ? q.dst2[i] : dst[i];
         if (!d) continue;
-        const bool last = (i == n - 1) && (w == 1 || !q.dst2[i]);
+        const bool last = (i == n - 1) && (w == 1 || !dst[i]);
         hipError_t e = launch_reduce2(d, a[i], b[i], counts[i], dtype, op, s, first ? es : nullptr, last ? ee : nullptr);
         if (e != hipSuccess) return e;
         first = false;
@@ -1164,6 +1372,52 @@ void set_grid_cap(int cap) { g_grid_cap = cap < 0 ? 0 : cap; }
 hipError_t launch_signal(uint64_t* flag, uint64_t value, hipStream_t s) {
   hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(1), 0, s, flag, value);
   return hipGetLastError();
+}
+
+namespace {
+template <typename T, int OP, int NSRC, int U>
+hipError_t dsync_go(const DsyncArgs& a, int grid_x, hipStream_t s, hipEvent_t es, hipEvent_t ee) {
+  const dim3 grid(grid_x < 1 ? 1 : grid_x, a.nseg < 1 ? 1 : a.nseg);
+  XMPI_LAUNCH((dsync_fold_kernel<T, OP, NSRC, U>), grid, dim3(kBlock), s, es, ee, a);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t dsync_typed(const DsyncArgs& a, int nsrc, int op, int grid_x, int unroll, hipStream_t s, hipEvent_t es,
+                       hipEvent_t ee) {
+  if (op == OP_SUM) {  // the hot operator: sources unrolled, one or two packets per lane per source in flight
+#define XMPI_DS(NS)                                                              \
+  case NS:                                                                       \
+    return unroll >= 2 ? dsync_go<T, OP_SUM, NS, 2>(a, grid_x, s, es, ee) : dsync_go<T, OP_SUM, NS, 1>(a, grid_x, s, es, ee);
+    switch (nsrc) {
+      XMPI_DS(1) XMPI_DS(2) XMPI_DS(3) XMPI_DS(4) XMPI_DS(5) XMPI_DS(6) XMPI_DS(7) XMPI_DS(8)
+      default: return dsync_go<T, OP_SUM, 0, 1>(a, grid_x, s, es, ee);
+    }
+#undef XMPI_DS
+  }
+  switch (op) {
+    case OP_PROD: return dsync_go<T, OP_PROD, 0, 1>(a, grid_x, s, es, ee);
+    case OP_MIN: return dsync_go<T, OP_MIN, 0, 1>(a, grid_x, s, es, ee);
+    case OP_MAX: return dsync_go<T, OP_MAX, 0, 1>(a, grid_x, s, es, ee);
+    default: return hipErrorInvalidValue;
+  }
+}
+}  // namespace
+
+hipError_t launch_dsync_fold(const DsyncArgs& a, int nsrc, int dtype, int op, int grid_x, int unroll, hipStream_t s,
+                             hipEvent_t es, hipEvent_t ee) {
+  if (a.n < 1 || a.n > kDsyncRanks || a.nseg < 0 || a.nseg > kDsyncRanks || nsrc < 0 || nsrc > kDsyncRanks)
+    return hipErrorInvalidValue;
+  switch (dtype) {
+    case DT_U8: return dsync_typed<uint8_t>(a, nsrc, op, grid_x, unroll, s, es, ee);
+    case DT_I32: return dsync_typed<int32_t>(a, nsrc, op, grid_x, unroll, s, es, ee);
+    case DT_I64: return dsync_typed<int64_t>(a, nsrc, op, grid_x, unroll, s, es, ee);
+    case DT_F16: return dsync_typed<_Float16>(a, nsrc, op, grid_x, unroll, s, es, ee);
+    case DT_F32: return dsync_typed<float>(a, nsrc, op, grid_x, unroll, s, es, ee);
+    case DT_F64: return dsync_typed<double>(a, nsrc, op, grid_x, unroll, s, es, ee);
+    case DT_BF16: return dsync_typed<bf16_t>(a, nsrc, op, grid_x, unroll, s, es, ee);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 }  // namespace xmpi

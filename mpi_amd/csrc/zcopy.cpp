@@ -121,7 +121,7 @@ bool fill_ref(xmpi_comm* c, const void* p, size_t need, BufRef* ref, bool* fresh
   return true;
 }
 
-double tmo(const xmpi_comm* c) { return c->timeout_s > 0 ? (double)c->timeout_s : 3600.0; }
+double tmo(const xmpi_comm* c) { return c->timeout_s > 0 ? (double)c->timeout_s : 1e18; }
 
 int count_open_fds() {
   int n = 0;
@@ -205,6 +205,13 @@ void registry_remove(xmpi_comm* c, void* base) {
     log->count.store(n + 1, std::memory_order_release);
   }
   g_reg.erase(it);
+}
+
+bool registry_alive(uint64_t gen) {
+  std::lock_guard<std::mutex> g(g_reg_mu);
+  for (auto& kv : g_reg)
+    if (kv.second.gen == gen) return true;
+  return false;
 }
 
 namespace {

@@ -169,7 +169,7 @@ Error XGMI::Init() {
   if (Timeout > 0) {
     char t[32];
     snprintf(t, sizeof t, "%d", (int)(Timeout + 0.999));
-    setenv("XMPI_TIMEOUT_S", t, 0);
+    setenv("XMPI_INIT_TIMEOUT_S", t, 1);  // bounds Init only, as -mpi-inittimeout does (network.go:223-234,307-312)
   }
   return from_code(xmpi_init(rank, size, device, key, &comm_), "mpi init");
 }
@@ -227,6 +227,22 @@ Error XGMI::Barrier() { return from_code(xmpi_barrier(comm_), "mpi barrier"); }
 Error XGMI::IAllreduce(const Data& send, Data recv, xmpi_op op, xmpi_request** req) {
   if (recv.resize) recv.resize(recv.owner, send.count, &recv);
   return from_code(xmpi_iallreduce(comm_, send.ptr, recv.ptr, send.count, send.dtype, op, Algo, req), "mpi iallreduce");
+}
+
+void* XGMI::Stream() { return xmpi_stream_create(comm_); }
+void XGMI::StreamDestroy(void* stream) { xmpi_stream_destroy(comm_, stream); }
+Error XGMI::StreamSync(void* stream) { return from_code(xmpi_stream_sync(comm_, stream), "mpi stream sync"); }
+Error XGMI::AllreduceOnStream(const Data& send, Data recv, xmpi_op op, void* stream) {
+  return from_code(xmpi_allreduce_on_stream(comm_, send.ptr, recv.ptr, send.count, send.dtype, op, stream), "mpi allreduce");
+}
+Error XGMI::AllgatherOnStream(const Data& send, Data recv, void* stream) {
+  return from_code(xmpi_allgather_on_stream(comm_, send.ptr, recv.ptr, send.count, send.dtype, stream), "mpi allgather");
+}
+Error XGMI::BcastOnStream(Data buf, int root, void* stream) {
+  return from_code(xmpi_bcast_on_stream(comm_, buf.ptr, buf.count, buf.dtype, root, stream), "mpi bcast");
+}
+Error XGMI::ReduceOnStream(const Data& send, Data recv, xmpi_op op, int root, void* stream) {
+  return from_code(xmpi_reduce_on_stream(comm_, send.ptr, recv.ptr, send.count, send.dtype, op, root, stream), "mpi reduce");
 }
 
 Error XGMI::WaitRequest(xmpi_request* req) { return from_code(xmpi_request_wait(req), "mpi wait"); }

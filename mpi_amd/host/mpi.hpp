@@ -176,6 +176,17 @@ class XGMI : public Interface, public Collective {
   Error IAllreduce(const Data& send, Data recv, xmpi_op op, xmpi_request** req);
   Error WaitRequest(xmpi_request* req);
 
+  // Stream-ordered collectives (xmpi_*_on_stream): enqueued on a HIP stream like a kernel launch, no host
+  // wait; Stream() = a new stream of this rank's GPU (nullptr = the communicator's own), StreamSync waits for
+  // everything enqueued on it.  The overlap the reference sketched for Send / Wait (mpi.go:132-152), on streams.
+  void* Stream();
+  void StreamDestroy(void* stream);
+  Error StreamSync(void* stream);
+  Error AllreduceOnStream(const Data& send, Data recv, xmpi_op op, void* stream);
+  Error AllgatherOnStream(const Data& send, Data recv, void* stream);
+  Error BcastOnStream(Data buf, int root, void* stream);
+  Error ReduceOnStream(const Data& send, Data recv, xmpi_op op, int root, void* stream);
+
   // Device memory from another allocator joins the zero-copy paths with RegisterBuffer (Malloc'd memory
   // is registered as it is); DeregisterBuffer before it is freed.
   Error RegisterBuffer(void* p, size_t bytes);

@@ -86,6 +86,13 @@ SYMBOLS = [
     ("xmpi_reduce_local_multi", _I, [_P, C.POINTER(_P), _I, C.POINTER(_P), _I, _Z, _I, _I]),
     ("xmpi_copy_local_multi", _I, [_P, C.POINTER(_P), _I, _P, _Z]),
     ("xmpi_zc_chunk", _I, [_Z, _Z, _I, _I, C.POINTER(_Z), C.POINTER(_Z)]),
+    ("xmpi_allreduce_on_stream", _I, [_P, _P, _P, _Z, _I, _I, _P]),
+    ("xmpi_allgather_on_stream", _I, [_P, _P, _P, _Z, _I, _P]),
+    ("xmpi_bcast_on_stream", _I, [_P, _P, _Z, _I, _I, _P]),
+    ("xmpi_reduce_on_stream", _I, [_P, _P, _P, _Z, _I, _I, _I, _P]),
+    ("xmpi_stream_create", _P, [_P]),
+    ("xmpi_stream_destroy", _I, [_P, _P]),
+    ("xmpi_stream_sync", _I, [_P, _P]),
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -289,6 +296,34 @@ class Comm:
         """`iters` back-to-back allreduces inside one call (a benchmark's step loop without the interpreter)."""
         _check(lib().xmpi_allreduce_repeat(self.handle, _ptr(send), _ptr(recv), count, dtype, op, algo, iters),
                "xmpi_allreduce_repeat")
+
+    # stream-ordered forms: enqueue on a HIP stream (None = the communicator's own), return at once
+    def stream_create(self) -> int:
+        s = lib().xmpi_stream_create(self.handle)
+        if not s:
+            raise XmpiError(ERR_HIP, "xmpi_stream_create", lib().xmpi_last_error().decode())
+        return s
+
+    def stream_destroy(self, stream) -> None:
+        _check(lib().xmpi_stream_destroy(self.handle, stream), "xmpi_stream_destroy")
+
+    def stream_sync(self, stream=None) -> None:
+        _check(lib().xmpi_stream_sync(self.handle, stream), "xmpi_stream_sync")
+
+    def allreduce_on_stream(self, send, recv, count: int, dtype: int, op: int = SUM, stream=None) -> None:
+        _check(lib().xmpi_allreduce_on_stream(self.handle, _ptr(send), _ptr(recv), count, dtype, op, stream),
+               "xmpi_allreduce_on_stream")
+
+    def allgather_on_stream(self, send, recv, count: int, dtype: int, stream=None) -> None:
+        _check(lib().xmpi_allgather_on_stream(self.handle, _ptr(send), _ptr(recv), count, dtype, stream),
+               "xmpi_allgather_on_stream")
+
+    def bcast_on_stream(self, buf, count: int, dtype: int, root: int, stream=None) -> None:
+        _check(lib().xmpi_bcast_on_stream(self.handle, _ptr(buf), count, dtype, root, stream), "xmpi_bcast_on_stream")
+
+    def reduce_on_stream(self, send, recv, count: int, dtype: int, op: int, root: int, stream=None) -> None:
+        _check(lib().xmpi_reduce_on_stream(self.handle, _ptr(send), _ptr(recv), count, dtype, op, root, stream),
+               "xmpi_reduce_on_stream")
 
     def allgather(self, send, recv, count: int, dtype: int, algo: int = ALGO_AUTO) -> None:
         _check(lib().xmpi_allgather(self.handle, _ptr(send), _ptr(recv), count, dtype, algo), "xmpi_allgather")

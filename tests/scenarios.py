@@ -41,19 +41,21 @@ def check_reduced(got: np.ndarray, ins, dtype: int, op: int, exact: bool, what: 
 
 
 def allreduce_case(comm, dtype, count, algo, op=xmpi.SUM, pattern=xmpi.PAT_UNIFORM, inplace=False, seed0=1000,
-                   exact=None):
+                   exact=None, misalign=0):
+    """misalign: the buffers start `misalign` elements into their (256-byte aligned) allocations"""
     rank, size = comm.rank(), comm.size()
     es = xmpi.DTYPE_SIZE[dtype]
-    send = comm.alloc(count * es)
-    recv = send if inplace else comm.alloc(count * es)
-    comm.fill(send, count, dtype, pattern, seed0 + rank)
+    shift = misalign * es
+    send = comm.alloc(count * es + shift)
+    recv = send if inplace else comm.alloc(count * es + shift)
+    comm.fill(send.at(shift), count, dtype, pattern, seed0 + rank)
     ins = [oracle.fill(count, dtype, pattern, seed0 + r) for r in range(size)]
-    mine = send.download(xmpi.NUMPY_DTYPE[dtype], count)
+    mine = send.download(xmpi.NUMPY_DTYPE[dtype], count, byte_offset=shift)
     assert mine.tobytes() == ins[rank].tobytes(), "device fill differs from oracle fill"
     if not inplace:
-        comm.memset(recv, 0xA5, count * es)
-    comm.allreduce(send, recv, count, dtype, op, algo)
-    got = recv.download(xmpi.NUMPY_DTYPE[dtype], count)
+        comm.memset(recv, 0xA5, count * es + shift)
+    comm.allreduce(send.at(shift), recv.at(shift), count, dtype, op, algo)
+    got = recv.download(xmpi.NUMPY_DTYPE[dtype], count, byte_offset=shift)
     if exact is None:
         # rank-order algorithms and exactly-summable inputs must be bit-identical
         exact = algo in (xmpi.ALGO_DIRECT, xmpi.ALGO_ZCOPY, xmpi.ALGO_AUTO) or size <= 2 or pattern in (xmpi.PAT_CONST,) or (
@@ -61,7 +63,7 @@ def allreduce_case(comm, dtype, count, algo, op=xmpi.SUM, pattern=xmpi.PAT_UNIFO
     check_reduced(got, ins, dtype, op, exact,
                   f"allreduce {xmpi.DTYPE_NAME[dtype]} n={count} algo={algo} op={op} pat={pattern} inplace={inplace}")
     if not inplace:
-        again = send.download(xmpi.NUMPY_DTYPE[dtype], count)
+        again = send.download(xmpi.NUMPY_DTYPE[dtype], count, byte_offset=shift)
         assert again.tobytes() == ins[rank].tobytes(), "sendbuf was modified"
         recv.free()
     send.free()
@@ -86,6 +88,13 @@ def sc_allreduce_small(comm, args):
         allreduce_case(comm, xmpi.F32, 100003, algo, pattern=xmpi.PAT_SIGNED)
         allreduce_case(comm, xmpi.F64, 50001, algo, pattern=xmpi.PAT_SIGNED)
         allreduce_case(comm, xmpi.I64, 4097, algo, pattern=xmpi.PAT_CONST)  # x_r = r+1 -> N(N+1)/2
+    # buffers that start one element into their allocation (no 16-byte packets: the element kernels), in place:
+    # a fused ring step stores the same sum twice (locally and into the next rank's slot) -- both from the
+    # untouched operands, also when the local destination IS an operand
+    for algo in (xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_DIRECT, xmpi.ALGO_AUTO):
+        allreduce_case(comm, xmpi.F32, 40001, algo, pattern=xmpi.PAT_SIGNED, inplace=True, misalign=1)
+        allreduce_case(comm, xmpi.I64, 5003, algo, pattern=xmpi.PAT_UNIFORM, inplace=True, misalign=1, op=xmpi.PROD)
+        allreduce_case(comm, xmpi.F16, 30011, algo, misalign=3)
     # known answer: x_r[i] = r + 1  =>  every element N(N+1)/2
     n = comm.size()
     buf = comm.alloc(4 * 1024)
@@ -274,13 +283,17 @@ def sc_zero_copy(comm, args):
                     recv.free()
                 send.free()
 
-    # buffers the peers cannot map: every rank falls back to the staged schedule, together
-    n0 = _zc_launches(comm)
+    # buffers the peers cannot map.  Ranks that meet through the control block (threads of one process on one
+    # GPU) all fall back to the staged schedule, together; ranks that meet on the device (dsync.cpp: one process
+    # per rank) stand a registered arena block in for such a buffer and run the same kernel
+    dsync = comm.get_param("dsync") == 1
+    bounced0 = comm.get_param("dsync_bounced")
     x = oracle.fill(1000, xmpi.F32, xmpi.PAT_UNIFORM, 5 + rank)
     out = np.zeros_like(x)
     comm.allreduce(x, out, 1000, xmpi.F32, xmpi.SUM, Z)  # host memory
     want = oracle.reduce_ranks([oracle.fill(1000, xmpi.F32, xmpi.PAT_UNIFORM, 5 + r) for r in range(size)], xmpi.F32, 0)
     assert out.tobytes() == want.tobytes()
+    assert not dsync or comm.get_param("dsync_bounced") == bounced0 + 2, "host send + receive buffer: two stand-ins"
     # device memory from another allocator (here: plain hipMalloc) on ONE rank: staged until it is registered,
     # zero-copy while it is, staged again after deregistration
     import ctypes
@@ -307,14 +320,17 @@ def sc_zero_copy(comm, args):
         if rank == size - 1 and phase == "deregistered":
             comm.deregister(recv_ptr)
         comm.memset(recv_ptr, 0, count * 4)
-        before = _zc_launches(comm)
+        before, b0 = _zc_launches(comm), comm.get_param("dsync_bounced")
         comm.allreduce(send, recv_ptr, count, xmpi.F32, xmpi.SUM, Z)
         check_reduced(result(), ins, xmpi.F32, xmpi.SUM, True, f"foreign buffer, {phase}")
-        if phase == "registered":
+        if dsync:  # the kernel runs in every phase; only the owner of the foreign buffer needs a stand-in, unless registered
+            assert _zc_launches(comm) > before
+            assert comm.get_param("dsync_bounced") - b0 == (1 if rank == size - 1 and phase != "registered" else 0), phase
+        elif phase == "registered":
             assert rank != 0 or _zc_launches(comm) > before, _zc_why(comm)
         else:
             assert _zc_launches(comm) == before, "zero-copy kernel ran although a peer's buffer was not registered"
-    assert comm.get_param("zc_fallbacks_unregistered") == staged0 + 2, _zc_why(comm)
+    assert dsync or comm.get_param("zc_fallbacks_unregistered") == staged0 + 2, _zc_why(comm)
     assert comm.get_param("zc_fallbacks_unmappable") == 0, _zc_why(comm)
     # buffers of xmpi_malloc are blocks of long-lived arenas: nothing was mapped per call
     assert comm.get_param("heap_arenas") <= 8, comm.get_param("heap_arenas")
@@ -677,6 +693,108 @@ def oracle_fill_window(dtype, seed, start, n):
     raise NotImplementedError
 
 
+def sc_stream_ordered(comm, args):
+    """xmpi_*_on_stream: collectives ENQUEUED on a HIP stream, several back to back without any host wait in between;
+    each consumes what the previous one produced, so a result that matches the oracle proves the stream order.  With
+    one process per rank the ranks meet inside the kernels (dsync.cpp); ranks hosted by threads meet on the host."""
+    rank, size = comm.rank(), comm.size()
+    dsync = comm.get_param("dsync") == 1
+    st = comm.stream_create()
+    launches0 = comm.get_param("dsync_launches")
+    for count in args.get("counts", [1, 1000, 4099, (1 << 18) + 3]):
+        # int64: x -> allreduce -> allreduce (in place) -> allreduce: exact whatever the order, wraps like Go
+        a, b = comm.alloc(count * 8), comm.alloc(count * 8)
+        comm.fill(a, count, xmpi.I64, xmpi.PAT_UNIFORM, 600 + rank)
+        comm.sync()
+        comm.allreduce_on_stream(a, b, count, xmpi.I64, xmpi.SUM, st)
+        comm.allreduce_on_stream(b, b, count, xmpi.I64, xmpi.SUM, st)
+        comm.allreduce_on_stream(b, a, count, xmpi.I64, xmpi.SUM, st)
+        comm.stream_sync(st)
+        ins = [oracle.fill(count, xmpi.I64, xmpi.PAT_UNIFORM, 600 + r) for r in range(size)]
+        s1 = oracle.reduce_ranks(ins, xmpi.I64, xmpi.SUM)
+        with np.errstate(over="ignore"):
+            want = (s1.astype(np.uint64) * np.uint64(size) * np.uint64(size)).astype(np.int64)
+        got = a.download(np.int64, count)
+        assert got.tobytes() == want.tobytes(), f"chained allreduce on a stream, n={count}"
+        # f32 in rank order: bit-identical to the oracle; then a broadcast of the result of the last rank's
+        # private modification, an allgather of the broadcast, a reduce of the gathered blocks
+        f, g = comm.alloc(count * 4), comm.alloc(count * 4)
+        gath = comm.alloc(count * 4 * size)
+        red = comm.alloc(count * 4 * size)
+        comm.fill(f, count, xmpi.F32, xmpi.PAT_SIGNED, 700 + rank)
+        comm.sync()
+        root = size - 1
+        comm.allreduce_on_stream(f, g, count, xmpi.F32, xmpi.SUM, st)
+        comm.bcast_on_stream(f, count, xmpi.F32, root, st)           # everybody's f = the root's input
+        comm.allgather_on_stream(g, gath, count, xmpi.F32, st)      # size copies of the sum
+        comm.reduce_on_stream(gath, red if rank == 0 else None, count * size, xmpi.F32, xmpi.MAX, 0, st)
+        comm.stream_sync(st)
+        fin = [oracle.fill(count, xmpi.F32, xmpi.PAT_SIGNED, 700 + r) for r in range(size)]
+        want_sum = oracle.reduce_ranks(fin, xmpi.F32, xmpi.SUM)
+        assert g.download(np.float32, count).tobytes() == want_sum.tobytes(), f"allreduce_on_stream f32 n={count}"
+        assert f.download(np.float32, count).tobytes() == fin[root].tobytes(), f"bcast_on_stream n={count}"
+        assert gath.download(np.float32, count * size).tobytes() == np.tile(want_sum, size).tobytes(), "allgather_on_stream"
+        if rank == 0:
+            assert red.download(np.float32, count * size).tobytes() == np.tile(want_sum, size).tobytes(), "reduce_on_stream"
+        for x in (a, b, f, g, gath, red):
+            x.free()
+    # the communicator's own stream (stream = None), then a blocking collective right behind it
+    n = 50021
+    a, b = comm.alloc(n * 4), comm.alloc(n * 4)
+    comm.fill(a, n, xmpi.F32, xmpi.PAT_UNIFORM, 800 + rank)
+    comm.allreduce_on_stream(a, b, n, xmpi.F32, xmpi.SUM, None)
+    comm.allreduce(b, a, n, xmpi.F32, xmpi.MAX, xmpi.ALGO_AUTO)
+    want = oracle.reduce_ranks([oracle.fill(n, xmpi.F32, xmpi.PAT_UNIFORM, 800 + r) for r in range(size)], xmpi.F32, xmpi.SUM)
+    assert a.download(np.float32, n).tobytes() == want.tobytes()
+    a.free()
+    b.free()
+    if dsync:
+        assert comm.get_param("dsync_launches") > launches0, "the device-synchronised kernels did not run"
+        # device memory of another allocator, never registered: copied through a registered block on the same stream
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        n = 30011
+        src, dst = ctypes.c_void_p(0), ctypes.c_void_p(0)
+        comm.sync()
+        assert hip.hipMalloc(ctypes.byref(src), ctypes.c_size_t(n * 4)) == 0
+        assert hip.hipMalloc(ctypes.byref(dst), ctypes.c_size_t(n * 4)) == 0
+        comm.fill(src.value, n, xmpi.F32, xmpi.PAT_SIGNED, 900 + rank)
+        b0 = comm.get_param("dsync_bounced")
+        comm.allreduce_on_stream(src.value, dst.value, n, xmpi.F32, xmpi.SUM, st)
+        comm.allreduce_on_stream(dst.value, dst.value, n, xmpi.F32, xmpi.MAX, st)
+        comm.stream_sync(st)
+        out = np.empty(n, dtype=np.float32)
+        xmpi._check(xmpi.lib().xmpi_memcpy(comm.handle, out.ctypes.data, dst.value, n * 4), "download")
+        want = oracle.reduce_ranks([oracle.fill(n, xmpi.F32, xmpi.PAT_SIGNED, 900 + r) for r in range(size)], xmpi.F32, xmpi.SUM)
+        assert out.tobytes() == want.tobytes(), "unregistered buffers on a stream"
+        assert comm.get_param("dsync_bounced") == b0 + 3
+        comm.barrier()
+        assert hip.hipFree(src) == 0 and hip.hipFree(dst) == 0
+    comm.stream_destroy(st)
+
+
+def sc_lifecycle_stress(comm, args):
+    """init -> a few collectives with the copy kernel as transport (batched pushes) -> finalize, over and over, each
+    rank leaving at its own pace: nothing may still write through a mapping that a peer has already released"""
+    import random
+    import time
+    rank, size = comm.rank(), comm.size()
+    rnd = random.Random(1234 + rank)
+    base = args.get("key", "life")
+    for it in range(args.get("iters", 50)):
+        c2 = xmpi.Comm(rank, size, comm.device(), f"{base}-{it}")
+        c2.set_param("copy_engine", 1)
+        c2.set_param("batch_copies", 1)
+        for algo in (xmpi.ALGO_RING, xmpi.ALGO_DIRECT, xmpi.ALGO_AUTO):
+            allreduce_case(c2, xmpi.F32, 4099 + it, algo)
+        if it % 5 == 0:
+            allgather_case(c2, xmpi.I64, 1000 + it, xmpi.ALGO_RING)
+        time.sleep(rnd.random() * 0.004)  # ranks reach finalize at different times
+        c2.finalize()
+        if args.get("verbose") and rank == 0 and it % 5 == 0:
+            print(f"lifetime {it}: {comm.get_param('hbm_free_mib')} MiB of HBM free", flush=True)
+
+
 SCENARIOS = {
     "allreduce_small": sc_allreduce_small,
     "allreduce_medium": sc_allreduce_medium,
@@ -688,4 +806,6 @@ SCENARIOS = {
     "fullsize": sc_fullsize,
     "zero_copy": sc_zero_copy,
     "nonblocking": sc_nonblocking,
+    "stream_ordered": sc_stream_ordered,
+    "lifecycle_stress": sc_lifecycle_stress,
 }

@@ -61,13 +61,14 @@ def test_mismatched_world_size_is_refused(monkeypatch):
 
 def test_cpu_baseline_reports_what_it_used():
     m = _bench()
-    r = m.cpu_baseline(4, 1 << 16)
+    r = m.cpu_baseline(4, 1 << 16, 2)
     if r is None:
         pytest.skip("oracle/refpath_bin not built")
     assert "error" not in r, r
     assert r["kind"] == "port" and r["unit"] == "GB/s" and r["value"] > 0
     assert 1.0 <= r["cores"] <= r["host_cores"] and r["threads"] == 4 * 2 * 4  # busy cores measured, not the host's count
-    assert "4 ranks" in r["sample"]
+    assert "4 ranks" in r["sample"] and "2 repetitions" in r["sample"]
+    assert abs(r["value"] - (1 << 18) / r["seconds_per_allreduce"] / 1e9) < 1e-9  # algbw = S / t, no rank multiplier
 
 
 def test_cpu_reference_bounce_runs_the_reference_lengths():

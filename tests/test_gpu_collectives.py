@@ -74,6 +74,31 @@ def test_zero_copy_disabled_by_param():
     run_ranks("allreduce_small", 2, {"counts": [1, 4099], "dtypes": [4]}, timeout=300, env={"XMPI_ZERO_COPY": "0"})
 
 
+@pytest.mark.parametrize("size", [2, 4, 8])
+def test_stream_ordered_collectives(size):
+    """xmpi_*_on_stream between processes: one kernel per rank is the collective, the ranks meet through flag words in HBM"""
+    run_ranks("stream_ordered", size, timeout=600)
+
+
+def test_stream_ordered_collectives_threads():
+    """ranks hosted by threads of one process share a stream: the same API, met on the host"""
+    run_threads("stream_ordered", 3, {"counts": [1, 4099]})
+
+
+def test_device_sync_disabled_by_env():
+    """XMPI_DSYNC=0: processes meet through the control block again (the round-1 path stays alive)"""
+    run_ranks("zero_copy", 2, {"counts": [1, 4099]}, timeout=600, env={"XMPI_DSYNC": "0"})
+    run_ranks("stream_ordered", 2, {"counts": [1, 4099]}, timeout=600, env={"XMPI_DSYNC": "0"})
+
+
+@pytest.mark.parametrize("size", [2, 8])
+def test_lifecycle_stress(size):
+    """200 / 80 communicator lifetimes with the copy kernel as transport: init -> collectives -> finalize at each
+    rank's own pace (the one unexplained GPU fault of round 1 was in this configuration)"""
+    run_ranks("lifecycle_stress", size, {"iters": 200 if size == 2 else 80}, timeout=900,
+              env={"XMPI_COPY_ENGINE": "1", "XMPI_BATCH_COPIES": "1"})
+
+
 @pytest.mark.parametrize("size", [2, 5])
 def test_nonblocking_collectives(size):
     run_ranks("nonblocking", size, timeout=300)
