@@ -2,22 +2,36 @@
 // the message buffers resident in HBM (BASELINE config 2).  Even ranks send to rank+1, odd ranks
 // echo; the even rank checks the echo is bit-identical (bytes.Equal / floats.Equal upstream, the
 // LDS+shuffle compare kernel here) and prints the mean round-trip time in microseconds per length.
-//   xmpirun 2 bounce [--host]      --host keeps the buffers in host memory (staged through HBM)
+//   xmpirun 2 bounce [--host | --tcp]   --host keeps the buffers in host memory (staged through HBM);
+//                                        --tcp runs the reference's TCP + gob protocol instead (mpi::Network)
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <random>
 #include <vector>
 
 #include "mpi.hpp"
+#include "network.hpp"
 
 static const size_t kLengths[] = {0, 1, 10, 100, 1000, 10000, 100000, 1000000, 10000000};  // bounce.go:33
-static const int kRepeats = 10;                                                            // bounce.go:35
+static int kRepeats = 10;                                                                  // bounce.go:35
 
 int main(int argc, char** argv) {
   mpi::ParseFlags(&argc, argv);
-  bool host = false;
-  for (int i = 1; i < argc; i++) host = host || !strcmp(argv[i], "--host");
+  bool host = false, tcp = false;
+  size_t max_length = 10000000;  // the reference's longest message; tests may stop earlier
+  for (int i = 1; i < argc; i++) {
+    host = host || !strcmp(argv[i], "--host");
+    tcp = tcp || !strcmp(argv[i], "--tcp");  // the reference's own backend (TCP + gob, wire-compatible); host buffers
+    if (!strcmp(argv[i], "--max-length") && i + 1 < argc) max_length = (size_t)atoll(argv[++i]);
+    else if (!strcmp(argv[i], "--repeats") && i + 1 < argc) kRepeats = atoi(argv[++i]);
+  }
+  static mpi::Network net;
+  if (tcp) {
+    host = true;
+    mpi::Register(&net);
+  }
   if (mpi::Error err = mpi::Init()) {
     fprintf(stderr, "error initializing: %s\n", err.What().c_str());
     return 1;
@@ -61,7 +75,8 @@ int main(int argc, char** argv) {
     gpu->Memcpy(msgf, h_msgf.data(), maxsize / 8 * 8);
   }
 
-  const size_t nlen = sizeof kLengths / sizeof kLengths[0];
+  size_t nlen = 0;
+  while (nlen < sizeof kLengths / sizeof kLengths[0] && kLengths[nlen] <= max_length) nlen++;
   std::vector<long long> times(nlen, 0), timesf(nlen, 0);
   auto same = [&](const void* a, const void* b, size_t bytes) {
     if (host) return memcmp(a, b, bytes) == 0;

@@ -1,17 +1,25 @@
 // helloworld -- the reference's examples/helloworld/helloworld.go against the C++ mirror of package
 // mpi (BASELINE config 1).  Same behaviour: every rank prints its greeting, then concurrently
 // sends a string to every rank (itself included) with tag 0 and receives one from every rank.
-//   xmpirun N helloworld        (or: helloworld -mpi-addr :6000 -mpi-alladdr :6000,:6001,...)
+//   xmpirun N helloworld [--tcp]   (or: helloworld -mpi-addr :6000 -mpi-alladdr :6000,:6001,...)
 #include <cstdio>
 #include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
+#include <cstring>
+
 #include "mpi.hpp"
+#include "network.hpp"
 
 int main(int argc, char** argv) {
   mpi::ParseFlags(&argc, argv);  // flag.Parse() must be called to set the addresses (mpi.go:43)
+  // --tcp: the reference's own backend (TCP + gob, wire-compatible: the other ranks may be reference processes)
+  // instead of the xGMI one -- what `mpi.Register(&mpi.Network{})` is in a reference program (mpi.go:56-67)
+  static mpi::Network net;
+  for (int i = 1; i < argc; i++)
+    if (!strcmp(argv[i], "--tcp")) mpi::Register(&net);
   if (mpi::Error err = mpi::Init()) {
     fprintf(stderr, "%s\n", err.What().c_str());
     return 1;

@@ -7,9 +7,12 @@
 // plus the collectives the reference only stubs out (mpi.go:130).
 //
 // NOTE: the build image of this repository has no Go toolchain, so this file is shipped as
-// source and has NOT been compiled here.  It is deliberately thin: one cgo call per method and
-// no logic beyond argument marshalling; the same C entry points are exercised from C++
-// (mpi_amd/host) and Python (mpi_amd/xmpi.py) by the test-suite.
+// source and has NOT been compiled here (acceptance when one exists: `go vet ./...` in go/, then
+// examples/helloworld and examples/bounce of the reference with the one-line Register).  It is
+// deliberately thin: one cgo call per method and no logic beyond argument marshalling.  The calling
+// pattern it imposes on the C ABI -- every call from an OS thread that never selected a device,
+// stack out-parameters, nil pointers for empty slices -- is exercised in C by tests/cgo_shape_check.c;
+// the same entry points are driven from C++ (mpi_amd/host) and Python (mpi_amd/xmpi.py) by the test-suite.
 package xgmi
 
 /*
@@ -27,6 +30,7 @@ import (
 	"fmt"
 	"hash/fnv"
 	"os"
+	"reflect"
 	"sort"
 	"strconv"
 	"strings"
@@ -87,10 +91,16 @@ func status(rc C.int, where string) error {
 	if rc == 0 {
 		return nil
 	}
-	if rc == C.XMPI_ERR_TAG_EXISTS {
-		return errors.New(C.GoString(C.xmpi_last_error())) // text of mpi.TagExists.Error()
-	}
 	return fmt.Errorf("%s: %s; %s", where, C.GoString(C.xmpi_strerror(rc)), C.GoString(C.xmpi_last_error()))
+}
+
+// statusTag is status for the calls that take a tag: a {peer, tag} pair already in use is reported with the
+// reference's own error type (mpi.go:172-182; the reference declares it and then panics instead, network.go:469).
+func statusTag(rc C.int, where string, tag int) error {
+	if rc == C.XMPI_ERR_TAG_EXISTS {
+		return mpi.TagExists{Tag: tag}
+	}
+	return status(rc, where)
 }
 
 // Init implements mpi.Interface (replaces (*Network).Init, network.go:53-65).
@@ -154,48 +164,35 @@ func (b *Backend) Rank() int { return int(C.xmpi_rank(b.comm)) }
 // Size implements mpi.Interface: 0 before Init.
 func (b *Backend) Size() int { return int(C.xmpi_size(b.comm)) }
 
+// sliceTypes is THE table of Go types that travel as raw typed payloads: Send (view) and Receive both
+// consult it, so whatever one side sends raw the other side can receive raw.
+var sliceTypes = map[reflect.Type]DType{
+	reflect.TypeOf([]byte(nil)):    U8,
+	reflect.TypeOf(mpi.Raw(nil)):   U8,
+	reflect.TypeOf([]int32(nil)):   I32,
+	reflect.TypeOf([]int64(nil)):   I64,
+	reflect.TypeOf([]Float16(nil)): F16,
+	reflect.TypeOf([]float32(nil)): F32,
+	reflect.TypeOf([]float64(nil)): F64,
+}
+
 // view returns (pointer, count, dtype) for the payload types that travel without encoding.
 func view(data interface{}) (unsafe.Pointer, int, DType, bool) {
-	switch v := data.(type) {
-	case DeviceBuffer:
+	if v, ok := data.(DeviceBuffer); ok {
 		return v.Ptr, v.Count, v.Type, true
-	case []byte:
-		if len(v) == 0 {
-			return nil, 0, U8, true
-		}
-		return unsafe.Pointer(&v[0]), len(v), U8, true
-	case mpi.Raw:
-		if len(v) == 0 {
-			return nil, 0, U8, true
-		}
-		return unsafe.Pointer(&v[0]), len(v), U8, true
-	case []int32:
-		if len(v) == 0 {
-			return nil, 0, I32, true
-		}
-		return unsafe.Pointer(&v[0]), len(v), I32, true
-	case []int64:
-		if len(v) == 0 {
-			return nil, 0, I64, true
-		}
-		return unsafe.Pointer(&v[0]), len(v), I64, true
-	case []Float16:
-		if len(v) == 0 {
-			return nil, 0, F16, true
-		}
-		return unsafe.Pointer(&v[0]), len(v), F16, true
-	case []float32:
-		if len(v) == 0 {
-			return nil, 0, F32, true
-		}
-		return unsafe.Pointer(&v[0]), len(v), F32, true
-	case []float64:
-		if len(v) == 0 {
-			return nil, 0, F64, true
-		}
-		return unsafe.Pointer(&v[0]), len(v), F64, true
 	}
-	return nil, 0, U8, false
+	if data == nil {
+		return nil, 0, U8, false
+	}
+	rv := reflect.ValueOf(data)
+	dt, ok := sliceTypes[rv.Type()]
+	if !ok {
+		return nil, 0, U8, false
+	}
+	if rv.Len() == 0 {
+		return nil, 0, dt, true // empty slice: nil pointer, count 0 (the C side accepts that)
+	}
+	return rv.UnsafePointer(), rv.Len(), dt, true
 }
 
 // Send implements mpi.Interface (replaces (*Network).Send, network.go:518-572).  Numeric slices
@@ -203,7 +200,7 @@ func view(data interface{}) (unsafe.Pointer, int, DType, bool) {
 // gob-encoded like the reference does and sent as bytes.
 func (b *Backend) Send(data interface{}, destination, tag int) error {
 	if p, n, dt, ok := view(data); ok {
-		return status(C.xmpi_send(b.comm, p, C.size_t(n), C.xmpi_dtype(dt), C.int(destination), C.int(tag)), "mpi send")
+		return statusTag(C.xmpi_send(b.comm, p, C.size_t(n), C.xmpi_dtype(dt), C.int(destination), C.int(tag)), "mpi send", tag)
 	}
 	var buf bytes.Buffer
 	if err := gob.NewEncoder(&buf).Encode(data); err != nil {
@@ -214,7 +211,7 @@ func (b *Backend) Send(data interface{}, destination, tag int) error {
 	if len(raw) > 0 {
 		p = unsafe.Pointer(&raw[0])
 	}
-	return status(C.xmpi_send(b.comm, p, C.size_t(len(raw)), C.xmpi_dtype(U8), C.int(destination), C.int(tag)), "mpi send")
+	return statusTag(C.xmpi_send(b.comm, p, C.size_t(len(raw)), C.xmpi_dtype(U8), C.int(destination), C.int(tag)), "mpi send", tag)
 }
 
 // SendNoWait and Wait are the pair sketched in the comment block of mpi.go:132-152: SendNoWait
@@ -225,7 +222,7 @@ func (b *Backend) SendNoWait(data interface{}, destination, tag int) error {
 	if !ok {
 		return errPayload
 	}
-	return status(C.xmpi_send_nowait(b.comm, p, C.size_t(n), C.xmpi_dtype(dt), C.int(destination), C.int(tag)), "mpi send")
+	return statusTag(C.xmpi_send_nowait(b.comm, p, C.size_t(n), C.xmpi_dtype(dt), C.int(destination), C.int(tag)), "mpi send", tag)
 }
 
 func (b *Backend) Wait(destination, tag int) error {
@@ -241,56 +238,35 @@ func (b *Backend) probe(source, tag int) (int, error) {
 
 func (b *Backend) recvInto(p unsafe.Pointer, n int, dt DType, source, tag int) error {
 	var got C.size_t
-	return status(C.xmpi_recv(b.comm, p, C.size_t(n), C.xmpi_dtype(dt), C.int(source), C.int(tag), &got), "mpi receive")
+	return statusTag(C.xmpi_recv(b.comm, p, C.size_t(n), C.xmpi_dtype(dt), C.int(source), C.int(tag), &got), "mpi receive", tag)
 }
 
 // Receive implements mpi.Interface (replaces (*Network).Receive, network.go:575-602).  A pointer
 // to a slice is re-sliced / re-allocated to the incoming length, as gob's in-place decode does
 // (bounce.go:89,94).
 func (b *Backend) Receive(data interface{}, source, tag int) error {
-	switch v := data.(type) {
-	case DeviceBuffer:
+	if v, ok := data.(DeviceBuffer); ok {
 		return b.recvInto(v.Ptr, v.Count, v.Type, source, tag)
-	case *[]byte:
-		n, err := b.probe(source, tag)
-		if err != nil {
-			return err
+	}
+	// *[]T for every T of sliceTypes (incl. *mpi.Raw): size the slice to the message, receive in place
+	if rv := reflect.ValueOf(data); rv.Kind() == reflect.Ptr && !rv.IsNil() {
+		if dt, ok := sliceTypes[rv.Elem().Type()]; ok {
+			n, err := b.probe(source, tag)
+			if err != nil {
+				return err
+			}
+			s := rv.Elem()
+			if s.Cap() < n {
+				s.Set(reflect.MakeSlice(s.Type(), n, n))
+			} else {
+				s.SetLen(n)
+			}
+			var p unsafe.Pointer
+			if n > 0 {
+				p = s.UnsafePointer()
+			}
+			return b.recvInto(p, n, dt, source, tag)
 		}
-		if cap(*v) < n {
-			*v = make([]byte, n)
-		}
-		*v = (*v)[:n]
-		return b.recvInto(ptrOrNil(n, func() unsafe.Pointer { return unsafe.Pointer(&(*v)[0]) }), n, U8, source, tag)
-	case *[]float32:
-		n, err := b.probe(source, tag)
-		if err != nil {
-			return err
-		}
-		if cap(*v) < n {
-			*v = make([]float32, n)
-		}
-		*v = (*v)[:n]
-		return b.recvInto(ptrOrNil(n, func() unsafe.Pointer { return unsafe.Pointer(&(*v)[0]) }), n, F32, source, tag)
-	case *[]float64:
-		n, err := b.probe(source, tag)
-		if err != nil {
-			return err
-		}
-		if cap(*v) < n {
-			*v = make([]float64, n)
-		}
-		*v = (*v)[:n]
-		return b.recvInto(ptrOrNil(n, func() unsafe.Pointer { return unsafe.Pointer(&(*v)[0]) }), n, F64, source, tag)
-	case *[]int64:
-		n, err := b.probe(source, tag)
-		if err != nil {
-			return err
-		}
-		if cap(*v) < n {
-			*v = make([]int64, n)
-		}
-		*v = (*v)[:n]
-		return b.recvInto(ptrOrNil(n, func() unsafe.Pointer { return unsafe.Pointer(&(*v)[0]) }), n, I64, source, tag)
 	}
 	// anything else arrives gob-encoded (see Send)
 	n, err := b.probe(source, tag)
@@ -373,6 +349,33 @@ func (b *Backend) IAllreduce(send, recv DeviceBuffer, op int) <-chan error {
 	}
 	go func() { done <- status(C.xmpi_request_wait(req), "mpi iallreduce") }()
 	return done
+}
+
+// Stream-ordered collectives (xmpi_*_on_stream): enqueued on a HIP stream of this rank's GPU like a kernel
+// launch -- the call returns without waiting for any peer, one kernel per rank is the whole collective.  Device
+// buffers only.  Stream() creates a stream (nil = the communicator's own); StreamSync waits for it and returns
+// the status of the collectives that ran on it.  The overlap sketched at mpi.go:132-152, on streams.
+func (b *Backend) Stream() unsafe.Pointer { return C.xmpi_stream_create(b.comm) }
+func (b *Backend) StreamDestroy(stream unsafe.Pointer) {
+	C.xmpi_stream_destroy(b.comm, stream)
+}
+func (b *Backend) StreamSync(stream unsafe.Pointer) error {
+	return status(C.xmpi_stream_sync(b.comm, stream), "mpi stream sync")
+}
+func (b *Backend) AllreduceOnStream(send, recv DeviceBuffer, op int, stream unsafe.Pointer) error {
+	return status(C.xmpi_allreduce_on_stream(b.comm, send.Ptr, recv.Ptr, C.size_t(send.Count), C.xmpi_dtype(send.Type),
+		C.xmpi_op(op), stream), "mpi allreduce")
+}
+func (b *Backend) AllgatherOnStream(send, recv DeviceBuffer, stream unsafe.Pointer) error {
+	return status(C.xmpi_allgather_on_stream(b.comm, send.Ptr, recv.Ptr, C.size_t(send.Count), C.xmpi_dtype(send.Type),
+		stream), "mpi allgather")
+}
+func (b *Backend) BcastOnStream(buf DeviceBuffer, root int, stream unsafe.Pointer) error {
+	return status(C.xmpi_bcast_on_stream(b.comm, buf.Ptr, C.size_t(buf.Count), C.xmpi_dtype(buf.Type), C.int(root), stream), "mpi bcast")
+}
+func (b *Backend) ReduceOnStream(send, recv DeviceBuffer, op int, root int, stream unsafe.Pointer) error {
+	return status(C.xmpi_reduce_on_stream(b.comm, send.Ptr, recv.Ptr, C.size_t(send.Count), C.xmpi_dtype(send.Type),
+		C.xmpi_op(op), C.int(root), stream), "mpi reduce")
 }
 
 // Register makes device memory that did not come from Malloc (another allocator's) reachable by the

@@ -268,6 +268,11 @@ int xmpi_checksum(xmpi_comm* comm, const void* buf, size_t bytes, uint64_t* sum)
  * mismatch; a, b of dtype F16/BF16/F32/F64; accumulated in double. */
 int xmpi_diff_stats(xmpi_comm* comm, const void* a, const void* b, size_t count,
                     xmpi_dtype dtype, double stats[3]);
+/* *max_rel = max_i |a_i - b_i| / |b_i| (0/0 = 0, x/0 = inf; inf if a NaN sits on one side only), in double.  With
+ * non-negative inputs b_i (a rank-order sum) equals sum_r |x_r,i|, so this evaluates the per-element tolerance
+ * rule |delta_i| <= tol * sum_r |x_r,i| of BASELINE.md for a whole buffer on the device. */
+int xmpi_diff_rel(xmpi_comm* comm, const void* a, const void* b, size_t count, xmpi_dtype dtype,
+                  double* max_rel);
 /* Fill with the deterministic test pattern shared with the CPU oracle (oracle/xmpi_oracle.c
  * `oracle_fill`): see DESIGN.md "synthetic inputs". */
 int xmpi_fill_pattern(xmpi_comm* comm, void* buf, size_t count, xmpi_dtype dtype, int pattern,

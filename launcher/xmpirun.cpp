@@ -9,6 +9,7 @@
 // purpose:
 //   * rank i is pinned to GPU i % G (XMPI_DEVICE; G = $XMPI_NGPUS or the number of /dev/dri
 //     render nodes) -- "one rank owns one MI355X";
+//   * when ranks share a GPU (N > G) each copy is limited to 2 hardware queues (GPU_MAX_HW_QUEUES, unless set);
 //   * every copy gets the same fresh job id (XMPI_JOB) so two jobs never meet in one control block;
 //   * the exit status is the worst child status (the reference drops it: gompirun.go:89).
 #include <dirent.h>
@@ -66,6 +67,9 @@ int main(int argc, char** argv) {
       setenv("XMPI_JOB", job, 1);
       setenv("XMPI_DEVICE", std::to_string(i % gpus).c_str(), 0);
       setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
+      // ranks sharing a GPU share its hardware queues too: a process may hold 4 by default, and beyond a few
+      // dozen in total the GPU's scheduler time-slices them (milliseconds per collective instead of microseconds)
+      if (n > gpus) setenv("GPU_MAX_HW_QUEUES", "2", 0);
       std::vector<char*> av;
       av.push_back(argv[2]);
       for (int k = 3; k < argc; k++) av.push_back(argv[k]);

@@ -116,10 +116,12 @@ def build_host(force: bool = False) -> list[str]:
     inc = ["-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "mpi_amd", "host")]
     host_dir = os.path.join(ROOT, "mpi_amd", "host")
     mpi_cpp = os.path.join(host_dir, "mpi.cpp")
+    net_cpp = os.path.join(host_dir, "network.cpp")
     if os.path.exists(mpi_cpp):
-        deps = [mpi_cpp, os.path.join(host_dir, "mpi.hpp"), os.path.join(ROOT, "include", "xmpi.h")]
+        deps = [mpi_cpp, net_cpp, os.path.join(host_dir, "mpi.hpp"), os.path.join(host_dir, "network.hpp"),
+                os.path.join(host_dir, "gobwire.hpp"), os.path.join(ROOT, "include", "xmpi.h")]
         if force or _newer(HOSTLIB, deps):
-            _run(["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-shared", *inc, mpi_cpp, "-o", HOSTLIB,
+            _run(["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-shared", *inc, mpi_cpp, net_cpp, "-o", HOSTLIB,
                   "-L", os.path.dirname(LIB), "-lxmpi", "-Wl,-rpath,$ORIGIN", "-lpthread"], HOSTLIB, deps)
         outs.append(HOSTLIB)
         for name, src in (("helloworld", os.path.join(ROOT, "examples", "helloworld.cpp")),

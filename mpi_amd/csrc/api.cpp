@@ -219,6 +219,20 @@ void pool_release(void* ptr) {
     if (b.ptr == ptr) b.in_use = false;
 }
 
+// the per-peer / batch streams of the staged schedules (engine.cpp), created on first use
+int ensure_streams(xmpi_comm* c) {
+  if (c->shared_stream || c->staged_streams) return XMPI_OK;
+  XMPI_HIP(hipStreamCreateWithFlags(&c->batch_send_stream, hipStreamNonBlocking));
+  XMPI_HIP(hipStreamCreateWithFlags(&c->batch_recv_stream, hipStreamNonBlocking));
+  for (int p = 0; p < c->size; p++) {
+    if (p == c->rank) continue;
+    XMPI_HIP(hipStreamCreateWithFlags(&c->send_stream[p], hipStreamNonBlocking));
+    XMPI_HIP(hipStreamCreateWithFlags(&c->recv_stream[p], hipStreamNonBlocking));
+  }
+  c->staged_streams = true;
+  return XMPI_OK;
+}
+
 static hipStream_t shared_stream_for(int device) {
   static std::mutex mu;
   static std::vector<std::pair<int, hipStream_t>> streams;
@@ -517,6 +531,11 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
     static_assert(sizeof(h) <= sizeof(me->ipc_handle), "ipc handle size");
     memcpy(me->ipc_handle, &h, sizeof h);
   }
+  // this rank's stream, before anything is enqueued anywhere (the null stream would cost a second hardware queue)
+  if (hipStreamCreateWithFlags(&c->local_stream, hipStreamNonBlocking) != hipSuccess) {
+    hip_fail(hipGetLastError(), "hipStreamCreate", __FILE__, __LINE__);
+    return fail(XMPI_ERR_HIP);
+  }
   c->dsync = env_long("XMPI_DSYNC", 1) ? 1 : 0;
   c->dsync_grid_cap = std::max<long>(0, env_long("XMPI_DSYNC_GRID", 0));
   (void)dsync_prepare(c);  // this rank's flag page (device-synchronised collectives), published with the window
@@ -572,26 +591,14 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
       return fail(XMPI_ERR_HIP);
     }
     for (int p = 0; p < size; p++) c->send_stream[p] = c->recv_stream[p] = (p == rank) ? nullptr : s;
+    (void)hipStreamSynchronize(c->local_stream);
+    (void)hipStreamDestroy(c->local_stream);
     c->local_stream = c->batch_send_stream = c->batch_recv_stream = s;
-  } else {
-    if (hipStreamCreateWithFlags(&c->batch_send_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->batch_recv_stream, hipStreamNonBlocking) != hipSuccess) {
-      hip_fail(hipGetLastError(), "hipStreamCreate", __FILE__, __LINE__);
-      return fail(XMPI_ERR_HIP);
-    }
-    for (int p = 0; p < size; p++) {
-      if (p == rank) continue;
-      if (hipStreamCreateWithFlags(&c->send_stream[p], hipStreamNonBlocking) != hipSuccess ||
-          hipStreamCreateWithFlags(&c->recv_stream[p], hipStreamNonBlocking) != hipSuccess) {
-        hip_fail(hipGetLastError(), "hipStreamCreate", __FILE__, __LINE__);
-        return fail(XMPI_ERR_HIP);
-      }
-    }
-    if (hipStreamCreateWithFlags(&c->local_stream, hipStreamNonBlocking) != hipSuccess) {
-      hip_fail(hipGetLastError(), "hipStreamCreate", __FILE__, __LINE__);
-      return fail(XMPI_ERR_HIP);
-    }
   }
+  // Otherwise ONE stream (made above); the per-peer streams of the staged schedules are made when a staged schedule
+  // first runs (ensure_streams).  Every stream costs the process a hardware queue (the runtime multiplexes streams
+  // over GPU_MAX_HW_QUEUES of them), and a GPU runs only a few dozen queues at once: 8 processes x 4 queues on one
+  // GPU were time-sliced by the scheduler -- 22 ms per collective instead of 40 us (profiles/r02).
   rc = dsync_connect(c);
   if (rc != XMPI_OK) return fail(rc);
   c->dsync_unroll = env_long("XMPI_DSYNC_UNROLL", c->dsync_sharers > 1 ? 1 : 2);
@@ -718,7 +725,10 @@ int xmpi_deregister(xmpi_comm* c, void* p) {
 
 int xmpi_memcpy(xmpi_comm* c, void* dst, const void* src, size_t bytes) {
   XMPI_ENTER(c);
-  if (bytes) XMPI_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDefault));
+  if (bytes) {  // on the communicator's stream (the null stream would cost the process another hardware queue)
+    XMPI_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, c->local_stream));
+    XMPI_HIP(hipStreamSynchronize(c->local_stream));
+  }
   return XMPI_OK;
 }
 
@@ -846,6 +856,12 @@ static int on_stream(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     if (rc != XMPI_OK || done) return rc;
     set_last_error("stream-ordered collectives need buffers of xmpi_malloc / xmpi_register when ranks share a process and a GPU");
     return XMPI_ERR_UNSUPPORTED;
+  }
+  // device memory only: a copy to or from pageable host memory would block this call until the kernel before it
+  // has ended, i.e. until every peer has arrived -- the opposite of what the stream-ordered forms are for
+  if (!is_device_pointer(sendbuf) || !is_device_pointer(recvbuf)) {
+    set_last_error("stream-ordered collectives take device memory (use the blocking forms for host buffers)");
+    return XMPI_ERR_ARG;
   }
   return dsync_collective(c, coll, root, sendbuf, recvbuf, count, dtype, op, s, /*blocking=*/false);
 }
@@ -1116,6 +1132,22 @@ int xmpi_diff_stats(xmpi_comm* c, const void* a, const void* b, size_t count, xm
   return XMPI_OK;
 }
 
+int xmpi_diff_rel(xmpi_comm* c, const void* a, const void* b, size_t count, xmpi_dtype dtype, double* max_rel) {
+  XMPI_ENTER(c);
+  if (!max_rel) return XMPI_ERR_ARG;
+  if (dtype != XMPI_F16 && dtype != XMPI_BF16 && dtype != XMPI_F32 && dtype != XMPI_F64) return XMPI_ERR_ARG;
+  std::lock_guard<std::mutex> g(c->coll_mu);
+  hipStream_t s = c->local_stream;
+  uint64_t w[4] = {0, 0, 0, 0};
+  XMPI_HIP(hipMemsetAsync(c->dev_words, 0, 32, s));
+  XMPI_HIP(launch_diff_stats(a, b, count, (int)dtype, c->dev_words, s));
+  XMPI_HIP(hipMemcpyAsync(w, c->dev_words, 32, hipMemcpyDeviceToHost, s));
+  XMPI_HIP(hipStreamSynchronize(s));
+  memcpy(max_rel, &w[3], 8);
+  if (w[2]) *max_rel = 1.0 / 0.0;  // a NaN on one side only
+  return XMPI_OK;
+}
+
 int xmpi_fill_pattern(xmpi_comm* c, void* buf, size_t count, xmpi_dtype dtype, int pattern, uint64_t seed) {
   XMPI_ENTER(c);
   if (!xmpi_dtype_size(dtype) || pattern < 0 || pattern > 3) return XMPI_ERR_ARG;
@@ -1225,6 +1257,10 @@ int xmpi_link_probe(xmpi_comm* c, int peer, size_t bytes, int engine, int iters,
   XMPI_ENTER(c);
   if (peer < 0 || peer >= c->size || iters < 1 || !gbps) return XMPI_ERR_ARG;
   std::lock_guard<std::mutex> g(c->coll_mu);
+  {
+    const int src = ensure_streams(c);
+    if (src != XMPI_OK) return src;
+  }
   // the FIFO slots this rank owns in the peer's window (idle between collectives) are the remote
   // end; the slots the peer owns in this rank's window are the local end
   const size_t span = (size_t)c->lanes * c->fifo_depth * c->slot_bytes;

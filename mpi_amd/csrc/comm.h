@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -91,6 +92,7 @@ struct xmpi_comm {
   long fuse_ring = 1;    // ring: receive-reduce-send / receive-copy-send as one kernel
   long batch_copies = 1;  // with the copy kernel: all ready SENDs (RECV_COPYs) go out in one launch
   bool shared_stream = false;  // all of the above alias one per-device stream (co-located ranks)
+  bool staged_streams = false;  // the per-peer / batch streams exist (made when a staged schedule first runs)
   bool peer_coloc[xmpi::kMaxRanks] = {false};  // peer is a thread of this process on this GPU
   long prof_every = 1;  // profile every k-th launch (events cost stream bubbles)
   uint64_t prof_seq[xmpi::PROF_KINDS] = {0};
@@ -101,7 +103,6 @@ struct xmpi_comm {
   xmpi::DsyncPage* dpage = nullptr;                       // this rank's flag page (uncached HBM)
   xmpi::DsyncPage* peer_page[xmpi::kMaxRanks] = {nullptr};  // everybody's, as addressable from here
   bool peer_page_opened[xmpi::kMaxRanks] = {false};
-  hipStream_t dsync_copy_stream = nullptr;  // host -> translation table updates
   const int32_t* dsync_abort_dev = nullptr;  // the job's abort flag as the GPU reads it
   bool dsync_ctl_registered = false;
   uint32_t* dsync_status = nullptr;          // pinned host word a kernel writes its first failure to ...
@@ -111,12 +112,15 @@ struct xmpi_comm {
   long dsync_unroll = 1;         // 16-byte packets per lane per source in flight (2 = deeper, for links)
   uint64_t dsync_epoch = 0;      // kernels launched so far: the same number on every rank
   uint64_t dsync_launches = 0, dsync_bounced = 0;  // diagnostics: kernels; buffers stood in for by arena blocks
-  xmpi::DsyncEntry dsync_table[xmpi::kMaxRanks][xmpi::kDsyncArenas];  // host copy of dpage->table
+  xmpi::DsyncEntry* dsync_table = nullptr;            // [kMaxRanks][kDsyncArenas], pinned host memory the kernels read
+  const xmpi::DsyncEntry* dsync_table_dev = nullptr;  // ... as the GPU addresses it
   uint64_t dsync_seen[xmpi::kMaxRanks] = {0};         // published entries of each peer processed so far
   uint64_t dsync_slot_gen[xmpi::kDsyncArenas] = {0};  // my registrations the peers hold, by table slot
   uint64_t dsync_slot_pub[xmpi::kDsyncArenas] = {0};  // ... published as entry number (1-based)
   uint64_t dsync_slot_used[xmpi::kDsyncArenas] = {0};  // ... last used by epoch
   std::mutex dsync_mu;           // dsync_service may be entered from any thread of the rank
+  std::thread dsync_helper;      // ... and from this one, once a millisecond, whatever the rank's own threads do
+  std::atomic<bool> dsync_helper_stop{false};
   struct DsyncDeferred {
     hipEvent_t done;
     std::vector<void*> bufs;
@@ -170,6 +174,7 @@ struct xmpi_comm {
 };
 
 namespace xmpi {
+int ensure_streams(xmpi_comm* c);
 int run_plan(xmpi_comm* c, const Plan& plan, const void* sendbuf, void* recvbuf, int dtype, int op);
 int p2p_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, int tag, bool wait_ack = true);
 int p2p_wait(xmpi_comm* c, int dest, int tag);

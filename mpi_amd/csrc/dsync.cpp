@@ -19,6 +19,7 @@
 // Applies when no two ranks share a (process, GPU) pair -- the production layout, one process per MI355X.
 // Ranks hosted by threads of one process on one GPU (bench.py on a single-GPU box) keep the host-synchronised
 // path: they share one in-order stream, and a kernel that waits for a kernel queued behind it never ends.
+#include <time.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -39,15 +40,6 @@ double wait_limit(const xmpi_comm* c) { return c->timeout_s > 0 ? (double)c->tim
 
 void idle_hook(void* arg) { dsync_service((xmpi_comm*)arg); }
 
-// host -> device table of this rank (a few dozen bytes, on the rare occasions a peer registers something)
-int push_table_entry(xmpi_comm* c, int owner, int slot) {
-  const DsyncEntry* src = &c->dsync_table[owner][slot];
-  DsyncEntry* dst = &c->dpage->table[owner][slot];
-  XMPI_HIP(hipMemcpyAsync(dst, src, sizeof *src, hipMemcpyHostToDevice, c->dsync_copy_stream));
-  XMPI_HIP(hipStreamSynchronize(c->dsync_copy_stream));
-  return XMPI_OK;
-}
-
 }  // namespace
 
 // Called by xmpi_init before this rank's RankInfo is published (state 2).
@@ -62,7 +54,7 @@ int dsync_prepare(xmpi_comm* c) {
     (void)hipGetLastError();
     return XMPI_OK;  // no such memory here: every rank sees flag_addr == 0 and keeps to the host-synchronised path
   }
-  if (hipMemset(page, 0, kPageBytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+  if (hipMemsetAsync(page, 0, kPageBytes, c->local_stream) != hipSuccess || hipStreamSynchronize(c->local_stream) != hipSuccess) {
     (void)hipGetLastError();
     pool_release(page);
     return XMPI_OK;
@@ -112,7 +104,16 @@ int dsync_connect(xmpi_comm* c) {
       c->peer_page_opened[p] = true;
     }
   }
-  XMPI_HIP(hipStreamCreateWithFlags(&c->dsync_copy_stream, hipStreamNonBlocking));
+  // the translation table {peer, slot} -> {registration number, where this process mapped it}: pinned host memory
+  // the kernels read; the host is its only writer and needs no hardware queue to update it
+  if (hipHostMalloc((void**)&c->dsync_table, sizeof(DsyncEntry) * kMaxRanks * kDsyncArenas, hipHostMallocMapped) != hipSuccess)
+    return hip_fail(hipGetLastError(), "hipHostMalloc(translation table)", __FILE__, __LINE__);
+  memset(c->dsync_table, 0, sizeof(DsyncEntry) * kMaxRanks * kDsyncArenas);
+  {
+    void* dev = nullptr;
+    XMPI_HIP(hipHostGetDevicePointer(&dev, c->dsync_table, 0));
+    c->dsync_table_dev = (const DsyncEntry*)dev;
+  }
   // the job's abort flag, readable by the GPU: a kernel that waits for a dead peer gives up
   if (hipHostRegister(c->ctl->base(), 4096, hipHostRegisterMapped) == hipSuccess) {
     void* dev = nullptr;
@@ -129,17 +130,34 @@ int dsync_connect(xmpi_comm* c) {
   // Every block of the kernel spins until the peers' kernels have started: the kernels of all ranks on this GPU
   // must be resident at once, in at most half of its 8192 wave slots (4 waves per block).
   c->dsync_sharers = std::max(1, sharers);
-  memset(c->dsync_table, 0, sizeof c->dsync_table);
   c->dsync_ok = true;
+  // A rank must map what its peers register even while its own threads are blocked somewhere the library cannot
+  // see (a hipStreamSynchronize of the caller's, a long computation): a helper looks once a millisecond -- one load
+  // per peer when there is nothing to do.  (Every wait loop of the library looks as well, so inside the library
+  // the answer comes within microseconds.)
+  c->dsync_helper_stop = false;
+  c->dsync_helper = std::thread([c] {
+    (void)hipSetDevice(c->device);
+    while (!c->dsync_helper_stop.load(std::memory_order_acquire)) {
+      dsync_service(c);
+      timespec ts{0, 1000000};
+      nanosleep(&ts, nullptr);
+    }
+  });
   return XMPI_OK;
 }
 
 void dsync_finalize(xmpi_comm* c) {
+  if (c->dsync_helper.joinable()) {
+    c->dsync_helper_stop.store(true, std::memory_order_release);
+    c->dsync_helper.join();
+  }
   for (int p = 0; p < c->size; p++)
     if (c->peer_page_opened[p]) ipc_close_shared(c->peer_page[p]);
   if (c->dsync_ctl_registered) (void)hipHostUnregister(c->ctl->base());
   if (c->dsync_status) (void)hipHostFree(c->dsync_status);
-  if (c->dsync_copy_stream) (void)hipStreamDestroy(c->dsync_copy_stream);
+  if (c->dsync_table) (void)hipHostFree(c->dsync_table);
+  c->dsync_table = nullptr;
   for (auto& b : c->dsync_deferred) {
     (void)hipEventDestroy(b.done);
     for (void* p : b.bufs) (void)heap_free(p);
@@ -184,9 +202,12 @@ void dsync_service(xmpi_comm* c) {
         if (zc_import(c, p, ref, &mapped)) ent.base = (uint64_t)(uintptr_t)mapped;
         else ent.gen = 0;  // cannot be mapped here: a kernel that meets it reports DSYNC_UNMAPPED
       }
-      if (slot >= 0 && slot < kDsyncArenas) {
-        c->dsync_table[p][slot] = ent;
-        (void)push_table_entry(c, p, slot);
+      if (slot >= 0 && slot < kDsyncArenas) {  // the number last: a kernel that reads it (acquire) sees the rest
+        DsyncEntry* t = &c->dsync_table[p * kDsyncArenas + slot];
+        __atomic_store_n(&t->gen, 0, __ATOMIC_RELEASE);
+        t->base = ent.base;
+        t->bytes = ent.bytes;
+        __atomic_store_n(&t->gen, ent.gen, __ATOMIC_RELEASE);
       }
     }
     c->dsync_seen[p] = n;
@@ -385,8 +406,11 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
   a.n = N;
   a.send_gen = r.sref.gen;
   a.send_off = r.sref.offset;
+  a.send_slot = (uint64_t)sslot;
   a.recv_gen = r.rref.gen;
   a.recv_off = r.rref.offset;
+  a.recv_slot = (uint64_t)rslot;
+  a.table = c->dsync_table_dev;
   a.my_send = r.send;
   a.my_recv = r.recv;
   a.abort_word = c->dsync_abort_dev;
@@ -475,11 +499,16 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
   }
   if (rc != XMPI_OK) return fail(rc);
 
-  // 4. results of a stand-in go home; stand-ins go back to the arena when the stream has passed them
-  if (r.tmp_recv) XMPI_HIP(hipMemcpyAsync(recvbuf, r.tmp_recv, recv_bytes, hipMemcpyDefault, stream));
-  else if (r.tmp_send && recv_significant && (in_place || coll == COLL_BCAST) && coll != COLL_ALLGATHER)
-    XMPI_HIP(hipMemcpyAsync(recvbuf, r.tmp_send, recv_bytes, hipMemcpyDefault, stream));
+  // 4. results of a stand-in go home; stand-ins go back to the arena when the stream has passed them.
+  //    (A copy into pageable host memory blocks the calling thread until the kernel before it has ended -- and the
+  //    kernel ends only when every peer has arrived, which a peer may be unable to do before THIS rank has mapped a
+  //    buffer it just registered.  So a blocking call copies out after its polling wait below, which serves the
+  //    peers; the stream-ordered forms take device memory only, where the copy really is asynchronous.)
+  const void* out_src = r.tmp_recv ? r.tmp_recv
+                        : (r.tmp_send && recv_significant && (in_place || coll == COLL_BCAST) && coll != COLL_ALLGATHER) ? r.tmp_send
+                                                                                                                          : nullptr;
   if (!blocking) {
+    if (out_src) XMPI_HIP(hipMemcpyAsync(recvbuf, out_src, recv_bytes, hipMemcpyDeviceToDevice, stream));
     if (!lent.empty()) {
       xmpi_comm::DsyncDeferred d;
       if (hipEventCreateWithFlags(&d.done, hipEventDisableTiming) != hipSuccess) return fail(XMPI_ERR_HIP);
@@ -506,6 +535,10 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     bo.pause();
   }
   ev_put(c, fin, false);
+  if (out_src) {
+    XMPI_HIP(hipMemcpyAsync(recvbuf, out_src, recv_bytes, hipMemcpyDefault, stream));
+    XMPI_HIP(hipStreamSynchronize(stream));
+  }
   for (void* p : lent) (void)heap_free(p);
   lent.clear();
   if (pstart) {

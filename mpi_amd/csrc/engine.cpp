@@ -611,6 +611,10 @@ struct Exec {
 
 int run_plan(xmpi_comm* c, const Plan& plan, const void* sendbuf, void* recvbuf, int dtype, int op) {
   if (plan.steps.empty()) return XMPI_OK;
+  {
+    const int src = ensure_streams(c);
+    if (src != XMPI_OK) return src;
+  }
   if (plan.temp_bytes > c->temp_bytes) {
     if (c->temp) XMPI_HIP(hipFree(c->temp));
     c->temp = nullptr;

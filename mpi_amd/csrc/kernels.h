@@ -51,7 +51,7 @@ hipError_t launch_count_mismatch(const void* a, const void* b, size_t bytes, uin
 // *d_out += sum of LE u32 words + trailing bytes
 hipError_t launch_checksum(const void* buf, size_t bytes, uint64_t* d_out, hipStream_t stream);
 // d_out[0] = bits of max|a-b| (as u64 of a non-negative double), d_out[1] = sum|b| (double),
-// d_out[2] = NaN-mismatch count (u64); caller zeroes the 24 bytes
+// d_out[2] = NaN-mismatch count (u64), d_out[3] = bits of max_i |a_i-b_i| / |b_i|; caller zeroes the 32 bytes
 hipError_t launch_diff_stats(const void* a, const void* b, size_t count, int dtype, void* d_out,
                              hipStream_t stream);
 hipError_t launch_fill(void* buf, size_t count, int dtype, int pattern, uint64_t seed,
@@ -74,7 +74,8 @@ constexpr int kDsyncArenas = 32;  // live allocations of one peer this rank can 
 struct DsyncSlot {
   uint64_t epoch;  // written last, system-scope release: the fields below belong to this collective
   uint64_t send_gen, send_off, recv_gen, recv_off;  // the peer's buffers: registration number + byte offset
-  uint64_t pad[3];
+  uint64_t send_slot, recv_slot;                    // ... and the table slot the peer published them under
+  uint64_t pad;
 };
 struct DsyncEntry {  // a peer's registration number -> where this process mapped that allocation
   uint64_t gen;      // 0 = free
@@ -86,7 +87,10 @@ struct DsyncPage {
   uint64_t done[kDsyncRanks][8];  // 64 bytes apart
   uint32_t ticket;                // blocks of the running kernel that have finished their stores
   uint32_t pad[15];
-  DsyncEntry table[kDsyncRanks][kDsyncArenas];  // written by the host (between kernels), read by the kernels
+  // what this rank's kernels have looked up in the host's translation table (DsyncArgs::table) so far: the host
+  // never writes device memory for this (a copy would need a hardware queue -- possibly the one a waiting kernel
+  // occupies), the kernels fill the cache themselves and re-fetch when the registration number differs
+  DsyncEntry cache[kDsyncRanks][kDsyncArenas];
 };
 
 // what a block of the kernel moves: the fold of the source ranks' buffers (rank order) -> the destination ranks'
@@ -103,8 +107,10 @@ struct DsyncArgs {
   int32_t me, n;
   uint64_t epoch;
   uint64_t send_gen, send_off, recv_gen, recv_off;  // what this rank tells its peers
+  uint64_t send_slot, recv_slot;
   const void* my_send;
   void* my_recv;
+  const DsyncEntry* table;    // [kDsyncRanks][kDsyncArenas] in pinned host memory, written by the host (dsync_service)
   const int32_t* abort_word;  // host memory the GPU can read (the job's abort flag), may be null
   uint32_t* status;           // host memory the GPU can write: first failure (DsyncStatus), may be null
   uint64_t spin_limit;        // wall-clock ticks (100 MHz) a wait may last, 0 = for ever

@@ -579,11 +579,13 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void diff_stats_kernel(const T* a, const T* b, size_t count,
                                                             unsigned long long* out_max,
                                                             double* out_sum,
-                                                            unsigned long long* out_nan) {
+                                                            unsigned long long* out_nan,
+                                                            unsigned long long* out_rel) {
   __shared__ double lds_max[kBlock / 64];
   __shared__ double lds_sum[kBlock / 64];
   __shared__ uint64_t lds_nan[kBlock / 64];
-  double mx = 0.0, sb = 0.0;
+  __shared__ double lds_rel[kBlock / 64];
+  double mx = 0.0, sb = 0.0, rl = 0.0;
   uint64_t nn = 0;
   const size_t stride = (size_t)gridDim.x * kBlock;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride) {
@@ -595,8 +597,13 @@ __global__ __launch_bounds__(kBlock) void diff_stats_kernel(const T* a, const T*
       const double d = fabs(x - y);
       mx = (d > mx) ? d : mx;
       sb += fabs(y);
+      // per-element relative deviation |a_i - b_i| / |b_i| (0/0 = 0, x/0 = inf): with non-negative inputs
+      // b_i = sum_r |x_r,i|, so this IS the per-element bound of BASELINE.md, evaluated on the device
+      const double r = (d == 0.0) ? 0.0 : d / fabs(y);
+      rl = (r > rl) ? r : rl;
     }
   }
+  rl = wave_max_f64(rl);
   mx = wave_max_f64(mx);
   sb = wave_sum_f64(sb);
   nn = wave_sum_u64(nn);
@@ -605,19 +612,22 @@ __global__ __launch_bounds__(kBlock) void diff_stats_kernel(const T* a, const T*
     lds_max[wave] = mx;
     lds_sum[wave] = sb;
     lds_nan[wave] = nn;
+    lds_rel[wave] = rl;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double m = 0.0, s = 0.0;
+    double m = 0.0, s = 0.0, r = 0.0;
     uint64_t n = 0;
 #pragma unroll
     for (int w = 0; w < kBlock / 64; w++) {
+      r = (lds_rel[w] > r) ? lds_rel[w] : r;
       m = (lds_max[w] > m) ? lds_max[w] : m;
       s += lds_sum[w];
       n += lds_nan[w];
     }
     // non-negative doubles order like their bit patterns
     atomicMax(out_max, (unsigned long long)__double_as_longlong(m));
+    atomicMax(out_rel, (unsigned long long)__double_as_longlong(r));
     atomicAdd(out_sum, s);
     if (n) atomicAdd(out_nan, (unsigned long long)n);
   }
@@ -745,12 +755,26 @@ struct DsyncShared {
   uint32_t fail, last;
 };
 
-__device__ uint64_t dsync_translate(const DsyncPage* mine, int peer, uint64_t gen, uint64_t off) {
-  for (int k = 0; k < kDsyncArenas; k++) {
-    const DsyncEntry* e = &mine->table[peer][k];
-    if (e->gen == gen && gen != 0) return (off <= e->bytes) ? e->base + off : 0;
+// Where this process mapped registration `gen` (table slot `slot`) of `peer`: from the cache in this rank's page, or
+// -- the first time, and after the peer re-used the slot -- from the host's table (a few loads over PCIe).
+__device__ uint64_t dsync_translate(const DsyncArgs& a, DsyncPage* mine, int peer, uint64_t slot, uint64_t gen, uint64_t off) {
+  if (gen == 0 || slot >= (uint64_t)kDsyncArenas) return 0;
+  DsyncEntry* c = &mine->cache[peer][slot];
+  uint64_t base, bytes;
+  if (__hip_atomic_load(&c->gen, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+    base = __hip_atomic_load(&c->base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bytes = __hip_atomic_load(&c->bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    const DsyncEntry* h = &a.table[peer * kDsyncArenas + (int)slot];
+    if (__hip_atomic_load(&h->gen, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != gen) return 0;
+    base = __hip_atomic_load(&h->base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    bytes = __hip_atomic_load(&h->bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // several blocks may do this at once: they all write the same values, the number last
+    __hip_atomic_store(&c->base, base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&c->bytes, bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&c->gen, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
-  return 0;
+  return (off <= bytes) ? base + off : 0;
 }
 
 __device__ void dsync_begin(const DsyncArgs& a, DsyncShared& sh) {
@@ -767,16 +791,18 @@ __device__ void dsync_begin(const DsyncArgs& a, DsyncShared& sh) {
       DsyncSlot* out = &a.page[t]->ready[me];
       st_sys64(&out->send_gen, a.send_gen);
       st_sys64(&out->send_off, a.send_off);
+      st_sys64(&out->send_slot, a.send_slot);
       st_sys64(&out->recv_gen, a.recv_gen);
       st_sys64(&out->recv_off, a.recv_off);
+      st_sys64(&out->recv_slot, a.recv_slot);
       __hip_atomic_store(&out->epoch, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     const DsyncSlot* in = &mine->ready[t];
     uint32_t why = dsync_spin(&in->epoch, a.epoch, a);
     if (why == DSYNC_OK) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-      const uint64_t s = dsync_translate(mine, t, ld_sys64(&in->send_gen), ld_sys64(&in->send_off));
-      const uint64_t r = dsync_translate(mine, t, ld_sys64(&in->recv_gen), ld_sys64(&in->recv_off));
+      const uint64_t s = dsync_translate(a, mine, t, ld_sys64(&in->send_slot), ld_sys64(&in->send_gen), ld_sys64(&in->send_off));
+      const uint64_t r = dsync_translate(a, mine, t, ld_sys64(&in->recv_slot), ld_sys64(&in->recv_gen), ld_sys64(&in->recv_off));
       sh.send[t] = s;
       sh.recv[t] = r;
       if (!s || !r) why = DSYNC_UNMAPPED;
@@ -1333,23 +1359,24 @@ hipError_t launch_diff_stats(const void* a, const void* b, size_t count, int dty
   unsigned long long* o_max = (unsigned long long*)d_out;
   double* o_sum = (double*)d_out + 1;
   unsigned long long* o_nan = (unsigned long long*)d_out + 2;
+  unsigned long long* o_rel = (unsigned long long*)d_out + 3;
   const dim3 grid(grid_for(count, kBlock * 8)), block(kBlock);
   switch (dtype) {
     case DT_F16:
       hipLaunchKernelGGL(diff_stats_kernel<_Float16>, grid, block, 0, s, (const _Float16*)a,
-                         (const _Float16*)b, count, o_max, o_sum, o_nan);
+                         (const _Float16*)b, count, o_max, o_sum, o_nan, o_rel);
       break;
     case DT_BF16:
       hipLaunchKernelGGL(diff_stats_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)a,
-                         (const bf16_t*)b, count, o_max, o_sum, o_nan);
+                         (const bf16_t*)b, count, o_max, o_sum, o_nan, o_rel);
       break;
     case DT_F32:
       hipLaunchKernelGGL(diff_stats_kernel<float>, grid, block, 0, s, (const float*)a, (const float*)b,
-                         count, o_max, o_sum, o_nan);
+                         count, o_max, o_sum, o_nan, o_rel);
       break;
     case DT_F64:
       hipLaunchKernelGGL(diff_stats_kernel<double>, grid, block, 0, s, (const double*)a,
-                         (const double*)b, count, o_max, o_sum, o_nan);
+                         (const double*)b, count, o_max, o_sum, o_nan, o_rel);
       break;
     default:
       return hipErrorInvalidValue;

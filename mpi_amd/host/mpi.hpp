@@ -15,7 +15,9 @@
 //   type Raw []byte                  mpi.go:75-91    using Raw = std::vector<uint8_t>
 //   type TagExists                   mpi.go:172-182  Error::IsTagExists()
 //   flags -mpi-addr ...              flags.go:44-50  mpi::ParseFlags(&argc, argv)
-//   type Network (TCP backend)       network.go      class XGMI (HBM windows over xGMI, via libxmpi.so)
+//   type Network (TCP backend)       network.go      class XGMI (HBM windows over xGMI, via libxmpi.so);
+//                                                    class Network (network.hpp): the reference's own TCP + gob
+//                                                    protocol, wire-compatible, for CPU / mixed / multi-node ranks
 //   //func AllReduce() {}            mpi.go:130      mpi::Allreduce / Bcast / Reduce / Allgather
 //                                                    (optional Collective interface, cf. the unused
 //                                                     isAllReducer probe at mpi.go:69-71)
@@ -52,6 +54,7 @@ struct Data {
   void* ptr = nullptr;
   size_t count = 0;
   xmpi_dtype dtype = XMPI_U8;
+  bool is_string = false;  // a Go `string` rather than a `[]byte` (they differ on the reference's wire: gob ids 6 / 5)
   // Receive only: the container to re-size to the incoming length (Go re-slices / re-allocates the
   // pointed-to slice, mpi.go:83-91, bounce.go:89,94).  Null for fixed spans (device buffers).
   void* owner = nullptr;
@@ -73,7 +76,7 @@ template <typename T> Data Slice(const std::vector<T>& v) {
   Data d; d.ptr = const_cast<T*>(v.data()); d.count = v.size(); d.dtype = DTypeOf<T>::v; return d;
 }
 inline Data Slice(const std::string& s) {
-  Data d; d.ptr = const_cast<char*>(s.data()); d.count = s.size(); d.dtype = XMPI_U8; return d;
+  Data d; d.ptr = const_cast<char*>(s.data()); d.count = s.size(); d.dtype = XMPI_U8; d.is_string = true; return d;
 }
 template <typename T> Data Span(const T* p, size_t n) {  // host or device pointer
   Data d; d.ptr = const_cast<T*>(p); d.count = n; d.dtype = DTypeOf<T>::v; return d;
@@ -85,7 +88,7 @@ template <typename T> Data Into(std::vector<T>* v) {
   return d;
 }
 inline Data Into(std::string* s) {
-  Data d; d.ptr = &(*s)[0]; d.count = s->size(); d.dtype = XMPI_U8; d.owner = s;
+  Data d; d.ptr = &(*s)[0]; d.count = s->size(); d.dtype = XMPI_U8; d.is_string = true; d.owner = s;
   d.resize = [](void* o, size_t n, Data* self) { auto* ss = static_cast<std::string*>(o); ss->resize(n); self->ptr = &(*ss)[0]; self->count = n; };
   return d;
 }

@@ -61,6 +61,7 @@ SYMBOLS = [
     ("xmpi_count_mismatch", _I, [_P, _P, _P, _Z, C.POINTER(C.c_uint64)]),
     ("xmpi_checksum", _I, [_P, _P, _Z, C.POINTER(C.c_uint64)]),
     ("xmpi_diff_stats", _I, [_P, _P, _P, _Z, _I, C.POINTER(C.c_double)]),
+    ("xmpi_diff_rel", _I, [_P, _P, _P, _Z, _I, C.POINTER(C.c_double)]),
     ("xmpi_fill_pattern", _I, [_P, _P, _Z, _I, _I, C.c_uint64]),
     ("xmpi_set_param", _I, [_P, C.c_char_p, _L]),
     ("xmpi_get_param", _L, [_P, C.c_char_p]),
@@ -371,6 +372,12 @@ class Comm:
         out = (C.c_double * 3)()
         _check(lib().xmpi_diff_stats(self.handle, _ptr(a), _ptr(b), count, dtype, out), "diff_stats")
         return out[0], out[1], out[2]
+
+    def diff_rel(self, a, b, count: int, dtype: int) -> float:
+        """max_i |a_i - b_i| / |b_i| over the whole buffer, on the device"""
+        out = C.c_double(0)
+        _check(lib().xmpi_diff_rel(self.handle, _ptr(a), _ptr(b), count, dtype, C.byref(out)), "diff_rel")
+        return out.value
 
     def fill(self, buf, count: int, dtype: int, pattern: int, seed: int) -> None:
         _check(lib().xmpi_fill_pattern(self.handle, _ptr(buf), count, dtype, pattern, seed), "fill_pattern")

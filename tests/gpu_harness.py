@@ -14,6 +14,7 @@ def run_ranks(scenario: str, size: int, args: dict | None = None, timeout: float
     e = dict(os.environ)
     e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     e.setdefault("XMPI_TIMEOUT_S", "60")
+    e.setdefault("GPU_MAX_HW_QUEUES", "2")  # the ranks of a test share one GPU and its hardware queues (see launcher/xmpirun.cpp)
     e.update(env or {})
     procs = []
     for r in range(size):

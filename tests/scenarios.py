@@ -654,9 +654,13 @@ def sc_fullsize(comm, args):
         if dtype == xmpi.F16:
             assert comm.count_mismatch(out, ref, count * es) == 0, f"{which} algo {algo}: not bit-identical"
         else:
+            # BASELINE.md's rule, per element, over all 67 108 864 of them, on the device: the inputs are
+            # non-negative, so the rank-order sum ref_i IS sum_r |x_r,i| and the rule reads
+            # |out_i - ref_i| <= 1e-6 * ref_i  (two summation orders of 8 floats differ by <= 2*7*2^-24 = 8.3e-7)
+            rel = comm.diff_rel(out, ref, count, dtype)
+            assert rel <= 1e-6, f"{which} algo {algo}: max_i |delta_i| / sum_r|x_r,i| = {rel}"
             mx, sb, nn = comm.diff_stats(out, ref, count, dtype)
-            # inputs in [0,1): sum_i|x_i| <= N, so |delta| <= 1e-6 * N is the BASELINE.md bound
-            assert nn == 0 and mx <= 1e-6 * size, f"{which} algo {algo}: max|delta| {mx}"
+            assert nn == 0 and mx <= 1e-6 * size
             s1, s2 = comm.checksum(out, count * es), comm.checksum(ref, count * es)
             assert s1 != 0 and s2 != 0
     # idempotence of the data path: the same call again gives the same bits

@@ -227,6 +227,27 @@ def test_diff_stats(comm, dtype):
     db.free()
 
 
+@pytest.mark.parametrize("dtype", [xmpi.F32, xmpi.F64, xmpi.F16])
+def test_diff_rel_is_the_per_element_bound(comm, dtype):
+    """max_i |a_i - b_i| / |b_i| over the whole buffer (what the full-size float checks use), against numpy"""
+    n = 300007
+    b = oracle.fill(n, dtype, xmpi.PAT_UNIFORM, 3)
+    a = b.copy()
+    rng = np.random.default_rng(11)
+    idx = rng.choice(n, size=50, replace=False)
+    a[idx] = (oracle.as_float64(a[idx], dtype) * (1 + 1e-3) + 1e-3).astype(a.dtype)
+    da, db = comm.alloc(a.nbytes).upload(a), comm.alloc(b.nbytes).upload(b)
+    got = comm.diff_rel(da, db, n, dtype)
+    a64, b64 = oracle.as_float64(a, dtype), oracle.as_float64(b, dtype)
+    d = np.abs(a64 - b64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        want = np.max(np.where(d == 0, 0.0, d / np.abs(b64)))
+    assert got == want, (got, want)
+    assert comm.diff_rel(db, db, n, dtype) == 0.0
+    da.free()
+    db.free()
+
+
 def test_send_to_self_needs_no_peer(comm):
     """size-1 communicator: collectives degenerate to the local copy kernel"""
     n = 100001

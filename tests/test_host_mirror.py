@@ -73,3 +73,30 @@ def test_allreduce_program(n, elems):
                        capture_output=True, text=True, timeout=300, env={**os.environ, "XMPI_BASEPORT": str(6300 + 10 * n)})
     assert r.returncode == 0, r.stdout + r.stderr
     assert f"allreduce of {elems} float32 over {n} nodes" in r.stdout and "every result exact" in r.stdout
+
+
+def _build_cgo_shape_check(tmp_path):
+    exe = str(tmp_path / "cgo_shape_check")
+    subprocess.check_call(["gcc", "-O1", "-std=c11", "-Wall", "-Wextra", "-Werror", "-D_GNU_SOURCE", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cgo_shape_check.c"), "-o", exe, "-L", os.path.join(ROOT, "mpi_amd"),
+                           "-lxmpi", "-Wl,-rpath," + os.path.join(ROOT, "mpi_amd"), "-lpthread"])
+    return exe
+
+
+def test_cgo_shape_check_compiles_as_plain_c(tmp_path):
+    """include/xmpi.h is consumable by a C compiler exactly as cgo would see it (no C++-isms), and the program that
+    drives the ABI the way go/xgmi/xgmi.go does links against libxmpi.so"""
+    assert os.path.exists(_build_cgo_shape_check(tmp_path))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 2, 4])
+def test_cgo_calling_pattern(n, tmp_path):
+    """tests/cgo_shape_check.c: every ABI call from a fresh OS thread that never selected a device, stack
+    out-parameters, (NULL, 0) for empty slices, concurrent Send / Receive with distinct {peer, tag} -- the contract
+    cgo imposes, tested without a Go toolchain"""
+    exe = _build_cgo_shape_check(tmp_path)
+    r = subprocess.run([os.path.join(BIN, "xmpirun"), str(n), exe], capture_output=True, text=True, timeout=300,
+                       env={**os.environ, "XMPI_BASEPORT": str(6500 + 10 * n), "XMPI_TIMEOUT_S": "60"})
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"cgo shape check: {n} ranks, every call from a fresh OS thread: ok" in r.stdout

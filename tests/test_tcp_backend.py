@@ -1,0 +1,111 @@
+"""mpi::Network (mpi_amd/host/network.cpp): the reference's TCP + gob protocol, product side.
+
+No Go toolchain exists in the image, so the peer that speaks the reference's wire format is oracle/refpath_bin, the
+repository's function-by-function restatement of network.go:53-625 (test infrastructure).  The product backend was
+written separately (it does not include, link or execute anything under oracle/ -- checked below); that the two
+interoperate, both ways, at every message length of examples/bounce/bounce.go:33, is the end-to-end check of this
+project's reading of the reference's Send / Receive.  CPU only: no GPU is touched.
+"""
+import json
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "mpi_amd", "bin")
+REF = os.path.join(ROOT, "oracle", "refpath_bin")
+
+
+def _ports(base, n):
+    return [f":{base + i}" for i in range(n)]
+
+
+def _spawn(cmd, addr, alladdr, extra=()):
+    return subprocess.Popen([*cmd, "-mpi-addr", addr, "-mpi-alladdr", ",".join(alladdr), *extra], stdout=subprocess.PIPE,
+                            stderr=subprocess.STDOUT, text=True, cwd=ROOT)
+
+
+def _hello_lines(rank, n):
+    want = [f"Hello world, I'm node {rank} in a land with {n} nodes"]
+    for src in range(n):
+        msg = f"\"I'm just node {rank} talking to myself\"" if src == rank else f"\"Hello node {rank}, I'm node {src}\""
+        want.append(f"I, node {rank}, received a message: {msg}")
+    return sorted(want)
+
+
+def test_gobwire_known_answers(tmp_path):
+    exe = str(tmp_path / "gobwire_check")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "mpi_amd", "host"),
+                           os.path.join(ROOT, "tests", "gobwire_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout
+
+
+def test_product_tcp_backend_does_not_use_the_oracle():
+    for fn in ("network.cpp", "network.hpp", "gobwire.hpp"):
+        text = open(os.path.join(ROOT, "mpi_amd", "host", fn)).read()
+        assert "#include \"../../oracle" not in text and "gob_codec.h" not in text.replace("oracle/gob_codec.h is test", "")
+
+
+@pytest.mark.parametrize("n", [1, 2, 4])
+def test_helloworld_over_the_product_tcp_backend(n):
+    """examples/helloworld.cpp --tcp: every rank the product's mpi::Network"""
+    ports = _ports(7800 + 10 * n, n)
+    procs = [_spawn([os.path.join(BIN, "helloworld"), "--tcp"], p, ports, ["-mpi-inittimeout", "30s"]) for p in ports]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    for rank, out in enumerate(outs):
+        assert sorted(out.strip().split("\n")) == _hello_lines(rank, n)
+
+
+@pytest.mark.parametrize("product_rank", [0, 1, 2])
+def test_helloworld_mixed_with_reference_path_peers(product_rank):
+    """3 ranks: one runs the product's mpi::Network, the other two the restated reference (oracle/refpath_bin)"""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/refpath_bin not built")
+    ports = _ports(7900 + 10 * product_rank, 3)
+    procs = []
+    for r, p in enumerate(ports):
+        if r == product_rank:
+            procs.append(_spawn([os.path.join(BIN, "helloworld"), "--tcp"], p, ports, ["-mpi-inittimeout", "30s"]))
+        else:
+            procs.append(_spawn([REF, "helloworld"], p, ports))
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    for rank, out in enumerate(outs):
+        assert sorted(out.strip().split("\n")) == _hello_lines(rank, 3), (rank, out)
+
+
+@pytest.mark.parametrize("product_is_even", [True, False])
+def test_bounce_against_the_reference_path(product_is_even):
+    """examples/bounce/bounce.go: lossless echo of []byte and []float64 at lengths 0 ... 1e6 bytes, one side the product's
+    backend, the other the restated reference; the even side compares what comes back with what it sent"""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/refpath_bin not built")
+    ports = _ports(8000 + (10 if product_is_even else 20), 2)
+    prod = [os.path.join(BIN, "bounce"), "--tcp", "--max-length", "1000000", "--repeats", "3"]
+    ref = [REF, "bounce"]
+    even = _spawn(prod if product_is_even else ref, ports[0], ports, [] if product_is_even else ["1000000", "3"])
+    odd = _spawn(ref if product_is_even else prod, ports[1], ports, ["1000000", "3"] if product_is_even else [])
+    out_even, out_odd = even.communicate(timeout=300)[0], odd.communicate(timeout=300)[0]
+    assert even.returncode == 0 and odd.returncode == 0, (out_even, out_odd)
+    assert "message not the same" not in out_even + out_odd
+    if product_is_even:
+        assert "Average byte trip time in µs between node 0 and 1: [" in out_even
+        assert "Average float64 trip time in µs between node 0 and 1: [" in out_even
+    else:
+        row = json.loads(out_even.strip().split("\n")[-1])
+        assert len(row["bytes_us"]) == 8 and len(row["float64_us"]) == 8  # lengths 0 ... 1e6
+
+
+def test_tcp_backend_error_values(tmp_path):
+    """duplicate {peer, tag} -> TagExists as an error value (the reference panics, network.go:469); wrong password ->
+    Init fails on both sides (network.go:343-346); Rank() == -1 / Size() == 0 before Init (network.go:41-50)"""
+    exe = str(tmp_path / "tcp_api_check")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"), "-I",
+                           os.path.join(ROOT, "mpi_amd", "host"), os.path.join(ROOT, "tests", "tcp_api_check.cpp"), "-o", exe,
+                           "-L", os.path.join(ROOT, "mpi_amd"), "-lxmpi_host", "-lxmpi", "-Wl,-rpath," + os.path.join(ROOT, "mpi_amd"),
+                           "-lpthread"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
