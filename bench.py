@@ -94,15 +94,20 @@ class Job:
         port = os.environ.get("MASTER_PORT", "0")
         self.key = os.environ.get("XMPI_BENCH_KEY") or f"bench-{port}-{os.getppid() if self.procs > 1 else os.getpid()}"
         self.zero_copy_ok = True
+        self.probe = "not run"
         # ranks sharing a GPU have no link to pipeline against: large pieces (one launch per chunk)
         # keep every kernel at full-chip bandwidth; one rank per GPU keeps the library defaults
         if self.ranks // n >= 4:
             os.environ.setdefault("XMPI_SLOT_BYTES", str(32 << 20))
             os.environ.setdefault("XMPI_FIFO_DEPTH", "4")
-        if self.ranks // n == 1:
-            # one rank per GPU drives up to 7 peer links at once, each on its own stream: give the HIP
-            # runtime more hardware queues than its default of 4 so those streams do not serialise
+        if self.ranks // n == 1 and "XMPI_BENCH_DEVICE" not in os.environ:
+            # one rank per GPU drives up to 7 peer links at once, each on its own stream (staged schedules): give the
+            # HIP runtime more hardware queues than its default of 4 so those streams do not serialise
             os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+        if "XMPI_BENCH_DEVICE" in os.environ:
+            # rehearsal of the multi-process launch on ONE GPU: its processes share that GPU's hardware queues, and
+            # beyond a few dozen the scheduler time-slices them (22 ms per collective instead of 40 us)
+            os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
         self.result = {}
         self.errors = []
         self.lock = threading.Lock()
@@ -181,6 +186,26 @@ def rank_main(job: Job, grank: int):
     comm.fill(send, count, dtype, xmpi.PAT_UNIFORM, seed0 + grank)
     comm.memset(recv, 0, nbytes)
 
+    dsync_can = comm.get_param("dsync") == 1  # one rank per (process, GPU): the ranks may meet on the device
+    ndev_used = len({job.device_of(r) for r in range(R)})
+    # ---- the links first (multi-GPU only), before anything is tuned: what one xGMI link gives, per engine ----------
+    link = None
+    other = next((r for r in range(R) if job.device_of(r) != job.device_of(0)), None)
+    if other is not None and not a.no_extras:
+        probe = {}
+        for eng, name in ((0, "hipMemcpyAsync"), (1, "copy_kernel")):
+            comm.barrier()
+            if grank == 0:
+                probe[name + "_write_GBps"] = comm.link_probe(other, 64 << 20, eng, 10, 0)
+                probe[name + "_read_GBps"] = comm.link_probe(other, 64 << 20, eng, 10, 1)
+            comm.barrier()
+            if grank in (0, other):  # both directions at once
+                v = comm.link_probe(other if grank == 0 else 0, 64 << 20, eng, 10, 0)
+                if grank == 0:
+                    probe[name + "_bidir_each_GBps"] = v
+            comm.barrier()
+        link = {"between_ranks": [0, other], **probe}
+
     def run(algo, cnt=count, s=send, r=recv, dt=dtype):
         comm.allreduce(s, r, cnt, dt, xmpi.SUM, algo)
 
@@ -204,24 +229,40 @@ def rank_main(job: Job, grank: int):
             cands = [(xmpi.ALGO_RING, 1, 0)]
         slot = comm.get_param("slot_bytes")
         pieces = sorted({0, slot}) if R > 1 else [0]  # 0 = library heuristic (~4 pieces per chunk)
+        cands = [(al, ch, eng, {}) for al, ch, eng in cands]
         if R > 1 and zc_ok:
-            cands.append((xmpi.ALGO_ZCOPY, 1, 0))  # no staging: channels / engine / piece size do not apply
-            cands.append((xmpi.ALGO_ZPUSH, 1, 0))  # ... the variant that only writes over xGMI (3 kernels)
-        for algo, ch, eng in cands:
+            # no staging: channels / engine / piece size do not apply.  One process per GPU: the ranks can meet on the
+            # device (one kernel per rank is the collective) -- with 1 or 2 packets per lane per source in flight (remote
+            # loads over a link are round trips) -- or on the host as before; co-located ranks only meet on the host
+            if dsync_can:
+                cands.append((xmpi.ALGO_ZCOPY, 1, 0, {"dsync": 1, "dsync_unroll": 1}))
+                cands.append((xmpi.ALGO_ZCOPY, 1, 0, {"dsync": 1, "dsync_unroll": 2}))
+                cands.append((xmpi.ALGO_ZCOPY, 1, 0, {"dsync": 0}))
+                cands.append((xmpi.ALGO_ZPUSH, 1, 0, {"dsync": 0}))  # only WRITES over xGMI (3 kernels, host barriers)
+            else:
+                cands.append((xmpi.ALGO_ZCOPY, 1, 0, {}))
+                cands.append((xmpi.ALGO_ZPUSH, 1, 0, {}))
+        for algo, ch, eng, extra in cands:
             for pc in (pieces if algo not in ZC_ALGOS else [0]):
                 comm.set_param("channels", ch)
                 comm.set_param("copy_engine", eng)
                 comm.set_param("piece_bytes", pc)
+                for k, v in extra.items():
+                    comm.set_param(k, v)
                 run(algo)
                 t = timed(comm, None, 2, batch=lambda k: run_n(algo, k))
                 tune.append({"algo": ALGO_NAME[algo], "channels": ch, "copy_engine": eng, "piece_bytes": pc,
-                             "ms": t * 1e3, "algbw_GBps": nbytes / t / 1e9})
+                             "params": extra, "ms": t * 1e3, "algbw_GBps": nbytes / t / 1e9})
+            if dsync_can:
+                comm.set_param("dsync", 1)
         best = min(tune, key=lambda x: x["ms"])
         best_ring = min((x for x in tune if x["algo"] == "ring"), key=lambda x: x["ms"])
         algo = {v: k for k, v in ALGO_NAME.items()}[best["algo"]]
         comm.set_param("channels", best["channels"])
         comm.set_param("copy_engine", best["copy_engine"])
         comm.set_param("piece_bytes", best["piece_bytes"])
+        for k, v in best.get("params", {}).items():
+            comm.set_param(k, v)
     else:
         forced = a.algo if (a.algo not in ("zcopy", "zpush") or zc_ok) else "ring"
         algo = {v: k for k, v in ALGO_NAME.items()}[forced]
@@ -240,6 +281,8 @@ def rank_main(job: Job, grank: int):
         comm.set_param("channels", cand["channels"])
         comm.set_param("copy_engine", cand["copy_engine"])
         comm.set_param("piece_bytes", cand.get("piece_bytes", 0))
+        for k, v in cand.get("params", {}).items():
+            comm.set_param(k, v)
         comm.memset(recv, 0, nbytes)
         for _ in range(max(1, a.warmup)):
             run(algo)
@@ -308,13 +351,13 @@ def rank_main(job: Job, grank: int):
 
     # what the bytes actually cross: only ranks on DIFFERENT devices talk over xGMI (a multi-process rehearsal on
     # one GPU does not, whatever --gpus says)
-    ndev_used = len({job.device_of(r) for r in range(R)})
     transport = ("xGMI (one rank per GPU)" if ndev_used == R else
                  "intra-HBM (all ranks share one GPU)" if ndev_used == 1 else f"mixed: {R} ranks on {ndev_used} GPUs (intra-HBM + xGMI)")
-    out = {"transport": transport, "devices": ndev_used, "dsync": comm.get_param("dsync"), "t_step": t_step, "prof": prof, "tune": tune, "best": best, "best_ring": best_ring, "parity": parity,
+    out = {"link": link, "transport": transport, "devices": ndev_used, "dsync": comm.get_param("dsync"), "t_step": t_step, "prof": prof, "tune": tune, "best": best, "best_ring": best_ring, "parity": parity,
            "algo": algo, "nbytes": nbytes, "count": count, "iso": iso, "parity_failures": parity_failures,
            "shared_stream": comm.get_param("shared_stream"), "slot_bytes": comm.get_param("slot_bytes"),
-           "zero_copy_probe": "ok" if zc_ok else "failed: staged schedules only"}
+           "zero_copy_probe": {"dsync": "ok: ranks meet on the device", "host": "device rendezvous failed, host rendezvous ok",
+                               "failed": "failed: staged schedules only", "not run": "ok"}[job.probe] if zc_ok else "failed: staged schedules only"}
 
     # ---- untimed extras: what the next round needs to tune blind multi-GPU runs -----------------------
     extras = {}
@@ -323,6 +366,8 @@ def rank_main(job: Job, grank: int):
             comm.set_param("channels", cand["channels"])
             comm.set_param("copy_engine", cand["copy_engine"])
             comm.set_param("piece_bytes", cand.get("piece_bytes", 0))
+            for k, v in cand.get("params", {}).items():
+                comm.set_param(k, v)
 
         extras["algos_at_size"] = {}
         for al in (xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_DIRECT) + (ZC_ALGOS if zc_ok else ()):
@@ -457,25 +502,8 @@ def rank_main(job: Job, grank: int):
             extras["cfg5_allreduce_f16_sweep"] = {"ranks": R, "iterations": 5, "rows": rows5}
             for b in (s5, r5, ref5):
                 b.free()
-        # link probe between rank 0 and the first rank living on another GPU (xGMI), both engines
-        dev0 = job.device_of(0)
-        other = next((r for r in range(R) if (r * a.gpus // R if job.procs == 1 else r // job.ranks_per_proc) != 0), None)
-        if other is not None and a.gpus > 1:
-            probe = {}
-            for eng, name in ((0, "hipMemcpyAsync"), (1, "copy_kernel")):
-                comm.barrier()
-                if grank == 0:
-                    probe[name + "_write_GBps"] = comm.link_probe(other, 64 << 20, eng, 10, 0)
-                    probe[name + "_read_GBps"] = comm.link_probe(other, 64 << 20, eng, 10, 1)
-                comm.barrier()
-                if grank in (0, other):  # both directions at once
-                    peer = other if grank == 0 else 0
-                    v = comm.link_probe(peer, 64 << 20, eng, 10, 0)
-                    if grank == 0:
-                        probe[name + "_bidir_each_GBps"] = v
-                comm.barrier()
-            extras["xgmi_link_probe"] = {"between_ranks": [0, other], **probe}
-            del dev0
+        if link is not None:
+            extras["xgmi_link_probe"] = link
     out["extras"] = extras
     with job.lock:
         job.result[grank] = out
@@ -584,21 +612,25 @@ def probe_rank(job: Job, grank: int):
         raise AssertionError(f"rank {grank}: zero-copy probe failed (staged fallbacks: {went_staged})")
 
 
-def probe_zero_copy(job: Job) -> bool:
-    """The zero-copy kernels load and store through xGMI-mapped peer memory.  On a node this code has not run
-    on before, try that in a job of its own (child processes): if it faults, hangs or gives wrong bits, this
-    run keeps to the staged schedules instead of dying without a result."""
-    env = dict(os.environ, XMPI_BENCH_KEY=job.key + "-probe", XMPI_TIMEOUT_S="30")
-    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(job.args.gpus), "--ranks", str(job.ranks), "--probe"]
-    try:
-        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=150)
-    except subprocess.TimeoutExpired:
-        sys.stderr.write("[bench] zero-copy probe timed out: keeping to the staged schedules\n")
-        return False
-    if p.returncode != 0:
-        sys.stderr.write(f"[bench] zero-copy probe failed (exit {p.returncode}): keeping to the staged schedules\n"
-                         f"{(p.stdout or '')[-1500:]}\n")
-    return p.returncode == 0
+def probe_zero_copy(job: Job) -> str:
+    """The zero-copy kernels load and store through xGMI-mapped peer memory, and with one process per GPU the ranks
+    meet inside those kernels (flag words in HBM).  On a node this code has not run on before, try that in a job of
+    its own (child processes): if it faults, hangs or gives wrong bits, try again with the ranks meeting on the host
+    (XMPI_DSYNC=0); if that fails too, this run keeps to the staged schedules instead of dying without a result.
+    Returns "dsync" | "host" | "failed"."""
+    for attempt, extra in (("dsync", {}), ("host", {"XMPI_DSYNC": "0"})):
+        env = dict(os.environ, XMPI_BENCH_KEY=f"{job.key}-probe-{attempt}", XMPI_TIMEOUT_S="30", **extra)
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(job.args.gpus), "--ranks", str(job.ranks), "--probe"]
+        try:
+            p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=150)
+        except subprocess.TimeoutExpired:
+            sys.stderr.write(f"[bench] zero-copy probe ({attempt}) timed out\n")
+            continue
+        if p.returncode == 0:
+            return attempt
+        sys.stderr.write(f"[bench] zero-copy probe ({attempt}) failed (exit {p.returncode}):\n{(p.stdout or '')[-1500:]}\n")
+    sys.stderr.write("[bench] keeping to the staged schedules\n")
+    return "failed"
 
 
 def main():
@@ -614,8 +646,16 @@ def main():
         for g, tb in job.errors:
             sys.stderr.write(f"[probe] rank {g}:\n{tb}\n")
         sys.exit(1 if job.errors else 0)
+    # One OS process per rank on this box's GPU, before THIS process opens the GPU: a GPU schedules the queues of at most
+    # 8 processes at once, and a ninth (this one, with its rank threads) would have the other eight time-sliced
+    mp_sweep = None
+    if args.gpus == 1 and job.procs == 1 and not args.no_extras and not args.probe:
+        mp_sweep = multiprocess_sweep(job.ranks)
     if (args.gpus > 1 or job.procs > 1) and not args.no_probe:
-        job.zero_copy_ok = probe_zero_copy(job)
+        job.probe = probe_zero_copy(job)
+        job.zero_copy_ok = job.probe != "failed"
+        if job.probe == "host":
+            os.environ["XMPI_DSYNC"] = "0"  # the communicators of this run are created after this point
     threads = [threading.Thread(target=_guard, args=(job, g)) for g in job.my_ranks()]
     for t in threads:
         t.start()
@@ -638,6 +678,10 @@ def main():
         kname, launches, ms, by = ("zero-copy push pipeline: copy_batch_kernel (contributions into the peers' receive buffers) + "
                                    f"reduce_n_multi_kernel<float,SUM,{R}> (local rank-order fold) + copy_multi_kernel (results to "
                                    "all peers); bytes and time summed over the three"), nz, msz, bz
+    elif nz and msz >= max(ms2, msn) and r0["dsync"] == 1 and r0["best"].get("params", {}).get("dsync", 1) == 1:
+        kname, launches, ms, by = (f"dsync_fold_kernel<float,SUM,{R}> (one kernel per rank IS the allreduce: rendezvous through flag "
+                                   f"words in HBM, fold of chunk j of the {R} send buffers in rank order into the {R} receive buffers, "
+                                   "completion exchange; its duration includes waiting for the slowest peer)"), nz, msz, bz
     elif nz and msz >= max(ms2, msn):
         kname, launches, ms, by = (f"reduce_n_multi_kernel<float,SUM,{R}> (zero-copy allreduce: folds chunk j of the {R} send "
                                    f"buffers in rank order, stores it into the {R} receive buffers)"), nz, msz, bz
@@ -693,20 +737,26 @@ def main():
                    "shared_stream": bool(r0["shared_stream"]),
                    "transport": r0["transport"]},
         "algbw_GBps": algbw, "busbw_GBps": busbw, "ranks_meet": "on the device (dsync)" if r0["dsync"] == 1 else "on the host (control block)",
-        "xgmi": {"per_link_peak_GBps": XGMI_LINK_GBPS, "busbw_frac_of_link_peak": busbw / XGMI_LINK_GBPS,
-                 "meaningful": r0["devices"] == R},
+        # per rank 2(R-1)/R x S bytes leave (and arrive) per allreduce; the full-mesh schedules spread them over the R-1
+        # links of a GPU, a single ring puts them on one.  153 GB/s per link is both directions together (76.8 each way)
+        "xgmi": {"per_link_peak_GBps": XGMI_LINK_GBPS, "per_link_peak_each_direction_GBps": XGMI_LINK_GBPS / 2,
+                 "busbw_frac_of_link_peak": busbw / XGMI_LINK_GBPS,
+                 "wire_GBps_per_rank_each_direction": busbw,
+                 "wire_GBps_per_link_each_direction_if_spread_over_all_links": busbw / max(1, R - 1),
+                 "frac_of_one_link_direction_if_spread": busbw / max(1, R - 1) / (XGMI_LINK_GBPS / 2),
+                 "link_probe": r0["link"], "meaningful": r0["devices"] == R},
         "zero_copy_probe": r0["zero_copy_probe"] if (args.gpus > 1 or job.procs > 1) and not args.no_probe else "not run (1 GPU)",
         "roofline": roof, "roofline_isolated": r0["iso"], "other_kernels": others, "parity": r0["parity"], "parity_failures": r0["parity_failures"], "autotune": r0["tune"], "ring_best": r0["best_ring"],
         "extras": r0["extras"],
     }
     if args.gpus == 1 and not args.no_cpu and job.proc_rank == 0:
         line["cpu_baseline"] = cpu_baseline(R, args.cpu_count or r0["count"], args.cpu_reps)
-        if not args.no_extras and isinstance(line.get("extras"), dict):
-            line["extras"]["multiprocess_sweep"] = multiprocess_sweep(R)
         if isinstance(line.get("extras"), dict) and "bounce_sweep_u8" in line["extras"]:
             line["extras"]["cpu_reference_bounce_u8"] = cpu_bounce()  # same lengths, the reference path on the host
     else:
         line["cpu_baseline"] = None
+    if mp_sweep is not None and isinstance(line.get("extras"), dict):
+        line["extras"]["multiprocess_sweep"] = mp_sweep
     print(json.dumps(line))
     sys.stdout.flush()
 

@@ -11,17 +11,28 @@
 //     render nodes) -- "one rank owns one MI355X";
 //   * when ranks share a GPU (N > G) each copy is limited to 2 hardware queues (GPU_MAX_HW_QUEUES, unless set);
 //   * every copy gets the same fresh job id (XMPI_JOB) so two jobs never meet in one control block;
-//   * the exit status is the worst child status (the reference drops it: gompirun.go:89).
+//   * the exit status is the worst child status (the reference drops it: gompirun.go:89);
+//   * SIGTERM / SIGINT / SIGHUP are passed on to the ranks.
 #include <dirent.h>
+#include <signal.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
 #include <string>
 #include <vector>
+
+// a launcher that is told to stop takes its ranks with it (a rank left behind keeps its GPU queue and memory)
+static pid_t g_kids[256];
+static int g_nkids = 0;
+static void forward_signal(int sig) {
+  for (int i = 0; i < g_nkids; i++)
+    if (g_kids[i] > 0) kill(g_kids[i], sig == SIGINT ? SIGINT : SIGTERM);
+}
 
 static int count_gpus() {
   if (const char* e = getenv("XMPI_NGPUS")) return atoi(e) > 0 ? atoi(e) : 1;
@@ -83,11 +94,16 @@ int main(int argc, char** argv) {
       _exit(127);
     }
     kids.push_back(pid);
+    if (g_nkids < 256) g_kids[g_nkids++] = pid;
   }
+  signal(SIGTERM, forward_signal);
+  signal(SIGINT, forward_signal);
+  signal(SIGHUP, forward_signal);
   int worst = 0;
   for (pid_t k : kids) {
     int st = 0;
-    if (waitpid(k, &st, 0) < 0) continue;
+    while (waitpid(k, &st, 0) < 0 && errno == EINTR) {
+    }
     int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
     if (code > worst) worst = code;
   }

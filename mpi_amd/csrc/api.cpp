@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -26,6 +27,16 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
   (void)hipGetLastError();
   return XMPI_ERR_HIP;
 }
+
+// XMPI_TRACE=1: one line per bootstrap step on stderr (where does a rank that hangs in Init hang?)
+static bool trace_on() {
+  static const bool on = getenv("XMPI_TRACE") && atoi(getenv("XMPI_TRACE")) != 0;
+  return on;
+}
+#define XMPI_TRACE_STEP(rank, what)                                                                          \
+  do {                                                                                                       \
+    if (::xmpi::trace_on()) fprintf(stderr, "[xmpi %d %.6f] %s\n", (rank), ::xmpi::now_seconds(), (what)); \
+  } while (0)
 
 static long env_long(const char* name, long dflt) {
   const char* v = getenv(name);
@@ -148,19 +159,24 @@ struct PooledBlock {
   bool in_use;
   bool have_handle;
   hipIpcMemHandle_t handle;
+  uint64_t mark;  // what the last user left behind for the next one (flag pages: the last epoch written into it)
 };
 static std::mutex g_pool_mu;
 static std::vector<PooledBlock> g_pool;
 
 // HBM that peers map: taken from the pool of blocks earlier communicators of this process left behind, or
 // allocated (kind 1: uncached / fine-grained, for flag words polled by kernels)
-void* pool_acquire(int device, size_t bytes, int kind) {
+void* pool_acquire(int device, size_t bytes, int kind, bool* fresh, uint64_t* mark) {
   std::lock_guard<std::mutex> g(g_pool_mu);
+  if (fresh) *fresh = false;
+  if (mark) *mark = 0;
   for (PooledBlock& b : g_pool)
     if (!b.in_use && b.device == device && b.bytes == bytes && b.kind == kind) {
       b.in_use = true;
+      if (mark) *mark = b.mark;
       return b.ptr;
     }
+  if (fresh) *fresh = true;
   void* p = nullptr;
   hipError_t e;
   if (kind == 1) {
@@ -213,22 +229,52 @@ hipError_t pool_handle(void* ptr, void* handle_out) {
   return hipErrorInvalidValue;
 }
 
-void pool_release(void* ptr) {
+// Streams outlive communicators too.  Creating a stream's hardware queue while the GPU's queues are
+// oversubscribed (several processes on one GPU, a test runner holding a context of its own) made the FIRST operation
+// on a new stream take 17-32 SECONDS (lifecycle trace, profiles/README.md r02): a finalised communicator's streams go
+// back to a per-process pool instead of being destroyed.
+static std::mutex g_stream_mu;
+static std::vector<std::pair<int, hipStream_t>> g_stream_pool;
+
+hipStream_t stream_acquire(int device) {
+  {
+    std::lock_guard<std::mutex> g(g_stream_mu);
+    for (size_t i = 0; i < g_stream_pool.size(); i++)
+      if (g_stream_pool[i].first == device) {
+        hipStream_t s = g_stream_pool[i].second;
+        g_stream_pool.erase(g_stream_pool.begin() + (long)i);
+        return s;
+      }
+  }
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  return s;
+}
+
+void stream_release(int device, hipStream_t s) {
+  if (!s) return;
+  std::lock_guard<std::mutex> g(g_stream_mu);
+  g_stream_pool.push_back({device, s});
+}
+
+void pool_release(void* ptr, uint64_t mark) {
   std::lock_guard<std::mutex> g(g_pool_mu);
   for (PooledBlock& b : g_pool)
-    if (b.ptr == ptr) b.in_use = false;
+    if (b.ptr == ptr) {
+      b.in_use = false;
+      b.mark = mark;
+    }
 }
 
 // the per-peer / batch streams of the staged schedules (engine.cpp), created on first use
 int ensure_streams(xmpi_comm* c) {
   if (c->shared_stream || c->staged_streams) return XMPI_OK;
-  XMPI_HIP(hipStreamCreateWithFlags(&c->batch_send_stream, hipStreamNonBlocking));
-  XMPI_HIP(hipStreamCreateWithFlags(&c->batch_recv_stream, hipStreamNonBlocking));
-  for (int p = 0; p < c->size; p++) {
+  bool ok = (c->batch_send_stream = stream_acquire(c->device)) && (c->batch_recv_stream = stream_acquire(c->device));
+  for (int p = 0; p < c->size && ok; p++) {
     if (p == c->rank) continue;
-    XMPI_HIP(hipStreamCreateWithFlags(&c->send_stream[p], hipStreamNonBlocking));
-    XMPI_HIP(hipStreamCreateWithFlags(&c->recv_stream[p], hipStreamNonBlocking));
+    ok = (c->send_stream[p] = stream_acquire(c->device)) && (c->recv_stream[p] = stream_acquire(c->device));
   }
+  if (!ok) return hip_fail(hipGetLastError(), "hipStreamCreate", __FILE__, __LINE__);
   c->staged_streams = true;
   return XMPI_OK;
 }
@@ -469,6 +515,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   // compute for minutes before it posts its Receive); tests set it so a bug shows up as an error, not a hang.
   const double timeout = (double)env_long("XMPI_INIT_TIMEOUT_S", 60);
 
+  XMPI_TRACE_STEP(rank, "init: joining the control block");
   std::string key = (job_key && *job_key) ? job_key : "default";
   std::string err;
   Ctl* ctl = nullptr;
@@ -477,6 +524,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
     set_last_error("xmpi_init: " + err);
     return rc;
   }
+  XMPI_TRACE_STEP(rank, "init: joined");
   xmpi_comm* c = new xmpi_comm;
   c->rank = rank;
   c->size = size;
@@ -507,11 +555,13 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
 
   auto fail = [&](int code) {
     ctl->set_abort(code);
+    dsync_stop_helper(c);  // (it reads the control block)
     delete ctl;
     delete c;
     return code;
   };
-  c->window = (char*)pool_acquire(device, c->window_bytes, 0);
+  XMPI_TRACE_STEP(rank, "init: window");
+  c->window = (char*)pool_acquire(device, c->window_bytes, 0, nullptr, nullptr);
   if (!c->window) {
     hip_fail(hipGetLastError(), "hipMalloc(window)", __FILE__, __LINE__);
     return fail(XMPI_ERR_NOMEM);
@@ -531,20 +581,25 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
     static_assert(sizeof(h) <= sizeof(me->ipc_handle), "ipc handle size");
     memcpy(me->ipc_handle, &h, sizeof h);
   }
+  XMPI_TRACE_STEP(rank, "init: stream");
   // this rank's stream, before anything is enqueued anywhere (the null stream would cost a second hardware queue)
-  if (hipStreamCreateWithFlags(&c->local_stream, hipStreamNonBlocking) != hipSuccess) {
+  c->local_stream = stream_acquire(device);
+  if (!c->local_stream) {
     hip_fail(hipGetLastError(), "hipStreamCreate", __FILE__, __LINE__);
     return fail(XMPI_ERR_HIP);
   }
   c->dsync = env_long("XMPI_DSYNC", 1) ? 1 : 0;
   c->dsync_grid_cap = std::max<long>(0, env_long("XMPI_DSYNC_GRID", 0));
+  XMPI_TRACE_STEP(rank, "init: flag page");
   (void)dsync_prepare(c);  // this rank's flag page (device-synchronised collectives), published with the window
+  XMPI_TRACE_STEP(rank, "init: published, waiting for the peers' windows");
   me->state.store(2, std::memory_order_release);
   rc = ctl->wait_all_state(2, timeout > 0 ? timeout : 3600.0);
   if (rc != XMPI_OK) {
     set_last_error("xmpi_init: a peer did not publish its HBM window");
     return fail(rc);
   }
+  XMPI_TRACE_STEP(rank, "init: mapping the peers' windows");
   const int mypid = (int)getpid();
   for (int p = 0; p < size; p++) {
     if (p == rank) {
@@ -592,15 +647,17 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
     }
     for (int p = 0; p < size; p++) c->send_stream[p] = c->recv_stream[p] = (p == rank) ? nullptr : s;
     (void)hipStreamSynchronize(c->local_stream);
-    (void)hipStreamDestroy(c->local_stream);
+    stream_release(device, c->local_stream);
     c->local_stream = c->batch_send_stream = c->batch_recv_stream = s;
   }
   // Otherwise ONE stream (made above); the per-peer streams of the staged schedules are made when a staged schedule
   // first runs (ensure_streams).  Every stream costs the process a hardware queue (the runtime multiplexes streams
   // over GPU_MAX_HW_QUEUES of them), and a GPU runs only a few dozen queues at once: 8 processes x 4 queues on one
   // GPU were time-sliced by the scheduler -- 22 ms per collective instead of 40 us (profiles/r02).
+  XMPI_TRACE_STEP(rank, "init: connecting flag pages");
   rc = dsync_connect(c);
   if (rc != XMPI_OK) return fail(rc);
+  XMPI_TRACE_STEP(rank, "init: final barrier");
   c->dsync_unroll = env_long("XMPI_DSYNC_UNROLL", c->dsync_sharers > 1 ? 1 : 2);
   if (hipMalloc((void**)&c->dev_words, 4 * sizeof(uint64_t)) != hipSuccess) {
     hip_fail(hipGetLastError(), "hipStreamCreate/hipMalloc", __FILE__, __LINE__);
@@ -612,6 +669,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
     return fail(rc);
   }
   heap_comm_created();
+  XMPI_TRACE_STEP(rank, "init: done");
   *out = c;
   return XMPI_OK;
 }
@@ -620,28 +678,31 @@ int xmpi_finalize(xmpi_comm* c) {
   if (!c) return XMPI_ERR_STATE;
   if (c->finalized) return XMPI_OK;
   stop_worker(c);  // outstanding non-blocking collectives complete first
+  XMPI_TRACE_STEP(c->rank, "finalize: device sync");
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
+  XMPI_TRACE_STEP(c->rank, "finalize: barrier");
   // nobody may still be writing into a window that is about to be unmapped
   if (!c->ctl->aborted()) {
     Backoff bo;
     arm(bo, c);
     (void)c->ctl->barrier(wait_limit(c), &bo);
   }
+  XMPI_TRACE_STEP(c->rank, "finalize: closing");
   zc_close_peers(c);
   dsync_finalize(c);
   for (int p = 0; p < c->size; p++) {
     if (c->peer_opened[p]) ipc_close_shared(c->peer_window[p]);
     if (c->shared_stream) continue;  // the per-device shared stream outlives communicators
-    if (c->send_stream[p]) (void)hipStreamDestroy(c->send_stream[p]);
-    if (c->recv_stream[p]) (void)hipStreamDestroy(c->recv_stream[p]);
+    stream_release(c->device, c->send_stream[p]);
+    stream_release(c->device, c->recv_stream[p]);
   }
-  if (c->local_stream && !c->shared_stream) (void)hipStreamDestroy(c->local_stream);
+  if (!c->shared_stream) stream_release(c->device, c->local_stream);
   if (!c->shared_stream) {
-    if (c->batch_send_stream) (void)hipStreamDestroy(c->batch_send_stream);
-    if (c->batch_recv_stream) (void)hipStreamDestroy(c->batch_recv_stream);
+    stream_release(c->device, c->batch_send_stream);
+    stream_release(c->device, c->batch_recv_stream);
   }
-  for (hipStream_t s : c->p2p_streams) (void)hipStreamDestroy(s);
+  for (hipStream_t s : c->p2p_streams) stream_release(c->device, s);
   for (hipEvent_t e : c->ev_free) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev_timed_free) (void)hipEventDestroy(e);
   if (!c->ctl->aborted()) (void)c->ctl->barrier(wait_limit(c));
@@ -650,6 +711,7 @@ int xmpi_finalize(xmpi_comm* c) {
   if (c->host_stage) (void)hipFree(c->host_stage);
   if (c->dev_words) (void)hipFree(c->dev_words);
   heap_comm_destroyed(c);  // last communicator of the process: empty arenas go back to the device
+  XMPI_TRACE_STEP(c->rank, "finalize: done");
   c->ctl->info(c->rank)->state.store(3, std::memory_order_release);
   delete c->ctl;
   c->ctl = nullptr;

@@ -110,7 +110,8 @@ struct xmpi_comm {
   int dsync_sharers = 1;         // ranks of this job on this rank's GPU (bounds the grid: their kernels spin together)
   long dsync_grid_cap = 0;       // blocks per kernel; 0 = 1024 / sharers
   long dsync_unroll = 1;         // 16-byte packets per lane per source in flight (2 = deeper, for links)
-  uint64_t dsync_epoch = 0;      // kernels launched so far: the same number on every rank
+  uint64_t dsync_epoch = 0;      // epoch of the last kernel launched: the same number on every rank
+  uint64_t dsync_tag = 1;        // tags this communicator's entries in the (pooled, uncleared) page's translation cache
   uint64_t dsync_launches = 0, dsync_bounced = 0;  // diagnostics: kernels; buffers stood in for by arena blocks
   xmpi::DsyncEntry* dsync_table = nullptr;            // [kMaxRanks][kDsyncArenas], pinned host memory the kernels read
   const xmpi::DsyncEntry* dsync_table_dev = nullptr;  // ... as the GPU addresses it
@@ -194,13 +195,16 @@ bool registry_alive(uint64_t gen);
 // process across communicators (exported memory is not given back by the runtime while the processes live)
 hipError_t ipc_open_shared(int owner_pid, uint64_t owner_addr, const void* handle_bytes, void** out);
 void ipc_close_shared(void* ptr);
-void* pool_acquire(int device, size_t bytes, int kind);
-void pool_release(void* ptr);
+void* pool_acquire(int device, size_t bytes, int kind, bool* fresh, uint64_t* mark);
+void pool_release(void* ptr, uint64_t mark = 0);
 hipError_t pool_handle(void* ptr, void* handle_out);
+hipStream_t stream_acquire(int device);
+void stream_release(int device, hipStream_t s);
 // dsync.cpp
 int dsync_prepare(xmpi_comm* c);
 int dsync_connect(xmpi_comm* c);
 void dsync_finalize(xmpi_comm* c);
+void dsync_stop_helper(xmpi_comm* c);
 void dsync_service(xmpi_comm* c);
 bool dsync_usable(const xmpi_comm* c);
 int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void* recvbuf, size_t count, int dtype,

@@ -18,7 +18,7 @@ constexpr int kMaxRanks = 16;
 constexpr int kMaxLanes = 4;
 constexpr int kMailEntries = 4;  // concurrent messages per ordered rank pair
 constexpr uint64_t kCtlMagic = 0x584D504943544C31ull;  // "XMPICTL1"
-constexpr uint32_t kCtlVersion = 5;  // layout of the block: bump with every change of the structs below
+constexpr uint32_t kCtlVersion = 6;  // layout of the block: bump with every change of the structs below
 
 struct alignas(64) Counter {
   std::atomic<uint64_t> v;
@@ -73,6 +73,7 @@ struct alignas(64) RankInfo {
   uint8_t ipc_handle[64];  // hipIpcMemHandle_t of the window
   char busid[32];
   uint64_t flag_addr;       // this rank's flag page (uncached HBM; device-synchronised collectives), 0 = none
+  uint64_t flag_epoch;      // the highest epoch an earlier communicator left in that (pooled, never cleared) page
   uint8_t flag_handle[64];  // its hipIpcMemHandle_t
 };
 

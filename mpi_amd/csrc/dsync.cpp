@@ -48,21 +48,27 @@ int dsync_prepare(xmpi_comm* c) {
   me->flag_addr = 0;
   if (c->size < 2 || !c->dsync) return XMPI_OK;
   // uncached HBM: the page is polled by this GPU and written by the others; it must never sit in an L2.
-  // (From the per-process pool: exported memory outlives communicators -- api.cpp.)
-  void* page = pool_acquire(c->device, kPageBytes, 1);
+  // From the per-process pool (exported memory outlives communicators -- api.cpp), and NOT cleared when it is
+  // re-used: clearing is GPU work on a page seven other processes have mapped, and in a crowded GPU (eight ranks
+  // plus a test runner with a context of its own) that one 64 KiB fill took 10-50 s.  Instead the epochs of the new
+  // communicator start above everything an earlier one may have left in any rank's page (flag_epoch, dsync_connect).
+  bool fresh = false;
+  uint64_t last_epoch = 0;
+  void* page = pool_acquire(c->device, kPageBytes, 1, &fresh, &last_epoch);
   if (!page) {
     (void)hipGetLastError();
     return XMPI_OK;  // no such memory here: every rank sees flag_addr == 0 and keeps to the host-synchronised path
   }
-  if (hipMemsetAsync(page, 0, kPageBytes, c->local_stream) != hipSuccess || hipStreamSynchronize(c->local_stream) != hipSuccess) {
+  if (fresh && (hipMemsetAsync(page, 0, kPageBytes, c->local_stream) != hipSuccess || hipStreamSynchronize(c->local_stream) != hipSuccess)) {
     (void)hipGetLastError();
-    pool_release(page);
+    pool_release(page, last_epoch);
     return XMPI_OK;
   }
+  me->flag_epoch = last_epoch;
   hipIpcMemHandle_t h;
   if (pool_handle(page, &h) != hipSuccess) {
     (void)hipGetLastError();
-    pool_release(page);
+    pool_release(page, last_epoch);
     return XMPI_OK;
   }
   c->dpage = (DsyncPage*)page;
@@ -130,6 +136,12 @@ int dsync_connect(xmpi_comm* c) {
   // Every block of the kernel spins until the peers' kernels have started: the kernels of all ranks on this GPU
   // must be resident at once, in at most half of its 8192 wave slots (4 waves per block).
   c->dsync_sharers = std::max(1, sharers);
+  // epochs of this communicator: above whatever earlier communicators left in ANY rank's (pooled, uncleared) page;
+  // the same number on every rank.  It also tags the translations this communicator's kernels cache in the page.
+  uint64_t base = 0;
+  for (int p = 0; p < N; p++) base = std::max(base, c->ctl->info(p)->flag_epoch);
+  c->dsync_epoch = base;
+  c->dsync_tag = base + 1;
   c->dsync_ok = true;
   // A rank must map what its peers register even while its own threads are blocked somewhere the library cannot
   // see (a hipStreamSynchronize of the caller's, a long computation): a helper looks once a millisecond -- one load
@@ -147,11 +159,15 @@ int dsync_connect(xmpi_comm* c) {
   return XMPI_OK;
 }
 
-void dsync_finalize(xmpi_comm* c) {
+void dsync_stop_helper(xmpi_comm* c) {
   if (c->dsync_helper.joinable()) {
     c->dsync_helper_stop.store(true, std::memory_order_release);
     c->dsync_helper.join();
   }
+}
+
+void dsync_finalize(xmpi_comm* c) {
+  dsync_stop_helper(c);
   for (int p = 0; p < c->size; p++)
     if (c->peer_page_opened[p]) ipc_close_shared(c->peer_page[p]);
   if (c->dsync_ctl_registered) (void)hipHostUnregister(c->ctl->base());
@@ -163,7 +179,7 @@ void dsync_finalize(xmpi_comm* c) {
     for (void* p : b.bufs) (void)heap_free(p);
   }
   c->dsync_deferred.clear();
-  if (c->dpage) pool_release(c->dpage);
+  if (c->dpage) pool_release(c->dpage, c->dsync_epoch);  // the next user of the page starts above this
   c->dpage = nullptr;
   (void)hipGetLastError();
 }
@@ -411,6 +427,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
   a.recv_off = r.rref.offset;
   a.recv_slot = (uint64_t)rslot;
   a.table = c->dsync_table_dev;
+  a.tag = c->dsync_tag;
   a.my_send = r.send;
   a.my_recv = r.recv;
   a.abort_word = c->dsync_abort_dev;

@@ -650,9 +650,7 @@ hipStream_t p2p_stream_get(xmpi_comm* c) {
     c->p2p_streams.pop_back();
     return s;
   }
-  hipStream_t s = nullptr;
-  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-  return s;
+  return stream_acquire(c->device);
 }
 
 void p2p_stream_put(xmpi_comm* c, hipStream_t s) {

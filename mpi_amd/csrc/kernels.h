@@ -79,7 +79,8 @@ struct DsyncSlot {
 };
 struct DsyncEntry {  // a peer's registration number -> where this process mapped that allocation
   uint64_t gen;      // 0 = free
-  uint64_t base, bytes, pad;
+  uint64_t base, bytes;
+  uint64_t tag;      // cache entries only: the communicator that wrote it (DsyncArgs::tag)
 };
 // One per rank, in that rank's HBM, allocated uncached (never held in an L2): polled by the owner, written by peers.
 struct DsyncPage {
@@ -110,6 +111,7 @@ struct DsyncArgs {
   uint64_t send_slot, recv_slot;
   const void* my_send;
   void* my_recv;
+  uint64_t tag;               // of this communicator: cache entries written under another tag are somebody else's
   const DsyncEntry* table;    // [kDsyncRanks][kDsyncArenas] in pinned host memory, written by the host (dsync_service)
   const int32_t* abort_word;  // host memory the GPU can read (the job's abort flag), may be null
   uint32_t* status;           // host memory the GPU can write: first failure (DsyncStatus), may be null

@@ -761,7 +761,8 @@ __device__ uint64_t dsync_translate(const DsyncArgs& a, DsyncPage* mine, int pee
   if (gen == 0 || slot >= (uint64_t)kDsyncArenas) return 0;
   DsyncEntry* c = &mine->cache[peer][slot];
   uint64_t base, bytes;
-  if (__hip_atomic_load(&c->gen, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+  if (__hip_atomic_load(&c->gen, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen &&
+      __hip_atomic_load(&c->tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.tag) {
     base = __hip_atomic_load(&c->base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     bytes = __hip_atomic_load(&c->bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
@@ -770,8 +771,11 @@ __device__ uint64_t dsync_translate(const DsyncArgs& a, DsyncPage* mine, int pee
     base = __hip_atomic_load(&h->base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     bytes = __hip_atomic_load(&h->bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // several blocks may do this at once: they all write the same values, the number last
+    __hip_atomic_store(&c->gen, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __hip_atomic_store(&c->base, base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&c->bytes, bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&c->tag, a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&c->gen, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
   return (off <= bytes) ? base + off : 0;

@@ -22,7 +22,10 @@
 // (everyone's input is ready, everyone's output may be overwritten) -> kernel -> barrier (all
 // remote reads of my input and writes of my output have completed).
 #include <dirent.h>
+#include <signal.h>
 #include <unistd.h>
+
+#include <cerrno>
 
 #include <algorithm>
 #include <atomic>
@@ -274,19 +277,19 @@ bool zc_import(xmpi_comm* c, int peer, const BufRef& ref, void** out) {
   return true;
 }
 
+// A communicator is being finalised.  The mappings of its peers' allocations are NOT closed: other communicators
+// of this process may address the same peers through them (arenas outlive communicators), and closing and
+// re-opening mappings while other processes do the same is exactly what fails sporadically on this stack
+// ("invalid device pointer").  They go when their allocation is retired (drop_retired) or their owner is gone.
 void zc_close_peers(const xmpi_comm* c) {
-  const int mypid = (int)getpid();
+  (void)c;
   std::lock_guard<std::mutex> g(g_map_mu);
-  for (int p = 0; p < c->size; p++) {
-    const int pid = c->ctl->info(p)->pid;
-    if (pid == mypid) continue;
-    for (size_t i = 0; i < g_maps.size();) {
-      if (g_maps[i].pid == pid) {
-        (void)hipIpcCloseMemHandle(g_maps[i].ptr);
-        g_maps.erase(g_maps.begin() + (long)i);
-      } else {
-        i++;
-      }
+  for (size_t i = 0; i < g_maps.size();) {
+    if (kill(g_maps[i].pid, 0) != 0 && errno == ESRCH) {
+      (void)hipIpcCloseMemHandle(g_maps[i].ptr);
+      g_maps.erase(g_maps.begin() + (long)i);
+    } else {
+      i++;
     }
   }
   (void)hipGetLastError();

@@ -15,6 +15,7 @@ def run_ranks(scenario: str, size: int, args: dict | None = None, timeout: float
     e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     e.setdefault("XMPI_TIMEOUT_S", "60")
     e.setdefault("GPU_MAX_HW_QUEUES", "2")  # the ranks of a test share one GPU and its hardware queues (see launcher/xmpirun.cpp)
+    e.setdefault("XMPI_TEST_DUMP_AFTER", str(max(30.0, timeout - 30.0)))  # a rank that hangs says where before it is killed
     e.update(env or {})
     procs = []
     for r in range(size):
@@ -46,28 +47,14 @@ def run_ranks(scenario: str, size: int, args: dict | None = None, timeout: float
     return outs
 
 
-def run_threads(scenario: str, size: int, args: dict | None = None):
-    """All ranks as threads of THIS process (pid-equal peers share pointers instead of hipIpc)."""
-    from mpi_amd import xmpi
-    from tests import scenarios
-    key = f"th{os.getpid()}-{uuid.uuid4().hex[:8]}"
-    errors = []
-
-    def body(r):
-        try:
-            comm = xmpi.Comm(r, size, (args or {}).get("device", -1), key)
-            for k, v in (args or {}).get("params", {}).items():
-                comm.set_param(k, v)
-            scenarios.SCENARIOS[scenario](comm, args or {})
-            comm.barrier()
-            comm.finalize()
-        except BaseException as e:  # noqa: BLE001
-            import traceback
-            errors.append((r, traceback.format_exc()))
-
-    ts = [threading.Thread(target=body, args=(r,)) for r in range(size)]
-    for t in ts:
-        t.start()
-    for t in ts:
-        t.join()
-    assert not errors, "\n".join(f"rank {r}:\n{tb}" for r, tb in errors)
+def run_threads(scenario: str, size: int, args: dict | None = None, timeout: float = 600.0):
+    """All ranks as threads of ONE process (pid-equal peers share pointers instead of hipIpc) -- a child process, not
+    the test runner: a GPU schedules the queues of at most 8 processes at once (8 compute VMIDs), so a runner that held
+    a HIP context of its own would make every 8-process test the 9th process' problem (time-sliced: ~25 s per
+    communicator lifetime instead of 0.15 s, measured with tests/test_gpu_collectives.py::test_lifecycle_stress)."""
+    e = dict(os.environ)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    e.setdefault("XMPI_TIMEOUT_S", "60")
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "rank_worker.py"), "--threads", scenario, str(size), json.dumps(args or {})]
+    p = subprocess.run(cmd, cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
+    assert p.returncode == 0, f"scenario {scenario} with {size} rank threads failed\n{p.stdout[-6000:]}"

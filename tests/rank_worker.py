@@ -8,8 +8,47 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def threads_main():
+    """python tests/rank_worker.py --threads <scenario> <size> [json]: every rank a thread of this process"""
+    import threading
+    import uuid
+    name, size = sys.argv[2], int(sys.argv[3])
+    args = json.loads(sys.argv[4]) if len(sys.argv) > 4 else {}
+    from mpi_amd import xmpi
+    from tests import scenarios
+    key = f"th{os.getpid()}-{uuid.uuid4().hex[:8]}"
+    errors = []
+
+    def body(r):
+        try:
+            comm = xmpi.Comm(r, size, args.get("device", -1), key)
+            for k, v in args.get("params", {}).items():
+                comm.set_param(k, v)
+            scenarios.SCENARIOS[name](comm, args)
+            comm.barrier()
+            comm.finalize()
+        except BaseException:  # noqa: BLE001
+            errors.append((r, traceback.format_exc()))
+
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(size)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errors:
+        print("\n".join(f"rank {r}:\n{tb}" for r, tb in errors))
+        sys.stdout.flush()
+        os._exit(1)
+    print(f"{size} rank threads {name}: ok")
+
+
 def main():
+    if sys.argv[1] == "--threads":
+        return threads_main()
     name, rank, size, key = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    if os.environ.get("XMPI_TEST_DUMP_AFTER"):  # where is a rank that hangs?  (python stacks of all its threads)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["XMPI_TEST_DUMP_AFTER"]), exit=False)
     args = json.loads(sys.argv[5]) if len(sys.argv) > 5 else {}
     from mpi_amd import xmpi
     from tests import scenarios

@@ -785,6 +785,7 @@ def sc_lifecycle_stress(comm, args):
     rank, size = comm.rank(), comm.size()
     rnd = random.Random(1234 + rank)
     base = args.get("key", "life")
+    t_start = time.time()
     for it in range(args.get("iters", 50)):
         c2 = xmpi.Comm(rank, size, comm.device(), f"{base}-{it}")
         c2.set_param("copy_engine", 1)
@@ -796,7 +797,7 @@ def sc_lifecycle_stress(comm, args):
         time.sleep(rnd.random() * 0.004)  # ranks reach finalize at different times
         c2.finalize()
         if args.get("verbose") and rank == 0 and it % 5 == 0:
-            print(f"lifetime {it}: {comm.get_param('hbm_free_mib')} MiB of HBM free", flush=True)
+            print(f"lifetime {it}: {comm.get_param('hbm_free_mib')} MiB of HBM free, {time.time() - t_start:.2f} s so far", flush=True)
 
 
 SCENARIOS = {

@@ -55,6 +55,9 @@ def test_bench_extras_tables():
     assert {x["bytes"] for x in rows if x["ranks"] == 8} == {1 << 10, 1 << 12, 1 << 14, 1 << 16, 1 << 18, 1 << 20, 1 << 22, 1 << 24}
     c3 = d["extras"]["cfg3_allgather_i64_16MiB_4ranks"]
     assert c3["ranks"] == 4 and c3["auto"]["ms"] > 0 and c3["ring"]["ms"] > 0
+    mp = d["extras"]["multiprocess_sweep"]  # eight PROCESSES on this GPU, meeting on the device
+    assert mp["ranks"] == 8 and mp["exact"] is True and "device" in mp["meet"], mp
+    assert mp["rows"][0]["bytes"] == 1024 and mp["rows"][0]["queued_us"] < 1000, mp["rows"][0]
 
 
 def test_coll_sweep_one_process_per_rank():

@@ -95,8 +95,8 @@ def test_device_sync_disabled_by_env():
 def test_lifecycle_stress(size):
     """200 / 80 communicator lifetimes with the copy kernel as transport: init -> collectives -> finalize at each
     rank's own pace (the one unexplained GPU fault of round 1 was in this configuration)"""
-    run_ranks("lifecycle_stress", size, {"iters": 200 if size == 2 else 80}, timeout=900,
-              env={"XMPI_COPY_ENGINE": "1", "XMPI_BATCH_COPIES": "1"})
+    run_ranks("lifecycle_stress", size, {"iters": 200 if size == 2 else 80}, timeout=300,
+              env={"XMPI_COPY_ENGINE": "1", "XMPI_BATCH_COPIES": "1", "XMPI_TEST_DUMP_AFTER": "200", "XMPI_TRACE": "1"})
 
 
 @pytest.mark.parametrize("size", [2, 5])
