@@ -234,7 +234,8 @@ int xmpi_stream_sync(xmpi_comm* comm, void* stream);
 
 /* The same allreduce `iters` times back to back: the step loop of a benchmark without per-call
  * host-language overhead (bench.py hosts several ranks as Python threads, which would otherwise
- * queue for the interpreter lock between steps; a Go or C++ caller has no such cost). */
+ * queue for the interpreter lock between steps; a Go or C++ caller has no such cost).  With one process
+ * per GPU the steps are enqueued on the communicator's stream and waited for once at the end. */
 int xmpi_allreduce_repeat(xmpi_comm* comm, const void* sendbuf, void* recvbuf, size_t count,
                           xmpi_dtype dtype, xmpi_op op, int algo, int iters);
 

@@ -1046,6 +1046,24 @@ int xmpi_request_wait(xmpi_request* r) {
 int xmpi_allreduce_repeat(xmpi_comm* c, const void* sendbuf, void* recvbuf, size_t count, xmpi_dtype dtype, xmpi_op op,
                           int algo, int iters) {
   XMPI_ENTER(c);
+  // Ranks that meet on the device: the steps are ENQUEUED back to back on the communicator's stream and waited for
+  // once -- what a stream-ordered caller does, and what the device rendezvous is for (no host round trip per
+  // step).  Launches that are sampled for profiling stay blocking: their events are read right after them.
+  const bool on_device = dsync_usable(c) && count > 0 && sendbuf && recvbuf && xmpi_dtype_size(dtype) &&
+                         (algo == XMPI_ALGO_ZCOPY || (algo == XMPI_ALGO_AUTO && c->zero_copy)) &&
+                         is_device_pointer(sendbuf) && is_device_pointer(recvbuf);
+  if (on_device) {
+    drain_worker(c);
+    std::lock_guard<std::mutex> g(c->coll_mu);
+    for (int i = 0; i < iters; i++) {
+      const bool sampled = c->prof_on && (c->prof_seq[PROF_ZCOPY] % (uint64_t)std::max<long>(1, c->prof_every)) == 0;
+      if (!sampled && c->prof_on) c->prof_seq[PROF_ZCOPY]++;  // (a blocking call counts itself)
+      const int rc = dsync_collective(c, COLL_ALLREDUCE, 0, sendbuf, recvbuf, count, (int)dtype, (int)op, c->local_stream,
+                                      /*blocking=*/sampled || i == iters - 1);
+      if (rc != XMPI_OK) return rc;
+    }
+    return XMPI_OK;
+  }
   for (int i = 0; i < iters; i++) {
     const int rc = collective(c, COLL_ALLREDUCE, algo, 0, sendbuf, recvbuf, count, (int)dtype, (int)op);
     if (rc != XMPI_OK) return rc;
@@ -1450,6 +1468,47 @@ int xmpi_ctl_selftest(const char* job_key, int rank, int size, int rounds) {
         good = lp->gen[j % kRetireRing] == (((uint64_t)p << 32) | j);
       if (!good) rc = XMPI_ERR_STATE;
     }
+    if (rc != XMPI_OK) break;
+    // device-synchronised collectives: a rank publishes a registration (slot k % 4), every peer reads it and
+    // acknowledges, and the owner goes on only when all have (dsync.cpp `publish` / `dsync_service` / `await_acks`)
+    PubTable* pt = ctl->published(rank);
+    const uint64_t n = pt->count.load(std::memory_order_relaxed);
+    PubEntry& pe = pt->e[n % kPubRing];
+    pe.gen = (uint64_t)k * 1000u + (uint64_t)rank;
+    pe.base = 0x200000u * (uint64_t)(rank + 1);
+    pe.bytes = (uint64_t)k << 20;
+    pe.reserved = (uint64_t)(k % 4);
+    for (size_t b = 0; b < sizeof pe.handle; b++) pe.handle[b] = (uint8_t)(b ^ (size_t)rank ^ (size_t)k);
+    pt->count.store(n + 1, std::memory_order_release);
+    bool mine_acked = false;
+    std::vector<uint64_t> seen((size_t)size, (uint64_t)(k - 1));
+    rc = wait_for([&] {
+      for (int p = 0; p < size; p++) {  // serve the peers while waiting for them, like every wait loop of the library
+        if (p == rank) continue;
+        PubTable* pp = ctl->published(p);
+        const uint64_t np = pp->count.load(std::memory_order_acquire);
+        while (seen[(size_t)p] < np) {
+          const PubEntry& e = pp->e[seen[(size_t)p] % kPubRing];
+          const uint64_t kk = seen[(size_t)p] + 1;  // entry number == round it was published in
+          if (e.gen != kk * 1000u + (uint64_t)p || e.base != 0x200000u * (uint64_t)(p + 1) || e.bytes != (kk << 20) ||
+              e.reserved != kk % 4 || e.handle[7] != (uint8_t)(7 ^ (size_t)p ^ (size_t)kk))
+            return true;  // corrupt entry: leave the wait, the check below fails
+          seen[(size_t)p]++;
+        }
+        ctl->acked(rank, p)->store(seen[(size_t)p], std::memory_order_release);
+      }
+      mine_acked = true;
+      bool served_all = true;  // (the library keeps serving from inside its barrier; here: stay until every peer's entry of this round is acknowledged)
+      for (int p = 0; p < size; p++) {
+        if (p == rank) continue;
+        if (ctl->acked(p, rank)->load(std::memory_order_acquire) < n + 1) mine_acked = false;
+        if (seen[(size_t)p] < n + 1) served_all = false;
+      }
+      return mine_acked && served_all;
+    });
+    if (rc == XMPI_OK && !mine_acked) rc = XMPI_ERR_STATE;
+    if (rc != XMPI_OK) break;
+    rc = ctl->barrier(30.0);  // nobody starts the next round's publication before everybody has checked this one
   }
   if (rc != XMPI_OK) ctl->set_abort(rc);
   else rc = ctl->barrier(30.0);

@@ -629,7 +629,17 @@ def sc_fullsize(comm, args):
     if which == "cfg4":  # allreduce-sum f32 256 MiB
         count, dtype = args.get("count", 67108864), xmpi.F32
     else:  # cfg5: fp16, exactly summable inputs (k/64) -> every algorithm bit-identical
-        count, dtype = args.get("count", 536870912), xmpi.F16
+        count = args.get("count", 536870912)
+        if count == "auto":  # the full 1 GiB per rank when the GPU(s) have room for every rank's three buffers, else 256 MiB
+            sharers = max(1, comm.get_param("dsync_sharers")) if comm.get_param("dsync") == 1 else size
+            need_mib = 3 * 1024 * sharers + 8192
+            count = 536870912 if comm.get_param("hbm_free_mib") >= need_mib else 134217728
+            # every rank must take the same size: agree on the smallest
+            agreed = np.array([count], dtype=np.int64)
+            out = np.zeros(1, dtype=np.int64)
+            comm.allreduce(agreed, out, 1, xmpi.I64, xmpi.MIN, xmpi.ALGO_DIRECT)
+            count = int(out[0])
+        dtype = xmpi.F16
     es = xmpi.DTYPE_SIZE[dtype]
     send = comm.alloc(count * es)
     ref = comm.alloc(count * es)
@@ -750,6 +760,12 @@ def sc_stream_ordered(comm, args):
     comm.allreduce(b, a, n, xmpi.F32, xmpi.MAX, xmpi.ALGO_AUTO)
     want = oracle.reduce_ranks([oracle.fill(n, xmpi.F32, xmpi.PAT_UNIFORM, 800 + r) for r in range(size)], xmpi.F32, xmpi.SUM)
     assert a.download(np.float32, n).tobytes() == want.tobytes()
+    # the same allreduce several times inside one call: with ranks that meet on the device the steps are enqueued
+    # back to back and waited for once (in place: every step folds the previous result, exact in int64)
+    comm.fill(a, n // 2, xmpi.I64, xmpi.PAT_CONST, rank)  # x_r = r + 1
+    comm.allreduce_repeat(a, a, n // 2, xmpi.I64, xmpi.SUM, xmpi.ALGO_AUTO, 4)
+    want_rep = np.full(n // 2, (size * (size + 1) // 2) * size ** 3, dtype=np.int64)
+    assert a.download(np.int64, n // 2).tobytes() == want_rep.tobytes(), "allreduce_repeat"
     a.free()
     b.free()
     if dsync:

@@ -152,6 +152,7 @@ def test_cfg4_allreduce_f32_full():
 
 
 def test_cfg5_allreduce_f16_large():
-    """BASELINE cfg 5: fp16 allreduce, ring vs recursive halving, exactly-summable inputs.
-    256 MiB per rank here (8 ranks share one GPU on the test box); bench.py runs the 1 GiB size."""
-    run_ranks("fullsize", 8, {"which": "cfg5", "count": 134217728}, timeout=900)
+    """BASELINE cfg 5: fp16 allreduce, ring vs recursive halving, exactly-summable inputs, at the FULL 1 GiB per rank
+    whenever the GPU(s) have room for every rank's three buffers (one MI355X has: 8 ranks x 3 GiB of its 288),
+    otherwise 256 MiB per rank."""
+    run_ranks("fullsize", 8, {"which": "cfg5", "count": "auto"}, timeout=900)
