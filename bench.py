@@ -237,8 +237,9 @@ def rank_main(job: Job, grank: int):
             if dsync_can:
                 cands.append((xmpi.ALGO_ZCOPY, 1, 0, {"dsync": 1, "dsync_unroll": 1}))
                 cands.append((xmpi.ALGO_ZCOPY, 1, 0, {"dsync": 1, "dsync_unroll": 2}))
+                cands.append((xmpi.ALGO_ZPUSH, 1, 0, {"dsync": 1}))  # only WRITES over xGMI: push, local fold, push back
                 cands.append((xmpi.ALGO_ZCOPY, 1, 0, {"dsync": 0}))
-                cands.append((xmpi.ALGO_ZPUSH, 1, 0, {"dsync": 0}))  # only WRITES over xGMI (3 kernels, host barriers)
+                cands.append((xmpi.ALGO_ZPUSH, 1, 0, {"dsync": 0}))  # ... the same with host barriers between the kernels
             else:
                 cands.append((xmpi.ALGO_ZCOPY, 1, 0, {}))
                 cands.append((xmpi.ALGO_ZPUSH, 1, 0, {}))

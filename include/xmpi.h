@@ -54,8 +54,9 @@ typedef enum {
                            buffers (rank order) and stores straight into them; no staging  */
   XMPI_ALGO_ZPUSH = 6,  /* zero-copy allreduce that only WRITES over xGMI: contributions are pushed
                            into the peers' receive buffers, folded locally (rank order), results
-                           pushed back; 3 kernels; out-of-place, count divisible by ranks x 16 B,
-                           otherwise (and for the other collectives) the same as ZCOPY       */
+                           pushed back; 3 kernels; out-of-place (on every rank or on none), count
+                           divisible by ranks x 16 B, otherwise (and for the other collectives)
+                           the same as ZCOPY                                                 */
   XMPI_ALGO_COUNT = 7
 } xmpi_algo;
 

@@ -379,8 +379,9 @@ static int collective(xmpi_comm* c, int coll, int algo, int root, const void* se
   // rank, enqueued on this communicator's stream, no host barrier.  Whether this path is taken depends on the
   // job's layout and the arguments only, so every rank decides alike; buffers the peers cannot map are stood in
   // for by registered arena blocks inside.
-  if (dsync_usable(c) && (algo == XMPI_ALGO_ZCOPY || (algo == XMPI_ALGO_AUTO && c->zero_copy)))
-    return dsync_collective(c, coll, root, sendbuf, recvbuf, count, dtype, op, c->local_stream, /*blocking=*/true);
+  if (dsync_usable(c) && (zc_algo || (algo == XMPI_ALGO_AUTO && c->zero_copy)))
+    return dsync_collective(c, coll, root, sendbuf, recvbuf, count, dtype, op, c->local_stream, /*blocking=*/true,
+                            /*push=*/algo == XMPI_ALGO_ZPUSH);
   if (c->size > 1 && (zc_algo || (algo == XMPI_ALGO_AUTO && c->zero_copy))) {
     bool done = false;
     int zrc = zero_copy_collective(c, coll, root, sendbuf, recvbuf, count, dtype, op, algo == XMPI_ALGO_ZPUSH, &done);
@@ -1050,7 +1051,7 @@ int xmpi_allreduce_repeat(xmpi_comm* c, const void* sendbuf, void* recvbuf, size
   // once -- what a stream-ordered caller does, and what the device rendezvous is for (no host round trip per
   // step).  Launches that are sampled for profiling stay blocking: their events are read right after them.
   const bool on_device = dsync_usable(c) && count > 0 && sendbuf && recvbuf && xmpi_dtype_size(dtype) &&
-                         (algo == XMPI_ALGO_ZCOPY || (algo == XMPI_ALGO_AUTO && c->zero_copy)) &&
+                         (algo == XMPI_ALGO_ZCOPY || algo == XMPI_ALGO_ZPUSH || (algo == XMPI_ALGO_AUTO && c->zero_copy)) &&
                          is_device_pointer(sendbuf) && is_device_pointer(recvbuf);
   if (on_device) {
     drain_worker(c);
@@ -1059,7 +1060,7 @@ int xmpi_allreduce_repeat(xmpi_comm* c, const void* sendbuf, void* recvbuf, size
       const bool sampled = c->prof_on && (c->prof_seq[PROF_ZCOPY] % (uint64_t)std::max<long>(1, c->prof_every)) == 0;
       if (!sampled && c->prof_on) c->prof_seq[PROF_ZCOPY]++;  // (a blocking call counts itself)
       const int rc = dsync_collective(c, COLL_ALLREDUCE, 0, sendbuf, recvbuf, count, (int)dtype, (int)op, c->local_stream,
-                                      /*blocking=*/sampled || i == iters - 1);
+                                      /*blocking=*/sampled || i == iters - 1, /*push=*/algo == XMPI_ALGO_ZPUSH);
       if (rc != XMPI_OK) return rc;
     }
     return XMPI_OK;

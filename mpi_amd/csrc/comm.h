@@ -208,7 +208,7 @@ void dsync_stop_helper(xmpi_comm* c);
 void dsync_service(xmpi_comm* c);
 bool dsync_usable(const xmpi_comm* c);
 int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void* recvbuf, size_t count, int dtype,
-                     int op, hipStream_t stream, bool blocking);
+                     int op, hipStream_t stream, bool blocking, bool push = false);
 int dsync_check(xmpi_comm* c);
 // a rank that waits keeps serving its peers
 inline void arm(Backoff& bo, xmpi_comm* c) {

@@ -357,7 +357,7 @@ int dsync_grid(const xmpi_comm* c, size_t packets_per_segment, int nseg, int unr
 // otherwise return once it is enqueued (xmpi_*_on_stream).  Every rank of the job takes this path for the same
 // calls (the decision depends on the communicator and the arguments only), so the epochs agree.
 int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void* recvbuf, size_t count, int dtype,
-                     int op, hipStream_t stream, bool blocking) {
+                     int op, hipStream_t stream, bool blocking, bool push) {
   const int N = c->size, me = c->rank;
   const size_t es = xmpi_dtype_size((xmpi_dtype)dtype);
   const size_t send_bytes = count * es;
@@ -453,7 +453,43 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     return XMPI_OK;
   };
 
-  if (coll == COLL_ALLREDUCE || coll == COLL_REDUCE) {
+  const bool use_push = push && coll == COLL_ALLREDUCE && r.send != r.recv && count % ((size_t)N * al) == 0;
+  if (use_push) {
+    // Write-only variant (XMPI_ALGO_ZPUSH): nothing is READ over xGMI -- loads over a link are round trips, stores are
+    // posted.  The receive buffer of rank q is its own staging area: region p (p != q) receives rank p's contribution
+    // to chunk q, region q is where q folds them in rank order; then every rank pushes its folded chunk to everybody.
+    // Two device-synchronised kernels with a plain local fold in between (when kernel 1 ends every peer's contribution
+    // has landed; kernel 3's rendezvous is every peer saying "my fold has read its staging regions").  Needs
+    // out-of-place buffers and equal chunks; otherwise the read-based form below runs.
+    const size_t C = count / (size_t)N, cb = C * es;
+    for (int q = 0; q < N; q++) {
+      if (q == me) continue;
+      DsyncSeg& g = a.seg[a.nseg++];
+      g.src_off = (size_t)q * cb;   // my contribution to chunk q ...
+      g.dst_off = (size_t)me * cb;  // ... into region `me` of rank q's receive buffer
+      g.count = cb;
+      g.src_mask = 1u << me;
+      g.dst_mask = 1u << q;
+    }
+    traffic = 2 * (size_t)(N - 1) * cb;
+    rc = launch(1, XMPI_U8, XMPI_SUM, cb / 16);
+    if (rc == XMPI_OK) {  // all operands of chunk `me` are local now: the rank-order fold is an ordinary kernel
+      const void* srcs[kMaxRanks];
+      for (int p = 0; p < N; p++) srcs[p] = (p == me) ? (const char*)r.send + (size_t)me * cb : (const char*)r.recv + (size_t)p * cb;
+      void* d1[1] = {(char*)r.recv + (size_t)me * cb};
+      XMPI_HIP(launch_reduce_n_multi(d1, 1, srcs, N, C, dtype, op, stream));
+      traffic += (size_t)(N + 1) * cb;
+      memset(a.seg, 0, sizeof a.seg);
+      a.nseg = 1;
+      a.seg[0].src_off = a.seg[0].dst_off = (size_t)me * cb;  // my folded chunk -> region `me` of everybody's receive buffer
+      a.seg[0].count = cb;
+      a.seg[0].src_mask = 1u << me;
+      a.seg[0].src_from_recv = 1;
+      a.seg[0].dst_mask = everyone & ~(1u << me);
+      traffic += (size_t)N * cb;
+      rc = launch(1, XMPI_U8, XMPI_SUM, cb / 16);
+    }
+  } else if (coll == COLL_ALLREDUCE || coll == COLL_REDUCE) {
     size_t off = 0, cnt = 0;
     zc_chunk(count, es, N, me, &off, &cnt);
     a.nseg = cnt > 0 ? 1 : 0;

@@ -99,6 +99,8 @@ struct DsyncSeg {
   uint64_t src_off, dst_off;  // byte offsets into the send / receive buffers
   uint64_t count;             // elements
   uint32_t src_mask, dst_mask;  // ranks whose SEND buffer is read / whose RECEIVE buffer is written
+  uint32_t src_from_recv;       // 1: the sources are the ranks' RECEIVE buffers (forwarding what a previous step put there)
+  uint32_t pad;
 };
 
 enum DsyncStatus : uint32_t { DSYNC_OK = 0, DSYNC_TIMEOUT = 1, DSYNC_ABORTED = 2, DSYNC_UNMAPPED = 3 };

@@ -857,7 +857,7 @@ __global__ __launch_bounds__(kBlock) void dsync_fold_kernel(DsyncArgs a) {
     if (t == 0) {  // this block's pointer lists
       int ns = 0, nd = 0;
       for (int r = 0; r < n; r++)
-        if (g.src_mask >> r & 1u) sh.src[ns++] = sh.send[r] + g.src_off;
+        if (g.src_mask >> r & 1u) sh.src[ns++] = (g.src_from_recv ? sh.recv[r] : sh.send[r]) + g.src_off;
       for (int d = 0; d < n; d++) {
         const int r = (me + d) % n;
         if (g.dst_mask >> r & 1u) sh.dst[nd++] = sh.recv[r] + g.dst_off;
