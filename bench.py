@@ -18,7 +18,8 @@ and `busbw_table` holds busbw against message size at 1 / 2 / 4 / 8 ranks (the o
 
 roofline: the dominant kernel of the timed region -- reduce_n_multi_kernel<float,SUM,8> on the zero-copy
 path (folds chunk j of the 8 send buffers in rank order and stores it into the 8 receive buffers:
-8 reads + 8 writes = 64 algorithmic bytes per f32 element), reduce2 / reduce_n on the staged schedules.
+8 reads + 8 writes = 64 algorithmic bytes per f32 element; with one process per GPU the same fold inside
+dsync_fold_kernel, which is also where the ranks meet), reduce2 / reduce_n on the staged schedules.
 Sampled launches inside the timed region carry HIP events attached to their dispatch (libxmpi's
 profiling hooks), on the stream the kernel runs on.  Before timing, the schedule is auto-tuned
 (zero-copy vs ring / halving / direct and their knobs) and only a candidate whose result matches the
@@ -108,6 +109,9 @@ class Job:
             # rehearsal of the multi-process launch on ONE GPU: its processes share that GPU's hardware queues, and
             # beyond a few dozen the scheduler time-slices them (22 ms per collective instead of 40 us)
             os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+        # a wait that makes no progress for two minutes is an error with a message, not a bench that never returns
+        # (the library's own default is to wait for ever, like the reference's blocking calls)
+        os.environ.setdefault("XMPI_TIMEOUT_S", "120")
         self.result = {}
         self.errors = []
         self.lock = threading.Lock()
@@ -392,7 +396,9 @@ def rank_main(job: Job, grank: int):
             row = {"bytes": sz}
             for al in (xmpi.ALGO_RING, xmpi.ALGO_DIRECT) + ZC:
                 run(al, cnt)
-                t = timed(comm, lambda: run(al, cnt), 5 if sz <= (16 << 20) else 2)
+                # inside one native call: what the library costs, not what 8 Python threads cost each other
+                t = timed(comm, None, 10 if sz <= (16 << 20) else 3,
+                          batch=lambda k, a2=al, c2=cnt: comm.allreduce_repeat(send, recv, c2, dtype, xmpi.SUM, a2, k))
                 row[ALGO_NAME[al] + "_us"] = t * 1e6
                 row[ALGO_NAME[al] + "_busbw_GBps"] = sz / t / 1e9 * 2 * (R - 1) / R
             sweep.append(row)
