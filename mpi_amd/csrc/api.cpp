@@ -660,6 +660,9 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   if (rc != XMPI_OK) return fail(rc);
   XMPI_TRACE_STEP(rank, "init: final barrier");
   c->dsync_unroll = env_long("XMPI_DSYNC_UNROLL", c->dsync_sharers > 1 ? 1 : 2);
+  // ranks sharing a GPU: fewer, longer blocks (8 processes on one MI355X: 4 MiB 170 -> 90 us, 16 MiB 231 -> 169 us);
+  // a rank with a GPU to itself keeps one tile per block -- over links more waves in flight is what hides latency
+  c->dsync_tiles = std::max<long>(1, env_long("XMPI_DSYNC_TILES", c->dsync_sharers > 1 ? 8 : 1));
   if (hipMalloc((void**)&c->dev_words, 4 * sizeof(uint64_t)) != hipSuccess) {
     hip_fail(hipGetLastError(), "hipStreamCreate/hipMalloc", __FILE__, __LINE__);
     return fail(XMPI_ERR_HIP);
@@ -1259,6 +1262,7 @@ int xmpi_set_param(xmpi_comm* c, const char* name, long value) {
   else if (n == "dsync") c->dsync = value ? 1 : 0;
   else if (n == "dsync_grid") c->dsync_grid_cap = std::max<long>(0, value);
   else if (n == "dsync_unroll") c->dsync_unroll = std::max<long>(1, std::min<long>(2, value));
+  else if (n == "dsync_tiles") c->dsync_tiles = std::max<long>(1, value);
   else if (n == "kernel_mode") set_kernel_mode((int)value);  // process-wide
   else if (n == "grid_cap") set_grid_cap((int)value);        // process-wide
   else return XMPI_ERR_ARG;

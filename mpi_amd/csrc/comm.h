@@ -110,6 +110,7 @@ struct xmpi_comm {
   int dsync_sharers = 1;         // ranks of this job on this rank's GPU (bounds the grid: their kernels spin together)
   long dsync_grid_cap = 0;       // blocks per kernel; 0 = 1024 / sharers
   long dsync_unroll = 1;         // 16-byte packets per lane per source in flight (2 = deeper, for links)
+  long dsync_tiles = 1;          // tiles (256 lanes x unroll packets) a block walks before the grid grows
   uint64_t dsync_epoch = 0;      // epoch of the last kernel launched: the same number on every rank
   uint64_t dsync_tag = 1;        // tags this communicator's entries in the (pooled, uncleared) page's translation cache
   uint64_t dsync_launches = 0, dsync_bounced = 0;  // diagnostics: kernels; buffers stood in for by arena blocks

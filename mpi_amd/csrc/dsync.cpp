@@ -348,7 +348,9 @@ int dsync_grid(const xmpi_comm* c, size_t packets_per_segment, int nseg, int unr
   // blocks of all ranks on this GPU fit in half of its wave slots (256 CUs x 32 waves, 4 waves per block)
   long cap = c->dsync_grid_cap > 0 ? c->dsync_grid_cap : 1024 / c->dsync_sharers;
   cap = std::max<long>(1, cap / std::max(1, nseg));
-  const size_t per_block = (size_t)256 * (size_t)std::max(1, unroll);
+  // several tiles per block: every block costs seven polling lanes on this rank's page and a ticket, which is what a
+  // small collective spends its time on (8 processes, 1 MiB: 32 blocks per rank -> 84 us, see profiles/README.md)
+  const size_t per_block = (size_t)256 * (size_t)std::max(1, unroll) * (size_t)std::max<long>(1, c->dsync_tiles);
   const size_t want = (packets_per_segment + per_block - 1) / per_block;
   return (int)std::max<size_t>(1, std::min<size_t>(want, (size_t)cap));
 }
