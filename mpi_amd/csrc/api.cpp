@@ -1068,7 +1068,24 @@ int xmpi_allreduce_repeat(xmpi_comm* c, const void* sendbuf, void* recvbuf, size
     }
     return XMPI_OK;
   }
-  for (int i = 0; i < iters; i++) {
+  // Every rank of the job a thread of this process on this GPU (bench.py on a 1-GPU box): they share one in-order
+  // stream and one launch folds everybody's chunks, so K steps are K launches enqueued back to back between two
+  // rendezvous instead of K x (rendezvous, launch, wait, rendezvous).  Anything the zero-copy path cannot take
+  // (unregistered buffers) falls through to the step-by-step loop -- on every rank alike, the decision is collective.
+  bool all_coloc = c->shared_stream && c->zc_group_launch && c->size > 1 && iters > 1;
+  for (int p = 0; p < c->size && all_coloc; p++)
+    if (p != c->rank && !c->peer_coloc[p]) all_coloc = false;
+  int first = 0;
+  if (all_coloc && count > 0 && sendbuf && recvbuf && xmpi_dtype_size(dtype) && op >= 0 && op < XMPI_OP_COUNT &&
+      (algo == XMPI_ALGO_ZCOPY || (algo == XMPI_ALGO_AUTO && c->zero_copy))) {
+    drain_worker(c);
+    std::lock_guard<std::mutex> g(c->coll_mu);
+    bool done = false;
+    const int rc = zero_copy_collective(c, COLL_ALLREDUCE, 0, sendbuf, recvbuf, count, (int)dtype, (int)op, false, &done, iters);
+    if (rc != XMPI_OK || done) return rc;
+    first = 0;  // went staged (collectively): run the steps one by one
+  }
+  for (int i = first; i < iters; i++) {
     const int rc = collective(c, COLL_ALLREDUCE, algo, 0, sendbuf, recvbuf, count, (int)dtype, (int)op);
     if (rc != XMPI_OK) return rc;
   }

@@ -185,7 +185,7 @@ int p2p_probe(xmpi_comm* c, int src, int tag, size_t* bytes, int* dtype);
 // zcopy.cpp.  *done = false: some rank's buffers are not registered HBM -- every rank saw that and
 // the caller runs the staged schedule instead (no rank is left behind: the decision is collective).
 int zero_copy_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void* recvbuf, size_t count,
-                         int dtype, int op, bool push, bool* done);
+                         int dtype, int op, bool push, bool* done, int iters = 1);
 int registry_add(void* base, size_t bytes, int device);
 void registry_remove(xmpi_comm* c, void* base);
 void zc_close_peers(const xmpi_comm* c);

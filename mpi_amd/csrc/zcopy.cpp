@@ -296,7 +296,7 @@ void zc_close_peers(const xmpi_comm* c) {
 }
 
 static int zc_run(xmpi_comm* c, int coll, int root, const void* sendbuf, void* recvbuf, size_t count, int dtype,
-                  int op, bool push, bool* done) {
+                  int op, bool push, bool* done, int iters) {
   *done = false;
   const int N = c->size, me = c->rank;
   const size_t es = xmpi_dtype_size((xmpi_dtype)dtype);
@@ -473,11 +473,32 @@ static int zc_run(xmpi_comm* c, int coll, int root, const void* sendbuf, void* r
         dsts[nd++] = precv[me] + off * es;  // local store first, then one store per link
         for (int d = 1; d < N; d++) dsts[nd++] = precv[(me + d) % N] + off * es;
       }
-      rc = L.begin((size_t)(N + nd) * cnt * es);
-      if (rc) return rc;
-      XMPI_HIP(launch_reduce_n_multi(dsts, nd, srcs, N, cnt, dtype, op, s, L.start, L.stop));
+      // iters > 1 (xmpi_allreduce_repeat, every rank of the job a thread of this process on this GPU): the same
+      // allreduce `iters` times, enqueued back to back on the one in-order stream all ranks share and waited for
+      // once -- stream order is all the synchronisation K identical steps need.  Sampled launches carry their own
+      // begin / end events, read after the wait.
+      std::vector<std::pair<hipEvent_t, hipEvent_t>> sampled;
+      for (int it = 0; it < iters; it++) {
+        rc = L.begin((size_t)(N + nd) * cnt * es);
+        if (rc) return rc;
+        XMPI_HIP(launch_reduce_n_multi(dsts, nd, srcs, N, cnt, dtype, op, s, L.start, L.stop));
+        if (it + 1 < iters && L.start) {
+          sampled.push_back({L.start, L.stop});
+          L.start = L.stop = nullptr;
+        }
+      }
       rc = L.finish();
       if (rc) return rc;
+      for (auto& ev : sampled) {
+        float ms = 0.f;
+        XMPI_HIP(hipEventElapsedTime(&ms, ev.first, ev.second));
+        ProfCounter& pc = c->prof[PROF_ZCOPY];
+        pc.launches++;
+        pc.total_ms += ms;
+        pc.bytes += (size_t)(N + nd) * cnt * es;
+        ev_put(c, ev.first, true);
+        ev_put(c, ev.second, true);
+      }
     }
   } else if (coll == COLL_ALLGATHER) {
     void* dsts[kMaxRanks];
@@ -563,8 +584,8 @@ static int zc_run(xmpi_comm* c, int coll, int root, const void* sendbuf, void* r
 }
 
 int zero_copy_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void* recvbuf, size_t count,
-                         int dtype, int op, bool push, bool* done) {
-  const int rc = zc_run(c, coll, root, sendbuf, recvbuf, count, dtype, op, push, done);
+                         int dtype, int op, bool push, bool* done, int iters) {
+  const int rc = zc_run(c, coll, root, sendbuf, recvbuf, count, dtype, op, push, done, iters);
   if (rc != XMPI_OK) c->ctl->set_abort(rc);  // peers waiting in a barrier stop waiting
   return rc;
 }
