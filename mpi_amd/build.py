@@ -121,7 +121,7 @@ def build_host(force: bool = False) -> list[str]:
         deps = [mpi_cpp, net_cpp, os.path.join(host_dir, "mpi.hpp"), os.path.join(host_dir, "network.hpp"),
                 os.path.join(host_dir, "gobwire.hpp"), os.path.join(ROOT, "include", "xmpi.h")]
         if force or _newer(HOSTLIB, deps):
-            _run(["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-shared", *inc, mpi_cpp, net_cpp, "-o", HOSTLIB,
+            _run(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wextra", "-shared", *inc, mpi_cpp, net_cpp, "-o", HOSTLIB,
                   "-L", os.path.dirname(LIB), "-lxmpi", "-Wl,-rpath,$ORIGIN", "-lpthread"], HOSTLIB, deps)
         outs.append(HOSTLIB)
         for name, src in (("helloworld", os.path.join(ROOT, "examples", "helloworld.cpp")),

@@ -401,6 +401,165 @@ Error Network::Receive(Data d, int source, int tag) {
   return body.ok() ? Error() : Error(XMPI_ERR_ARG, "mpi receive: short payload");
 }
 
+// ---- collectives: whole-buffer exchange + rank-order fold on the host -----------------------------------------------
+namespace {
+
+constexpr int kCollTag = 0x7C011;  // the tag the collectives travel under (one collective at a time per job)
+
+size_t elem_size(xmpi_dtype dt) {
+  switch (dt) {
+    case XMPI_U8: return 1;
+    case XMPI_I32: case XMPI_F32: return 4;
+    case XMPI_I64: case XMPI_F64: return 8;
+    default: return 0;  // half / bfloat16 have no Go type: not on this backend
+  }
+}
+
+template <typename T>
+T fold1(T a, T b, xmpi_op op) {
+  switch (op) {
+    case XMPI_SUM: return (T)(a + b);
+    case XMPI_PROD: return (T)(a * b);
+    case XMPI_MIN: return (b < a) ? b : a;  // spelled like the kernels and the oracle: NaN / -0 behave alike
+    default: return (a < b) ? b : a;
+  }
+}
+template <typename T>
+void fold_into(void* acc, const void* x, size_t n, xmpi_op op) {
+  T* a = (T*)acc;
+  const T* b = (const T*)x;
+  for (size_t i = 0; i < n; i++) a[i] = fold1<T>(a[i], b[i], op);
+}
+// wrapping integer arithmetic (Go semantics) without signed-overflow UB
+template <typename T, typename U>
+void fold_into_int(void* acc, const void* x, size_t n, xmpi_op op) {
+  T* a = (T*)acc;
+  const T* b = (const T*)x;
+  for (size_t i = 0; i < n; i++) {
+    if (op == XMPI_SUM) a[i] = (T)((U)a[i] + (U)b[i]);
+    else if (op == XMPI_PROD) a[i] = (T)((U)a[i] * (U)b[i]);
+    else a[i] = fold1<T>(a[i], b[i], op);
+  }
+}
+
+}  // namespace
+
+// every rank sends its buffer to every rank (or to `only_to`) and receives everybody's: all[r] = rank r's bytes
+Error Network::exchange(const Data& send, std::vector<std::vector<uint8_t>>* all, int only_to) {
+  const size_t es = elem_size(send.dtype);
+  if (!es) return Error(XMPI_ERR_UNSUPPORTED, "mpi collective: this element type has no Go counterpart on the TCP backend");
+  const int n = size_;
+  all->assign((size_t)n, std::vector<uint8_t>());
+  std::vector<Error> serr((size_t)n), rerr((size_t)n);
+  std::vector<std::thread> ts;
+  for (int p = 0; p < n; p++)
+    if (only_to < 0 || p == only_to) ts.emplace_back([&, p] { serr[(size_t)p] = Send(send, p, kCollTag); });
+  if (only_to < 0 || only_to == rank_)
+    for (int p = 0; p < n; p++)
+      ts.emplace_back([&, p] {
+        std::vector<uint8_t>& dst = (*all)[(size_t)p];
+        Data d;
+        d.dtype = send.dtype;
+        d.is_string = send.is_string;
+        d.owner = &dst;
+        d.resize = [](void* o, size_t cnt, Data* self) {
+          auto* v = static_cast<std::vector<uint8_t>*>(o);
+          v->resize(cnt * elem_size(self->dtype));
+          self->ptr = v->data();
+          self->count = cnt;
+        };
+        rerr[(size_t)p] = Receive(d, p, kCollTag);
+      });
+  for (auto& t : ts) t.join();
+  for (int p = 0; p < n; p++) {
+    if (serr[(size_t)p]) return serr[(size_t)p];
+    if (rerr[(size_t)p]) return rerr[(size_t)p];
+  }
+  return Error();
+}
+
+Error Network::Allgather(const Data& send, Data recv) {
+  std::vector<std::vector<uint8_t>> all;
+  if (Error e = exchange(send, &all, -1)) return e;
+  const size_t es = elem_size(send.dtype), each = send.count * es;
+  if (recv.resize) recv.resize(recv.owner, send.count * (size_t)size_, &recv);
+  if (recv.count < send.count * (size_t)size_) return Error(XMPI_ERR_TRUNCATE, "mpi allgather: receive buffer too small");
+  for (int r = 0; r < size_; r++) {
+    if (all[(size_t)r].size() != each) return Error(XMPI_ERR_ARG, "mpi allgather: ranks passed different counts");
+    if (each) memcpy((char*)recv.ptr + (size_t)r * each, all[(size_t)r].data(), each);
+  }
+  return Error();
+}
+
+Error Network::Reduce(const Data& send, Data recv, xmpi_op op, int root) {
+  if (root < 0 || root >= size_) return Error(XMPI_ERR_ARG, "mpi reduce: bad root");
+  std::vector<std::vector<uint8_t>> all;
+  if (Error e = exchange(send, &all, root)) return e;
+  if (rank_ != root) return Error();
+  const size_t es = elem_size(send.dtype), bytes = send.count * es;
+  if (recv.resize) recv.resize(recv.owner, send.count, &recv);
+  if (recv.count < send.count) return Error(XMPI_ERR_TRUNCATE, "mpi reduce: receive buffer too small");
+  for (int r = 0; r < size_; r++)
+    if (all[(size_t)r].size() != bytes) return Error(XMPI_ERR_ARG, "mpi reduce: ranks passed different counts");
+  if (bytes) memcpy(recv.ptr, all[0].data(), bytes);
+  for (int r = 1; r < size_; r++) {  // strictly left to right in rank order: ((x0 op x1) op x2) ...
+    const void* x = all[(size_t)r].data();
+    switch (send.dtype) {
+      case XMPI_U8: fold_into_int<uint8_t, uint8_t>(recv.ptr, x, send.count, op); break;
+      case XMPI_I32: fold_into_int<int32_t, uint32_t>(recv.ptr, x, send.count, op); break;
+      case XMPI_I64: fold_into_int<int64_t, uint64_t>(recv.ptr, x, send.count, op); break;
+      case XMPI_F32: fold_into<float>(recv.ptr, x, send.count, op); break;
+      case XMPI_F64: fold_into<double>(recv.ptr, x, send.count, op); break;
+      default: return Error(XMPI_ERR_UNSUPPORTED, "mpi reduce: element type");
+    }
+  }
+  return Error();
+}
+
+Error Network::Allreduce(const Data& send, Data recv, xmpi_op op) {
+  // every rank gathers everything and folds for itself -- what the oracle's definition says, not the cheapest schedule
+  std::vector<std::vector<uint8_t>> all;
+  if (Error e = exchange(send, &all, -1)) return e;
+  const size_t es = elem_size(send.dtype), bytes = send.count * es;
+  if (recv.resize) recv.resize(recv.owner, send.count, &recv);
+  if (recv.count < send.count) return Error(XMPI_ERR_TRUNCATE, "mpi allreduce: receive buffer too small");
+  for (int r = 0; r < size_; r++)
+    if (all[(size_t)r].size() != bytes) return Error(XMPI_ERR_ARG, "mpi allreduce: ranks passed different counts");
+  if (bytes) memcpy(recv.ptr, all[0].data(), bytes);
+  for (int r = 1; r < size_; r++) {
+    const void* x = all[(size_t)r].data();
+    switch (send.dtype) {
+      case XMPI_U8: fold_into_int<uint8_t, uint8_t>(recv.ptr, x, send.count, op); break;
+      case XMPI_I32: fold_into_int<int32_t, uint32_t>(recv.ptr, x, send.count, op); break;
+      case XMPI_I64: fold_into_int<int64_t, uint64_t>(recv.ptr, x, send.count, op); break;
+      case XMPI_F32: fold_into<float>(recv.ptr, x, send.count, op); break;
+      case XMPI_F64: fold_into<double>(recv.ptr, x, send.count, op); break;
+      default: return Error(XMPI_ERR_UNSUPPORTED, "mpi allreduce: element type");
+    }
+  }
+  return Error();
+}
+
+Error Network::Bcast(Data buf, int root) {
+  if (root < 0 || root >= size_) return Error(XMPI_ERR_ARG, "mpi bcast: bad root");
+  if (rank_ == root) {
+    std::vector<Error> errs((size_t)size_);
+    std::vector<std::thread> ts;
+    for (int p = 0; p < size_; p++)
+      if (p != root) ts.emplace_back([&, p] { errs[(size_t)p] = Send(buf, p, kCollTag); });
+    for (auto& t : ts) t.join();
+    for (const Error& e : errs)
+      if (e) return e;
+    return Error();
+  }
+  return Receive(buf, root, kCollTag);
+}
+
+Error Network::Barrier() {
+  std::vector<uint8_t> token = {1}, all;
+  return Allgather(Slice(token), Into(&all));
+}
+
 void Network::close_all() {
   for (auto& up : peers_) {
     Peer& P = *up;

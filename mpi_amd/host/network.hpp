@@ -19,7 +19,13 @@
 
 namespace mpi {
 
-class Network : public Interface {
+// It also provides the collectives the reference only stubs (mpi.go:130), composed the way a reference user would
+// compose them -- every rank exchanges whole buffers with Send / Receive (the all-to-all idiom of
+// examples/helloworld/helloworld.go:53-81) and folds them on the host in rank order 0..N-1, one rounding per
+// operation.  That composition is, word for word, what this repository's oracle DEFINES the collectives to be
+// (DESIGN.md section 5); here it is a backend a program can run, so the xGMI backend's results can be compared with
+// it bit for bit on the same inputs.
+class Network : public Interface, public Collective {
  public:
   // the reference's fields (network.go:25-39); zero values are filled from the flags (network.go:69-90)
   std::string NetProto;            // -mpi-protocol; "tcp"
@@ -35,6 +41,12 @@ class Network : public Interface {
   int Size() override;
   Error Send(const Data& data, int destination, int tag) override;
   Error Receive(Data data, int source, int tag) override;
+
+  Error Bcast(Data buf, int root) override;
+  Error Reduce(const Data& send, Data recv, xmpi_op op, int root) override;
+  Error Allreduce(const Data& send, Data recv, xmpi_op op) override;
+  Error Allgather(const Data& send, Data recv) override;
+  Error Barrier() override;
 
  private:
   // pairwiseConnection (network.go:501-506) + its two tagManagers (network.go:448-497)
@@ -57,6 +69,7 @@ class Network : public Interface {
   std::string check_peer(const std::string& password, int64_t id, int n) const;
   void reader_loop(int peer, bool acks);
   void close_all();
+  Error exchange(const Data& send, std::vector<std::vector<uint8_t>>* all, int only_to);  // only_to < 0: everybody
 };
 
 }  // namespace mpi

@@ -109,3 +109,47 @@ def test_tcp_backend_error_values(tmp_path):
                            "-lpthread"])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("n", [1, 2, 4])
+def test_allreduce_program_over_tcp(n):
+    """examples/allreduce.cpp --tcp: the package-level collectives on the reference's own transport, closed forms"""
+    r = subprocess.run([os.path.join(BIN, "xmpirun"), str(n), os.path.join(BIN, "allreduce"), "50021", "--tcp"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env={**os.environ, "XMPI_BASEPORT": str(8400 + 10 * n)})
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"allreduce of 50021 float32 over {n} nodes" in r.stdout and "every result exact" in r.stdout
+
+
+@pytest.mark.parametrize("dtype,op,size", [("f32", "sum", 3), ("f32", "sum", 8), ("f64", "sum", 4), ("f32", "prod", 3), ("f32", "min", 4),
+                                           ("i64", "sum", 5), ("i32", "prod", 3), ("f64", "max", 2)])
+def test_tcp_collectives_are_the_oracle_bit_for_bit(dtype, op, size, tmp_path):
+    """The collectives of mpi::Network are the composition this repository's oracle is DEFINED as (whole-buffer exchange
+    over the reference's Send / Receive, host fold in rank order, one rounding per operation) -- as a running backend.
+    Signed, cancelling float inputs: any other summation order would show."""
+    import numpy as np
+    from mpi_amd import xmpi
+    from oracle import oracle
+    exe = str(tmp_path / "tcp_coll_io")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"), "-I",
+                           os.path.join(ROOT, "mpi_amd", "host"), os.path.join(ROOT, "tests", "tcp_coll_io.cpp"), "-o", exe,
+                           "-L", os.path.join(ROOT, "mpi_amd"), "-lxmpi_host", "-lxmpi", "-Wl,-rpath," + os.path.join(ROOT, "mpi_amd"),
+                           "-lpthread"])
+    dt = {"f32": xmpi.F32, "f64": xmpi.F64, "i64": xmpi.I64, "i32": xmpi.I32}[dtype]
+    o = {"sum": xmpi.SUM, "prod": xmpi.PROD, "min": xmpi.MIN, "max": xmpi.MAX}[op]
+    count = 20011
+    ins = [oracle.fill(count, dt, xmpi.PAT_SIGNED, 4242 + r) for r in range(size)]
+    ports = _ports(8500 + 20 * size + {"sum": 0, "prod": 1, "min": 2, "max": 3}[op] * 200 + {"f32": 0, "f64": 40, "i64": 80, "i32": 120}[dtype], size)
+    procs = []
+    for r in range(size):
+        ins[r].tofile(tmp_path / f"in{r}.bin")
+        procs.append(_spawn([exe, dtype, op, str(tmp_path / f"in{r}.bin"), str(tmp_path / f"out{r}")], ports[r], ports,
+                            ["-mpi-inittimeout", "30s"]))
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    npdt = xmpi.NUMPY_DTYPE[dt]
+    want = oracle.reduce_ranks(ins, dt, o)
+    for r in range(size):
+        assert np.fromfile(tmp_path / f"out{r}.allreduce", dtype=npdt).tobytes() == want.tobytes(), f"allreduce on rank {r}"
+        assert np.fromfile(tmp_path / f"out{r}.allgather", dtype=npdt).tobytes() == oracle.allgather(ins, dt).tobytes()
+        assert np.fromfile(tmp_path / f"out{r}.bcast", dtype=npdt).tobytes() == ins[0].tobytes()
+    assert np.fromfile(tmp_path / f"out{size - 1}.reduce", dtype=npdt).tobytes() == want.tobytes()
