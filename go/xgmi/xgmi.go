@@ -378,6 +378,24 @@ func (b *Backend) ReduceOnStream(send, recv DeviceBuffer, op int, root int, stre
 		C.xmpi_op(op), C.int(root), stream), "mpi reduce")
 }
 
+// GraphBegin / GraphEnd capture the stream-ordered collectives enqueued on `stream` in between (and anything else the
+// caller enqueues there) into an executable hipGraph; GraphLaunch replays it.  Every rank captures the same sequence
+// and replays it equally often.
+func (b *Backend) GraphBegin(stream unsafe.Pointer) error {
+	return status(C.xmpi_graph_begin(b.comm, stream), "mpi graph begin")
+}
+func (b *Backend) GraphEnd(stream unsafe.Pointer) (unsafe.Pointer, error) {
+	var g unsafe.Pointer
+	err := status(C.xmpi_graph_end(b.comm, stream, &g), "mpi graph end")
+	return g, err
+}
+func (b *Backend) GraphLaunch(graph, stream unsafe.Pointer) error {
+	return status(C.xmpi_graph_launch(b.comm, graph, stream), "mpi graph launch")
+}
+func (b *Backend) GraphDestroy(graph unsafe.Pointer) {
+	C.xmpi_graph_destroy(b.comm, graph)
+}
+
 // Register makes device memory that did not come from Malloc (another allocator's) reachable by the
 // zero-copy collectives and the direct point-to-point path; Deregister before freeing it.
 func (b *Backend) Register(ptr unsafe.Pointer, bytes int) error {

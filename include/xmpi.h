@@ -233,6 +233,16 @@ void* xmpi_stream_create(xmpi_comm* comm);
 int xmpi_stream_destroy(xmpi_comm* comm, void* stream);
 int xmpi_stream_sync(xmpi_comm* comm, void* stream);
 
+/* hipGraph capture: the stream-ordered collectives enqueued on `stream` between xmpi_graph_begin and xmpi_graph_end
+ * (registered device buffers; call each once before capturing so that everything is mapped) become an executable
+ * graph that xmpi_graph_launch replays -- one launch for the whole sequence, the caller's own kernels captured on
+ * that stream included.  Every rank captures the same sequence and replays it equally often.  Needs ranks that
+ * meet on the device (one process per GPU); XMPI_ERR_UNSUPPORTED otherwise. */
+int xmpi_graph_begin(xmpi_comm* comm, void* stream);
+int xmpi_graph_end(xmpi_comm* comm, void* stream, void** graph);
+int xmpi_graph_launch(xmpi_comm* comm, void* graph, void* stream);
+int xmpi_graph_destroy(xmpi_comm* comm, void* graph);
+
 /* The same allreduce `iters` times back to back: the step loop of a benchmark without per-call
  * host-language overhead (bench.py hosts several ranks as Python threads, which would otherwise
  * queue for the interpreter lock between steps; a Go or C++ caller has no such cost).  With one process

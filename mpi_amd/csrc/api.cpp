@@ -975,6 +975,52 @@ int xmpi_stream_destroy(xmpi_comm* c, void* stream) {
   return XMPI_OK;
 }
 
+// ---- hipGraph capture of stream-ordered collectives ---------------------------------------------------------------
+// A device-synchronised collective is one kernel launch whose arguments do not change from call to call on the same
+// buffers (its epoch is counted on the device, DsyncPage::epoch_now), so a sequence of them -- with the caller's own
+// kernels in between -- can be captured once and replayed: the launch-bound inner loop of an iterative solver becomes one
+// hipGraphLaunch per iteration.  Every rank captures the same sequence and replays it the same number of times.
+int xmpi_graph_begin(xmpi_comm* c, void* stream) {
+  XMPI_ENTER(c);
+  if (!stream) {
+    set_last_error("graph capture needs a stream of the caller's (xmpi_stream_create)");
+    return XMPI_ERR_ARG;
+  }
+  if (!dsync_usable(c)) {
+    set_last_error("graph capture needs ranks that meet on the device (one process per GPU)");
+    return XMPI_ERR_UNSUPPORTED;
+  }
+  // relaxed: other threads of this process (the helper that maps peers' buffers) may keep calling the runtime
+  XMPI_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeRelaxed));
+  return XMPI_OK;
+}
+
+int xmpi_graph_end(xmpi_comm* c, void* stream, void** graph_out) {
+  XMPI_ENTER(c);
+  if (!stream || !graph_out) return XMPI_ERR_ARG;
+  hipGraph_t g = nullptr;
+  XMPI_HIP(hipStreamEndCapture((hipStream_t)stream, &g));
+  hipGraphExec_t exec = nullptr;
+  hipError_t e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) return hip_fail(e, "hipGraphInstantiate", __FILE__, __LINE__);
+  *graph_out = (void*)exec;
+  return XMPI_OK;
+}
+
+int xmpi_graph_launch(xmpi_comm* c, void* graph, void* stream) {
+  XMPI_ENTER(c);
+  if (!graph) return XMPI_ERR_ARG;
+  XMPI_HIP(hipGraphLaunch((hipGraphExec_t)graph, stream ? (hipStream_t)stream : c->local_stream));
+  return XMPI_OK;
+}
+
+int xmpi_graph_destroy(xmpi_comm* c, void* graph) {
+  XMPI_ENTER(c);
+  if (graph) XMPI_HIP(hipGraphExecDestroy((hipGraphExec_t)graph));
+  return XMPI_OK;
+}
+
 int xmpi_stream_sync(xmpi_comm* c, void* stream) {
   XMPI_ENTER(c);
   hipStream_t s = stream ? (hipStream_t)stream : c->local_stream;

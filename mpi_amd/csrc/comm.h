@@ -112,6 +112,7 @@ struct xmpi_comm {
   long dsync_unroll = 1;         // 16-byte packets per lane per source in flight (2 = deeper, for links)
   long dsync_tiles = 1;          // tiles (256 lanes x unroll packets) a block walks before the grid grows
   uint64_t dsync_epoch = 0;      // epoch of the last kernel launched: the same number on every rank
+  uint64_t dsync_base = 0;       // where this communicator's epochs start (epoch_floor of its kernels)
   uint64_t dsync_tag = 1;        // tags this communicator's entries in the (pooled, uncleared) page's translation cache
   uint64_t dsync_launches = 0, dsync_bounced = 0;  // diagnostics: kernels; buffers stood in for by arena blocks
   xmpi::DsyncEntry* dsync_table = nullptr;            // [kMaxRanks][kDsyncArenas], pinned host memory the kernels read

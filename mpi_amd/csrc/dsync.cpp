@@ -128,7 +128,7 @@ int dsync_connect(xmpi_comm* c) {
   }
   (void)hipGetLastError();
   if (hipHostMalloc((void**)&c->dsync_status, 64, hipHostMallocMapped) == hipSuccess) {
-    *c->dsync_status = 0;
+    memset(c->dsync_status, 0, 64);  // word 0: first failure of a kernel; bytes 8..15: epoch of the last kernel that ended
     void* dev = nullptr;
     if (hipHostGetDevicePointer(&dev, c->dsync_status, 0) == hipSuccess) c->dsync_status_dev = (uint32_t*)dev;
   }
@@ -141,6 +141,7 @@ int dsync_connect(xmpi_comm* c) {
   uint64_t base = 0;
   for (int p = 0; p < N; p++) base = std::max(base, c->ctl->info(p)->flag_epoch);
   c->dsync_epoch = base;
+  c->dsync_base = base;
   c->dsync_tag = base + 1;
   c->dsync_ok = true;
   // A rank must map what its peers register even while its own threads are blocked somewhere the library cannot
@@ -168,10 +169,15 @@ void dsync_stop_helper(xmpi_comm* c) {
 
 void dsync_finalize(xmpi_comm* c) {
   dsync_stop_helper(c);
+  // the next user of the page starts above the last epoch written into it (graph replays are counted on the device:
+  // the kernels copy the page's counter into the pinned status area)
+  uint64_t last = c->dsync_epoch;
+  if (c->dsync_status) last = std::max<uint64_t>(last, __atomic_load_n((const uint64_t*)(c->dsync_status + 2), __ATOMIC_ACQUIRE));
   for (int p = 0; p < c->size; p++)
     if (c->peer_page_opened[p]) ipc_close_shared(c->peer_page[p]);
   if (c->dsync_ctl_registered) (void)hipHostUnregister(c->ctl->base());
   if (c->dsync_status) (void)hipHostFree(c->dsync_status);
+  c->dsync_status = nullptr;
   if (c->dsync_table) (void)hipHostFree(c->dsync_table);
   c->dsync_table = nullptr;
   for (auto& b : c->dsync_deferred) {
@@ -179,7 +185,7 @@ void dsync_finalize(xmpi_comm* c) {
     for (void* p : b.bufs) (void)heap_free(p);
   }
   c->dsync_deferred.clear();
-  if (c->dpage) pool_release(c->dpage, c->dsync_epoch);  // the next user of the page starts above this
+  if (c->dpage) pool_release(c->dpage, last);
   c->dpage = nullptr;
   (void)hipGetLastError();
 }
@@ -430,6 +436,8 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
   a.recv_slot = (uint64_t)rslot;
   a.table = c->dsync_table_dev;
   a.tag = c->dsync_tag;
+  a.epoch_floor = c->dsync_base;
+  a.host_epoch = c->dsync_status_dev ? (uint64_t*)(c->dsync_status_dev + 2) : nullptr;
   a.my_send = r.send;
   a.my_recv = r.recv;
   a.abort_word = c->dsync_abort_dev;
@@ -443,7 +451,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
   const bool sampled = blocking && c->prof_on && (c->prof_seq[PROF_ZCOPY]++ % (uint64_t)std::max<long>(1, c->prof_every)) == 0;
   size_t traffic = 0;
   auto launch = [&](int nsrc, int kdtype, int kop, size_t packets) -> int {
-    a.epoch = ++c->dsync_epoch;
+    ++c->dsync_epoch;  // the host's count (the kernels count for themselves, from the page: see epoch_floor)
     const int gx = a.nseg > 0 ? dsync_grid(c, packets, a.nseg, unroll) : 1;
     if (sampled && !pstart) {
       pstart = ev_get(c, true);

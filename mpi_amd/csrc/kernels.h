@@ -87,7 +87,11 @@ struct DsyncPage {
   DsyncSlot ready[kDsyncRanks];
   uint64_t done[kDsyncRanks][8];  // 64 bytes apart
   uint32_t ticket;                // blocks of the running kernel that have finished their stores
-  uint32_t pad[15];
+  uint32_t pad0;
+  uint64_t epoch_now;             // epoch of the last kernel of this rank that has ended (written by its closing block):
+                                  // the next kernel's epoch is derived from it ON THE DEVICE, so a captured hipGraph
+                                  // that replays the same launch keeps counting
+  uint32_t pad[12];
   // what this rank's kernels have looked up in the host's translation table (DsyncArgs::table) so far: the host
   // never writes device memory for this (a copy would need a hardware queue -- possibly the one a waiting kernel
   // occupies), the kernels fill the cache themselves and re-fetch when the registration number differs
@@ -108,7 +112,9 @@ enum DsyncStatus : uint32_t { DSYNC_OK = 0, DSYNC_TIMEOUT = 1, DSYNC_ABORTED = 2
 struct DsyncArgs {
   DsyncPage* page[kDsyncRanks];  // [me]: own page, others: the peers' pages as mapped here
   int32_t me, n;
-  uint64_t epoch;
+  uint64_t epoch_floor;       // this kernel's epoch = max(page.epoch_now, epoch_floor) + 1: the floor is where the
+                              // communicator's epochs start (above what earlier users left in the pooled, uncleared pages)
+  uint64_t* host_epoch;       // pinned host word that follows page.epoch_now (what the host gives back to the pool), may be null
   uint64_t send_gen, send_off, recv_gen, recv_off;  // what this rank tells its peers
   uint64_t send_slot, recv_slot;
   const void* my_send;

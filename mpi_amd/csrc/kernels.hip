@@ -749,6 +749,7 @@ __device__ uint32_t dsync_spin(const uint64_t* p, uint64_t want, const DsyncArgs
 }
 
 struct DsyncShared {
+  uint64_t epoch;                                 // of this kernel
   uint64_t send[kDsyncRanks], recv[kDsyncRanks];  // every rank's buffers as addressable from here
   uint64_t src[kDsyncRanks], dst[kDsyncRanks];    // this block's segment: sources in rank order, destinations local first
   int nsrc, ndst;
@@ -788,8 +789,13 @@ __device__ void dsync_begin(const DsyncArgs& a, DsyncShared& sh) {
     sh.fail = DSYNC_OK;
     sh.send[me] = (uint64_t)(uintptr_t)a.my_send;
     sh.recv[me] = (uint64_t)(uintptr_t)a.my_recv;
+    // the epoch is counted on the device (every block reads the same value: only the closing block of a kernel
+    // advances it, after all the others have finished), so replaying a captured launch counts on
+    const uint64_t seen = ld_sys64(&mine->epoch_now);
+    sh.epoch = (seen > a.epoch_floor ? seen : a.epoch_floor) + 1;
   }
   __syncthreads();
+  const uint64_t epoch = sh.epoch;
   if (t < n && t != me) {
     if (blockIdx.x == 0 && blockIdx.y == 0) {  // one block announces this rank
       DsyncSlot* out = &a.page[t]->ready[me];
@@ -799,10 +805,10 @@ __device__ void dsync_begin(const DsyncArgs& a, DsyncShared& sh) {
       st_sys64(&out->recv_gen, a.recv_gen);
       st_sys64(&out->recv_off, a.recv_off);
       st_sys64(&out->recv_slot, a.recv_slot);
-      __hip_atomic_store(&out->epoch, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&out->epoch, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     const DsyncSlot* in = &mine->ready[t];
-    uint32_t why = dsync_spin(&in->epoch, a.epoch, a);
+    uint32_t why = dsync_spin(&in->epoch, epoch, a);
     if (why == DSYNC_OK) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
       const uint64_t s = dsync_translate(a, mine, t, ld_sys64(&in->send_slot), ld_sys64(&in->send_gen), ld_sys64(&in->send_off));
@@ -835,13 +841,17 @@ __device__ void dsync_end(const DsyncArgs& a, DsyncShared& sh) {
   if (t == 0) __hip_atomic_store(&mine->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   uint32_t why = DSYNC_OK;
   if (t < n && t != me) {
-    __hip_atomic_store(&a.page[t]->done[me][0], a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (sh.fail == DSYNC_OK) why = dsync_spin(&mine->done[t][0], a.epoch, a);
+    __hip_atomic_store(&a.page[t]->done[me][0], sh.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (sh.fail == DSYNC_OK) why = dsync_spin(&mine->done[t][0], sh.epoch, a);
     if (why != DSYNC_OK) atomicMax(&sh.fail, why);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   __syncthreads();
-  if (t == 0 && sh.fail != DSYNC_OK && a.status) __hip_atomic_store(a.status, sh.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (t == 0) {
+    st_sys64(&mine->epoch_now, sh.epoch);  // this kernel is over: the next one (an ordinary launch or a graph replay) counts from here
+    if (a.host_epoch) st_sys64(a.host_epoch, sh.epoch);
+    if (sh.fail != DSYNC_OK && a.status) __hip_atomic_store(a.status, sh.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // NSRC > 0: the number of sources is a compile-time constant and all their loads are issued before the first

@@ -245,6 +245,11 @@ Error XGMI::ReduceOnStream(const Data& send, Data recv, xmpi_op op, int root, vo
   return from_code(xmpi_reduce_on_stream(comm_, send.ptr, recv.ptr, send.count, send.dtype, op, root, stream), "mpi reduce");
 }
 
+Error XGMI::GraphBegin(void* stream) { return from_code(xmpi_graph_begin(comm_, stream), "mpi graph begin"); }
+Error XGMI::GraphEnd(void* stream, void** graph) { return from_code(xmpi_graph_end(comm_, stream, graph), "mpi graph end"); }
+Error XGMI::GraphLaunch(void* graph, void* stream) { return from_code(xmpi_graph_launch(comm_, graph, stream), "mpi graph launch"); }
+void XGMI::GraphDestroy(void* graph) { xmpi_graph_destroy(comm_, graph); }
+
 Error XGMI::WaitRequest(xmpi_request* req) { return from_code(xmpi_request_wait(req), "mpi wait"); }
 
 Error XGMI::RegisterBuffer(void* p, size_t bytes) { return from_code(xmpi_register(comm_, p, bytes), "mpi register"); }

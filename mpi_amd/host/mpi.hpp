@@ -189,6 +189,11 @@ class XGMI : public Interface, public Collective {
   Error AllgatherOnStream(const Data& send, Data recv, void* stream);
   Error BcastOnStream(Data buf, int root, void* stream);
   Error ReduceOnStream(const Data& send, Data recv, xmpi_op op, int root, void* stream);
+  // hipGraph capture of what is enqueued on `stream` between GraphBegin and GraphEnd; GraphLaunch replays it
+  Error GraphBegin(void* stream);
+  Error GraphEnd(void* stream, void** graph);
+  Error GraphLaunch(void* graph, void* stream);
+  void GraphDestroy(void* graph);
 
   // Device memory from another allocator joins the zero-copy paths with RegisterBuffer (Malloc'd memory
   // is registered as it is); DeregisterBuffer before it is freed.

@@ -94,6 +94,10 @@ SYMBOLS = [
     ("xmpi_stream_create", _P, [_P]),
     ("xmpi_stream_destroy", _I, [_P, _P]),
     ("xmpi_stream_sync", _I, [_P, _P]),
+    ("xmpi_graph_begin", _I, [_P, _P]),
+    ("xmpi_graph_end", _I, [_P, _P, C.POINTER(_P)]),
+    ("xmpi_graph_launch", _I, [_P, _P, _P]),
+    ("xmpi_graph_destroy", _I, [_P, _P]),
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -310,6 +314,21 @@ class Comm:
 
     def stream_sync(self, stream=None) -> None:
         _check(lib().xmpi_stream_sync(self.handle, stream), "xmpi_stream_sync")
+
+    # hipGraph capture of the stream-ordered collectives enqueued on `stream` between graph_begin and graph_end
+    def graph_begin(self, stream) -> None:
+        _check(lib().xmpi_graph_begin(self.handle, stream), "xmpi_graph_begin")
+
+    def graph_end(self, stream) -> int:
+        g = _P()
+        _check(lib().xmpi_graph_end(self.handle, stream, C.byref(g)), "xmpi_graph_end")
+        return g.value
+
+    def graph_launch(self, graph, stream=None) -> None:
+        _check(lib().xmpi_graph_launch(self.handle, graph, stream), "xmpi_graph_launch")
+
+    def graph_destroy(self, graph) -> None:
+        _check(lib().xmpi_graph_destroy(self.handle, graph), "xmpi_graph_destroy")
 
     def allreduce_on_stream(self, send, recv, count: int, dtype: int, op: int = SUM, stream=None) -> None:
         _check(lib().xmpi_allreduce_on_stream(self.handle, _ptr(send), _ptr(recv), count, dtype, op, stream),

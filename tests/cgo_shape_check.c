@@ -152,6 +152,15 @@ static void do_coll(void* p) {
     case 9: a->rc = xmpi_allgather_on_stream(g_comm, a->s, a->r, a->n, a->dt, a->stream); break;
     case 10: a->rc = xmpi_bcast_on_stream(g_comm, a->r, a->n, a->dt, a->root, a->stream); break;
     case 11: a->rc = xmpi_reduce_on_stream(g_comm, a->s, a->r, a->n, a->dt, (xmpi_op)a->op, a->root, a->stream); break;
+    case 12: a->rc = xmpi_graph_begin(g_comm, a->stream); break;
+    case 13: {
+      void* g = NULL; /* out-parameter of the caller's frame */
+      a->rc = xmpi_graph_end(g_comm, a->stream, &g);
+      a->r = g;
+      break;
+    }
+    case 14: a->rc = xmpi_graph_launch(g_comm, a->r, a->stream); break;
+    case 15: a->rc = xmpi_graph_destroy(g_comm, a->r); break;
   }
   keep_error(a->rc);
 }
@@ -315,6 +324,18 @@ int main(int argc, char** argv) {
           fprintf(stderr, "rank %d: gathered block %d element %zu = %g, want %g\n", me, r, i, host[(size_t)r * n + i], want);
         EXPECT(host[(size_t)r * n + i] == want || said > 4, "AllgatherOnStream / ReduceOnStream value");
       }
+    if (N > 1) { /* GraphBegin ... GraphEnd, GraphLaunch x3: begin, capture, end and every replay from different threads */
+      EXPECT(coll(7, ms.out, mr.out, n, XMPI_F32, XMPI_MAX, 0, st.out) == XMPI_OK, "AllreduceOnStream (warm)");
+      EXPECT(coll(8, NULL, NULL, 0, XMPI_F32, 0, 0, st.out) == XMPI_OK, "StreamSync");
+      EXPECT(coll(12, NULL, NULL, 0, XMPI_F32, 0, 0, st.out) == XMPI_OK, "GraphBegin");
+      EXPECT(coll(7, ms.out, mr.out, n, XMPI_F32, XMPI_MAX, 0, st.out) == XMPI_OK, "AllreduceOnStream (captured)");
+      struct coll_args ge = {13, NULL, NULL, 0, XMPI_F32, 0, 0, st.out, 0, NULL};
+      on_new_thread(do_coll, &ge);
+      EXPECT(ge.rc == XMPI_OK && ge.r != NULL, "GraphEnd");
+      for (int k = 0; k < 3; k++) EXPECT(coll(14, NULL, ge.r, 0, XMPI_F32, 0, 0, st.out) == XMPI_OK, "GraphLaunch");
+      EXPECT(coll(8, NULL, NULL, 0, XMPI_F32, 0, 0, st.out) == XMPI_OK, "StreamSync after replays");
+      EXPECT(coll(15, NULL, ge.r, 0, XMPI_F32, 0, 0, NULL) == XMPI_OK, "GraphDestroy");
+    }
     struct mem_args sd = {st.out, NULL, 0, NULL, 0};
     on_new_thread(do_stream_destroy, &sd);
     struct mem_args f1 = {ms.out, NULL, 0, NULL, 0}, f2 = {mr.out, NULL, 0, NULL, 0}, f3 = {mg.out, NULL, 0, NULL, 0};

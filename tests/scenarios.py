@@ -770,6 +770,31 @@ def sc_stream_ordered(comm, args):
     b.free()
     if dsync:
         assert comm.get_param("dsync_launches") > launches0, "the device-synchronised kernels did not run"
+        # hipGraph: two allreduces captured once, replayed five times (in place on int64: every replay multiplies by
+        # size^2 -- exact, wraps like Go); then ordinary calls again: the epochs are counted on the device, so
+        # captured and ordinary launches interleave
+        m = 20011
+        g1, g2 = comm.alloc(m * 8), comm.alloc(m * 8)
+        comm.fill(g1, m, xmpi.I64, xmpi.PAT_CONST, 0)  # all ones
+        comm.allreduce_on_stream(g1, g2, m, xmpi.I64, xmpi.SUM, st)  # warm: everything mapped; g2 = size
+        comm.allreduce_on_stream(g2, g1, m, xmpi.I64, xmpi.SUM, st)  # g1 = size^2
+        comm.stream_sync(st)
+        comm.graph_begin(st)
+        comm.allreduce_on_stream(g1, g2, m, xmpi.I64, xmpi.SUM, st)
+        comm.allreduce_on_stream(g2, g1, m, xmpi.I64, xmpi.SUM, st)
+        graph = comm.graph_end(st)
+        for _ in range(5):
+            comm.graph_launch(graph, st)
+        comm.allreduce_on_stream(g1, g2, m, xmpi.I64, xmpi.SUM, st)  # an ordinary launch right behind the replays
+        comm.stream_sync(st)
+        want_g1 = np.uint64(size) ** np.uint64(12)
+        with np.errstate(over="ignore"):
+            want_g2 = want_g1 * np.uint64(size)
+        assert np.all(g1.download(np.int64, m).view(np.uint64) == want_g1), "graph replays"
+        assert np.all(g2.download(np.int64, m).view(np.uint64) == want_g2), "ordinary launch after graph replays"
+        comm.graph_destroy(graph)
+        g1.free()
+        g2.free()
         # device memory of another allocator, never registered: copied through a registered block on the same stream
         import ctypes
         hip = ctypes.CDLL("libamdhip64.so")
