@@ -1,4 +1,7 @@
-"""Parity of the HIP kernels with the CPU oracle, through the C ABI, on one MI355X.
+"""(Named to run LAST: this module opens the GPU in the test runner's own process, and a GPU schedules the queues of
+only 8 processes at once -- the 8-process tests of the other modules should not find a ninth already there.)
+
+Parity of the HIP kernels with the CPU oracle, through the C ABI, on one MI355X.
 Bit-exact for every dtype and operator (a two-operand combine has no ordering freedom; the
 N-way fold is strictly left to right like the oracle's)."""
 import numpy as np
