@@ -557,6 +557,10 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   auto fail = [&](int code) {
     ctl->set_abort(code);
     dsync_stop_helper(c);  // (it reads the control block)
+    // what this attempt took from the per-process pools goes back (a later xmpi_init in this process finds it)
+    if (c->window) pool_release(c->window);
+    if (c->dpage) pool_release(c->dpage, ctl->info(rank)->flag_epoch);
+    if (c->local_stream && !c->shared_stream) stream_release(c->device, c->local_stream);
     delete ctl;
     delete c;
     return code;
