@@ -44,8 +44,12 @@ typedef enum {
 typedef enum { XMPI_SUM = 0, XMPI_PROD = 1, XMPI_MIN = 2, XMPI_MAX = 3, XMPI_OP_COUNT = 4 } xmpi_op;
 
 /* collective schedules */
+/* With one process per GPU, RING (allreduce, allgather), RHD (allreduce) and TREE (bcast) are ONE kernel per rank that
+ * runs every step of the schedule itself, the steps released by flag words between the peers' kernels (sched.hip);
+ * with ranks that share a process and a GPU -- and for TREE reduce, DIRECT -- they are step tables run by the host
+ * through the HBM receive windows. */
 typedef enum {
-  XMPI_ALGO_AUTO = 0,
+  XMPI_ALGO_AUTO = 0,   /* the library's choice: its tuned table (xmpi_tune) or the zero-copy fold */
   XMPI_ALGO_RING = 1,   /* multi-channel ring: reduce-scatter + allgather            */
   XMPI_ALGO_RHD = 2,    /* recursive halving (reduce-scatter) + doubling (allgather) */
   XMPI_ALGO_DIRECT = 3, /* full-mesh one-hop reduce-scatter + allgather; rank-order sum */
@@ -226,6 +230,20 @@ int xmpi_allgather_on_stream(xmpi_comm* comm, const void* sendbuf, void* recvbuf
 int xmpi_bcast_on_stream(xmpi_comm* comm, void* buf, size_t count, xmpi_dtype dtype, int root, void* stream);
 int xmpi_reduce_on_stream(xmpi_comm* comm, const void* sendbuf, void* recvbuf, size_t count,
                           xmpi_dtype dtype, xmpi_op op, int root, void* stream);
+/* Stream-ordered Send / Receive: the reference's message + ack (network.go:562-571, 616-624) as ONE kernel on each side.
+ * The sender's kernel puts {message number, tag, dtype, bytes, where the payload lives} into a 64-byte box of the
+ * receiver's flag allocation (a store over xGMI) and ends when the receiver has answered; the receiver's kernel waits for
+ * a box carrying its tag, pulls the payload straight out of the sender's HBM into `buf` and answers with its verdict (a
+ * message longer than `capacity` or of another dtype is consumed and both sides get the error).  Like the collectives
+ * above they are ordered with the work on `stream` and no host thread waits; failures are reported by the next
+ * xmpi_stream_sync.  Device memory only; an unregistered send buffer is copied through a registered block.  At most 8
+ * messages of an ordered pair may be unanswered at once.  A kernel that waits holds its stream (and, while it waits, the
+ * hardware queue behind it): enqueue matching sends and receives so that no stream waits for work queued behind it --
+ * the blocking xmpi_send / xmpi_recv have no such rule and do not use these kernels.  Needs ranks that meet on the
+ * device (one process per GPU); XMPI_ERR_UNSUPPORTED otherwise. */
+int xmpi_send_on_stream(xmpi_comm* comm, const void* buf, size_t count, xmpi_dtype dtype, int dest, int tag, void* stream);
+int xmpi_recv_on_stream(xmpi_comm* comm, void* buf, size_t capacity, xmpi_dtype dtype, int src, int tag, void* stream);
+
 /* Streams for callers without a HIP binding of their own (the cgo shim, ctypes): a non-blocking hipStream_t of
  * the communicator's device; xmpi_stream_sync waits for everything enqueued on it (NULL = the communicator's
  * own stream) and returns the status of the collectives that ran on it. */
@@ -296,6 +314,19 @@ int xmpi_fill_pattern(xmpi_comm* comm, void* buf, size_t count, xmpi_dtype dtype
  * see DESIGN.md.  Must be called identically on every rank. */
 int xmpi_set_param(xmpi_comm* comm, const char* name, long value);
 long xmpi_get_param(const xmpi_comm* comm, const char* name);
+
+/* The library's own schedule table.  xmpi_tune times, on this job's real layout and links, the schedules it offers
+ * for an allreduce (one zero-copy kernel with 1 or 2 packets in flight, the meet / body / done form, the push-only
+ * form, the ring kernel, the halving kernel) and an allgather, for message sizes 1 KiB ... max_bytes (x4 steps), lets
+ * every rank see the slowest rank's figures and keeps the winner per size class: XMPI_ALGO_AUTO (and the
+ * stream-ordered forms) consult that table from then on, so a Go or C caller gets the schedule a benchmark would pick.
+ * Collective (same max_bytes on every rank); a few hundred milliseconds.  The table is readable through
+ * xmpi_get_param("tune_algo_<collective>_<class>") (collective 0 = allreduce, 1 = allgather; class k = messages of
+ * [2^(k+8), 2^(k+9)) bytes per rank; -1 = built-in rule), "tune_split_..." (1 = meet / body / done), "tune_unroll_...".
+ * xmpi_tune_decide is the decision it applies to one row of (max-over-ranks) mean times in microseconds, <= 0 = not
+ * run: the fastest, except that candidate 0 (the default) stays unless beaten by more than `margin` (host logic only). */
+int xmpi_tune(xmpi_comm* comm, size_t max_bytes);
+int xmpi_tune_decide(const double* mean_us, int n, double margin);
 
 /* Kernel profiling: when enabled every reduction / copy kernel launch is bracketed by HIP
  * events on the stream it runs on.  kind: 0 = reduce2, 1 = reduceN, 2 = copy kernel,

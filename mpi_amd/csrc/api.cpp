@@ -379,9 +379,10 @@ static int collective(xmpi_comm* c, int coll, int algo, int root, const void* se
   // rank, enqueued on this communicator's stream, no host barrier.  Whether this path is taken depends on the
   // job's layout and the arguments only, so every rank decides alike; buffers the peers cannot map are stood in
   // for by registered arena blocks inside.
-  if (dsync_usable(c) && (zc_algo || (algo == XMPI_ALGO_AUTO && c->zero_copy)))
-    return dsync_collective(c, coll, root, sendbuf, recvbuf, count, dtype, op, c->local_stream, /*blocking=*/true,
-                            /*push=*/algo == XMPI_ALGO_ZPUSH);
+  // RING / RHD (allreduce), RING (allgather) and TREE (bcast) name the stepped kernels there (sched.hip): every step of
+  // the schedule inside one kernel per rank; with ranks that meet on the host they name the staged schedules below.
+  if (dsync_takes(c, coll, algo))
+    return dsync_collective(c, coll, root, sendbuf, recvbuf, count, dtype, op, c->local_stream, /*blocking=*/true, algo);
   if (c->size > 1 && (zc_algo || (algo == XMPI_ALGO_AUTO && c->zero_copy))) {
     bool done = false;
     int zrc = zero_copy_collective(c, coll, root, sendbuf, recvbuf, count, dtype, op, algo == XMPI_ALGO_ZPUSH, &done);
@@ -556,10 +557,15 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
 
   auto fail = [&](int code) {
     ctl->set_abort(code);
-    dsync_stop_helper(c);  // (it reads the control block)
-    // what this attempt took from the per-process pools goes back (a later xmpi_init in this process finds it)
+    // what this attempt took from the per-process pools goes back (a later xmpi_init in this process finds it);
+    // dsync_finalize stops the helper (it reads the control block), closes the peers' flag pages, frees the pinned
+    // tables and gives the page back
+    dsync_finalize(c);
+    if (c->ctl_registered) (void)hipHostUnregister(ctl->base());
+    if (c->p2p_tickets) (void)hipFree(c->p2p_tickets);
+    if (c->dev_words) (void)hipFree(c->dev_words);
+    (void)hipGetLastError();
     if (c->window) pool_release(c->window);
-    if (c->dpage) pool_release(c->dpage, ctl->info(rank)->flag_epoch);
     if (c->local_stream && !c->shared_stream) stream_release(c->device, c->local_stream);
     delete ctl;
     delete c;
@@ -594,6 +600,13 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
     return fail(XMPI_ERR_HIP);
   }
   c->dsync = env_long("XMPI_DSYNC", 1) ? 1 : 0;
+  c->dsync_split_bytes = std::max<long>(0, env_long("XMPI_DSYNC_SPLIT_BYTES", 8 << 20));
+  c->sched_channels = std::max<long>(0, env_long("XMPI_SCHED_CHANNELS", 0));
+  c->sched_grid = std::max<long>(0, env_long("XMPI_SCHED_GRID", 0));
+  c->tree_piece_bytes = std::max<long>(4096, env_long("XMPI_TREE_PIECE_BYTES", 256 << 10));
+  memset(c->tune_algo, -1, sizeof c->tune_algo);
+  memset(c->tune_split, -1, sizeof c->tune_split);
+  memset(c->tune_unroll, 0, sizeof c->tune_unroll);
   c->dsync_grid_cap = std::max<long>(0, env_long("XMPI_DSYNC_GRID", 0));
   XMPI_TRACE_STEP(rank, "init: flag page");
   (void)dsync_prepare(c);  // this rank's flag page (device-synchronised collectives), published with the window
@@ -659,6 +672,17 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   // first runs (ensure_streams).  Every stream costs the process a hardware queue (the runtime multiplexes streams
   // over GPU_MAX_HW_QUEUES of them), and a GPU runs only a few dozen queues at once: 8 processes x 4 queues on one
   // GPU were time-sliced by the scheduler -- 22 ms per collective instead of 40 us (profiles/r02).
+  // the control block as the GPU sees it: kernels read the job's abort flag there and write the ack of a
+  // point-to-point message straight into its mail entry (engine.cpp)
+  if (hipHostRegister(ctl->base(), ctl->bytes(), hipHostRegisterMapped) == hipSuccess) {
+    c->ctl_registered = true;
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, ctl->base(), 0) == hipSuccess) c->ctl_dev = (char*)dev;
+  }
+  (void)hipGetLastError();
+  if (hipMalloc((void**)&c->p2p_tickets, 64 * sizeof(uint32_t)) == hipSuccess)
+    (void)hipMemsetAsync(c->p2p_tickets, 0, 64 * sizeof(uint32_t), c->local_stream);
+  (void)hipGetLastError();
   XMPI_TRACE_STEP(rank, "init: connecting flag pages");
   rc = dsync_connect(c);
   if (rc != XMPI_OK) return fail(rc);
@@ -714,6 +738,8 @@ int xmpi_finalize(xmpi_comm* c) {
   for (hipEvent_t e : c->ev_free) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev_timed_free) (void)hipEventDestroy(e);
   if (!c->ctl->aborted()) (void)c->ctl->barrier(wait_limit(c));
+  if (c->ctl_registered) (void)hipHostUnregister(c->ctl->base());
+  if (c->p2p_tickets) (void)hipFree(c->p2p_tickets);
   if (c->window) pool_release(c->window);  // exported memory is never given back by the runtime: the next communicator reuses it
   if (c->temp) (void)hipFree(c->temp);
   if (c->host_stage) (void)hipFree(c->host_stage);
@@ -933,7 +959,7 @@ static int on_stream(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     set_last_error("stream-ordered collectives take device memory (use the blocking forms for host buffers)");
     return XMPI_ERR_ARG;
   }
-  return dsync_collective(c, coll, root, sendbuf, recvbuf, count, dtype, op, s, /*blocking=*/false);
+  return dsync_collective(c, coll, root, sendbuf, recvbuf, count, dtype, op, s, /*blocking=*/false, XMPI_ALGO_AUTO);
 }
 
 int xmpi_allreduce_on_stream(xmpi_comm* c, const void* sendbuf, void* recvbuf, size_t count, xmpi_dtype dtype, xmpi_op op,
@@ -1015,7 +1041,11 @@ int xmpi_graph_end(xmpi_comm* c, void* stream, void** graph_out) {
 int xmpi_graph_launch(xmpi_comm* c, void* graph, void* stream) {
   XMPI_ENTER(c);
   if (!graph) return XMPI_ERR_ARG;
-  XMPI_HIP(hipGraphLaunch((hipGraphExec_t)graph, stream ? (hipStream_t)stream : c->local_stream));
+  hipStream_t s = stream ? (hipStream_t)stream : c->local_stream;
+  std::lock_guard<std::mutex> g(c->coll_mu);
+  dsync_graph_launched(c, s, /*before=*/true);
+  XMPI_HIP(hipGraphLaunch((hipGraphExec_t)graph, s));
+  dsync_graph_launched(c, s, /*before=*/false);
   return XMPI_OK;
 }
 
@@ -1043,7 +1073,43 @@ int xmpi_stream_sync(xmpi_comm* c, void* stream) {
   }
   ev_put(c, fin, false);
   std::lock_guard<std::mutex> g(c->coll_mu);
-  return dsync_check(c);
+  const int prc = c->dsync_ok ? dsync_p2p_reap(c) : XMPI_OK;  // the stream-ordered sends / receives that have completed
+  const int crc = dsync_check(c);
+  return crc != XMPI_OK ? crc : prc;
+}
+
+// ---- stream-ordered Send / Receive ----------------------------------------------------------------------------------
+static int p2p_on_stream_ok(xmpi_comm* c, const void* buf, size_t count, xmpi_dtype dtype, int peer) {
+  const size_t es = xmpi_dtype_size(dtype);
+  if (!es || peer < 0 || peer >= c->size || (count && !buf)) {
+    set_last_error("send / receive: bad dtype / peer / buffer");
+    return XMPI_ERR_ARG;
+  }
+  if (!c->dsync_ok || !c->dpage) {
+    set_last_error("stream-ordered send / receive need ranks that meet on the device (one process per GPU)");
+    return XMPI_ERR_UNSUPPORTED;
+  }
+  if (count && !is_device_pointer(buf)) {
+    set_last_error("stream-ordered send / receive take device memory (use the blocking forms for host buffers)");
+    return XMPI_ERR_ARG;
+  }
+  return XMPI_OK;
+}
+
+int xmpi_send_on_stream(xmpi_comm* c, const void* buf, size_t count, xmpi_dtype dtype, int dest, int tag, void* stream) {
+  XMPI_ENTER(c);
+  const int rc = p2p_on_stream_ok(c, buf, count, dtype, dest);
+  if (rc != XMPI_OK) return rc;
+  std::lock_guard<std::mutex> g(c->coll_mu);
+  return dsync_send(c, buf, count * xmpi_dtype_size(dtype), (int)dtype, dest, tag, (hipStream_t)stream);
+}
+
+int xmpi_recv_on_stream(xmpi_comm* c, void* buf, size_t capacity, xmpi_dtype dtype, int src, int tag, void* stream) {
+  XMPI_ENTER(c);
+  const int rc = p2p_on_stream_ok(c, buf, capacity, dtype, src);
+  if (rc != XMPI_OK) return rc;
+  std::lock_guard<std::mutex> g(c->coll_mu);
+  return dsync_recv(c, buf, capacity * xmpi_dtype_size(dtype), (int)dtype, src, tag, (hipStream_t)stream);
 }
 
 int xmpi_iallreduce(xmpi_comm* c, const void* sendbuf, void* recvbuf, size_t count, xmpi_dtype dtype, xmpi_op op, int algo,
@@ -1103,9 +1169,8 @@ int xmpi_allreduce_repeat(xmpi_comm* c, const void* sendbuf, void* recvbuf, size
   // Ranks that meet on the device: the steps are ENQUEUED back to back on the communicator's stream and waited for
   // once -- what a stream-ordered caller does, and what the device rendezvous is for (no host round trip per
   // step).  Launches that are sampled for profiling stay blocking: their events are read right after them.
-  const bool on_device = dsync_usable(c) && count > 0 && sendbuf && recvbuf && xmpi_dtype_size(dtype) &&
-                         (algo == XMPI_ALGO_ZCOPY || algo == XMPI_ALGO_ZPUSH || (algo == XMPI_ALGO_AUTO && c->zero_copy)) &&
-                         is_device_pointer(sendbuf) && is_device_pointer(recvbuf);
+  const bool on_device = count > 0 && sendbuf && recvbuf && xmpi_dtype_size(dtype) && algo >= 0 && algo < XMPI_ALGO_COUNT &&
+                         dsync_takes(c, COLL_ALLREDUCE, algo) && is_device_pointer(sendbuf) && is_device_pointer(recvbuf);
   if (on_device) {
     drain_worker(c);
     std::lock_guard<std::mutex> g(c->coll_mu);
@@ -1113,7 +1178,7 @@ int xmpi_allreduce_repeat(xmpi_comm* c, const void* sendbuf, void* recvbuf, size
       const bool sampled = c->prof_on && (c->prof_seq[PROF_ZCOPY] % (uint64_t)std::max<long>(1, c->prof_every)) == 0;
       if (!sampled && c->prof_on) c->prof_seq[PROF_ZCOPY]++;  // (a blocking call counts itself)
       const int rc = dsync_collective(c, COLL_ALLREDUCE, 0, sendbuf, recvbuf, count, (int)dtype, (int)op, c->local_stream,
-                                      /*blocking=*/sampled || i == iters - 1, /*push=*/algo == XMPI_ALGO_ZPUSH);
+                                      /*blocking=*/sampled || i == iters - 1, algo);
       if (rc != XMPI_OK) return rc;
     }
     return XMPI_OK;
@@ -1330,6 +1395,11 @@ int xmpi_set_param(xmpi_comm* c, const char* name, long value) {
   else if (n == "dsync_grid") c->dsync_grid_cap = std::max<long>(0, value);
   else if (n == "dsync_unroll") c->dsync_unroll = std::max<long>(1, std::min<long>(2, value));
   else if (n == "dsync_tiles") c->dsync_tiles = std::max<long>(1, value);
+  else if (n == "dsync_split_bytes") c->dsync_split_bytes = std::max<long>(0, value);  // 0: always one kernel
+  else if (n == "sched_channels") c->sched_channels = std::max<long>(0, value);
+  else if (n == "sched_grid") c->sched_grid = std::max<long>(0, value);
+  else if (n == "tree_piece_bytes") c->tree_piece_bytes = std::max<long>(4096, value);
+  else if (n == "tuned") c->tuned = value != 0;  // 0: AUTO forgets the table of xmpi_tune
   else if (n == "kernel_mode") set_kernel_mode((int)value);  // process-wide
   else if (n == "grid_cap") set_grid_cap((int)value);        // process-wide
   else return XMPI_ERR_ARG;
@@ -1362,6 +1432,26 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
   if (n == "dsync_bounced") return (long)c->dsync_bounced;
   if (n == "dsync_sharers") return c->dsync_sharers;
   if (n == "dsync_unroll") return c->dsync_unroll;
+  if (n == "dsync_tiles") return c->dsync_tiles;
+  if (n == "dsync_grid") return c->dsync_grid_cap;
+  if (n == "dsync_split_bytes") return c->dsync_split_bytes;
+  if (n == "dsync_split_launches") return (long)c->dsync_split_launches;
+  if (n == "dsync_sched_launches") return (long)c->dsync_sched_launches;
+  if (n == "sched_channels") return c->sched_channels;
+  if (n == "sched_grid") return c->sched_grid;
+  if (n == "tree_piece_bytes") return c->tree_piece_bytes;
+  if (n == "tuned") return c->tuned ? 1 : 0;
+  if (n.rfind("tune_", 0) == 0) {  // tune_<algo|split|unroll>_<collective 0..3>_<size class>: the table of xmpi_tune
+    int coll = -1, cls = -1;
+    char what[16] = {0};
+    if (sscanf(name, "tune_%15[a-z]_%d_%d", what, &coll, &cls) == 3 && coll >= 0 && coll < 4 && cls >= 0 && cls < xmpi_comm::kTuneClasses) {
+      const std::string w = what;
+      if (w == "algo") return c->tune_algo[coll][cls];
+      if (w == "split") return c->tune_split[coll][cls];
+      if (w == "unroll") return c->tune_unroll[coll][cls];
+    }
+    return -1;
+  }
   if (n == "p2p_direct_count") return (long)c->p2p_direct_count;
   if (n == "p2p_staged_count") return (long)c->p2p_staged_count;
   if (n == "zc_seq") return (long)c->zc_seq;
@@ -1586,6 +1676,119 @@ int xmpi_ctl_selftest(const char* job_key, int rank, int size, int rounds) {
   else rc = ctl->barrier(30.0);
   delete ctl;
   return rc;
+}
+
+// ---- the library's own schedule table ---------------------------------------------------------------------------------
+
+// Which of n candidates (mean times in microseconds; <= 0 = did not run) AUTO should take: the fastest -- but the default
+// (index 0) stays unless another one beats it by more than `margin` (a fraction: noise must not flip the schedule).
+int xmpi_tune_decide(const double* us, int n, double margin) {
+  if (!us || n < 1) return -1;
+  int best = -1;
+  for (int i = 0; i < n; i++)
+    if (us[i] > 0 && (best < 0 || us[i] < us[best])) best = i;
+  if (best < 0) return -1;
+  if (best != 0 && us[0] > 0 && us[best] >= us[0] * (1.0 - (margin > 0 ? margin : 0.0))) return 0;
+  return best;
+}
+
+// Times the schedules this job's layout offers for allreduce-sum f32 (and allgather) on the real buffers, size class by size
+// class, lets every rank see the same (max over ranks) figures and fills the table AUTO consults (dsync.cpp tuned_choice).
+// Collective: every rank calls it with the same max_bytes.  With ranks that meet on the host there is nothing to choose.
+int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
+  XMPI_ENTER(c);
+  drain_worker(c);
+  if (!dsync_usable(c) || c->size < 2) return XMPI_OK;
+  max_bytes = std::min<size_t>(std::max<size_t>(max_bytes, 1024), (size_t)1 << 30);
+  void* send = heap_alloc(c->device, max_bytes);
+  void* recv = heap_alloc(c->device, max_bytes);
+  if (!send || !recv) {
+    if (send) (void)heap_free(send);
+    if (recv) (void)heap_free(recv);
+    set_last_error("xmpi_tune: out of device memory");
+    return XMPI_ERR_NOMEM;
+  }
+  int rc = XMPI_OK;
+  {
+    std::lock_guard<std::mutex> g(c->coll_mu);
+    if (hipMemsetAsync(send, 0, max_bytes, c->local_stream) != hipSuccess || hipStreamSynchronize(c->local_stream) != hipSuccess)
+      rc = hip_fail(hipGetLastError(), "hipMemset", __FILE__, __LINE__);
+  }
+  struct Cand {
+    int algo, split, unroll;
+  };
+  const int u0 = (int)std::max<long>(1, std::min<long>(2, c->dsync_unroll));
+  std::vector<Cand> cands = {{XMPI_ALGO_ZCOPY, 0, u0},  // the default comes first (xmpi_tune_decide keeps it on a tie)
+                             {XMPI_ALGO_ZCOPY, 0, 3 - u0},
+                             {XMPI_ALGO_ZCOPY, 1, u0},
+                             {XMPI_ALGO_ZPUSH, 0, u0},
+                             {XMPI_ALGO_RING, 0, u0}};
+  if ((c->size & (c->size - 1)) == 0) cands.push_back({XMPI_ALGO_RHD, 0, u0});
+  const long keep_split = c->dsync_split_bytes, keep_unroll = c->dsync_unroll;
+  const bool keep_tuned = c->tuned;
+  c->tuned = false;
+  memset(c->tune_algo, -1, sizeof c->tune_algo);
+  memset(c->tune_split, -1, sizeof c->tune_split);
+  memset(c->tune_unroll, 0, sizeof c->tune_unroll);
+  for (int coll : {(int)COLL_ALLREDUCE, (int)COLL_ALLGATHER}) {
+    for (size_t bytes = 1024; bytes <= max_bytes && rc == XMPI_OK; bytes *= 4) {
+      const size_t per_rank = coll == COLL_ALLGATHER ? bytes / (size_t)c->size / 16 * 16 : bytes;
+      if (per_rank < 16) continue;
+      const int iters = bytes <= ((size_t)1 << 20) ? 20 : (bytes <= ((size_t)32 << 20) ? 6 : 3);
+      std::vector<double> us(cands.size(), 0.0), worst(cands.size(), 0.0);
+      for (size_t k = 0; k < cands.size() && rc == XMPI_OK; k++) {
+        const Cand& cd = cands[k];
+        if (coll == COLL_ALLGATHER && (cd.algo == XMPI_ALGO_ZPUSH || cd.algo == XMPI_ALGO_RHD || cd.unroll != u0)) continue;
+        rc = xmpi_barrier(c);
+        if (rc != XMPI_OK) break;
+        std::lock_guard<std::mutex> g(c->coll_mu);
+        c->dsync_split_bytes = cd.split ? 1 : 0;
+        c->dsync_unroll = cd.unroll;
+        double t0 = 0;
+        for (int i = -1; i < iters && rc == XMPI_OK; i++) {  // i = -1: a warm-up that also maps whatever is new
+          if (i == 0) t0 = now_seconds();
+          rc = dsync_collective(c, coll, 0, send, recv, per_rank / 4, XMPI_F32, XMPI_SUM, c->local_stream,
+                                /*blocking=*/i == -1 || i == iters - 1, cd.algo);
+        }
+        us[k] = (now_seconds() - t0) / iters * 1e6;
+        c->dsync_split_bytes = keep_split;
+        c->dsync_unroll = keep_unroll;
+      }
+      if (rc != XMPI_OK) break;
+      // every rank must read the same figures: the slowest rank's
+      rc = collective(c, COLL_ALLREDUCE, XMPI_ALGO_DIRECT, 0, us.data(), worst.data(), us.size(), XMPI_F64, XMPI_MAX);
+      if (rc != XMPI_OK) break;
+      const int best = xmpi_tune_decide(worst.data(), (int)worst.size(), 0.03);
+      if (best < 0) continue;
+      int k = 0;
+      while (k + 1 < xmpi_comm::kTuneClasses && (per_rank >> (k + 9)) != 0) k++;
+      for (int kk = k; kk < xmpi_comm::kTuneClasses && kk < k + 2; kk++) {  // this class and the one to the next measured size
+        c->tune_algo[coll][kk] = (int8_t)cands[(size_t)best].algo;
+        c->tune_split[coll][kk] = (int8_t)cands[(size_t)best].split;
+        c->tune_unroll[coll][kk] = (int8_t)cands[(size_t)best].unroll;
+      }
+      for (int kk = k + 2; kk < xmpi_comm::kTuneClasses; kk++) {  // beyond the largest measured size: what won there
+        c->tune_algo[coll][kk] = c->tune_algo[coll][k];
+        c->tune_split[coll][kk] = c->tune_split[coll][k];
+        c->tune_unroll[coll][kk] = c->tune_unroll[coll][k];
+      }
+    }
+  }
+  c->dsync_split_bytes = keep_split;
+  c->dsync_unroll = keep_unroll;
+  (void)heap_free(send);
+  (void)heap_free(recv);
+  if (rc != XMPI_OK) {
+    c->tuned = keep_tuned;
+    return rc;
+  }
+  // reduce and bcast move like the allreduce's two halves: they inherit the split rule, not the algorithm
+  for (int kk = 0; kk < xmpi_comm::kTuneClasses; kk++) {
+    c->tune_split[COLL_REDUCE][kk] = c->tune_algo[COLL_ALLREDUCE][kk] == XMPI_ALGO_ZCOPY ? c->tune_split[COLL_ALLREDUCE][kk] : (int8_t)-1;
+    c->tune_split[COLL_BCAST][kk] = -1;
+  }
+  c->tuned = true;
+  return xmpi_barrier(c);
 }
 
 int xmpi_plan_dump(int coll, int algo, int size, int rank, int root, size_t count, size_t elem_size, int channels,

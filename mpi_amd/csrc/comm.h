@@ -104,7 +104,36 @@ struct xmpi_comm {
   xmpi::DsyncPage* peer_page[xmpi::kMaxRanks] = {nullptr};  // everybody's, as addressable from here
   bool peer_page_opened[xmpi::kMaxRanks] = {false};
   const int32_t* dsync_abort_dev = nullptr;  // the job's abort flag as the GPU reads it
-  bool dsync_ctl_registered = false;
+  char* ctl_dev = nullptr;        // the control block as the GPU addresses it (hipHostRegister; kernels read the abort flag and
+  bool ctl_registered = false;    //   write the ack of a point-to-point message straight into its mail entry)
+  xmpi::DsyncResolved* dsync_res = nullptr;  // split form: what the meet kernel leaves for the data kernel (device memory)
+  hipEvent_t dsync_order_ev = nullptr;       // recorded behind every device-synchronised launch: a launch on ANOTHER stream waits for it
+  hipStream_t dsync_last_stream = nullptr;   //   (the kernels of one rank share the page's epoch, ticket and slots: one at a time)
+  long dsync_split_bytes = 8 << 20;  // collectives moving at least this much per rank run as meet / body / done (0 = never)
+  long sched_channels = 0;           // ring channels of the stepped kernels; 0 = every link direction (1 when ranks share a GPU)
+  long sched_grid = 0;               // workers (blocks) of a stepped kernel; 0 = by size, bounded like dsync_grid_cap
+  long tree_piece_bytes = 256 << 10; // binary-tree broadcast: pieces of this size travel down the tree pipelined
+  // stream-ordered Send / Receive (dsync.cpp p2p_*_on_stream): message numbers per ordered pair, completion words
+  uint64_t p2p_out_seq[xmpi::kMaxRanks] = {0};
+  uint64_t p2p_op_id = 0;
+  static constexpr int kP2PDoneSlots = 64;
+  uint64_t* p2p_done = nullptr;      // pinned host: 4 words per slot {done id, status, bytes, -}
+  uint64_t* p2p_done_dev = nullptr;
+  uint64_t p2p_done_next = 0;
+  struct P2PPending {
+    int slot;
+    uint64_t id;
+    std::vector<void*> bufs;  // stand-ins to give back
+  };
+  std::vector<P2PPending> p2p_pending;  // stream-ordered operations whose completion nobody has looked at yet
+  uint32_t* p2p_tickets = nullptr;      // device: block counters of the pull kernels (blocking Receive)
+  uint64_t p2p_pull_seq = 0;
+  // the library's own schedule table (xmpi_tune): algorithm per collective and size class, agreed by all ranks
+  static constexpr int kTuneClasses = 24;  // class k: messages of [2^(k+8), 2^(k+9)) bytes per rank
+  int8_t tune_algo[4][kTuneClasses];       // [collective][class]: an xmpi_algo, or -1 = not tuned (built-in rule)
+  int8_t tune_split[4][kTuneClasses];      // 1 = split form, 0 = one kernel, -1 = by dsync_split_bytes
+  int8_t tune_unroll[4][kTuneClasses];
+  bool tuned = false;
   uint32_t* dsync_status = nullptr;          // pinned host word a kernel writes its first failure to ...
   uint32_t* dsync_status_dev = nullptr;      // ... and its device address
   int dsync_sharers = 1;         // ranks of this job on this rank's GPU (bounds the grid: their kernels spin together)
@@ -115,6 +144,7 @@ struct xmpi_comm {
   uint64_t dsync_base = 0;       // where this communicator's epochs start (epoch_floor of its kernels)
   uint64_t dsync_tag = 1;        // tags this communicator's entries in the (pooled, uncleared) page's translation cache
   uint64_t dsync_launches = 0, dsync_bounced = 0;  // diagnostics: kernels; buffers stood in for by arena blocks
+  uint64_t dsync_split_launches = 0, dsync_sched_launches = 0;  // ... collectives run as meet / body / done; as a stepped kernel
   xmpi::DsyncEntry* dsync_table = nullptr;            // [kMaxRanks][kDsyncArenas], pinned host memory the kernels read
   const xmpi::DsyncEntry* dsync_table_dev = nullptr;  // ... as the GPU addresses it
   uint64_t dsync_seen[xmpi::kMaxRanks] = {0};         // published entries of each peer processed so far
@@ -209,8 +239,14 @@ void dsync_finalize(xmpi_comm* c);
 void dsync_stop_helper(xmpi_comm* c);
 void dsync_service(xmpi_comm* c);
 bool dsync_usable(const xmpi_comm* c);
+// algo: AUTO / ZCOPY (one fold per rank: one kernel, or meet / body / done), ZPUSH, RING, RHD, TREE (the stepped kernels)
 int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void* recvbuf, size_t count, int dtype,
-                     int op, hipStream_t stream, bool blocking, bool push = false);
+                     int op, hipStream_t stream, bool blocking, int algo = 0);
+bool dsync_takes(const xmpi_comm* c, int coll, int algo);
+void dsync_graph_launched(xmpi_comm* c, hipStream_t stream, bool before);
+int dsync_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, int tag, hipStream_t stream);
+int dsync_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int tag, hipStream_t stream);
+int dsync_p2p_reap(xmpi_comm* c);
 int dsync_check(xmpi_comm* c);
 // a rank that waits keeps serving its peers
 inline void arm(Backoff& bo, xmpi_comm* c) {

@@ -31,8 +31,8 @@
 namespace xmpi {
 
 static_assert(kDsyncRanks == kMaxRanks, "dsync tables are sized by kMaxRanks");
-static_assert(sizeof(DsyncPage) <= 65536, "flag page");
-constexpr size_t kPageBytes = 65536;
+static_assert(sizeof(DsyncPage) <= kStepOff, "flag page");
+constexpr size_t kPageBytes = kDsyncPageBytes;  // the page, the step flags of the stepped kernels, the Send / Receive boxes
 
 namespace {
 
@@ -121,10 +121,17 @@ int dsync_connect(xmpi_comm* c) {
     c->dsync_table_dev = (const DsyncEntry*)dev;
   }
   // the job's abort flag, readable by the GPU: a kernel that waits for a dead peer gives up
-  if (hipHostRegister(c->ctl->base(), 4096, hipHostRegisterMapped) == hipSuccess) {
+  if (c->ctl_dev) c->dsync_abort_dev = (const int32_t*)(c->ctl_dev + ((char*)&c->ctl->header()->abort_code - (char*)c->ctl->base()));
+  // split form (sched.hip): what the meet kernel resolves for the data kernel, in ordinary device memory
+  if (hipMalloc((void**)&c->dsync_res, sizeof(DsyncResolved)) != hipSuccess)
+    return hip_fail(hipGetLastError(), "hipMalloc(resolved table)", __FILE__, __LINE__);
+  if (hipEventCreateWithFlags(&c->dsync_order_ev, hipEventDisableTiming) != hipSuccess)
+    return hip_fail(hipGetLastError(), "hipEventCreate", __FILE__, __LINE__);
+  // completion words of the stream-ordered Send / Receive kernels (pinned host memory the GPU writes, the host polls)
+  if (hipHostMalloc((void**)&c->p2p_done, sizeof(uint64_t) * 4 * xmpi_comm::kP2PDoneSlots, hipHostMallocMapped) == hipSuccess) {
+    memset(c->p2p_done, 0, sizeof(uint64_t) * 4 * xmpi_comm::kP2PDoneSlots);
     void* dev = nullptr;
-    if (hipHostGetDevicePointer(&dev, &c->ctl->header()->abort_code, 0) == hipSuccess) c->dsync_abort_dev = (const int32_t*)dev;
-    c->dsync_ctl_registered = true;
+    if (hipHostGetDevicePointer(&dev, c->p2p_done, 0) == hipSuccess) c->p2p_done_dev = (uint64_t*)dev;
   }
   (void)hipGetLastError();
   if (hipHostMalloc((void**)&c->dsync_status, 64, hipHostMallocMapped) == hipSuccess) {
@@ -172,14 +179,23 @@ void dsync_finalize(xmpi_comm* c) {
   // the next user of the page starts above the last epoch written into it (graph replays are counted on the device:
   // the kernels copy the page's counter into the pinned status area)
   uint64_t last = c->dsync_epoch;
+  if (c->ctl) last = std::max<uint64_t>(last, c->ctl->info(c->rank)->flag_epoch);  // (a communicator that never got going)
   if (c->dsync_status) last = std::max<uint64_t>(last, __atomic_load_n((const uint64_t*)(c->dsync_status + 2), __ATOMIC_ACQUIRE));
   for (int p = 0; p < c->size; p++)
     if (c->peer_page_opened[p]) ipc_close_shared(c->peer_page[p]);
-  if (c->dsync_ctl_registered) (void)hipHostUnregister(c->ctl->base());
   if (c->dsync_status) (void)hipHostFree(c->dsync_status);
   c->dsync_status = nullptr;
+  if (c->p2p_done) (void)hipHostFree(c->p2p_done);
+  c->p2p_done = nullptr;
+  if (c->dsync_res) (void)hipFree(c->dsync_res);
+  c->dsync_res = nullptr;
+  if (c->dsync_order_ev) (void)hipEventDestroy(c->dsync_order_ev);
+  c->dsync_order_ev = nullptr;
   if (c->dsync_table) (void)hipHostFree(c->dsync_table);
   c->dsync_table = nullptr;
+  for (auto& p : c->p2p_pending)
+    for (void* b : p.bufs) (void)heap_free(b);
+  c->p2p_pending.clear();
   for (auto& b : c->dsync_deferred) {
     (void)hipEventDestroy(b.done);
     for (void* p : b.bufs) (void)heap_free(p);
@@ -241,7 +257,7 @@ namespace {
 
 // the slot of my translation-table row that holds registration `gen`; publishes it if need be.
 // *pub_index = how many published entries a peer must have processed to know it.
-int publish(xmpi_comm* c, const BufRef& ref, int* slot_out, uint64_t* pub_index) {
+int publish(xmpi_comm* c, const BufRef& ref, int* slot_out, uint64_t* pub_index, bool capturing = false) {
   for (int s = 0; s < kDsyncArenas; s++)
     if (c->dsync_slot_gen[s] == ref.gen) {
       c->dsync_slot_used[s] = c->dsync_epoch + 1;
@@ -261,6 +277,10 @@ int publish(xmpi_comm* c, const BufRef& ref, int* slot_out, uint64_t* pub_index)
   if (slot < 0) {
     // all slots hold live registrations: re-use the one that has not been used for longest.  Collectives in
     // flight may still name it -- let them finish first (this is rare: > 32 registered allocations in use).
+    if (capturing) {  // a synchronisation is not allowed while a stream of the thread captures
+      set_last_error("graph capture: the buffer's registration has no translation slot yet (use it in one collective before capturing)");
+      return XMPI_ERR_ARG;
+    }
     XMPI_HIP(hipDeviceSynchronize());
     slot = 0;
     for (int s = 1; s < kDsyncArenas; s++)
@@ -327,7 +347,7 @@ void reap_deferred(xmpi_comm* c, bool wait) {
   for (size_t i = 0; i < c->dsync_deferred.size();) {
     auto& b = c->dsync_deferred[i];
     hipError_t e = wait ? hipEventSynchronize(b.done) : hipEventQuery(b.done);
-    if (e == hipErrorNotReady) {
+    if (e != hipSuccess) {  // not passed yet -- or not knowable (an error): the blocks stay lent rather than be re-used under a kernel
       (void)hipGetLastError();
       i++;
       continue;
@@ -350,10 +370,16 @@ struct Resolved {
 
 bool dsync_usable(const xmpi_comm* c) { return c->dsync_ok && c->dsync && c->size > 1; }
 
+// blocks a kernel of this rank may keep waiting at once: the kernels of all ranks on one GPU spin together, so with
+// several ranks per GPU they must all be resident (half of its 8192 wave slots, 4 waves per block, shared); a rank that
+// has its GPU to itself may fill it -- blocks that are not resident yet only start later, nothing waits for them
+static long dsync_block_cap(const xmpi_comm* c) {
+  if (c->dsync_grid_cap > 0) return c->dsync_grid_cap;
+  return c->dsync_sharers > 1 ? 1024 / c->dsync_sharers : 2048;
+}
+
 int dsync_grid(const xmpi_comm* c, size_t packets_per_segment, int nseg, int unroll) {
-  // blocks of all ranks on this GPU fit in half of its wave slots (256 CUs x 32 waves, 4 waves per block)
-  long cap = c->dsync_grid_cap > 0 ? c->dsync_grid_cap : 1024 / c->dsync_sharers;
-  cap = std::max<long>(1, cap / std::max(1, nseg));
+  long cap = std::max<long>(1, dsync_block_cap(c) / std::max(1, nseg));
   // several tiles per block: every block costs seven polling lanes on this rank's page and a ticket, which is what a
   // small collective spends its time on (8 processes, 1 MiB: 32 blocks per rank -> 84 us, see profiles/README.md)
   const size_t per_block = (size_t)256 * (size_t)std::max(1, unroll) * (size_t)std::max<long>(1, c->dsync_tiles);
@@ -361,11 +387,50 @@ int dsync_grid(const xmpi_comm* c, size_t packets_per_segment, int nseg, int unr
   return (int)std::max<size_t>(1, std::min<size_t>(want, (size_t)cap));
 }
 
+// which calls the device-synchronised path takes (the same answer on every rank: it depends on the job's layout
+// and the arguments only)
+bool dsync_takes(const xmpi_comm* c, int coll, int algo) {
+  if (!dsync_usable(c)) return false;
+  switch (algo) {
+    case XMPI_ALGO_AUTO: return c->zero_copy != 0;
+    case XMPI_ALGO_ZCOPY:
+    case XMPI_ALGO_ZPUSH: return true;
+    case XMPI_ALGO_RING: return coll == COLL_ALLREDUCE || coll == COLL_ALLGATHER;  // the stepped kernels (sched.hip)
+    case XMPI_ALGO_RHD: return coll == COLL_ALLREDUCE;
+    case XMPI_ALGO_TREE: return coll == COLL_BCAST;
+    default: return false;
+  }
+}
+
+// hipGraphLaunch of a captured sequence of collectives is a device-synchronised launch like any other: it is ordered
+// against the rank's other streams (before = true: ahead of the launch; false: behind it)
+void dsync_graph_launched(xmpi_comm* c, hipStream_t stream, bool before) {
+  if (!c->dsync_ok || !c->dsync_order_ev) return;
+  if (before) {
+    if (c->dsync_last_stream && c->dsync_last_stream != stream) (void)hipStreamWaitEvent(stream, c->dsync_order_ev, 0);
+  } else {
+    (void)hipEventRecord(c->dsync_order_ev, stream);
+    c->dsync_last_stream = stream;
+  }
+  (void)hipGetLastError();
+}
+
+// the library's schedule for an AUTO call (xmpi_tune fills the table; untuned: the zero-copy fold, split by size)
+static void tuned_choice(const xmpi_comm* c, int coll, size_t bytes, int* algo, int* split, int* unroll) {
+  int k = 0;
+  while (k + 1 < xmpi_comm::kTuneClasses && (bytes >> (k + 9)) != 0) k++;
+  if (c->tuned && coll >= 0 && coll < 4) {
+    if (c->tune_algo[coll][k] >= 0) *algo = c->tune_algo[coll][k];
+    if (c->tune_split[coll][k] >= 0) *split = c->tune_split[coll][k];
+    if (c->tune_unroll[coll][k] > 0) *unroll = c->tune_unroll[coll][k];
+  }
+}
+
 // One device-synchronised collective, enqueued on `stream`.  blocking: wait for it (the xmpi_allreduce family);
 // otherwise return once it is enqueued (xmpi_*_on_stream).  Every rank of the job takes this path for the same
 // calls (the decision depends on the communicator and the arguments only), so the epochs agree.
 int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void* recvbuf, size_t count, int dtype,
-                     int op, hipStream_t stream, bool blocking, bool push) {
+                     int op, hipStream_t stream, bool blocking, int algo) {
   const int N = c->size, me = c->rank;
   const size_t es = xmpi_dtype_size((xmpi_dtype)dtype);
   const size_t send_bytes = count * es;
@@ -374,6 +439,18 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
   if (!stream) stream = c->local_stream;
   dsync_service(c);
   reap_deferred(c, false);
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(stream, &cap);
+  (void)hipGetLastError();
+  const bool capturing = cap != hipStreamCaptureStatusNone;
+
+  // the schedule: what the caller named, or the library's own table
+  int split_pref = -1, unroll = (int)std::max<long>(1, std::min<long>(2, c->dsync_unroll));
+  if (algo == XMPI_ALGO_AUTO) tuned_choice(c, coll, send_bytes, &algo, &split_pref, &unroll);
+  if (algo == XMPI_ALGO_RHD && (N & (N - 1)) != 0) algo = XMPI_ALGO_RING;  // halving needs a power of two
+  const bool stepped = (algo == XMPI_ALGO_RING && (coll == COLL_ALLREDUCE || coll == COLL_ALLGATHER)) ||
+                       (algo == XMPI_ALGO_RHD && coll == COLL_ALLREDUCE) || (algo == XMPI_ALGO_TREE && coll == COLL_BCAST);
+  const bool push = algo == XMPI_ALGO_ZPUSH;
 
   // 1. buffers the peers can map.  Anything else -- host memory, device memory that was never registered --
   //    is stood in for by a block of a registered arena (one local copy in, one out); the collective itself is
@@ -388,7 +465,13 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     c->ctl->set_abort(rc);
     return rc;
   };
+  // a capture bakes addresses into the graph: a stand-in would be given back to the arena while replays still use it
+  auto no_standin = [&]() {
+    set_last_error("graph capture needs registered device buffers (xmpi_malloc / xmpi_register)");
+    return XMPI_ERR_ARG;
+  };
   if (!zc_export(c, r.send, send_bytes, &r.sref)) {
+    if (capturing) return no_standin();
     r.tmp_send = heap_alloc(c->device, send_bytes);
     if (!r.tmp_send) return fail(XMPI_ERR_NOMEM);
     lent.push_back(r.tmp_send);
@@ -402,6 +485,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     r.recv = const_cast<void*>(r.send);
     r.rref = r.sref;
   } else if (!zc_export(c, r.recv, recv_bytes, &r.rref)) {
+    if (capturing) return no_standin();
     r.tmp_recv = heap_alloc(c->device, recv_bytes);
     if (!r.tmp_recv) return fail(XMPI_ERR_NOMEM);
     lent.push_back(r.tmp_recv);
@@ -413,14 +497,18 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
   // 2. the peers know the allocations
   int sslot = 0, rslot = 0;
   uint64_t need = 0, pi = 0;
-  int rc = publish(c, r.sref, &sslot, &pi);
+  int rc = publish(c, r.sref, &sslot, &pi, capturing);
   if (rc) return fail(rc);
   need = std::max(need, pi);
-  rc = publish(c, r.rref, &rslot, &pi);
+  rc = publish(c, r.rref, &rslot, &pi, capturing);
   if (rc) return fail(rc);
   need = std::max(need, pi);
   rc = await_acks(c, need);
   if (rc) return fail(rc);
+
+  // the kernels of one rank share the page's epoch counter, ticket and slots: one at a time.  On one stream that is
+  // stream order; a launch on another stream than the previous one waits for it (an event behind every launch).
+  if (!capturing && c->dsync_last_stream && c->dsync_last_stream != stream) XMPI_HIP(hipStreamWaitEvent(stream, c->dsync_order_ev, 0));
 
   // 3. the kernel(s)
   DsyncArgs a;
@@ -445,26 +533,90 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
   a.spin_limit = c->timeout_s > 0 ? (uint64_t)c->timeout_s * 100000000ull : 0;  // wall_clock64 ticks at 100 MHz
   const uint32_t everyone = N >= 32 ? 0xffffffffu : ((1u << N) - 1u);
   const size_t al = std::max<size_t>(1, 16 / es);
-  const int unroll = (int)std::max<long>(1, std::min<long>(2, c->dsync_unroll));
 
   hipEvent_t pstart = nullptr, pstop = nullptr;
   const bool sampled = blocking && c->prof_on && (c->prof_seq[PROF_ZCOPY]++ % (uint64_t)std::max<long>(1, c->prof_every)) == 0;
   size_t traffic = 0;
-  auto launch = [&](int nsrc, int kdtype, int kop, size_t packets) -> int {
-    ++c->dsync_epoch;  // the host's count (the kernels count for themselves, from the page: see epoch_floor)
-    const int gx = a.nseg > 0 ? dsync_grid(c, packets, a.nseg, unroll) : 1;
+  auto prof_events = [&]() -> bool {
     if (sampled && !pstart) {
       pstart = ev_get(c, true);
       pstop = ev_get(c, true);
-      if (!pstart || !pstop) return XMPI_ERR_HIP;
+      if (!pstart || !pstop) return false;
     }
+    return true;
+  };
+  // one rendezvous + data movement + completion exchange: ONE kernel, or -- large messages -- meet / body / done
+  auto launch = [&](int nsrc, int kdtype, int kop, size_t packets, size_t bytes_moved) -> int {
+    ++c->dsync_epoch;  // the host's count (the kernels count for themselves, from the page: see epoch_floor)
+    if (!prof_events()) return XMPI_ERR_HIP;
+    const bool split = a.nseg > 0 && c->dsync_res &&
+                       (split_pref >= 0 ? split_pref != 0 : (c->dsync_split_bytes > 0 && bytes_moved >= (size_t)c->dsync_split_bytes));
+    if (split) {
+      XMPI_HIP(launch_dsync_meet(a, c->dsync_res, stream));
+      XMPI_HIP(launch_dsync_body(c->dsync_res, a.nseg, packets + 1, nsrc, kdtype, kop, bytes_moved, stream, sampled ? pstart : nullptr,
+                                 sampled ? pstop : nullptr));
+      XMPI_HIP(launch_dsync_done(a, c->dsync_res, stream));
+      c->dsync_launches += 3;
+      c->dsync_split_launches++;
+      return XMPI_OK;
+    }
+    const int gx = a.nseg > 0 ? dsync_grid(c, packets, a.nseg, unroll) : 1;
     XMPI_HIP(launch_dsync_fold(a, nsrc, kdtype, kop, gx, unroll, stream, sampled ? pstart : nullptr, sampled ? pstop : nullptr));
     c->dsync_launches++;
     return XMPI_OK;
   };
 
   const bool use_push = push && coll == COLL_ALLREDUCE && r.send != r.recv && count % ((size_t)N * al) == 0;
-  if (use_push) {
+  if (stepped) {
+    // ring / recursive halving + doubling / binary tree: ONE kernel per rank runs every step of the schedule, the steps
+    // released by flag words between the peers' kernels (sched.hip) -- the schedules north_star names, without a host
+    // between their steps
+    DsyncSchedArgs sa;
+    memset(&sa, 0, sizeof sa);
+    sa.d = a;
+    sa.root = root;
+    sa.count = count;
+    sa.elem_size = (uint32_t)es;
+    sa.pieces = 1;
+    size_t step_bytes = send_bytes;  // what the largest step of the schedule moves
+    int nchan = 1;
+    if (algo == XMPI_ALGO_RING) {
+      sa.sched = coll == COLL_ALLREDUCE ? SCHED_RING_ALLREDUCE : SCHED_RING_ALLGATHER;
+      step_bytes = coll == COLL_ALLREDUCE ? (send_bytes + (size_t)N - 1) / (size_t)N : send_bytes;
+      // every channel is a different cyclic order of the ranks (plan.cpp ring_order: on an even mesh N-2 directed rings
+      // that share no link direction); ranks sharing a GPU have no links to spread over
+      const int avail = std::min(ring_channel_count(N), kMaxSchedChannels);
+      nchan = c->sched_channels > 0 ? (int)std::min<long>(c->sched_channels, avail) : (c->dsync_sharers > 1 ? 1 : avail);
+      traffic = coll == COLL_ALLREDUCE ? 5 * (size_t)(N - 1) * step_bytes : 2 * (size_t)N * send_bytes;
+    } else if (algo == XMPI_ALGO_RHD) {
+      sa.sched = SCHED_RHD_ALLREDUCE;
+      step_bytes = send_bytes / 2;
+      traffic = 5 * (send_bytes - send_bytes / (size_t)N);  // halving: 3 x (S/2 + S/4 + ...), doubling: 2 x the same
+    } else {
+      sa.sched = SCHED_TREE_BCAST;
+      const size_t piece = (size_t)std::max<long>(4096, c->tree_piece_bytes);
+      sa.pieces = (int)std::min<size_t>(32, std::max<size_t>(1, (send_bytes + piece - 1) / piece));
+      step_bytes = (send_bytes + (size_t)sa.pieces - 1) / (size_t)sa.pieces;
+      traffic = me == root ? 0 : 2 * send_bytes;
+    }
+    const size_t tiles = std::max<size_t>(1, (step_bytes + kSchedTileBytes - 1) / kSchedTileBytes);
+    long workers = c->sched_grid > 0 ? c->sched_grid : (long)std::min<size_t>(tiles, (size_t)dsync_block_cap(c));
+    workers = std::max<long>(1, std::min<long>(workers, kStepSlots));
+    nchan = (int)std::max<long>(1, std::min<long>(nchan, workers));
+    const int gx = (int)std::max<long>(1, workers / nchan);
+    sa.nchan = nchan;
+    for (int ch = 0; ch < nchan; ch++) {
+      std::vector<int> ord;
+      ring_order(N, ch, &ord);
+      for (int i = 0; i < N; i++) sa.order[ch][i] = (uint8_t)ord[(size_t)i];
+    }
+    ++c->dsync_epoch;
+    if (!prof_events()) return fail(XMPI_ERR_HIP);
+    XMPI_HIP(launch_dsync_sched(sa, dtype, op, gx, stream, sampled ? pstart : nullptr, sampled ? pstop : nullptr));
+    c->dsync_launches++;
+    c->dsync_sched_launches++;
+    rc = XMPI_OK;
+  } else if (use_push) {
     // Write-only variant (XMPI_ALGO_ZPUSH): nothing is READ over xGMI -- loads over a link are round trips, stores are
     // posted.  The receive buffer of rank q is its own staging area: region p (p != q) receives rank p's contribution
     // to chunk q, region q is where q folds them in rank order; then every rank pushes its folded chunk to everybody.
@@ -472,6 +624,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     // has landed; kernel 3's rendezvous is every peer saying "my fold has read its staging regions").  Needs
     // out-of-place buffers and equal chunks; otherwise the read-based form below runs.
     const size_t C = count / (size_t)N, cb = C * es;
+    split_pref = 0;  // (the pushes are small next to the fold; their rendezvous is what orders the three kernels)
     for (int q = 0; q < N; q++) {
       if (q == me) continue;
       DsyncSeg& g = a.seg[a.nseg++];
@@ -482,7 +635,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
       g.dst_mask = 1u << q;
     }
     traffic = 2 * (size_t)(N - 1) * cb;
-    rc = launch(1, XMPI_U8, XMPI_SUM, cb / 16);
+    rc = launch(1, XMPI_U8, XMPI_SUM, cb / 16, 2 * (size_t)(N - 1) * cb);
     if (rc == XMPI_OK) {  // all operands of chunk `me` are local now: the rank-order fold is an ordinary kernel
       const void* srcs[kMaxRanks];
       for (int p = 0; p < N; p++) srcs[p] = (p == me) ? (const char*)r.send + (size_t)me * cb : (const char*)r.recv + (size_t)p * cb;
@@ -497,7 +650,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
       a.seg[0].src_from_recv = 1;
       a.seg[0].dst_mask = everyone & ~(1u << me);
       traffic += (size_t)N * cb;
-      rc = launch(1, XMPI_U8, XMPI_SUM, cb / 16);
+      rc = launch(1, XMPI_U8, XMPI_SUM, cb / 16, (size_t)N * cb);
     }
   } else if (coll == COLL_ALLREDUCE || coll == COLL_REDUCE) {
     size_t off = 0, cnt = 0;
@@ -508,7 +661,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     a.seg[0].src_mask = everyone;
     a.seg[0].dst_mask = coll == COLL_REDUCE ? (1u << root) : everyone;
     traffic = (size_t)(N + (coll == COLL_REDUCE ? 1 : N)) * cnt * es;
-    rc = launch(N, dtype, op, cnt / al);
+    rc = launch(N, dtype, op, cnt / al, traffic);
   } else if (coll == COLL_ALLGATHER) {
     a.nseg = 1;
     a.seg[0].src_off = 0;
@@ -517,20 +670,22 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     a.seg[0].src_mask = 1u << me;
     a.seg[0].dst_mask = everyone;
     traffic = (size_t)(1 + N) * send_bytes;
-    rc = launch(1, XMPI_U8, XMPI_SUM, send_bytes / 16);
+    rc = launch(1, XMPI_U8, XMPI_SUM, send_bytes / 16, traffic);
   } else {  // COLL_BCAST: `send` and `recv` are the same buffer on every rank
-    const bool push = N <= 2 || send_bytes <= (size_t)std::max<long>(0, c->zc_bcast_push_bytes);
-    if (push) {  // the root stores into every buffer; the others only take part in the rendezvous
+    const bool root_pushes = N <= 2 || send_bytes <= (size_t)std::max<long>(0, c->zc_bcast_push_bytes);
+    if (root_pushes) {  // the root stores into every buffer; the others only take part in the rendezvous
       a.nseg = me == root ? 1 : 0;
       a.seg[0].count = send_bytes;
       a.seg[0].src_mask = 1u << root;
       a.seg[0].dst_mask = everyone & ~(1u << root);
       traffic = me == root ? (size_t)N * send_bytes : 0;
-      rc = launch(1, XMPI_U8, XMPI_SUM, send_bytes / 16);
+      split_pref = 0;  // (the ranks differ in what they launch: keep to the one-kernel form, whose shape does not matter)
+      rc = launch(1, XMPI_U8, XMPI_SUM, send_bytes / 16, traffic);
     } else {
       // the root scatters chunk j to rank j (one segment per destination, each over its own link), then every
       // rank forwards its chunk to the others: each link carries S/N twice instead of the root's links carrying S
       size_t maxp = 0;
+      split_pref = 0;
       if (me == root) {
         for (int j = 0; j < N; j++) {
           size_t off = 0, cnt = 0;
@@ -545,7 +700,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
           traffic += 2 * cnt * es;
         }
       }
-      rc = launch(1, XMPI_U8, XMPI_SUM, maxp);
+      rc = launch(1, XMPI_U8, XMPI_SUM, maxp, traffic);
       if (rc == XMPI_OK) {
         memset(a.seg, 0, sizeof a.seg);
         size_t off = 0, cnt = 0;
@@ -556,11 +711,15 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
         a.seg[0].src_mask = 1u << me;
         a.seg[0].dst_mask = everyone & ~(1u << me) & ~(1u << root);
         traffic += (size_t)(N - 1) * cnt * es;
-        rc = launch(1, XMPI_U8, XMPI_SUM, cnt * es / 16);
+        rc = launch(1, XMPI_U8, XMPI_SUM, cnt * es / 16, (size_t)(N - 1) * cnt * es);
       }
     }
   }
   if (rc != XMPI_OK) return fail(rc);
+  if (!capturing) {
+    XMPI_HIP(hipEventRecord(c->dsync_order_ev, stream));
+    c->dsync_last_stream = stream;
+  }
 
   // 4. results of a stand-in go home; stand-ins go back to the arena when the stream has passed them.
   //    (A copy into pageable host memory blocks the calling thread until the kernel before it has ended -- and the
@@ -615,6 +774,150 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     ev_put(c, pstop, true);
   }
   return dsync_check(c);
+}
+
+// ---- stream-ordered Send / Receive ------------------------------------------------------------------------------------
+// The reference's Send is a gob message on a net.Conn and a wait for the ack message (network.go:562-571), its Receive
+// reads, routes by tag, acks and decodes (network.go:575-625).  Here both are ONE kernel each, enqueued on a stream:
+// the sender's writes {message number, tag, dtype, bytes, where the payload lives} into a box of the receiver's flag
+// allocation (64 bytes over xGMI) and waits for the answer; the receiver's waits for a box with its tag, pulls the
+// payload straight out of the sender's HBM and answers.  Nothing is polled by a host thread.  (The blocking
+// xmpi_send / xmpi_recv do NOT use waiting kernels -- engine.cpp: a kernel that waits for a peer holds its hardware
+// queue, and the reference's semantics let a program block in several Sends / Receives at once, in any order.)
+
+namespace {
+
+int p2p_done_slot(xmpi_comm* c, uint64_t* id_out) {
+  const uint64_t id = ++c->p2p_done_next;
+  *id_out = id;
+  const int slot = (int)(id % xmpi_comm::kP2PDoneSlots);
+  __atomic_store_n(&c->p2p_done[4 * slot], 0, __ATOMIC_RELEASE);
+  return slot;
+}
+
+int p2p_status_to_rc(uint64_t st) {
+  if (st == 0) return XMPI_OK;
+  if (st >= 0x100) {
+    const uint32_t why = (uint32_t)(st - 0x100);
+    if (why == DSYNC_TIMEOUT) {
+      set_last_error("send / receive: the peer did not arrive within XMPI_TIMEOUT_S (kernel wait cut short)");
+      return XMPI_ERR_TIMEOUT;
+    }
+    if (why == DSYNC_UNMAPPED) {
+      set_last_error("receive: the sender's buffer is not mapped here");
+      return XMPI_ERR_STATE;
+    }
+    set_last_error("send / receive: the job was aborted while the kernel waited");
+    return XMPI_ERR_PEER;
+  }
+  if (st == 6) set_last_error("receive: the message does not fit the buffer");
+  else set_last_error("receive: dtype differs from the sender's");
+  return -(int)st;
+}
+
+void p2p_fill(xmpi_comm* c, P2PArgs* a, int peer, int tag, int dtype) {
+  memset(a, 0, sizeof *a);
+  a->my_page = c->dpage;
+  a->peer_page = c->peer_page[peer];
+  a->me = c->rank;
+  a->peer = peer;
+  a->tag = tag;
+  a->dtype = dtype;
+  a->comm_tag = c->dsync_tag;
+  a->table = c->dsync_table_dev;
+  a->abort_word = c->dsync_abort_dev;
+  a->spin_limit = c->timeout_s > 0 ? (uint64_t)c->timeout_s * 100000000ull : 0;
+}
+
+}  // namespace
+
+// the operations that have completed since the last look: their stand-ins go back, the first failure is returned
+int dsync_p2p_reap(xmpi_comm* c) {
+  int rc = XMPI_OK;
+  for (size_t i = 0; i < c->p2p_pending.size();) {
+    xmpi_comm::P2PPending& p = c->p2p_pending[i];
+    if (__atomic_load_n(&c->p2p_done[4 * p.slot], __ATOMIC_ACQUIRE) != p.id) {
+      i++;
+      continue;
+    }
+    const int r = p2p_status_to_rc(c->p2p_done[4 * p.slot + 1]);
+    if (r != XMPI_OK && rc == XMPI_OK) rc = r;
+    for (void* b : p.bufs) (void)heap_free(b);
+    c->p2p_pending.erase(c->p2p_pending.begin() + (long)i);
+  }
+  return rc;
+}
+
+int dsync_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, int tag, hipStream_t stream) {
+  if (!stream) stream = c->local_stream;
+  dsync_service(c);
+  if ((int)c->p2p_pending.size() >= xmpi_comm::kP2PDoneSlots - 2) {  // completion words are a ring: do not lap it
+    set_last_error("too many stream-ordered sends / receives outstanding: xmpi_stream_sync first");
+    return XMPI_ERR_STATE;
+  }
+  BufRef ref;
+  memset(&ref, 0, sizeof ref);
+  std::vector<void*> lent;
+  int slot = 0;
+  if (bytes > 0) {
+    const void* src = buf;
+    if (!zc_export(c, src, bytes, &ref)) {  // memory the receiver cannot map: a registered stand-in (one local copy)
+      void* tmp = heap_alloc(c->device, bytes);
+      if (!tmp) return XMPI_ERR_NOMEM;
+      lent.push_back(tmp);
+      XMPI_HIP(hipMemcpyAsync(tmp, buf, bytes, hipMemcpyDeviceToDevice, stream));
+      if (!zc_export(c, tmp, bytes, &ref)) {
+        (void)heap_free(tmp);
+        return XMPI_ERR_HIP;
+      }
+      c->dsync_bounced++;
+    }
+    uint64_t pi = 0;
+    int rc = publish(c, ref, &slot, &pi);
+    if (rc == XMPI_OK) rc = await_acks(c, pi);
+    if (rc != XMPI_OK) {
+      for (void* p : lent) (void)heap_free(p);
+      return rc;
+    }
+  }
+  P2PArgs a;
+  p2p_fill(c, &a, dest, tag, dtype);
+  a.seq = ++c->p2p_out_seq[dest];
+  a.bytes = bytes;
+  a.gen = ref.gen;
+  a.slot = (uint64_t)slot;
+  a.off = ref.offset;
+  uint64_t id = 0;
+  const int ds = p2p_done_slot(c, &id);
+  a.host_done = c->p2p_done_dev + 4 * ds;
+  a.done_value = id;
+  XMPI_HIP(launch_p2p_send(a, stream));
+  c->p2p_pending.push_back({ds, id, lent});
+  return XMPI_OK;
+}
+
+int dsync_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int tag, hipStream_t stream) {
+  if (!stream) stream = c->local_stream;
+  dsync_service(c);
+  if ((int)c->p2p_pending.size() >= xmpi_comm::kP2PDoneSlots - 2) {
+    set_last_error("too many stream-ordered sends / receives outstanding: xmpi_stream_sync first");
+    return XMPI_ERR_STATE;
+  }
+  P2PArgs a;
+  p2p_fill(c, &a, src, tag, dtype);
+  a.bytes = cap_bytes;
+  a.buf = buf;
+  a.op_id = ++c->p2p_op_id;
+  uint64_t id = 0;
+  const int ds = p2p_done_slot(c, &id);
+  a.host_done = c->p2p_done_dev + 4 * ds;
+  a.done_value = id;
+  // a few blocks for a large message; every block but the first only waits for the first (a local word)
+  long gx = (long)(cap_bytes >> 16);
+  gx = std::max<long>(1, std::min<long>(gx, c->dsync_sharers > 1 ? 16 : 64));
+  XMPI_HIP(launch_p2p_recv(a, (int)gx, stream));
+  c->p2p_pending.push_back({ds, id, {}});
+  return XMPI_OK;
 }
 
 // the first failure a kernel of this rank reported since the last look (a wait that was cut short, a buffer

@@ -1,0 +1,270 @@
+// kdev.h -- device-side building blocks shared by the kernel files (kernels.hip, sched.hip): element / packet
+// arithmetic, cache-policy loads and stores, and the rendezvous of the device-synchronised collectives.
+// Included by HIP translation units only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace xmpi {
+namespace {
+
+constexpr int kBlock = 256;      // 4 waves: one per SIMD
+constexpr int kUnroll = 4;       // 16-byte packets per lane per operand in flight
+
+enum { DT_U8 = 0, DT_I32 = 1, DT_I64 = 2, DT_F16 = 3, DT_F32 = 4, DT_F64 = 5, DT_BF16 = 6 };
+enum { OP_SUM = 0, OP_PROD = 1, OP_MIN = 2, OP_MAX = 3 };
+
+struct bf16_t {
+  uint16_t bits;
+};
+
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+// 16-byte packet: a native vector (not HIP's pack_t struct) so it always lives in 4 VGPRs
+typedef unsigned int pack_t __attribute__((ext_vector_type(4)));
+
+// ---- scalar combine: one rounding per operation, min/max spelled as in oracle/xmpi_oracle.c ---
+
+template <typename T, int OP>
+__device__ __forceinline__ T combine(T a, T b) {
+  if constexpr (OP == OP_SUM) return a + b;
+  else if constexpr (OP == OP_PROD) return a * b;
+  else if constexpr (OP == OP_MIN) return (b < a) ? b : a;
+  else return (a < b) ? b : a;
+}
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+template <int OP>
+__device__ __forceinline__ bf16_t combine_bf16(bf16_t a, bf16_t b) {
+  float x = bf16_to_f32(a.bits), y = bf16_to_f32(b.bits);
+  if constexpr (OP == OP_SUM) return bf16_t{f32_to_bf16(x + y)};
+  else if constexpr (OP == OP_PROD) return bf16_t{f32_to_bf16(x * y)};
+  else if constexpr (OP == OP_MIN) return (y < x) ? b : a;
+  else return (x < y) ? b : a;
+}
+
+// wrapping integer arithmetic (Go semantics) without signed-overflow UB
+template <int OP>
+__device__ __forceinline__ int32_t combine_i32(int32_t a, int32_t b) {
+  if constexpr (OP == OP_SUM) return (int32_t)((uint32_t)a + (uint32_t)b);
+  else if constexpr (OP == OP_PROD) return (int32_t)((uint32_t)a * (uint32_t)b);
+  else return combine<int32_t, OP>(a, b);
+}
+template <int OP>
+__device__ __forceinline__ int64_t combine_i64(int64_t a, int64_t b) {
+  if constexpr (OP == OP_SUM) return (int64_t)((uint64_t)a + (uint64_t)b);
+  else if constexpr (OP == OP_PROD) return (int64_t)((uint64_t)a * (uint64_t)b);
+  else return combine<int64_t, OP>(a, b);
+}
+
+template <typename T, int OP>
+__device__ __forceinline__ T combine_any(T a, T b) {
+  if constexpr (sizeof(T) == 2 && !__is_same(T, _Float16)) return combine_bf16<OP>(a, b);
+  else if constexpr (__is_same(T, int32_t)) return combine_i32<OP>(a, b);
+  else if constexpr (__is_same(T, int64_t)) return combine_i64<OP>(a, b);
+  else if constexpr (__is_same(T, uint8_t)) {
+    if constexpr (OP == OP_SUM) return (uint8_t)(a + b);
+    else if constexpr (OP == OP_PROD) return (uint8_t)(a * b);
+    else return combine<uint8_t, OP>(a, b);
+  } else return combine<T, OP>(a, b);
+}
+
+// ---- 16-byte packet combine ------------------------------------------------------------------
+
+template <typename T, int OP>
+__device__ __forceinline__ pack_t combine16(pack_t a, pack_t b) {
+  constexpr int N = 16 / sizeof(T);
+  if constexpr (__is_same(T, _Float16) && (OP == OP_SUM || OP == OP_PROD)) {
+    // packed halves: v_pk_add_f16 / v_pk_mul_f16, 2 elements per VALU lane-op
+    union { pack_t u; half2_t h[4]; } x, y, r;
+    x.u = a; y.u = b;
+#pragma unroll
+    for (int i = 0; i < 4; i++) r.h[i] = (OP == OP_SUM) ? (x.h[i] + y.h[i]) : (x.h[i] * y.h[i]);
+    return r.u;
+  } else {
+    union { pack_t u; T e[N]; } x, y, r;
+    x.u = a; y.u = b;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.e[i] = combine_any<T, OP>(x.e[i], y.e[i]);
+    return r.u;
+  }
+}
+
+// ---- cache policy of the streaming accesses ----------------------------------------------------
+// MODE 0: plain loads and stores.  MODE 1: non-temporal loads and stores.  MODE 2: non-temporal
+// loads, plain stores.  Data that is touched once should not displace lines in L2 / the Infinity
+// Cache: measured on MI355X at 256 MiB operands (beyond the 256 MiB Infinity Cache) nt loads take
+// reduce2<f32> from 5.45 to 6.6-6.8 TB/s; which mode wins at a given size is a launch-time choice
+// (set_kernel_mode / XMPI_KERNEL_MODE), the arithmetic is identical in all three.
+template <int MODE>
+__device__ __forceinline__ pack_t ldp(const pack_t* p) {
+  if constexpr (MODE != 0) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <int MODE>
+__device__ __forceinline__ void stp(pack_t* p, pack_t v) {
+  if constexpr (MODE == 1) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
+// ---- device-synchronised collectives: system-scope flag words, rendezvous, completion --------------------
+__device__ __forceinline__ uint64_t ld_sys64(const uint64_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void st_sys64(uint64_t* p, uint64_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {  // the value is the same in every lane: keep it in SGPRs
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// Wait until *p >= want.  0 = it did; otherwise why not (the job was aborted / the wait outlasted spin_limit).
+__device__ uint32_t spin_until(const uint64_t* p, uint64_t want, const int32_t* abort_word, uint64_t spin_limit) {
+  if (ld_sys64(p) >= want) return DSYNC_OK;
+  const uint64_t t0 = wall_clock64();
+  for (uint32_t k = 1;; k++) {
+    __builtin_amdgcn_s_sleep(1);
+    if (ld_sys64(p) >= want) return DSYNC_OK;
+    if ((k & 127u) == 0) {  // the expensive checks (a load over PCIe, the clock) now and then only
+      if (abort_word && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return DSYNC_ABORTED;
+      if (spin_limit && wall_clock64() - t0 > spin_limit) return DSYNC_TIMEOUT;
+    }
+  }
+}
+__device__ __forceinline__ uint32_t dsync_spin(const uint64_t* p, uint64_t want, const DsyncArgs& a) {
+  return spin_until(p, want, a.abort_word, a.spin_limit);
+}
+
+struct DsyncShared {
+  uint64_t epoch;                                 // of this kernel
+  uint64_t send[kDsyncRanks], recv[kDsyncRanks];  // every rank's buffers as addressable from here
+  uint64_t src[kDsyncRanks], dst[kDsyncRanks];    // this block's segment: sources in rank order, destinations local first
+  int nsrc, ndst;
+  uint32_t fail, last;
+};
+
+// Where this process mapped registration `gen` (table slot `slot`) of `peer`: from the cache in this rank's page, or
+// -- the first time, and after the peer re-used the slot -- from the host's table (a few loads over PCIe).
+__device__ uint64_t translate(uint64_t comm_tag, const DsyncEntry* table, DsyncPage* mine, int peer, uint64_t slot, uint64_t gen, uint64_t off) {
+  if (gen == 0 || slot >= (uint64_t)kDsyncArenas) return 0;
+  DsyncEntry* c = &mine->cache[peer][slot];
+  uint64_t base, bytes;
+  if (__hip_atomic_load(&c->gen, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen &&
+      __hip_atomic_load(&c->tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == comm_tag) {
+    base = __hip_atomic_load(&c->base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bytes = __hip_atomic_load(&c->bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    const DsyncEntry* h = &table[peer * kDsyncArenas + (int)slot];
+    if (__hip_atomic_load(&h->gen, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != gen) return 0;
+    base = __hip_atomic_load(&h->base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    bytes = __hip_atomic_load(&h->bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // several blocks may do this at once: they all write the same values, the number last
+    __hip_atomic_store(&c->gen, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_store(&c->base, base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&c->bytes, bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&c->tag, comm_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&c->gen, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return (off <= bytes) ? base + off : 0;
+}
+
+__device__ __forceinline__ uint64_t dsync_translate(const DsyncArgs& a, DsyncPage* mine, int peer, uint64_t slot, uint64_t gen, uint64_t off) {
+  return translate(a.tag, a.table, mine, peer, slot, gen, off);
+}
+
+__device__ void dsync_begin(const DsyncArgs& a, DsyncShared& sh) {
+  const int t = threadIdx.x, me = a.me, n = a.n;
+  DsyncPage* mine = a.page[me];
+  if (t == 0) {
+    sh.fail = DSYNC_OK;
+    sh.send[me] = (uint64_t)(uintptr_t)a.my_send;
+    sh.recv[me] = (uint64_t)(uintptr_t)a.my_recv;
+    // the epoch is counted on the device (every block reads the same value: only the closing block of a kernel
+    // advances it, after all the others have finished), so replaying a captured launch counts on
+    const uint64_t seen = ld_sys64(&mine->epoch_now);
+    sh.epoch = (seen > a.epoch_floor ? seen : a.epoch_floor) + 1;
+  }
+  __syncthreads();
+  const uint64_t epoch = sh.epoch;
+  if (t < n && t != me) {
+    if (blockIdx.x == 0 && blockIdx.y == 0) {  // one block announces this rank
+      DsyncSlot* out = &a.page[t]->ready[me];
+      st_sys64(&out->send_gen, a.send_gen);
+      st_sys64(&out->send_off, a.send_off);
+      st_sys64(&out->send_slot, a.send_slot);
+      st_sys64(&out->recv_gen, a.recv_gen);
+      st_sys64(&out->recv_off, a.recv_off);
+      st_sys64(&out->recv_slot, a.recv_slot);
+      __hip_atomic_store(&out->epoch, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const DsyncSlot* in = &mine->ready[t];
+    uint32_t why = dsync_spin(&in->epoch, epoch, a);
+    if (why == DSYNC_OK) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+      const uint64_t s = dsync_translate(a, mine, t, ld_sys64(&in->send_slot), ld_sys64(&in->send_gen), ld_sys64(&in->send_off));
+      const uint64_t r = dsync_translate(a, mine, t, ld_sys64(&in->recv_slot), ld_sys64(&in->recv_gen), ld_sys64(&in->recv_off));
+      sh.send[t] = s;
+      sh.recv[t] = r;
+      if (!s || !r) why = DSYNC_UNMAPPED;
+    }
+    if (why != DSYNC_OK) atomicMax(&sh.fail, why);
+  }
+  // every lane acquires: what the peers wrote before they announced themselves (their inputs) must not be
+  // served from a stale line of this CU's L1 / this XCD's L2
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  __syncthreads();
+}
+
+// true in the block that finished last (after it has exchanged "done" with every peer)
+__device__ void dsync_end(const DsyncArgs& a, DsyncShared& sh) {
+  const int t = threadIdx.x, me = a.me, n = a.n;
+  DsyncPage* mine = a.page[me];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left
+  __syncthreads();
+  if (t == 0) {
+    // a block that gave up (its own wait timed out, the job was aborted) says so where the closing block looks:
+    // a kernel whose closing block happened to see nothing wrong must not report success for it
+    if (sh.fail != DSYNC_OK) __hip_atomic_fetch_max(&mine->failword, sh.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // ... and are visible system-wide (writes back this XCD's L2)
+    const uint32_t total = gridDim.x * gridDim.y;
+    sh.last = (__hip_atomic_fetch_add(&mine->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == total - 1) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!sh.last) return;
+  if (t == 0) {
+    __hip_atomic_store(&mine->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t f = __hip_atomic_exchange(&mine->failword, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (f > sh.fail) sh.fail = f;
+  }
+  __syncthreads();
+  uint32_t why = DSYNC_OK;
+  if (t < n && t != me) {
+    __hip_atomic_store(&a.page[t]->done[me][0], sh.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (sh.fail == DSYNC_OK) why = dsync_spin(&mine->done[t][0], sh.epoch, a);
+    if (why != DSYNC_OK) atomicMax(&sh.fail, why);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  __syncthreads();
+  if (t == 0) {
+    st_sys64(&mine->epoch_now, sh.epoch);  // this kernel is over: the next one (an ordinary launch or a graph replay) counts from here
+    if (a.host_epoch) st_sys64(a.host_epoch, sh.epoch);
+    if (sh.fail != DSYNC_OK && a.status) __hip_atomic_store(a.status, sh.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+
+__device__ __forceinline__ uint64_t* step_flags(DsyncPage* page) {
+  return reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(page) + kStepOff);
+}
+
+}  // namespace
+}  // namespace xmpi

@@ -87,7 +87,7 @@ struct DsyncPage {
   DsyncSlot ready[kDsyncRanks];
   uint64_t done[kDsyncRanks][8];  // 64 bytes apart
   uint32_t ticket;                // blocks of the running kernel that have finished their stores
-  uint32_t pad0;
+  uint32_t failword;              // first failure any block of the running kernel met (the closing block reports and clears it)
   uint64_t epoch_now;             // epoch of the last kernel of this rank that has ended (written by its closing block):
                                   // the next kernel's epoch is derived from it ON THE DEVICE, so a captured hipGraph
                                   // that replays the same launch keeps counting
@@ -97,6 +97,48 @@ struct DsyncPage {
   // occupies), the kernels fill the cache themselves and re-fetch when the registration number differs
   DsyncEntry cache[kDsyncRanks][kDsyncArenas];
 };
+
+// The flag allocation of a rank (kDsyncPageBytes of uncached HBM, mapped by every peer) holds more than the page:
+//   [0, 64 KiB)               DsyncPage
+//   [kStepOff, +256 KiB)      uint64_t step[kDsyncRanks][kStepSlots]: step[p][w] is written by rank p only -- "worker w of
+//                             rank p has finished step k of epoch e" as (e << 8) | k (stepped kernels: ring, halving, tree)
+//   [kBoxOff, +8 KiB)         P2PBox box[kDsyncRanks][kP2PBoxes]: box[p][b] is written by rank p only -- a message p sends here
+//   [kAckOff, +8 KiB)         P2PAck ack[kDsyncRanks][kP2PBoxes]: ack[q][b] is written by rank q only -- q's verdict on the
+//                             message this rank put into box b of q's page
+constexpr size_t kDsyncPageBytes = 1u << 20;
+constexpr int kStepSlots = 2048;
+constexpr size_t kStepOff = 65536;
+constexpr int kP2PBoxes = 8;  // messages in flight per ordered rank pair (stream-ordered Send / Receive)
+constexpr size_t kBoxOff = kStepOff + sizeof(uint64_t) * kDsyncRanks * kStepSlots;
+struct P2PBox {
+  uint64_t seq;    // written last (release): message number of the ordered pair, 1-based; box = (seq - 1) % kP2PBoxes
+  uint64_t tag;    // low 32 bits: the tag (as int32), bits 32..39: dtype
+  uint64_t bytes;
+  uint64_t gen, slot, off;  // where the payload lives: the sender's registration number, table slot, byte offset
+  uint64_t pad[2];
+};
+struct P2PAck {
+  uint64_t seq;     // the message this answers (written last, release)
+  uint64_t status;  // 0 = consumed, otherwise the receiver's verdict as a negated xmpi code (truncate, dtype mismatch)
+  uint64_t pad[6];
+};
+constexpr size_t kAckOff = kBoxOff + sizeof(P2PBox) * kDsyncRanks * kP2PBoxes;
+// local state of the receive kernels (never written by a peer):
+//   [kTakenOff, +1 KiB)   uint64_t taken[kDsyncRanks][kP2PBoxes]: number of the last message consumed from box b of rank p
+//   [kGoOff, +2 KiB)      P2PGo go[kP2PGoSlots]: what block 0 of a receive kernel found, for its other blocks
+constexpr size_t kTakenOff = kAckOff + sizeof(P2PAck) * kDsyncRanks * kP2PBoxes;
+constexpr int kP2PGoSlots = 16;
+struct P2PGo {
+  uint64_t id;      // written last: the receive operation this belongs to
+  uint64_t src;     // payload address as mapped here
+  uint64_t bytes;
+  uint64_t status;
+  uint32_t ticket, pad0;
+  uint64_t seq, box;  // which message / box of the pair (the block that finishes last answers the sender)
+  uint64_t pad[1];
+};
+constexpr size_t kGoOff = kTakenOff + sizeof(uint64_t) * kDsyncRanks * kP2PBoxes;
+static_assert(kGoOff + sizeof(P2PGo) * kP2PGoSlots <= kDsyncPageBytes, "flag allocation");
 
 // what a block of the kernel moves: the fold of the source ranks' buffers (rank order) -> the destination ranks'
 struct DsyncSeg {
@@ -136,5 +178,78 @@ hipError_t launch_dsync_fold(const DsyncArgs& a, int nsrc, int dtype, int op, in
 
 // one lane: system-scope release store of `value` to *flag (host-registered or device memory)
 hipError_t launch_signal(uint64_t* flag, uint64_t value, hipStream_t stream);
+
+// ---- split form of a device-synchronised collective (sched.hip): three launches on one stream -----------------------------
+// The one-kernel form keeps every block spinning until the peers arrive, so its grid must stay resident (bounded).
+// For large messages the collective is split: a ONE-block kernel meets the peers and writes the translated buffer
+// addresses into device memory (DsyncResolved), the data kernel is an ordinary streaming kernel with one tile per block
+// and no flag anywhere (what reduce_n_multi_kernel is), and a one-block kernel exchanges "done".  Only two blocks ever
+// wait for a peer; the chip is free for the caller's other streams meanwhile.
+struct DsyncResolvedSeg {
+  uint64_t src[kDsyncRanks], dst[kDsyncRanks];  // sources in rank order, destinations local first
+  uint64_t count;   // elements
+  int32_t nsrc, ndst;
+  uint32_t vec, pad;  // vec: every pointer is 16-byte aligned
+};
+struct DsyncResolved {
+  uint64_t epoch;
+  uint32_t fail, nseg;
+  DsyncResolvedSeg seg[kDsyncRanks];
+};
+hipError_t launch_dsync_meet(const DsyncArgs& a, DsyncResolved* out, hipStream_t stream);
+// nsrc_hint: sources per segment when it is the same for all (unrolled loads), 0 = read it from the table
+hipError_t launch_dsync_body(const DsyncResolved* res, int nseg, size_t max_packets, int nsrc_hint, int dtype, int op,
+                             size_t traffic_bytes, hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+hipError_t launch_dsync_done(const DsyncArgs& a, const DsyncResolved* res, hipStream_t stream);
+
+// ---- stepped collectives in ONE kernel per rank (sched.hip): ring, recursive halving / doubling, binary tree ------------
+// All steps of the schedule run inside the kernel: worker w (a block) owns the tiles T of the buffer with T % W == w on
+// EVERY rank, so step k of worker w depends on step k-1 of worker w of one peer only -- one flag word per (peer, worker)
+// (DsyncPage allocation, `step`).  Data is PULLED: a step reads the peer's buffer (send or receive buffer, in place
+// included) and writes only local memory; the flag says "my step k is in my buffer".
+enum DsyncSched : int32_t {
+  SCHED_RING_ALLREDUCE = 1,  // reduce-scatter + allgather round each channel's ring, 2(N-1) steps
+  SCHED_RHD_ALLREDUCE = 2,   // recursive halving + doubling, 2 log2 N steps (N a power of two)
+  SCHED_RING_ALLGATHER = 3,  // N steps (the first is the local copy of the own block)
+  SCHED_TREE_BCAST = 4,      // binary tree rooted at `root`, the buffer cut into `pieces` pipelined pieces
+};
+constexpr int kMaxSchedChannels = 8;
+struct DsyncSchedArgs {
+  DsyncArgs d;          // pages, this rank's buffers, epoch floor ... (nseg / seg unused)
+  int32_t sched, nchan; // nchan = gridDim.y: ring channels (each a different cyclic order of the ranks)
+  int32_t root, pieces;
+  uint64_t count;       // elements (allgather: per rank)
+  uint32_t elem_size, pad;
+  uint8_t order[kMaxSchedChannels][kDsyncRanks];  // order[c][i]: the rank at position i of channel c's ring
+};
+hipError_t launch_dsync_sched(const DsyncSchedArgs& a, int dtype, int op, int grid_x, hipStream_t stream,
+                              hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// tile bytes of the stepped kernels (what a worker moves per iteration): grid_x = min(cap, ceil(step bytes / this))
+constexpr size_t kSchedTileBytes = 16384;
+
+// ---- stream-ordered Send / Receive (sched.hip) ---------------------------------------------------------------------------
+// The sender's kernel puts {seq, tag, dtype, bytes, where the payload is} into box (seq-1) % kP2PBoxes of the receiver's
+// flag allocation and waits for the receiver's ack; the receiver's kernel waits for a box with its tag, pulls the payload
+// straight out of the sender's buffer and acks with its verdict.  What the reference does with a gob message and an ack
+// message over a net.Conn (network.go:562-571, 616-624).
+struct P2PArgs {
+  DsyncPage* my_page;    // this rank's flag allocation
+  DsyncPage* peer_page;  // the other rank's, as mapped here
+  int32_t me, peer;
+  int32_t tag, dtype;
+  uint64_t seq;          // send: number of this message of the pair (me -> peer); its box must be free (acked) -- the host checks
+  uint64_t bytes;        // send: payload size; receive: capacity of `buf`
+  uint64_t gen, slot, off;  // send: where the payload lives
+  void* buf;             // receive: destination (local memory)
+  uint64_t comm_tag;     // translation cache tag (DsyncArgs::tag)
+  const DsyncEntry* table;
+  const int32_t* abort_word;
+  uint64_t spin_limit;
+  uint64_t* host_done;   // pinned host: [0] = done flag (written last), [1] = status, [2] = bytes received; may be null
+  uint64_t done_value;   // what to write into host_done[0]
+  uint64_t op_id;        // receive: number of this operation (go slot = op_id % kP2PGoSlots), never 0
+};
+hipError_t launch_p2p_send(const P2PArgs& a, hipStream_t stream);
+hipError_t launch_p2p_recv(const P2PArgs& a, int grid_x, hipStream_t stream);
 
 }  // namespace xmpi

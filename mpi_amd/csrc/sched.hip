@@ -1,0 +1,675 @@
+// sched.hip -- gfx950 kernels of the device-synchronised schedules that are more than one fold:
+//
+//   * the SPLIT form of the zero-copy collectives (meet / body / done: three launches, only two blocks ever wait);
+//   * the STEPPED schedules north_star names -- ring allreduce (reduce-scatter + allgather over several ring
+//     channels), recursive halving + doubling, ring allgather, binary-tree broadcast -- each as ONE kernel per
+//     rank that runs every step itself, step k of a worker released by a flag word the peer's worker wrote
+//     after its step k-1 (no host between the steps: what engine.cpp does with a host progress loop, an event
+//     and a counter in /dev/shm per step);
+//   * stream-ordered Send / Receive: the reference's message + ack (network.go:562-571, 616-624) as two
+//     64-byte records in the flag allocations and one pull of the payload.
+//
+// The reference has none of this (mpi.go:130 is a stub; a user composes collectives from Send / Receive as
+// examples/helloworld/helloworld.go:53-81 does).  Protocol and layouts: kernels.h.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include "kdev.h"
+#include "kernels.h"
+
+namespace xmpi {
+namespace {
+
+#define XMPI_LAUNCH(kern, grid, block, stream, es, ee, ...)                                  \
+  do {                                                                                       \
+    if ((es) || (ee)) hipExtLaunchKernelGGL(kern, grid, block, 0, stream, es, ee, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__);                      \
+  } while (0)
+
+// =====================================================================================================================
+// split form: meet
+// =====================================================================================================================
+
+// ONE block: announce, wait for every peer, translate their buffers -- and leave what the data kernel needs in
+// ordinary device memory (the kernel boundary publishes it).  No completion exchange here: the done kernel does it.
+__global__ __launch_bounds__(64) void dsync_meet_kernel(DsyncArgs a, DsyncResolved* out) {
+  __shared__ DsyncShared sh;
+  dsync_begin(a, sh);
+  if (threadIdx.x == 0) {
+    const int me = a.me, n = a.n;
+    out->epoch = sh.epoch;
+    out->fail = sh.fail;
+    out->nseg = (uint32_t)a.nseg;
+    for (int y = 0; y < a.nseg; y++) {
+      const DsyncSeg& g = a.seg[y];
+      DsyncResolvedSeg& o = out->seg[y];
+      int ns = 0, nd = 0;
+      uint64_t all = 0;
+      for (int r = 0; r < n; r++)
+        if (g.src_mask >> r & 1u) all |= (o.src[ns++] = (g.src_from_recv ? sh.recv[r] : sh.send[r]) + g.src_off);
+      for (int d = 0; d < n; d++) {
+        const int r = (me + d) % n;
+        if (g.dst_mask >> r & 1u) all |= (o.dst[nd++] = sh.recv[r] + g.dst_off);
+      }
+      for (int k = ns; k < kDsyncRanks; k++) o.src[k] = o.src[0];
+      for (int k = nd; k < kDsyncRanks; k++) o.dst[k] = o.dst[0];
+      o.count = g.count;
+      o.nsrc = ns;
+      o.ndst = nd;
+      o.vec = (all & 15u) == 0 ? 1u : 0u;
+    }
+  }
+}
+
+// =====================================================================================================================
+// split form: body -- the fold of reduce_n_multi_kernel, pointers from the table the meet kernel left
+// =====================================================================================================================
+
+template <typename T, int OP, int NSRC, int MODE>
+__global__ __launch_bounds__(kBlock) void dsync_body_kernel(const DsyncResolved* __restrict__ res) {
+  // the table is this GPU's own memory, written by the kernel before this one: uniform loads, before any fence
+  const DsyncResolvedSeg* __restrict__ g = &res->seg[blockIdx.y];
+  const uint32_t fail = res->fail;
+  const int nsrc = (NSRC > 0) ? NSRC : g->nsrc, ndst = g->ndst;
+  const size_t count = g->count;
+  const uint32_t vec = g->vec;
+  uint64_t dp[kDsyncRanks];
+#pragma unroll
+  for (int k = 0; k < kDsyncRanks; k++) dp[k] = g->dst[k];
+  uint64_t sp[NSRC > 0 ? NSRC : 1];
+  if constexpr (NSRC > 0) {
+#pragma unroll
+    for (int k = 0; k < NSRC; k++) sp[k] = g->src[k];
+  }
+  // what the peers wrote before they announced themselves (their inputs) must not come from a stale cache line
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  if (fail != DSYNC_OK) return;
+  const int t = threadIdx.x;
+  constexpr size_t N = 16 / sizeof(T);
+  if (vec) {
+    const size_t npack = count / N;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + t; i < npack; i += stride) {
+      pack_t acc;
+      if constexpr (NSRC > 0) {
+        pack_t v[NSRC];
+#pragma unroll
+        for (int k = 0; k < NSRC; k++) v[k] = ldp<MODE>(reinterpret_cast<const pack_t*>(sp[k]) + i);
+        acc = v[0];
+#pragma unroll
+        for (int k = 1; k < NSRC; k++) acc = combine16<T, OP>(acc, v[k]);
+      } else {
+        acc = ldp<MODE>(reinterpret_cast<const pack_t*>(g->src[0]) + i);
+        for (int k = 1; k < nsrc; k++) acc = combine16<T, OP>(acc, ldp<MODE>(reinterpret_cast<const pack_t*>(g->src[k]) + i));
+      }
+#pragma unroll
+      for (int k = 0; k < kDsyncRanks; k++)
+        if (k < ndst) stp<(MODE != 0) ? 1 : 0>(reinterpret_cast<pack_t*>(dp[k]) + i, acc);
+    }
+    const size_t done = npack * N;  // ragged tail (< 16 bytes): the first lanes of the segment's block 0
+    if (blockIdx.x == 0 && done + t < count) {
+      const size_t i = done + t;
+      T acc = reinterpret_cast<const T*>(g->src[0])[i];
+      for (int k = 1; k < nsrc; k++) acc = combine_any<T, OP>(acc, reinterpret_cast<const T*>(g->src[k])[i]);
+      for (int k = 0; k < ndst; k++) reinterpret_cast<T*>(g->dst[k])[i] = acc;
+    }
+  } else {  // some buffer is not 16-byte aligned: one element per lane
+    for (size_t i = (size_t)blockIdx.x * kBlock + t; i < count; i += (size_t)gridDim.x * kBlock) {
+      T acc = reinterpret_cast<const T*>(g->src[0])[i];
+      for (int k = 1; k < nsrc; k++) acc = combine_any<T, OP>(acc, reinterpret_cast<const T*>(g->src[k])[i]);
+      for (int k = 0; k < ndst; k++) reinterpret_cast<T*>(g->dst[k])[i] = acc;
+    }
+  }
+}
+
+// =====================================================================================================================
+// split form: done -- a few blocks (one per XCD: each releases at system scope, i.e. writes back the L2 it runs on),
+// the last of them exchanges "done" with every peer and advances the epoch
+// =====================================================================================================================
+
+__global__ __launch_bounds__(64) void dsync_done_kernel(DsyncArgs a, const DsyncResolved* res) {
+  __shared__ DsyncShared sh;
+  if (threadIdx.x == 0) {
+    sh.epoch = res->epoch;
+    sh.fail = res->fail;
+  }
+  __syncthreads();
+  dsync_end(a, sh);
+}
+
+// =====================================================================================================================
+// stepped schedules
+// =====================================================================================================================
+
+// One tile: D[x] = A[x] (NS == 1) or A[x] op B[x] (NS == 2) for the byte offsets x in [lo, hi) -- multiples of
+// sizeof(T); all three are addressed with the SAME offset.  vec: the three bases are 16-byte aligned.
+// Loads are non-temporal (every byte is read once by this rank), stores plain: what a step writes is what the
+// next rank's step reads a moment later.
+template <typename T, int OP, int NS>
+__device__ __forceinline__ void tile_apply(char* D, const char* A, const char* B, size_t lo, size_t hi, bool vec) {
+  const int t = threadIdx.x;
+  constexpr size_t ES = sizeof(T);
+  if (vec) {
+    const size_t plo = (lo + 15) & ~(size_t)15, phi = hi & ~(size_t)15;
+    if (plo < phi) {
+      if (phi - plo == kSchedTileBytes) {  // a whole tile: every load issued before the first use
+        constexpr int U = (int)(kSchedTileBytes / 16 / kBlock);
+        const pack_t* pa = reinterpret_cast<const pack_t*>(A + plo) + t;
+        const pack_t* pb = reinterpret_cast<const pack_t*>(B + plo) + t;
+        pack_t* pd = reinterpret_cast<pack_t*>(D + plo) + t;
+        pack_t va[U], vb[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          va[u] = ldp<2>(pa + u * kBlock);
+          if constexpr (NS == 2) vb[u] = ldp<2>(pb + u * kBlock);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          if constexpr (NS == 2) va[u] = combine16<T, OP>(va[u], vb[u]);
+          pd[u * kBlock] = va[u];
+        }
+      } else {
+        for (size_t x = plo + (size_t)t * 16; x < phi; x += (size_t)kBlock * 16) {
+          pack_t v = ldp<2>(reinterpret_cast<const pack_t*>(A + x));
+          if constexpr (NS == 2) v = combine16<T, OP>(v, ldp<2>(reinterpret_cast<const pack_t*>(B + x)));
+          *reinterpret_cast<pack_t*>(D + x) = v;
+        }
+      }
+      // the elements before the first and after the last whole packet (fewer than 16 bytes each)
+      size_t x = lo + (size_t)t * ES;
+      if (x < plo) {
+        T v = *reinterpret_cast<const T*>(A + x);
+        if constexpr (NS == 2) v = combine_any<T, OP>(v, *reinterpret_cast<const T*>(B + x));
+        *reinterpret_cast<T*>(D + x) = v;
+      }
+      x = phi + (size_t)t * ES;
+      if (x < hi) {
+        T v = *reinterpret_cast<const T*>(A + x);
+        if constexpr (NS == 2) v = combine_any<T, OP>(v, *reinterpret_cast<const T*>(B + x));
+        *reinterpret_cast<T*>(D + x) = v;
+      }
+      return;
+    }
+  }
+  for (size_t x = lo + (size_t)t * ES; x < hi; x += (size_t)kBlock * ES) {
+    T v = *reinterpret_cast<const T*>(A + x);
+    if constexpr (NS == 2) v = combine_any<T, OP>(v, *reinterpret_cast<const T*>(B + x));
+    *reinterpret_cast<T*>(D + x) = v;
+  }
+}
+
+// worker w of W: the tiles ti of [rlo, rhi) with ti % W == w (tile = kSchedTileBytes of the buffer, counted from
+// the start of the BUFFER, not of the range: the same bytes belong to the same worker on every rank at every step)
+template <typename T, int OP, int NS>
+__device__ void range_apply(uint64_t D, uint64_t A, uint64_t B, size_t rlo, size_t rhi, uint32_t w, uint32_t W) {
+  if (rlo >= rhi) return;
+  const bool vec = ((D | A | (NS == 2 ? B : A)) & 15u) == 0;
+  constexpr size_t TB = kSchedTileBytes;
+  const size_t t0 = rlo / TB;
+  size_t ti = t0 + (size_t)((w + W - (uint32_t)(t0 % W)) % W);
+  for (; ti * TB < rhi; ti += W) {
+    const size_t lo = ti * TB > rlo ? ti * TB : rlo;
+    const size_t hi = (ti + 1) * TB < rhi ? (ti + 1) * TB : rhi;
+    tile_apply<T, OP, NS>(reinterpret_cast<char*>(D), reinterpret_cast<const char*>(A), reinterpret_cast<const char*>(B), lo, hi, vec);
+  }
+}
+
+struct SchedStep {
+  int32_t wait_rank;   // whose step this one needs (-1: nobody's -- the rendezvous was enough)
+  uint32_t wait_val;   // ... and which
+  int32_t sig[2];      // who is told when this step is done (-1: nobody)
+  uint32_t sig_val;
+  int32_t ns;          // 0 = nothing to move, 1 = copy, 2 = combine
+  uint64_t D, A, B;    // bases: byte offset x of the buffer is at base + x
+  uint64_t lo, hi;     // byte range of the buffer this step covers
+};
+
+__device__ __forceinline__ void chunk_bytes(uint64_t count, uint32_t es, int parts, int j, uint64_t* lo, uint64_t* hi) {
+  const uint64_t al = es >= 16 ? 1 : 16 / es;
+  uint64_t base = (count + (uint64_t)parts - 1) / (uint64_t)parts;
+  base = (base + al - 1) / al * al;
+  const uint64_t a = (uint64_t)j * base, b = (uint64_t)(j + 1) * base;
+  *lo = (a < count ? a : count) * es;
+  *hi = (b < count ? b : count) * es;
+}
+
+__device__ int sched_nsteps(const DsyncSchedArgs& a) {
+  const int n = a.d.n;
+  switch (a.sched) {
+    case SCHED_RING_ALLREDUCE: return 2 * (n - 1);
+    case SCHED_RHD_ALLREDUCE: {
+      int l = 0;
+      while ((1 << l) < n) l++;
+      return 2 * l;
+    }
+    case SCHED_RING_ALLGATHER: return n;
+    default: return a.pieces;
+  }
+}
+
+// step g (1-based) of this rank on ring channel `ch`
+__device__ void sched_step(const DsyncSchedArgs& a, const DsyncShared& sh, int g, int ch, SchedStep* st) {
+  const int n = a.d.n, me = a.d.me;
+  const uint32_t es = a.elem_size;
+  st->wait_rank = -1;
+  st->wait_val = 0;
+  st->sig[0] = st->sig[1] = -1;
+  st->sig_val = (uint32_t)g;
+  st->ns = 0;
+  st->D = sh.recv[me];
+  st->A = st->B = 0;
+  st->lo = st->hi = 0;
+  if (a.sched == SCHED_RING_ALLREDUCE || a.sched == SCHED_RING_ALLGATHER) {
+    int pos = 0;
+    for (int i = 0; i < n; i++)
+      if (a.order[ch][i] == me) pos = i;
+    const int prev = a.order[ch][(pos + n - 1) % n], next = a.order[ch][(pos + 1) % n];
+    if (g >= 2) {
+      st->wait_rank = prev;
+      st->wait_val = (uint32_t)(g - 1);
+    }
+    if (a.sched == SCHED_RING_ALLREDUCE) {
+      if (g < 2 * (n - 1)) st->sig[0] = next;
+      if (g <= n - 1) {  // reduce-scatter: my partial of chunk (pos - g) = the previous rank's partial + my contribution
+        const int c = (pos + n - g) % n;
+        chunk_bytes(a.count, es, n, c, &st->lo, &st->hi);
+        st->ns = 2;
+        st->A = g == 1 ? sh.send[prev] : sh.recv[prev];
+        st->B = sh.send[me];
+      } else {  // allgather: the finished chunk (pos + 1 - t) travels on
+        const int t = g - (n - 1);
+        const int c = (pos + 1 + n - t) % n;
+        chunk_bytes(a.count, es, n, c, &st->lo, &st->hi);
+        st->ns = 1;
+        st->A = sh.recv[prev];
+      }
+    } else {
+      const uint64_t blk = a.count * es;
+      if (g < n) st->sig[0] = next;
+      if (g == 1) {  // my own block into its place
+        st->lo = (uint64_t)me * blk;
+        st->hi = st->lo + blk;
+        st->A = sh.send[me] - st->lo;
+        st->ns = st->A == st->D ? 0 : 1;
+      } else {  // the block that reached the previous rank one step ago
+        const int r = a.order[ch][(pos + n - (g - 1)) % n];
+        st->lo = (uint64_t)r * blk;
+        st->hi = st->lo + blk;
+        st->A = sh.recv[prev];
+        st->ns = 1;
+      }
+    }
+    return;
+  }
+  if (a.sched == SCHED_RHD_ALLREDUCE) {
+    int l = 0;
+    while ((1 << l) < n) l++;
+    // the ranges: R_0 = the buffer, R_{k+1} = the half of R_k this rank keeps at halving step k
+    const int level = g <= l ? g - 1 : 2 * l - g;  // halving step k = g-1; doubling undoes level 2l-g
+    uint64_t lo = 0, hi = a.count * es;
+    uint64_t klo = 0, khi = 0, olo = 0, ohi = 0;  // kept half / other half at `level`
+    for (int k = 0; k <= level; k++) {
+      const int d = n >> (k + 1);
+      const uint64_t mid = lo + (((hi - lo) / 2) & ~(uint64_t)15);
+      if (me & d) {
+        klo = mid, khi = hi, olo = lo, ohi = mid;
+      } else {
+        klo = lo, khi = mid, olo = mid, ohi = hi;
+      }
+      lo = klo;
+      hi = khi;
+    }
+    const int p = me ^ (n >> (level + 1));
+    if (g >= 2) {
+      st->wait_rank = p;
+      st->wait_val = (uint32_t)(g - 1);
+    }
+    if (g < 2 * l) {
+      const int nlevel = g + 1 <= l ? g : 2 * l - g - 1;
+      st->sig[0] = me ^ (n >> (nlevel + 1));
+    }
+    if (g <= l) {  // halving: my half of the partner's accumulator joins mine
+      st->ns = 2;
+      st->lo = klo;
+      st->hi = khi;
+      st->A = g == 1 ? sh.send[p] : sh.recv[p];
+      st->B = g == 1 ? sh.send[me] : sh.recv[me];
+    } else {  // doubling: the partner's finished half
+      st->ns = 1;
+      st->lo = olo;
+      st->hi = ohi;
+      st->A = sh.recv[p];
+    }
+    return;
+  }
+  // SCHED_TREE_BCAST: piece g of the buffer comes from the parent and is announced to the children
+  const int v = (me - a.root + n) % n;
+  const int c1 = 2 * v + 1, c2 = 2 * v + 2;
+  if (c1 < n) st->sig[0] = (c1 + a.root) % n;
+  if (c2 < n) st->sig[1] = (c2 + a.root) % n;
+  uint64_t lo, hi;
+  chunk_bytes(a.count * es, 1, a.pieces, g - 1, &lo, &hi);
+  if (v != 0) {
+    const int parent = ((v - 1) / 2 + a.root) % n;
+    if ((v - 1) / 2 != 0) {  // the root's buffer is complete when it announces itself; anybody else's piece by piece
+      st->wait_rank = parent;
+      st->wait_val = (uint32_t)g;
+    }
+    st->ns = 1;
+    st->lo = lo;
+    st->hi = hi;
+    st->A = sh.recv[parent];
+  }
+}
+
+template <typename T, int OP>
+__global__ __launch_bounds__(kBlock) void dsync_sched_kernel(DsyncSchedArgs a) {
+  __shared__ DsyncShared sh;
+  __shared__ SchedStep st;
+  dsync_begin(a.d, sh);
+  const int t = threadIdx.x, me = a.d.me;
+  const uint32_t W = gridDim.x * gridDim.y, w = blockIdx.y * gridDim.x + blockIdx.x;
+  DsyncPage* mine = a.d.page[me];
+  if (sh.fail == DSYNC_OK) {
+    const int nsteps = sched_nsteps(a);
+    for (int g = 1; g <= nsteps; g++) {
+      if (t == 0) sched_step(a, sh, g, (int)blockIdx.y, &st);
+      __syncthreads();
+      const int wait_rank = st.wait_rank, ns = st.ns;
+      if (wait_rank >= 0) {
+        if (t == 0) {
+          const uint32_t why = dsync_spin(step_flags(mine) + (size_t)wait_rank * kStepSlots + w, (sh.epoch << 8) | st.wait_val, a.d);
+          if (why != DSYNC_OK) atomicMax(&sh.fail, why);
+        }
+        __syncthreads();
+        if (sh.fail != DSYNC_OK) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // the peer's step is in its buffer: not from a stale line
+      }
+      const uint64_t D = st.D, A = st.A, B = st.B, lo = st.lo, hi = st.hi;
+      if (ns == 2) range_apply<T, OP, 2>(D, A, B, lo, hi, w, W);
+      else if (ns == 1) range_apply<uint8_t, OP_SUM, 1>(D, A, A, lo, hi, w, W);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t == 0 && (st.sig[0] >= 0 || st.sig[1] >= 0)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // what this worker stored is visible before the flag is
+        const uint64_t val = (sh.epoch << 8) | st.sig_val;
+        for (int k = 0; k < 2; k++)
+          if (st.sig[k] >= 0) st_sys64(step_flags(a.d.page[st.sig[k]]) + (size_t)me * kStepSlots + w, val);
+      }
+      __syncthreads();  // st is rewritten by the next step
+    }
+  }
+  dsync_end(a.d, sh);
+}
+
+// =====================================================================================================================
+// stream-ordered Send / Receive
+// =====================================================================================================================
+
+__device__ __forceinline__ P2PBox* p2p_boxes(DsyncPage* page) {
+  return reinterpret_cast<P2PBox*>(reinterpret_cast<char*>(page) + kBoxOff);
+}
+__device__ __forceinline__ P2PAck* p2p_acks(DsyncPage* page) {
+  return reinterpret_cast<P2PAck*>(reinterpret_cast<char*>(page) + kAckOff);
+}
+__device__ __forceinline__ uint64_t* p2p_taken(DsyncPage* page) {
+  return reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(page) + kTakenOff);
+}
+__device__ __forceinline__ P2PGo* p2p_go(DsyncPage* page) {
+  return reinterpret_cast<P2PGo*>(reinterpret_cast<char*>(page) + kGoOff);
+}
+
+__device__ __forceinline__ uint32_t p2p_spin(const uint64_t* p, uint64_t want, const P2PArgs& a) {
+  return spin_until(p, want, a.abort_word, a.spin_limit);
+}
+
+__device__ __forceinline__ void p2p_host_done(const P2PArgs& a, uint64_t status, uint64_t bytes) {
+  if (!a.host_done) return;
+  st_sys64(a.host_done + 1, status);
+  st_sys64(a.host_done + 2, bytes);
+  __hip_atomic_store(a.host_done, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// One wave.  Message `seq` of the pair goes into box (seq - 1) % kP2PBoxes of the receiver's allocation -- once the
+// message that used the box before has been answered -- and the kernel ends when the receiver has answered this one:
+// the payload has been consumed, the caller's buffer is free (the rendezvous of network.go:569).
+__global__ __launch_bounds__(64) void p2p_send_kernel(P2PArgs a) {
+  if (threadIdx.x != 0) return;
+  const int b = (int)((a.seq - 1) % kP2PBoxes);
+  P2PAck* ack = p2p_acks(a.my_page) + (size_t)a.peer * kP2PBoxes + b;  // written by the receiver
+  uint32_t why = DSYNC_OK;
+  if (a.seq > (uint64_t)kP2PBoxes) why = p2p_spin(&ack->seq, a.seq - kP2PBoxes, a);
+  uint64_t status = 0;
+  if (why == DSYNC_OK) {
+    P2PBox* box = p2p_boxes(a.peer_page) + (size_t)a.me * kP2PBoxes + b;
+    st_sys64(&box->tag, (uint64_t)(uint32_t)a.tag | ((uint64_t)(uint32_t)a.dtype << 32));
+    st_sys64(&box->bytes, a.bytes);
+    st_sys64(&box->gen, a.gen);
+    st_sys64(&box->slot, a.slot);
+    st_sys64(&box->off, a.off);
+    // the payload was written by earlier work on this stream (possibly on another XCD: the kernel boundary wrote
+    // that back); the release orders the record before its number
+    __hip_atomic_store(&box->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    why = p2p_spin(&ack->seq, a.seq, a);
+    if (why == DSYNC_OK) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+      status = ld_sys64(&ack->status);
+    }
+  }
+  if (why != DSYNC_OK) status = 0x100u + why;  // (xmpi codes are small: 0x100 + DsyncStatus marks a wait that was cut short)
+  p2p_host_done(a, status, a.bytes);
+}
+
+// Block 0 finds the box of (peer -> me) that carries this tag, checks it, translates where the payload lives and
+// tells the other blocks (go record); everybody copies; the block that finishes last answers the sender and the host.
+__global__ __launch_bounds__(kBlock) void p2p_recv_kernel(P2PArgs a) {
+  __shared__ uint64_t s_src, s_bytes, s_status, s_seq;
+  __shared__ int s_box;
+  __shared__ uint32_t s_last;
+  const int t = threadIdx.x;
+  P2PGo* go = p2p_go(a.my_page) + (a.op_id % kP2PGoSlots);
+  if (t == 0) {
+    if (blockIdx.x == 0) {
+      P2PBox* boxes = p2p_boxes(a.my_page) + (size_t)a.peer * kP2PBoxes;
+      uint64_t* taken = p2p_taken(a.my_page) + (size_t)a.peer * kP2PBoxes;
+      uint64_t status = 0, src = 0, bytes = 0, seq = 0;
+      int found = -1;
+      const uint64_t t0 = wall_clock64();
+      for (uint32_t k = 1;; k++) {
+        uint64_t best = ~0ull;
+        for (int b = 0; b < kP2PBoxes; b++) {  // the oldest unconsumed message with this tag
+          const uint64_t s = __hip_atomic_load(&boxes[b].seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (s == 0 || s <= ld_sys64(&taken[b]) || s >= best) continue;
+          if ((int32_t)(uint32_t)ld_sys64(&boxes[b].tag) != a.tag) continue;
+          best = s;
+          found = b;
+        }
+        if (found >= 0) break;
+        __builtin_amdgcn_s_sleep(1);
+        if ((k & 63u) == 0) {
+          if (a.abort_word && __hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
+            status = 0x100u + DSYNC_ABORTED;
+            break;
+          }
+          if (a.spin_limit && wall_clock64() - t0 > a.spin_limit) {
+            status = 0x100u + DSYNC_TIMEOUT;
+            break;
+          }
+        }
+      }
+      if (found >= 0) {
+        const P2PBox* box = &boxes[found];
+        seq = ld_sys64(&box->seq);
+        bytes = ld_sys64(&box->bytes);
+        const int dt = (int)(ld_sys64(&box->tag) >> 32) & 0xff;
+        if (dt != a.dtype) status = 1;         // -> XMPI_ERR_ARG
+        else if (bytes > a.bytes) status = 6;  // -> XMPI_ERR_TRUNCATE
+        else if (bytes > 0) {
+          src = translate(a.comm_tag, a.table, a.my_page, a.peer, ld_sys64(&box->slot), ld_sys64(&box->gen), ld_sys64(&box->off));
+          if (!src) status = 0x100u + DSYNC_UNMAPPED;
+        }
+        st_sys64(&taken[found], seq);
+      }
+      s_src = src;
+      s_bytes = bytes;
+      s_status = status;
+      s_seq = seq;
+      s_box = found;
+      if (gridDim.x > 1) {
+        st_sys64(&go->src, src);
+        st_sys64(&go->bytes, bytes);
+        st_sys64(&go->status, status);
+        st_sys64(&go->seq, seq);
+        st_sys64(&go->box, (uint64_t)(int64_t)found);
+        __hip_atomic_store(&go->id, a.op_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      while (__hip_atomic_load(&go->id, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != a.op_id) __builtin_amdgcn_s_sleep(1);
+      s_src = ld_sys64(&go->src);
+      s_bytes = ld_sys64(&go->bytes);
+      s_status = ld_sys64(&go->status);
+      s_seq = ld_sys64(&go->seq);
+      s_box = (int)(int64_t)ld_sys64(&go->box);
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // the payload as the sender left it, not a stale line
+  const uint64_t src = s_src, bytes = s_status ? 0 : s_bytes;
+  if (bytes) {
+    char* dst = reinterpret_cast<char*>(a.buf);
+    if (((src | (uint64_t)(uintptr_t)dst) & 15u) == 0) {
+      const size_t npack = bytes / 16;
+      for (size_t i = (size_t)blockIdx.x * kBlock + t; i < npack; i += (size_t)gridDim.x * kBlock)
+        reinterpret_cast<pack_t*>(dst)[i] = ldp<2>(reinterpret_cast<const pack_t*>(src) + i);
+      if (blockIdx.x == 0 && npack * 16 + t < bytes) dst[npack * 16 + t] = reinterpret_cast<const char*>(src)[npack * 16 + t];
+    } else {
+      for (size_t i = (size_t)blockIdx.x * kBlock + t; i < bytes; i += (size_t)gridDim.x * kBlock) dst[i] = reinterpret_cast<const char*>(src)[i];
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (t == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    s_last = gridDim.x == 1 || __hip_atomic_fetch_add(&go->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!s_last || t != 0) return;
+  if (gridDim.x > 1) __hip_atomic_store(&go->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (s_box >= 0) {  // the answer: the message has been consumed (or why not) -- network.go:616-624's ack
+    P2PAck* ack = p2p_acks(a.peer_page) + (size_t)a.me * kP2PBoxes + s_box;
+    st_sys64(&ack->status, s_status);
+    __hip_atomic_store(&ack->seq, s_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  p2p_host_done(a, s_status, s_bytes);
+}
+
+// =====================================================================================================================
+// launchers
+// =====================================================================================================================
+
+template <typename T, int OP>
+hipError_t body_go(const DsyncResolved* res, dim3 grid, int nsrc_hint, int mode, hipStream_t s, hipEvent_t es, hipEvent_t ee) {
+#define XMPI_BODY(NS)                                                                                         \
+  do {                                                                                                        \
+    if (mode != 0) XMPI_LAUNCH((dsync_body_kernel<T, OP, NS, 2>), grid, dim3(kBlock), s, es, ee, res);        \
+    else XMPI_LAUNCH((dsync_body_kernel<T, OP, NS, 0>), grid, dim3(kBlock), s, es, ee, res);                  \
+    return hipGetLastError();                                                                                 \
+  } while (0)
+  if constexpr (OP == OP_SUM) {
+    if (nsrc_hint == 2) XMPI_BODY(2);
+    if (nsrc_hint == 4) XMPI_BODY(4);
+    if (nsrc_hint == 8) XMPI_BODY(8);
+  }
+  XMPI_BODY(0);
+#undef XMPI_BODY
+}
+
+template <typename T>
+hipError_t body_op(const DsyncResolved* res, dim3 grid, int nsrc_hint, int op, int mode, hipStream_t s, hipEvent_t es, hipEvent_t ee) {
+  switch (op) {
+    case OP_SUM: return body_go<T, OP_SUM>(res, grid, nsrc_hint, mode, s, es, ee);
+    case OP_PROD: return body_go<T, OP_PROD>(res, grid, nsrc_hint, mode, s, es, ee);
+    case OP_MIN: return body_go<T, OP_MIN>(res, grid, nsrc_hint, mode, s, es, ee);
+    case OP_MAX: return body_go<T, OP_MAX>(res, grid, nsrc_hint, mode, s, es, ee);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+template <typename T>
+hipError_t sched_op(const DsyncSchedArgs& a, int op, dim3 grid, hipStream_t s, hipEvent_t es, hipEvent_t ee) {
+  switch (op) {
+    case OP_SUM: XMPI_LAUNCH((dsync_sched_kernel<T, OP_SUM>), grid, dim3(kBlock), s, es, ee, a); break;
+    case OP_PROD: XMPI_LAUNCH((dsync_sched_kernel<T, OP_PROD>), grid, dim3(kBlock), s, es, ee, a); break;
+    case OP_MIN: XMPI_LAUNCH((dsync_sched_kernel<T, OP_MIN>), grid, dim3(kBlock), s, es, ee, a); break;
+    case OP_MAX: XMPI_LAUNCH((dsync_sched_kernel<T, OP_MAX>), grid, dim3(kBlock), s, es, ee, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_dsync_meet(const DsyncArgs& a, DsyncResolved* out, hipStream_t s) {
+  if (a.n < 1 || a.n > kDsyncRanks || a.nseg < 0 || a.nseg > kDsyncRanks || !out) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(dsync_meet_kernel, dim3(1), dim3(64), 0, s, a, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_dsync_body(const DsyncResolved* res, int nseg, size_t max_packets, int nsrc_hint, int dtype, int op,
+                             size_t traffic_bytes, hipStream_t s, hipEvent_t es, hipEvent_t ee) {
+  if (nseg < 1 || nseg > kDsyncRanks || !res) return hipErrorInvalidValue;
+  size_t gx = (max_packets + kBlock - 1) / kBlock;
+  if (gx < 1) gx = 1;
+  if (gx > 0x3fffffu) gx = 0x3fffffu;
+  const dim3 grid((unsigned)gx, (unsigned)nseg);
+  // launches that stream more than the caches hold use non-temporal loads and stores (kernels.hip kernel_mode_for)
+  const int mode = get_kernel_mode() >= 0 ? get_kernel_mode() : (traffic_bytes >= (size_t)(48u << 20) ? 2 : 0);
+  switch (dtype) {
+    case DT_U8: return body_op<uint8_t>(res, grid, nsrc_hint, op, mode, s, es, ee);
+    case DT_I32: return body_op<int32_t>(res, grid, nsrc_hint, op, mode, s, es, ee);
+    case DT_I64: return body_op<int64_t>(res, grid, nsrc_hint, op, mode, s, es, ee);
+    case DT_F16: return body_op<_Float16>(res, grid, nsrc_hint, op, mode, s, es, ee);
+    case DT_F32: return body_op<float>(res, grid, nsrc_hint, op, mode, s, es, ee);
+    case DT_F64: return body_op<double>(res, grid, nsrc_hint, op, mode, s, es, ee);
+    case DT_BF16: return body_op<bf16_t>(res, grid, nsrc_hint, op, mode, s, es, ee);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_dsync_done(const DsyncArgs& a, const DsyncResolved* res, hipStream_t s) {
+  if (!res) return hipErrorInvalidValue;
+  // one block per XCD (the dispatcher deals consecutive blocks round the 8 XCDs): each writes back the L2 it runs on
+  hipLaunchKernelGGL(dsync_done_kernel, dim3(8), dim3(64), 0, s, a, res);
+  return hipGetLastError();
+}
+
+hipError_t launch_dsync_sched(const DsyncSchedArgs& a, int dtype, int op, int grid_x, hipStream_t s, hipEvent_t es, hipEvent_t ee) {
+  if (a.d.n < 1 || a.d.n > kDsyncRanks || a.nchan < 1 || a.nchan > kMaxSchedChannels || grid_x < 1 ||
+      (size_t)grid_x * (size_t)a.nchan > (size_t)kStepSlots)
+    return hipErrorInvalidValue;
+  const dim3 grid((unsigned)grid_x, (unsigned)a.nchan);
+  if (a.sched == SCHED_RING_ALLGATHER || a.sched == SCHED_TREE_BCAST) return sched_op<uint8_t>(a, OP_SUM, grid, s, es, ee);
+  switch (dtype) {
+    case DT_U8: return sched_op<uint8_t>(a, op, grid, s, es, ee);
+    case DT_I32: return sched_op<int32_t>(a, op, grid, s, es, ee);
+    case DT_I64: return sched_op<int64_t>(a, op, grid, s, es, ee);
+    case DT_F16: return sched_op<_Float16>(a, op, grid, s, es, ee);
+    case DT_F32: return sched_op<float>(a, op, grid, s, es, ee);
+    case DT_F64: return sched_op<double>(a, op, grid, s, es, ee);
+    case DT_BF16: return sched_op<bf16_t>(a, op, grid, s, es, ee);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_p2p_send(const P2PArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(p2p_send_kernel, dim3(1), dim3(64), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_p2p_recv(const P2PArgs& a, int grid_x, hipStream_t s) {
+  if (grid_x < 1) grid_x = 1;
+  hipLaunchKernelGGL(p2p_recv_kernel, dim3((unsigned)grid_x), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace xmpi

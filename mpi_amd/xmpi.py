@@ -98,6 +98,10 @@ SYMBOLS = [
     ("xmpi_graph_end", _I, [_P, _P, C.POINTER(_P)]),
     ("xmpi_graph_launch", _I, [_P, _P, _P]),
     ("xmpi_graph_destroy", _I, [_P, _P]),
+    ("xmpi_send_on_stream", _I, [_P, _P, _Z, _I, _I, _I, _P]),
+    ("xmpi_recv_on_stream", _I, [_P, _P, _Z, _I, _I, _I, _P]),
+    ("xmpi_tune", _I, [_P, _Z]),
+    ("xmpi_tune_decide", _I, [C.POINTER(C.c_double), _I, C.c_double]),
 ]
 
 _lib: Optional[C.CDLL] = None
