@@ -1,33 +1,35 @@
 #!/usr/bin/env python3
-"""bench.py -- allreduce bandwidth of the xmpi hot path (BASELINE.json metric), one JSON line.
+"""bench.py -- allreduce bandwidth of the xmpi hot path (BASELINE.json metric), ONE compact JSON line.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (BASELINE.json config 4, the one the metric is quoted on): allreduce-sum of 256 MiB of
 float32 per rank over 8 ranks.  The job always has 8 ranks; they are spread over the N GPUs the
-run was given (N = 8: one rank per MI355X, the north-star layout; N = 4 / 2 / 1: 2 / 4 / 8 ranks
-share each GPU, hosted as threads of the per-GPU process and talking through the same HBM windows,
-pipes and kernels -- peer copies between co-located ranks stay inside one HBM instead of crossing
-xGMI).  Total work is fixed as N grows, so "scaling" is "strong".  A step = one allreduce; inputs
-are generated on the device before the timed region (nothing crosses PCIe while timing).
+run was given (N = 8: one rank per MI355X, the north-star layout, ranks meeting on the device; N = 4 / 2 / 1:
+2 / 4 / 8 ranks share each GPU, hosted as threads of the per-GPU process).  Total work is fixed as N grows,
+so "scaling" is "strong".  A step = one allreduce; inputs are generated on the device before the timed
+region (nothing crosses PCIe while timing).
 
 value = algbw = S / t, the nccl-tests convention BASELINE.json's metric names (S = bytes per rank, GB = 1e9 B),
-with t = max over ranks of the barrier-bracketed time of K steps / K; busbw = algbw x 2(R-1)/R is alongside,
-and `busbw_table` holds busbw against message size at 1 / 2 / 4 / 8 ranks (the other half of the metric).
+with t = max over ranks of the barrier-bracketed time of K steps / K; busbw = algbw x 2(R-1)/R alongside, and
+`busbw_at_size` = busbw at the workload's size for 1 / 2 / 4 / 8 ranks.
 
-roofline: the dominant kernel of the timed region -- reduce_n_multi_kernel<float,SUM,8> on the zero-copy
-path (folds chunk j of the 8 send buffers in rank order and stores it into the 8 receive buffers:
-8 reads + 8 writes = 64 algorithmic bytes per f32 element; with one process per GPU the same fold inside
-dsync_fold_kernel, which is also where the ranks meet), reduce2 / reduce_n on the staged schedules.
-Sampled launches inside the timed region carry HIP events attached to their dispatch (libxmpi's
-profiling hooks), on the stream the kernel runs on.  Before timing, the schedule is auto-tuned
-(zero-copy vs ring / halving / direct and their knobs) and only a candidate whose result matches the
-rank-order oracle on every rank is timed.
+The schedule is the LIBRARY's (XMPI_ALGO_AUTO: its own tuned table where ranks meet on the device -- xmpi_tune --
+and the zero-copy fold otherwise); `--algo` names one instead.  The result of the schedule that is timed is checked
+against the CPU oracle over the WHOLE buffer before timing (rank r its chunk and the chunk boundaries, all ranks'
+buffers shown identical by checksums).
 
-cpu_baseline (N = 1, rank 0 only): the reference path -- mpi.Network over loopback TCP with gob
-framing -- restated in C++ (oracle/refpath.cpp, "kind": "port": the image has no Go toolchain),
-8 OS processes on the host cores, composing the allreduce the way a reference user would.
+roofline: the dominant kernel of the timed region with HIP events attached to sampled dispatches (on the stream the
+kernel runs on).  N = 1 hosts the 8 ranks as threads: reduce_n_multi_kernel folds all chunks.  `roofline_production`
+(N = 1 only) is the same workload with ONE OS PROCESS PER RANK (examples/allreduce_bench under the launcher): the kernels
+the north-star layout runs -- dsync_fold_kernel, or dsync_body_kernel between the meet and done kernels.
+
+cpu_baseline (N = 1, rank 0 only): the reference path -- mpi.Network over loopback TCP with gob framing -- restated in
+C++ (oracle/refpath.cpp, "kind": "port": the image has no Go toolchain), 8 OS processes on the host cores.
+
+Everything else (per-algorithm times, size sweeps, cfg 2 / 3 / 5, the one-process-per-rank sweeps) goes to
+bench_extras.json beside this file (and gpurun_out/ when that exists), not to stdout.
 """
 from __future__ import annotations
 
@@ -65,6 +67,8 @@ def parse_args():
     ap.add_argument("--algo", default="auto", choices=["auto", "ring", "rhd", "direct", "zcopy", "zpush"])
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed sweeps after the timed region")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU reference-path baseline")
+    ap.add_argument("--no-production", action="store_true",
+                    help="skip the one-process-per-rank run of the same workload (roofline_production, N = 1 only)")
     ap.add_argument("--probe", action="store_true",
                     help="(internal) a short zero-copy allreduce in a job of its own; the exit status is the verdict")
     ap.add_argument("--no-probe", action="store_true", help="skip the zero-copy probe before a multi-GPU run")
@@ -157,18 +161,28 @@ def timed(comm, fn, iters: int, prof: bool = False, batch=None) -> float:
     return all_max(comm, dt)
 
 
-def check_window(comm, send, recv, count, dtype, seed0, off, n):
-    """the result window [off, off+n) against the rank-order CPU oracle"""
+def check_whole(comm, recv, count, dtype, seed0):
+    """This rank's share of the WHOLE result against the rank-order CPU oracle (oracle_check_allreduce regenerates every
+    rank's input block by block): chunk `rank` and 4 Ki elements either side of it -- all chunks and all chunk boundaries
+    are covered between the ranks -- plus a checksum of the entire buffer, which the caller compares across ranks.
+    f32 / f16 inputs are such that the rank-order sum is what every schedule must reproduce within 1e-6 * sum|x| (f32) or
+    exactly (f16: k/64)."""
     from oracle import oracle
-    from tests.scenarios import oracle_fill_window
-    ins = [oracle_fill_window(dtype, seed0 + r, off, n) for r in range(comm.size())]
-    want = oracle.reduce_ranks(ins, dtype, oracle.SUM)
-    got = recv.download(xmpi.NUMPY_DTYPE[dtype], n, byte_offset=off * xmpi.DTYPE_SIZE[dtype])
-    if dtype == xmpi.F16:
-        return got.tobytes() == want.tobytes(), 0.0
-    err = np.abs(got.astype(np.float64) - want.astype(np.float64))
-    bound = 1e-6 * np.sum([np.abs(x.astype(np.float64)) for x in ins], axis=0)
-    return bool(np.all(err <= bound)), float(err.max())
+    R, r = comm.size(), comm.rank()
+    es = xmpi.DTYPE_SIZE[dtype]
+    per = (count + R - 1) // R
+    lo, hi = max(0, r * per - 4096), min(count, (r + 1) * per + 4096)
+    got = recv.download(xmpi.NUMPY_DTYPE[dtype], hi - lo, byte_offset=lo * es)
+    bad, first = oracle.check_allreduce(got, lo, dtype, xmpi.PAT_UNIFORM, seed0, R, oracle.SUM)
+    worst = 0.0
+    ok = bad == 0
+    if bad and dtype == xmpi.F32:  # another summation order: the per-element tolerance rule over the same range
+        ins = [oracle.fill_range(lo, hi - lo, dtype, xmpi.PAT_UNIFORM, seed0 + q).astype(np.float64) for q in range(R)]
+        want = oracle.reduce_ranks([x.astype(np.float32) for x in ins], dtype, oracle.SUM).astype(np.float64)
+        err = np.abs(got.astype(np.float64) - want)
+        worst = float(err.max())
+        ok = bool(np.all(err <= 1e-6 * np.sum(np.abs(ins), axis=0)))
+    return ok, bad, worst, comm.checksum(recv, count * es), hi - lo
 
 
 def rank_main(job: Job, grank: int):
@@ -216,106 +230,66 @@ def rank_main(job: Job, grank: int):
     def run_n(algo, iters):
         comm.allreduce_repeat(send, recv, count, dtype, xmpi.SUM, algo, iters)
 
-    # ---- untimed: pick the schedule (all ranks see the same max-over-ranks times) -----------------
-    tune = []
+    # ---- the schedule: the LIBRARY's (AUTO), unless one was named ---------------------------------------------------
+    # Ranks that meet on the device: xmpi_tune times the library's schedules on these very GPUs / links and AUTO follows
+    # its table; ranks hosted by threads of one process meet on the host, where AUTO is the zero-copy fold.
+    by_name = {v: k for k, v in ALGO_NAME.items()}
+    tune = {"by": "library defaults (ranks meet on the host: one schedule)"}
     if a.algo == "auto":
-        cands = []
-        if R > 1:
-            nch = max(1, comm.get_param("ring_channels"))  # N-2 edge-disjoint directed rings on an even mesh
-            for ch in sorted({k for k in (1, 2, 4, nch) if k <= nch}):
-                for eng in (0, 1):
-                    cands.append((xmpi.ALGO_RING, ch, eng))
-            for eng in (0, 1):
-                cands.append((xmpi.ALGO_DIRECT, 1, eng))
-                if R & (R - 1) == 0:
-                    cands.append((xmpi.ALGO_RHD, 1, eng))
-        else:
-            cands = [(xmpi.ALGO_RING, 1, 0)]
-        slot = comm.get_param("slot_bytes")
-        pieces = sorted({0, slot}) if R > 1 else [0]  # 0 = library heuristic (~4 pieces per chunk)
-        cands = [(al, ch, eng, {}) for al, ch, eng in cands]
-        if R > 1 and zc_ok:
-            # no staging: channels / engine / piece size do not apply.  One process per GPU: the ranks can meet on the
-            # device (one kernel per rank is the collective) -- with 1 or 2 packets per lane per source in flight (remote
-            # loads over a link are round trips) -- or on the host as before; co-located ranks only meet on the host
-            if dsync_can:
-                cands.append((xmpi.ALGO_ZCOPY, 1, 0, {"dsync": 1, "dsync_unroll": 1}))
-                cands.append((xmpi.ALGO_ZCOPY, 1, 0, {"dsync": 1, "dsync_unroll": 2}))
-                cands.append((xmpi.ALGO_ZPUSH, 1, 0, {"dsync": 1}))  # only WRITES over xGMI: push, local fold, push back
-                cands.append((xmpi.ALGO_ZCOPY, 1, 0, {"dsync": 0}))
-                cands.append((xmpi.ALGO_ZPUSH, 1, 0, {"dsync": 0}))  # ... the same with host barriers between the kernels
-            else:
-                cands.append((xmpi.ALGO_ZCOPY, 1, 0, {}))
-                cands.append((xmpi.ALGO_ZPUSH, 1, 0, {}))
-        for algo, ch, eng, extra in cands:
-            for pc in (pieces if algo not in ZC_ALGOS else [0]):
-                comm.set_param("channels", ch)
-                comm.set_param("copy_engine", eng)
-                comm.set_param("piece_bytes", pc)
-                for k, v in extra.items():
-                    comm.set_param(k, v)
-                run(algo)
-                t = timed(comm, None, 2, batch=lambda k: run_n(algo, k))
-                tune.append({"algo": ALGO_NAME[algo], "channels": ch, "copy_engine": eng, "piece_bytes": pc,
-                             "params": extra, "ms": t * 1e3, "algbw_GBps": nbytes / t / 1e9})
-            if dsync_can:
-                comm.set_param("dsync", 1)
-        best = min(tune, key=lambda x: x["ms"])
-        best_ring = min((x for x in tune if x["algo"] == "ring"), key=lambda x: x["ms"])
-        algo = {v: k for k, v in ALGO_NAME.items()}[best["algo"]]
-        comm.set_param("channels", best["channels"])
-        comm.set_param("copy_engine", best["copy_engine"])
-        comm.set_param("piece_bytes", best["piece_bytes"])
-        for k, v in best.get("params", {}).items():
-            comm.set_param(k, v)
+        algo = xmpi.ALGO_AUTO
+        if dsync_can:
+            t0 = time.perf_counter()
+            comm.tune(min(nbytes, 1 << 30))
+            cls = max(0, min(23, nbytes.bit_length() - 9))
+            tune = {"by": "xmpi_tune (library)", "ms": (time.perf_counter() - t0) * 1e3, "size_class": cls,
+                    "algo": ALGO_NAME.get(comm.get_param(f"tune_algo_0_{cls}"), "default"),
+                    "split": comm.get_param(f"tune_split_0_{cls}"), "unroll": comm.get_param(f"tune_unroll_0_{cls}"),
+                    "table_algo": [comm.get_param(f"tune_algo_0_{k}") for k in range(24)],
+                    "table_split": [comm.get_param(f"tune_split_0_{k}") for k in range(24)]}
+        order = [xmpi.ALGO_AUTO] + ([xmpi.ALGO_ZCOPY] if zc_ok else []) + [xmpi.ALGO_DIRECT, xmpi.ALGO_RING]
     else:
         forced = a.algo if (a.algo not in ("zcopy", "zpush") or zc_ok) else "ring"
-        algo = {v: k for k, v in ALGO_NAME.items()}[forced]
-        best = {"algo": forced, "channels": comm.get_param("channels"), "copy_engine": comm.get_param("copy_engine"),
-                "piece_bytes": comm.get_param("piece_bytes")}
-        best_ring = None
+        algo = by_name[forced]
+        order = [algo]
 
-    # ---- warmup + parity of the chosen schedule against the oracle --------------------------------
-    # Candidates in order of measured speed; the first whose result matches the oracle ON EVERY RANK is
-    # used (a schedule that is fast but wrong on this machine is reported, never timed).
-    by_name = {v: k for k, v in ALGO_NAME.items()}
-    order = sorted(tune, key=lambda x: x["ms"]) if tune else [best]
+    # ---- warmup + parity of the schedule that will be timed, over the WHOLE buffer ------------------------------------
+    # (a schedule that is wrong on this machine is reported and the next one takes its place, never timed)
     parity, parity_failures, chosen = {"checked": False}, [], None
-    for cand in order[:6]:
-        algo = by_name[cand["algo"]]
-        comm.set_param("channels", cand["channels"])
-        comm.set_param("copy_engine", cand["copy_engine"])
-        comm.set_param("piece_bytes", cand.get("piece_bytes", 0))
-        for k, v in cand.get("params", {}).items():
-            comm.set_param(k, v)
+    for cand in order:
         comm.memset(recv, 0, nbytes)
         for _ in range(max(1, a.warmup)):
-            run(algo)
-        info = {"checked": False}
-        ok_here = True
+            run(cand)
+        info, ok_here, csum = {"checked": False}, True, 0
         if dtype in (xmpi.F32, xmpi.F16) and count >= 1 << 16:
-            oks, worst = [], 0.0
-            for off in (0, (count // 3) // 8 * 8, count - 65536):
-                ok, err = check_window(comm, send, recv, count, dtype, seed0, off, 65536)
-                oks.append(ok)
-                worst = max(worst, err)
-            ok_here = all(oks)
-            info = {"checked": True, "ok": ok_here, "max_abs_err": worst, "bit_identical": worst == 0.0 and ok_here,
+            ok_here, nbad, worst, csum, nchecked = check_whole(comm, recv, count, dtype, seed0)
+            info = {"checked": True, "ok": ok_here, "elements_checked_by_this_rank": nchecked, "not_bit_identical": nbad,
+                    "max_abs_err": worst, "bit_identical": nbad == 0,
+                    "coverage": "whole buffer: rank r checks chunk r and the chunk boundaries against the rank-order oracle; "
+                                "the ranks' buffers are identical (checksums)",
                     "rule": "bit-exact" if dtype == xmpi.F16 else "|delta| <= 1e-6 * sum_i|x_i| vs rank-order oracle"}
-        if all_max(comm, 0.0 if ok_here else 1.0) == 0.0:
-            parity, chosen, best = info, cand, cand
+        sums = np.zeros(R, dtype=np.int64)
+        comm.allgather(np.array([csum & 0x7FFFFFFFFFFFFFFF], dtype=np.int64), sums, 1, xmpi.I64, xmpi.ALGO_DIRECT)
+        same = bool(np.all(sums == sums[0]))
+        if all_max(comm, 0.0 if (ok_here and same) else 1.0) == 0.0:
+            parity, chosen, algo = info, cand, cand
             break
-        parity_failures.append({"candidate": cand, "rank": grank, "local": info})
+        parity_failures.append({"algo": ALGO_NAME.get(cand, "auto"), "rank": grank, "local": info, "buffers_identical": same})
     if chosen is None:
         raise AssertionError(f"rank {grank}: no schedule reproduces the oracle: {parity_failures}")
+    best = {"algo": ALGO_NAME.get(algo, "auto (library)"), "channels": comm.get_param("channels"),
+            "copy_engine": comm.get_param("copy_engine"), "piece_bytes": comm.get_param("piece_bytes")}
+    best_ring = None
 
     # ---- timed region: exactly K steps ----------------------------------------------------------------
     comm.prof_reset()
     # every 4th launch of a kind carries its own begin/end events (hipExtLaunchKernelGGL): the events are
     # exact per dispatch whatever runs around them, and sampling keeps their cost out of `value`
     # (a zero-copy step is ONE launch per GPU process: every 2nd carries events)
-    comm.set_param("prof_every", 2 if algo == xmpi.ALGO_ZCOPY else (1 if algo == xmpi.ALGO_ZPUSH else 4))
+    comm.set_param("prof_every", 2 if algo in (xmpi.ALGO_ZCOPY, xmpi.ALGO_AUTO) else (1 if algo == xmpi.ALGO_ZPUSH else 4))
+    sl0, sc0 = comm.get_param("dsync_split_launches"), comm.get_param("dsync_sched_launches")
     t_step = timed(comm, None, a.steps, prof=True, batch=lambda k: run_n(algo, k))
+    form = ("stepped" if comm.get_param("dsync_sched_launches") > sc0 else
+            "split" if comm.get_param("dsync_split_launches") > sl0 else "one kernel")
     prof = {k: comm.prof_get(k) for k in (xmpi.PROF_REDUCE2, xmpi.PROF_REDUCEN, xmpi.PROF_COPY, xmpi.PROF_PEER,
                                           xmpi.PROF_ZCOPY)}
 
@@ -328,7 +302,7 @@ def rank_main(job: Job, grank: int):
         comm.prof_reset()
         comm.prof_enable(True)
         comm.set_param("prof_every", 1)
-        if algo == xmpi.ALGO_ZCOPY:  # the same N-source, N-destination launch, all operands local
+        if algo in (xmpi.ALGO_ZCOPY, xmpi.ALGO_AUTO) and prof[xmpi.PROF_ZCOPY][0]:  # the same N-source, N-destination launch, all operands local
             nz, _, bz = prof[xmpi.PROF_ZCOPY]
             per = int(bz / nz / (2 * R * es)) if nz else chunk  # elements one launch of the timed region folded
             zs = [comm.alloc(per * es) for _ in range(R)]
@@ -358,7 +332,7 @@ def rank_main(job: Job, grank: int):
     # one GPU does not, whatever --gpus says)
     transport = ("xGMI (one rank per GPU)" if ndev_used == R else
                  "intra-HBM (all ranks share one GPU)" if ndev_used == 1 else f"mixed: {R} ranks on {ndev_used} GPUs (intra-HBM + xGMI)")
-    out = {"link": link, "transport": transport, "devices": ndev_used, "dsync": comm.get_param("dsync"), "t_step": t_step, "prof": prof, "tune": tune, "best": best, "best_ring": best_ring, "parity": parity,
+    out = {"form": form, "link": link, "transport": transport, "devices": ndev_used, "dsync": comm.get_param("dsync"), "t_step": t_step, "prof": prof, "tune": tune, "best": best, "best_ring": best_ring, "parity": parity,
            "algo": algo, "nbytes": nbytes, "count": count, "iso": iso, "parity_failures": parity_failures,
            "shared_stream": comm.get_param("shared_stream"), "slot_bytes": comm.get_param("slot_bytes"),
            "zero_copy_probe": {"dsync": "ok: ranks meet on the device", "host": "device rendezvous failed, host rendezvous ok",
@@ -367,28 +341,14 @@ def rank_main(job: Job, grank: int):
     # ---- untimed extras: what the next round needs to tune blind multi-GPU runs -----------------------
     extras = {}
     if not a.no_extras and R > 1:
-        def apply(cand):
-            comm.set_param("channels", cand["channels"])
-            comm.set_param("copy_engine", cand["copy_engine"])
-            comm.set_param("piece_bytes", cand.get("piece_bytes", 0))
-            for k, v in cand.get("params", {}).items():
-                comm.set_param(k, v)
-
         extras["algos_at_size"] = {}
         for al in (xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_DIRECT) + (ZC_ALGOS if zc_ok else ()):
             if al == xmpi.ALGO_RHD and R & (R - 1):
                 continue
-            mine = [x for x in tune if x["algo"] == ALGO_NAME[al]]
-            cand = min(mine, key=lambda x: x["ms"]) if mine else best
-            apply(cand)  # each algorithm with ITS best tuned settings
             run(al)
-            t = timed(comm, lambda: run(al), 3)
+            t = timed(comm, None, 3, batch=lambda k, a2=al: run_n(a2, k))
             extras["algos_at_size"][ALGO_NAME[al]] = {"ms": t * 1e3, "algbw_GBps": nbytes / t / 1e9,
-                                                      "busbw_GBps": nbytes / t / 1e9 * 2 * (R - 1) / R,
-                                                      "channels": cand["channels"], "copy_engine": cand["copy_engine"],
-                                                      "piece_bytes": cand.get("piece_bytes", 0)}
-        apply(best)
-        comm.set_param("piece_bytes", 0)  # the size sweep lets the library pick the piece size per message
+                                                      "busbw_GBps": nbytes / t / 1e9 * 2 * (R - 1) / R}
         sweep = []
         sz = 1 << 10
         while sz <= min(nbytes, 1 << 30):
@@ -655,10 +615,12 @@ def main():
         sys.exit(1 if job.errors else 0)
     # One OS process per rank on this box's GPU, before THIS process opens the GPU: a GPU schedules the queues of at most
     # 8 processes at once, and a ninth (this one, with its rank threads) would have the other eight time-sliced
-    mp_sweep = None
-    mp_first = os.environ.get("XMPI_BENCH_MP_FIRST", "1") == "1"  # (0: afterwards -- measured 862 us instead of 35: hipDeviceReset does not give the queues back)
-    if mp_first and args.gpus == 1 and job.procs == 1 and not args.no_extras and not args.probe:
-        mp_sweep = multiprocess_sweep(job.ranks)
+    # (afterwards would not do -- measured 862 us instead of 35: hipDeviceReset does not give the queues back)
+    job.mp_sweep = job.production = None
+    if args.gpus == 1 and job.procs == 1 and not args.probe and not args.no_production:
+        job.production = production_layout(job.ranks, int(args.size_mib * (1 << 20)), args.steps, args.warmup)
+    if args.gpus == 1 and job.procs == 1 and not args.no_extras and not args.probe:
+        job.mp_sweep = multiprocess_sweep(job.ranks)
     if (args.gpus > 1 or job.procs > 1) and not args.no_probe:
         job.probe = probe_zero_copy(job)
         job.zero_copy_ok = job.probe != "failed"
@@ -686,7 +648,13 @@ def main():
         kname, launches, ms, by = ("zero-copy push pipeline: copy_batch_kernel (contributions into the peers' receive buffers) + "
                                    f"reduce_n_multi_kernel<float,SUM,{R}> (local rank-order fold) + copy_multi_kernel (results to "
                                    "all peers); bytes and time summed over the three"), nz, msz, bz
-    elif nz and msz >= max(ms2, msn) and r0["dsync"] == 1 and r0["best"].get("params", {}).get("dsync", 1) == 1:
+    elif nz and msz >= max(ms2, msn) and r0["dsync"] == 1 and r0["form"] == "stepped":
+        kname, launches, ms, by = (f"dsync_sched_kernel<float,SUM> (a stepped schedule -- ring or recursive halving + doubling -- inside ONE "
+                                   "kernel per rank: every step released by the peer's flag word; its duration includes waiting)"), nz, msz, bz
+    elif nz and msz >= max(ms2, msn) and r0["dsync"] == 1 and r0["form"] == "split":
+        kname, launches, ms, by = (f"dsync_body_kernel<float,SUM,{R}> (the fold of chunk j of the {R} send buffers in rank order into the {R} "
+                                   "receive buffers, between the one-block meet and done kernels: no waiting inside)"), nz, msz, bz
+    elif nz and msz >= max(ms2, msn) and r0["dsync"] == 1:
         kname, launches, ms, by = (f"dsync_fold_kernel<float,SUM,{R}> (one kernel per rank IS the allreduce: rendezvous through flag "
                                    f"words in HBM, fold of chunk j of the {R} send buffers in rank order into the {R} receive buffers, "
                                    "completion exchange; its duration includes waiting for the slowest peer)"), nz, msz, bz
@@ -706,18 +674,19 @@ def main():
     # attached only when this run launched the same kernel on the same number of bytes
     traffic, traffic_src = None, "PMC counters are collected in separate rocprofv3 passes (profiles/); none matches this launch size"
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:  # rewritten from each round's --pmc passes
             pmc = json.load(f)
         stem = kname.split("<")[0].split(" ")[0]
         for row in pmc["rows"]:
             if row["kernel"].startswith(stem) and launches and abs(row["traffic_bytes_per_launch"] / (by / launches) - 1) < 0.01:
                 traffic = row["traffic_bytes_per_launch"]
-                traffic_src = "profiles/pmc_traffic.json (" + row["kernel"] + ", " + row["schedule"] + "): " + pmc["source"]
+                traffic_src = f"profiles/pmc_traffic.json round {pmc.get('round')} (" + row["kernel"] + ", " + row["schedule"] + "): " + pmc["source"]
                 break
     except (OSError, ValueError, KeyError):
         pass
-    roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+    roof = {"bound": "hbm", "kernel": kname.split(" (")[0], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_from_profile": True, "traffic_source": traffic_src,
+            "kernel_detail": kname,
             "launches": launches, "avg_launch_us": (ms * 1e3 / launches) if launches else None,
             "algorithmic_bytes_per_launch": (by / launches) if launches else None,
             "note": "live HIP events on the kernel's own stream inside the timed region (rank 0's launches); "
@@ -732,6 +701,14 @@ def main():
         if n_k and ms_k > 0:
             others[label] = {"launches": n_k, "avg_launch_us": ms_k * 1e3 / n_k, "bytes_per_launch": factor * by_k / n_k,
                              "GBps": factor * by_k / (ms_k * 1e-3) / 1e9, "frac_of_hbm_peak": factor * by_k / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    size_rows = {}
+    try:
+        for x in r0["extras"].get("busbw_table", {}).get("rows", []):
+            if x["bytes"] == min(S, 1 << 30) or x["bytes"] == max(y["bytes"] for y in r0["extras"]["busbw_table"]["rows"]):
+                size_rows[str(x["ranks"])] = {"bytes": x["bytes"], "busbw_GBps": round(x["busbw_GBps"], 2), "algbw_GBps": round(x["algbw_GBps"], 2)}
+    except (KeyError, ValueError, TypeError):
+        pass
+    meaningful = r0["devices"] == R
     line = {
         "metric": f"allreduce_sum_{args.dtype}_{args.size_mib:g}MiB algbw",
         "value": algbw, "unit": "GB/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
@@ -739,42 +716,116 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"BASELINE cfg 4: allreduce-sum {args.dtype} {args.size_mib:g} MiB/rank, {R} ranks",
                    "ranks": R, "ranks_per_gpu": R // args.gpus, "bytes_per_rank": S,
-                   "algo": r0["best"]["algo"], "channels": r0["best"]["channels"],
-                   "copy_engine": "copy_kernel" if r0["best"]["copy_engine"] else "hipMemcpyAsync",
-                   "piece_bytes": r0["best"].get("piece_bytes", 0), "slot_bytes": r0["slot_bytes"],
-                   "shared_stream": bool(r0["shared_stream"]),
+                   "algo": r0["best"]["algo"], "schedule_by": r0["tune"].get("by"),
+                   "tuned": {k: r0["tune"][k] for k in ("algo", "split", "unroll", "ms") if k in r0["tune"]},
                    "transport": r0["transport"]},
-        "algbw_GBps": algbw, "busbw_GBps": busbw, "ranks_meet": "on the device (dsync)" if r0["dsync"] == 1 else "on the host (control block)",
-        # per rank 2(R-1)/R x S bytes leave (and arrive) per allreduce; the full-mesh schedules spread them over the R-1
-        # links of a GPU, a single ring puts them on one.  153 GB/s per link is both directions together (76.8 each way)
-        "xgmi": {"per_link_peak_GBps": XGMI_LINK_GBPS, "per_link_peak_each_direction_GBps": XGMI_LINK_GBPS / 2,
-                 "busbw_frac_of_link_peak": busbw / XGMI_LINK_GBPS,
-                 "wire_GBps_per_rank_each_direction": busbw,
-                 "wire_GBps_per_link_each_direction_if_spread_over_all_links": busbw / max(1, R - 1),
-                 "frac_of_one_link_direction_if_spread": busbw / max(1, R - 1) / (XGMI_LINK_GBPS / 2),
-                 "link_probe": r0["link"], "meaningful": r0["devices"] == R},
-        "zero_copy_probe": r0["zero_copy_probe"] if (args.gpus > 1 or job.procs > 1) and not args.no_probe else "not run (1 GPU)",
-        "roofline": roof, "roofline_isolated": r0["iso"], "other_kernels": others, "parity": r0["parity"], "parity_failures": r0["parity_failures"], "autotune": r0["tune"], "ring_best": r0["best_ring"],
-        "extras": r0["extras"],
+        "algbw_GBps": algbw, "busbw_GBps": busbw,
+        "ranks_meet": "on the device (dsync)" if r0["dsync"] == 1 else "on the host (control block)",
+        "roofline": roof,
+        "parity": {k: r0["parity"].get(k) for k in ("checked", "ok", "bit_identical", "max_abs_err", "rule", "coverage")},
+        "parity_failures": len(r0["parity_failures"]),
+        "busbw_at_size": size_rows,
     }
+    if r0["iso"]:
+        line["roofline_isolated"] = {k: r0["iso"][k] for k in ("avg_launch_us", "achieved", "frac")}
+    if meaningful or r0["link"]:
+        # per rank 2(R-1)/R x S bytes leave (and arrive) per allreduce; the full-mesh schedules spread them over the R-1
+        # links of a GPU, a ring channel puts its share on one.  153 GB/s per link is both directions together (76.8 each way)
+        line["xgmi"] = {"per_link_peak_GBps": XGMI_LINK_GBPS, "wire_GBps_per_rank_each_direction": busbw,
+                        "wire_GBps_per_link_each_direction_if_spread": busbw / max(1, R - 1),
+                        "frac_of_link_peak": busbw / max(1, R - 1) / (XGMI_LINK_GBPS / 2),
+                        "busbw_frac_of_one_link": busbw / XGMI_LINK_GBPS, "link_probe": r0["link"], "meaningful": meaningful}
+    if (args.gpus > 1 or job.procs > 1) and not args.no_probe:
+        line["zero_copy_probe"] = r0["zero_copy_probe"]
+    extras_out = {"autotune": r0["tune"], "parity_failures": r0["parity_failures"], "other_kernels": others,
+                  "roofline_isolated": r0["iso"], "extras": r0["extras"], "roofline_note": roof.pop("note", None),
+                  "traffic_source": roof.pop("traffic_source", None), "kernel_detail": roof.pop("kernel_detail", None)}
     if args.gpus == 1 and not args.no_cpu and job.proc_rank == 0:
-        line["cpu_baseline"] = cpu_baseline(R, args.cpu_count or r0["count"], args.cpu_reps)
-        if isinstance(line.get("extras"), dict) and "bounce_sweep_u8" in line["extras"]:
-            line["extras"]["cpu_reference_bounce_u8"] = cpu_bounce()  # same lengths, the reference path on the host
+        cb = cpu_baseline(R, args.cpu_count or r0["count"], args.cpu_reps)
+        line["cpu_baseline"] = cb
+        if isinstance(r0["extras"], dict) and "bounce_sweep_u8" in r0["extras"]:
+            extras_out["extras"]["cpu_reference_bounce_u8"] = cpu_bounce()  # same lengths, the reference path on the host
     else:
         line["cpu_baseline"] = None
-    if not mp_first and args.gpus == 1 and job.procs == 1 and not args.no_extras:
-        # ... after this process has given its GPU context back (every communicator is finalised): it would be the ninth
-        try:
-            import ctypes
-            ctypes.CDLL("libamdhip64.so").hipDeviceReset()
-        except OSError:
-            pass
-        mp_sweep = multiprocess_sweep(job.ranks)
-    if mp_sweep is not None and isinstance(line.get("extras"), dict):
-        line["extras"]["multiprocess_sweep"] = mp_sweep
-    print(json.dumps(line))
+    if job.production is not None:
+        extras_out["production_layout"] = job.production
+        rp = production_roofline(job.production)
+        if rp:
+            line["roofline_production"] = rp
+    if job.mp_sweep is not None:
+        extras_out["extras"]["multiprocess_sweep"] = job.mp_sweep
+    line["extras_file"] = write_extras(extras_out)
+    print(json.dumps(line, separators=(",", ":")))
     sys.stdout.flush()
+
+
+def write_extras(obj) -> str:
+    """everything that is not the contract line: bench_extras.json beside bench.py, and a copy in gpurun_out/ when present"""
+    name = "bench_extras.json"
+    where = []
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, name), "w") as f:
+                    json.dump(obj, f, indent=1)
+                where.append(os.path.relpath(os.path.join(d, name), ROOT))
+            except OSError:
+                pass
+    return where[0] if where else ""
+
+
+def production_layout(ranks: int, nbytes: int, steps: int, warmup: int):
+    """examples/allreduce_bench under the launcher: ONE OS PROCESS PER RANK on this box's GPU -- the north-star layout,
+    ranks meeting on the device.  The library tunes itself (xmpi_tune) and AUTO runs; the one-kernel and the
+    meet / body / done form are timed by name beside it."""
+    run = os.path.join(ROOT, "mpi_amd", "bin", "xmpirun")
+    prog = os.path.join(ROOT, "mpi_amd", "bin", "allreduce_bench")
+    if not (os.path.exists(run) and os.path.exists(prog)):
+        return None
+    env = dict(os.environ, XMPI_TIMEOUT_S="60", XMPI_BASEPORT=str(9000 + os.getpid() % 1000 * 16))
+    env.pop("XMPI_SLOT_BYTES", None)
+    env.pop("XMPI_FIFO_DEPTH", None)
+    try:
+        p = subprocess.run([run, str(ranks), prog, str(nbytes), str(steps), str(warmup), "auto", "fused", "split"], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    except subprocess.TimeoutExpired:
+        return {"error": "timed out"}
+    if p.returncode != 0:
+        return {"error": (p.stderr or p.stdout)[-400:]}
+    try:
+        return json.loads(p.stdout.strip().split("\n")[-1])
+    except ValueError:
+        return {"error": p.stdout[-400:]}
+
+
+def production_roofline(prod):
+    """the compact line's `roofline_production`: what AUTO ran with one process per rank, and its dominant kernel"""
+    try:
+        row = next(x for x in prod["rows"] if x["mode"] == "auto")
+    except (KeyError, StopIteration, TypeError):
+        return {"error": (prod or {}).get("error", "no result")} if isinstance(prod, dict) else None
+    split = row["tuned"]["split"] == 1 or (row["tuned"]["split"] < 0 and row["split_launches"] > 0)
+    algo = ALGO_NAME.get(row["tuned"]["algo"], "zcopy")
+    kernel = ("dsync_sched_kernel (stepped: ring / halving inside one kernel)" if algo in ("ring", "rhd") else
+              "dsync_body_kernel<float,SUM,8> between the meet and done kernels" if split else
+              "dsync_fold_kernel<float,SUM,8> (rendezvous + fold + completion in one kernel: its duration includes waiting for peers)")
+    ranks = prod["ranks"]
+    # every rank's kernel runs at the same time on the one GPU: the chip's HBM serves ranks x (bytes per launch) in the
+    # time of one launch
+    agg = row["kernel_bytes_per_launch"] * ranks / (row["kernel_avg_us"] * 1e-6) / 1e9 if row["kernel_avg_us"] else 0.0
+    out = {"layout": f"{ranks} processes, one rank each, on this GPU; ranks meet {prod['meet']}", "algo": algo, "split": bool(split),
+           "kernel": kernel, "ms_per_step": row["us_per_step"] / 1e3, "algbw_GBps": row["algbw_GBps"],
+           "avg_launch_us": row["kernel_avg_us"], "algorithmic_bytes_per_launch": row["kernel_bytes_per_launch"],
+           "achieved_all_ranks": agg, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": agg / HBM_PEAK_GBPS, "exact": prod.get("exact")}
+    for m in ("fused", "split"):
+        try:
+            r = next(x for x in prod["rows"] if x["mode"] == m)
+            out[m + "_ms_per_step"] = r["us_per_step"] / 1e3
+        except (StopIteration, KeyError):
+            pass
+    if prod.get("bounce"):
+        out["bounce_half_round_trip_us"] = {str(b["bytes"]): b["half_round_trip_us"] for b in prod["bounce"]}
+    return out
 
 
 def _guard(job, g, fn=None):

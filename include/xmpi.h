@@ -353,6 +353,12 @@ int xmpi_ctl_selftest(const char* job_key, int rank, int size, int rounds);
 int xmpi_plan_dump(int coll, int algo, int size, int rank, int root, size_t count,
                    size_t elem_size, int channels, size_t piece_elems, char* out, size_t cap);
 
+/* The step program of a stepped kernel (ring allreduce = 1, recursive halving + doubling = 2, ring allgather = 3,
+ * binary-tree bcast = 4) for one rank and ring channel, as text, from the very function the kernel runs (host logic only,
+ * no GPU needed: the CPU test-suite executes all ranks' programs under random interleavings).  Returns the needed length. */
+int xmpi_sched_dump(int sched, int size, int rank, int root, int pieces, size_t count, size_t elem_size, int nchan,
+                    int channel, char* out, size_t cap);
+
 /* Chunk j of a count-element buffer cut for `size` ranks the way the zero-copy collectives cut it
  * (16-byte aligned boundaries): element offset and length.  Host logic only. */
 int xmpi_zc_chunk(size_t count, size_t elem_size, int size, int j, size_t* elem_off, size_t* elem_cnt);

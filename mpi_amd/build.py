@@ -27,7 +27,7 @@ ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wextra"]
 
 LIB_SOURCES = ["kernels.hip", "sched.hip", "engine.cpp", "api.cpp", "ctl.cpp", "plan.cpp", "zcopy.cpp", "heap.cpp", "dsync.cpp"]
-LIB_HEADERS = ["kernels.h", "kdev.h", "comm.h", "ctl.h", "plan.h", os.path.join("..", "..", "include", "xmpi.h")]
+LIB_HEADERS = ["kernels.h", "kdev.h", "sched_steps.h", "comm.h", "ctl.h", "plan.h", os.path.join("..", "..", "include", "xmpi.h")]
 
 
 MANIFEST = os.path.join(ROOT, "mpi_amd", ".build_manifest.json")
@@ -127,7 +127,8 @@ def build_host(force: bool = False) -> list[str]:
         for name, src in (("helloworld", os.path.join(ROOT, "examples", "helloworld.cpp")),
                           ("bounce", os.path.join(ROOT, "examples", "bounce.cpp")),
                           ("allreduce", os.path.join(ROOT, "examples", "allreduce.cpp")),
-                          ("coll_sweep", os.path.join(ROOT, "examples", "coll_sweep.cpp"))):
+                          ("coll_sweep", os.path.join(ROOT, "examples", "coll_sweep.cpp")),
+                          ("allreduce_bench", os.path.join(ROOT, "examples", "allreduce_bench.cpp"))):
             if os.path.exists(src):
                 out = os.path.join(BIN, name)
                 if force or _newer(out, [src] + deps):

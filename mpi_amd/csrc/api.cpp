@@ -13,6 +13,7 @@
 
 #include "comm.h"
 #include "kernels.h"
+#include "sched_steps.h"
 
 namespace xmpi {
 
@@ -563,6 +564,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
     dsync_finalize(c);
     if (c->ctl_registered) (void)hipHostUnregister(ctl->base());
     if (c->p2p_tickets) (void)hipFree(c->p2p_tickets);
+    if (c->p2p_done) (void)hipHostFree(c->p2p_done);
     if (c->dev_words) (void)hipFree(c->dev_words);
     (void)hipGetLastError();
     if (c->window) pool_release(c->window);
@@ -680,9 +682,21 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
     if (hipHostGetDevicePointer(&dev, ctl->base(), 0) == hipSuccess) c->ctl_dev = (char*)dev;
   }
   (void)hipGetLastError();
-  if (hipMalloc((void**)&c->p2p_tickets, 64 * sizeof(uint32_t)) == hipSuccess)
-    (void)hipMemsetAsync(c->p2p_tickets, 0, 64 * sizeof(uint32_t), c->local_stream);
+  if (hipMalloc((void**)&c->p2p_tickets, xmpi_comm::kP2PDoneSlots * sizeof(uint32_t)) == hipSuccess)
+    (void)hipMemsetAsync(c->p2p_tickets, 0, xmpi_comm::kP2PDoneSlots * sizeof(uint32_t), c->local_stream);
+  else c->p2p_tickets = nullptr;
   (void)hipGetLastError();
+  // completion words the GPU writes and a host thread polls (stream-ordered Send / Receive: slots 0..63; the pull kernels
+  // of the blocking Receive: 64..127)
+  if (hipHostMalloc((void**)&c->p2p_done, sizeof(uint64_t) * 4 * 2 * xmpi_comm::kP2PDoneSlots, hipHostMallocMapped) == hipSuccess) {
+    memset(c->p2p_done, 0, sizeof(uint64_t) * 4 * 2 * xmpi_comm::kP2PDoneSlots);
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, c->p2p_done, 0) == hipSuccess) c->p2p_done_dev = (uint64_t*)dev;
+  } else {
+    c->p2p_done = nullptr;
+  }
+  (void)hipGetLastError();
+  c->p2p_kernel_ack = env_long("XMPI_P2P_KERNEL_ACK", 1) ? 1 : 0;
   XMPI_TRACE_STEP(rank, "init: connecting flag pages");
   rc = dsync_connect(c);
   if (rc != XMPI_OK) return fail(rc);
@@ -740,6 +754,7 @@ int xmpi_finalize(xmpi_comm* c) {
   if (!c->ctl->aborted()) (void)c->ctl->barrier(wait_limit(c));
   if (c->ctl_registered) (void)hipHostUnregister(c->ctl->base());
   if (c->p2p_tickets) (void)hipFree(c->p2p_tickets);
+  if (c->p2p_done) (void)hipHostFree(c->p2p_done);
   if (c->window) pool_release(c->window);  // exported memory is never given back by the runtime: the next communicator reuses it
   if (c->temp) (void)hipFree(c->temp);
   if (c->host_stage) (void)hipFree(c->host_stage);
@@ -1168,17 +1183,15 @@ int xmpi_allreduce_repeat(xmpi_comm* c, const void* sendbuf, void* recvbuf, size
   XMPI_ENTER(c);
   // Ranks that meet on the device: the steps are ENQUEUED back to back on the communicator's stream and waited for
   // once -- what a stream-ordered caller does, and what the device rendezvous is for (no host round trip per
-  // step).  Launches that are sampled for profiling stay blocking: their events are read right after them.
+  // step).  Sampled launches carry their own events, read when the last step has been waited for.
   const bool on_device = count > 0 && sendbuf && recvbuf && xmpi_dtype_size(dtype) && algo >= 0 && algo < XMPI_ALGO_COUNT &&
                          dsync_takes(c, COLL_ALLREDUCE, algo) && is_device_pointer(sendbuf) && is_device_pointer(recvbuf);
   if (on_device) {
     drain_worker(c);
     std::lock_guard<std::mutex> g(c->coll_mu);
     for (int i = 0; i < iters; i++) {
-      const bool sampled = c->prof_on && (c->prof_seq[PROF_ZCOPY] % (uint64_t)std::max<long>(1, c->prof_every)) == 0;
-      if (!sampled && c->prof_on) c->prof_seq[PROF_ZCOPY]++;  // (a blocking call counts itself)
       const int rc = dsync_collective(c, COLL_ALLREDUCE, 0, sendbuf, recvbuf, count, (int)dtype, (int)op, c->local_stream,
-                                      /*blocking=*/sampled || i == iters - 1, algo);
+                                      /*blocking=*/i == iters - 1, algo);
       if (rc != XMPI_OK) return rc;
     }
     return XMPI_OK;
@@ -1391,6 +1404,7 @@ int xmpi_set_param(xmpi_comm* c, const char* name, long value) {
   else if (n == "zc_bcast_push_bytes") c->zc_bcast_push_bytes = std::max<long>(0, value);
   else if (n == "zc_group_launch") c->zc_group_launch = value ? 1 : 0;
   else if (n == "p2p_direct_bytes") c->p2p_direct_bytes = value;  // < 0: always through the mail slots
+  else if (n == "p2p_kernel_ack") c->p2p_kernel_ack = value ? 1 : 0;
   else if (n == "dsync") c->dsync = value ? 1 : 0;
   else if (n == "dsync_grid") c->dsync_grid_cap = std::max<long>(0, value);
   else if (n == "dsync_unroll") c->dsync_unroll = std::max<long>(1, std::min<long>(2, value));
@@ -1426,6 +1440,7 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
     return (long)((n == "hbm_free_mib" ? fr : tot) >> 20);
   }
   if (n == "p2p_direct_bytes") return c->p2p_direct_bytes;
+  if (n == "p2p_kernel_ack") return c->p2p_kernel_ack;
   if (n == "dsync") return dsync_usable(c) ? 1 : 0;
   if (n == "dsync_epoch") return (long)c->dsync_epoch;
   if (n == "dsync_launches") return (long)c->dsync_launches;
@@ -1789,6 +1804,68 @@ int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
   }
   c->tuned = true;
   return xmpi_barrier(c);
+}
+
+// The step program a stepped kernel (sched.hip) runs on `rank` for ring channel `channel`, as text -- produced by the very
+// function the kernel calls (sched_steps.h).  One line per step:
+//   g wait=<rank>:<value> sig=<rank>,<rank>:<value> ns=<0|1|2> D=<rank>.<s|r><+offset> A=... B=... lo=<byte> hi=<byte>
+// (host logic only; tests/sched_sim.py executes all ranks' programs on the CPU).  Returns the needed length.
+int xmpi_sched_dump(int sched, int size, int rank, int root, int pieces, size_t count, size_t elem_size, int nchan, int channel,
+                    char* out, size_t cap) {
+  if (size < 1 || size > kMaxRanks || rank < 0 || rank >= size || root < 0 || root >= size || elem_size < 1 || nchan < 1 ||
+      nchan > kMaxSchedChannels || channel < 0 || channel >= nchan || sched < SCHED_RING_ALLREDUCE || sched > SCHED_TREE_BCAST)
+    return XMPI_ERR_ARG;
+  if (sched == SCHED_RHD_ALLREDUCE && (size & (size - 1)) != 0) return XMPI_ERR_UNSUPPORTED;
+  DsyncSchedArgs a;
+  memset(&a, 0, sizeof a);
+  a.d.me = rank;
+  a.d.n = size;
+  a.sched = sched;
+  a.nchan = nchan;
+  a.root = root;
+  a.pieces = std::max(1, pieces);
+  a.count = count;
+  a.elem_size = (uint32_t)elem_size;
+  for (int ch = 0; ch < nchan; ch++) {
+    std::vector<int> ord;
+    ring_order(size, ch, &ord);
+    for (int i = 0; i < size; i++) a.order[ch][i] = (uint8_t)ord[(size_t)i];
+  }
+  // recognisable addresses: rank r's send / receive buffer = ((r+1) << 44) | (kind << 42) | 2^41 (+ a signed offset)
+  uint64_t send[kMaxRanks], recv[kMaxRanks];
+  auto fake = [](int r, int kind) { return ((uint64_t)(r + 1) << 44) | ((uint64_t)kind << 42) | (1ull << 41); };
+  for (int r = 0; r < size; r++) {
+    send[r] = fake(r, 0);
+    recv[r] = fake(r, 1);
+  }
+  auto show = [&](uint64_t base, char* buf, size_t n) {
+    if (!base) {
+      snprintf(buf, n, "-");
+      return;
+    }
+    const int r = (int)(base >> 44) - 1, kind = (int)((base >> 42) & 3);
+    const long long off = (long long)(base - fake(r, kind));
+    snprintf(buf, n, "%d.%c%+lld", r, kind ? 'r' : 's', off);
+  };
+  std::string t;
+  const int ns = sched_nsteps(a);
+  for (int g = 1; g <= ns; g++) {
+    SchedStep st;
+    sched_step(a, send, recv, g, channel, &st);
+    char d[48], x[48], y[48], line[320];
+    show(st.D, d, sizeof d);
+    show(st.ns >= 1 ? st.A : 0, x, sizeof x);
+    show(st.ns == 2 ? st.B : 0, y, sizeof y);
+    snprintf(line, sizeof line, "%d wait=%d:%u sig=%d,%d:%u ns=%d D=%s A=%s B=%s lo=%llu hi=%llu\n", g, st.wait_rank, st.wait_val,
+             st.sig[0], st.sig[1], st.sig_val, st.ns, d, x, y, (unsigned long long)st.lo, (unsigned long long)st.hi);
+    t += line;
+  }
+  if (out && cap) {
+    const size_t n = std::min(cap - 1, t.size());
+    memcpy(out, t.data(), n);
+    out[n] = 0;
+  }
+  return (int)std::min<size_t>(t.size() + 1, 0x7fffffff);
 }
 
 int xmpi_plan_dump(int coll, int algo, int size, int rank, int root, size_t count, size_t elem_size, int channels,

@@ -116,18 +116,19 @@ struct xmpi_comm {
   // stream-ordered Send / Receive (dsync.cpp p2p_*_on_stream): message numbers per ordered pair, completion words
   uint64_t p2p_out_seq[xmpi::kMaxRanks] = {0};
   uint64_t p2p_op_id = 0;
-  static constexpr int kP2PDoneSlots = 64;
+  static constexpr int kP2PDoneSlots = 64;  // ... of the stream-ordered forms; as many again for the blocking Receive's pull kernels
   uint64_t* p2p_done = nullptr;      // pinned host: 4 words per slot {done id, status, bytes, -}
   uint64_t* p2p_done_dev = nullptr;
   uint64_t p2p_done_next = 0;
+  std::atomic<uint64_t> p2p_pull_next{0};
+  long p2p_kernel_ack = 1;           // blocking Receive: one kernel copies AND acks (0: hipMemcpyAsync / copy kernel + event + host ack)
   struct P2PPending {
     int slot;
     uint64_t id;
     std::vector<void*> bufs;  // stand-ins to give back
   };
   std::vector<P2PPending> p2p_pending;  // stream-ordered operations whose completion nobody has looked at yet
-  uint32_t* p2p_tickets = nullptr;      // device: block counters of the pull kernels (blocking Receive)
-  uint64_t p2p_pull_seq = 0;
+  uint32_t* p2p_tickets = nullptr;      // device: block counters of the pull kernels (blocking Receive), one per done slot
   // the library's own schedule table (xmpi_tune): algorithm per collective and size class, agreed by all ranks
   static constexpr int kTuneClasses = 24;  // class k: messages of [2^(k+8), 2^(k+9)) bytes per rank
   int8_t tune_algo[4][kTuneClasses];       // [collective][class]: an xmpi_algo, or -1 = not tuned (built-in rule)
@@ -159,6 +160,11 @@ struct xmpi_comm {
     std::vector<void*> bufs;
   };
   std::vector<DsyncDeferred> dsync_deferred;  // arena blocks lent to collectives still on a stream
+  struct DsyncProf {
+    hipEvent_t start, stop;
+    size_t bytes;
+  };
+  std::vector<DsyncProf> dsync_prof_pending;  // sampled launches that were only enqueued: read by the next blocking call
 
   // per collective pipe: slots issued / consumed so far (monotonic across operations)
   uint64_t sent[xmpi::kMaxRanks][xmpi::kMaxLanes] = {{0}};

@@ -127,13 +127,6 @@ int dsync_connect(xmpi_comm* c) {
     return hip_fail(hipGetLastError(), "hipMalloc(resolved table)", __FILE__, __LINE__);
   if (hipEventCreateWithFlags(&c->dsync_order_ev, hipEventDisableTiming) != hipSuccess)
     return hip_fail(hipGetLastError(), "hipEventCreate", __FILE__, __LINE__);
-  // completion words of the stream-ordered Send / Receive kernels (pinned host memory the GPU writes, the host polls)
-  if (hipHostMalloc((void**)&c->p2p_done, sizeof(uint64_t) * 4 * xmpi_comm::kP2PDoneSlots, hipHostMallocMapped) == hipSuccess) {
-    memset(c->p2p_done, 0, sizeof(uint64_t) * 4 * xmpi_comm::kP2PDoneSlots);
-    void* dev = nullptr;
-    if (hipHostGetDevicePointer(&dev, c->p2p_done, 0) == hipSuccess) c->p2p_done_dev = (uint64_t*)dev;
-  }
-  (void)hipGetLastError();
   if (hipHostMalloc((void**)&c->dsync_status, 64, hipHostMallocMapped) == hipSuccess) {
     memset(c->dsync_status, 0, 64);  // word 0: first failure of a kernel; bytes 8..15: epoch of the last kernel that ended
     void* dev = nullptr;
@@ -181,12 +174,17 @@ void dsync_finalize(xmpi_comm* c) {
   uint64_t last = c->dsync_epoch;
   if (c->ctl) last = std::max<uint64_t>(last, c->ctl->info(c->rank)->flag_epoch);  // (a communicator that never got going)
   if (c->dsync_status) last = std::max<uint64_t>(last, __atomic_load_n((const uint64_t*)(c->dsync_status + 2), __ATOMIC_ACQUIRE));
+  last += 1;  // every communicator gets a number of its own (dsync_tag = base + 1), also one that never ran a collective: the
+              // tag marks its translation-cache entries and its Send / Receive message numbers in the (uncleared) page
+  for (auto& p : c->dsync_prof_pending) {
+    (void)hipEventDestroy(p.start);
+    (void)hipEventDestroy(p.stop);
+  }
+  c->dsync_prof_pending.clear();
   for (int p = 0; p < c->size; p++)
     if (c->peer_page_opened[p]) ipc_close_shared(c->peer_page[p]);
   if (c->dsync_status) (void)hipHostFree(c->dsync_status);
   c->dsync_status = nullptr;
-  if (c->p2p_done) (void)hipHostFree(c->p2p_done);
-  c->p2p_done = nullptr;
   if (c->dsync_res) (void)hipFree(c->dsync_res);
   c->dsync_res = nullptr;
   if (c->dsync_order_ev) (void)hipEventDestroy(c->dsync_order_ev);
@@ -535,7 +533,9 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
   const size_t al = std::max<size_t>(1, 16 / es);
 
   hipEvent_t pstart = nullptr, pstop = nullptr;
-  const bool sampled = blocking && c->prof_on && (c->prof_seq[PROF_ZCOPY]++ % (uint64_t)std::max<long>(1, c->prof_every)) == 0;
+  // sampled launches carry their own begin / end events (attached to the dispatch); a launch that is only enqueued
+  // leaves them for the next blocking call to read, so sampling does not put a host wait between enqueued steps
+  const bool sampled = !capturing && c->prof_on && (c->prof_seq[PROF_ZCOPY]++ % (uint64_t)std::max<long>(1, c->prof_every)) == 0;
   size_t traffic = 0;
   auto prof_events = [&]() -> bool {
     if (sampled && !pstart) {
@@ -730,6 +730,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
                         : (r.tmp_send && recv_significant && (in_place || coll == COLL_BCAST) && coll != COLL_ALLGATHER) ? r.tmp_send
                                                                                                                           : nullptr;
   if (!blocking) {
+    if (pstart) c->dsync_prof_pending.push_back({pstart, pstop, traffic});
     if (out_src) XMPI_HIP(hipMemcpyAsync(recvbuf, out_src, recv_bytes, hipMemcpyDeviceToDevice, stream));
     if (!lent.empty()) {
       xmpi_comm::DsyncDeferred d;
@@ -763,15 +764,22 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
   }
   for (void* p : lent) (void)heap_free(p);
   lent.clear();
-  if (pstart) {
+  if (pstart) c->dsync_prof_pending.push_back({pstart, pstop, traffic});
+  for (size_t i = 0; i < c->dsync_prof_pending.size();) {  // this launch's events and those of enqueued launches that have ended
+    auto& p = c->dsync_prof_pending[i];
     float ms = 0.f;
-    XMPI_HIP(hipEventElapsedTime(&ms, pstart, pstop));
+    if (hipEventQuery(p.stop) != hipSuccess || hipEventElapsedTime(&ms, p.start, p.stop) != hipSuccess) {
+      (void)hipGetLastError();
+      i++;
+      continue;
+    }
     ProfCounter& pc = c->prof[PROF_ZCOPY];
     pc.launches++;
     pc.total_ms += ms;
-    pc.bytes += traffic;
-    ev_put(c, pstart, true);
-    ev_put(c, pstop, true);
+    pc.bytes += p.bytes;
+    ev_put(c, p.start, true);
+    ev_put(c, p.stop, true);
+    c->dsync_prof_pending.erase(c->dsync_prof_pending.begin() + (long)i);
   }
   return dsync_check(c);
 }
@@ -882,7 +890,7 @@ int dsync_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest,
   }
   P2PArgs a;
   p2p_fill(c, &a, dest, tag, dtype);
-  a.seq = ++c->p2p_out_seq[dest];
+  a.seq = ((c->dsync_tag & 0xffffffffull) << 32) | ++c->p2p_out_seq[dest];
   a.bytes = bytes;
   a.gen = ref.gen;
   a.slot = (uint64_t)slot;

@@ -13,6 +13,7 @@
 // cross-process precondition already holds, so streams cannot deadlock however HIP maps them
 // to hardware queues.  Same-process dependencies are chained with events (no host round trip).
 #include <algorithm>
+#include <cstddef>
 #include <cstring>
 
 #include "comm.h"
@@ -741,7 +742,7 @@ int p2p_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, i
   }
   StreamLease lease(c);
   if (!lease.s) return hip_fail(hipGetLastError(), "hipStreamCreate", __FILE__, __LINE__);
-  const bool dev_src = bytes == 0 || is_device_pointer(buf);
+  const bool dev_src = bytes == 0 || heap_owns(buf) || is_device_pointer(buf);  // (the arena lookup is the cheap answer)
   const double t0 = now_seconds();
   Backoff bo;
   arm(bo, c);
@@ -987,7 +988,7 @@ int p2p_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int 
     m->state.store(MAIL_DONE, std::memory_order_release);
     return verdict;
   }
-  const bool dev_dst = bytes == 0 || is_device_pointer(buf);
+  const bool dev_dst = bytes == 0 || heap_owns(buf) || is_device_pointer(buf);
   int rc = XMPI_OK;
   double tp = now_seconds();
   if (m->direct.load(std::memory_order_acquire) == DIRECT_OFFERED) {
@@ -995,6 +996,41 @@ int p2p_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int 
     void* from = nullptr;
     if (dev_dst && zc_import(c, src, m->src, &from)) {
       m->direct.store(DIRECT_ACCEPTED, std::memory_order_release);
+      if (c->p2p_kernel_ack && c->ctl_dev && c->p2p_done_dev && c->p2p_tickets) {
+        // ONE kernel copies and acks: its last block writes DONE into the message's mail entry (the sender's host thread
+        // polls it: the ack of network.go:616-624, without this rank's host in between) and the completion word this
+        // thread polls.  Nothing in it waits for anybody.
+        const uint64_t id = c->p2p_pull_next.fetch_add(1, std::memory_order_relaxed) + 1;
+        const int slot = (int)(id % (uint64_t)xmpi_comm::kP2PDoneSlots);
+        volatile uint64_t* done = c->p2p_done + 4 * (xmpi_comm::kP2PDoneSlots + slot);
+        P2PPullArgs pa;
+        memset(&pa, 0, sizeof pa);
+        pa.dst = buf;
+        pa.src = from;
+        pa.bytes = bytes;
+        pa.ticket = c->p2p_tickets + slot;
+        pa.host_done = c->p2p_done_dev + 4 * (xmpi_comm::kP2PDoneSlots + slot);
+        pa.done_value = id;
+        char* mdev = c->ctl_dev + ((char*)m - (char*)c->ctl->base());
+        pa.mail_state = (uint32_t*)(mdev + ((char*)&m->state - (char*)m));
+        pa.mail_status = (int32_t*)(mdev + ((char*)&m->status - (char*)m));
+        pa.mail_done_value = MAIL_DONE;
+        long gx = (long)(bytes >> 16);  // 64 KiB per block, a few dozen blocks at most: a message is not a collective
+        gx = std::max<long>(1, std::min<long>(gx, 64));
+        hipError_t e = launch_p2p_pull(pa, (int)gx, lease.s);
+        if (e != hipSuccess) rc = hip_fail(e, "p2p pull kernel", __FILE__, __LINE__);
+        bo.n = 0;
+        while (rc == XMPI_OK && __atomic_load_n((const uint64_t*)done, __ATOMIC_ACQUIRE) != id) {
+          if ((bo.n & 1023u) == 1023u && c->ctl->aborted()) rc = XMPI_ERR_PEER;
+          bo.pause();
+        }
+        if (rc != XMPI_OK) {
+          c->ctl->set_abort(rc);
+          return rc;
+        }
+        __atomic_fetch_add(&c->p2p_direct_count, 1, __ATOMIC_RELAXED);
+        return XMPI_OK;
+      }
       hipError_t e = c->copy_engine == 1 ? launch_copy(buf, from, bytes, lease.s)
                                          : hipMemcpyAsync(buf, from, bytes, hipMemcpyDeviceToDevice, lease.s);
       hipEvent_t ev = (e == hipSuccess) ? ev_get(c, false) : nullptr;

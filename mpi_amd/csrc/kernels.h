@@ -250,6 +250,20 @@ struct P2PArgs {
   uint64_t op_id;        // receive: number of this operation (go slot = op_id % kP2PGoSlots), never 0
 };
 hipError_t launch_p2p_send(const P2PArgs& a, hipStream_t stream);
+// the copy of a blocking Receive the host has already matched: dst = src, then the acks (see sched.hip)
+struct P2PPullArgs {
+  void* dst;
+  const void* src;
+  uint64_t bytes;
+  uint32_t* ticket;       // device word, zero between launches (grids of more than one block)
+  uint64_t* host_done;    // pinned host word this rank's thread polls
+  uint64_t done_value;
+  uint32_t* mail_state;   // the message's mail entry in the shared control block, as the GPU addresses it (may be null)
+  int32_t* mail_status;
+  uint32_t mail_done_value;
+  uint32_t pad;
+};
+hipError_t launch_p2p_pull(const P2PPullArgs& a, int grid_x, hipStream_t stream);
 hipError_t launch_p2p_recv(const P2PArgs& a, int grid_x, hipStream_t stream);
 
 }  // namespace xmpi

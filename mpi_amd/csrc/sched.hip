@@ -16,6 +16,7 @@
 
 #include "kdev.h"
 #include "kernels.h"
+#include "sched_steps.h"
 
 namespace xmpi {
 namespace {
@@ -214,154 +215,6 @@ __device__ void range_apply(uint64_t D, uint64_t A, uint64_t B, size_t rlo, size
   }
 }
 
-struct SchedStep {
-  int32_t wait_rank;   // whose step this one needs (-1: nobody's -- the rendezvous was enough)
-  uint32_t wait_val;   // ... and which
-  int32_t sig[2];      // who is told when this step is done (-1: nobody)
-  uint32_t sig_val;
-  int32_t ns;          // 0 = nothing to move, 1 = copy, 2 = combine
-  uint64_t D, A, B;    // bases: byte offset x of the buffer is at base + x
-  uint64_t lo, hi;     // byte range of the buffer this step covers
-};
-
-__device__ __forceinline__ void chunk_bytes(uint64_t count, uint32_t es, int parts, int j, uint64_t* lo, uint64_t* hi) {
-  const uint64_t al = es >= 16 ? 1 : 16 / es;
-  uint64_t base = (count + (uint64_t)parts - 1) / (uint64_t)parts;
-  base = (base + al - 1) / al * al;
-  const uint64_t a = (uint64_t)j * base, b = (uint64_t)(j + 1) * base;
-  *lo = (a < count ? a : count) * es;
-  *hi = (b < count ? b : count) * es;
-}
-
-__device__ int sched_nsteps(const DsyncSchedArgs& a) {
-  const int n = a.d.n;
-  switch (a.sched) {
-    case SCHED_RING_ALLREDUCE: return 2 * (n - 1);
-    case SCHED_RHD_ALLREDUCE: {
-      int l = 0;
-      while ((1 << l) < n) l++;
-      return 2 * l;
-    }
-    case SCHED_RING_ALLGATHER: return n;
-    default: return a.pieces;
-  }
-}
-
-// step g (1-based) of this rank on ring channel `ch`
-__device__ void sched_step(const DsyncSchedArgs& a, const DsyncShared& sh, int g, int ch, SchedStep* st) {
-  const int n = a.d.n, me = a.d.me;
-  const uint32_t es = a.elem_size;
-  st->wait_rank = -1;
-  st->wait_val = 0;
-  st->sig[0] = st->sig[1] = -1;
-  st->sig_val = (uint32_t)g;
-  st->ns = 0;
-  st->D = sh.recv[me];
-  st->A = st->B = 0;
-  st->lo = st->hi = 0;
-  if (a.sched == SCHED_RING_ALLREDUCE || a.sched == SCHED_RING_ALLGATHER) {
-    int pos = 0;
-    for (int i = 0; i < n; i++)
-      if (a.order[ch][i] == me) pos = i;
-    const int prev = a.order[ch][(pos + n - 1) % n], next = a.order[ch][(pos + 1) % n];
-    if (g >= 2) {
-      st->wait_rank = prev;
-      st->wait_val = (uint32_t)(g - 1);
-    }
-    if (a.sched == SCHED_RING_ALLREDUCE) {
-      if (g < 2 * (n - 1)) st->sig[0] = next;
-      if (g <= n - 1) {  // reduce-scatter: my partial of chunk (pos - g) = the previous rank's partial + my contribution
-        const int c = (pos + n - g) % n;
-        chunk_bytes(a.count, es, n, c, &st->lo, &st->hi);
-        st->ns = 2;
-        st->A = g == 1 ? sh.send[prev] : sh.recv[prev];
-        st->B = sh.send[me];
-      } else {  // allgather: the finished chunk (pos + 1 - t) travels on
-        const int t = g - (n - 1);
-        const int c = (pos + 1 + n - t) % n;
-        chunk_bytes(a.count, es, n, c, &st->lo, &st->hi);
-        st->ns = 1;
-        st->A = sh.recv[prev];
-      }
-    } else {
-      const uint64_t blk = a.count * es;
-      if (g < n) st->sig[0] = next;
-      if (g == 1) {  // my own block into its place
-        st->lo = (uint64_t)me * blk;
-        st->hi = st->lo + blk;
-        st->A = sh.send[me] - st->lo;
-        st->ns = st->A == st->D ? 0 : 1;
-      } else {  // the block that reached the previous rank one step ago
-        const int r = a.order[ch][(pos + n - (g - 1)) % n];
-        st->lo = (uint64_t)r * blk;
-        st->hi = st->lo + blk;
-        st->A = sh.recv[prev];
-        st->ns = 1;
-      }
-    }
-    return;
-  }
-  if (a.sched == SCHED_RHD_ALLREDUCE) {
-    int l = 0;
-    while ((1 << l) < n) l++;
-    // the ranges: R_0 = the buffer, R_{k+1} = the half of R_k this rank keeps at halving step k
-    const int level = g <= l ? g - 1 : 2 * l - g;  // halving step k = g-1; doubling undoes level 2l-g
-    uint64_t lo = 0, hi = a.count * es;
-    uint64_t klo = 0, khi = 0, olo = 0, ohi = 0;  // kept half / other half at `level`
-    for (int k = 0; k <= level; k++) {
-      const int d = n >> (k + 1);
-      const uint64_t mid = lo + (((hi - lo) / 2) & ~(uint64_t)15);
-      if (me & d) {
-        klo = mid, khi = hi, olo = lo, ohi = mid;
-      } else {
-        klo = lo, khi = mid, olo = mid, ohi = hi;
-      }
-      lo = klo;
-      hi = khi;
-    }
-    const int p = me ^ (n >> (level + 1));
-    if (g >= 2) {
-      st->wait_rank = p;
-      st->wait_val = (uint32_t)(g - 1);
-    }
-    if (g < 2 * l) {
-      const int nlevel = g + 1 <= l ? g : 2 * l - g - 1;
-      st->sig[0] = me ^ (n >> (nlevel + 1));
-    }
-    if (g <= l) {  // halving: my half of the partner's accumulator joins mine
-      st->ns = 2;
-      st->lo = klo;
-      st->hi = khi;
-      st->A = g == 1 ? sh.send[p] : sh.recv[p];
-      st->B = g == 1 ? sh.send[me] : sh.recv[me];
-    } else {  // doubling: the partner's finished half
-      st->ns = 1;
-      st->lo = olo;
-      st->hi = ohi;
-      st->A = sh.recv[p];
-    }
-    return;
-  }
-  // SCHED_TREE_BCAST: piece g of the buffer comes from the parent and is announced to the children
-  const int v = (me - a.root + n) % n;
-  const int c1 = 2 * v + 1, c2 = 2 * v + 2;
-  if (c1 < n) st->sig[0] = (c1 + a.root) % n;
-  if (c2 < n) st->sig[1] = (c2 + a.root) % n;
-  uint64_t lo, hi;
-  chunk_bytes(a.count * es, 1, a.pieces, g - 1, &lo, &hi);
-  if (v != 0) {
-    const int parent = ((v - 1) / 2 + a.root) % n;
-    if ((v - 1) / 2 != 0) {  // the root's buffer is complete when it announces itself; anybody else's piece by piece
-      st->wait_rank = parent;
-      st->wait_val = (uint32_t)g;
-    }
-    st->ns = 1;
-    st->lo = lo;
-    st->hi = hi;
-    st->A = sh.recv[parent];
-  }
-}
-
 template <typename T, int OP>
 __global__ __launch_bounds__(kBlock) void dsync_sched_kernel(DsyncSchedArgs a) {
   __shared__ DsyncShared sh;
@@ -373,7 +226,7 @@ __global__ __launch_bounds__(kBlock) void dsync_sched_kernel(DsyncSchedArgs a) {
   if (sh.fail == DSYNC_OK) {
     const int nsteps = sched_nsteps(a);
     for (int g = 1; g <= nsteps; g++) {
-      if (t == 0) sched_step(a, sh, g, (int)blockIdx.y, &st);
+      if (t == 0) sched_step(a, sh.send, sh.recv, g, (int)blockIdx.y, &st);
       __syncthreads();
       const int wait_rank = st.wait_rank, ns = st.ns;
       if (wait_rank >= 0) {
@@ -435,10 +288,13 @@ __device__ __forceinline__ void p2p_host_done(const P2PArgs& a, uint64_t status,
 // the payload has been consumed, the caller's buffer is free (the rendezvous of network.go:569).
 __global__ __launch_bounds__(64) void p2p_send_kernel(P2PArgs a) {
   if (threadIdx.x != 0) return;
-  const int b = (int)((a.seq - 1) % kP2PBoxes);
+  // a.seq = (communicator number << 32) | n: pages are pooled and never cleared, the communicator number keeps the
+  // message numbers of successive communicators apart (and growing)
+  const uint64_t n = a.seq & 0xffffffffull;
+  const int b = (int)((n - 1) % kP2PBoxes);
   P2PAck* ack = p2p_acks(a.my_page) + (size_t)a.peer * kP2PBoxes + b;  // written by the receiver
   uint32_t why = DSYNC_OK;
-  if (a.seq > (uint64_t)kP2PBoxes) why = p2p_spin(&ack->seq, a.seq - kP2PBoxes, a);
+  if (n > (uint64_t)kP2PBoxes) why = p2p_spin(&ack->seq, a.seq - kP2PBoxes, a);
   uint64_t status = 0;
   if (why == DSYNC_OK) {
     P2PBox* box = p2p_boxes(a.peer_page) + (size_t)a.me * kP2PBoxes + b;
@@ -479,7 +335,7 @@ __global__ __launch_bounds__(kBlock) void p2p_recv_kernel(P2PArgs a) {
         uint64_t best = ~0ull;
         for (int b = 0; b < kP2PBoxes; b++) {  // the oldest unconsumed message with this tag
           const uint64_t s = __hip_atomic_load(&boxes[b].seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-          if (s == 0 || s <= ld_sys64(&taken[b]) || s >= best) continue;
+          if ((s >> 32) != (a.comm_tag & 0xffffffffull) || s <= ld_sys64(&taken[b]) || s >= best) continue;  // not this communicator's / consumed
           if ((int32_t)(uint32_t)ld_sys64(&boxes[b].tag) != a.tag) continue;
           best = s;
           found = b;
@@ -561,6 +417,41 @@ __global__ __launch_bounds__(kBlock) void p2p_recv_kernel(P2PArgs a) {
     __hip_atomic_store(&ack->seq, s_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   p2p_host_done(a, s_status, s_bytes);
+}
+
+// The blocking Receive's copy (engine.cpp p2p_recv): the host has matched the message, so nothing here waits for a
+// peer -- the payload comes straight out of the sender's buffer, and the block that finishes last writes the ack
+// where the SENDER's host thread polls (its mail entry in the shared control block, over PCIe) and the completion word
+// where this rank's host thread polls.  No event, no host hop between the copy and the ack (network.go:616-624).
+__global__ __launch_bounds__(kBlock) void p2p_pull_kernel(P2PPullArgs a) {
+  __shared__ uint32_t s_last;
+  const int t = threadIdx.x;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // the payload as the sender left it, not a stale line
+  const char* src = reinterpret_cast<const char*>(a.src);
+  char* dst = reinterpret_cast<char*>(a.dst);
+  const size_t bytes = a.bytes;
+  if ((((uintptr_t)src | (uintptr_t)dst) & 15u) == 0) {
+    const size_t npack = bytes / 16;
+    for (size_t i = (size_t)blockIdx.x * kBlock + t; i < npack; i += (size_t)gridDim.x * kBlock)
+      reinterpret_cast<pack_t*>(dst)[i] = ldp<2>(reinterpret_cast<const pack_t*>(src) + i);
+    if (blockIdx.x == 0 && npack * 16 + t < bytes) dst[npack * 16 + t] = src[npack * 16 + t];
+  } else {
+    for (size_t i = (size_t)blockIdx.x * kBlock + t; i < bytes; i += (size_t)gridDim.x * kBlock) dst[i] = src[i];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (t == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    s_last = gridDim.x == 1 || __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!s_last || t != 0) return;
+  if (gridDim.x > 1) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (a.mail_state) {
+    if (a.mail_status) __hip_atomic_store(a.mail_status, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(a.mail_state, a.mail_done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (a.host_done) __hip_atomic_store(a.host_done, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // =====================================================================================================================
@@ -659,6 +550,12 @@ hipError_t launch_dsync_sched(const DsyncSchedArgs& a, int dtype, int op, int gr
     case DT_BF16: return sched_op<bf16_t>(a, op, grid, s, es, ee);
     default: return hipErrorInvalidValue;
   }
+}
+
+hipError_t launch_p2p_pull(const P2PPullArgs& a, int grid_x, hipStream_t s) {
+  if (grid_x < 1) grid_x = 1;
+  hipLaunchKernelGGL(p2p_pull_kernel, dim3((unsigned)grid_x), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
 }
 
 hipError_t launch_p2p_send(const P2PArgs& a, hipStream_t s) {

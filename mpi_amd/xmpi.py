@@ -102,6 +102,7 @@ SYMBOLS = [
     ("xmpi_recv_on_stream", _I, [_P, _P, _Z, _I, _I, _I, _P]),
     ("xmpi_tune", _I, [_P, _Z]),
     ("xmpi_tune_decide", _I, [C.POINTER(C.c_double), _I, C.c_double]),
+    ("xmpi_sched_dump", _I, [_I, _I, _I, _I, _I, _Z, _Z, _I, _I, C.c_char_p, _Z]),
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -146,6 +147,26 @@ def plan_text(coll: int, algo: int, size: int, rank: int, root: int, count: int,
     buf = C.create_string_buffer(n + 1)
     L.xmpi_plan_dump(coll, algo, size, rank, root, count, elem_size, channels, piece_elems, buf, n + 1)
     return buf.value.decode()
+
+
+SCHED_RING_ALLREDUCE, SCHED_RHD_ALLREDUCE, SCHED_RING_ALLGATHER, SCHED_TREE_BCAST = 1, 2, 3, 4
+
+
+def sched_text(sched: int, size: int, rank: int, root: int, pieces: int, count: int, elem_size: int, nchan: int,
+               channel: int) -> str:
+    """Step program of a stepped kernel (sched.hip) for one rank and channel (host logic only: works without a GPU)."""
+    L = lib()
+    n = L.xmpi_sched_dump(sched, size, rank, root, pieces, count, elem_size, nchan, channel, None, 0)
+    if n < 0:
+        raise XmpiError(n, "xmpi_sched_dump")
+    buf = C.create_string_buffer(n + 1)
+    L.xmpi_sched_dump(sched, size, rank, root, pieces, count, elem_size, nchan, channel, buf, n + 1)
+    return buf.value.decode()
+
+
+def tune_decide(mean_us: Sequence[float], margin: float = 0.03) -> int:
+    arr = (C.c_double * len(mean_us))(*mean_us)
+    return lib().xmpi_tune_decide(arr, len(mean_us), margin)
 
 
 def zc_chunk(count: int, elem_size: int, size: int, j: int):
@@ -337,6 +358,15 @@ class Comm:
     def allreduce_on_stream(self, send, recv, count: int, dtype: int, op: int = SUM, stream=None) -> None:
         _check(lib().xmpi_allreduce_on_stream(self.handle, _ptr(send), _ptr(recv), count, dtype, op, stream),
                "xmpi_allreduce_on_stream")
+
+    def send_on_stream(self, buf, count: int, dtype: int, dest: int, tag: int, stream=None) -> None:
+        _check(lib().xmpi_send_on_stream(self.handle, _ptr(buf), count, dtype, dest, tag, stream), "xmpi_send_on_stream")
+
+    def recv_on_stream(self, buf, capacity: int, dtype: int, src: int, tag: int, stream=None) -> None:
+        _check(lib().xmpi_recv_on_stream(self.handle, _ptr(buf), capacity, dtype, src, tag, stream), "xmpi_recv_on_stream")
+
+    def tune(self, max_bytes: int) -> None:
+        _check(lib().xmpi_tune(self.handle, max_bytes), "xmpi_tune")
 
     def allgather_on_stream(self, send, recv, count: int, dtype: int, stream=None) -> None:
         _check(lib().xmpi_allgather_on_stream(self.handle, _ptr(send), _ptr(recv), count, dtype, stream),

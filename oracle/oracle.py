@@ -38,6 +38,9 @@ def lib() -> C.CDLL:
         L.oracle_dtype_size.restype, L.oracle_dtype_size.argtypes = Z, [I]
         L.oracle_hash.restype, L.oracle_hash.argtypes = U64, [U64, U64]
         L.oracle_fill.restype, L.oracle_fill.argtypes = I, [P, Z, I, I, U64]
+        L.oracle_fill_range.restype, L.oracle_fill_range.argtypes = I, [P, Z, Z, I, I, U64]
+        L.oracle_check_allreduce.restype = U64
+        L.oracle_check_allreduce.argtypes = [P, Z, Z, I, I, U64, I, I, C.POINTER(U64)]
         L.oracle_reduce2.restype, L.oracle_reduce2.argtypes = I, [P, P, P, Z, I, I]
         L.oracle_reduce_ranks.restype, L.oracle_reduce_ranks.argtypes = I, [P, C.POINTER(P), I, Z, I, I]
         L.oracle_allgather.restype, L.oracle_allgather.argtypes = I, [P, C.POINTER(P), I, Z, I]
@@ -57,6 +60,22 @@ def fill(count: int, dtype: int, pattern: int, seed: int) -> np.ndarray:
     rc = lib().oracle_fill(out.ctypes.data, count, dtype, pattern, seed)
     assert rc == 0
     return out
+
+
+def fill_range(start: int, count: int, dtype: int, pattern: int, seed: int) -> np.ndarray:
+    out = np.empty(count, dtype=NP[dtype])
+    rc = lib().oracle_fill_range(out.ctypes.data, start, count, dtype, pattern, seed)
+    assert rc == 0
+    return out
+
+
+def check_allreduce(got: np.ndarray, start: int, dtype: int, pattern: int, seed0: int, nranks: int, op: int):
+    """(number of elements of `got` = result[start : start + got.size] whose bits differ from the rank-order fold of
+    the ranks' regenerated inputs, index of the first one)"""
+    got = np.ascontiguousarray(got)
+    first = C.c_uint64(0)
+    bad = lib().oracle_check_allreduce(got.ctypes.data, start, got.size, dtype, pattern, seed0, nranks, op, C.byref(first))
+    return int(bad), int(first.value)
 
 
 def reduce2(a: np.ndarray, b: np.ndarray, dtype: int, op: int) -> np.ndarray:

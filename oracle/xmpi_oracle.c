@@ -127,60 +127,64 @@ static double pattern_real(int dtype, int pattern, uint64_t seed, uint64_t i) {
   }
 }
 
-int oracle_fill(void* buf, size_t count, int dtype, int pattern, uint64_t seed) {
+int oracle_fill_range(void* buf, size_t start, size_t count, int dtype, int pattern, uint64_t seed) {
   size_t i;
   if (pattern < 0 || pattern > OR_PAT_SIGNED) return -1;
   switch (dtype) {
     case OR_U8: {
       uint8_t* p = (uint8_t*)buf;
       for (i = 0; i < count; i++) {
-        if (pattern == OR_PAT_INDEX) p[i] = (uint8_t)(seed * 31u + i);
+        if (pattern == OR_PAT_INDEX) p[i] = (uint8_t)(seed * 31u + (start + i));
         else if (pattern == OR_PAT_CONST) p[i] = (uint8_t)(seed + 1u);
-        else p[i] = (uint8_t)(oracle_hash(seed, i) >> 56);
+        else p[i] = (uint8_t)(oracle_hash(seed, start + i) >> 56);
       }
       return 0;
     }
     case OR_I32: {
       int32_t* p = (int32_t*)buf;
       for (i = 0; i < count; i++) {
-        if (pattern == OR_PAT_INDEX) p[i] = (int32_t)(((uint32_t)seed << 24) | ((uint32_t)i & 0xFFFFFFu));
+        if (pattern == OR_PAT_INDEX) p[i] = (int32_t)(((uint32_t)seed << 24) | ((uint32_t)(start + i) & 0xFFFFFFu));
         else if (pattern == OR_PAT_CONST) p[i] = (int32_t)(seed + 1u);
-        else p[i] = (int32_t)(uint32_t)(oracle_hash(seed, i) >> 32);
+        else p[i] = (int32_t)(uint32_t)(oracle_hash(seed, start + i) >> 32);
       }
       return 0;
     }
     case OR_I64: {
       int64_t* p = (int64_t*)buf;
       for (i = 0; i < count; i++) {
-        if (pattern == OR_PAT_INDEX) p[i] = (int64_t)((seed << 40) | (uint64_t)i); /* BASELINE cfg 3 */
+        if (pattern == OR_PAT_INDEX) p[i] = (int64_t)((seed << 40) | (uint64_t)(start + i)); /* BASELINE cfg 3 */
         else if (pattern == OR_PAT_CONST) p[i] = (int64_t)(seed + 1u);
-        else p[i] = (int64_t)oracle_hash(seed, i);
+        else p[i] = (int64_t)oracle_hash(seed, start + i);
       }
       return 0;
     }
     case OR_F16: {
       uint16_t* p = (uint16_t*)buf;
-      for (i = 0; i < count; i++) p[i] = oracle_double_to_half(pattern_real(dtype, pattern, seed, i));
+      for (i = 0; i < count; i++) p[i] = oracle_double_to_half(pattern_real(dtype, pattern, seed, start + i));
       return 0;
     }
     case OR_BF16: {
       uint16_t* p = (uint16_t*)buf;
-      for (i = 0; i < count; i++) p[i] = oracle_float_to_bf16((float)pattern_real(dtype, pattern, seed, i));
+      for (i = 0; i < count; i++) p[i] = oracle_float_to_bf16((float)pattern_real(dtype, pattern, seed, start + i));
       return 0;
     }
     case OR_F32: {
       float* p = (float*)buf;
-      for (i = 0; i < count; i++) p[i] = (float)pattern_real(dtype, pattern, seed, i);
+      for (i = 0; i < count; i++) p[i] = (float)pattern_real(dtype, pattern, seed, start + i);
       return 0;
     }
     case OR_F64: {
       double* p = (double*)buf;
-      for (i = 0; i < count; i++) p[i] = pattern_real(dtype, pattern, seed, i);
+      for (i = 0; i < count; i++) p[i] = pattern_real(dtype, pattern, seed, start + i);
       return 0;
     }
     default:
       return -1;
   }
+}
+
+int oracle_fill(void* buf, size_t count, int dtype, int pattern, uint64_t seed) {
+  return oracle_fill_range(buf, 0, count, dtype, pattern, seed);
 }
 
 /* ---- elementwise combine -------------------------------------------------------------------
@@ -360,4 +364,46 @@ int oracle_diff_stats(const void* a, const void* b, size_t count, int dtype, dou
   stats[1] = sb;
   stats[2] = nn;
   return 0;
+}
+
+/* The whole-buffer check of an allreduce at ANY size: elements [start, start + n) of the result `got` against the
+ * rank-order fold of the ranks' inputs, which are regenerated here block by block (rank r's input is
+ * oracle_fill(pattern, seed0 + r)) -- nothing of the size of the buffers is ever held on the host but `got`.
+ * Returns the number of elements whose bits differ; *first_bad (optional) = index of the first. */
+uint64_t oracle_check_allreduce(const void* got, size_t start, size_t n, int dtype, int pattern, uint64_t seed0,
+                                int nranks, int op, uint64_t* first_bad) {
+  enum { BLK = 1 << 16 };
+  const size_t es = oracle_dtype_size(dtype);
+  uint64_t bad = 0;
+  size_t done = 0;
+  int r;
+  unsigned char *in, *acc;
+  if (es == 0 || nranks < 1) return ~0ull;
+  in = (unsigned char*)malloc((size_t)BLK * es);
+  acc = (unsigned char*)malloc((size_t)BLK * es);
+  if (!in || !acc) {
+    free(in);
+    free(acc);
+    return ~0ull;
+  }
+  while (done < n) {
+    const size_t m = n - done < (size_t)BLK ? n - done : (size_t)BLK;
+    size_t i;
+    oracle_fill_range(acc, start + done, m, dtype, pattern, seed0);
+    for (r = 1; r < nranks; r++) {
+      oracle_fill_range(in, start + done, m, dtype, pattern, seed0 + (uint64_t)r);
+      oracle_reduce2(acc, acc, in, m, dtype, op);
+    }
+    if (memcmp(acc, (const unsigned char*)got + done * es, m * es) != 0) {
+      for (i = 0; i < m; i++)
+        if (memcmp(acc + i * es, (const unsigned char*)got + (done + i) * es, es) != 0) {
+          if (bad == 0 && first_bad) *first_bad = (uint64_t)(start + done + i);
+          bad++;
+        }
+    }
+    done += m;
+  }
+  free(in);
+  free(acc);
+  return bad;
 }

@@ -36,6 +36,13 @@ size_t oracle_dtype_size(int dtype);
 /* counter-based generator shared with the device-side xmpi_fill_pattern */
 uint64_t oracle_hash(uint64_t seed, uint64_t i);
 int oracle_fill(void* buf, size_t count, int dtype, int pattern, uint64_t seed);
+/* elements [start, start + count) of the same sequence, without generating the prefix */
+int oracle_fill_range(void* buf, size_t start, size_t count, int dtype, int pattern, uint64_t seed);
+/* elements [start, start + n) of an allreduce result against the rank-order fold of oracle_fill(pattern, seed0 + r),
+ * r = 0..nranks-1, regenerated block by block: the WHOLE buffer of a full-size configuration can be checked against the
+ * oracle.  Returns the number of elements whose bits differ (~0 on bad arguments); *first_bad = the first such index. */
+uint64_t oracle_check_allreduce(const void* got, size_t start, size_t n, int dtype, int pattern, uint64_t seed0,
+                                int nranks, int op, uint64_t* first_bad);
 
 /* dst[i] = a[i] op b[i] */
 int oracle_reduce2(void* dst, const void* a, const void* b, size_t count, int dtype, int op);

@@ -650,14 +650,29 @@ def sc_fullsize(comm, args):
     comm.allreduce(send, ref, count, dtype, xmpi.SUM, xmpi.ALGO_DIRECT)
     for off in (0, count // 3, count - 65536):
         off = off // 8 * 8
-        ins = []
-        for r in range(size):  # regenerate the same window of every rank's input on the CPU
-            ins.append(oracle_fill_window(dtype, seed0 + r, off, 65536))
         mine = send.download(xmpi.NUMPY_DTYPE[dtype], 65536, byte_offset=off * es)
-        assert mine.tobytes() == ins[rank].tobytes(), "device fill window differs from the oracle's"
-        want = oracle.reduce_ranks(ins, dtype, xmpi.SUM)
-        got = ref.download(xmpi.NUMPY_DTYPE[dtype], 65536, byte_offset=off * es)
-        assert got.tobytes() == want.tobytes(), f"{which}: DIRECT differs from the rank-order oracle at {off}"
+        assert mine.tobytes() == oracle.fill_range(off, 65536, dtype, xmpi.PAT_UNIFORM, seed0 + rank).tobytes(), \
+            "device fill window differs from the oracle's"
+    # The WHOLE result against the CPU oracle (oracle_check_allreduce regenerates every rank's input block by block and
+    # folds in rank order): every chunk, every chunk boundary.  f32 (the headline, 64 Mi elements): every rank checks its
+    # whole buffer.  fp16 at 1 GiB (512 Mi elements x 8 inputs of software half conversions): rank r checks the r-th
+    # eighth plus the 4 Ki elements either side of its ends, and all ranks' buffers are shown identical by their checksums.
+    if dtype == xmpi.F32:
+        lo, hi = 0, count
+    else:
+        per = (count + size - 1) // size
+        lo, hi = max(0, rank * per - 4096), min(count, (rank + 1) * per + 4096)
+    step = 1 << 25  # 32 Mi elements per download
+    for start in range(lo, hi, step):
+        n = min(step, hi - start)
+        got = ref.download(xmpi.NUMPY_DTYPE[dtype], n, byte_offset=start * es)
+        bad, first = oracle.check_allreduce(got, start, dtype, xmpi.PAT_UNIFORM, seed0, size, xmpi.SUM)
+        assert bad == 0, f"{which}: DIRECT differs from the rank-order oracle in {bad} elements of [{start}, {start + n}), first at {first}"
+        del got
+    sums = np.zeros(size, dtype=np.int64)
+    mine_sum = np.array([comm.checksum(ref, count * es) & 0x7FFFFFFFFFFFFFFF], dtype=np.int64)
+    comm.allgather(mine_sum, sums, 1, xmpi.I64, xmpi.ALGO_DIRECT)
+    assert np.all(sums == sums[0]), f"{which}: the ranks' results differ from each other: {sums}"
     for algo in (xmpi.ALGO_RING, xmpi.ALGO_RHD):
         comm.memset(out, 0, count * es)
         comm.allreduce(send, out, count, dtype, xmpi.SUM, algo)
@@ -841,7 +856,249 @@ def sc_lifecycle_stress(comm, args):
             print(f"lifetime {it}: {comm.get_param('hbm_free_mib')} MiB of HBM free, {time.time() - t_start:.2f} s so far", flush=True)
 
 
+def sc_sched(comm, args):
+    """The stepped kernels (sched.hip): ring allreduce / allgather, recursive halving + doubling, binary-tree broadcast as
+    ONE kernel per rank -- every dtype and operator, in place, odd alignments, one to many workers and ring channels."""
+    rank, size = comm.rank(), comm.size()
+    if comm.get_param("dsync") != 1:
+        return  # ranks that meet on the host run these names as host-driven step tables (other scenarios)
+    l0 = comm.get_param("dsync_sched_launches")
+    for channels, grid in args.get("shapes", [(0, 0), (1, 1), (2, 3), (0, 8)]):
+        comm.set_param("sched_channels", channels)
+        comm.set_param("sched_grid", grid)
+        for dtype in (xmpi.F32, xmpi.I64, xmpi.F16, xmpi.BF16, xmpi.U8, xmpi.F64, xmpi.I32):
+            for algo in (xmpi.ALGO_RING, xmpi.ALGO_RHD):
+                for count in args.get("counts", [1, 17, 4099, 65536 + 5]):
+                    allreduce_case(comm, dtype, count, algo)
+        for algo in (xmpi.ALGO_RING, xmpi.ALGO_RHD):
+            allreduce_case(comm, xmpi.F32, (3 << 20) + 7, algo, pattern=xmpi.PAT_SIGNED)
+            allreduce_case(comm, xmpi.F32, (1 << 20) + 1, algo, inplace=True)
+            allreduce_case(comm, xmpi.I64, 300007, algo, pattern=xmpi.PAT_UNIFORM, inplace=True, op=xmpi.PROD)
+            allreduce_case(comm, xmpi.F16, 70001, algo, misalign=3)
+            allreduce_case(comm, xmpi.F32, 40001, algo, pattern=xmpi.PAT_SIGNED, inplace=True, misalign=1)
+            for op in (xmpi.MIN, xmpi.MAX):
+                allreduce_case(comm, xmpi.F32, 30011, algo, op=op, pattern=xmpi.PAT_SIGNED)
+                allreduce_case(comm, xmpi.BF16, 3001, algo, op=op, pattern=xmpi.PAT_SIGNED)
+            allreduce_case(comm, xmpi.I64, 4097, algo, pattern=xmpi.PAT_CONST)
+        for dtype in (xmpi.I64, xmpi.U8, xmpi.F32):
+            for count in (1, 5, 1000, 4099, (1 << 20) + 3):
+                allgather_case(comm, dtype, count, xmpi.ALGO_RING)
+        allgather_case(comm, xmpi.I64, 70001, xmpi.ALGO_RING, inplace=True)
+        for piece in (256 << 10, 4096):
+            comm.set_param("tree_piece_bytes", piece)
+            for root in sorted({0, size - 1, size // 2}):
+                for dtype, count in ((xmpi.U8, 1), (xmpi.U8, 37), (xmpi.I64, 4099), (xmpi.F32, (1 << 20) + 9)):
+                    es = xmpi.DTYPE_SIZE[dtype]
+                    buf = comm.alloc(count * es)
+                    comm.fill(buf, count, dtype, xmpi.PAT_UNIFORM, 40 + rank)
+                    comm.bcast(buf, count, dtype, root, xmpi.ALGO_TREE)
+                    got = buf.download(xmpi.NUMPY_DTYPE[dtype], count)
+                    want = oracle.fill(count, dtype, xmpi.PAT_UNIFORM, 40 + root)
+                    assert got.tobytes() == want.tobytes(), f"tree bcast root={root} {xmpi.DTYPE_NAME[dtype]} n={count} piece={piece}"
+                    buf.free()
+        comm.set_param("tree_piece_bytes", 256 << 10)
+    comm.set_param("sched_channels", 0)
+    comm.set_param("sched_grid", 0)
+    assert comm.get_param("dsync_sched_launches") > l0, "the stepped kernels did not run"
+    # a host buffer and a never-registered device buffer take the same kernels through registered stand-ins
+    x = oracle.fill(5000, xmpi.I64, xmpi.PAT_UNIFORM, 5 + rank)
+    out = np.zeros_like(x)
+    comm.allreduce(x, out, 5000, xmpi.I64, xmpi.SUM, xmpi.ALGO_RING)
+    want = oracle.reduce_ranks([oracle.fill(5000, xmpi.I64, xmpi.PAT_UNIFORM, 5 + r) for r in range(size)], xmpi.I64, 0)
+    assert out.tobytes() == want.tobytes()
+
+
+def sc_split(comm, args):
+    """The meet / body / done form of the zero-copy collectives, forced for every size (dsync_split_bytes = 1): the same
+    bits as the one-kernel form, rank order, in place, odd alignments; mixed freely with one-kernel collectives."""
+    rank, size = comm.rank(), comm.size()
+    if comm.get_param("dsync") != 1:
+        return
+    Z = xmpi.ALGO_ZCOPY
+    l0 = comm.get_param("dsync_split_launches")
+    comm.set_param("dsync_split_bytes", 1)
+    for dtype in (xmpi.F32, xmpi.I64, xmpi.F16, xmpi.F64, xmpi.I32, xmpi.U8, xmpi.BF16):
+        for count in args.get("counts", [1, 3, 17, 1000, 4099, 65536 + 5]):
+            allreduce_case(comm, dtype, count, Z, exact=True)
+    allreduce_case(comm, xmpi.F32, (3 << 20) + 7, Z, pattern=xmpi.PAT_SIGNED, exact=True)
+    allreduce_case(comm, xmpi.F32, (3 << 20) + 7, xmpi.ALGO_AUTO, pattern=xmpi.PAT_SIGNED, inplace=True, exact=True)
+    for op in (xmpi.PROD, xmpi.MIN, xmpi.MAX):
+        for dtype in (xmpi.F32, xmpi.I32, xmpi.F16, xmpi.BF16):
+            allreduce_case(comm, dtype, 3001, Z, op=op, pattern=xmpi.PAT_SIGNED, exact=True)
+    allreduce_case(comm, xmpi.F16, 30011, Z, misalign=3, exact=True)
+    for k in range(6):  # the two forms alternate on one stream
+        comm.set_param("dsync_split_bytes", 1 if k % 2 else 0)
+        allreduce_case(comm, xmpi.F64, 50001 + k, Z, pattern=xmpi.PAT_SIGNED, inplace=bool(k & 2), exact=True)
+    comm.set_param("dsync_split_bytes", 1)
+    for dtype in (xmpi.I64, xmpi.U8):
+        for count in (1, 1000, (1 << 20) + 3):
+            allgather_case(comm, dtype, count, Z)
+    for root in sorted({0, size - 1}):
+        for dtype, count, pat in ((xmpi.F32, 100003, xmpi.PAT_SIGNED), (xmpi.I64, 4099, xmpi.PAT_UNIFORM)):
+            es = xmpi.DTYPE_SIZE[dtype]
+            send, recv = comm.alloc(count * es), comm.alloc(count * es)
+            comm.fill(send, count, dtype, pat, 70 + rank)
+            comm.reduce(send, recv if rank == root else None, count, dtype, xmpi.SUM, root, Z)
+            if rank == root:
+                ins = [oracle.fill(count, dtype, pat, 70 + r) for r in range(size)]
+                check_reduced(recv.download(xmpi.NUMPY_DTYPE[dtype], count), ins, dtype, xmpi.SUM, True, f"split reduce root={root}")
+            send.free()
+            recv.free()
+    # stream-ordered, several back to back, a graph replay of split collectives
+    st = comm.stream_create()
+    m = 20011
+    g1, g2 = comm.alloc(m * 8), comm.alloc(m * 8)
+    comm.fill(g1, m, xmpi.I64, xmpi.PAT_CONST, 0)
+    comm.allreduce_on_stream(g1, g2, m, xmpi.I64, xmpi.SUM, st)
+    comm.allreduce_on_stream(g2, g1, m, xmpi.I64, xmpi.SUM, st)
+    comm.stream_sync(st)
+    comm.graph_begin(st)
+    comm.allreduce_on_stream(g1, g2, m, xmpi.I64, xmpi.SUM, st)
+    comm.allreduce_on_stream(g2, g1, m, xmpi.I64, xmpi.SUM, st)
+    graph = comm.graph_end(st)
+    for _ in range(3):
+        comm.graph_launch(graph, st)
+    comm.stream_sync(st)
+    assert np.all(g1.download(np.int64, m).view(np.uint64) == np.uint64(size) ** np.uint64(8)), "graph replays of split collectives"
+    comm.graph_destroy(graph)
+    comm.stream_destroy(st)
+    g1.free()
+    g2.free()
+    comm.set_param("dsync_split_bytes", 8 << 20)
+    assert comm.get_param("dsync_split_launches") > l0, "the split form did not run"
+
+
+def sc_multistream(comm, args):
+    """Device-synchronised collectives of one rank on DIFFERENT streams with no host synchronisation between them (a
+    stream-ordered one on a user stream, a blocking one on the communicator's stream right behind it, another user
+    stream): the kernels of a rank share its page's epoch, ticket and slots, so the library orders them itself."""
+    rank, size = comm.rank(), comm.size()
+    if comm.get_param("dsync") != 1:
+        return
+    s1, s2 = comm.stream_create(), comm.stream_create()
+    n = 30011
+    bufs = [(comm.alloc(n * 8), comm.alloc(n * 8)) for _ in range(3)]
+    for k, (a, _) in enumerate(bufs):
+        comm.fill(a, n, xmpi.I64, xmpi.PAT_UNIFORM, 100 * k + rank)
+    comm.sync()
+    for it in range(args.get("iters", 25)):
+        comm.allreduce_on_stream(bufs[0][0], bufs[0][1], n, xmpi.I64, xmpi.SUM, s1)
+        comm.allreduce(bufs[1][0], bufs[1][1], n, xmpi.I64, xmpi.MAX, xmpi.ALGO_AUTO)  # blocking, the communicator's own stream
+        comm.allreduce_on_stream(bufs[2][0], bufs[2][1], n, xmpi.I64, xmpi.SUM, s2)
+        if it % 5 == 4:
+            comm.allreduce(bufs[1][0], bufs[1][1], n, xmpi.I64, xmpi.MAX, xmpi.ALGO_RING)
+    comm.stream_sync(s1)
+    comm.stream_sync(s2)
+    for k, op in ((0, xmpi.SUM), (1, xmpi.MAX), (2, xmpi.SUM)):
+        ins = [oracle.fill(n, xmpi.I64, xmpi.PAT_UNIFORM, 100 * k + r) for r in range(size)]
+        check_reduced(bufs[k][1].download(np.int64, n), ins, xmpi.I64, op, True, f"multi-stream collective {k}")
+    comm.stream_destroy(s1)
+    comm.stream_destroy(s2)
+    for a, b in bufs:
+        a.free()
+        b.free()
+
+
+def sc_p2p_stream(comm, args):
+    """xmpi_send_on_stream / xmpi_recv_on_stream: the reference's Send / Receive as one kernel on each side (message + ack
+    through the flag allocations, the payload pulled out of the sender's HBM), ordered with the other work on the stream."""
+    rank, size = comm.rank(), comm.size()
+    if comm.get_param("dsync") != 1:
+        return
+    assert size % 2 == 0
+    even, peer = rank % 2 == 0, rank ^ 1
+    st = comm.stream_create()
+    nmax = (1 << 20) + 5
+    a, b = comm.alloc(nmax * 4), comm.alloc(nmax * 4)
+    # ping-pong, the echo enqueued right behind the receive on the same stream; the sizes of the reference's bounce
+    for k, n in enumerate([0, 1, 3, 1000, 4099, 65536 + 3, nmax]):
+        comm.fill(a, n, xmpi.F32, xmpi.PAT_SIGNED, 10 * k + rank)
+        comm.memset(b, 0, nmax * 4)
+        if even:
+            comm.send_on_stream(a, n, xmpi.F32, peer, 5, st)
+            comm.recv_on_stream(b, n, xmpi.F32, peer, 5, st)
+            comm.stream_sync(st)
+            assert comm.count_mismatch(a, b, n * 4) == 0, f"echo of {n} floats differs"
+        else:
+            comm.recv_on_stream(b, nmax, xmpi.F32, peer, 5, st)  # room for more than arrives
+            comm.send_on_stream(b, n, xmpi.F32, peer, 5, st)
+            comm.stream_sync(st)
+            assert b.download(np.float32, n).tobytes() == oracle.fill(n, xmpi.F32, xmpi.PAT_SIGNED, 10 * k + peer).tobytes()
+    # more messages than a pair has boxes, back to back, no host in between; then a collective on the same stream
+    n = 5003
+    comm.fill(a, n, xmpi.I64, xmpi.PAT_UNIFORM, 77 + rank)
+    for k in range(20):
+        if even:
+            comm.send_on_stream(a, n, xmpi.I64, peer, 100 + k, st)
+        else:
+            comm.recv_on_stream(b.at(k * n * 8 % (nmax * 4 - n * 8) // 8 * 8), n, xmpi.I64, peer, 100 + k, st)
+    comm.allreduce_on_stream(a, a, n, xmpi.I64, xmpi.SUM, st)
+    comm.stream_sync(st)
+    ins = [oracle.fill(n, xmpi.I64, xmpi.PAT_UNIFORM, 77 + r) for r in range(size)]
+    check_reduced(a.download(np.int64, n), ins, xmpi.I64, xmpi.SUM, True, "allreduce behind 20 messages on one stream")
+    if not even:
+        off = 19 * n * 8 % (nmax * 4 - n * 8) // 8 * 8
+        assert b.download(np.int64, n, byte_offset=off).tobytes() == ins[peer].tobytes()
+    # a message that does not fit / of another dtype: consumed, and both sides learn it from stream_sync
+    for tag, cap, dt in ((7, 50, xmpi.F32), (8, 100, xmpi.I32)):
+        try:
+            if even:
+                comm.send_on_stream(a, 100, xmpi.F32, peer, tag, st)
+            else:
+                comm.recv_on_stream(b, cap, dt, peer, tag, st)
+            comm.stream_sync(st)
+            raise AssertionError("a truncated / mistyped message must fail on both sides")
+        except xmpi.XmpiError as e:
+            assert e.code == (xmpi.ERR_TRUNCATE if tag == 7 else xmpi.ERR_ARG), e
+    # the job goes on; a payload in memory the receiver cannot map (plain hipMalloc) travels through a registered block
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    src = ctypes.c_void_p(0)
+    comm.sync()
+    assert hip.hipMalloc(ctypes.byref(src), ctypes.c_size_t(40000)) == 0
+    comm.fill(src.value, 10000, xmpi.F32, xmpi.PAT_UNIFORM, 500 + rank)
+    if even:
+        comm.send_on_stream(src.value, 10000, xmpi.F32, peer, 9, st)
+    else:
+        comm.recv_on_stream(b, 10000, xmpi.F32, peer, 9, st)
+    comm.stream_sync(st)
+    if not even:
+        assert b.download(np.float32, 10000).tobytes() == oracle.fill(10000, xmpi.F32, xmpi.PAT_UNIFORM, 500 + peer).tobytes()
+    comm.barrier()
+    assert hip.hipFree(src) == 0
+    comm.stream_destroy(st)
+    a.free()
+    b.free()
+
+
+def sc_tune(comm, args):
+    """xmpi_tune: the library times its own schedules and AUTO follows the table -- the same table on every rank."""
+    rank, size = comm.rank(), comm.size()
+    comm.tune(args.get("max_bytes", 4 << 20))
+    if comm.get_param("dsync") != 1:
+        assert comm.get_param("tuned") == 0
+        return
+    assert comm.get_param("tuned") == 1
+    table = np.array([comm.get_param(f"tune_{w}_{c}_{k}") for w in ("algo", "split", "unroll") for c in (0, 1) for k in range(24)],
+                     dtype=np.int64)
+    everybody = np.zeros(table.size * size, dtype=np.int64)
+    comm.allgather(table, everybody, table.size, xmpi.I64, xmpi.ALGO_DIRECT)
+    assert np.all(everybody.reshape(size, -1) == table), "the ranks tuned different tables"
+    assert any(v >= 0 for v in table[:24]), "nothing was tuned"
+    for count in (1, 300, 4099, 100003, (1 << 20) + 1):  # whatever AUTO now takes: the right result (int64: exact in any order)
+        allreduce_case(comm, xmpi.I64, count, xmpi.ALGO_AUTO, exact=True)
+        allreduce_case(comm, xmpi.F32, count, xmpi.ALGO_AUTO, exact=False)
+        allgather_case(comm, xmpi.I64, count, xmpi.ALGO_AUTO)
+    if rank == 0:
+        print("tuned allreduce table:", [int(v) for v in table[:24]], "split:", [int(v) for v in table[48:72]], flush=True)
+
+
 SCENARIOS = {
+    "sched": sc_sched,
+    "split": sc_split,
+    "multistream": sc_multistream,
+    "p2p_stream": sc_p2p_stream,
+    "tune": sc_tune,
     "allreduce_small": sc_allreduce_small,
     "allreduce_medium": sc_allreduce_medium,
     "allgather": sc_allgather,

@@ -18,7 +18,8 @@ def test_bench_json_contract():
                         "--no-extras", "--cpu-count", "65536"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")]
-    assert len(lines) == 1
+    assert len(lines) == 1 and r.stdout.strip().split("\n")[-1] == lines[0]
+    assert len(lines[0]) < 6000, len(lines[0])  # the driver's parser must see the whole line (round 2's 20 KB line was lost)
     d = json.loads(lines[0])
     for k in REQUIRED:
         assert k in d, k
@@ -37,27 +38,62 @@ def test_bench_json_contract():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert abs(cb["value"] - 65536 * 4 / cb["seconds_per_allreduce"] / 1e9) < 1e-6 * cb["value"]  # algbw too, not x ranks
-    assert d["parity"]["checked"] and d["parity"]["ok"]
-    assert not d["parity_failures"]
+    assert d["parity"]["checked"] and d["parity"]["ok"] and d["parity"]["bit_identical"] and "whole buffer" in d["parity"]["coverage"]
+    assert d["parity_failures"] == 0
+    # the same workload with one OS process per rank: the kernels of the production layout, ranks meeting on the device
+    rp = d["roofline_production"]
+    assert rp["exact"] is True and "device" in rp["layout"] and rp["ms_per_step"] > 0 and rp["avg_launch_us"] > 0, rp
+    assert 0 < rp["frac"] < 1.2 and abs(rp["frac"] - rp["achieved_all_ranks"] / rp["peak"]) < 1e-9
+    assert rp["fused_ms_per_step"] > 0 and rp["split_ms_per_step"] > 0
+    assert os.path.exists(os.path.join(ROOT, d["extras_file"]))
 
 
 def test_bench_extras_tables():
-    """the untimed extras at a small size: busbw against message size at 1 / 2 / 4 / 8 ranks, cfg 3 at its 4 ranks,
-    and the one-process-per-rank sweep (ranks meeting on the device)"""
+    """the untimed extras at a small size (bench_extras.json): busbw against message size at 1 / 2 / 4 / 8 ranks, cfg 3 at its
+    4 ranks, and the one-process-per-rank sweep (ranks meeting on the device)"""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--size-mib", "16",
-                        "--no-cpu"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        "--no-cpu", "--no-production"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    d = json.loads([ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")][0])
-    rows = d["extras"]["busbw_table"]["rows"]
+    line = [ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")][0]
+    assert len(line) < 6000
+    d = json.loads(line)
+    assert set(d["busbw_at_size"]) == {"1", "2", "4", "8"} and all(v["bytes"] == 16 << 20 for v in d["busbw_at_size"].values())
+    with open(os.path.join(ROOT, d["extras_file"])) as f:
+        ex = json.load(f)["extras"]
+    rows = ex["busbw_table"]["rows"]
     assert {x["ranks"] for x in rows} == {1, 2, 4, 8}
     for x in rows:
         assert x["us"] > 0 and abs(x["busbw_GBps"] - x["algbw_GBps"] * 2 * (x["ranks"] - 1) / x["ranks"]) < 1e-9
     assert {x["bytes"] for x in rows if x["ranks"] == 8} == {1 << 10, 1 << 12, 1 << 14, 1 << 16, 1 << 18, 1 << 20, 1 << 22, 1 << 24}
-    c3 = d["extras"]["cfg3_allgather_i64_16MiB_4ranks"]
+    c3 = ex["cfg3_allgather_i64_16MiB_4ranks"]
     assert c3["ranks"] == 4 and c3["auto"]["ms"] > 0 and c3["ring"]["ms"] > 0
-    mp = d["extras"]["multiprocess_sweep"]  # eight PROCESSES on this GPU, meeting on the device
+    mp = ex["multiprocess_sweep"]  # eight PROCESSES on this GPU, meeting on the device
     assert mp["ranks"] == 8 and mp["exact"] is True and "device" in mp["meet"], mp
     assert mp["rows"][0]["bytes"] == 1024 and mp["rows"][0]["queued_us"] < 1000, mp["rows"][0]
+
+
+@pytest.mark.parametrize("nproc", [2, 4, 8])
+def test_bench_multi_process_launch_rehearsal(nproc):
+    """the driver's SCALE launch (torch.distributed.run, one process per GPU) rehearsed on this box's one GPU: the line
+    must come out whole whatever N is (N = 8: one rank per process, ranks meet on the device, the library tunes itself)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, XMPI_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1",
+           "--size-mib", "16", "--no-extras", "--no-probe"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().split("\n") if ln.startswith("{\"metric\"")]
+    assert len(lines) == 1 and len(lines[0]) < 6000
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == nproc and d["value"] > 0 and d["parity"]["ok"] and d["parity_failures"] == 0
+    assert d["config"]["ranks"] == 8 and d["config"]["ranks_per_gpu"] == 8 // nproc
+    if nproc == 8:
+        assert d["ranks_meet"].startswith("on the device") and d["config"]["schedule_by"].startswith("xmpi_tune")
+        assert d["roofline"]["kernel"].startswith("dsync_")
 
 
 def test_coll_sweep_one_process_per_rank():

@@ -26,13 +26,15 @@ def test_allreduce_pipelined(size):
 def test_allreduce_tiny_slots():
     """4 KiB slots and a 2-deep FIFO force heavy slot reuse and back-pressure"""
     run_ranks("allreduce_medium", 4, timeout=600,
-              env={"XMPI_SLOT_BYTES": "65536", "XMPI_FIFO_DEPTH": "2", "XMPI_P2P_SLOT_BYTES": "8192"})
+              env={"XMPI_SLOT_BYTES": "65536", "XMPI_FIFO_DEPTH": "2", "XMPI_P2P_SLOT_BYTES": "8192", "XMPI_DSYNC": "0"})
 
 
 @pytest.mark.parametrize("size", [2, 8])
 def test_copy_kernel_transport_and_batched_copies(size):
     """peer pushes by the copy kernel; all ready pushes / slot drains of a rank go out in one launch"""
-    env = {"XMPI_COPY_ENGINE": "1", "XMPI_BATCH_COPIES": "1"}
+    # (XMPI_DSYNC=0: the host-driven step tables, which is what these transports belong to -- with ranks that meet on the
+    # device RING / RHD name the stepped kernels instead, tests below)
+    env = {"XMPI_COPY_ENGINE": "1", "XMPI_BATCH_COPIES": "1", "XMPI_DSYNC": "0"}
     run_ranks("allreduce_small", size, {"counts": [1, 4099, 65536 + 5], "dtypes": [4, 2, 3]}, timeout=600, env=env)
     run_ranks("allgather", size, timeout=600, env=env)
     run_ranks("bcast_reduce", size, timeout=600, env=env)
@@ -156,3 +158,43 @@ def test_cfg5_allreduce_f16_large():
     whenever the GPU(s) have room for every rank's three buffers (one MI355X has: 8 ranks x 3 GiB of its 288),
     otherwise 256 MiB per rank."""
     run_ranks("fullsize", 8, {"which": "cfg5", "count": "auto"}, timeout=900)
+
+
+@pytest.mark.parametrize("size", [2, 3, 4, 8])
+def test_stepped_kernels(size):
+    """ring allreduce / allgather, recursive halving + doubling (ring when the ranks are no power of two), binary-tree
+    broadcast: every step inside ONE kernel per rank, released by flag words between the peers' kernels"""
+    args = {} if size in (2, 8) else {"shapes": [(0, 0), (2, 3)], "counts": [1, 4099, 65536 + 5]}
+    run_ranks("sched", size, args, timeout=900)
+
+
+def test_staged_schedules_between_processes():
+    """XMPI_DSYNC=0: RING / RHD / TREE between processes are the host-driven step tables again"""
+    run_ranks("allreduce_small", 4, {"counts": [1, 4099, 65536 + 5], "dtypes": [4, 2]}, timeout=600, env={"XMPI_DSYNC": "0"})
+    run_ranks("allgather", 3, timeout=600, env={"XMPI_DSYNC": "0"})
+
+
+@pytest.mark.parametrize("size", [2, 5, 8])
+def test_split_form(size):
+    """meet / body / done: the zero-copy collectives as three launches, only two blocks of which ever wait"""
+    run_ranks("split", size, timeout=600)
+
+
+@pytest.mark.parametrize("size", [2, 4])
+def test_collectives_on_several_streams(size):
+    run_ranks("multistream", size, timeout=300)
+
+
+@pytest.mark.parametrize("size", [2, 4])
+def test_stream_ordered_send_recv(size):
+    run_ranks("p2p_stream", size, timeout=300)
+
+
+@pytest.mark.parametrize("size", [2, 8])
+def test_library_tuner(size):
+    run_ranks("tune", size, timeout=600)
+
+
+def test_library_tuner_threads():
+    """ranks that meet on the host have one schedule: nothing to tune, AUTO unchanged"""
+    run_threads("tune", 3)

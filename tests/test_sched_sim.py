@@ -1,0 +1,72 @@
+"""The stepped kernels' step programs (ring / halving / allgather / tree), executed on the CPU under random
+interleavings -- see tests/sched_sim.py.  No GPU needed: the programs come from libxmpi's host-callable step function."""
+import pytest
+
+from mpi_amd import xmpi
+from tests import sched_sim as sim
+
+
+def check(sched, size, count, **kw):
+    root = kw.get("root", 0)
+    recv, orig = sim.run(sched, size, count, **kw)
+    want = sim.expected(sched, size, count, orig, root)
+    for r in range(size):
+        got = list(recv[r])
+        assert got == want[r], f"rank {r}: sched {sched} N={size} count={count} {kw}: first diff at " \
+                               f"{next(i for i in range(len(got)) if got[i] != want[r][i])}"
+
+
+@pytest.mark.parametrize("size", [2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("inplace", [False, True])
+def test_ring_allreduce(size, inplace):
+    for seed, (count, nchan, gx) in enumerate([(1, 1, 1), (size * 4, 1, 2), (37, 2, 2), (101, min(3, max(1, size - 2)), 3)]):
+        nchan = min(nchan, max(1, size - 2)) if size >= 4 and size % 2 == 0 else 1
+        check(xmpi.SCHED_RING_ALLREDUCE, size, count, nchan=nchan, gx=gx, inplace=inplace, seed=seed)
+        check(xmpi.SCHED_RING_ALLREDUCE, size, count, nchan=nchan, gx=gx, inplace=inplace, seed=100 + seed, bias=seed % size)
+
+
+@pytest.mark.parametrize("size", [2, 4, 8, 16])
+@pytest.mark.parametrize("inplace", [False, True])
+def test_recursive_halving_doubling(size, inplace):
+    for seed, (count, gx) in enumerate([(1, 1), (size, 2), (53, 3), (64, 4), (131, 5)]):
+        check(xmpi.SCHED_RHD_ALLREDUCE, size, count, gx=gx, inplace=inplace, seed=seed)
+        check(xmpi.SCHED_RHD_ALLREDUCE, size, count, gx=gx, inplace=inplace, seed=50 + seed, bias=(seed * 3) % size)
+
+
+def test_halving_needs_a_power_of_two():
+    assert xmpi.lib().xmpi_sched_dump(xmpi.SCHED_RHD_ALLREDUCE, 6, 0, 0, 1, 100, 4, 1, 0, None, 0) == xmpi.ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("size", [2, 3, 4, 7, 8])
+def test_ring_allgather(size):
+    for seed, (count, es, nchan, gx) in enumerate([(1, 4, 1, 1), (5, 8, 1, 2), (33, 4, 2, 2), (64, 1, 1, 3)]):
+        nchan = nchan if size >= 4 and size % 2 == 0 else 1
+        check(xmpi.SCHED_RING_ALLGATHER, size, count, es=es, nchan=nchan, gx=gx, seed=seed)
+        check(xmpi.SCHED_RING_ALLGATHER, size, count, es=es, nchan=nchan, gx=gx, seed=seed + 9, bias=size - 1)
+
+
+@pytest.mark.parametrize("size", [2, 3, 5, 8, 13])
+def test_tree_bcast(size):
+    for seed, (count, pieces, gx) in enumerate([(1, 1, 1), (40, 1, 2), (100, 4, 2), (257, 8, 3)]):
+        for root in {0, size - 1, size // 2}:
+            check(xmpi.SCHED_TREE_BCAST, size, count, pieces=pieces, gx=gx, root=root, seed=seed)
+            check(xmpi.SCHED_TREE_BCAST, size, count, pieces=pieces, gx=gx, root=root, seed=seed + 20, bias=(root + 1) % size)
+
+
+def test_the_checker_notices_a_missing_wait(monkeypatch):
+    """the same programs with every wait removed: some interleaving must read a region before it is complete"""
+    real = sim.program
+
+    def no_waits(*a):
+        steps = real(*a)
+        for s in steps:
+            s["wait"] = (-1, 0)
+        return steps
+
+    monkeypatch.setattr(sim, "program", no_waits)
+    bad = 0
+    for seed in range(6):
+        recv, orig = sim.run(xmpi.SCHED_RING_ALLREDUCE, 4, 40, gx=2, seed=seed, bias=seed % 4)
+        want = sim.expected(xmpi.SCHED_RING_ALLREDUCE, 4, 40, orig)
+        bad += any(list(recv[r]) != want[r] for r in range(4))
+    assert bad > 0
