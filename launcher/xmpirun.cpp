@@ -76,6 +76,10 @@ int main(int argc, char** argv) {
     if (pid == 0) {
       // ports sort lexicographically like their numbers as long as they have equal width
       setenv("XMPI_JOB", job, 1);
+      // for programs on the bare C ABI (the Go / C++ front ends derive the rank from the -mpi-* flags: network.go:94-109;
+      // the ports below sort like their numbers, so that rank is i as well)
+      setenv("XMPI_RANK", std::to_string(i).c_str(), 1);
+      setenv("XMPI_SIZE", std::to_string(n).c_str(), 1);
       setenv("XMPI_DEVICE", std::to_string(i % gpus).c_str(), 0);
       setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
       // ranks sharing a GPU share its hardware queues too: a process may hold 4 by default, and beyond a few

@@ -1016,7 +1016,14 @@ void* xmpi_stream_create(xmpi_comm* c) {
 
 int xmpi_stream_destroy(xmpi_comm* c, void* stream) {
   XMPI_ENTER(c);
-  if (stream) XMPI_HIP(hipStreamDestroy((hipStream_t)stream));
+  if (stream) {
+    std::lock_guard<std::mutex> g(c->coll_mu);
+    if (c->dsync_last_stream == (hipStream_t)stream) {  // the next device-synchronised launch would order itself behind it
+      (void)hipStreamSynchronize((hipStream_t)stream);
+      c->dsync_last_stream = nullptr;
+    }
+    XMPI_HIP(hipStreamDestroy((hipStream_t)stream));
+  }
   return XMPI_OK;
 }
 

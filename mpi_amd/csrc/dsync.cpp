@@ -405,9 +405,11 @@ bool dsync_takes(const xmpi_comm* c, int coll, int algo) {
 void dsync_graph_launched(xmpi_comm* c, hipStream_t stream, bool before) {
   if (!c->dsync_ok || !c->dsync_order_ev) return;
   if (before) {
-    if (c->dsync_last_stream && c->dsync_last_stream != stream) (void)hipStreamWaitEvent(stream, c->dsync_order_ev, 0);
+    if (c->dsync_last_stream && c->dsync_last_stream != stream) {
+      (void)hipEventRecord(c->dsync_order_ev, c->dsync_last_stream);
+      (void)hipStreamWaitEvent(stream, c->dsync_order_ev, 0);
+    }
   } else {
-    (void)hipEventRecord(c->dsync_order_ev, stream);
     c->dsync_last_stream = stream;
   }
   (void)hipGetLastError();
@@ -506,7 +508,17 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
 
   // the kernels of one rank share the page's epoch counter, ticket and slots: one at a time.  On one stream that is
   // stream order; a launch on another stream than the previous one waits for it (an event behind every launch).
-  if (!capturing && c->dsync_last_stream && c->dsync_last_stream != stream) XMPI_HIP(hipStreamWaitEvent(stream, c->dsync_order_ev, 0));
+  // (The event is recorded when the stream CHANGES, at the tail of the previous stream -- not behind every launch: an event
+  // per collective costs the queue a packet and was visible in the small-message figures.)
+  if (!capturing && c->dsync_last_stream && c->dsync_last_stream != stream) {
+    hipStreamCaptureStatus pc = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(c->dsync_last_stream, &pc);
+    (void)hipGetLastError();
+    if (pc == hipStreamCaptureStatusNone) {  // (a capturing stream runs nothing until its graph is launched: dsync_graph_launched)
+      XMPI_HIP(hipEventRecord(c->dsync_order_ev, c->dsync_last_stream));
+      XMPI_HIP(hipStreamWaitEvent(stream, c->dsync_order_ev, 0));
+    }
+  }
 
   // 3. the kernel(s)
   DsyncArgs a;
@@ -716,10 +728,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     }
   }
   if (rc != XMPI_OK) return fail(rc);
-  if (!capturing) {
-    XMPI_HIP(hipEventRecord(c->dsync_order_ev, stream));
-    c->dsync_last_stream = stream;
-  }
+  if (!capturing) c->dsync_last_stream = stream;
 
   // 4. results of a stand-in go home; stand-ins go back to the arena when the stream has passed them.
   //    (A copy into pageable host memory blocks the calling thread until the kernel before it has ended -- and the
@@ -921,8 +930,8 @@ int dsync_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, in
   a.host_done = c->p2p_done_dev + 4 * ds;
   a.done_value = id;
   // a few blocks for a large message; every block but the first only waits for the first (a local word)
-  long gx = (long)(cap_bytes >> 16);
-  gx = std::max<long>(1, std::min<long>(gx, c->dsync_sharers > 1 ? 16 : 64));
+  long gx = (long)((cap_bytes + 16383) >> 14);
+  gx = std::max<long>(1, std::min<long>(gx, c->dsync_sharers > 1 ? 16 : 128));
   XMPI_HIP(launch_p2p_recv(a, (int)gx, stream));
   c->p2p_pending.push_back({ds, id, {}});
   return XMPI_OK;

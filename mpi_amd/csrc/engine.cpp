@@ -1015,8 +1015,8 @@ int p2p_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int 
         pa.mail_state = (uint32_t*)(mdev + ((char*)&m->state - (char*)m));
         pa.mail_status = (int32_t*)(mdev + ((char*)&m->status - (char*)m));
         pa.mail_done_value = MAIL_DONE;
-        long gx = (long)(bytes >> 16);  // 64 KiB per block, a few dozen blocks at most: a message is not a collective
-        gx = std::max<long>(1, std::min<long>(gx, 64));
+        long gx = (long)((bytes + 16383) >> 14);  // a 16 KiB tile per block and pass, at most 128 blocks: a message is not a collective
+        gx = std::max<long>(1, std::min<long>(gx, 128));
         hipError_t e = launch_p2p_pull(pa, (int)gx, lease.s);
         if (e != hipSuccess) rc = hip_fail(e, "p2p pull kernel", __FILE__, __LINE__);
         bo.n = 0;

@@ -262,6 +262,94 @@ __device__ void dsync_end(const DsyncArgs& a, DsyncShared& sh) {
 }
 
 
+// ---- data that another rank's kernel writes WHILE this kernel runs (the steps of ring / halving / tree) -------------
+// 16 bytes straight from / to memory at system scope (sc0 sc1): a load is never served from a line of this XCD's L2 (or
+// this CU's L1) that predates the peer's store, a store is written through -- so a step needs no cache maintenance at all:
+// the writer waits for its stores' acknowledgements (s_waitcnt vmcnt(0)) and raises the flag, the reader sees the flag and
+// loads.  (The alternative -- ordinary accesses bracketed by release / acquire fences -- writes back and invalidates a
+// whole L2 per block per step: 2.64 ms for the 8 x 256 MiB ring where the data alone needs 1.7, r03 session 1.)
+// The loads are asynchronous inline assembly: sys128_wait() is what makes their results usable.
+__device__ __forceinline__ void ld_sys128_issue(pack_t& v, const pack_t* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(v) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void st_sys128(pack_t* p, pack_t v) {
+  // (s_nop: the two wait states the hardware needs before the data registers of a store of more than 8 bytes may be
+  // overwritten -- the compiler inserts them for its own stores, it cannot see into this one)
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+template <int U>
+__device__ __forceinline__ void sys128_wait(pack_t (&v)[U]) {
+  static_assert(U == 1 || U == 2 || U == 4, "unroll");
+  if constexpr (U == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0])::"memory");
+  else if constexpr (U == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1])::"memory");
+  else asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])::"memory");
+}
+// one element, same scope (the ragged ends of a tile, buffers at odd alignments)
+template <typename T>
+__device__ __forceinline__ T ld_sys_elem(const T* p) {
+  T out;
+  if constexpr (sizeof(T) == 1) {
+    const uint8_t u = __hip_atomic_load(reinterpret_cast<const uint8_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_memcpy(&out, &u, 1);
+  } else if constexpr (sizeof(T) == 2) {
+    const uint16_t u = __hip_atomic_load(reinterpret_cast<const uint16_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_memcpy(&out, &u, 2);
+  } else if constexpr (sizeof(T) == 4) {
+    const uint32_t u = __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_memcpy(&out, &u, 4);
+  } else {
+    const uint64_t u = __hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_memcpy(&out, &u, 8);
+  }
+  return out;
+}
+template <typename T>
+__device__ __forceinline__ void st_sys_elem(T* p, T v) {
+  if constexpr (sizeof(T) == 1) {
+    uint8_t u;
+    __builtin_memcpy(&u, &v, 1);
+    __hip_atomic_store(reinterpret_cast<uint8_t*>(p), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  } else if constexpr (sizeof(T) == 2) {
+    uint16_t u;
+    __builtin_memcpy(&u, &v, 2);
+    __hip_atomic_store(reinterpret_cast<uint16_t*>(p), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  } else if constexpr (sizeof(T) == 4) {
+    uint32_t u;
+    __builtin_memcpy(&u, &v, 4);
+    __hip_atomic_store(reinterpret_cast<uint32_t*>(p), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  } else {
+    uint64_t u;
+    __builtin_memcpy(&u, &v, 8);
+    __hip_atomic_store(reinterpret_cast<uint64_t*>(p), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// dst = src, all blocks of the grid together: 16 KiB tiles, four 16-byte loads per lane in flight (a message is pulled
+// over a link: round trips), bytes at odd alignments one by one
+__device__ __forceinline__ void copy_span(char* dst, const char* src, size_t bytes) {
+  const int t = threadIdx.x;
+  if ((((uintptr_t)src | (uintptr_t)dst) & 15u) == 0) {
+    const size_t npack = bytes / 16;
+    constexpr size_t kTile = (size_t)kBlock * 4;
+    const pack_t* ps = reinterpret_cast<const pack_t*>(src);
+    pack_t* pd = reinterpret_cast<pack_t*>(dst);
+    for (size_t base = (size_t)blockIdx.x * kTile; base < npack; base += (size_t)gridDim.x * kTile) {
+      if (base + kTile <= npack) {
+        pack_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = ldp<2>(ps + base + (size_t)u * kBlock + t);
+#pragma unroll
+        for (int u = 0; u < 4; u++) pd[base + (size_t)u * kBlock + t] = v[u];
+      } else {
+        for (size_t i = base + t; i < npack; i += kBlock) pd[i] = ldp<2>(ps + i);
+      }
+    }
+    if (blockIdx.x == 0 && npack * 16 + t < bytes) dst[npack * 16 + t] = src[npack * 16 + t];
+  } else {
+    for (size_t i = (size_t)blockIdx.x * kBlock + t; i < bytes; i += (size_t)gridDim.x * kBlock) dst[i] = src[i];
+  }
+}
+
 __device__ __forceinline__ uint64_t* step_flags(DsyncPage* page) {
   return reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(page) + kStepOff);
 }

@@ -31,12 +31,14 @@ namespace {
 // split form: meet
 // =====================================================================================================================
 
-// ONE block: announce, wait for every peer, translate their buffers -- and leave what the data kernel needs in
-// ordinary device memory (the kernel boundary publishes it).  No completion exchange here: the done kernel does it.
+// A few blocks (one per XCD): announce (block 0), wait for every peer, acquire at system scope -- each block for the L2
+// of the XCD it runs on, so that the data kernel behind this one cannot be served a stale line of a peer's input -- and
+// block 0 translates the peers' buffers and leaves what the data kernel needs in ordinary device memory (the kernel
+// boundary publishes it).  No completion exchange here: the done kernel does it.
 __global__ __launch_bounds__(64) void dsync_meet_kernel(DsyncArgs a, DsyncResolved* out) {
   __shared__ DsyncShared sh;
   dsync_begin(a, sh);
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
     const int me = a.me, n = a.n;
     out->epoch = sh.epoch;
     out->fail = sh.fail;
@@ -82,8 +84,9 @@ __global__ __launch_bounds__(kBlock) void dsync_body_kernel(const DsyncResolved*
 #pragma unroll
     for (int k = 0; k < NSRC; k++) sp[k] = g->src[k];
   }
-  // what the peers wrote before they announced themselves (their inputs) must not come from a stale cache line
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  // No fence here: the meet kernel's blocks acquired at system scope (one per XCD) after the peers had announced
+  // themselves, and the kernel boundary orders this kernel behind them.  (A per-block acquire -- an L2 invalidate per
+  // block of an unbounded grid -- cost more than the fold itself: 1.66 ms instead of 0.8 for 8 x 256 MiB, r03 session 1.)
   if (fail != DSYNC_OK) return;
   const int t = threadIdx.x;
   constexpr size_t N = 16 / sizeof(T);
@@ -144,12 +147,18 @@ __global__ __launch_bounds__(64) void dsync_done_kernel(DsyncArgs a, const Dsync
 
 // One tile: D[x] = A[x] (NS == 1) or A[x] op B[x] (NS == 2) for the byte offsets x in [lo, hi) -- multiples of
 // sizeof(T); all three are addressed with the SAME offset.  vec: the three bases are 16-byte aligned.
-// Loads are non-temporal (every byte is read once by this rank), stores plain: what a step writes is what the
-// next rank's step reads a moment later.
+// A is what a peer's kernel may have written a moment ago and D is what a peer's kernel will read next: both go
+// straight to memory at system scope (kdev.h ld_sys128_issue / st_sys128: no fence, no cache maintenance per step).
+// B is this rank's own data (its input, or what THIS block stored in an earlier step): an ordinary non-temporal load.
 template <typename T, int OP, int NS>
 __device__ __forceinline__ void tile_apply(char* D, const char* A, const char* B, size_t lo, size_t hi, bool vec) {
   const int t = threadIdx.x;
   constexpr size_t ES = sizeof(T);
+  auto one = [&](size_t x) {
+    T v = ld_sys_elem(reinterpret_cast<const T*>(A + x));
+    if constexpr (NS == 2) v = combine_any<T, OP>(v, *reinterpret_cast<const T*>(B + x));
+    st_sys_elem(reinterpret_cast<T*>(D + x), v);
+  };
   if (vec) {
     const size_t plo = (lo + 15) & ~(size_t)15, phi = hi & ~(size_t)15;
     if (plo < phi) {
@@ -161,42 +170,35 @@ __device__ __forceinline__ void tile_apply(char* D, const char* A, const char* B
         pack_t va[U], vb[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-          va[u] = ldp<2>(pa + u * kBlock);
+          ld_sys128_issue(va[u], pa + u * kBlock);
           if constexpr (NS == 2) vb[u] = ldp<2>(pb + u * kBlock);
         }
+        sys128_wait<U>(va);
 #pragma unroll
         for (int u = 0; u < U; u++) {
           if constexpr (NS == 2) va[u] = combine16<T, OP>(va[u], vb[u]);
-          pd[u * kBlock] = va[u];
+          st_sys128(pd + u * kBlock, va[u]);
         }
       } else {
         for (size_t x = plo + (size_t)t * 16; x < phi; x += (size_t)kBlock * 16) {
-          pack_t v = ldp<2>(reinterpret_cast<const pack_t*>(A + x));
-          if constexpr (NS == 2) v = combine16<T, OP>(v, ldp<2>(reinterpret_cast<const pack_t*>(B + x)));
-          *reinterpret_cast<pack_t*>(D + x) = v;
+          pack_t v[1];
+          ld_sys128_issue(v[0], reinterpret_cast<const pack_t*>(A + x));
+          pack_t w;
+          if constexpr (NS == 2) w = ldp<2>(reinterpret_cast<const pack_t*>(B + x));
+          sys128_wait<1>(v);
+          if constexpr (NS == 2) v[0] = combine16<T, OP>(v[0], w);
+          st_sys128(reinterpret_cast<pack_t*>(D + x), v[0]);
         }
       }
       // the elements before the first and after the last whole packet (fewer than 16 bytes each)
       size_t x = lo + (size_t)t * ES;
-      if (x < plo) {
-        T v = *reinterpret_cast<const T*>(A + x);
-        if constexpr (NS == 2) v = combine_any<T, OP>(v, *reinterpret_cast<const T*>(B + x));
-        *reinterpret_cast<T*>(D + x) = v;
-      }
+      if (x < plo) one(x);
       x = phi + (size_t)t * ES;
-      if (x < hi) {
-        T v = *reinterpret_cast<const T*>(A + x);
-        if constexpr (NS == 2) v = combine_any<T, OP>(v, *reinterpret_cast<const T*>(B + x));
-        *reinterpret_cast<T*>(D + x) = v;
-      }
+      if (x < hi) one(x);
       return;
     }
   }
-  for (size_t x = lo + (size_t)t * ES; x < hi; x += (size_t)kBlock * ES) {
-    T v = *reinterpret_cast<const T*>(A + x);
-    if constexpr (NS == 2) v = combine_any<T, OP>(v, *reinterpret_cast<const T*>(B + x));
-    *reinterpret_cast<T*>(D + x) = v;
-  }
+  for (size_t x = lo + (size_t)t * ES; x < hi; x += (size_t)kBlock * ES) one(x);
 }
 
 // worker w of W: the tiles ti of [rlo, rhi) with ti % W == w (tile = kSchedTileBytes of the buffer, counted from
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(kBlock) void dsync_sched_kernel(DsyncSchedArgs a) {
         }
         __syncthreads();
         if (sh.fail != DSYNC_OK) break;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // the peer's step is in its buffer: not from a stale line
+        // (no fence: what the peer's step stored was written through before its flag, and is loaded past the caches)
       }
       const uint64_t D = st.D, A = st.A, B = st.B, lo = st.lo, hi = st.hi;
       if (ns == 2) range_apply<T, OP, 2>(D, A, B, lo, hi, w, W);
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(kBlock) void dsync_sched_kernel(DsyncSchedArgs a) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (t == 0 && (st.sig[0] >= 0 || st.sig[1] >= 0)) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // what this worker stored is visible before the flag is
+        // every wave has waited for the acknowledgements of its (written-through) stores: the flag may follow them
         const uint64_t val = (sh.epoch << 8) | st.sig_val;
         for (int k = 0; k < 2; k++)
           if (st.sig[k] >= 0) st_sys64(step_flags(a.d.page[st.sig[k]]) + (size_t)me * kStepSlots + w, val);
@@ -391,17 +393,7 @@ __global__ __launch_bounds__(kBlock) void p2p_recv_kernel(P2PArgs a) {
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // the payload as the sender left it, not a stale line
   const uint64_t src = s_src, bytes = s_status ? 0 : s_bytes;
-  if (bytes) {
-    char* dst = reinterpret_cast<char*>(a.buf);
-    if (((src | (uint64_t)(uintptr_t)dst) & 15u) == 0) {
-      const size_t npack = bytes / 16;
-      for (size_t i = (size_t)blockIdx.x * kBlock + t; i < npack; i += (size_t)gridDim.x * kBlock)
-        reinterpret_cast<pack_t*>(dst)[i] = ldp<2>(reinterpret_cast<const pack_t*>(src) + i);
-      if (blockIdx.x == 0 && npack * 16 + t < bytes) dst[npack * 16 + t] = reinterpret_cast<const char*>(src)[npack * 16 + t];
-    } else {
-      for (size_t i = (size_t)blockIdx.x * kBlock + t; i < bytes; i += (size_t)gridDim.x * kBlock) dst[i] = reinterpret_cast<const char*>(src)[i];
-    }
-  }
+  if (bytes) copy_span(reinterpret_cast<char*>(a.buf), reinterpret_cast<const char*>(src), bytes);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (t == 0) {
@@ -427,17 +419,7 @@ __global__ __launch_bounds__(kBlock) void p2p_pull_kernel(P2PPullArgs a) {
   __shared__ uint32_t s_last;
   const int t = threadIdx.x;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // the payload as the sender left it, not a stale line
-  const char* src = reinterpret_cast<const char*>(a.src);
-  char* dst = reinterpret_cast<char*>(a.dst);
-  const size_t bytes = a.bytes;
-  if ((((uintptr_t)src | (uintptr_t)dst) & 15u) == 0) {
-    const size_t npack = bytes / 16;
-    for (size_t i = (size_t)blockIdx.x * kBlock + t; i < npack; i += (size_t)gridDim.x * kBlock)
-      reinterpret_cast<pack_t*>(dst)[i] = ldp<2>(reinterpret_cast<const pack_t*>(src) + i);
-    if (blockIdx.x == 0 && npack * 16 + t < bytes) dst[npack * 16 + t] = src[npack * 16 + t];
-  } else {
-    for (size_t i = (size_t)blockIdx.x * kBlock + t; i < bytes; i += (size_t)gridDim.x * kBlock) dst[i] = src[i];
-  }
+  copy_span(reinterpret_cast<char*>(a.dst), reinterpret_cast<const char*>(a.src), a.bytes);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (t == 0) {
@@ -502,7 +484,7 @@ hipError_t sched_op(const DsyncSchedArgs& a, int op, dim3 grid, hipStream_t s, h
 
 hipError_t launch_dsync_meet(const DsyncArgs& a, DsyncResolved* out, hipStream_t s) {
   if (a.n < 1 || a.n > kDsyncRanks || a.nseg < 0 || a.nseg > kDsyncRanks || !out) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(dsync_meet_kernel, dim3(1), dim3(64), 0, s, a, out);
+  hipLaunchKernelGGL(dsync_meet_kernel, dim3(8), dim3(64), 0, s, a, out);
   return hipGetLastError();
 }
 

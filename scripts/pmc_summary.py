@@ -13,14 +13,15 @@ import sys
 
 
 def load(d, counter):
-    p = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True))[-1]
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(p)):
-        if r["Counter_Name"] != counter:
-            continue
-        name = r["Kernel_Name"]
-        short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
-        agg[(short, int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+    # one file per traced process (a job of 8 rank processes leaves 8): all of them
+    for p in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
+        for r in csv.DictReader(open(p)):
+            if r["Counter_Name"] != counter:
+                continue
+            name = r["Kernel_Name"]
+            short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+            agg[(short, int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
     return agg
 
 

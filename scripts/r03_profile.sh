@@ -1,0 +1,42 @@
+#!/bin/bash
+# Round-3 evidence on one MI355X (run through gpurun from the repo root); everything lands in gpurun_out/r03/:
+#   1. the default bench line (N=1: 8 ranks as threads of one process; roofline_production from 8 processes)
+#   2. rocprofv3 --kernel-trace --stats of the N=1 line's command (reduce_n_multi_kernel)
+#   3. THE PRODUCTION LAYOUT: one OS process per rank, 8 x 256 MiB f32 (examples/allreduce_bench under the launcher), modes
+#      auto (the library's tuned choice: meet / body / done), fused, ring, rhd -- plain, and under rocprofv3 --kernel-trace --stats
+#      (one kernel_stats.csv per rank)
+#   4. PMC traffic (separate --pmc passes, kernel-trace only) of the N=1 command and of the production layout
+#   5. what a collective costs the caller's other streams (scripts/overlap_probe.hip, 2 processes)
+set -x
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+O=$GRAFT_REPO_ROOT/gpurun_out/r03
+rm -rf $O; mkdir -p $O
+BIN=$GRAFT_REPO_ROOT/mpi_amd/bin
+timeout 600 python bench.py > $O/bench_n1_default.json 2> $O/bench_n1_default.err
+cp bench_extras.json $O/bench_n1_default_extras.json
+tail -c 400 $O/bench_n1_default.err
+B="python $GRAFT_REPO_ROOT/bench.py --algo zcopy --no-extras --no-cpu --no-production"
+PROD="$BIN/xmpirun 8 $BIN/allreduce_bench 268435456 20 5"
+export XMPI_TIMEOUT_S=40 XMPI_NGPUS=1
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_n1 -- $B > $O/bench_zcopy_under_rocprof.json 2> $O/stats_n1.err
+XMPI_BASEPORT=7100 timeout 200 $PROD auto fused fused2 split ring rhd zpush > $O/prod_8proc_256MiB.json 2> $O/prod.err
+XMPI_BASEPORT=7150 timeout 200 $BIN/xmpirun 8 $BIN/allreduce_bench 1073741824 5 2 auto ring rhd > $O/prod_8proc_1GiB.json 2>> $O/prod.err
+for m in split fused ring rhd; do
+  XMPI_BASEPORT=7200 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_prod_$m -- $PROD $m > $O/prod_${m}_under_rocprof.json 2> $O/stats_prod_$m.err
+done
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch_n1 -- $B --steps 5 > /dev/null 2> $O/fetch_n1.err
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write_n1 -- $B --steps 5 > /dev/null 2> $O/write_n1.err
+PRODS="$BIN/xmpirun 8 $BIN/allreduce_bench 268435456 5 2"
+XMPI_TIMEOUT_S=20 XMPI_BASEPORT=7300 timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch_prod -- $PRODS split fused > $O/prod_under_pmc_fetch.json 2> $O/fetch_prod.err
+echo "pmc fetch rc=$?" >> $O/prod.err
+XMPI_TIMEOUT_S=20 XMPI_BASEPORT=7350 timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write_prod -- $PRODS split fused > $O/prod_under_pmc_write.json 2> $O/write_prod.err
+echo "pmc write rc=$?" >> $O/prod.err
+XMPI_BASEPORT=7400 timeout 200 $BIN/xmpirun 2 $GRAFT_REPO_ROOT/scripts/overlap_probe_bin 268435456 5 > $O/overlap_2proc_256MiB.json 2> $O/overlap.err
+XMPI_BASEPORT=7450 timeout 200 $BIN/xmpirun 2 $GRAFT_REPO_ROOT/scripts/overlap_probe_bin 16777216 10 > $O/overlap_2proc_16MiB.json 2>> $O/overlap.err
+cd $GRAFT_REPO_ROOT
+python scripts/pmc_summary.py $O/fetch_n1 $O/write_n1 reduce_n_multi > $O/pmc_bench_zcopy.json
+python scripts/pmc_summary.py $O/fetch_prod $O/write_prod dsync_ > $O/pmc_prod.json 2>> $O/prod.err
+find $O -name "*kernel_stats.csv" | head -40; find $O -name "*.csv" ! -name "*kernel_stats.csv" -size +1M -delete; find $O -name "*.db" -delete
+du -sh $O
