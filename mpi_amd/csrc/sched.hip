@@ -429,11 +429,10 @@ __global__ __launch_bounds__(kBlock) void p2p_pull_kernel(P2PPullArgs a) {
   __syncthreads();
   if (!s_last || t != 0) return;
   if (gridDim.x > 1) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (a.mail_state) {
-    if (a.mail_status) __hip_atomic_store(a.mail_status, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(a.mail_state, a.mail_done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  if (a.host_done) __hip_atomic_store(a.host_done, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  // Every block has drained its stores and released them (above): the two words go out back to back, no further
+  // round trip between them (the entry's status is already XMPI_OK -- the sender wrote it when it posted the message).
+  if (a.mail_state) __hip_atomic_store(a.mail_state, a.mail_done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (a.host_done) __hip_atomic_store(a.host_done, a.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // =====================================================================================================================

@@ -1,11 +1,15 @@
 // overlap_probe -- what a device-synchronised collective costs the caller's OTHER work.
 // Every block of the one-kernel form spins until the peers arrive and holds its wave slots meanwhile; the meet / body /
-// done form only ever keeps two small kernels waiting.  This program measures it: a compute kernel of fixed work (an FMA
-// chain per lane, a grid that fills the chip) on stream A, alone and then concurrently with a float32 allreduce on
-// stream B (xmpi_allreduce_on_stream), for the one-kernel form with its grid capped at 1024 / 256 / 64 blocks and for the
-// split form.  Run under the launcher with 2 processes:  xmpirun 2 overlap_probe_bin [bytes] [reps]
-// Rank 0 prints one JSON line: compute time alone, compute time next to each form, the allreduce's time next to compute.
+// done form only ever keeps a few one-wave blocks waiting.  What that costs shows when a peer is LATE: rank 0 enqueues a
+// float32 allreduce on stream B and, right behind it on stream A, a train of compute kernels (an FMA chain per lane, a
+// grid that fills every wave slot of the chip); rank 1 enqueues its allreduce `delay` milliseconds later.  The train's
+// time next to the waiting collective, against the train alone, for the one-kernel form with its grid capped at
+// 1024 / 256 / 64 blocks and for the split form.  Run under the launcher with 2 processes:
+//   xmpirun 2 overlap_probe_bin [bytes] [reps] [delay_ms]
+// Rank 0 prints one JSON line.
 #include <hip/hip_runtime.h>
+
+#include <unistd.h>
 
 #include <chrono>
 #include <cstdio>
@@ -59,11 +63,12 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&a1));
   CK(hipEventCreate(&b0));
   CK(hipEventCreate(&b1));
-  const int iters = 400000;                 // ~ a millisecond of FMAs per lane
-  const dim3 grid(256 * 4), block(256);     // 4 blocks of 4 waves per CU: half of the chip's wave slots
-  auto compute_alone = [&](float* ms) -> int {
+  const int delay_us = (argc > 3 ? atoi(argv[3]) : 3) * 1000;
+  const int iters = 12000, train = 16;      // ~0.3 ms of FMAs per lane and launch
+  const dim3 grid(256 * 8), block(256);     // 8 blocks of 4 waves per CU: every wave slot of the chip
+  auto run_train = [&](float* ms) -> int {
     CK(hipEventRecord(a0, sa));
-    hipLaunchKernelGGL(burn, grid, block, 0, sa, sink, iters);
+    for (int k = 0; k < train; k++) hipLaunchKernelGGL(burn, grid, block, 0, sa, sink, iters);
     CK(hipEventRecord(a1, sa));
     CK(hipStreamSynchronize(sa));
     CK(hipEventElapsedTime(ms, a0, a1));
@@ -71,9 +76,9 @@ int main(int argc, char** argv) {
   };
   float alone = 0, t = 0;
   for (int i = 0; i < 3; i++)
-    if (compute_alone(&t)) return 1;
+    if (run_train(&t)) return 1;
   for (int i = 0; i < reps; i++) {
-    if (compute_alone(&t)) return 1;
+    if (run_train(&t)) return 1;
     alone += t / reps;
   }
   struct Form {
@@ -96,30 +101,32 @@ int main(int argc, char** argv) {
       CK(hipEventElapsedTime(&t, b0, b1));
       coll_alone += t / reps;
       XK(xmpi_barrier(c));
-      // the collective first (its blocks take their places), the caller's kernel right behind it on the other stream
-      CK(hipEventRecord(b0, sb));
-      XK(xmpi_allreduce_on_stream(c, send, recv, bytes / 4, XMPI_F32, XMPI_SUM, sb));
-      CK(hipEventRecord(b1, sb));
-      CK(hipEventRecord(a0, sa));
-      hipLaunchKernelGGL(burn, grid, block, 0, sa, sink, iters);
-      CK(hipEventRecord(a1, sa));
-      CK(hipStreamSynchronize(sa));
-      XK(xmpi_stream_sync(c, sb));
-      CK(hipEventElapsedTime(&t, a0, a1));
-      comp_with += t / reps;
-      CK(hipEventElapsedTime(&t, b0, b1));
-      coll_with += t / reps;
+      if (rank == 0) {
+        // the collective first (its blocks take their places and wait for the late peer), the caller's kernels behind it
+        CK(hipEventRecord(b0, sb));
+        XK(xmpi_allreduce_on_stream(c, send, recv, bytes / 4, XMPI_F32, XMPI_SUM, sb));
+        CK(hipEventRecord(b1, sb));
+        if (run_train(&t)) return 1;
+        comp_with += t / reps;
+        XK(xmpi_stream_sync(c, sb));
+        CK(hipEventElapsedTime(&t, b0, b1));
+        coll_with += t / reps;
+      } else {
+        usleep((useconds_t)delay_us);
+        XK(xmpi_allreduce_on_stream(c, send, recv, bytes / 4, XMPI_F32, XMPI_SUM, sb));
+        XK(xmpi_stream_sync(c, sb));
+      }
     }
-    char row[320];
-    snprintf(row, sizeof row, "%s{\"form\": \"%s\", \"allreduce_alone_ms\": %.3f, \"allreduce_next_to_compute_ms\": %.3f, "
-             "\"compute_next_to_allreduce_ms\": %.3f, \"compute_slowdown\": %.3f}", rows.empty() ? "" : ", ", f.name, coll_alone, coll_with,
-             comp_with, comp_with / alone);
+    char row[360];
+    snprintf(row, sizeof row, "%s{\"form\": \"%s\", \"allreduce_alone_ms\": %.3f, \"allreduce_with_late_peer_ms\": %.3f, "
+             "\"compute_train_next_to_waiting_allreduce_ms\": %.3f, \"compute_slowdown\": %.3f}", rows.empty() ? "" : ", ", f.name, coll_alone,
+             coll_with, comp_with, comp_with / alone);
     rows += row;
   }
   XK(xmpi_barrier(c));
   if (rank == 0)
-    printf("{\"ranks\": %d, \"bytes_per_rank\": %zu, \"compute_alone_ms\": %.3f, \"compute_grid_blocks\": %d, \"rows\": [%s]}\n", size, bytes,
-           alone, (int)grid.x, rows.c_str());
+    printf("{\"ranks\": %d, \"bytes_per_rank\": %zu, \"peer_delay_ms\": %.1f, \"compute_train_alone_ms\": %.3f, \"compute_grid_blocks\": %d, "
+           "\"launches_per_train\": %d, \"rows\": [%s]}\n", size, bytes, delay_us / 1e3, alone, (int)grid.x, train, rows.c_str());
   xmpi_free(c, send);
   xmpi_free(c, recv);
   XK(xmpi_finalize(c));
