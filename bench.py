@@ -466,7 +466,9 @@ def rank_main(job: Job, grank: int):
                                  "bit_identical_to_rank_order": same}
                 rows5.append(row)
                 b5 *= 4
-            extras["cfg5_allreduce_f16_sweep"] = {"ranks": R, "iterations": 5, "rows": rows5}
+            extras["cfg5_allreduce_f16_sweep"] = {"ranks": R, "iterations": 5, "rows": rows5,
+                                                  "layout": "rank threads of one process: ring / rhd are HOST-DRIVEN step tables here (the stepped kernels "
+                                                            "need ranks that meet on the device: cfg5_allreduce_f16_sweep_one_process_per_rank)"}
             for b in (s5, r5, ref5):
                 b.free()
         if link is not None:
@@ -619,8 +621,11 @@ def main():
     job.mp_sweep = job.production = None
     if args.gpus == 1 and job.procs == 1 and not args.probe and not args.no_production:
         job.production = production_layout(job.ranks, int(args.size_mib * (1 << 20)), args.steps, args.warmup)
+    job.cfg5 = None
     if args.gpus == 1 and job.procs == 1 and not args.no_extras and not args.probe:
         job.mp_sweep = multiprocess_sweep(job.ranks)
+        if args.size_mib >= 256:
+            job.cfg5 = cfg5_production(job.ranks, 1 << 30)
     if (args.gpus > 1 or job.procs > 1) and not args.no_probe:
         job.probe = probe_zero_copy(job)
         job.zero_copy_ok = job.probe != "failed"
@@ -754,6 +759,14 @@ def main():
             line["roofline_production"] = rp
     if job.mp_sweep is not None:
         extras_out["extras"]["multiprocess_sweep"] = job.mp_sweep
+    if job.cfg5 is not None:
+        extras_out["extras"]["cfg5_allreduce_f16_sweep_one_process_per_rank"] = job.cfg5
+        try:  # the compact line carries the two ends of the sweep
+            rows = job.cfg5["rows"]
+            line["cfg5_f16_us"] = {str(r["bytes"]): {k: round(r[k]["us"], 1) for k in ("ring", "rhd", "auto") if k in r} for r in (rows[0], rows[-1])}
+            line["cfg5_f16_us"]["all_bit_identical"] = job.cfg5["all_bit_identical"]
+        except (KeyError, IndexError, TypeError):
+            pass
     line["extras_file"] = write_extras(extras_out)
     print(json.dumps(line, separators=(",", ":")))
     sys.stdout.flush()
@@ -788,6 +801,29 @@ def production_layout(ranks: int, nbytes: int, steps: int, warmup: int):
     try:
         p = subprocess.run([run, str(ranks), prog, str(nbytes), str(steps), str(warmup), "auto", "fused", "split"], env=env,
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    except subprocess.TimeoutExpired:
+        return {"error": "timed out"}
+    if p.returncode != 0:
+        return {"error": (p.stderr or p.stdout)[-400:]}
+    try:
+        return json.loads(p.stdout.strip().split("\n")[-1])
+    except ValueError:
+        return {"error": p.stdout[-400:]}
+
+
+def cfg5_production(ranks: int, max_bytes: int):
+    """examples/cfg5_sweep under the launcher: BASELINE cfg 5 (fp16, recursive halving + doubling vs ring, 1 MiB ... 1 GiB)
+    with one OS process per rank -- ring and halving are the stepped KERNELS there, not host-driven step tables"""
+    run = os.path.join(ROOT, "mpi_amd", "bin", "xmpirun")
+    prog = os.path.join(ROOT, "mpi_amd", "bin", "cfg5_sweep")
+    if not (os.path.exists(run) and os.path.exists(prog)):
+        return None
+    env = dict(os.environ, XMPI_TIMEOUT_S="60", XMPI_BASEPORT=str(9500 + os.getpid() % 1000 * 16))
+    env.pop("XMPI_SLOT_BYTES", None)
+    env.pop("XMPI_FIFO_DEPTH", None)
+    try:
+        p = subprocess.run([run, str(ranks), prog, str(max_bytes), "5"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           text=True, timeout=300)
     except subprocess.TimeoutExpired:
         return {"error": "timed out"}
     if p.returncode != 0:

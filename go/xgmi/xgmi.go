@@ -334,6 +334,25 @@ func (b *Backend) Allgather(send, recv interface{}) error {
 // Barrier is a host-side rendezvous of all ranks.
 func (b *Backend) Barrier() error { return status(C.xmpi_barrier(b.comm), "mpi barrier") }
 
+// Tune lets the library time its own schedules on this job's GPUs and links for messages up to maxBytes per rank and keep
+// the winner per size class: Allreduce / Allgather (and the stream-ordered forms) follow that table from then on.  Collective:
+// every rank calls it with the same maxBytes, once, after Init.  (XMPI_AUTOTUNE_BYTES=N in the environment does the same
+// inside Init for a program that is not to be touched.)
+func (b *Backend) Tune(maxBytes int) error {
+	return status(C.xmpi_tune(b.comm, C.size_t(maxBytes)), "mpi tune")
+}
+
+// SendOnStream / ReceiveOnStream are Send and Receive as ONE kernel each, enqueued on a HIP stream (the message and the ack
+// of network.go:562-571, 616-624 as two 64-byte records in HBM, the payload pulled straight out of the sender's buffer):
+// no host thread waits; StreamSync reports what went wrong.  Device buffers only.  A kernel that waits holds its stream:
+// enqueue matching sends and receives so that no stream waits for work queued behind it.
+func (b *Backend) SendOnStream(buf DeviceBuffer, destination, tag int, stream unsafe.Pointer) error {
+	return status(C.xmpi_send_on_stream(b.comm, buf.Ptr, C.size_t(buf.Count), C.xmpi_dtype(buf.Type), C.int(destination), C.int(tag), stream), "mpi send")
+}
+func (b *Backend) ReceiveOnStream(buf DeviceBuffer, source, tag int, stream unsafe.Pointer) error {
+	return status(C.xmpi_recv_on_stream(b.comm, buf.Ptr, C.size_t(buf.Count), C.xmpi_dtype(buf.Type), C.int(source), C.int(tag), stream), "mpi receive")
+}
+
 // IAllreduce starts an allreduce on DeviceBuffers and returns at once; the error arrives on the
 // channel when the operation has completed (non-blocking collectives run in issue order on the
 // communicator's worker: issue them in the same order on every rank).  Device buffers only: C keeps

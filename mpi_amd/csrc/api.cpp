@@ -602,7 +602,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
     return fail(XMPI_ERR_HIP);
   }
   c->dsync = env_long("XMPI_DSYNC", 1) ? 1 : 0;
-  c->dsync_split_bytes = std::max<long>(0, env_long("XMPI_DSYNC_SPLIT_BYTES", 8 << 20));
+  c->dsync_split_bytes = std::max<long>(0, env_long("XMPI_DSYNC_SPLIT_BYTES", 4 << 20));
   c->sched_channels = std::max<long>(0, env_long("XMPI_SCHED_CHANNELS", 0));
   c->sched_grid = std::max<long>(0, env_long("XMPI_SCHED_GRID", 0));
   c->tree_piece_bytes = std::max<long>(4096, env_long("XMPI_TREE_PIECE_BYTES", 256 << 10));
@@ -715,6 +715,18 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
     return fail(rc);
   }
   heap_comm_created();
+  // XMPI_AUTOTUNE_BYTES=N: the library times its schedules for messages up to N bytes right here (xmpi_tune), so that a
+  // program that knows nothing about tuning gets the schedule a benchmark would pick on this node; every rank sees the
+  // same environment, so it is collective.  Default: off (a few hundred milliseconds and 2 x N bytes of HBM per rank).
+  const long tune_bytes = env_long("XMPI_AUTOTUNE_BYTES", 0);
+  if (tune_bytes > 0 && size > 1) {
+    XMPI_TRACE_STEP(rank, "init: tuning");
+    rc = xmpi_tune(c, (size_t)tune_bytes);
+    if (rc != XMPI_OK) {
+      (void)xmpi_finalize(c);
+      return rc;
+    }
+  }
   XMPI_TRACE_STEP(rank, "init: done");
   *out = c;
   return XMPI_OK;

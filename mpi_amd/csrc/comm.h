@@ -109,7 +109,7 @@ struct xmpi_comm {
   xmpi::DsyncResolved* dsync_res = nullptr;  // split form: what the meet kernel leaves for the data kernel (device memory)
   hipEvent_t dsync_order_ev = nullptr;       // recorded behind every device-synchronised launch: a launch on ANOTHER stream waits for it
   hipStream_t dsync_last_stream = nullptr;   //   (the kernels of one rank share the page's epoch, ticket and slots: one at a time)
-  long dsync_split_bytes = 8 << 20;  // collectives moving at least this much per rank run as meet / body / done (0 = never)
+  long dsync_split_bytes = 4 << 20;  // collectives moving at least this much per rank run as meet / body / done (0 = never)
   long sched_channels = 0;           // ring channels of the stepped kernels; 0 = every link direction (1 when ranks share a GPU)
   long sched_grid = 0;               // workers (blocks) of a stepped kernel; 0 = by size, bounded like dsync_grid_cap
   long tree_piece_bytes = 256 << 10; // binary-tree broadcast: pieces of this size travel down the tree pipelined

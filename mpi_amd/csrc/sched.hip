@@ -87,6 +87,10 @@ __global__ __launch_bounds__(kBlock) void dsync_body_kernel(const DsyncResolved*
   // No fence here: the meet kernel's blocks acquired at system scope (one per XCD) after the peers had announced
   // themselves, and the kernel boundary orders this kernel behind them.  (A per-block acquire -- an L2 invalidate per
   // block of an unbounded grid -- cost more than the fold itself: 1.66 ms instead of 0.8 for 8 x 256 MiB, r03 session 1.)
+  // Nor does this kernel close the collective itself: a variant whose stores were written through at system scope, with
+  // the last block exchanging "done" (two launches instead of three), made every one-tile block wait for HBM to
+  // acknowledge its stores before it could give its wave slots back -- 4.2 ms instead of 0.95 (r03 session 3).  The done
+  // kernel's few blocks release once per XCD instead.
   if (fail != DSYNC_OK) return;
   const int t = threadIdx.x;
   constexpr size_t N = 16 / sizeof(T);

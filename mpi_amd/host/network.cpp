@@ -30,6 +30,7 @@
 #include <cerrno>
 #include <chrono>
 #include <cstring>
+#include <new>
 
 #include "gobwire.hpp"
 
@@ -66,8 +67,13 @@ bool read_exact(int fd, uint8_t* p, size_t n) {
   return true;
 }
 
+// the largest message body accepted: a handshake is a few dozen bytes (4 KiB is generous: a stranger's first bytes are
+// read BEFORE its password is checked and must not be able to make this rank allocate at will); a data message is bounded
+// by what a rank can hold (64 GiB)
+constexpr uint64_t kMaxHandshakeBytes = 4096, kMaxMessageBytes = (uint64_t)64 << 30;
+
 // one gob message off the wire: the length prefix, then the body; appended to `stream` as it arrived
-bool read_gob_message(int fd, gobwire::Bytes* stream, bool* is_value) {
+bool read_gob_message(int fd, gobwire::Bytes* stream, bool* is_value, uint64_t max_len) {
   uint8_t first;
   if (!read_exact(fd, &first, 1)) return false;
   stream->push_back(first);
@@ -81,9 +87,13 @@ bool read_gob_message(int fd, gobwire::Bytes* stream, bool* is_value) {
     len = 0;
     for (int k = 0; k < n; k++) len = (len << 8) | be[k];
   }
-  if (len > ((uint64_t)1 << 40)) return false;
+  if (len > max_len) return false;
   const size_t at = stream->size();
-  stream->resize(at + (size_t)len);
+  try {
+    stream->resize(at + (size_t)len);
+  } catch (const std::bad_alloc&) {  // (the accept / dial threads must never terminate the process)
+    return false;
+  }
   if (!read_exact(fd, stream->data() + at, (size_t)len)) return false;
   gobwire::Reader body(stream->data() + at, (size_t)len);
   const int64_t id = body.i();
@@ -92,13 +102,14 @@ bool read_gob_message(int fd, gobwire::Bytes* stream, bool* is_value) {
 }
 
 // everything a fresh gob.Encoder sent for ONE Encode call: type definitions, then the value
-bool read_gob_value(int fd, gobwire::Bytes* stream) {
+bool read_gob_value(int fd, gobwire::Bytes* stream, uint64_t max_len = kMaxMessageBytes) {
   stream->clear();
-  for (;;) {
+  for (int messages = 0; messages < 64; messages++) {  // (a handful of type definitions precede a value, never dozens)
     bool is_value = false;
-    if (!read_gob_message(fd, stream, &is_value)) return false;
+    if (!read_gob_message(fd, stream, &is_value, max_len)) return false;
     if (is_value) return true;
   }
+  return false;
 }
 
 // "host:port" / ":port" as the reference's net.Listen / net.Dial take them
@@ -199,19 +210,32 @@ std::string Network::accept_peers(int n) {
       break;
     }
     setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+    {  // a client that connects and then says nothing must not hold Init past its timeout (30 s when there is none)
+      const double left = Timeout > 0 ? std::max(0.05, Timeout - (now_s() - t0)) : 30.0;
+      timeval tv{(time_t)left, (suseconds_t)((left - (double)(time_t)left) * 1e6)};
+      setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+    }
     gobwire::Bytes in;
     std::string pw;
     int64_t id = -1;
-    if (!read_gob_value(fd, &in) || !gobwire::parse_initial(in.data(), in.size(), &pw, &id)) {
-      ::close(fd);
-      err = "error decoding initial message";
-      break;
+    if (!read_gob_value(fd, &in, kMaxHandshakeBytes) || !gobwire::parse_initial(in.data(), in.size(), &pw, &id)) {
+      ::close(fd);  // a stray connection (a port scanner, a rank of another job): not this job's problem -- keep listening
+      continue;
     }
     const std::string bad = check_peer(pw, id, n);
     if (!bad.empty()) {
       ::close(fd);
       err = bad;
       break;
+    }
+    if (peers_[(size_t)id]->listen_fd >= 0) {  // that rank has shaken hands already: a duplicate must not replace it
+      ::close(fd);
+      err = "two peers claim to be rank " + std::to_string(id);
+      break;
+    }
+    {
+      timeval none{0, 0};  // the data path blocks for as long as it takes (network.go: no deadlines after Init)
+      setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &none, sizeof none);
     }
     peers_[(size_t)id]->listen_fd = fd;  // the peer's data in, my acks out (network.go:255)
     const gobwire::Bytes reply = gobwire::initial_message(Password, rank_);
@@ -254,7 +278,7 @@ std::string Network::dial_peers(int n) {
     gobwire::Bytes in;
     std::string pw;
     int64_t id = -1;
-    if (!write_all(fd, hello.data(), hello.size()) || !read_gob_value(fd, &in) ||
+    if (!write_all(fd, hello.data(), hello.size()) || !read_gob_value(fd, &in, kMaxHandshakeBytes) ||
         !gobwire::parse_initial(in.data(), in.size(), &pw, &id)) {
       ::close(fd);
       return "error in the dial handshake with " + Addrs[(size_t)p];

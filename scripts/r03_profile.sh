@@ -6,7 +6,8 @@
 #      auto (the library's tuned choice: meet / body / done), fused, ring, rhd -- plain, and under rocprofv3 --kernel-trace --stats
 #      (one kernel_stats.csv per rank)
 #   4. PMC traffic (separate --pmc passes, kernel-trace only) of the N=1 command and of the production layout
-#   5. what a collective costs the caller's other streams (scripts/overlap_probe.hip, 2 processes)
+#   5. what a collective costs the caller's other streams (scripts/overlap_probe.hip, 2 processes); BASELINE cfg 5 with one
+#      process per rank (examples/cfg5_sweep); the production program at 2 / 4 processes and at 16 MiB / 1 MiB
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
@@ -33,8 +34,12 @@ XMPI_TIMEOUT_S=20 XMPI_BASEPORT=7300 timeout 200 rocprofv3 --pmc FETCH_SIZE --ke
 echo "pmc fetch rc=$?" >> $O/prod.err
 XMPI_TIMEOUT_S=20 XMPI_BASEPORT=7350 timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write_prod -- $PRODS split fused > $O/prod_under_pmc_write.json 2> $O/write_prod.err
 echo "pmc write rc=$?" >> $O/prod.err
-XMPI_BASEPORT=7400 timeout 200 $BIN/xmpirun 2 $GRAFT_REPO_ROOT/scripts/overlap_probe_bin 268435456 5 > $O/overlap_2proc_256MiB.json 2> $O/overlap.err
-XMPI_BASEPORT=7450 timeout 200 $BIN/xmpirun 2 $GRAFT_REPO_ROOT/scripts/overlap_probe_bin 16777216 10 > $O/overlap_2proc_16MiB.json 2>> $O/overlap.err
+XMPI_BASEPORT=7400 timeout 200 $BIN/xmpirun 2 $GRAFT_REPO_ROOT/scripts/overlap_probe_bin 268435456 8 3 > $O/overlap_2proc_256MiB.json 2> $O/overlap.err
+XMPI_BASEPORT=7450 timeout 200 $BIN/xmpirun 2 $GRAFT_REPO_ROOT/scripts/overlap_probe_bin 16777216 8 3 > $O/overlap_2proc_16MiB.json 2>> $O/overlap.err
+XMPI_BASEPORT=7500 timeout 300 $BIN/xmpirun 8 $BIN/cfg5_sweep 1073741824 5 > $O/cfg5_8proc.json 2> $O/cfg5.err
+for n in 2 4; do XMPI_BASEPORT=7600 timeout 200 $BIN/xmpirun $n $BIN/allreduce_bench 268435456 20 5 auto fused split ring rhd > $O/prod_${n}proc_256MiB.json 2>> $O/prod.err; done
+XMPI_BASEPORT=7700 timeout 200 $BIN/xmpirun 8 $BIN/allreduce_bench 16777216 50 5 auto fused split ring rhd > $O/prod_8proc_16MiB.json 2>> $O/prod.err
+XMPI_BASEPORT=7800 timeout 200 $BIN/xmpirun 8 $BIN/allreduce_bench 1048576 200 10 auto fused split ring rhd > $O/prod_8proc_1MiB.json 2>> $O/prod.err
 cd $GRAFT_REPO_ROOT
 python scripts/pmc_summary.py $O/fetch_n1 $O/write_n1 reduce_n_multi > $O/pmc_bench_zcopy.json
 python scripts/pmc_summary.py $O/fetch_prod $O/write_prod dsync_ > $O/pmc_prod.json 2>> $O/prod.err

@@ -1,0 +1,44 @@
+#!/bin/bash
+# One command for an 8-GPU MI355X node: the SCALE line plus the link roofline and per-rank kernel evidence.
+# Run from the repo root; writes under profiles/r03_8gpu/ (small files only).
+#   bash scripts/r03_profile_8gpu.sh [N=8]
+# 1. bench.py --gpus N under torch.distributed.run (one process per GPU, ranks meet on the device): the compact JSON line with
+#    value = algbw @ 256 MiB f32, busbw, `xgmi` {link_probe taken before anything is tuned: SDMA vs copy kernel, write / read /
+#    both directions; wire GB/s per rank and per link against 76.8 / 153 GB/s; frac_of_link_peak}, `config.tuned` = what the
+#    LIBRARY's tuner (xmpi_tune) chose on these links; bench_extras.json beside it (per-algorithm times, sweeps).
+# 2. the production-layout program on the links: examples/allreduce_bench with every schedule by name -- the library's choice,
+#    the one-kernel fold (1 / 2 packets in flight), meet / body / done, push-only, the ring kernel (all ring channels = all
+#    links), the halving kernel -- at 256 MiB and 1 MiB, plain and under rocprofv3 --kernel-trace --stats (one
+#    kernel_stats.csv PER RANK); and the Send / Receive ping-pong between GPU 0 and GPU 1 (half round trip, through the C ABI).
+# 3. BASELINE cfg 5 on the links: examples/cfg5_sweep (fp16, ring vs halving vs the library's choice, 1 MiB ... 1 GiB).
+# 4. the ring kernel's channel count on real links: 1, 2, all.
+set -x
+N=${1:-8}
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+O=$ROOT/profiles/r03_8gpu
+mkdir -p $O
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0 XMPI_TIMEOUT_S=120
+BIN=$ROOT/mpi_amd/bin
+cd $ROOT
+LAUNCH="python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 29533"
+timeout 1500 $LAUNCH bench.py --gpus $N --steps 20 --warmup 5 > $O/bench_n$N.json 2> $O/bench_n$N.err
+cp bench_extras.json $O/bench_n${N}_extras.json 2>/dev/null
+tail -c 800 $O/bench_n$N.err
+MODES="auto fused fused2 split zpush ring rhd"
+XMPI_BASEPORT=7100 timeout 600 $BIN/xmpirun $N $BIN/allreduce_bench 268435456 20 5 $MODES > $O/prod_n${N}_256MiB.json 2> $O/prod.err
+XMPI_BASEPORT=7150 timeout 600 $BIN/xmpirun $N $BIN/allreduce_bench 16777216 50 5 $MODES > $O/prod_n${N}_16MiB.json 2>> $O/prod.err
+XMPI_BASEPORT=7200 timeout 600 $BIN/xmpirun $N $BIN/allreduce_bench 1048576 200 10 $MODES > $O/prod_n${N}_1MiB.json 2>> $O/prod.err
+XMPI_BASEPORT=7250 timeout 900 $BIN/xmpirun $N $BIN/cfg5_sweep 1073741824 5 > $O/cfg5_n$N.json 2>> $O/prod.err
+for ch in 1 2 0; do
+  XMPI_SCHED_CHANNELS=$ch XMPI_BASEPORT=7300 timeout 600 $BIN/xmpirun $N $BIN/allreduce_bench 268435456 20 5 ring > $O/ring_channels_${ch}_n$N.json 2>> $O/prod.err
+done
+cd /tmp
+for m in auto ring rhd; do
+  XMPI_BASEPORT=7400 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$m -- $BIN/xmpirun $N $BIN/allreduce_bench 268435456 20 5 $m \
+      > $O/prod_${m}_under_rocprof.json 2> $O/stats_$m.err
+done
+cd $ROOT
+find $O -name "*.csv" ! -name "*kernel_stats.csv" -delete; find $O -name "*.db" -delete
+find $O -name "*kernel_stats.csv" | head -40
+python scripts/show_bench.py $O/bench_n$N.json 2>/dev/null | head -40
+du -sh $O

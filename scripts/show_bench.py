@@ -1,5 +1,6 @@
-"""Pretty-print the JSON line(s) bench.py wrote:  python scripts/show_bench.py file [file...]"""
+"""Pretty-print the compact JSON line bench.py wrote (and bench_extras.json beside it):  python scripts/show_bench.py file [file...]"""
 import json
+import os
 import sys
 
 
@@ -15,24 +16,29 @@ for f in sys.argv[1:]:
     d = json.loads(txt.split("\n")[-1])
     cfg = d["config"]
     print(f"== {f}: n_gpus={d['n_gpus']} ranks={cfg['ranks']} value={r(d['value'])} {d['unit']} "
-          f"ms/step={r(d['ms_per_step'], 3)} algbw={r(d['algbw_GBps'])} busbw={r(d['busbw_GBps'])}")
-    print("   config:", {k: v for k, v in cfg.items() if k != "workload"})
+          f"ms/step={r(d['ms_per_step'], 3)} algbw={r(d['algbw_GBps'])} busbw={r(d['busbw_GBps'])}  [{len(txt.split(chr(10))[-1])} bytes]")
+    print("   config:", {k: v for k, v in cfg.items() if k != "workload"}, "|", d.get("ranks_meet"))
     ro = d["roofline"]
-    print(f"   roofline: {ro['kernel'][:40]} achieved={r(ro['achieved'])} frac={r(ro['frac'], 3)} launches={ro['launches']} "
-          f"avg_us={r(ro['avg_launch_us'])} bytes/launch={ro['algorithmic_bytes_per_launch']}")
-    if d.get("roofline_isolated"):
-        i = d["roofline_isolated"]
-        print(f"   isolated: achieved={r(i['achieved'])} frac={r(i['frac'], 3)} avg_us={r(i['avg_launch_us'])} bytes/launch={i['bytes_per_launch']}")
-    print("   parity:", d["parity"])
+    print(f"   roofline: {ro['kernel'][:48]} achieved={r(ro['achieved'])} frac={r(ro['frac'], 3)} launches={ro['launches']} "
+          f"avg_us={r(ro['avg_launch_us'])} bytes/launch={ro['algorithmic_bytes_per_launch']} traffic={ro.get('traffic')}")
+    for k in ("roofline_production", "roofline_isolated", "xgmi", "busbw_at_size", "cfg5_f16_us", "parity"):
+        if d.get(k):
+            v = d[k]
+            print(f"   {k}:", {a: (r(b, 3) if not isinstance(b, dict) else {x: r(y, 2) for x, y in b.items()}) for a, b in v.items()} if isinstance(v, dict) else v)
     if d.get("cpu_baseline"):
-        c = d["cpu_baseline"]
-        print("   cpu:", {k: r(v, 4) for k, v in c.items() if k != "sample"})
-    for t in d.get("autotune", []):
-        print("     tune", {k: r(v) for k, v in t.items()})
-    ex = d.get("extras") or {}
-    for k, v in ex.items():
-        if k == "size_sweep":
-            for row in v:
-                print("      ", {a: r(b, 1) for a, b in row.items()})
-        else:
-            print("    ", k, {a: (r(b) if not isinstance(b, dict) else {x: r(y) for x, y in b.items()}) for a, b in v.items()} if isinstance(v, dict) else v)
+        print("   cpu:", {k: r(v, 4) for k, v in d["cpu_baseline"].items() if k != "sample"})
+    ex = os.path.join(os.path.dirname(os.path.abspath(f)), os.path.basename(f).replace(".json", "_extras.json"))
+    if os.path.exists(ex):
+        e = json.load(open(ex))
+        print("   autotune:", {k: v for k, v in e.get("autotune", {}).items() if not k.startswith("table")})
+        for k, v in (e.get("extras") or {}).items():
+            if isinstance(v, dict) and "rows" in v:
+                print("    ", k)
+                for row in v["rows"]:
+                    print("       ", {a: (r(b, 1) if not isinstance(b, dict) else {x: r(y, 1) for x, y in b.items()}) for a, b in row.items()})
+            elif isinstance(v, list):
+                print("    ", k)
+                for row in v:
+                    print("       ", {a: r(b, 1) for a, b in row.items()} if isinstance(row, dict) else row)
+            else:
+                print("    ", k, {a: (r(b) if not isinstance(b, dict) else {x: r(y) for x, y in b.items()}) for a, b in v.items()} if isinstance(v, dict) else v)

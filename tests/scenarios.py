@@ -964,7 +964,7 @@ def sc_split(comm, args):
     comm.stream_destroy(st)
     g1.free()
     g2.free()
-    comm.set_param("dsync_split_bytes", 8 << 20)
+    comm.set_param("dsync_split_bytes", 4 << 20)
     assert comm.get_param("dsync_split_launches") > l0, "the split form did not run"
 
 
@@ -1074,7 +1074,8 @@ def sc_p2p_stream(comm, args):
 def sc_tune(comm, args):
     """xmpi_tune: the library times its own schedules and AUTO follows the table -- the same table on every rank."""
     rank, size = comm.rank(), comm.size()
-    comm.tune(args.get("max_bytes", 4 << 20))
+    if not args.get("tuned_by_init"):  # (XMPI_AUTOTUNE_BYTES: xmpi_init has tuned already)
+        comm.tune(args.get("max_bytes", 4 << 20))
     if comm.get_param("dsync") != 1:
         assert comm.get_param("tuned") == 0
         return

@@ -195,6 +195,11 @@ def test_library_tuner(size):
     run_ranks("tune", size, timeout=600)
 
 
+def test_library_tuner_from_the_environment():
+    """XMPI_AUTOTUNE_BYTES: a program that never heard of tuning gets the tuned table from xmpi_init"""
+    run_ranks("tune", 4, {"tuned_by_init": True}, timeout=600, env={"XMPI_AUTOTUNE_BYTES": str(2 << 20)})
+
+
 def test_library_tuner_threads():
     """ranks that meet on the host have one schedule: nothing to tune, AUTO unchanged"""
     run_threads("tune", 3)

@@ -153,3 +153,44 @@ def test_tcp_collectives_are_the_oracle_bit_for_bit(dtype, op, size, tmp_path):
         assert np.fromfile(tmp_path / f"out{r}.allgather", dtype=npdt).tobytes() == oracle.allgather(ins, dt).tobytes()
         assert np.fromfile(tmp_path / f"out{r}.bcast", dtype=npdt).tobytes() == ins[0].tobytes()
     assert np.fromfile(tmp_path / f"out{size - 1}.reduce", dtype=npdt).tobytes() == want.tobytes()
+
+
+def test_init_survives_strangers_on_its_port():
+    """a connection that is not a rank of this job -- garbage, a 2^60-byte length prefix, or silence -- reaches the listener
+    BEFORE its password is checked: it must cost neither memory nor the job (the handshake reads are bounded and timed)"""
+    import socket
+    import threading
+    import time
+    ports = _ports(7950, 2)
+    procs = [_spawn([os.path.join(BIN, "helloworld"), "--tcp"], p, ports, ["-mpi-inittimeout", "20s"]) for p in ports[:1]]
+    time.sleep(0.3)  # rank 0 is listening; rank 1 is not there yet
+
+    def stranger(payload, linger):
+        for _ in range(50):
+            try:
+                sk = socket.create_connection(("127.0.0.1", 7950), timeout=2)
+                break
+            except OSError:
+                time.sleep(0.05)
+        else:
+            return
+        try:
+            if payload:
+                sk.sendall(payload)
+            time.sleep(linger)
+        finally:
+            sk.close()
+
+    ts = [threading.Thread(target=stranger, args=(b"\xf8" + b"\x10" + b"\x00" * 7 + b"junk", 0.2)),  # 8-byte length: 2^60
+          threading.Thread(target=stranger, args=(b"GET / HTTP/1.0\r\n\r\n", 0.2)),
+          threading.Thread(target=stranger, args=(b"", 1.0))]  # connects and says nothing
+    for x in ts:
+        x.start()
+    time.sleep(0.2)
+    procs.append(_spawn([os.path.join(BIN, "helloworld"), "--tcp"], ports[1], ports, ["-mpi-inittimeout", "20s"]))
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    for x in ts:
+        x.join()
+    assert all(p.returncode == 0 for p in procs), outs
+    for rank, out in enumerate(outs):
+        assert sorted(out.strip().split("\n")) == _hello_lines(rank, 2)
