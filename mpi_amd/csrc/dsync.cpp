@@ -369,11 +369,13 @@ struct Resolved {
 bool dsync_usable(const xmpi_comm* c) { return c->dsync_ok && c->dsync && c->size > 1; }
 
 // blocks a kernel of this rank may keep waiting at once: the kernels of all ranks on one GPU spin together, so with
-// several ranks per GPU they must all be resident (half of its 8192 wave slots, 4 waves per block, shared); a rank that
-// has its GPU to itself may fill it -- blocks that are not resident yet only start later, nothing waits for them
+// several ranks per GPU they must all be resident (half of its 8192 wave slots, 4 waves per block, shared)
 static long dsync_block_cap(const xmpi_comm* c) {
   if (c->dsync_grid_cap > 0) return c->dsync_grid_cap;
-  return c->dsync_sharers > 1 ? 1024 / c->dsync_sharers : 2048;
+  // (a rank alone on its GPU keeps to half of the chip too: while its blocks wait for a late peer the caller's other streams
+  // still find wave slots -- scripts/overlap_probe.hip: a full-chip compute kernel next to a waiting 1024-block collective
+  // runs 5 % slower, next to the meet / body / done form 1.5 %)
+  return 1024 / std::max(1, c->dsync_sharers);
 }
 
 int dsync_grid(const xmpi_comm* c, size_t packets_per_segment, int nseg, int unroll) {
