@@ -99,6 +99,7 @@ class Job:
         port = os.environ.get("MASTER_PORT", "0")
         self.key = os.environ.get("XMPI_BENCH_KEY") or f"bench-{port}-{os.getppid() if self.procs > 1 else os.getpid()}"
         self.zero_copy_ok = True
+        self.probe_ok = None  # the schedules the probe saw working (None: not probed)
         self.probe = "not run"
         # ranks sharing a GPU have no link to pipeline against: large pieces (one launch per chunk)
         # keep every kernel at full-chip bandwidth; one rank per GPU keeps the library defaults
@@ -237,6 +238,14 @@ def rank_main(job: Job, grank: int):
     tune = {"by": "library defaults (ranks meet on the host: one schedule)"}
     if a.algo == "auto":
         algo = xmpi.ALGO_AUTO
+        if dsync_can and job.probe_ok is not None:  # what the probe saw failing on this machine is not a candidate
+            mask = -1
+            for name, bit in TUNE_BIT.items():
+                if name not in job.probe_ok:
+                    mask &= ~(1 << bit)
+            comm.set_param("tune_mask", mask)
+            if "split" not in job.probe_ok:
+                comm.set_param("dsync_split_bytes", 0)
         if dsync_can:
             t0 = time.perf_counter()
             comm.tune(min(nbytes, 1 << 30))
@@ -245,7 +254,8 @@ def rank_main(job: Job, grank: int):
                     "algo": ALGO_NAME.get(comm.get_param(f"tune_algo_0_{cls}"), "default"),
                     "split": comm.get_param(f"tune_split_0_{cls}"), "unroll": comm.get_param(f"tune_unroll_0_{cls}"),
                     "table_algo": [comm.get_param(f"tune_algo_0_{k}") for k in range(24)],
-                    "table_split": [comm.get_param(f"tune_split_0_{k}") for k in range(24)]}
+                    "table_split": [comm.get_param(f"tune_split_0_{k}") for k in range(24)],
+                    "probe_ok": sorted(job.probe_ok) if job.probe_ok is not None else None}
         order = [xmpi.ALGO_AUTO] + ([xmpi.ALGO_ZCOPY] if zc_ok else []) + [xmpi.ALGO_DIRECT, xmpi.ALGO_RING]
     else:
         forced = a.algo if (a.algo not in ("zcopy", "zpush") or zc_ok) else "ring"
@@ -558,27 +568,61 @@ def cpu_bounce():
             for n, us in zip(lens, row["bytes_us"])]
 
 
+PROBE_FORMS = (("fused", xmpi.ALGO_ZCOPY, {"dsync_split_bytes": 0}), ("split", xmpi.ALGO_ZCOPY, {"dsync_split_bytes": 1}),
+               ("zpush", xmpi.ALGO_ZPUSH, {}), ("ring", xmpi.ALGO_RING, {}), ("rhd", xmpi.ALGO_RHD, {}))
+TUNE_BIT = {"split": 2, "zpush": 3, "ring": 4, "rhd": 5}  # xmpi_set_param("tune_mask"): candidate numbers of xmpi_tune
+
+
 def probe_rank(job: Job, grank: int):
-    """--probe: one zero-copy allreduce of 16 MiB per rank, checked bit for bit against the oracle"""
+    """--probe: every schedule the library may choose, ONE communicator each (a schedule that hangs aborts its own job
+    only), a 16 MiB allreduce checked against the oracle (bit for bit where the fold is in rank order, within 1e-6 * sum|x|
+    for ring / halving).  The first form (the one-kernel fold) must work: its failure is the probe's exit status.  The
+    others are reported on stdout -- `PROBE_OK fused,split,...` -- after all ranks agreed."""
     from oracle import oracle
     if os.environ.get("XMPI_BENCH_FAIL_PROBE"):  # rehearsal of the fallback
         raise AssertionError("probe failure forced by XMPI_BENCH_FAIL_PROBE")
-    comm = xmpi.Comm(grank, job.ranks, job.device_of(grank), job.key)
     count = 4 << 20
-    send, recv = comm.alloc(count * 4), comm.alloc(count * 4)
-    comm.fill(send, count, xmpi.F32, xmpi.PAT_SIGNED, 4000 + grank)
-    comm.memset(recv, 0, count * 4)
-    for _ in range(3):
-        comm.allreduce(send, recv, count, xmpi.F32, xmpi.SUM, xmpi.ALGO_ZCOPY)
-    went_staged = comm.get_param("zc_fallbacks_unregistered") + comm.get_param("zc_fallbacks_unmappable")
     off = (count // 3) // 8 * 8
-    ins = [oracle.fill(count, xmpi.F32, xmpi.PAT_SIGNED, 4000 + r)[off:off + 65536] for r in range(job.ranks)]
-    got = recv.download(np.float32, 65536, byte_offset=off * 4)
-    ok = went_staged == 0 and got.tobytes() == oracle.reduce_ranks(ins, xmpi.F32, oracle.SUM).tobytes()
-    comm.barrier()
-    comm.finalize()
-    if not ok:
-        raise AssertionError(f"rank {grank}: zero-copy probe failed (staged fallbacks: {went_staged})")
+    ins = [oracle.fill_range(off, 65536, xmpi.F32, xmpi.PAT_SIGNED, 4000 + r) for r in range(job.ranks)]
+    want = oracle.reduce_ranks(ins, xmpi.F32, oracle.SUM)
+    bound = 1e-6 * np.sum([np.abs(x.astype(np.float64)) for x in ins], axis=0)
+    good = []
+    for name, algo, params in PROBE_FORMS:
+        if algo == xmpi.ALGO_RHD and job.ranks & (job.ranks - 1):
+            continue
+        if name == "ring" and os.environ.get("XMPI_BENCH_FAIL_RING"):  # rehearsal: a schedule that does not work here
+            continue
+        ok = False
+        try:
+            comm = xmpi.Comm(grank, job.ranks, job.device_of(grank), f"{job.key}-{name}")
+            if name != "fused" and comm.get_param("dsync") != 1:
+                comm.finalize()
+                break  # ranks meet on the host: there is one schedule
+            for k, v in params.items():
+                comm.set_param(k, v)
+            send, recv = comm.alloc(count * 4), comm.alloc(count * 4)
+            comm.fill(send, count, xmpi.F32, xmpi.PAT_SIGNED, 4000 + grank)
+            comm.memset(recv, 0, count * 4)
+            for _ in range(3):
+                comm.allreduce(send, recv, count, xmpi.F32, xmpi.SUM, algo)
+            went_staged = comm.get_param("zc_fallbacks_unregistered") + comm.get_param("zc_fallbacks_unmappable")
+            got = recv.download(np.float32, 65536, byte_offset=off * 4)
+            if name in ("ring", "rhd"):
+                ok = bool(np.all(np.abs(got.astype(np.float64) - want.astype(np.float64)) <= bound))
+            else:
+                ok = went_staged == 0 and got.tobytes() == want.tobytes()
+            ok = all_max(comm, 0.0 if ok else 1.0) == 0.0  # every rank, or nobody
+            comm.barrier()
+            comm.finalize()
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write(f"[probe] rank {grank}: {name}: {e}\n")
+            ok = False
+        if ok:
+            good.append(name)
+        elif name == "fused":
+            raise AssertionError(f"rank {grank}: the zero-copy fold failed the probe")
+    if grank == job.my_ranks()[0]:
+        print("PROBE_OK " + ",".join(good), flush=True)
 
 
 def probe_zero_copy(job: Job) -> str:
@@ -586,16 +630,20 @@ def probe_zero_copy(job: Job) -> str:
     meet inside those kernels (flag words in HBM).  On a node this code has not run on before, try that in a job of
     its own (child processes): if it faults, hangs or gives wrong bits, try again with the ranks meeting on the host
     (XMPI_DSYNC=0); if that fails too, this run keeps to the staged schedules instead of dying without a result.
-    Returns "dsync" | "host" | "failed"."""
+    Returns "dsync" | "host" | "failed"; job.probe_ok = the schedules that worked (the library's tuner is told to leave
+    the others out)."""
     for attempt, extra in (("dsync", {}), ("host", {"XMPI_DSYNC": "0"})):
         env = dict(os.environ, XMPI_BENCH_KEY=f"{job.key}-probe-{attempt}", XMPI_TIMEOUT_S="30", **extra)
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(job.args.gpus), "--ranks", str(job.ranks), "--probe"]
         try:
-            p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=150)
+            p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=400)
         except subprocess.TimeoutExpired:
             sys.stderr.write(f"[bench] zero-copy probe ({attempt}) timed out\n")
             continue
         if p.returncode == 0:
+            for ln in (p.stdout or "").split("\n"):
+                if ln.startswith("PROBE_OK "):
+                    job.probe_ok = set(ln[len("PROBE_OK "):].strip().split(","))
             return attempt
         sys.stderr.write(f"[bench] zero-copy probe ({attempt}) failed (exit {p.returncode}):\n{(p.stdout or '')[-1500:]}\n")
     sys.stderr.write("[bench] keeping to the staged schedules\n")

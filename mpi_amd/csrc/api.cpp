@@ -1433,6 +1433,8 @@ int xmpi_set_param(xmpi_comm* c, const char* name, long value) {
   else if (n == "sched_grid") c->sched_grid = std::max<long>(0, value);
   else if (n == "tree_piece_bytes") c->tree_piece_bytes = std::max<long>(4096, value);
   else if (n == "tuned") c->tuned = value != 0;  // 0: AUTO forgets the table of xmpi_tune
+  else if (n == "tune_mask") c->tune_mask = value;  // bit k = 0: xmpi_tune leaves candidate k out (1 other unroll, 2 meet / body / done,
+                                                    // 3 push-only, 4 ring kernel, 5 halving kernel); the default form always runs
   else if (n == "kernel_mode") set_kernel_mode((int)value);  // process-wide
   else if (n == "grid_cap") set_grid_cap((int)value);        // process-wide
   else return XMPI_ERR_ARG;
@@ -1475,6 +1477,7 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
   if (n == "sched_grid") return c->sched_grid;
   if (n == "tree_piece_bytes") return c->tree_piece_bytes;
   if (n == "tuned") return c->tuned ? 1 : 0;
+  if (n == "tune_mask") return c->tune_mask;
   if (n.rfind("tune_", 0) == 0) {  // tune_<algo|split|unroll>_<collective 0..3>_<size class>: the table of xmpi_tune
     int coll = -1, cls = -1;
     char what[16] = {0};
@@ -1773,6 +1776,7 @@ int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
       for (size_t k = 0; k < cands.size() && rc == XMPI_OK; k++) {
         const Cand& cd = cands[k];
         if (coll == COLL_ALLGATHER && (cd.algo == XMPI_ALGO_ZPUSH || cd.algo == XMPI_ALGO_RHD || cd.unroll != u0)) continue;
+        if (k > 0 && !((c->tune_mask >> k) & 1)) continue;  // a schedule the caller has ruled out on this machine (never the default)
         rc = xmpi_barrier(c);
         if (rc != XMPI_OK) break;
         std::lock_guard<std::mutex> g(c->coll_mu);

@@ -135,6 +135,7 @@ struct xmpi_comm {
   int8_t tune_split[4][kTuneClasses];      // 1 = split form, 0 = one kernel, -1 = by dsync_split_bytes
   int8_t tune_unroll[4][kTuneClasses];
   bool tuned = false;
+  long tune_mask = -1;  // candidates xmpi_tune may time (bit per candidate; see xmpi_set_param "tune_mask")
   uint32_t* dsync_status = nullptr;          // pinned host word a kernel writes its first failure to ...
   uint32_t* dsync_status_dev = nullptr;      // ... and its device address
   int dsync_sharers = 1;         // ranks of this job on this rank's GPU (bounds the grid: their kernels spin together)

@@ -96,6 +96,27 @@ def test_bench_multi_process_launch_rehearsal(nproc):
         assert d["roofline"]["kernel"].startswith("dsync_")
 
 
+def test_bench_probe_rules_out_a_schedule():
+    """a multi-process run first tries EVERY schedule the library may choose in jobs of its own (child processes); one that
+    does not work on the machine (here: forced) is left out of the library's tuning instead of killing the run"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, XMPI_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", XMPI_BENCH_FAIL_RING="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1",
+           "--size-mib", "16", "--no-extras"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.strip().split("\n") if ln.startswith("{\"metric\"")][0])
+    assert d["zero_copy_probe"].startswith("ok") and d["parity"]["ok"]
+    with open(os.path.join(ROOT, d["extras_file"])) as f:
+        tune = json.load(f)["autotune"]
+    assert tune["probe_ok"] == ["fused", "rhd", "split", "zpush"], tune
+    assert 1 not in tune["table_algo"]  # XMPI_ALGO_RING never made it into the table
+
+
 def test_coll_sweep_one_process_per_rank():
     """examples/coll_sweep under the launcher: 4 processes, blocking and stream-queued allreduce, exact results"""
     env = dict(os.environ, XMPI_TIMEOUT_S="60", XMPI_NGPUS="1", XMPI_BASEPORT="7400")
