@@ -256,16 +256,21 @@ def rank_main(job: Job, grank: int):
                     "table_algo": [comm.get_param(f"tune_algo_0_{k}") for k in range(24)],
                     "table_split": [comm.get_param(f"tune_split_0_{k}") for k in range(24)],
                     "probe_ok": sorted(job.probe_ok) if job.probe_ok is not None else None}
-        order = [xmpi.ALGO_AUTO] + ([xmpi.ALGO_ZCOPY] if zc_ok else []) + [xmpi.ALGO_DIRECT, xmpi.ALGO_RING]
+        # should the library's choice not reproduce the oracle on this machine: the one-kernel fold (no tuned table, nothing
+        # split), then the host-driven schedules
+        order = [(xmpi.ALGO_AUTO, {})] + ([(xmpi.ALGO_ZCOPY, {"tuned": 0, "dsync_split_bytes": 0})] if zc_ok else []) + \
+                [(xmpi.ALGO_DIRECT, {}), (xmpi.ALGO_RING, {"tuned": 0, "dsync": 0} if dsync_can else {})]
     else:
         forced = a.algo if (a.algo not in ("zcopy", "zpush") or zc_ok) else "ring"
         algo = by_name[forced]
-        order = [algo]
+        order = [(algo, {})]
 
     # ---- warmup + parity of the schedule that will be timed, over the WHOLE buffer ------------------------------------
     # (a schedule that is wrong on this machine is reported and the next one takes its place, never timed)
     parity, parity_failures, chosen = {"checked": False}, [], None
-    for cand in order:
+    for cand, cand_params in order:
+        for k, v in cand_params.items():
+            comm.set_param(k, v)
         comm.memset(recv, 0, nbytes)
         for _ in range(max(1, a.warmup)):
             run(cand)
@@ -350,146 +355,158 @@ def rank_main(job: Job, grank: int):
 
     # ---- untimed extras: what the next round needs to tune blind multi-GPU runs -----------------------
     extras = {}
-    if not a.no_extras and R > 1:
-        extras["algos_at_size"] = {}
-        for al in (xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_DIRECT) + (ZC_ALGOS if zc_ok else ()):
-            if al == xmpi.ALGO_RHD and R & (R - 1):
-                continue
-            run(al)
-            t = timed(comm, None, 3, batch=lambda k, a2=al: run_n(a2, k))
-            extras["algos_at_size"][ALGO_NAME[al]] = {"ms": t * 1e3, "algbw_GBps": nbytes / t / 1e9,
-                                                      "busbw_GBps": nbytes / t / 1e9 * 2 * (R - 1) / R}
-        sweep = []
-        sz = 1 << 10
-        while sz <= min(nbytes, 1 << 30):
-            cnt = sz // es
-            row = {"bytes": sz}
-            for al in (xmpi.ALGO_RING, xmpi.ALGO_DIRECT) + ZC:
-                run(al, cnt)
-                # inside one native call: what the library costs, not what 8 Python threads cost each other
-                t = timed(comm, None, 10 if sz <= (16 << 20) else 3,
-                          batch=lambda k, a2=al, c2=cnt: comm.allreduce_repeat(send, recv, c2, dtype, xmpi.SUM, a2, k))
-                row[ALGO_NAME[al] + "_us"] = t * 1e6
-                row[ALGO_NAME[al] + "_busbw_GBps"] = sz / t / 1e9 * 2 * (R - 1) / R
-            sweep.append(row)
-            sz *= 4
-        extras["size_sweep"] = sweep
-        # BASELINE.json's metric: busbw against message size at 1 / 2 / 4 / 8 ranks.  Smaller communicators among the
-        # first ranks of this job (the others wait at the barrier); the schedule is the library's own choice (AUTO).
-        # One rank: an allreduce is a copy, busbw is defined 0, algbw is the figure.  cfg 3 rides along at 4 ranks.
-        table = []
-        sizes = []
-        sz = 1 << 10
-        while sz <= min(nbytes, 1 << 30):
-            sizes.append(sz)
-            sz *= 4
-        for r2 in (1, 2, 4, R):
-            if r2 > R:
-                continue
-            comm.barrier()
-            if grank < r2:
-                sub = comm if r2 == R else xmpi.Comm(grank, r2, job.device_of(grank), f"{job.key}-r{r2}")
-                s2, d2 = (send, recv) if r2 == R else (sub.alloc(nbytes), sub.alloc(nbytes))
-                if r2 != R:
-                    sub.fill(s2, count, dtype, xmpi.PAT_UNIFORM, seed0 + grank)
-                for b in sizes:
-                    cnt = b // es
-                    sub.allreduce(s2, d2, cnt, dtype, xmpi.SUM, xmpi.ALGO_AUTO)
-                    it = 20 if b <= (1 << 20) else (5 if b <= (64 << 20) else 3)
-                    t = timed(sub, None, it, batch=lambda k, c=cnt: sub.allreduce_repeat(s2, d2, c, dtype, xmpi.SUM, xmpi.ALGO_AUTO, k))
-                    if grank == 0:
-                        table.append({"ranks": r2, "bytes": b, "us": t * 1e6, "algbw_GBps": b / t / 1e9,
-                                      "busbw_GBps": b / t / 1e9 * 2 * (r2 - 1) / r2})
-                if r2 == 4:  # BASELINE cfg 3: allgather int64, 16 MiB per rank, 4 ranks
-                    cnt3 = min(2097152, nbytes // 8 // 4)
-                    row3 = {"ranks": 4, "bytes_per_rank": cnt3 * 8}
-                    for al in (xmpi.ALGO_AUTO, xmpi.ALGO_RING):
-                        sub.allgather(s2, d2, cnt3, xmpi.I64, al)
-                        t = timed(sub, lambda: sub.allgather(s2, d2, cnt3, xmpi.I64, al), 5)
-                        row3["auto" if al == xmpi.ALGO_AUTO else "ring"] = {
-                            "ms": t * 1e3, "algbw_GBps": cnt3 * 8 * 4 / t / 1e9, "busbw_GBps": cnt3 * 8 * 4 / t / 1e9 * 3 / 4}
-                    if grank == 0:
-                        extras["cfg3_allgather_i64_16MiB_4ranks"] = row3
-                if r2 != R:
-                    s2.free()
-                    d2.free()
-                    sub.finalize()
-            comm.barrier()
-        extras["busbw_table"] = {"schedule": "AUTO (the library's choice)", "unit_note": "GB = 1e9 B; busbw = algbw x 2(R-1)/R; 1 rank: busbw is 0 by definition, algbw is a device copy",
-                                 "rows": table}
-        # BASELINE cfg 2: 1 MiB float32 ping-pong between ranks 0 and 1 (half round trip)
-        n1 = 262144
-        if grank in (0, 1):
-            peer = 1 - grank
-            iters = 50
-            for w in range(5 + iters):
-                if w == 5:
-                    t0 = time.perf_counter()
-                if grank == 0:
-                    comm.send(send, n1, xmpi.F32, peer, 3)
-                    comm.recv(recv, n1, xmpi.F32, peer, 3)
-                else:
-                    comm.recv(recv, n1, xmpi.F32, peer, 3)
-                    comm.send(recv, n1, xmpi.F32, peer, 3)
-            half = (time.perf_counter() - t0) / iters / 2
-            extras["bounce_1MiB_f32"] = {"half_round_trip_us": half * 1e6, "GBps": n1 * 4 / half / 1e9}
-            # the reference's own sweep (examples/bounce/bounce.go:33: message lengths 0 ... 1e7 bytes, 10 repetitions,
-            # bounce.go:140-151 prints the mean round trip per length)
-            sweep_b = []
-            for length in (0, 1, 10, 100, 1000, 10**4, 10**5, 10**6, 10**7):
-                if length > nbytes:
-                    break
-                reps = 10
-                for w in range(2 + reps):
-                    if w == 2:
+    out["extras"] = extras
+    with job.lock:  # the line's figures are safe from here on: whatever the untimed extras do, rank 0 can print them
+        job.result[grank] = out
+    # On real links only what the probe saw working is run by name (a schedule that hangs there would take the run's result
+    # with it); DIRECT -- a host-driven step table -- stays on one GPU, where round 1 and 2 validated it.
+    multi = ndev_used > 1
+    safe = set(job.probe_ok) if job.probe_ok is not None else {"fused", "split", "zpush", "ring", "rhd"}
+    named = [al for al, nm in ((xmpi.ALGO_RING, "ring"), (xmpi.ALGO_RHD, "rhd"), (xmpi.ALGO_ZPUSH, "zpush")) if not multi or nm in safe]
+    try:
+        if not a.no_extras and R > 1:
+            extras["algos_at_size"] = {}
+            for al in [x for x in named if x != xmpi.ALGO_ZPUSH] + ([] if multi else [xmpi.ALGO_DIRECT]) + ([x for x in ZC_ALGOS if x == xmpi.ALGO_ZCOPY or x in named] if zc_ok else []):
+                if al == xmpi.ALGO_RHD and R & (R - 1):
+                    continue
+                run(al)
+                t = timed(comm, None, 3, batch=lambda k, a2=al: run_n(a2, k))
+                extras["algos_at_size"][ALGO_NAME[al]] = {"ms": t * 1e3, "algbw_GBps": nbytes / t / 1e9,
+                                                          "busbw_GBps": nbytes / t / 1e9 * 2 * (R - 1) / R}
+            sweep = []
+            sz = 1 << 10
+            while sz <= min(nbytes, 1 << 30):
+                cnt = sz // es
+                row = {"bytes": sz}
+                for al in ([xmpi.ALGO_RING] if xmpi.ALGO_RING in named else []) + ([] if multi else [xmpi.ALGO_DIRECT]) + list(ZC):
+                    run(al, cnt)
+                    # inside one native call: what the library costs, not what 8 Python threads cost each other
+                    t = timed(comm, None, 10 if sz <= (16 << 20) else 3,
+                              batch=lambda k, a2=al, c2=cnt: comm.allreduce_repeat(send, recv, c2, dtype, xmpi.SUM, a2, k))
+                    row[ALGO_NAME[al] + "_us"] = t * 1e6
+                    row[ALGO_NAME[al] + "_busbw_GBps"] = sz / t / 1e9 * 2 * (R - 1) / R
+                sweep.append(row)
+                sz *= 4
+            extras["size_sweep"] = sweep
+            # BASELINE.json's metric: busbw against message size at 1 / 2 / 4 / 8 ranks.  Smaller communicators among the
+            # first ranks of this job (the others wait at the barrier); the schedule is the library's own choice (AUTO).
+            # One rank: an allreduce is a copy, busbw is defined 0, algbw is the figure.  cfg 3 rides along at 4 ranks.
+            table = []
+            sizes = []
+            sz = 1 << 10
+            while sz <= min(nbytes, 1 << 30):
+                sizes.append(sz)
+                sz *= 4
+            for r2 in (1, 2, 4, R):
+                if r2 > R:
+                    continue
+                comm.barrier()
+                if grank < r2:
+                    sub = comm if r2 == R else xmpi.Comm(grank, r2, job.device_of(grank), f"{job.key}-r{r2}")
+                    s2, d2 = (send, recv) if r2 == R else (sub.alloc(nbytes), sub.alloc(nbytes))
+                    if r2 != R:
+                        sub.fill(s2, count, dtype, xmpi.PAT_UNIFORM, seed0 + grank)
+                    for b in sizes:
+                        cnt = b // es
+                        sub.allreduce(s2, d2, cnt, dtype, xmpi.SUM, xmpi.ALGO_AUTO)
+                        it = 20 if b <= (1 << 20) else (5 if b <= (64 << 20) else 3)
+                        t = timed(sub, None, it, batch=lambda k, c=cnt: sub.allreduce_repeat(s2, d2, c, dtype, xmpi.SUM, xmpi.ALGO_AUTO, k))
+                        if grank == 0:
+                            table.append({"ranks": r2, "bytes": b, "us": t * 1e6, "algbw_GBps": b / t / 1e9,
+                                          "busbw_GBps": b / t / 1e9 * 2 * (r2 - 1) / r2})
+                    if r2 == 4:  # BASELINE cfg 3: allgather int64, 16 MiB per rank, 4 ranks
+                        cnt3 = min(2097152, nbytes // 8 // 4)
+                        row3 = {"ranks": 4, "bytes_per_rank": cnt3 * 8}
+                        for al in (xmpi.ALGO_AUTO, xmpi.ALGO_RING):
+                            sub.allgather(s2, d2, cnt3, xmpi.I64, al)
+                            t = timed(sub, lambda: sub.allgather(s2, d2, cnt3, xmpi.I64, al), 5)
+                            row3["auto" if al == xmpi.ALGO_AUTO else "ring"] = {
+                                "ms": t * 1e3, "algbw_GBps": cnt3 * 8 * 4 / t / 1e9, "busbw_GBps": cnt3 * 8 * 4 / t / 1e9 * 3 / 4}
+                        if grank == 0:
+                            extras["cfg3_allgather_i64_16MiB_4ranks"] = row3
+                    if r2 != R:
+                        s2.free()
+                        d2.free()
+                        sub.finalize()
+                comm.barrier()
+            extras["busbw_table"] = {"schedule": "AUTO (the library's choice)", "unit_note": "GB = 1e9 B; busbw = algbw x 2(R-1)/R; 1 rank: busbw is 0 by definition, algbw is a device copy",
+                                     "rows": table}
+            # BASELINE cfg 2: 1 MiB float32 ping-pong between ranks 0 and 1 (half round trip)
+            n1 = 262144
+            if grank in (0, 1):
+                peer = 1 - grank
+                iters = 50
+                for w in range(5 + iters):
+                    if w == 5:
                         t0 = time.perf_counter()
                     if grank == 0:
-                        comm.send(send, length, xmpi.U8, peer, 4)
-                        comm.recv(recv, length, xmpi.U8, peer, 4)
+                        comm.send(send, n1, xmpi.F32, peer, 3)
+                        comm.recv(recv, n1, xmpi.F32, peer, 3)
                     else:
-                        comm.recv(recv, length, xmpi.U8, peer, 4)
-                        comm.send(recv, length, xmpi.U8, peer, 4)
-                rt = (time.perf_counter() - t0) / reps
-                sweep_b.append({"bytes": length, "round_trip_us": rt * 1e6, "GBps": 2 * length / rt / 1e9})
-            extras["bounce_sweep_u8"] = sweep_b
+                        comm.recv(recv, n1, xmpi.F32, peer, 3)
+                        comm.send(recv, n1, xmpi.F32, peer, 3)
+                half = (time.perf_counter() - t0) / iters / 2
+                extras["bounce_1MiB_f32"] = {"half_round_trip_us": half * 1e6, "GBps": n1 * 4 / half / 1e9}
+                # the reference's own sweep (examples/bounce/bounce.go:33: message lengths 0 ... 1e7 bytes, 10 repetitions,
+                # bounce.go:140-151 prints the mean round trip per length)
+                sweep_b = []
+                for length in (0, 1, 10, 100, 1000, 10**4, 10**5, 10**6, 10**7):
+                    if length > nbytes:
+                        break
+                    reps = 10
+                    for w in range(2 + reps):
+                        if w == 2:
+                            t0 = time.perf_counter()
+                        if grank == 0:
+                            comm.send(send, length, xmpi.U8, peer, 4)
+                            comm.recv(recv, length, xmpi.U8, peer, 4)
+                        else:
+                            comm.recv(recv, length, xmpi.U8, peer, 4)
+                            comm.send(recv, length, xmpi.U8, peer, 4)
+                    rt = (time.perf_counter() - t0) / reps
+                    sweep_b.append({"bytes": length, "round_trip_us": rt * 1e6, "GBps": 2 * length / rt / 1e9})
+                extras["bounce_sweep_u8"] = sweep_b
+            comm.barrier()
+            # BASELINE cfg 5: allreduce-sum fp16 up to 1 GiB per rank, recursive halving vs ring (and the library's own
+            # choice) over sizes 1 MiB ... 1 GiB; exactly summable inputs k/64: every schedule must be bit-identical to
+            # the rank-order result.  >= 5 timed iterations per point.
+            if dtype == xmpi.F32 and nbytes >= (256 << 20):
+                n5 = (1 << 30) // 2
+                s5, r5, ref5 = comm.alloc(n5 * 2), comm.alloc(n5 * 2), comm.alloc(n5 * 2)
+                comm.fill(s5, n5, xmpi.F16, xmpi.PAT_UNIFORM, 2000 + grank)
+                rows5 = []
+                b5 = 1 << 20
+                while b5 <= (1 << 30):
+                    c5 = b5 // 2
+                    comm.allreduce(s5, ref5, c5, xmpi.F16, xmpi.SUM, xmpi.ALGO_ZCOPY if multi else xmpi.ALGO_DIRECT)  # rank order either way
+                    row = {"bytes": b5}
+                    for al, name in ((xmpi.ALGO_RING, "ring"), (xmpi.ALGO_RHD, "rhd"), (xmpi.ALGO_AUTO, "auto")):
+                        if (al == xmpi.ALGO_RHD and R & (R - 1)) or (al != xmpi.ALGO_AUTO and al not in named):
+                            continue
+                        comm.allreduce(s5, r5, c5, xmpi.F16, xmpi.SUM, al)
+                        same = comm.count_mismatch(r5, ref5, b5) == 0
+                        t = timed(comm, None, 5, batch=lambda k, a5=al, cc=c5: comm.allreduce_repeat(s5, r5, cc, xmpi.F16, xmpi.SUM, a5, k))
+                        row[name] = {"ms": t * 1e3, "algbw_GBps": b5 / t / 1e9, "busbw_GBps": b5 / t / 1e9 * 2 * (R - 1) / R,
+                                     "bit_identical_to_rank_order": same}
+                    rows5.append(row)
+                    b5 *= 4
+                extras["cfg5_allreduce_f16_sweep"] = {"ranks": R, "iterations": 5, "rows": rows5,
+                                                      "layout": "rank threads of one process: ring / rhd are HOST-DRIVEN step tables here (the stepped kernels "
+                                                                "need ranks that meet on the device: cfg5_allreduce_f16_sweep_one_process_per_rank)"}
+                for b in (s5, r5, ref5):
+                    b.free()
+            if link is not None:
+                extras["xgmi_link_probe"] = link
+    except Exception as e:  # noqa: BLE001  (an extra that fails must not cost the line)
+        extras["error"] = repr(e)[:300]
+
+    try:  # (a peer that failed in its extras no longer arrives: the figures above are stored already)
         comm.barrier()
-        # BASELINE cfg 5: allreduce-sum fp16 up to 1 GiB per rank, recursive halving vs ring (and the library's own
-        # choice) over sizes 1 MiB ... 1 GiB; exactly summable inputs k/64: every schedule must be bit-identical to
-        # the rank-order result.  >= 5 timed iterations per point.
-        if dtype == xmpi.F32 and nbytes >= (256 << 20):
-            n5 = (1 << 30) // 2
-            s5, r5, ref5 = comm.alloc(n5 * 2), comm.alloc(n5 * 2), comm.alloc(n5 * 2)
-            comm.fill(s5, n5, xmpi.F16, xmpi.PAT_UNIFORM, 2000 + grank)
-            rows5 = []
-            b5 = 1 << 20
-            while b5 <= (1 << 30):
-                c5 = b5 // 2
-                comm.allreduce(s5, ref5, c5, xmpi.F16, xmpi.SUM, xmpi.ALGO_DIRECT)
-                row = {"bytes": b5}
-                for al, name in ((xmpi.ALGO_RING, "ring"), (xmpi.ALGO_RHD, "rhd"), (xmpi.ALGO_AUTO, "auto")):
-                    if al == xmpi.ALGO_RHD and R & (R - 1):
-                        continue
-                    comm.allreduce(s5, r5, c5, xmpi.F16, xmpi.SUM, al)
-                    same = comm.count_mismatch(r5, ref5, b5) == 0
-                    t = timed(comm, None, 5, batch=lambda k, a5=al, cc=c5: comm.allreduce_repeat(s5, r5, cc, xmpi.F16, xmpi.SUM, a5, k))
-                    row[name] = {"ms": t * 1e3, "algbw_GBps": b5 / t / 1e9, "busbw_GBps": b5 / t / 1e9 * 2 * (R - 1) / R,
-                                 "bit_identical_to_rank_order": same}
-                rows5.append(row)
-                b5 *= 4
-            extras["cfg5_allreduce_f16_sweep"] = {"ranks": R, "iterations": 5, "rows": rows5,
-                                                  "layout": "rank threads of one process: ring / rhd are HOST-DRIVEN step tables here (the stepped kernels "
-                                                            "need ranks that meet on the device: cfg5_allreduce_f16_sweep_one_process_per_rank)"}
-            for b in (s5, r5, ref5):
-                b.free()
-        if link is not None:
-            extras["xgmi_link_probe"] = link
-    out["extras"] = extras
-    with job.lock:
-        job.result[grank] = out
-    comm.barrier()
-    send.free()
-    recv.free()
-    comm.finalize()
+        send.free()
+        recv.free()
+        comm.finalize()
+    except Exception as e:  # noqa: BLE001
+        extras.setdefault("error", repr(e)[:300])
     _ = lead
 
 
@@ -669,9 +686,10 @@ def main():
     job.mp_sweep = job.production = None
     if args.gpus == 1 and job.procs == 1 and not args.probe and not args.no_production:
         job.production = production_layout(job.ranks, int(args.size_mib * (1 << 20)), args.steps, args.warmup)
-    job.cfg5 = None
+    job.cfg5 = job.cfg3 = None
     if args.gpus == 1 and job.procs == 1 and not args.no_extras and not args.probe:
         job.mp_sweep = multiprocess_sweep(job.ranks)
+        job.cfg3 = cfg3_production()
         if args.size_mib >= 256:
             job.cfg5 = cfg5_production(job.ranks, 1 << 30)
     if (args.gpus > 1 or job.procs > 1) and not args.no_probe:
@@ -684,10 +702,10 @@ def main():
         t.start()
     for t in threads:
         t.join()
-    if job.errors:
-        for g, tb in job.errors:
-            sys.stderr.write(f"[bench] rank {g} failed:\n{tb}\n")
-        sys.exit(1)
+    for g, tb in job.errors:
+        sys.stderr.write(f"[bench] rank {g} failed:\n{tb}\n")
+    if any(g not in job.result for g in job.my_ranks()):
+        sys.exit(1)  # a rank of this process never got through the timed region: there is no figure to report
     if 0 not in job.result:
         return  # not the process hosting rank 0
     r0 = job.result[0]
@@ -807,6 +825,8 @@ def main():
             line["roofline_production"] = rp
     if job.mp_sweep is not None:
         extras_out["extras"]["multiprocess_sweep"] = job.mp_sweep
+    if job.cfg3 is not None:
+        extras_out["extras"]["cfg3_allgather_i64_16MiB_4ranks_one_process_per_rank"] = job.cfg3
     if job.cfg5 is not None:
         extras_out["extras"]["cfg5_allreduce_f16_sweep_one_process_per_rank"] = job.cfg5
         try:  # the compact line carries the two ends of the sweep
@@ -857,6 +877,23 @@ def production_layout(ranks: int, nbytes: int, steps: int, warmup: int):
         return json.loads(p.stdout.strip().split("\n")[-1])
     except ValueError:
         return {"error": p.stdout[-400:]}
+
+
+def cfg3_production():
+    """examples/cfg3_allgather under the launcher: BASELINE cfg 3 (allgather int64, 16 MiB per rank, 4 ranks, ring) with one
+    OS process per rank -- the ring is the stepped kernel there"""
+    run = os.path.join(ROOT, "mpi_amd", "bin", "xmpirun")
+    prog = os.path.join(ROOT, "mpi_amd", "bin", "cfg3_allgather")
+    if not (os.path.exists(run) and os.path.exists(prog)):
+        return None
+    env = dict(os.environ, XMPI_TIMEOUT_S="60", XMPI_BASEPORT=str(9800 + os.getpid() % 1000 * 16))
+    env.pop("XMPI_SLOT_BYTES", None)
+    env.pop("XMPI_FIFO_DEPTH", None)
+    try:
+        p = subprocess.run([run, "4", prog, "2097152", "20"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=200)
+        return json.loads(p.stdout.strip().split("\n")[-1]) if p.returncode == 0 else {"error": (p.stderr or p.stdout)[-400:]}
+    except (subprocess.TimeoutExpired, ValueError) as e:
+        return {"error": repr(e)[:200]}
 
 
 def cfg5_production(ranks: int, max_bytes: int):

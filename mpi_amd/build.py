@@ -129,7 +129,8 @@ def build_host(force: bool = False) -> list[str]:
                           ("allreduce", os.path.join(ROOT, "examples", "allreduce.cpp")),
                           ("coll_sweep", os.path.join(ROOT, "examples", "coll_sweep.cpp")),
                           ("allreduce_bench", os.path.join(ROOT, "examples", "allreduce_bench.cpp")),
-                          ("cfg5_sweep", os.path.join(ROOT, "examples", "cfg5_sweep.cpp"))):
+                          ("cfg5_sweep", os.path.join(ROOT, "examples", "cfg5_sweep.cpp")),
+                          ("cfg3_allgather", os.path.join(ROOT, "examples", "cfg3_allgather.cpp"))):
             if os.path.exists(src):
                 out = os.path.join(BIN, name)
                 if force or _newer(out, [src] + deps):

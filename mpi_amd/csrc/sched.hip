@@ -31,7 +31,11 @@ namespace {
 // split form: meet
 // =====================================================================================================================
 
-// A few blocks (one per XCD): announce (block 0), wait for every peer, acquire at system scope -- each block for the L2
+// one-wave blocks of the meet and done kernels: consecutive blocks are dealt round the 8 XCDs, two rounds so that every
+// XCD's L2 is acquired / released even if one block lands beside another
+constexpr int kXcdBlocks = 16;
+
+// A few blocks (at least one per XCD): announce (block 0), wait for every peer, acquire at system scope -- each block for the L2
 // of the XCD it runs on, so that the data kernel behind this one cannot be served a stale line of a peer's input -- and
 // block 0 translates the peers' buffers and leaves what the data kernel needs in ordinary device memory (the kernel
 // boundary publishes it).  No completion exchange here: the done kernel does it.
@@ -487,7 +491,7 @@ hipError_t sched_op(const DsyncSchedArgs& a, int op, dim3 grid, hipStream_t s, h
 
 hipError_t launch_dsync_meet(const DsyncArgs& a, DsyncResolved* out, hipStream_t s) {
   if (a.n < 1 || a.n > kDsyncRanks || a.nseg < 0 || a.nseg > kDsyncRanks || !out) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(dsync_meet_kernel, dim3(8), dim3(64), 0, s, a, out);
+  hipLaunchKernelGGL(dsync_meet_kernel, dim3(kXcdBlocks), dim3(64), 0, s, a, out);
   return hipGetLastError();
 }
 
@@ -514,8 +518,8 @@ hipError_t launch_dsync_body(const DsyncResolved* res, int nseg, size_t max_pack
 
 hipError_t launch_dsync_done(const DsyncArgs& a, const DsyncResolved* res, hipStream_t s) {
   if (!res) return hipErrorInvalidValue;
-  // one block per XCD (the dispatcher deals consecutive blocks round the 8 XCDs): each writes back the L2 it runs on
-  hipLaunchKernelGGL(dsync_done_kernel, dim3(8), dim3(64), 0, s, a, res);
+  // at least one block per XCD (the dispatcher deals consecutive blocks round the 8 XCDs): each writes back the L2 it runs on
+  hipLaunchKernelGGL(dsync_done_kernel, dim3(kXcdBlocks), dim3(64), 0, s, a, res);
   return hipGetLastError();
 }
 

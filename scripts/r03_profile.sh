@@ -37,6 +37,7 @@ echo "pmc write rc=$?" >> $O/prod.err
 XMPI_BASEPORT=7400 timeout 200 $BIN/xmpirun 2 $GRAFT_REPO_ROOT/scripts/overlap_probe_bin 268435456 8 3 > $O/overlap_2proc_256MiB.json 2> $O/overlap.err
 XMPI_BASEPORT=7450 timeout 200 $BIN/xmpirun 2 $GRAFT_REPO_ROOT/scripts/overlap_probe_bin 16777216 8 3 > $O/overlap_2proc_16MiB.json 2>> $O/overlap.err
 XMPI_BASEPORT=7500 timeout 300 $BIN/xmpirun 8 $BIN/cfg5_sweep 1073741824 5 > $O/cfg5_8proc.json 2> $O/cfg5.err
+XMPI_BASEPORT=7550 timeout 200 $BIN/xmpirun 4 $BIN/cfg3_allgather 2097152 20 > $O/cfg3_4proc.json 2>> $O/cfg5.err
 for n in 2 4; do XMPI_BASEPORT=7600 timeout 200 $BIN/xmpirun $n $BIN/allreduce_bench 268435456 20 5 auto fused split ring rhd > $O/prod_${n}proc_256MiB.json 2>> $O/prod.err; done
 XMPI_BASEPORT=7700 timeout 200 $BIN/xmpirun 8 $BIN/allreduce_bench 16777216 50 5 auto fused split ring rhd > $O/prod_8proc_16MiB.json 2>> $O/prod.err
 XMPI_BASEPORT=7800 timeout 200 $BIN/xmpirun 8 $BIN/allreduce_bench 1048576 200 10 auto fused split ring rhd > $O/prod_8proc_1MiB.json 2>> $O/prod.err

@@ -29,6 +29,7 @@ XMPI_BASEPORT=7100 timeout 600 $BIN/xmpirun $N $BIN/allreduce_bench 268435456 20
 XMPI_BASEPORT=7150 timeout 600 $BIN/xmpirun $N $BIN/allreduce_bench 16777216 50 5 $MODES > $O/prod_n${N}_16MiB.json 2>> $O/prod.err
 XMPI_BASEPORT=7200 timeout 600 $BIN/xmpirun $N $BIN/allreduce_bench 1048576 200 10 $MODES > $O/prod_n${N}_1MiB.json 2>> $O/prod.err
 XMPI_BASEPORT=7250 timeout 900 $BIN/xmpirun $N $BIN/cfg5_sweep 1073741824 5 > $O/cfg5_n$N.json 2>> $O/prod.err
+XMPI_BASEPORT=7280 timeout 300 $BIN/xmpirun 4 $BIN/cfg3_allgather 2097152 20 > $O/cfg3_4gpu.json 2>> $O/prod.err
 for ch in 1 2 0; do
   XMPI_SCHED_CHANNELS=$ch XMPI_BASEPORT=7300 timeout 600 $BIN/xmpirun $N $BIN/allreduce_bench 268435456 20 5 ring > $O/ring_channels_${ch}_n$N.json 2>> $O/prod.err
 done

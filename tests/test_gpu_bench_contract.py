@@ -117,6 +117,25 @@ def test_bench_probe_rules_out_a_schedule():
     assert 1 not in tune["table_algo"]  # XMPI_ALGO_RING never made it into the table
 
 
+def test_cfg3_and_cfg5_in_the_production_layout():
+    """BASELINE cfg 3 (allgather int64, 4 ranks, ring) and cfg 5 (fp16 allreduce, halving vs ring) with one process per rank:
+    ring and halving are the stepped kernels; every result bit-exact (cfg 5: exactly summable inputs)"""
+    env = dict(os.environ, XMPI_TIMEOUT_S="60", XMPI_NGPUS="1", XMPI_BASEPORT="7480")
+    run = os.path.join(ROOT, "mpi_amd", "bin", "xmpirun")
+    r = subprocess.run([run, "4", os.path.join(ROOT, "mpi_amd", "bin", "cfg3_allgather"), "2097152", "5"], capture_output=True, text=True,
+                       timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().split("\n")[-1])
+    assert d["exact"] is True and d["ranks"] == 4 and d["bytes_per_rank"] == 16 << 20 and "stepped kernel" in d["meet"]
+    assert d["ring"]["bit_exact_and_in_place"] and d["auto"]["bit_exact_and_in_place"] and d["ring"]["blocking_us"] > 0
+    r = subprocess.run([run, "8", os.path.join(ROOT, "mpi_amd", "bin", "cfg5_sweep"), str(16 << 20), "3"], capture_output=True, text=True,
+                       timeout=300, cwd=ROOT, env=dict(env, XMPI_BASEPORT="7520"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().split("\n")[-1])
+    assert d["all_bit_identical"] is True and [x["bytes"] for x in d["rows"]] == [1 << 20, 4 << 20, 16 << 20]
+    assert all(x[k]["bit_identical_to_rank_order"] and x[k]["us"] > 0 for x in d["rows"] for k in ("ring", "rhd", "auto"))
+
+
 def test_coll_sweep_one_process_per_rank():
     """examples/coll_sweep under the launcher: 4 processes, blocking and stream-queued allreduce, exact results"""
     env = dict(os.environ, XMPI_TIMEOUT_S="60", XMPI_NGPUS="1", XMPI_BASEPORT="7400")

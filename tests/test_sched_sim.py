@@ -70,3 +70,43 @@ def test_the_checker_notices_a_missing_wait(monkeypatch):
         want = sim.expected(xmpi.SCHED_RING_ALLREDUCE, 4, 40, orig)
         bad += any(list(recv[r]) != want[r] for r in range(4))
     assert bad > 0
+
+
+def test_tuner_decision_function():
+    """xmpi_tune_decide: the fastest candidate, but the default (index 0) stays unless beaten by more than the margin;
+    candidates that did not run (<= 0) never win; nothing ran: -1"""
+    d = xmpi.tune_decide
+    assert d([100.0, 90.0, 120.0], 0.03) == 1
+    assert d([100.0, 98.0, 120.0], 0.03) == 0          # 2 % is inside the noise margin: the default stays
+    assert d([100.0, 97.0 - 1e-9, 120.0], 0.03) == 1   # just beyond it
+    assert d([100.0, 0.0, -1.0, 50.0], 0.03) == 3      # not-run candidates are ignored
+    assert d([0.0, 80.0, 70.0], 0.03) == 2             # the default itself did not run
+    assert d([0.0, 0.0], 0.03) == -1
+    assert d([5.0], 0.5) == 0
+    assert d([10.0, 9.0], 0.0) == 1                    # no margin: plain argmin
+    assert d([10.0, 10.0], 0.0) == 0                   # a tie keeps the default
+
+
+def test_sched_dump_rejects_bad_arguments():
+    L = xmpi.lib()
+    assert L.xmpi_sched_dump(9, 4, 0, 0, 1, 100, 4, 1, 0, None, 0) == xmpi.ERR_ARG      # no such schedule
+    assert L.xmpi_sched_dump(1, 4, 4, 0, 1, 100, 4, 1, 0, None, 0) == xmpi.ERR_ARG      # rank out of range
+    assert L.xmpi_sched_dump(1, 4, 0, 0, 1, 100, 4, 9, 0, None, 0) == xmpi.ERR_ARG      # more channels than the kernel has
+    assert L.xmpi_sched_dump(4, 5, 0, 7, 1, 100, 1, 1, 0, None, 0) == xmpi.ERR_ARG      # root out of range
+    text = xmpi.sched_text(xmpi.SCHED_RING_ALLREDUCE, 8, 3, 0, 1, 1 << 20, 4, 2, 1)
+    assert len(text.strip().split("\n")) == 14  # 2 (N - 1) steps
+
+
+def test_ring_channels_are_different_cycles():
+    """every ring channel of the stepped kernel is another cyclic order of the ranks: on an even mesh no two channels send
+    over the same directed link (plan.cpp ring_order, Walecki's decomposition)"""
+    for n in (4, 6, 8):
+        nchan = min(n - 2, 8)
+        links = set()
+        for ch in range(nchan):
+            for rank in range(n):
+                first = sim.program(xmpi.SCHED_RING_ALLREDUCE, n, rank, 0, 1, n * 64, 4, nchan, ch)[1]  # step 2 waits for the previous rank
+                prev = first["wait"][0]
+                assert (prev, rank, ch) not in links
+                assert not any((prev, rank, c2) in links for c2 in range(nchan) if c2 != ch), f"N={n}: link {prev}->{rank} used by two channels"
+                links.add((prev, rank, ch))
