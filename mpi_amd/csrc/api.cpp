@@ -565,6 +565,8 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
     if (c->ctl_registered) (void)hipHostUnregister(ctl->base());
     if (c->p2p_tickets) (void)hipFree(c->p2p_tickets);
     if (c->p2p_done) (void)hipHostFree(c->p2p_done);
+    if (c->p2p_cmd) (void)hipHostFree(c->p2p_cmd);
+    if (c->p2p_rec) (void)hipFree(c->p2p_rec);
     if (c->dev_words) (void)hipFree(c->dev_words);
     (void)hipGetLastError();
     if (c->window) pool_release(c->window);
@@ -697,6 +699,18 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   }
   (void)hipGetLastError();
   c->p2p_kernel_ack = env_long("XMPI_P2P_KERNEL_ACK", 1) ? 1 : 0;
+  c->p2p_agent_us = std::max<long>(0, env_long("XMPI_P2P_AGENT_US", 40));
+  if (hipHostMalloc((void**)&c->p2p_cmd, 64, hipHostMallocMapped) == hipSuccess) {
+    memset(c->p2p_cmd, 0, 64);
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, c->p2p_cmd, 0) == hipSuccess) c->p2p_cmd_dev = (uint64_t*)dev;
+  } else {
+    c->p2p_cmd = nullptr;
+  }
+  if (hipMalloc((void**)&c->p2p_rec, 64) == hipSuccess)
+    (void)hipMemsetAsync(c->p2p_rec, 0, 64, c->local_stream);
+  else c->p2p_rec = nullptr;
+  (void)hipGetLastError();
   XMPI_TRACE_STEP(rank, "init: connecting flag pages");
   rc = dsync_connect(c);
   if (rc != XMPI_OK) return fail(rc);
@@ -736,6 +750,7 @@ int xmpi_finalize(xmpi_comm* c) {
   if (!c) return XMPI_ERR_STATE;
   if (c->finalized) return XMPI_OK;
   stop_worker(c);  // outstanding non-blocking collectives complete first
+  p2p_agent_stop(c);  // the receive agent (if it still lingers) is told to go
   XMPI_TRACE_STEP(c->rank, "finalize: device sync");
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
@@ -761,12 +776,15 @@ int xmpi_finalize(xmpi_comm* c) {
     stream_release(c->device, c->batch_recv_stream);
   }
   for (hipStream_t s : c->p2p_streams) stream_release(c->device, s);
+  if (c->agent_stream) stream_release(c->device, c->agent_stream);
   for (hipEvent_t e : c->ev_free) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev_timed_free) (void)hipEventDestroy(e);
   if (!c->ctl->aborted()) (void)c->ctl->barrier(wait_limit(c));
   if (c->ctl_registered) (void)hipHostUnregister(c->ctl->base());
   if (c->p2p_tickets) (void)hipFree(c->p2p_tickets);
   if (c->p2p_done) (void)hipHostFree(c->p2p_done);
+  if (c->p2p_cmd) (void)hipHostFree(c->p2p_cmd);
+  if (c->p2p_rec) (void)hipFree(c->p2p_rec);
   if (c->window) pool_release(c->window);  // exported memory is never given back by the runtime: the next communicator reuses it
   if (c->temp) (void)hipFree(c->temp);
   if (c->host_stage) (void)hipFree(c->host_stage);
@@ -1424,6 +1442,7 @@ int xmpi_set_param(xmpi_comm* c, const char* name, long value) {
   else if (n == "zc_group_launch") c->zc_group_launch = value ? 1 : 0;
   else if (n == "p2p_direct_bytes") c->p2p_direct_bytes = value;  // < 0: always through the mail slots
   else if (n == "p2p_kernel_ack") c->p2p_kernel_ack = value ? 1 : 0;
+  else if (n == "p2p_agent_us") c->p2p_agent_us = std::max<long>(0, value);
   else if (n == "dsync") c->dsync = value ? 1 : 0;
   else if (n == "dsync_grid") c->dsync_grid_cap = std::max<long>(0, value);
   else if (n == "dsync_unroll") c->dsync_unroll = std::max<long>(1, std::min<long>(2, value));
@@ -1462,6 +1481,9 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
   }
   if (n == "p2p_direct_bytes") return c->p2p_direct_bytes;
   if (n == "p2p_kernel_ack") return c->p2p_kernel_ack;
+  if (n == "p2p_agent_us") return c->p2p_agent_us;
+  if (n == "p2p_agent_served") return (long)c->p2p_agent_served;
+  if (n == "p2p_agent_launches") return (long)c->p2p_agent_launches;
   if (n == "dsync") return dsync_usable(c) ? 1 : 0;
   if (n == "dsync_epoch") return (long)c->dsync_epoch;
   if (n == "dsync_launches") return (long)c->dsync_launches;

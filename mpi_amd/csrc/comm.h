@@ -122,6 +122,16 @@ struct xmpi_comm {
   uint64_t p2p_done_next = 0;
   std::atomic<uint64_t> p2p_pull_next{0};
   long p2p_kernel_ack = 1;           // blocking Receive: one kernel copies AND acks (0: hipMemcpyAsync / copy kernel + event + host ack)
+  long p2p_agent_us = 40;            // ... by a kernel that stays this long after a message (the receive agent, sched.hip): the next
+                                     // Receive hands it a command instead of launching again (0: one launch per message)
+  uint64_t* p2p_cmd = nullptr;       // pinned host: the agent's command record (8 words)
+  uint64_t* p2p_cmd_dev = nullptr;
+  uint64_t* p2p_rec = nullptr;       // device: 8 words (block 0 -> other blocks)
+  std::mutex agent_mu;               // one command at a time
+  uint64_t agent_seq = 0;            // number of the last command written
+  bool agent_running = false;        // launched and not yet known to have gone
+  hipStream_t agent_stream = nullptr;
+  uint64_t p2p_agent_served = 0, p2p_agent_launches = 0;  // messages the agent copied; times it had to be launched
   struct P2PPending {
     int slot;
     uint64_t id;
@@ -220,6 +230,7 @@ int p2p_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, i
 int p2p_wait(xmpi_comm* c, int dest, int tag);
 int p2p_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int tag, size_t* got_bytes);
 int p2p_probe(xmpi_comm* c, int src, int tag, size_t* bytes, int* dtype);
+void p2p_agent_stop(xmpi_comm* c);
 // zcopy.cpp.  *done = false: some rank's buffers are not registered HBM -- every rank saw that and
 // the caller runs the staged schedule instead (no rank is left behind: the decision is collective).
 int zero_copy_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void* recvbuf, size_t count,

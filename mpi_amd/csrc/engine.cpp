@@ -729,6 +729,78 @@ int await_ack(xmpi_comm* c, MailEntry* m, int dest, int tag) {
 
 }  // namespace
 
+// ---- the receive agent: a copy-and-ack kernel that lingers (sched.hip p2p_agent_kernel) ------------------------------------
+// One command at a time per communicator.  Returns true when the agent copied the message and wrote both acks; false: the
+// caller launches the ordinary kernel (the agent could not be started).
+static bool agent_submit(xmpi_comm* c, void* dst, const void* from, size_t bytes, MailEntry* m) {
+  if (c->p2p_agent_us <= 0 || !c->p2p_cmd_dev || !c->p2p_rec || !c->ctl_dev || bytes == 0 || bytes >= ((size_t)1 << 22)) return false;
+  std::lock_guard<std::mutex> g(c->agent_mu);
+  volatile uint64_t* cmd = c->p2p_cmd;
+  const uint64_t seq = ++c->agent_seq;
+  const uint64_t mail_off = (uint64_t)((char*)&m->state - (char*)c->ctl->base());
+  cmd[1] = (uint64_t)(uintptr_t)from;
+  cmd[2] = (uint64_t)(uintptr_t)dst;
+  cmd[3] = (mail_off & 0xffffffffull) | (seq << 32);
+  __atomic_store_n((uint64_t*)&cmd[0], 1ull | ((uint64_t)bytes << 2) | (seq << 24), __ATOMIC_RELEASE);  // the doorbell last
+  auto launch = [&]() -> bool {
+    if (!c->agent_stream) c->agent_stream = stream_acquire(c->device);
+    if (!c->agent_stream) return false;
+    __atomic_store_n((uint64_t*)&cmd[7], 0, __ATOMIC_RELEASE);
+    P2PAgentArgs a;
+    memset(&a, 0, sizeof a);
+    a.cmd = c->p2p_cmd_dev;
+    a.rec = c->p2p_rec;
+    a.ctl_dev = (uint64_t)(uintptr_t)c->ctl_dev;
+    a.seq0 = seq;
+    a.launch = (c->p2p_agent_launches + 1) & 0x7fffff;
+    a.alone_bytes = 64 << 10;
+    a.patience_ticks = (uint64_t)c->p2p_agent_us * 100;  // wall_clock64 runs at 100 MHz
+    a.mail_done_value = MAIL_DONE;
+    if (launch_p2p_agent(a, 32, c->agent_stream) != hipSuccess) {  // 31 of them only ever watch a word in device memory
+      (void)hipGetLastError();
+      return false;
+    }
+    c->agent_running = true;
+    c->p2p_agent_launches++;
+    return true;
+  };
+  if (!c->agent_running && !launch()) {
+    __atomic_store_n((uint64_t*)&cmd[0], 0, __ATOMIC_RELEASE);  // nobody will read it
+    --c->agent_seq;
+    return false;
+  }
+  Backoff bo;
+  for (;;) {
+    if (__atomic_load_n((const uint64_t*)&cmd[6], __ATOMIC_ACQUIRE) == seq) break;  // copied and acknowledged
+    if (__atomic_load_n((const uint64_t*)&cmd[7], __ATOMIC_ACQUIRE) != 0) {  // the agent had gone (its patience ran out)
+      if (__atomic_load_n((const uint64_t*)&cmd[6], __ATOMIC_ACQUIRE) == seq) break;
+      c->agent_running = false;
+      if (!launch()) {  // (cannot happen after a launch that worked; give the message to the ordinary kernel)
+        __atomic_store_n((uint64_t*)&cmd[0], 0, __ATOMIC_RELEASE);
+        --c->agent_seq;
+        return false;
+      }
+    }
+    bo.pause();
+  }
+  c->p2p_agent_served++;
+  return true;
+}
+
+// a lingering agent is told to go and waited for (finalize; nothing else needs it: it goes by itself)
+void p2p_agent_stop(xmpi_comm* c) {
+  std::lock_guard<std::mutex> g(c->agent_mu);
+  if (!c->agent_running || !c->p2p_cmd) return;
+  volatile uint64_t* cmd = c->p2p_cmd;
+  const uint64_t seq = ++c->agent_seq;
+  cmd[3] = seq << 32;
+  __atomic_store_n((uint64_t*)&cmd[0], 2ull | (seq << 24), __ATOMIC_RELEASE);
+  Backoff bo;
+  const double t0 = now_seconds();
+  while (__atomic_load_n((const uint64_t*)&cmd[7], __ATOMIC_ACQUIRE) == 0 && now_seconds() - t0 < 5.0) bo.pause();
+  c->agent_running = false;
+}
+
 // wait_ack = false is the reference author's intended Send (commented out at mpi.go:132-152): return
 // once the payload has left the caller's buffer; p2p_wait() later collects the receiver's confirmation
 // and frees the {dest, tag} pair.
@@ -996,6 +1068,10 @@ int p2p_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int 
     void* from = nullptr;
     if (dev_dst && zc_import(c, src, m->src, &from)) {
       m->direct.store(DIRECT_ACCEPTED, std::memory_order_release);
+      if (c->p2p_kernel_ack && agent_submit(c, buf, from, bytes, m)) {  // the lingering agent took it: no launch at all
+        __atomic_fetch_add(&c->p2p_direct_count, 1, __ATOMIC_RELAXED);
+        return XMPI_OK;
+      }
       if (c->p2p_kernel_ack && c->ctl_dev && c->p2p_done_dev && c->p2p_tickets) {
         // ONE kernel copies and acks: its last block writes DONE into the message's mail entry (the sender's host thread
         // polls it: the ack of network.go:616-624, without this rank's host in between) and the completion word this

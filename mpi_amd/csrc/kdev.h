@@ -326,14 +326,14 @@ __device__ __forceinline__ void st_sys_elem(T* p, T v) {
 
 // dst = src, all blocks of the grid together: 16 KiB tiles, four 16-byte loads per lane in flight (a message is pulled
 // over a link: round trips), bytes at odd alignments one by one
-__device__ __forceinline__ void copy_span(char* dst, const char* src, size_t bytes) {
+__device__ __forceinline__ void copy_span(char* dst, const char* src, size_t bytes, unsigned bid = blockIdx.x, unsigned nb = gridDim.x) {
   const int t = threadIdx.x;
   if ((((uintptr_t)src | (uintptr_t)dst) & 15u) == 0) {
     const size_t npack = bytes / 16;
     constexpr size_t kTile = (size_t)kBlock * 4;
     const pack_t* ps = reinterpret_cast<const pack_t*>(src);
     pack_t* pd = reinterpret_cast<pack_t*>(dst);
-    for (size_t base = (size_t)blockIdx.x * kTile; base < npack; base += (size_t)gridDim.x * kTile) {
+    for (size_t base = (size_t)bid * kTile; base < npack; base += (size_t)nb * kTile) {
       if (base + kTile <= npack) {
         pack_t v[4];
 #pragma unroll
@@ -344,9 +344,9 @@ __device__ __forceinline__ void copy_span(char* dst, const char* src, size_t byt
         for (size_t i = base + t; i < npack; i += kBlock) pd[i] = ldp<2>(ps + i);
       }
     }
-    if (blockIdx.x == 0 && npack * 16 + t < bytes) dst[npack * 16 + t] = src[npack * 16 + t];
+    if (bid == 0 && npack * 16 + t < bytes) dst[npack * 16 + t] = src[npack * 16 + t];
   } else {
-    for (size_t i = (size_t)blockIdx.x * kBlock + t; i < bytes; i += (size_t)gridDim.x * kBlock) dst[i] = src[i];
+    for (size_t i = (size_t)bid * kBlock + t; i < bytes; i += (size_t)nb * kBlock) dst[i] = src[i];
   }
 }
 

@@ -264,6 +264,20 @@ struct P2PPullArgs {
   uint32_t pad;
 };
 hipError_t launch_p2p_pull(const P2PPullArgs& a, int grid_x, hipStream_t stream);
+// ... by a kernel that stays for a while after a message and takes the next one from a command record in pinned host memory
+// instead of being launched again (see sched.hip p2p_agent_kernel)
+struct P2PAgentArgs {
+  uint64_t* cmd;            // pinned host memory, 8 words, 64-byte aligned: [0..3] the command, [6] last number served, [7] "gone"
+  uint64_t* rec;            // device memory, 8 words: what block 0 tells the other blocks; [5] ticket, [6] number all blocks finished
+  uint64_t ctl_dev;         // the control block as the GPU addresses it (a command names its mail entry by offset)
+  uint64_t seq0;            // the number of the first command this launch serves
+  uint64_t launch;          // number of this launch (never 0; < 2^23)
+  uint64_t alone_bytes;     // messages up to this long are copied by block 0 alone (waking the other blocks costs ~2.5 us)
+  uint64_t patience_ticks;  // wall_clock64 ticks (100 MHz) block 0 waits for a command
+  uint32_t mail_done_value;
+  uint32_t pad;
+};
+hipError_t launch_p2p_agent(const P2PAgentArgs& a, int grid_x, hipStream_t stream);
 hipError_t launch_p2p_recv(const P2PArgs& a, int grid_x, hipStream_t stream);
 
 }  // namespace xmpi

@@ -443,6 +443,111 @@ __global__ __launch_bounds__(kBlock) void p2p_pull_kernel(P2PPullArgs a) {
   if (a.host_done) __hip_atomic_store(a.host_done, a.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// The receive AGENT (engine.cpp p2p_recv / agent_submit): the same copy-and-ack, by a kernel that STAYS for a while.
+// A blocking Receive pays one kernel launch per message -- about 5 us before the first wave runs, most of an 8 us half
+// round trip -- and a ping-pong cannot hide it (the Receive is called when the message is already on its way).  So the
+// kernel that served a message does not end at once: block 0 goes back to watching the command record in pinned host
+// memory, where the host thread of the NEXT Receive -- which does the matching, as always -- writes {where the payload
+// is, where it goes, how long}; the copy starts a PCIe read later instead of a launch later.  The agent waits for the
+// HOST's word only, and only for `patience` (tens of microseconds) after its last message; then it says so and ends, and
+// the next Receive launches it again.  Nothing on the GPU ever waits for a peer, and nothing waits for the host longer
+// than that bound: a program blocked in Receives whose messages arrive in any order (helloworld.go:53-81) cannot
+// deadlock, the streams that share the agent's hardware queue are delayed by the patience at most.
+//
+// The command is 32 bytes read with two 16-byte loads issued together (a load over PCIe is a microsecond or two):
+//   w0 = doorbell (1 = go, 2 = stop) | bytes << 2 (22 bits) | seq << 24     w1 = where the payload is
+//   w2 = where it goes                                                     w3 = mail entry's offset in the control block | seq << 32
+// written by the host w1, w2, w3, then w0 (x86 keeps the order; both halves lie in one cache line), accepted when BOTH
+// halves carry the expected number.  cmd[6] = number of the last command served; cmd[7] = "gone" (the number the agent was
+// waiting for, plus one).
+__global__ __launch_bounds__(kBlock) void p2p_agent_kernel(P2PAgentArgs a) {
+  __shared__ uint64_t s_src, s_dst, s_bytes, s_mail, s_seq;
+  __shared__ uint32_t s_go, s_last;
+  const int t = threadIdx.x;
+  // device memory: [0] what block 0 tells the other blocks: (launch << 40 | n) << 1 | go for its n-th word to them (the record
+  // outlives launches: the launch number keeps a stale word of the launch before from being taken for this one's),
+  // [1] src, [2] dst, [3] bytes, [5] ticket, [6] the word all blocks have finished with
+  uint64_t* rec = a.rec;
+  uint64_t seq = a.seq0, told = 0;  // next command number (block 0); words to the other blocks so far (every block counts)
+  for (;;) {
+    bool wide = true;  // all blocks copy (block 0 alone takes a short message: waking the others costs more than they save)
+    if (t == 0) {
+      if (blockIdx.x == 0) {
+        uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+        bool have = false;
+        const uint64_t t0 = wall_clock64();
+        for (;;) {
+          pack_t v[2];
+          ld_sys128_issue(v[0], reinterpret_cast<const pack_t*>(a.cmd));
+          ld_sys128_issue(v[1], reinterpret_cast<const pack_t*>(a.cmd) + 1);
+          sys128_wait<2>(v);
+          w0 = ((uint64_t)v[0].y << 32) | v[0].x;
+          w1 = ((uint64_t)v[0].w << 32) | v[0].z;
+          w2 = ((uint64_t)v[1].y << 32) | v[1].x;
+          w3 = ((uint64_t)v[1].w << 32) | v[1].z;
+          have = (w0 & 3u) != 0 && (w0 >> 24) == seq && (w3 >> 32) == (seq & 0xffffffffull);
+          if (have || wall_clock64() - t0 > a.patience_ticks) break;
+          __builtin_amdgcn_s_sleep(2);
+        }
+        if (have && (w0 & 3u) == 1) {
+          s_src = w1;
+          s_dst = w2;
+          s_bytes = (w0 >> 2) & 0x3fffffu;
+          s_mail = a.ctl_dev + (w3 & 0xffffffffull);
+          s_go = 1;
+        } else {  // told to stop, or nothing came in time: say so -- the next Receive launches the agent again
+          s_go = 0;
+          __hip_atomic_store(&a.cmd[7], seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        s_seq = seq;
+        if (gridDim.x > 1 && (!s_go || s_bytes > a.alone_bytes)) {
+          st_sys64(&rec[1], s_src);
+          st_sys64(&rec[2], s_dst);
+          st_sys64(&rec[3], s_bytes);
+          __hip_atomic_store(&rec[0], ((((uint64_t)a.launch << 40) | (told + 1)) << 1) | s_go, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      } else {
+        const uint64_t key = ((uint64_t)a.launch << 40) | (told + 1);
+        uint64_t v;
+        while (((v = __hip_atomic_load(&rec[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 1) != key) __builtin_amdgcn_s_sleep(2);
+        s_go = (uint32_t)(v & 1);
+        s_src = ld_sys64(&rec[1]);
+        s_dst = ld_sys64(&rec[2]);
+        s_bytes = ld_sys64(&rec[3]);
+      }
+    }
+    __syncthreads();
+    if (!s_go) return;
+    wide = gridDim.x > 1 && s_bytes > a.alone_bytes;
+    if (wide || blockIdx.x != 0) told++;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // the payload as the sender left it, not a stale line
+    if (wide) copy_span(reinterpret_cast<char*>(s_dst), reinterpret_cast<const char*>(s_src), s_bytes);
+    else copy_span(reinterpret_cast<char*>(s_dst), reinterpret_cast<const char*>(s_src), s_bytes, 0, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      const uint64_t key = ((uint64_t)a.launch << 40) | told;
+      uint32_t* ticket = reinterpret_cast<uint32_t*>(&rec[5]);
+      s_last = !wide || __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+      if (s_last && wide) {
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&rec[6], key, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (blockIdx.x == 0) {
+        // every block has finished this message (its stores drained and released) before the acks go out -- and before the
+        // record for the other blocks is rewritten for the next one
+        if (wide)
+          while (__hip_atomic_load(&rec[6], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != key) __builtin_amdgcn_s_sleep(1);
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(s_mail), a.mail_done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&a.cmd[6], s_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        seq++;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // =====================================================================================================================
 // launchers
 // =====================================================================================================================
@@ -544,6 +649,12 @@ hipError_t launch_dsync_sched(const DsyncSchedArgs& a, int dtype, int op, int gr
 hipError_t launch_p2p_pull(const P2PPullArgs& a, int grid_x, hipStream_t s) {
   if (grid_x < 1) grid_x = 1;
   hipLaunchKernelGGL(p2p_pull_kernel, dim3((unsigned)grid_x), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_p2p_agent(const P2PAgentArgs& a, int grid_x, hipStream_t s) {
+  if (grid_x < 1) grid_x = 1;
+  hipLaunchKernelGGL(p2p_agent_kernel, dim3((unsigned)grid_x), dim3(kBlock), 0, s, a);
   return hipGetLastError();
 }
 
