@@ -141,7 +141,10 @@ int xmpi_sync(xmpi_comm* comm);
  * the smallest such message, < 0 turns this off) is not pushed at all: the matching receive copies it
  * straight out of the sender's HBM (one pass, one xGMI crossing).  Host buffers and unregistered
  * device memory travel through the mail slots of the receiver's window (slot-in by the sender,
- * slot-out by the receiver). */
+ * slot-out by the receiver).  That copy is one kernel whose last block writes both acknowledgements itself, and which stays for
+ * p2p_agent_us (XMPI_P2P_AGENT_US, default 40; 0 = one launch per message) after a message to take the next one from a command
+ * record in pinned host memory instead of being launched again: between two processes a small message takes 4.5-5 us per
+ * direction.  Nothing on the GPU ever waits for a peer on this path. */
 int xmpi_send(xmpi_comm* comm, const void* buf, size_t count, xmpi_dtype dtype, int dest, int tag);
 
 /* The split of Send the reference's author sketched and left commented out (mpi.go:132-152):

@@ -509,7 +509,7 @@ __global__ __launch_bounds__(kBlock) void p2p_agent_kernel(P2PAgentArgs a) {
       } else {
         const uint64_t key = ((uint64_t)a.launch << 40) | (told + 1);
         uint64_t v;
-        while (((v = __hip_atomic_load(&rec[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 1) != key) __builtin_amdgcn_s_sleep(2);
+        while (((v = __hip_atomic_load(&rec[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 1) != key) __builtin_amdgcn_s_sleep(8);
         s_go = (uint32_t)(v & 1);
         s_src = ld_sys64(&rec[1]);
         s_dst = ld_sys64(&rec[2]);

@@ -447,6 +447,14 @@ def sc_bounce(comm, args):
     sizes = [c * xmpi.DTYPE_SIZE[d] for length in BOUNCE_LENGTHS for d, c in ((xmpi.U8, length), (xmpi.F64, length // 8))]
     want_direct = 0 if thr < 0 else sum(1 for b in sizes if b >= max(1, thr)) + 5
     assert direct == want_direct and staged == len(sizes) + 5 - want_direct, (direct, staged, want_direct)
+    # ... by the receive agent (the copy-and-ack kernel that lingers for the next message) when it is on and the message is
+    # not longer than it takes: every such message was served by it, with far fewer launches than messages
+    if comm.get_param("p2p_agent_us") > 0 and comm.get_param("p2p_kernel_ack") == 1 and thr >= 0:
+        small = sum(1 for b in sizes if max(1, thr) <= b <= 512 << 10) + 5 * (1 if n * 4 <= 512 << 10 else 0)
+        assert comm.get_param("p2p_agent_served") == small, (comm.get_param("p2p_agent_served"), small)
+        assert 1 <= comm.get_param("p2p_agent_launches") <= small
+    else:
+        assert comm.get_param("p2p_agent_served") == 0
 
 
 def sc_helloworld(comm, args):

@@ -121,6 +121,14 @@ def test_bounce_small_p2p_slots():
     run_ranks("bounce", 2, timeout=600, env={"XMPI_P2P_SLOT_BYTES": "8192", "XMPI_P2P_DIRECT_BYTES": "-1"})
 
 
+def test_bounce_without_the_receive_agent():
+    """XMPI_P2P_AGENT_US=0: one launch of the copy-and-ack kernel per message; XMPI_P2P_KERNEL_ACK=0: round 2's path
+    (hipMemcpyAsync + event + host ack)"""
+    run_ranks("bounce", 2, timeout=600, env={"XMPI_P2P_AGENT_US": "0"})
+    run_ranks("bounce", 2, timeout=600, env={"XMPI_P2P_KERNEL_ACK": "0"})
+    run_ranks("p2p_semantics", 2, timeout=300, env={"XMPI_P2P_SLOT_BYTES": "65536", "XMPI_P2P_AGENT_US": "0"})
+
+
 def test_bounce_threads():
     """ranks as threads of one process: the receiver reads the sender's buffer through its own pointer"""
     run_threads("bounce", 2)
