@@ -36,6 +36,8 @@ XMPI_TIMEOUT_S=20 XMPI_BASEPORT=7350 timeout 200 rocprofv3 --pmc WRITE_SIZE --ke
 echo "pmc write rc=$?" >> $O/prod.err
 XMPI_BASEPORT=7400 timeout 200 $BIN/xmpirun 2 $GRAFT_REPO_ROOT/scripts/overlap_probe_bin 268435456 8 3 > $O/overlap_2proc_256MiB.json 2> $O/overlap.err
 XMPI_BASEPORT=7450 timeout 200 $BIN/xmpirun 2 $GRAFT_REPO_ROOT/scripts/overlap_probe_bin 16777216 8 3 > $O/overlap_2proc_16MiB.json 2>> $O/overlap.err
+for us in 40 0; do XMPI_P2P_AGENT_US=$us XMPI_BASEPORT=$((7900 + us)) timeout 60 $BIN/xmpirun 2 $BIN/allreduce_bench 16777216 5 2 fused > $O/bounce_2proc_agent_${us}us.json 2>> $O/prod.err; done
+XMPI_P2P_KERNEL_ACK=0 XMPI_BASEPORT=7990 timeout 60 $BIN/xmpirun 2 $BIN/allreduce_bench 16777216 5 2 fused > $O/bounce_2proc_round2_path.json 2>> $O/prod.err
 XMPI_BASEPORT=7500 timeout 300 $BIN/xmpirun 8 $BIN/cfg5_sweep 1073741824 5 > $O/cfg5_8proc.json 2> $O/cfg5.err
 XMPI_BASEPORT=7550 timeout 200 $BIN/xmpirun 4 $BIN/cfg3_allgather 2097152 20 > $O/cfg3_4proc.json 2>> $O/cfg5.err
 for n in 2 4; do XMPI_BASEPORT=7600 timeout 200 $BIN/xmpirun $n $BIN/allreduce_bench 268435456 20 5 auto fused split ring rhd > $O/prod_${n}proc_256MiB.json 2>> $O/prod.err; done
