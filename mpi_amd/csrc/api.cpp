@@ -1548,6 +1548,11 @@ int xmpi_prof_get(xmpi_comm* c, int kind, uint64_t* launches, double* total_ms, 
   if (!c || c->finalized) return XMPI_ERR_STATE;
   if (kind < 0 || kind >= PROF_KINDS) return XMPI_ERR_ARG;
   std::lock_guard<std::mutex> g(c->coll_mu);
+  if (kind == PROF_ZCOPY && !c->dsync_prof_pending.empty()) {  // launches whose events nobody has read yet
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->local_stream);
+    dsync_prof_harvest(c);
+  }
   if (launches) *launches = c->prof[kind].launches;
   if (total_ms) *total_ms = c->prof[kind].total_ms;
   if (bytes) *bytes = c->prof[kind].bytes;

@@ -153,6 +153,7 @@ struct xmpi_comm {
   long dsync_unroll = 1;         // 16-byte packets per lane per source in flight (2 = deeper, for links)
   long dsync_tiles = 1;          // tiles (256 lanes x unroll packets) a block walks before the grid grows
   uint64_t dsync_epoch = 0;      // epoch of the last kernel launched: the same number on every rank
+  uint64_t dsync_done_seq = 0;   // numbers the calls for the pinned "done" word a blocking call polls
   uint64_t dsync_base = 0;       // where this communicator's epochs start (epoch_floor of its kernels)
   uint64_t dsync_tag = 1;        // tags this communicator's entries in the (pooled, uncleared) page's translation cache
   uint64_t dsync_launches = 0, dsync_bounced = 0;  // diagnostics: kernels; buffers stood in for by arena blocks
@@ -266,6 +267,7 @@ int dsync_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest,
 int dsync_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int tag, hipStream_t stream);
 int dsync_p2p_reap(xmpi_comm* c);
 int dsync_check(xmpi_comm* c);
+void dsync_prof_harvest(xmpi_comm* c);
 // a rank that waits keeps serving its peers
 inline void arm(Backoff& bo, xmpi_comm* c) {
   if (c->dsync_ok) {

@@ -538,6 +538,10 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
   a.tag = c->dsync_tag;
   a.epoch_floor = c->dsync_base;
   a.host_epoch = c->dsync_status_dev ? (uint64_t*)(c->dsync_status_dev + 2) : nullptr;
+  // a blocking call learns that the collective is over from a word its closing block writes (dsync_status bytes 16..23),
+  // not from an event: set on the LAST kernel of the collective only (below)
+  const uint64_t done_id = ++c->dsync_done_seq;
+  uint64_t* const done_dev = (blocking && c->dsync_status_dev) ? (uint64_t*)(c->dsync_status_dev + 4) : nullptr;
   a.my_send = r.send;
   a.my_recv = r.recv;
   a.abort_word = c->dsync_abort_dev;
@@ -560,9 +564,11 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     return true;
   };
   // one rendezvous + data movement + completion exchange: ONE kernel, or -- large messages -- meet / body / done
-  auto launch = [&](int nsrc, int kdtype, int kop, size_t packets, size_t bytes_moved) -> int {
+  auto launch = [&](int nsrc, int kdtype, int kop, size_t packets, size_t bytes_moved, bool last = true) -> int {
     ++c->dsync_epoch;  // the host's count (the kernels count for themselves, from the page: see epoch_floor)
     if (!prof_events()) return XMPI_ERR_HIP;
+    a.host_done = last ? done_dev : nullptr;
+    a.done_value = done_id;
     const bool split = a.nseg > 0 && c->dsync_res &&
                        (split_pref >= 0 ? split_pref != 0 : (c->dsync_split_bytes > 0 && bytes_moved >= (size_t)c->dsync_split_bytes));
     if (split) {
@@ -626,6 +632,8 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     }
     ++c->dsync_epoch;
     if (!prof_events()) return fail(XMPI_ERR_HIP);
+    sa.d.host_done = done_dev;
+    sa.d.done_value = done_id;
     XMPI_HIP(launch_dsync_sched(sa, dtype, op, gx, stream, sampled ? pstart : nullptr, sampled ? pstop : nullptr));
     c->dsync_launches++;
     c->dsync_sched_launches++;
@@ -649,7 +657,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
       g.dst_mask = 1u << q;
     }
     traffic = 2 * (size_t)(N - 1) * cb;
-    rc = launch(1, XMPI_U8, XMPI_SUM, cb / 16, 2 * (size_t)(N - 1) * cb);
+    rc = launch(1, XMPI_U8, XMPI_SUM, cb / 16, 2 * (size_t)(N - 1) * cb, /*last=*/false);
     if (rc == XMPI_OK) {  // all operands of chunk `me` are local now: the rank-order fold is an ordinary kernel
       const void* srcs[kMaxRanks];
       for (int p = 0; p < N; p++) srcs[p] = (p == me) ? (const char*)r.send + (size_t)me * cb : (const char*)r.recv + (size_t)p * cb;
@@ -714,7 +722,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
           traffic += 2 * cnt * es;
         }
       }
-      rc = launch(1, XMPI_U8, XMPI_SUM, maxp, traffic);
+      rc = launch(1, XMPI_U8, XMPI_SUM, maxp, traffic, /*last=*/false);
       if (rc == XMPI_OK) {
         memset(a.seg, 0, sizeof a.seg);
         size_t off = 0, cnt = 0;
@@ -755,20 +763,27 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
 
   // blocking call: wait for the stream (polling: the wake-up latency of hipStreamSynchronize is a visible share
   // of a small collective), serving the peers meanwhile
-  hipEvent_t fin = ev_get(c, false);
-  if (!fin) return fail(XMPI_ERR_HIP);
-  XMPI_HIP(hipEventRecord(fin, stream));
   Backoff bo;
   bo.idle = idle_hook;
   bo.idle_arg = c;
-  for (;;) {
-    const hipError_t e = hipEventQuery(fin);
-    if (e == hipSuccess) break;
-    if (e != hipErrorNotReady) return fail(hip_fail(e, "hipEventQuery", __FILE__, __LINE__));
-    (void)hipGetLastError();
-    bo.pause();
+  if (done_dev) {
+    // the closing block of the (last) kernel writes the call's number into a pinned word: no event between the kernel and this
+    // thread.  (The kernel itself gives up on a dead peer -- abort flag, XMPI_TIMEOUT_S -- and still writes the word.)
+    const volatile uint64_t* done = (const volatile uint64_t*)(c->dsync_status + 4);
+    while (__atomic_load_n((const uint64_t*)done, __ATOMIC_ACQUIRE) != done_id) bo.pause();
+  } else {
+    hipEvent_t fin = ev_get(c, false);
+    if (!fin) return fail(XMPI_ERR_HIP);
+    XMPI_HIP(hipEventRecord(fin, stream));
+    for (;;) {
+      const hipError_t e = hipEventQuery(fin);
+      if (e == hipSuccess) break;
+      if (e != hipErrorNotReady) return fail(hip_fail(e, "hipEventQuery", __FILE__, __LINE__));
+      (void)hipGetLastError();
+      bo.pause();
+    }
+    ev_put(c, fin, false);
   }
-  ev_put(c, fin, false);
   if (out_src) {
     XMPI_HIP(hipMemcpyAsync(recvbuf, out_src, recv_bytes, hipMemcpyDefault, stream));
     XMPI_HIP(hipStreamSynchronize(stream));
@@ -776,22 +791,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
   for (void* p : lent) (void)heap_free(p);
   lent.clear();
   if (pstart) c->dsync_prof_pending.push_back({pstart, pstop, traffic});
-  for (size_t i = 0; i < c->dsync_prof_pending.size();) {  // this launch's events and those of enqueued launches that have ended
-    auto& p = c->dsync_prof_pending[i];
-    float ms = 0.f;
-    if (hipEventQuery(p.stop) != hipSuccess || hipEventElapsedTime(&ms, p.start, p.stop) != hipSuccess) {
-      (void)hipGetLastError();
-      i++;
-      continue;
-    }
-    ProfCounter& pc = c->prof[PROF_ZCOPY];
-    pc.launches++;
-    pc.total_ms += ms;
-    pc.bytes += p.bytes;
-    ev_put(c, p.start, true);
-    ev_put(c, p.stop, true);
-    c->dsync_prof_pending.erase(c->dsync_prof_pending.begin() + (long)i);
-  }
+  dsync_prof_harvest(c);
   return dsync_check(c);
 }
 
@@ -937,6 +937,27 @@ int dsync_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, in
   XMPI_HIP(launch_p2p_recv(a, (int)gx, stream));
   c->p2p_pending.push_back({ds, id, {}});
   return XMPI_OK;
+}
+
+// the events of sampled launches that have ended (a launch that was only enqueued leaves them for a later look) go into
+// the profile counters
+void dsync_prof_harvest(xmpi_comm* c) {
+  for (size_t i = 0; i < c->dsync_prof_pending.size();) {
+    auto& p = c->dsync_prof_pending[i];
+    float ms = 0.f;
+    if (hipEventQuery(p.stop) != hipSuccess || hipEventElapsedTime(&ms, p.start, p.stop) != hipSuccess) {
+      (void)hipGetLastError();
+      i++;
+      continue;
+    }
+    ProfCounter& pc = c->prof[PROF_ZCOPY];
+    pc.launches++;
+    pc.total_ms += ms;
+    pc.bytes += p.bytes;
+    ev_put(c, p.start, true);
+    ev_put(c, p.stop, true);
+    c->dsync_prof_pending.erase(c->dsync_prof_pending.begin() + (long)i);
+  }
 }
 
 // the first failure a kernel of this rank reported since the last look (a wait that was cut short, a buffer

@@ -258,6 +258,8 @@ __device__ void dsync_end(const DsyncArgs& a, DsyncShared& sh) {
     st_sys64(&mine->epoch_now, sh.epoch);  // this kernel is over: the next one (an ordinary launch or a graph replay) counts from here
     if (a.host_epoch) st_sys64(a.host_epoch, sh.epoch);
     if (sh.fail != DSYNC_OK && a.status) __hip_atomic_store(a.status, sh.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // the blocking caller's word, last: every rank's stores into this rank's buffers were released before its "done"
+    if (a.host_done) __hip_atomic_store(a.host_done, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 

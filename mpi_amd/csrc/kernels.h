@@ -157,6 +157,8 @@ struct DsyncArgs {
   uint64_t epoch_floor;       // this kernel's epoch = max(page.epoch_now, epoch_floor) + 1: the floor is where the
                               // communicator's epochs start (above what earlier users left in the pooled, uncleared pages)
   uint64_t* host_epoch;       // pinned host word that follows page.epoch_now (what the host gives back to the pool), may be null
+  uint64_t* host_done;        // pinned host word the closing block writes `done_value` into when the collective is over (a blocking
+  uint64_t done_value;        //   call polls it: no event, no stream query between the kernel and the caller); may be null
   uint64_t send_gen, send_off, recv_gen, recv_off;  // what this rank tells its peers
   uint64_t send_slot, recv_slot;
   const void* my_send;

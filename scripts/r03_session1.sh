@@ -16,6 +16,8 @@ T=200 XMPI_BASEPORT=7700 run prod2p $BIN/xmpirun 2 $BIN/allreduce_bench $((16<<2
 T=200 XMPI_BASEPORT=7800 run prod2p256 $BIN/xmpirun 2 $BIN/allreduce_bench $((256<<20)) 20 5 auto fused split ring rhd
 T=200 XMPI_BASEPORT=7400 run overlap256 $BIN/xmpirun 2 scripts/overlap_probe_bin $((256<<20)) 5 3
 T=200 XMPI_BASEPORT=7450 run overlap16 $BIN/xmpirun 2 scripts/overlap_probe_bin $((16<<20)) 8 3
+T=120 XMPI_BASEPORT=7900 run sweep2 $BIN/xmpirun 2 $BIN/coll_sweep $((1<<20)) 200
+T=120 XMPI_BASEPORT=7950 run sweep8 $BIN/xmpirun 8 $BIN/coll_sweep $((1<<20)) 200
 T=600 run bench python bench.py
 cp bench_extras.json $OUT/ 2>/dev/null
 echo done >> $OUT/log.txt
