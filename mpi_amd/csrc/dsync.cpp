@@ -770,7 +770,24 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     // the closing block of the (last) kernel writes the call's number into a pinned word: no event between the kernel and this
     // thread.  (The kernel itself gives up on a dead peer -- abort flag, XMPI_TIMEOUT_S -- and still writes the word.)
     const volatile uint64_t* done = (const volatile uint64_t*)(c->dsync_status + 4);
-    while (__atomic_load_n((const uint64_t*)done, __ATOMIC_ACQUIRE) != done_id) bo.pause();
+    // Safety valve, off the fast path: once the wait is long, ask the stream now and then -- a stream that is idle (or broken)
+    // while the word is still missing must not hang the caller.
+    unsigned spins = 0;
+    while (__atomic_load_n((const uint64_t*)done, __ATOMIC_ACQUIRE) != done_id) {
+      bo.pause();
+      if ((++spins & 0x3fff) == 0) {
+        const hipError_t e = hipStreamQuery(stream);
+        if (e == hipErrorNotReady) {
+          (void)hipGetLastError();
+          continue;
+        }
+        if (e != hipSuccess) return fail(hip_fail(e, "hipStreamQuery", __FILE__, __LINE__));
+        if (__atomic_load_n((const uint64_t*)done, __ATOMIC_ACQUIRE) != done_id) {
+          set_last_error("collective: the stream drained but the closing block never reported (internal)");
+          return fail(XMPI_ERR_STATE);
+        }
+      }
+    }
   } else {
     hipEvent_t fin = ev_get(c, false);
     if (!fin) return fail(XMPI_ERR_HIP);
