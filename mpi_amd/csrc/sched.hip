@@ -485,7 +485,7 @@ __global__ __launch_bounds__(kBlock) void p2p_agent_kernel(P2PAgentArgs a) {
           w1 = ((uint64_t)v[0].w << 32) | v[0].z;
           w2 = ((uint64_t)v[1].y << 32) | v[1].x;
           w3 = ((uint64_t)v[1].w << 32) | v[1].z;
-          have = (w0 & 3u) != 0 && (w0 >> 24) == seq && (w3 >> 32) == (seq & 0xffffffffull);
+          have = (w0 & 3u) != 0 && (w0 >> 24) == (seq & 0xffffffffffull) && (w3 >> 32) == (seq & 0xffffffffull);
           if (have || wall_clock64() - t0 > a.patience_ticks) break;
           __builtin_amdgcn_s_sleep(2);
         }

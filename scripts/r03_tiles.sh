@@ -7,11 +7,11 @@ mkdir -p $O
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0 XMPI_TIMEOUT_S=20
 BIN=$ROOT/mpi_amd/bin
 port=7600
-for bytes in 1048576 4194304 16777216 67108864; do
-  for tiles in 8 4 2 1; do
-    for grid in 0 256; do
+for bytes in ${SIZES:-1048576 4194304 16777216 67108864}; do
+  for tiles in ${TILES:-8 4 2 1}; do
+    for grid in ${GRIDS:-0}; do
       port=$((port + 7))
-      XMPI_DSYNC_TILES=$tiles XMPI_DSYNC_GRID=$grid XMPI_BASEPORT=$port timeout 60 $BIN/xmpirun 8 $BIN/allreduce_bench $bytes 100 10 fused fused2 split \
+      XMPI_DSYNC_TILES=$tiles XMPI_DSYNC_GRID=$grid XMPI_BASEPORT=$port timeout 60 $BIN/xmpirun 8 $BIN/allreduce_bench $bytes 50 10 fused fused2 \
         > $O/b${bytes}_t${tiles}_g${grid}.json 2>> $O/err.txt || echo "rc=$? $bytes $tiles $grid" >> $O/err.txt
     done
   done
