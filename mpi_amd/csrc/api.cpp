@@ -512,6 +512,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   cfg.slot_bytes = (uint64_t)std::max<long>(4096, env_long("XMPI_SLOT_BYTES", 8l << 20)) / 256 * 256;
   cfg.p2p_depth = (int32_t)std::min<long>(16, std::max<long>(2, env_long("XMPI_P2P_DEPTH", 2)));
   cfg.p2p_slot_bytes = (uint64_t)std::max<long>(4096, env_long("XMPI_P2P_SLOT_BYTES", 4l << 20)) / 256 * 256;
+  cfg.host_lane_bytes = env_long("XMPI_HOST_LANES", 1) ? 1 : 0;  // a request: the creator of the block sizes and reserves them
   // Two different clocks.  XMPI_INIT_TIMEOUT_S (default 60) bounds the bootstrap only -- the reference's
   // -mpi-inittimeout (network.go:223-234,307-312).  XMPI_TIMEOUT_S is the no-progress limit of Send / Receive and
   // the collectives afterwards: default 0 = wait for ever, as the reference's blocking calls do (a receiver may
@@ -678,7 +679,10 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   // GPU were time-sliced by the scheduler -- 22 ms per collective instead of 40 us (profiles/r02).
   // the control block as the GPU sees it: kernels read the job's abort flag there and write the ack of a
   // point-to-point message straight into its mail entry (engine.cpp)
-  if (hipHostRegister(ctl->base(), ctl->bytes(), hipHostRegisterMapped) == hipSuccess) {
+  // (with the host lanes behind it, so that a lane's piece is copied to a device destination by DMA; the control
+  // structures alone if the runtime will not pin that much)
+  if (hipHostRegister(ctl->base(), ctl->bytes(), hipHostRegisterMapped) == hipSuccess ||
+      ((void)hipGetLastError(), hipHostRegister(ctl->base(), Ctl::layout_bytes(size), hipHostRegisterMapped) == hipSuccess)) {
     c->ctl_registered = true;
     void* dev = nullptr;
     if (hipHostGetDevicePointer(&dev, ctl->base(), 0) == hipSuccess) c->ctl_dev = (char*)dev;
@@ -1513,6 +1517,8 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
   }
   if (n == "p2p_direct_count") return (long)c->p2p_direct_count;
   if (n == "p2p_staged_count") return (long)c->p2p_staged_count;
+  if (n == "p2p_lane_count") return (long)c->p2p_lane_count;
+  if (n == "host_lane_bytes") return (long)c->ctl->host_lane_bytes();
   if (n == "zc_seq") return (long)c->zc_seq;
   if (n == "zc_fallbacks_unregistered") return (long)c->zc_fallbacks_unregistered;
   if (n == "zc_fallbacks_unmappable") return (long)c->zc_fallbacks_unmappable;

@@ -86,7 +86,7 @@ struct xmpi_comm {
   std::set<std::pair<uint64_t, uint64_t>> zc_announced;  // {base, gen} already published on this communicator
   std::mutex zc_mu;              // guards zc_retired_seen (collectives and p2p calls process the retire logs)
   long p2p_direct_bytes = 1;  // messages from a registered buffer at least this long: the receiver pulls them directly
-  uint64_t p2p_direct_count = 0, p2p_staged_count = 0;  // receives served each way (diagnostic)
+  uint64_t p2p_direct_count = 0, p2p_staged_count = 0, p2p_lane_count = 0;  // receives served each way (diagnostic)
   uint64_t zc_retired_seen[xmpi::kMaxRanks] = {0};      // how far each peer's retire log has been processed
   long oneshot_bytes = 1 << 20;  // direct allreduce up to this size: push everything, fold locally
   long fuse_ring = 1;    // ring: receive-reduce-send / receive-copy-send as one kernel

@@ -78,6 +78,13 @@ size_t Ctl::layout_bytes(int size) {
   return (b + 4095) / 4096 * 4096;
 }
 
+// 32 MiB of lanes per job at most: 256 KiB per entry for 2 ... 4 ranks, 128 KiB for 8, 32 KiB for 16
+size_t Ctl::lane_bytes_for(int size) {
+  size_t per = (size_t)256 << 10;
+  while (per > ((size_t)16 << 10) && per * (size_t)size * size * kMailEntries > ((size_t)32 << 20)) per /= 2;
+  return per;
+}
+
 static std::string shm_name(const std::string& key) {
   std::string n = "/xmpi-" + std::to_string((unsigned)getuid()) + "-";
   for (char c : key) n += (isalnum((unsigned char)c) || c == '-' || c == '_' || c == '.') ? c : '_';
@@ -117,7 +124,9 @@ int Ctl::join(const std::string& key, int rank, int size, const CtlConfig& cfg, 
     return XMPI_ERR_ARG;
   }
   const std::string name = shm_name(key);
-  const size_t bytes = layout_bytes(size);
+  const size_t ctl_bytes = layout_bytes(size);
+  const size_t lanes_total = lane_bytes_for(size) * (size_t)size * size * kMailEntries;
+  const size_t bytes = ctl_bytes + lanes_total;
   const double t0 = now_seconds();
   void* base = nullptr;
   bool creator = false;
@@ -155,13 +164,17 @@ int Ctl::join(const std::string& key, int rank, int size, const CtlConfig& cfg, 
       return XMPI_ERR_BOOTSTRAP;
     }
     base = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
+    const int fd_keep = fd;
     if (base == MAP_FAILED) {
       *err = std::string("mmap: ") + strerror(errno);
+      close(fd);
       shm_unlink(name.c_str());
       return XMPI_ERR_BOOTSTRAP;
     }
-    memset(base, 0, bytes);  // every counter, state and flag starts at zero
+    memset(base, 0, ctl_bytes);  // every counter, state and flag starts at zero (the lanes need no initial value)
+    // the lanes' pages exist before anybody writes to them, or the lanes are not used
+    const bool lanes_ok = cfg.host_lane_bytes != 0 && posix_fallocate(fd_keep, (off_t)ctl_bytes, (off_t)lanes_total) == 0;
+    close(fd_keep);
     CtlHeader* h = new (base) CtlHeader;
     h->version = kCtlVersion;
     h->size = size;
@@ -169,6 +182,7 @@ int Ctl::join(const std::string& key, int rank, int size, const CtlConfig& cfg, 
     h->creator_pid = (int32_t)getpid();
     h->creator_start = proc_start_time(getpid());
     h->cfg = cfg;
+    h->cfg.host_lane_bytes = lanes_ok ? lane_bytes_for(size) : 0;
     h->abort_code.store(0);
     h->bar_count.store(0);
     h->bar_gen.store(0);
@@ -249,6 +263,7 @@ int Ctl::join(const std::string& key, int rank, int size, const CtlConfig& cfg, 
   c->pub_ = reinterpret_cast<PubTable*>(p);
   p += sizeof(PubTable) * (size_t)size;
   c->acked_ = reinterpret_cast<std::atomic<uint64_t>*>(p);
+  c->lanes_ = reinterpret_cast<char*>(base) + ctl_bytes;
 
   RankInfo* me = c->info(rank);
   int32_t unclaimed = 0;

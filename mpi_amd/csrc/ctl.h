@@ -17,8 +17,9 @@ namespace xmpi {
 constexpr int kMaxRanks = 16;
 constexpr int kMaxLanes = 4;
 constexpr int kMailEntries = 4;  // concurrent messages per ordered rank pair
+constexpr int kHostLaneSlots = 4;  // pieces of a host-resident payload in flight per mail entry (the host lanes, below)
 constexpr uint64_t kCtlMagic = 0x584D504943544C31ull;  // "XMPICTL1"
-constexpr uint32_t kCtlVersion = 6;  // layout of the block: bump with every change of the structs below
+constexpr uint32_t kCtlVersion = 7;  // layout of the block: bump with every change of the structs below
 
 struct alignas(64) Counter {
   std::atomic<uint64_t> v;
@@ -48,7 +49,8 @@ enum MailDirect : int32_t {
   DIRECT_NONE = 0,      // through the mail slots of the receiver's window (two copies, pipelined)
   DIRECT_OFFERED = 1,   // the sender's buffer is registered: `src` says where it is
   DIRECT_ACCEPTED = 2,  // the receiver copies straight out of it (one copy, one xGMI crossing)
-  DIRECT_DECLINED = 3,  // the receiver cannot (host destination, mapping failed): sender uses the slots
+  DIRECT_DECLINED = 3,  // the receiver cannot (mapping failed): sender uses the slots
+  DIRECT_HOST = 4,      // the payload is in HOST memory (a Go slice, network.go:518): it travels through the entry's host lane
 };
 
 struct alignas(64) MailEntry {
@@ -123,6 +125,7 @@ struct CtlConfig {
   uint64_t slot_bytes;  // bytes per collective slot
   int32_t p2p_depth;    // slots per mail entry
   uint64_t p2p_slot_bytes;
+  uint64_t host_lane_bytes;  // per mail entry, kHostLaneSlots pieces; 0 = no host lanes (the creator could not reserve them)
 };
 
 struct alignas(64) CtlHeader {
@@ -166,8 +169,16 @@ class Ctl {
   PubTable* published(int r) { return &pub_[r]; }
   // how many of rank `owner`'s published entries rank `reader` has mapped (written by `reader` only)
   std::atomic<uint64_t>* acked(int reader, int owner) { return &acked_[((size_t)reader * size_ + owner) * 8]; }
+  // Host lanes: host-resident payloads (what a Go program hands to Send: slices) travel between the processes of a node
+  // through shared memory -- a ring of kHostLaneSlots pieces per mail entry, after the control structures in the same
+  // segment (reserved with posix_fallocate by the creator: a full /dev/shm disables them, it never faults a writer).
+  size_t host_lane_bytes() const { return hdr_->cfg.host_lane_bytes; }
+  char* host_lane(int src, int dst, int e) {
+    return lanes_ + (((size_t)src * size_ + dst) * kMailEntries + e) * hdr_->cfg.host_lane_bytes;
+  }
+  static size_t lane_bytes_for(int size);  // what a job of `size` ranks asks for per entry
   void* base() const { return base_; }
-  size_t bytes() const { return bytes_; }
+  size_t bytes() const { return bytes_; }  // control structures + host lanes
 
   // all ranks reach `state` (RankInfo.state >= state) or timeout / abort
   int wait_all_state(int state, double timeout_s);
@@ -196,6 +207,7 @@ class Ctl {
   RetireLog* retire_ = nullptr;
   PubTable* pub_ = nullptr;
   std::atomic<uint64_t>* acked_ = nullptr;  // [reader][owner], one cache line each
+  char* lanes_ = nullptr;
   bool creator_ = false;
 };
 

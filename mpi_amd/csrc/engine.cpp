@@ -843,6 +843,62 @@ int p2p_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, i
   m->dtype = dtype;
   m->bytes = bytes;
   m->status.store(XMPI_OK, std::memory_order_relaxed);
+  // A payload in HOST memory -- what the reference's callers pass: Go slices (network.go:518, bounce.go:96) -- travels
+  // through the entry's host lane in the shared segment: the first pieces are in place before the message is posted, the
+  // rest follows as the receiver drains.  (Staging it through both GPUs' HBM took 3 PCIe crossings, a hipMalloc and two
+  // events per message: 40 us one way for 8 bytes -- the reference's loopback TCP takes 8.)
+  const size_t lane_bytes = c->ctl->host_lane_bytes();
+  if (!dev_src && bytes > 0 && lane_bytes > 0) {
+    const size_t piece = lane_bytes / kHostLaneSlots;
+    const uint64_t np = (bytes + piece - 1) / piece;
+    char* lane = c->ctl->host_lane(c->rank, dest, entry);
+    uint64_t filled = 0;
+    auto fill = [&]() {
+      const size_t off = (size_t)filled * piece;
+      memcpy(lane + (size_t)(filled % kHostLaneSlots) * piece, (const char*)buf + off, std::min(piece, bytes - off));
+      filled++;
+    };
+    while (filled < np && filled < (uint64_t)kHostLaneSlots) fill();
+    m->pipe.head.v.store(filled, std::memory_order_relaxed);
+    m->direct.store(DIRECT_HOST, std::memory_order_relaxed);
+    m->state.store(MAIL_POSTED, std::memory_order_release);
+    int rc = XMPI_OK;
+    double tp = now_seconds();
+    bo.n = 0;
+    while (filled < np) {
+      if (filled - m->pipe.tail.v.load(std::memory_order_acquire) < (uint64_t)kHostLaneSlots) {
+        fill();
+        m->pipe.head.v.store(filled, std::memory_order_release);
+        tp = now_seconds();
+        bo.n = 0;
+        continue;
+      }
+      if (m->state.load(std::memory_order_acquire) == MAIL_DONE) break;  // the receiver gave up (truncate ...)
+      if (c->ctl->aborted()) {
+        rc = XMPI_ERR_PEER;
+        break;
+      }
+      if (c->timeout_s > 0 && now_seconds() - tp > (double)c->timeout_s) {
+        if (withdraw(m)) {
+          set_last_error("send to rank " + std::to_string(dest) + " tag " + std::to_string(tag) + ": no matching receive");
+          return XMPI_ERR_TIMEOUT;
+        }
+        tp = now_seconds();
+      }
+      bo.pause();
+    }
+    if (rc != XMPI_OK) {
+      c->ctl->set_abort(rc);
+      return rc;
+    }
+    if (!wait_ack) {
+      std::lock_guard<std::mutex> g(c->p2p_mu);
+      c->pending_sends[{dest, tag}] = m;
+      tg.held = false;
+      return XMPI_OK;
+    }
+    return await_ack(c, m, dest, tag);
+  }
   // A registered source (xmpi_malloc / xmpi_register) is offered to the receiver, which then copies
   // straight out of it: one pass over the data and one xGMI crossing instead of slot-in + slot-out.
   const bool offered = wait_ack && dev_src && c->p2p_direct_bytes >= 0 && bytes >= (size_t)std::max<long>(1, c->p2p_direct_bytes) &&
@@ -1063,9 +1119,64 @@ int p2p_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int 
   const bool dev_dst = bytes == 0 || heap_owns(buf) || is_device_pointer(buf);
   int rc = XMPI_OK;
   double tp = now_seconds();
+  if (m->direct.load(std::memory_order_acquire) == DIRECT_HOST) {
+    // the payload comes through the entry's host lane (p2p_send): a host destination takes it with memcpy, piece by
+    // piece; a device destination by DMA out of the (registered) lane, as many pieces at a time as have arrived
+    const size_t piece = c->ctl->host_lane_bytes() / kHostLaneSlots;
+    const uint64_t np = (bytes + piece - 1) / piece;
+    const char* lane = c->ctl->host_lane(src, c->rank, entry);
+    uint64_t taken = 0;
+    bo.n = 0;
+    while (rc == XMPI_OK && taken < np) {
+      const uint64_t head = m->pipe.head.v.load(std::memory_order_acquire);
+      if (head > taken) {
+        for (uint64_t k = taken; k < head && rc == XMPI_OK; k++) {
+          const size_t off = (size_t)k * piece, n = std::min(piece, bytes - off);
+          const char* from = lane + (size_t)(k % kHostLaneSlots) * piece;
+          if (!dev_dst) memcpy((char*)buf + off, from, n);
+          else if (hipMemcpyAsync((char*)buf + off, from, n, hipMemcpyHostToDevice, lease.s) != hipSuccess)
+            rc = hip_fail(hipGetLastError(), "p2p receive from the host lane", __FILE__, __LINE__);
+        }
+        if (dev_dst && rc == XMPI_OK && hipStreamSynchronize(lease.s) != hipSuccess)
+          rc = hip_fail(hipGetLastError(), "hipStreamSynchronize", __FILE__, __LINE__);
+        taken = head;
+        m->pipe.tail.v.store(taken, std::memory_order_release);
+        tp = now_seconds();
+        bo.n = 0;
+        continue;
+      }
+      if (c->ctl->aborted()) rc = XMPI_ERR_PEER;
+      else if (c->timeout_s > 0 && now_seconds() - tp > (double)c->timeout_s) {
+        set_last_error("receive: sender stalled");
+        rc = XMPI_ERR_TIMEOUT;
+      }
+      bo.pause();
+    }
+    if (rc != XMPI_OK) {
+      c->ctl->set_abort(rc);
+      return rc;
+    }
+    __atomic_fetch_add(&c->p2p_lane_count, 1, __ATOMIC_RELAXED);
+    m->status.store(XMPI_OK, std::memory_order_release);
+    m->state.store(MAIL_DONE, std::memory_order_release);  // the ack (network.go:616-624)
+    return XMPI_OK;
+  }
   if (m->direct.load(std::memory_order_acquire) == DIRECT_OFFERED) {
     // the sender's buffer is registered: copy straight out of it (mapped once per allocation)
     void* from = nullptr;
+    if (!dev_dst && zc_import(c, src, m->src, &from)) {
+      // ... into HOST memory (the caller handed a slice): one copy device -> host, no slots in between
+      m->direct.store(DIRECT_ACCEPTED, std::memory_order_release);
+      if (hipMemcpyAsync(buf, from, bytes, hipMemcpyDeviceToHost, lease.s) != hipSuccess || hipStreamSynchronize(lease.s) != hipSuccess) {
+        rc = hip_fail(hipGetLastError(), "p2p direct copy to the host", __FILE__, __LINE__);
+        c->ctl->set_abort(rc);
+        return rc;
+      }
+      __atomic_fetch_add(&c->p2p_direct_count, 1, __ATOMIC_RELAXED);
+      m->status.store(XMPI_OK, std::memory_order_release);
+      m->state.store(MAIL_DONE, std::memory_order_release);
+      return XMPI_OK;
+    }
     if (dev_dst && zc_import(c, src, m->src, &from)) {
       m->direct.store(DIRECT_ACCEPTED, std::memory_order_release);
       if (c->p2p_kernel_ack && agent_submit(c, buf, from, bytes, m)) {  // the lingering agent took it: no launch at all

@@ -457,6 +457,132 @@ def sc_bounce(comm, args):
         assert comm.get_param("p2p_agent_served") == 0
 
 
+def sc_host_payloads(comm, args):
+    """What the reference's callers hand to Send / Receive is HOST memory (Go slices: bounce.go:96, helloworld.go:58).  Here
+    every mix -- host -> host (the host lanes of the shared segment), host -> device (DMA out of the lane), device -> host
+    (one copy out of the sender's registered HBM), device -> device -- at lengths around the lane's piece and ring sizes,
+    with odd offsets, bit for bit against the oracle's pattern; then truncation, an un-waited send, many tags at once."""
+    import threading
+    rank, size = comm.rank(), comm.size()
+    assert size == 2
+    peer = 1 - rank
+    lane = comm.get_param("host_lane_bytes")
+    lanes_on = lane > 0
+    piece = lane // 4 if lanes_on else 65536
+    lengths = [1, 8, 1000, piece - 1, piece, piece + 1, 4 * piece, 4 * piece + 1, 9 * piece + 5, (1 << 20) + 3, 10_000_000]
+    cap = max(lengths) + 64
+    dev_a, dev_b = comm.alloc(cap), comm.alloc(cap)
+    host_a, host_b = np.zeros(cap, dtype=np.uint8), np.zeros(cap, dtype=np.uint8)
+    lane0, direct0, staged0 = comm.get_param("p2p_lane_count"), comm.get_param("p2p_direct_count"), comm.get_param("p2p_staged_count")
+    n_lane = n_direct = 0
+    tag = 0
+    for src_kind in ("host", "dev"):
+        for dst_kind in ("host", "dev"):
+            for i, n in enumerate(lengths):
+                off = (3 * i) % 16 if src_kind == "host" or dst_kind == "host" else 0  # host spans need no alignment
+                tag += 1
+                want = oracle.fill(n, xmpi.U8, xmpi.PAT_UNIFORM, 100 + tag)
+                if rank == 0:
+                    if src_kind == "host":
+                        host_a[off:off + n] = want
+                        comm.send(host_a[off:off + n], n, xmpi.U8, peer, tag)
+                        host_a[off:off + n] = 0
+                    else:
+                        dev_a.upload(want, 0)
+                        comm.send(dev_a, n, xmpi.U8, peer, tag)
+                else:
+                    if dst_kind == "host":
+                        host_b[:] = 0xEE
+                        got = comm.recv(host_b[off:off + n], n, xmpi.U8, peer, tag)
+                        assert got == n
+                        assert host_b[off:off + n].tobytes() == want.tobytes(), f"{src_kind}->{dst_kind} {n} bytes differ"
+                        assert (off == 0 or host_b[off - 1] == 0xEE) and host_b[off + n] == 0xEE, "wrote outside the destination"
+                    else:
+                        comm.memset(dev_b, 0xEE, cap)
+                        got = comm.recv(dev_b, n, xmpi.U8, peer, tag)
+                        assert got == n
+                        back = dev_b.download(np.uint8, n + 1)
+                        assert back[:n].tobytes() == want.tobytes(), f"{src_kind}->{dst_kind} {n} bytes differ"
+                        assert back[n] == 0xEE, "wrote past the destination"
+                    if src_kind == "host":
+                        n_lane += 1
+                    else:  # a registered source is pulled by the receiver, whatever the destination
+                        n_direct += 1
+    if rank == 1:
+        lanes_used = comm.get_param("p2p_lane_count") - lane0
+        if lanes_on:
+            assert lanes_used == n_lane, (lanes_used, n_lane)
+            assert comm.get_param("p2p_staged_count") == staged0, "nothing went through the HBM slots"
+            assert comm.get_param("p2p_direct_count") - direct0 == n_direct
+        else:
+            assert lanes_used == 0
+    # a message longer than the destination: both sides learn it (the payload, partly in the lane, is dropped)
+    for n, capn in ((100, 10), (6 * piece, 2 * piece)):
+        tag += 1
+        try:
+            if rank == 0:
+                host_a[:n] = 7
+                comm.send(host_a[:n], n, xmpi.U8, peer, tag)
+            else:
+                comm.recv(host_b[:capn], capn, xmpi.U8, peer, tag)
+            raise AssertionError("truncation must be reported on both sides")
+        except xmpi.XmpiError as e:
+            assert e.code == xmpi.ERR_TRUNCATE, e
+    # Send without waiting: a payload that fits the lane's ring has left the caller's slice when the call returns
+    tag += 1
+    k = 3 * piece
+    want = oracle.fill(k, xmpi.U8, xmpi.PAT_UNIFORM, 900)
+    if rank == 0:
+        host_a[:k] = want
+        comm.send_nowait(host_a[:k], k, xmpi.U8, peer, tag)
+        host_a[:k] = 0
+        comm.wait(peer, tag)
+    else:
+        import time
+        time.sleep(0.3)
+        comm.recv(host_b[:k], k, xmpi.U8, peer, tag)
+        assert host_b[:k].tobytes() == want.tobytes()
+    # helloworld's shape: several messages of one pair in flight at once (one mail entry and one lane each), any order
+    errs = []
+
+    def one(t, n):
+        try:
+            w = oracle.fill(n, xmpi.U8, xmpi.PAT_UNIFORM, 1000 + t)
+            if rank == 0:
+                comm.send(w.copy(), n, xmpi.U8, peer, 2000 + t)
+            else:
+                h = np.zeros(n, dtype=np.uint8)
+                comm.recv(h, n, xmpi.U8, peer, 2000 + (3 - t))
+                assert h.tobytes() == oracle.fill(n, xmpi.U8, xmpi.PAT_UNIFORM, 1000 + (3 - t)).tobytes()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    sizes = [5 * piece + 1, 17, piece, 2 * piece + 9]
+    ths = [threading.Thread(target=one, args=(t, sizes[t] if rank == 0 else sizes[3 - t])) for t in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    # the ping-pong of bounce.go with slices: what a round trip costs (reported, not asserted: boxes differ)
+    import time
+    small = np.zeros(8, dtype=np.uint8)
+    for w in range(220):
+        if w == 20:
+            t0 = time.perf_counter()
+        if rank == 0:
+            comm.send(small, 8, xmpi.U8, peer, 5)
+            comm.recv(small, 8, xmpi.U8, peer, 5)
+        else:
+            comm.recv(small, 8, xmpi.U8, peer, 5)
+            comm.send(small, 8, xmpi.U8, peer, 5)
+    if rank == 0:
+        print(f"host slices, 8 bytes, round trip through ctypes: {(time.perf_counter() - t0) / 200 * 1e6:.1f} us (lanes {'on' if lanes_on else 'off'})")
+    dev_a.free()
+    dev_b.free()
+    comm.barrier()
+
+
 def sc_helloworld(comm, args):
     """examples/helloworld/helloworld.go:53-81: every rank concurrently sends a string to every rank
     (itself included) with tag 0 and receives one from every rank."""
@@ -1113,6 +1239,7 @@ SCENARIOS = {
     "allgather": sc_allgather,
     "bcast_reduce": sc_bcast_reduce,
     "bounce": sc_bounce,
+    "host_payloads": sc_host_payloads,
     "helloworld": sc_helloworld,
     "p2p_semantics": sc_p2p_semantics,
     "fullsize": sc_fullsize,

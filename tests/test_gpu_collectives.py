@@ -129,6 +129,14 @@ def test_bounce_without_the_receive_agent():
     run_ranks("p2p_semantics", 2, timeout=300, env={"XMPI_P2P_SLOT_BYTES": "65536", "XMPI_P2P_AGENT_US": "0"})
 
 
+def test_host_payloads():
+    """Go slices on either side of Send / Receive: the host lanes of the shared segment, DMA out of a lane, one copy out of
+    the sender's HBM -- every mix, around the lane's piece and ring sizes; and the same with the lanes switched off (staged
+    through the HBM slots)"""
+    run_ranks("host_payloads", 2, timeout=600)
+    run_ranks("host_payloads", 2, timeout=600, env={"XMPI_HOST_LANES": "0"})
+
+
 def test_bounce_threads():
     """ranks as threads of one process: the receiver reads the sender's buffer through its own pointer"""
     run_threads("bounce", 2)
