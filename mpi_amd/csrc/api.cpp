@@ -688,8 +688,9 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
     if (hipHostGetDevicePointer(&dev, ctl->base(), 0) == hipSuccess) c->ctl_dev = (char*)dev;
   }
   (void)hipGetLastError();
-  if (hipMalloc((void**)&c->p2p_tickets, xmpi_comm::kP2PDoneSlots * sizeof(uint32_t)) == hipSuccess)
-    (void)hipMemsetAsync(c->p2p_tickets, 0, xmpi_comm::kP2PDoneSlots * sizeof(uint32_t), c->local_stream);
+  // (two more for the copy kernels that carry a host slice into / out of a collective's stand-in, dsync.cpp)
+  if (hipMalloc((void**)&c->p2p_tickets, (xmpi_comm::kP2PDoneSlots + 2) * sizeof(uint32_t)) == hipSuccess)
+    (void)hipMemsetAsync(c->p2p_tickets, 0, (xmpi_comm::kP2PDoneSlots + 2) * sizeof(uint32_t), c->local_stream);
   else c->p2p_tickets = nullptr;
   (void)hipGetLastError();
   // completion words the GPU writes and a host thread polls (stream-ordered Send / Receive: slots 0..63; the pull kernels
@@ -1518,6 +1519,7 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
   if (n == "p2p_direct_count") return (long)c->p2p_direct_count;
   if (n == "p2p_staged_count") return (long)c->p2p_staged_count;
   if (n == "p2p_lane_count") return (long)c->p2p_lane_count;
+  if (n == "host_bounce_calls") return (long)c->host_bounce_calls;
   if (n == "host_lane_bytes") return (long)c->ctl->host_lane_bytes();
   if (n == "zc_seq") return (long)c->zc_seq;
   if (n == "zc_fallbacks_unregistered") return (long)c->zc_fallbacks_unregistered;

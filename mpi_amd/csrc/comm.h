@@ -138,6 +138,12 @@ struct xmpi_comm {
     std::vector<void*> bufs;  // stand-ins to give back
   };
   std::vector<P2PPending> p2p_pending;  // stream-ordered operations whose completion nobody has looked at yet
+  // host slices in a blocking collective (dsync.cpp): pinned memory the GPU reads / writes directly -- [0, kHostBounce) on the
+  // way in, [kHostBounce, 2 kHostBounce) on the way out; allocated when the first such call comes
+  static constexpr size_t kHostBounce = 256u << 10;
+  char* host_bounce = nullptr;
+  char* host_bounce_dev = nullptr;
+  uint64_t host_bounce_calls = 0;
   uint32_t* p2p_tickets = nullptr;      // device: block counters of the pull kernels (blocking Receive), one per done slot
   // the library's own schedule table (xmpi_tune): algorithm per collective and size class, agreed by all ranks
   static constexpr int kTuneClasses = 24;  // class k: messages of [2^(k+8), 2^(k+9)) bytes per rank

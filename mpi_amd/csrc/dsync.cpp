@@ -183,6 +183,8 @@ void dsync_finalize(xmpi_comm* c) {
   c->dsync_prof_pending.clear();
   for (int p = 0; p < c->size; p++)
     if (c->peer_page_opened[p]) ipc_close_shared(c->peer_page[p]);
+  if (c->host_bounce_dev) (void)hipHostFree(c->host_bounce);
+  c->host_bounce = c->host_bounce_dev = nullptr;
   if (c->dsync_status) (void)hipHostFree(c->dsync_status);
   c->dsync_status = nullptr;
   if (c->dsync_res) (void)hipFree(c->dsync_res);
@@ -366,6 +368,43 @@ struct Resolved {
 
 }  // namespace
 
+// pinned memory for the host slices of blocking collectives; false = not available (the runtime's own staged copies serve)
+static bool host_bounce_ready(xmpi_comm* c) {
+  if (c->host_bounce_dev) return true;
+  if (c->host_bounce) return false;  // tried before
+  void* p = nullptr;
+  if (hipHostMalloc(&p, 2 * xmpi_comm::kHostBounce, hipHostMallocMapped) != hipSuccess) {
+    (void)hipGetLastError();
+    c->host_bounce = reinterpret_cast<char*>(1);  // remember the failure
+    return false;
+  }
+  void* dev = nullptr;
+  if (hipHostGetDevicePointer(&dev, p, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipHostFree(p);
+    c->host_bounce = reinterpret_cast<char*>(1);
+    return false;
+  }
+  c->host_bounce = (char*)p;
+  c->host_bounce_dev = (char*)dev;
+  return true;
+}
+
+// one launch of the copy-and-flag kernel (sched.hip p2p_pull_kernel) between a stand-in and the pinned memory above
+static hipError_t bounce_copy(xmpi_comm* c, void* dst, const void* src, size_t bytes, int which, uint64_t* done, uint64_t done_value,
+                              hipStream_t s) {
+  P2PPullArgs pa;
+  memset(&pa, 0, sizeof pa);
+  pa.dst = dst;
+  pa.src = src;
+  pa.bytes = bytes;
+  pa.ticket = c->p2p_tickets + xmpi_comm::kP2PDoneSlots + which;
+  pa.host_done = done;
+  pa.done_value = done_value;
+  const long gx = std::max<long>(1, std::min<long>(16, (long)((bytes + 16383) >> 14)));
+  return launch_p2p_pull(pa, (int)gx, s);
+}
+
 bool dsync_usable(const xmpi_comm* c) { return c->dsync_ok && c->dsync && c->size > 1; }
 
 // blocks a kernel of this rank may keep waiting at once: the kernels of all ranks on one GPU spin together, so with
@@ -479,8 +518,17 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     r.tmp_send = heap_alloc(c->device, send_bytes);
     if (!r.tmp_send) return fail(XMPI_ERR_NOMEM);
     lent.push_back(r.tmp_send);
-    if (coll != COLL_BCAST || me == root)
-      XMPI_HIP(hipMemcpyAsync(r.tmp_send, sendbuf, send_bytes, hipMemcpyDefault, stream));
+    if (coll != COLL_BCAST || me == root) {
+      // a host slice of a blocking call goes in through pinned memory the GPU reads itself (memcpy + one small kernel in
+      // stream order) -- the runtime's copy out of pageable memory is a staged, synchronous affair of 10 us and more
+      if (blocking && send_bytes <= xmpi_comm::kHostBounce && c->p2p_tickets && !is_device_pointer(sendbuf) && host_bounce_ready(c)) {
+        memcpy(c->host_bounce, sendbuf, send_bytes);
+        XMPI_HIP(bounce_copy(c, r.tmp_send, c->host_bounce_dev, send_bytes, 0, nullptr, 0, stream));
+        c->host_bounce_calls++;
+      } else {
+        XMPI_HIP(hipMemcpyAsync(r.tmp_send, sendbuf, send_bytes, hipMemcpyDefault, stream));
+      }
+    }
     r.send = r.tmp_send;
     if (!zc_export(c, r.send, send_bytes, &r.sref)) return fail(XMPI_ERR_HIP);
     c->dsync_bounced++;
@@ -497,6 +545,14 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     if (!zc_export(c, r.recv, recv_bytes, &r.rref)) return fail(XMPI_ERR_HIP);
     c->dsync_bounced++;
   }
+
+  // where the result of a stand-in goes home from (step 4), and how: a host slice of a blocking call comes out through pinned
+  // memory -- one more small kernel in stream order copies the stand-in there and THEN writes the completion word
+  const void* out_src = r.tmp_recv ? r.tmp_recv
+                        : (r.tmp_send && recv_significant && (in_place || coll == COLL_BCAST) && coll != COLL_ALLGATHER) ? r.tmp_send
+                                                                                                                          : nullptr;
+  const bool host_out = blocking && out_src && recv_bytes <= xmpi_comm::kHostBounce && c->p2p_tickets && c->dsync_status_dev &&
+                        !is_device_pointer(recvbuf) && host_bounce_ready(c);
 
   // 2. the peers know the allocations
   int sslot = 0, rslot = 0;
@@ -544,6 +600,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
   // not from an event: set on the LAST kernel of the collective only (below)
   const uint64_t done_id = ++c->dsync_done_seq;
   uint64_t* const done_dev = (blocking && c->dsync_status_dev) ? (uint64_t*)(c->dsync_status_dev + 4) : nullptr;
+  uint64_t* const done_k = host_out ? nullptr : done_dev;  // (host_out: the copy-out kernel behind the collective writes it)
   a.my_send = r.send;
   a.my_recv = r.recv;
   a.abort_word = c->dsync_abort_dev;
@@ -569,7 +626,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
   auto launch = [&](int nsrc, int kdtype, int kop, size_t packets, size_t bytes_moved, bool last = true) -> int {
     ++c->dsync_epoch;  // the host's count (the kernels count for themselves, from the page: see epoch_floor)
     if (!prof_events()) return XMPI_ERR_HIP;
-    a.host_done = last ? done_dev : nullptr;
+    a.host_done = last ? done_k : nullptr;
     a.done_value = done_id;
     const bool split = a.nseg > 0 && c->dsync_res &&
                        (split_pref >= 0 ? split_pref != 0 : (c->dsync_split_bytes > 0 && bytes_moved >= (size_t)c->dsync_split_bytes));
@@ -636,7 +693,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     }
     ++c->dsync_epoch;
     if (!prof_events()) return fail(XMPI_ERR_HIP);
-    sa.d.host_done = done_dev;
+    sa.d.host_done = done_k;
     sa.d.done_value = done_id;
     XMPI_HIP(launch_dsync_sched(sa, dtype, op, gx, stream, sampled ? pstart : nullptr, sampled ? pstop : nullptr));
     c->dsync_launches++;
@@ -744,14 +801,16 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
   if (rc != XMPI_OK) return fail(rc);
   if (!capturing) c->dsync_last_stream = stream;
 
+  if (host_out) {
+    XMPI_HIP(bounce_copy(c, c->host_bounce_dev + xmpi_comm::kHostBounce, out_src, recv_bytes, 1, done_dev, done_id, stream));
+    c->host_bounce_calls++;
+  }
+
   // 4. results of a stand-in go home; stand-ins go back to the arena when the stream has passed them.
   //    (A copy into pageable host memory blocks the calling thread until the kernel before it has ended -- and the
   //    kernel ends only when every peer has arrived, which a peer may be unable to do before THIS rank has mapped a
   //    buffer it just registered.  So a blocking call copies out after its polling wait below, which serves the
   //    peers; the stream-ordered forms take device memory only, where the copy really is asynchronous.)
-  const void* out_src = r.tmp_recv ? r.tmp_recv
-                        : (r.tmp_send && recv_significant && (in_place || coll == COLL_BCAST) && coll != COLL_ALLGATHER) ? r.tmp_send
-                                                                                                                          : nullptr;
   if (!blocking) {
     if (pstart) c->dsync_prof_pending.push_back({pstart, pstop, traffic});
     if (out_src) XMPI_HIP(hipMemcpyAsync(recvbuf, out_src, recv_bytes, hipMemcpyDeviceToDevice, stream));
@@ -805,7 +864,9 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     }
     ev_put(c, fin, false);
   }
-  if (out_src) {
+  if (host_out) {
+    memcpy(recvbuf, c->host_bounce + xmpi_comm::kHostBounce, recv_bytes);
+  } else if (out_src) {
     XMPI_HIP(hipMemcpyAsync(recvbuf, out_src, recv_bytes, hipMemcpyDefault, stream));
     XMPI_HIP(hipStreamSynchronize(stream));
   }

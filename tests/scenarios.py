@@ -578,6 +578,39 @@ def sc_host_payloads(comm, args):
             comm.send(small, 8, xmpi.U8, peer, 5)
     if rank == 0:
         print(f"host slices, 8 bytes, round trip through ctypes: {(time.perf_counter() - t0) / 200 * 1e6:.1f} us (lanes {'on' if lanes_on else 'off'})")
+    # ... and an allreduce of slices (collectives.go hands them to xmpi_allreduce as they are: stand-ins in HBM, the fold on the GPU)
+    hb0 = comm.get_param("host_bounce_calls")
+    for n in (2, 256, 65536, 65537, 262144):
+        x = oracle.fill(n, xmpi.F32, xmpi.PAT_SIGNED, 40 + rank)
+        out = np.zeros(n, dtype=np.float32)
+        comm.allreduce(x, out, n, xmpi.F32, xmpi.SUM, xmpi.ALGO_AUTO)
+        want = oracle.reduce_ranks([oracle.fill(n, xmpi.F32, xmpi.PAT_SIGNED, 40 + r) for r in range(size)], xmpi.F32, xmpi.SUM)
+        assert out.tobytes() == want.tobytes(), f"allreduce of host slices, {n} elements"
+        t0 = time.perf_counter()
+        for _ in range(50):
+            comm.allreduce(x, out, n, xmpi.F32, xmpi.SUM, xmpi.ALGO_AUTO)
+        if rank == 0:
+            print(f"allreduce of host slices, {n * 4} bytes: {(time.perf_counter() - t0) / 50 * 1e6:.1f} us per call")
+    if comm.get_param("dsync") == 1:  # up to 256 KiB a slice goes in and comes out through pinned memory the GPU touches itself
+        assert comm.get_param("host_bounce_calls") - hb0 == 3 * 51 * 2, comm.get_param("host_bounce_calls") - hb0
+    # in place, a reduce to one root, a broadcast, an allgather of slices
+    x = oracle.fill(1000, xmpi.I64, xmpi.PAT_SIGNED, 70 + rank)
+    ins = [oracle.fill(1000, xmpi.I64, xmpi.PAT_SIGNED, 70 + r) for r in range(size)]
+    y = x.copy()
+    comm.allreduce(y, y, 1000, xmpi.I64, xmpi.SUM, xmpi.ALGO_AUTO)
+    assert y.tobytes() == oracle.reduce_ranks(ins, xmpi.I64, xmpi.SUM).tobytes()
+    out = np.zeros(1000, dtype=np.int64)
+    comm.reduce(x, out, 1000, xmpi.I64, xmpi.MAX, 1)
+    if rank == 1:
+        assert out.tobytes() == oracle.reduce_ranks(ins, xmpi.I64, xmpi.MAX).tobytes()
+    else:
+        assert not out.any(), "a rank that is not the root keeps its receive slice"
+    b = ins[1].copy() if rank == 1 else np.zeros(1000, dtype=np.int64)
+    comm.bcast(b, 1000, xmpi.I64, 1)
+    assert b.tobytes() == ins[1].tobytes()
+    g = np.zeros(1000 * size, dtype=np.int64)
+    comm.allgather(x, g, 1000, xmpi.I64)
+    assert g.tobytes() == np.concatenate(ins).tobytes()
     dev_a.free()
     dev_b.free()
     comm.barrier()
