@@ -466,6 +466,26 @@ def rank_main(job: Job, grank: int):
                     rt = (time.perf_counter() - t0) / reps
                     sweep_b.append({"bytes": length, "round_trip_us": rt * 1e6, "GBps": 2 * length / rt / 1e9})
                 extras["bounce_sweep_u8"] = sweep_b
+                # the same with HOST slices on both sides -- what bounce.go itself passes (bounce.go:96) -- through the host lanes
+                # of the job's shared segment (never `value`: no HBM in it)
+                hs, hr = np.arange(10**7, dtype=np.uint8), np.zeros(10**7, dtype=np.uint8)
+                sweep_h = []
+                for length in (1, 10, 100, 1000, 10**4, 10**5, 10**6, 10**7):
+                    reps = 10
+                    for w in range(2 + reps):
+                        if w == 2:
+                            t0 = time.perf_counter()
+                        if grank == 0:
+                            comm.send(hs[:length], length, xmpi.U8, peer, 6)
+                            comm.recv(hr[:length], length, xmpi.U8, peer, 6)
+                        else:
+                            comm.recv(hr[:length], length, xmpi.U8, peer, 6)
+                            comm.send(hr[:length], length, xmpi.U8, peer, 6)
+                    rt = (time.perf_counter() - t0) / reps
+                    sweep_h.append({"bytes": length, "round_trip_us": rt * 1e6, "GBps": 2 * length / rt / 1e9})
+                if grank == 0 and not np.array_equal(hs, hr):
+                    parity_failures.append("bounce of host slices: echo differs")
+                extras["bounce_sweep_u8_host_slices"] = sweep_h
             comm.barrier()
             # BASELINE cfg 5: allreduce-sum fp16 up to 1 GiB per rank, recursive halving vs ring (and the library's own
             # choice) over sizes 1 MiB ... 1 GiB; exactly summable inputs k/64: every schedule must be bit-identical to

@@ -43,6 +43,13 @@ XMPI_BASEPORT=7550 timeout 200 $BIN/xmpirun 4 $BIN/cfg3_allgather 2097152 20 > $
 for n in 2 4; do XMPI_BASEPORT=7600 timeout 200 $BIN/xmpirun $n $BIN/allreduce_bench 268435456 20 5 auto fused split ring rhd > $O/prod_${n}proc_256MiB.json 2>> $O/prod.err; done
 XMPI_BASEPORT=7700 timeout 200 $BIN/xmpirun 8 $BIN/allreduce_bench 16777216 50 5 auto fused split ring rhd > $O/prod_8proc_16MiB.json 2>> $O/prod.err
 XMPI_BASEPORT=7800 timeout 200 $BIN/xmpirun 8 $BIN/allreduce_bench 1048576 200 10 auto fused split ring rhd > $O/prod_8proc_1MiB.json 2>> $O/prod.err
+# Send / Receive in the reference's own loop shape (examples/bounce.cpp = bounce.go): buffers in HBM, Go-style host slices
+# (host lanes of the shared segment; XMPI_HOST_LANES=0: staged through both GPUs), the reference's TCP + gob protocol
+for v in "" "--host" "--tcp"; do XMPI_BASEPORT=8100 timeout 100 $BIN/xmpirun 2 $BIN/bounce $v --repeats 50 > "$O/bounce_example${v#-}.txt" 2>> $O/prod.err; done
+XMPI_HOST_LANES=0 XMPI_BASEPORT=8150 timeout 100 $BIN/xmpirun 2 $BIN/bounce --host --repeats 50 > $O/bounce_example-host_staged_through_hbm.txt 2>> $O/prod.err
+# blocking vs enqueued collectives, 1 KiB ... 1 MiB (completion word instead of an event)
+XMPI_BASEPORT=8200 timeout 100 $BIN/xmpirun 2 $BIN/coll_sweep 1048576 200 > $O/coll_sweep_2proc.json 2>> $O/prod.err
+XMPI_BASEPORT=8250 timeout 100 $BIN/xmpirun 8 $BIN/coll_sweep 1048576 200 > $O/coll_sweep_8proc.json 2>> $O/prod.err
 cd $GRAFT_REPO_ROOT
 python scripts/pmc_summary.py $O/fetch_n1 $O/write_n1 reduce_n_multi > $O/pmc_bench_zcopy.json
 python scripts/pmc_summary.py $O/fetch_prod $O/write_prod dsync_ > $O/pmc_prod.json 2>> $O/prod.err
