@@ -13,7 +13,8 @@
  *   - calls are blocking (reference: mpi.go:47-48) except xmpi_send_nowait and the xmpi_i*
  *     collectives, and may be made from any OS thread (cgo moves goroutines between threads; each
  *     entry point re-selects the comm's device);
- *   - buffers may be device pointers (HBM, the hot path) or host pointers (staged by HIP);
+ *   - buffers may be device pointers (HBM, the hot path) or host pointers (Go slices: Send / Receive carry them through the
+ *     job's shared segment, collectives stand a registered HBM block in for them);
  *   - one communicator == one rank == one process == one MI355X.
  */
 #ifndef XMPI_H
@@ -139,9 +140,11 @@ int xmpi_sync(xmpi_comm* comm);
  * (network.go:545-548) when a concurrent xmpi_recv is posted from another thread.
  * A non-empty message from a registered buffer (xmpi_malloc / xmpi_register; p2p_direct_bytes = 1 is
  * the smallest such message, < 0 turns this off) is not pushed at all: the matching receive copies it
- * straight out of the sender's HBM (one pass, one xGMI crossing).  Host buffers and unregistered
- * device memory travel through the mail slots of the receiver's window (slot-in by the sender,
- * slot-out by the receiver).  That copy is one kernel whose last block writes both acknowledgements itself, and which stays for
+ * straight out of the sender's HBM (one pass, one xGMI crossing).  Unregistered
+ * device memory travels through the mail slots of the receiver's window (slot-in by the sender,
+ * slot-out by the receiver); a payload in HOST memory (network.go:518 takes Go values) through the entry's host lane in the
+ * shared segment (XMPI_HOST_LANES=0: staged through HBM like unregistered device memory) -- 1 us per direction for a small
+ * slice, and into a device destination by DMA out of the lane.  That copy is one kernel whose last block writes both acknowledgements itself, and which stays for
  * p2p_agent_us (XMPI_P2P_AGENT_US, default 40; 0 = one launch per message) after a message to take the next one from a command
  * record in pinned host memory instead of being launched again: between two processes a small message takes 4.5-5 us per
  * direction.  Nothing on the GPU ever waits for a peer on this path. */

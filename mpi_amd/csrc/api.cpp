@@ -1808,24 +1808,31 @@ int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
       if (per_rank < 16) continue;
       const int iters = bytes <= ((size_t)1 << 20) ? 20 : (bytes <= ((size_t)32 << 20) ? 6 : 3);
       std::vector<double> us(cands.size(), 0.0), worst(cands.size(), 0.0);
-      for (size_t k = 0; k < cands.size() && rc == XMPI_OK; k++) {
-        const Cand& cd = cands[k];
-        if (coll == COLL_ALLGATHER && (cd.algo == XMPI_ALGO_ZPUSH || cd.algo == XMPI_ALGO_RHD || cd.unroll != u0)) continue;
-        if (k > 0 && !((c->tune_mask >> k) & 1)) continue;  // a schedule the caller has ruled out on this machine (never the default)
-        rc = xmpi_barrier(c);
-        if (rc != XMPI_OK) break;
-        std::lock_guard<std::mutex> g(c->coll_mu);
-        c->dsync_split_bytes = cd.split ? 1 : 0;
-        c->dsync_unroll = cd.unroll;
-        double t0 = 0;
-        for (int i = -1; i < iters && rc == XMPI_OK; i++) {  // i = -1: a warm-up that also maps whatever is new
-          if (i == 0) t0 = now_seconds();
-          rc = dsync_collective(c, coll, 0, send, recv, per_rank / 4, XMPI_F32, XMPI_SUM, c->local_stream,
-                                /*blocking=*/i == -1 || i == iters - 1, cd.algo);
+      // few iterations fit a large message into a tuning budget, and a few iterations are noisy (eight processes on one GPU:
+      // +-6 % between two runs of one schedule): large sizes are measured twice, the candidates interleaved, and the better
+      // figure of each counts
+      const int rounds = bytes > ((size_t)1 << 20) ? 2 : 1;
+      for (int round = 0; round < rounds && rc == XMPI_OK; round++) {
+        for (size_t k = 0; k < cands.size() && rc == XMPI_OK; k++) {
+          const Cand& cd = cands[k];
+          if (coll == COLL_ALLGATHER && (cd.algo == XMPI_ALGO_ZPUSH || cd.algo == XMPI_ALGO_RHD || cd.unroll != u0)) continue;
+          if (k > 0 && !((c->tune_mask >> k) & 1)) continue;  // a schedule the caller has ruled out on this machine (never the default)
+          rc = xmpi_barrier(c);
+          if (rc != XMPI_OK) break;
+          std::lock_guard<std::mutex> g(c->coll_mu);
+          c->dsync_split_bytes = cd.split ? 1 : 0;
+          c->dsync_unroll = cd.unroll;
+          double t0 = 0;
+          for (int i = -1; i < iters && rc == XMPI_OK; i++) {  // i = -1: a warm-up that also maps whatever is new
+            if (i == 0) t0 = now_seconds();
+            rc = dsync_collective(c, coll, 0, send, recv, per_rank / 4, XMPI_F32, XMPI_SUM, c->local_stream,
+                                  /*blocking=*/i == -1 || i == iters - 1, cd.algo);
+          }
+          const double t_us = (now_seconds() - t0) / iters * 1e6;
+          us[k] = round == 0 ? t_us : std::min(us[k], t_us);
+          c->dsync_split_bytes = keep_split;
+          c->dsync_unroll = keep_unroll;
         }
-        us[k] = (now_seconds() - t0) / iters * 1e6;
-        c->dsync_split_bytes = keep_split;
-        c->dsync_unroll = keep_unroll;
       }
       if (rc != XMPI_OK) break;
       // every rank must read the same figures: the slowest rank's

@@ -414,9 +414,9 @@ static long dsync_block_cap(const xmpi_comm* c) {
   // (a rank alone on its GPU keeps to half of the chip too: while its blocks wait for a late peer the caller's other streams
   // still find wave slots -- scripts/overlap_probe.hip: a full-chip compute kernel next to a waiting 1024-block collective
   // runs 5 % slower, next to the meet / body / done form 1.5 %)
-  // Eight processes on one GPU: 64 blocks per rank beat 128 (64 MiB: 348 vs 422 us, 256 MiB: 0.99 vs 1.05 ms; 32: 1.2 ms;
-  // 256 = every wave slot of the chip: the kernels wait for each other for ever) -- scripts/r03_tiles.sh, r03 session 9.
-  return (c->dsync_sharers >= 4 ? 512 : 1024) / std::max(1, c->dsync_sharers);
+  // (Eight processes on one GPU, 64 instead of 128 blocks per rank: 6 % faster at 256 MiB on one box, 12 % slower on the next --
+  // scripts/r03_tiles.sh; XMPI_DSYNC_GRID=256 per rank = every wave slot of the chip: the kernels wait for each other for ever.)
+  return 1024 / std::max(1, c->dsync_sharers);
 }
 
 int dsync_grid(const xmpi_comm* c, size_t packets_per_segment, int nseg, int unroll) {
@@ -679,9 +679,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
       traffic = me == root ? 0 : 2 * send_bytes;
     }
     const size_t tiles = std::max<size_t>(1, (step_bytes + kSchedTileBytes - 1) / kSchedTileBytes);
-    // (the stepped kernels keep 1024 waiting blocks per GPU: their figures were taken with that)
-    const long sched_cap = c->dsync_grid_cap > 0 ? c->dsync_grid_cap : 1024 / std::max(1, c->dsync_sharers);
-    long workers = c->sched_grid > 0 ? c->sched_grid : (long)std::min<size_t>(tiles, (size_t)sched_cap);
+    long workers = c->sched_grid > 0 ? c->sched_grid : (long)std::min<size_t>(tiles, (size_t)dsync_block_cap(c));
     workers = std::max<long>(1, std::min<long>(workers, kStepSlots));
     nchan = (int)std::max<long>(1, std::min<long>(nchan, workers));
     const int gx = (int)std::max<long>(1, workers / nchan);
