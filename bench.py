@@ -202,6 +202,8 @@ def rank_main(job: Job, grank: int):
         comm.set_param("zero_copy", 0)
     ZC = (xmpi.ALGO_ZCOPY,) if zc_ok else ()
     send, recv = comm.alloc(nbytes), comm.alloc(nbytes)
+    if os.environ.get("XMPI_BENCH_DEBUG"):
+        print(f"[bench] rank {grank}: send {send.ptr:#x} (4 KiB slot {(send.ptr >> 12) & 15}) recv {recv.ptr:#x} (slot {(recv.ptr >> 12) & 15})", file=sys.stderr)
     comm.fill(send, count, dtype, xmpi.PAT_UNIFORM, seed0 + grank)
     comm.memset(recv, 0, nbytes)
 

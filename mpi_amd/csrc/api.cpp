@@ -733,6 +733,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
     set_last_error("xmpi_init: barrier failed");
     return fail(rc);
   }
+  heap_colour_seed(rank);
   heap_comm_created();
   // XMPI_AUTOTUNE_BYTES=N: the library times its schedules for messages up to N bytes right here (xmpi_tune), so that a
   // program that knows nothing about tuning gets the schedule a benchmark would pick on this node; every rank sees the

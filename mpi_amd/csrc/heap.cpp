@@ -43,14 +43,38 @@ size_t env_size(const char* name, size_t dflt) {
   return (end && end != v && x > 0) ? (size_t)x : dflt;
 }
 
-void* take(Arena* a, size_t need) {
+// Large blocks are COLOURED: block number n of the process starts at an address whose bits 12..15 are bitrev4(n mod 16), i.e.
+// in its own 4 KiB slot of a 64 KiB frame, consecutive blocks as far apart as the frame allows.  A fold kernel streams through
+// all ranks' send and receive buffers at the same index at the same time; buffers whose addresses are equal modulo a large
+// power of two -- which is where an allocator that packs 256 MiB blocks into 1 GiB arenas puts them -- meet in the same
+// HBM banks, each alternating between 16 rows.  Measured (scripts/placement_probe.py, placement_patterns.py: reduce_n_multi
+// over 8 + 8 buffers of 256 MiB): stride 256 MiB exactly 836-853 us; + k x 4 KiB 754-768; + k x 8 / 16 / 32 / 64 KiB or 1 MiB
+// 815-850 (bit 12 the same everywhere); the bit-reversed slots 749-752 whichever 8 of the 16 are the sources.  The skipped
+// prefix (< 128 KiB) stays an ordinary free block.  (heap_colour_seed: ranks in different processes would start the count at
+// 2 x rank -- a rank's send and receive buffer slots 8 apart, the ranks' pairs the rest -- if colouring is forced on there.)
+constexpr size_t kColourMin = (size_t)1 << 20, kColourFrame = (size_t)64 << 10, kColourSlot = 4096;
+uint64_t g_colour_next = 0;
+
+int colour_slot(uint64_t n) {
+  const unsigned k = (unsigned)(n & 15);
+  return (int)(((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | ((k & 8) >> 3));
+}
+
+// slot < 0: the block starts where the free range starts
+void* take(Arena* a, size_t need, int slot) {
   for (auto it = a->free_blocks.begin(); it != a->free_blocks.end(); ++it) {
-    if (it->second < need) continue;
     const size_t off = it->first, len = it->second;
+    size_t start = off;
+    if (slot >= 0) {  // by absolute address (an arena's base is 2 MiB aligned in practice, but nothing promises it)
+      const uintptr_t abs0 = ((uintptr_t)a->base + off + kColourFrame - 1) / kColourFrame * kColourFrame + (uintptr_t)slot * kColourSlot;
+      start = (size_t)(abs0 - (uintptr_t)a->base);
+    }
+    if (start + need > off + len) continue;
     a->free_blocks.erase(it);
-    if (len > need) a->free_blocks[off + need] = len - need;
-    a->used_blocks[off] = need;
-    return a->base + off;
+    if (start > off) a->free_blocks[off] = start - off;
+    if (off + len > start + need) a->free_blocks[start + need] = off + len - start - need;
+    a->used_blocks[start] = need;
+    return a->base + start;
   }
   return nullptr;
 }
@@ -81,20 +105,34 @@ void heap_comm_destroyed(xmpi_comm* c) {
   g_next_arena = 0;
 }
 
+// the first communicator of the process says which rank lives here: ranks in different processes take different colours
+void heap_colour_seed(int rank) {
+  std::lock_guard<std::mutex> g(g_heap_mu);
+  if (g_live_comms == 0) g_colour_next = 2 * (uint64_t)std::max(0, rank);
+}
+
 void* heap_alloc(int device, size_t bytes) {
   const size_t need = (std::max<size_t>(bytes, 1) + kGranule - 1) / kGranule * kGranule;
   std::lock_guard<std::mutex> g(g_heap_mu);
+  // Where it is on: a heap that serves SEVERAL ranks (threads of one process on one GPU: all buffers of a fold are blocks of
+  // this heap, 256 MiB apart -- N = 1 line: kernel 838 / 850 / 721 us without, 703 / 703 / 755 with, same box, interleaved).  With
+  // one process per rank the same A/B was inside the noise or against it (8 processes on one GPU: +3 ... +9 %, r03 session 12),
+  // so there the blocks stay where they were measured.  XMPI_HEAP_COLOUR=1 / 0 forces it.
+  static const int forced = getenv("XMPI_HEAP_COLOUR") ? atoi(getenv("XMPI_HEAP_COLOUR")) : -1;
+  const bool coloured = forced >= 0 ? forced != 0 : g_live_comms > 1;
+  const int slot = (coloured && need >= kColourMin) ? colour_slot(g_colour_next++) : -1;
+  const size_t colour = slot < 0 ? 0 : kColourFrame + (size_t)slot * kColourSlot;  // room the placement may take
   for (Arena* a : g_arenas)
     if (a->device == device)
-      if (void* p = take(a, need)) return p;
+      if (void* p = take(a, need, slot)) return p;
   const size_t lo = env_size("XMPI_ARENA_MIN_BYTES", 64u << 20), hi = env_size("XMPI_ARENA_MAX_BYTES", 1u << 30);
   if (g_next_arena < lo) g_next_arena = lo;
-  size_t want = std::max(need, std::min(g_next_arena, hi));
+  size_t want = std::max(need + colour, std::min(g_next_arena, hi));
   want = (want + kArenaAlign - 1) / kArenaAlign * kArenaAlign;
   void* base = nullptr;
   if (hipMalloc(&base, want) != hipSuccess) {
     (void)hipGetLastError();
-    want = (need + kArenaAlign - 1) / kArenaAlign * kArenaAlign;  // memory is tight: just what was asked for
+    want = (need + colour + kArenaAlign - 1) / kArenaAlign * kArenaAlign;  // memory is tight: just what was asked for
     if (hipMalloc(&base, want) != hipSuccess) return nullptr;
   }
   g_next_arena = std::min(hi, g_next_arena * 2);
@@ -105,7 +143,7 @@ void* heap_alloc(int device, size_t bytes) {
   a->free_blocks[0] = want;
   g_arenas.push_back(a);
   registry_add(base, want, device);  // the arena is what peers map
-  return take(a, need);
+  return take(a, need, slot);
 }
 
 namespace {
@@ -166,7 +204,7 @@ int heap_selftest(uint64_t seed, int rounds) {
     if (live.empty() || rnd() % 3 != 0) {
       const size_t want = (rnd() % 7 == 0) ? (size_t)(rnd() % (4u << 20)) + 1 : (size_t)(rnd() % 5000) + 1;
       const size_t need = (want + kGranule - 1) / kGranule * kGranule;
-      char* p = (char*)take(&a, need);
+      char* p = (char*)take(&a, need, need >= kColourMin ? colour_slot(rnd()) : -1);
       if (!p) continue;  // full: fine
       if (((uintptr_t)p & (kGranule - 1)) != 0) return 1;
       for (auto& b : live)
