@@ -1839,7 +1839,12 @@ int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
       // every rank must read the same figures: the slowest rank's
       rc = collective(c, COLL_ALLREDUCE, XMPI_ALGO_DIRECT, 0, us.data(), worst.data(), us.size(), XMPI_F64, XMPI_MAX);
       if (rc != XMPI_OK) break;
-      const int best = xmpi_tune_decide(worst.data(), (int)worst.size(), 0.03);
+      // "the default stays on a tie" -- and the untuned library already runs meet / body / done from dsync_split_bytes on: there
+      // candidate 2 is the default, so it is decided with the two swapped
+      const bool split_is_default = coll == COLL_ALLREDUCE && keep_split > 0 && per_rank >= (size_t)keep_split && worst[2] > 0;
+      if (split_is_default) std::swap(worst[0], worst[2]);
+      int best = xmpi_tune_decide(worst.data(), (int)worst.size(), 0.03);
+      if (split_is_default && (best == 0 || best == 2)) best = 2 - best;
       if (best < 0) continue;
       int k = 0;
       while (k + 1 < xmpi_comm::kTuneClasses && (per_rank >> (k + 9)) != 0) k++;
