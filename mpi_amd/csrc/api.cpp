@@ -728,12 +728,16 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
     hip_fail(hipGetLastError(), "hipStreamCreate/hipMalloc", __FILE__, __LINE__);
     return fail(XMPI_ERR_HIP);
   }
+  {  // before the barrier: no rank of this process can allocate before every one of them has said so
+    bool shared = false;
+    for (int p = 0; p < size; p++) shared = shared || (p != rank && ctl->info(p)->pid == (int32_t)getpid());
+    heap_colour_seed(rank, shared);
+  }
   rc = ctl->barrier(timeout > 0 ? timeout : 3600.0);
   if (rc != XMPI_OK) {
     set_last_error("xmpi_init: barrier failed");
     return fail(rc);
   }
-  heap_colour_seed(rank);
   heap_comm_created();
   // XMPI_AUTOTUNE_BYTES=N: the library times its schedules for messages up to N bytes right here (xmpi_tune), so that a
   // program that knows nothing about tuning gets the schedule a benchmark would pick on this node; every rank sees the

@@ -286,7 +286,7 @@ void* heap_alloc(int device, size_t bytes);
 bool heap_free(void* p);
 bool heap_owns(const void* p);
 void heap_comm_created();
-void heap_colour_seed(int rank);  // before heap_comm_created: which rank this process hosts (colours of large blocks)
+void heap_colour_seed(int rank, bool ranks_share_this_process);  // before heap_comm_created: which rank this process hosts (colours of large blocks)
 void heap_comm_destroyed(xmpi_comm* c);
 void heap_stats(int device, size_t* arenas, size_t* reserved, size_t* in_use);
 int heap_selftest(uint64_t seed, int rounds);

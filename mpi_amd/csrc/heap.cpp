@@ -54,6 +54,7 @@ size_t env_size(const char* name, size_t dflt) {
 // 2 x rank -- a rank's send and receive buffer slots 8 apart, the ranks' pairs the rest -- if colouring is forced on there.)
 constexpr size_t kColourMin = (size_t)1 << 20, kColourFrame = (size_t)64 << 10, kColourSlot = 4096;
 uint64_t g_colour_next = 0;
+bool g_heap_shared = false;  // several ranks of a job are threads of this process
 
 int colour_slot(uint64_t n) {
   const unsigned k = (unsigned)(n & 15);
@@ -90,6 +91,7 @@ void heap_comm_created() {
 void heap_comm_destroyed(xmpi_comm* c) {
   std::lock_guard<std::mutex> g(g_heap_mu);
   if (--g_live_comms > 0) return;
+  g_heap_shared = false;
   for (size_t i = 0; i < g_arenas.size();) {
     Arena* a = g_arenas[i];
     if (a->used_blocks.empty()) {
@@ -106,9 +108,10 @@ void heap_comm_destroyed(xmpi_comm* c) {
 }
 
 // the first communicator of the process says which rank lives here: ranks in different processes take different colours
-void heap_colour_seed(int rank) {
+void heap_colour_seed(int rank, bool ranks_share_this_process) {
   std::lock_guard<std::mutex> g(g_heap_mu);
   if (g_live_comms == 0) g_colour_next = 2 * (uint64_t)std::max(0, rank);
+  if (ranks_share_this_process) g_heap_shared = true;  // known before any of them can allocate (xmpi_init's last barrier)
 }
 
 void* heap_alloc(int device, size_t bytes) {
@@ -119,7 +122,7 @@ void* heap_alloc(int device, size_t bytes) {
   // one process per rank the same A/B was inside the noise or against it (8 processes on one GPU: +3 ... +9 %, r03 session 12),
   // so there the blocks stay where they were measured.  XMPI_HEAP_COLOUR=1 / 0 forces it.
   static const int forced = getenv("XMPI_HEAP_COLOUR") ? atoi(getenv("XMPI_HEAP_COLOUR")) : -1;
-  const bool coloured = forced >= 0 ? forced != 0 : g_live_comms > 1;
+  const bool coloured = forced >= 0 ? forced != 0 : g_heap_shared;
   const int slot = (coloured && need >= kColourMin) ? colour_slot(g_colour_next++) : -1;
   const size_t colour = slot < 0 ? 0 : kColourFrame + (size_t)slot * kColourSlot;  // room the placement may take
   for (Arena* a : g_arenas)

@@ -616,6 +616,37 @@ def sc_host_payloads(comm, args):
     comm.barrier()
 
 
+_COLOUR_SEEN = {}
+
+
+def sc_heap_colours(comm, args):
+    """heap.cpp: large blocks of a heap that serves several ranks (threads of one process) start in different 4 KiB slots of
+    a 64 KiB frame -- 16 consecutive large blocks in 16 different slots (bits 12..15 of the address) -- so that the buffers of
+    one fold do not meet in the same HBM banks; a heap with one rank leaves blocks where the free range starts.  Contents
+    survive, blocks do not overlap, freeing gives everything back."""
+    rank, size = comm.rank(), comm.size()
+    n = 16 // size
+    bufs = [comm.alloc(1 << 20) for _ in range(n)]
+    for i, b in enumerate(bufs):
+        comm.memset(b, 16 * rank + i, 1 << 20)
+    _COLOUR_SEEN[rank] = [b.ptr for b in bufs]
+    comm.barrier()
+    ptrs = sorted(p for r in range(size) for p in _COLOUR_SEEN.get(r, [])) if args.get("threads") else sorted(_COLOUR_SEEN[rank])
+    for a, b in zip(ptrs, ptrs[1:]):
+        assert a + (1 << 20) <= b, "blocks overlap"
+    slots = [(p >> 12) & 15 for p in ptrs]
+    if args.get("threads"):
+        assert len(ptrs) == 16 and sorted(slots) == list(range(16)), slots
+    else:
+        assert len(set(slots)) == 1, f"one rank per process: blocks are not coloured {slots}"
+    for i, b in enumerate(bufs):
+        back = b.download(np.uint8, 1 << 20)
+        assert back[0] == 16 * rank + i and back[-1] == 16 * rank + i and int(back.min()) == int(back.max())
+    comm.barrier()
+    for b in bufs:
+        b.free()
+
+
 def sc_helloworld(comm, args):
     """examples/helloworld/helloworld.go:53-81: every rank concurrently sends a string to every rank
     (itself included) with tag 0 and receives one from every rank."""
@@ -1272,6 +1303,7 @@ SCENARIOS = {
     "allgather": sc_allgather,
     "bcast_reduce": sc_bcast_reduce,
     "bounce": sc_bounce,
+    "heap_colours": sc_heap_colours,
     "host_payloads": sc_host_payloads,
     "helloworld": sc_helloworld,
     "p2p_semantics": sc_p2p_semantics,

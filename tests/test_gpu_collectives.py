@@ -140,6 +140,14 @@ def test_host_payloads():
                 print(line)
 
 
+def test_large_blocks_are_coloured_where_ranks_share_a_heap():
+    """xmpi_malloc, heap.cpp: 16 consecutive large blocks of a heap serving several ranks lie in 16 different 4 KiB slots of a
+    64 KiB frame (the fold's 16 streams then use different HBM banks); with one rank per process nothing moves"""
+    run_threads("heap_colours", 2, {"threads": 1})
+    run_threads("heap_colours", 8, {"threads": 1})
+    run_ranks("heap_colours", 2, timeout=300)
+
+
 def test_bounce_threads():
     """ranks as threads of one process: the receiver reads the sender's buffer through its own pointer"""
     run_threads("bounce", 2)
