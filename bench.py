@@ -488,6 +488,9 @@ def rank_main(job: Job, grank: int):
                 if grank == 0 and not np.array_equal(hs, hr):
                     parity_failures.append("bounce of host slices: echo differs")
                 extras["bounce_sweep_u8_host_slices"] = sweep_h
+                extras["bounce_sweep_note"] = ("both sweeps run between two PYTHON threads of this process (N = 1) or two Python processes: below 100 KB the "
+                                               "figures are interpreter hand-offs, not the library -- examples/bounce.cpp through the launcher: 2 us (host "
+                                               "slices), 8-9 us (HBM, ping-pong proper), profiles/r03/bounce_example*.txt, bounce_2proc_*.json")
             comm.barrier()
             # BASELINE cfg 5: allreduce-sum fp16 up to 1 GiB per rank, recursive halving vs ring (and the library's own
             # choice) over sizes 1 MiB ... 1 GiB; exactly summable inputs k/64: every schedule must be bit-identical to

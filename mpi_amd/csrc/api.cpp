@@ -681,7 +681,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   // point-to-point message straight into its mail entry (engine.cpp)
   // (with the host lanes behind it, so that a lane's piece is copied to a device destination by DMA; the control
   // structures alone if the runtime will not pin that much)
-  if (hipHostRegister(ctl->base(), ctl->bytes(), hipHostRegisterMapped) == hipSuccess ||
+  if ((ctl->host_lane_bytes() > 0 && hipHostRegister(ctl->base(), ctl->bytes(), hipHostRegisterMapped) == hipSuccess) ||
       ((void)hipGetLastError(), hipHostRegister(ctl->base(), Ctl::layout_bytes(size), hipHostRegisterMapped) == hipSuccess)) {
     c->ctl_registered = true;
     void* dev = nullptr;
