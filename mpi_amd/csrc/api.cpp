@@ -1615,7 +1615,7 @@ int xmpi_link_probe(xmpi_comm* c, int peer, size_t bytes, int engine, int iters,
 // ring through the pipe counters and a mail-entry handshake with the next rank.  Lets the N > 1
 // bootstrap / rendezvous logic be tested with plain OS processes on a machine without a GPU.
 int xmpi_ctl_selftest(const char* job_key, int rank, int size, int rounds) {
-  CtlConfig cfg{2, 8, 8u << 20, 2, 4u << 20};
+  CtlConfig cfg{2, 8, 8u << 20, 2, 4u << 20, 1};  // (host lanes requested)
   std::string err;
   Ctl* ctl = nullptr;
   int rc = Ctl::join(job_key ? job_key : "selftest", rank, size, cfg, 30.0, &ctl, &err);
@@ -1676,6 +1676,58 @@ int xmpi_ctl_selftest(const char* job_key, int rank, int size, int rounds) {
       rc = XMPI_ERR_STATE;
     out->state.store(MAIL_FREE, std::memory_order_release);
     if (rc != XMPI_OK) break;
+    // a host-resident payload through the entry's host lane (engine.cpp p2p_send / p2p_recv, DIRECT_HOST): a ring of
+    // kHostLaneSlots pieces, head written by the sender, tail by the receiver; every rank sends to the next and receives from
+    // the one before at once, lengths from one byte to three times the ring
+    if (ctl->host_lane_bytes() > 0) {
+      const size_t lane_bytes = ctl->host_lane_bytes(), piece = lane_bytes / kHostLaneSlots;
+      auto length = [&](int r) { return (size_t)(((uint64_t)k * 7919u + (uint64_t)r * 104729u) % (3u * lane_bytes)) + 1; };
+      auto byte_at = [&](int r, size_t i) { return (uint8_t)(i * 31u + (size_t)k + (size_t)r * 7u); };
+      const int e = k % kMailEntries;
+      const size_t out_bytes = length(rank), in_bytes = length(prev);
+      const uint64_t out_np = (out_bytes + piece - 1) / piece, in_np = (in_bytes + piece - 1) / piece;
+      char* lane_out = ctl->host_lane(rank, next, e);
+      const char* lane_in = ctl->host_lane(prev, rank, e);
+      PipeCtl* po = &ctl->mail(rank, next, e)->pipe;
+      PipeCtl* pin = &ctl->mail(prev, rank, e)->pipe;
+      std::vector<uint8_t> got(in_bytes);
+      uint64_t filled = 0, taken = 0;
+      const double t0 = now_seconds();
+      Backoff bo;
+      while ((filled < out_np || taken < in_np) && rc == XMPI_OK) {
+        bool moved = false;
+        if (filled < out_np && filled - po->tail.v.load(std::memory_order_acquire) < (uint64_t)kHostLaneSlots) {
+          const size_t off = (size_t)filled * piece, n = std::min(piece, out_bytes - off);
+          char* slot = lane_out + (size_t)(filled % kHostLaneSlots) * piece;
+          for (size_t i = 0; i < n; i++) slot[i] = (char)byte_at(rank, off + i);
+          po->head.v.store(++filled, std::memory_order_release);
+          moved = true;
+        }
+        if (taken < in_np && pin->head.v.load(std::memory_order_acquire) > taken) {
+          const size_t off = (size_t)taken * piece, n = std::min(piece, in_bytes - off);
+          memcpy(got.data() + off, lane_in + (size_t)(taken % kHostLaneSlots) * piece, n);
+          pin->tail.v.store(++taken, std::memory_order_release);
+          moved = true;
+        }
+        if (!moved) {
+          if (ctl->aborted()) rc = XMPI_ERR_PEER;
+          else if (now_seconds() - t0 > 30.0) rc = XMPI_ERR_TIMEOUT;
+          bo.pause();
+        }
+      }
+      for (size_t i = 0; i < in_bytes && rc == XMPI_OK; i++)
+        if (got[i] != byte_at(prev, i)) {
+          set_last_error("ctl selftest: host lane payload differs at byte " + std::to_string(i) + " of " + std::to_string(in_bytes));
+          rc = XMPI_ERR_STATE;
+        }
+      if (rc != XMPI_OK) break;
+      rc = ctl->barrier(30.0);  // everybody has drained its lane: the counters start the next message at zero
+      if (rc != XMPI_OK) break;
+      po->head.v.store(0, std::memory_order_relaxed);
+      pin->tail.v.store(0, std::memory_order_relaxed);
+      rc = ctl->barrier(30.0);
+      if (rc != XMPI_OK) break;
+    }
     // zero-copy collective k: descriptors are double-buffered by sequence parity; everybody reads
     // everybody's after the barrier, a rank that freed buffers says so in its retire log
     BufDesc* mine = ctl->desc(rank, (uint64_t)k);

@@ -1,7 +1,8 @@
 """World-size 2 / 4 / 8 runs of the control plane on the CPU (plain OS processes, no GPU, no HIP
 call): the shared-memory bootstrap that replaces the reference's TCP handshake
 (network.go:122-351), the barrier, the pipe counters and the mail-entry states behind
-Send/Receive.  Also a stale control block of a crashed job with the same key must not confuse a
+Send/Receive, and host-resident payloads of 1 byte ... 3 rings streaming through the entries' host
+lanes (every rank sending to the next and receiving from the one before at once).  Also a stale control block of a crashed job with the same key must not confuse a
 new job, and a world-size-2 torch.distributed (gloo) run executes the ring schedule's step tables
 over real inter-process messaging."""
 import os
