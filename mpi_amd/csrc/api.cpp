@@ -567,6 +567,9 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
     if (c->p2p_tickets) (void)hipFree(c->p2p_tickets);
     if (c->p2p_done) (void)hipHostFree(c->p2p_done);
     if (c->p2p_cmd) (void)hipHostFree(c->p2p_cmd);
+  if (c->p2p_bounce) (void)hipHostFree(c->p2p_bounce);
+  c->p2p_bounce = c->p2p_bounce_dev = nullptr;
+    if (c->p2p_bounce) (void)hipHostFree(c->p2p_bounce);
     if (c->p2p_rec) (void)hipFree(c->p2p_rec);
     if (c->dev_words) (void)hipFree(c->dev_words);
     (void)hipGetLastError();
@@ -681,12 +684,14 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   // point-to-point message straight into its mail entry (engine.cpp)
   // (with the host lanes behind it, so that a lane's piece is copied to a device destination by DMA; the control
   // structures alone if the runtime will not pin that much)
-  if ((ctl->host_lane_bytes() > 0 && hipHostRegister(ctl->base(), ctl->bytes(), hipHostRegisterMapped) == hipSuccess) ||
+  if (ctl->host_lane_bytes() > 0 && hipHostRegister(ctl->base(), ctl->bytes(), hipHostRegisterMapped) == hipSuccess) c->lanes_dev_ok = true;
+  if (c->lanes_dev_ok ||
       ((void)hipGetLastError(), hipHostRegister(ctl->base(), Ctl::layout_bytes(size), hipHostRegisterMapped) == hipSuccess)) {
     c->ctl_registered = true;
     void* dev = nullptr;
     if (hipHostGetDevicePointer(&dev, ctl->base(), 0) == hipSuccess) c->ctl_dev = (char*)dev;
   }
+  if (!c->ctl_dev) c->lanes_dev_ok = false;
   (void)hipGetLastError();
   // (two more for the copy kernels that carry a host slice into / out of a collective's stand-in, dsync.cpp)
   if (hipMalloc((void**)&c->p2p_tickets, (xmpi_comm::kP2PDoneSlots + 2) * sizeof(uint32_t)) == hipSuccess)

@@ -144,6 +144,10 @@ struct xmpi_comm {
   char* host_bounce = nullptr;
   char* host_bounce_dev = nullptr;
   uint64_t host_bounce_calls = 0;
+  bool lanes_dev_ok = false;  // the host lanes are pinned and mapped: kernels / DMA engines read them (ctl_dev + offset)
+  std::mutex p2p_bounce_mu;   // a message out of a peer's HBM into a host slice: through this pinned block (engine.cpp)
+  char* p2p_bounce = nullptr;
+  char* p2p_bounce_dev = nullptr;
   uint32_t* p2p_tickets = nullptr;      // device: block counters of the pull kernels (blocking Receive), one per done slot
   // the library's own schedule table (xmpi_tune): algorithm per collective and size class, agreed by all ranks
   static constexpr int kTuneClasses = 24;  // class k: messages of [2^(k+8), 2^(k+9)) bytes per rank

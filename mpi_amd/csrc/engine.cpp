@@ -729,6 +729,8 @@ int await_ack(xmpi_comm* c, MailEntry* m, int dest, int tag) {
 
 }  // namespace
 
+constexpr size_t kP2PBounceBytes = (size_t)256 << 10;  // device -> host slice through pinned memory up to this length
+
 // ---- the receive agent: a copy-and-ack kernel that lingers (sched.hip p2p_agent_kernel) ------------------------------------
 // One command at a time per communicator.  Returns true when the agent copied the message and wrote both acks; false: the
 // caller launches the ordinary kernel (the agent could not be started).
@@ -1127,31 +1129,88 @@ int p2p_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int 
     const char* lane = c->ctl->host_lane(src, c->rank, entry);
     uint64_t taken = 0;
     bo.n = 0;
-    while (rc == XMPI_OK && taken < np) {
-      const uint64_t head = m->pipe.head.v.load(std::memory_order_acquire);
-      if (head > taken) {
-        for (uint64_t k = taken; k < head && rc == XMPI_OK; k++) {
-          const size_t off = (size_t)k * piece, n = std::min(piece, bytes - off);
-          const char* from = lane + (size_t)(k % kHostLaneSlots) * piece;
-          if (!dev_dst) memcpy((char*)buf + off, from, n);
-          else if (hipMemcpyAsync((char*)buf + off, from, n, hipMemcpyHostToDevice, lease.s) != hipSuccess)
-            rc = hip_fail(hipGetLastError(), "p2p receive from the host lane", __FILE__, __LINE__);
-        }
-        if (dev_dst && rc == XMPI_OK && hipStreamSynchronize(lease.s) != hipSuccess)
-          rc = hip_fail(hipGetLastError(), "hipStreamSynchronize", __FILE__, __LINE__);
-        taken = head;
-        m->pipe.tail.v.store(taken, std::memory_order_release);
-        tp = now_seconds();
-        bo.n = 0;
-        continue;
-      }
+    auto stalled = [&]() {
       if (c->ctl->aborted()) rc = XMPI_ERR_PEER;
       else if (c->timeout_s > 0 && now_seconds() - tp > (double)c->timeout_s) {
         set_last_error("receive: sender stalled");
         rc = XMPI_ERR_TIMEOUT;
       }
       bo.pause();
+    };
+    if (dev_dst && c->lanes_dev_ok && c->p2p_kernel_ack && np <= (uint64_t)kHostLaneSlots) {
+      // a message that fits the ring lies there in one piece (it was complete before it was posted): the receive agent pulls it
+      // out of the pinned lane like it pulls a message out of a peer's HBM, and writes the ack -- no DMA call, no event
+      while (rc == XMPI_OK && m->pipe.head.v.load(std::memory_order_acquire) < np) stalled();
+      if (rc == XMPI_OK && agent_submit(c, buf, c->ctl_dev + (lane - (const char*)c->ctl->base()), bytes, m)) {
+        __atomic_fetch_add(&c->p2p_lane_count, 1, __ATOMIC_RELAXED);
+        return XMPI_OK;
+      }
     }
+    // Longer messages stream through the ring.  A host destination takes the pieces with memcpy.  A device destination has a
+    // kernel pull every run of pieces that has arrived (the GPU reads the pinned lane itself; its last block writes a completion
+    // word this thread polls) -- one DMA call + event per 64 KiB piece took twice as long (r03 session 14: 1 MiB 357 us per round
+    // trip instead of 240), and so does the runtime's staged copy when the lane could not be pinned (the fallback below).
+    const bool pull = dev_dst && c->lanes_dev_ok && c->p2p_kernel_ack && c->p2p_done_dev && c->p2p_tickets;
+    uint64_t pending = 0, pending_id = 0;
+    volatile uint64_t* pending_word = nullptr;
+    while (rc == XMPI_OK && taken < np) {
+      bool progressed = false;
+      const uint64_t head = m->pipe.head.v.load(std::memory_order_acquire);
+      if (head > taken && !dev_dst) {
+        for (uint64_t k = taken; k < head; k++) {
+          const size_t off = (size_t)k * piece;
+          memcpy((char*)buf + off, lane + (size_t)(k % kHostLaneSlots) * piece, std::min(piece, bytes - off));
+        }
+        taken = head;
+        m->pipe.tail.v.store(taken, std::memory_order_release);
+        progressed = true;
+      } else if (head > taken && pull && !pending) {
+        const uint64_t first = taken % kHostLaneSlots, run = std::min<uint64_t>(head - taken, kHostLaneSlots - first);  // contiguous in the lane
+        const size_t off = (size_t)taken * piece;
+        pending_id = c->p2p_pull_next.fetch_add(1, std::memory_order_relaxed) + 1;
+        const int slot = (int)(pending_id % (uint64_t)xmpi_comm::kP2PDoneSlots);
+        pending_word = c->p2p_done + 4 * (xmpi_comm::kP2PDoneSlots + slot);
+        P2PPullArgs pa;
+        memset(&pa, 0, sizeof pa);
+        pa.dst = (char*)buf + off;
+        pa.src = c->ctl_dev + ((lane + (size_t)first * piece) - (const char*)c->ctl->base());
+        pa.bytes = std::min((size_t)run * piece, bytes - off);
+        pa.ticket = c->p2p_tickets + slot;
+        pa.host_done = c->p2p_done_dev + 4 * (xmpi_comm::kP2PDoneSlots + slot);
+        pa.done_value = pending_id;
+        const long gx = std::max<long>(1, std::min<long>(16, (long)((pa.bytes + 16383) >> 14)));
+        if (launch_p2p_pull(pa, (int)gx, lease.s) != hipSuccess) {
+          rc = hip_fail(hipGetLastError(), "p2p pull out of the host lane", __FILE__, __LINE__);
+          break;
+        }
+        pending = run;
+        progressed = true;
+      } else if (head > taken && dev_dst && !pull) {
+        for (uint64_t k = taken; k < head && rc == XMPI_OK; k++) {
+          const size_t off = (size_t)k * piece;
+          if (hipMemcpyAsync((char*)buf + off, lane + (size_t)(k % kHostLaneSlots) * piece, std::min(piece, bytes - off), hipMemcpyHostToDevice,
+                             lease.s) != hipSuccess)
+            rc = hip_fail(hipGetLastError(), "p2p receive from the host lane", __FILE__, __LINE__);
+        }
+        if (rc == XMPI_OK && hipStreamSynchronize(lease.s) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipStreamSynchronize", __FILE__, __LINE__);
+        taken = head;
+        m->pipe.tail.v.store(taken, std::memory_order_release);
+        progressed = true;
+      }
+      if (pending && __atomic_load_n((const uint64_t*)pending_word, __ATOMIC_ACQUIRE) == pending_id) {
+        taken += pending;
+        pending = 0;
+        m->pipe.tail.v.store(taken, std::memory_order_release);
+        progressed = true;
+      }
+      if (progressed) {
+        tp = now_seconds();
+        bo.n = 0;
+        continue;
+      }
+      stalled();
+    }
+    if (pending) (void)hipStreamSynchronize(lease.s);  // (an error above: the kernel in flight must not outlive the call)
     if (rc != XMPI_OK) {
       c->ctl->set_abort(rc);
       return rc;
@@ -1167,6 +1226,27 @@ int p2p_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int 
     if (!dev_dst && zc_import(c, src, m->src, &from)) {
       // ... into HOST memory (the caller handed a slice): one copy device -> host, no slots in between
       m->direct.store(DIRECT_ACCEPTED, std::memory_order_release);
+      if (c->p2p_kernel_ack && bytes <= kP2PBounceBytes) {
+        // short: the receive agent copies into a pinned block and acks; the slice gets it with memcpy (the runtime's copy into
+        // pageable memory is a staged, synchronous affair of 20 us)
+        std::lock_guard<std::mutex> g(c->p2p_bounce_mu);
+        if (!c->p2p_bounce) {
+          void* p = nullptr;
+          void* dev = nullptr;
+          if (hipHostMalloc(&p, kP2PBounceBytes, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&dev, p, 0) == hipSuccess) {
+            c->p2p_bounce = (char*)p;
+            c->p2p_bounce_dev = (char*)dev;
+          } else {
+            (void)hipGetLastError();
+            if (p) (void)hipHostFree(p);
+          }
+        }
+        if (c->p2p_bounce_dev && agent_submit(c, c->p2p_bounce_dev, from, bytes, m)) {
+          memcpy(buf, c->p2p_bounce, bytes);
+          __atomic_fetch_add(&c->p2p_direct_count, 1, __ATOMIC_RELAXED);
+          return XMPI_OK;
+        }
+      }
       if (hipMemcpyAsync(buf, from, bytes, hipMemcpyDeviceToHost, lease.s) != hipSuccess || hipStreamSynchronize(lease.s) != hipSuccess) {
         rc = hip_fail(hipGetLastError(), "p2p direct copy to the host", __FILE__, __LINE__);
         c->ctl->set_abort(rc);

@@ -578,6 +578,22 @@ def sc_host_payloads(comm, args):
             comm.send(small, 8, xmpi.U8, peer, 5)
     if rank == 0:
         print(f"host slices, 8 bytes, round trip through ctypes: {(time.perf_counter() - t0) / 200 * 1e6:.1f} us (lanes {'on' if lanes_on else 'off'})")
+    # the mixes: a slice on one side, HBM on the other (round trip = one message each way, sender's kind -> receiver's kind)
+    for nb in (8, 1 << 20):
+        hbuf = np.zeros(nb, dtype=np.uint8)
+        for mine, theirs in (("host", "dev"), ("dev", "host")):
+            a_buf = hbuf if (mine if rank == 0 else theirs) == "host" else dev_a
+            for w in range(120):
+                if w == 20:
+                    t0 = time.perf_counter()
+                if rank == 0:
+                    comm.send(a_buf, nb, xmpi.U8, peer, 6)
+                    comm.recv(a_buf, nb, xmpi.U8, peer, 6)
+                else:
+                    comm.recv(a_buf, nb, xmpi.U8, peer, 6)
+                    comm.send(a_buf, nb, xmpi.U8, peer, 6)
+            if rank == 0:
+                print(f"host slices, {nb} bytes, rank 0 {mine} <-> rank 1 {theirs}: {(time.perf_counter() - t0) / 100 * 1e6:.1f} us per round trip")
     # ... and an allreduce of slices (collectives.go hands them to xmpi_allreduce as they are: stand-ins in HBM, the fold on the GPU)
     hb0 = comm.get_param("host_bounce_calls")
     for n in (2, 256, 65536, 65537, 262144):
