@@ -17,8 +17,10 @@ def main():
     if not os.path.isdir(SRC):
         sys.exit(f"{SRC}: run scripts/r03_profile.sh through gpurun first")
     os.makedirs(DST, exist_ok=True)
+    keep = ("host_slices_through_ctypes.txt", "bench_n1_uncoloured_fast_box.json", "bench_n1_default_fast_box.json")  # from other calls
     for f in glob.glob(os.path.join(DST, "*")):
-        os.remove(f)
+        if os.path.basename(f) not in keep:
+            os.remove(f)
     for f in sorted(glob.glob(os.path.join(SRC, "*.json")) + glob.glob(os.path.join(SRC, "*.txt"))):
         if os.path.getsize(f):
             shutil.copy(f, os.path.join(DST, os.path.basename(f)))
