@@ -62,7 +62,12 @@ typedef enum {
                            pushed back; 3 kernels; out-of-place (on every rank or on none), count
                            divisible by ranks x 16 B, otherwise (and for the other collectives)
                            the same as ZCOPY                                                 */
-  XMPI_ALGO_COUNT = 7
+  XMPI_ALGO_LL = 7,     /* low latency, messages up to 32 KiB per rank with one process per GPU: every rank pushes
+                           its payload as {data, flag} lines into the peers' flag allocations and folds
+                           locally in rank order -- one one-way hop, nothing registered, announced or read
+                           remotely (the reference: one message + one ack per Send, network.go:562-571);
+                           longer messages, or ranks that meet on the host: the same as ZCOPY / AUTO        */
+  XMPI_ALGO_COUNT = 8
 } xmpi_algo;
 
 /* error codes */

@@ -26,7 +26,7 @@ HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wextra"]
 
-LIB_SOURCES = ["kernels.hip", "sched.hip", "engine.cpp", "api.cpp", "ctl.cpp", "plan.cpp", "zcopy.cpp", "heap.cpp", "dsync.cpp"]
+LIB_SOURCES = ["kernels.hip", "sched.hip", "ll.hip", "engine.cpp", "api.cpp", "ctl.cpp", "plan.cpp", "zcopy.cpp", "heap.cpp", "dsync.cpp"]
 LIB_HEADERS = ["kernels.h", "kdev.h", "sched_steps.h", "comm.h", "ctl.h", "plan.h", os.path.join("..", "..", "include", "xmpi.h")]
 
 

@@ -375,7 +375,7 @@ static int collective(xmpi_comm* c, int coll, int algo, int root, const void* se
   // Zero-copy first (zcopy.cpp): when every rank's buffers are registered HBM one kernel per rank does
   // the whole collective in place.  Whether that holds is decided collectively, so either every rank
   // returns from here or every rank goes on to the staged schedule below.
-  const bool zc_algo = algo == XMPI_ALGO_ZCOPY || algo == XMPI_ALGO_ZPUSH;
+  const bool zc_algo = algo == XMPI_ALGO_ZCOPY || algo == XMPI_ALGO_ZPUSH || algo == XMPI_ALGO_LL;
   // One process per GPU (the production layout): the ranks meet on the device (dsync.cpp) -- one kernel per
   // rank, enqueued on this communicator's stream, no host barrier.  Whether this path is taken depends on the
   // job's layout and the arguments only, so every rank decides alike; buffers the peers cannot map are stood in
@@ -389,7 +389,7 @@ static int collective(xmpi_comm* c, int coll, int algo, int root, const void* se
     int zrc = zero_copy_collective(c, coll, root, sendbuf, recvbuf, count, dtype, op, algo == XMPI_ALGO_ZPUSH, &done);
     if (zrc != XMPI_OK || done) return zrc;
   }
-  if (zc_algo) algo = XMPI_ALGO_AUTO;
+  if (zc_algo) algo = XMPI_ALGO_AUTO;  // (LL lines need ranks that meet on the device: with the others it names the fold)
   PlanParams pp;
   pp.coll = coll;
   pp.algo = algo;
@@ -609,6 +609,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   }
   c->dsync = env_long("XMPI_DSYNC", 1) ? 1 : 0;
   c->dsync_split_bytes = std::max<long>(0, env_long("XMPI_DSYNC_SPLIT_BYTES", 4 << 20));
+  c->ll_bytes = env_long("XMPI_LL_BYTES", -1);  // -1: decided when the job's layout is known (dsync_connect)
   c->sched_channels = std::max<long>(0, env_long("XMPI_SCHED_CHANNELS", 0));
   c->sched_grid = std::max<long>(0, env_long("XMPI_SCHED_GRID", 0));
   c->tree_piece_bytes = std::max<long>(4096, env_long("XMPI_TREE_PIECE_BYTES", 256 << 10));
@@ -1462,6 +1463,7 @@ int xmpi_set_param(xmpi_comm* c, const char* name, long value) {
   else if (n == "dsync_grid") c->dsync_grid_cap = std::max<long>(0, value);
   else if (n == "dsync_unroll") c->dsync_unroll = std::max<long>(1, std::min<long>(2, value));
   else if (n == "dsync_tiles") c->dsync_tiles = std::max<long>(1, value);
+  else if (n == "ll_bytes") c->ll_bytes = std::max<long>(0, std::min<long>((long)kLLMaxPayload, value));  // untuned AUTO: LL lines up to here
   else if (n == "dsync_split_bytes") c->dsync_split_bytes = std::max<long>(0, value);  // 0: always one kernel
   else if (n == "sched_channels") c->sched_channels = std::max<long>(0, value);
   else if (n == "sched_grid") c->sched_grid = std::max<long>(0, value);
@@ -1506,6 +1508,9 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
   if (n == "dsync_sharers") return c->dsync_sharers;
   if (n == "dsync_unroll") return c->dsync_unroll;
   if (n == "dsync_tiles") return c->dsync_tiles;
+  if (n == "ll_bytes") return c->ll_bytes;
+  if (n == "ll_max_bytes") return (long)kLLMaxPayload;
+  if (n == "dsync_ll_launches") return (long)c->dsync_ll_launches;
   if (n == "dsync_grid") return c->dsync_grid_cap;
   if (n == "dsync_split_bytes") return c->dsync_split_bytes;
   if (n == "dsync_split_launches") return (long)c->dsync_split_launches;
@@ -1857,7 +1862,8 @@ int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
                              {XMPI_ALGO_ZCOPY, 1, u0},
                              {XMPI_ALGO_ZPUSH, 0, u0},
                              {XMPI_ALGO_RING, 0, u0}};
-  if ((c->size & (c->size - 1)) == 0) cands.push_back({XMPI_ALGO_RHD, 0, u0});
+  cands.push_back({(c->size & (c->size - 1)) == 0 ? XMPI_ALGO_RHD : -1, 0, u0});  // (-1: a place holder -- candidate numbers are fixed)
+  cands.push_back({XMPI_ALGO_LL, 0, u0});                                          // candidate 6
   const long keep_split = c->dsync_split_bytes, keep_unroll = c->dsync_unroll;
   const bool keep_tuned = c->tuned;
   c->tuned = false;
@@ -1877,7 +1883,9 @@ int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
       for (int round = 0; round < rounds && rc == XMPI_OK; round++) {
         for (size_t k = 0; k < cands.size() && rc == XMPI_OK; k++) {
           const Cand& cd = cands[k];
+          if (cd.algo < 0) continue;
           if (coll == COLL_ALLGATHER && (cd.algo == XMPI_ALGO_ZPUSH || cd.algo == XMPI_ALGO_RHD || cd.unroll != u0)) continue;
+          if (cd.algo == XMPI_ALGO_LL && per_rank > kLLMaxPayload) continue;
           if (k > 0 && !((c->tune_mask >> k) & 1)) continue;  // a schedule the caller has ruled out on this machine (never the default)
           rc = xmpi_barrier(c);
           if (rc != XMPI_OK) break;
@@ -1914,6 +1922,12 @@ int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
         c->tune_split[coll][kk] = (int8_t)cands[(size_t)best].split;
         c->tune_unroll[coll][kk] = (int8_t)cands[(size_t)best].unroll;
       }
+      if (bytes == 1024)  // below the smallest measured size: what won there
+        for (int kk = 0; kk < k; kk++) {
+          c->tune_algo[coll][kk] = c->tune_algo[coll][k];
+          c->tune_split[coll][kk] = c->tune_split[coll][k];
+          c->tune_unroll[coll][kk] = c->tune_unroll[coll][k];
+        }
       for (int kk = k + 2; kk < xmpi_comm::kTuneClasses; kk++) {  // beyond the largest measured size: what won there
         c->tune_algo[coll][kk] = c->tune_algo[coll][k];
         c->tune_split[coll][kk] = c->tune_split[coll][k];
@@ -1933,6 +1947,8 @@ int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
   for (int kk = 0; kk < xmpi_comm::kTuneClasses; kk++) {
     c->tune_split[COLL_REDUCE][kk] = c->tune_algo[COLL_ALLREDUCE][kk] == XMPI_ALGO_ZCOPY ? c->tune_split[COLL_ALLREDUCE][kk] : (int8_t)-1;
     c->tune_split[COLL_BCAST][kk] = -1;
+    // ... and go as LL lines where the allreduce does
+    c->tune_algo[COLL_REDUCE][kk] = c->tune_algo[COLL_BCAST][kk] = c->tune_algo[COLL_ALLREDUCE][kk] == XMPI_ALGO_LL ? (int8_t)XMPI_ALGO_LL : (int8_t)-1;
   }
   c->tuned = true;
   return xmpi_barrier(c);

@@ -167,6 +167,8 @@ struct xmpi_comm {
   uint64_t dsync_base = 0;       // where this communicator's epochs start (epoch_floor of its kernels)
   uint64_t dsync_tag = 1;        // tags this communicator's entries in the (pooled, uncleared) page's translation cache
   uint64_t dsync_launches = 0, dsync_bounced = 0;  // diagnostics: kernels; buffers stood in for by arena blocks
+  long ll_bytes = 0;             // untuned AUTO: collectives up to this many bytes per rank go as LL lines (ll.hip); XMPI_LL_BYTES
+  uint64_t dsync_ll_launches = 0;  // ... collectives that did
   uint64_t dsync_split_launches = 0, dsync_sched_launches = 0;  // ... collectives run as meet / body / done; as a stepped kernel
   xmpi::DsyncEntry* dsync_table = nullptr;            // [kMaxRanks][kDsyncArenas], pinned host memory the kernels read
   const xmpi::DsyncEntry* dsync_table_dev = nullptr;  // ... as the GPU addresses it

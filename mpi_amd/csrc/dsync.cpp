@@ -136,6 +136,12 @@ int dsync_connect(xmpi_comm* c) {
   // Every block of the kernel spins until the peers' kernels have started: the kernels of all ranks on this GPU
   // must be resident at once, in at most half of its 8192 wave slots (4 waves per block).
   c->dsync_sharers = std::max(1, sharers);
+  // Untuned AUTO sends messages up to ll_bytes per rank as LL lines (ll.hip).  Measured with 2 processes (each kernel has the
+  // GPU it runs on to itself, as on a node with one rank per GPU): 4.9 / 6.1 / 6.4 us enqueued at 1 / 4 / 16 KiB against
+  // 8.9 / 8.8 / 9.4 for the fold; eight processes time-slicing ONE GPU: 45 / 56 / 65 against 47 / 47 / 42 (their polling lanes
+  // compete with each other's stores for the one memory system) -- so ranks that share a GPU keep LL to 1 KiB.
+  if (c->ll_bytes < 0) c->ll_bytes = c->dsync_sharers > 2 ? 1024 : 8192;
+  c->ll_bytes = std::min<long>(c->ll_bytes, (long)kLLMaxPayload);
   // epochs of this communicator: above whatever earlier communicators left in ANY rank's (pooled, uncleared) page;
   // the same number on every rank.  It also tags the translations this communicator's kernels cache in the page.
   uint64_t base = 0;
@@ -405,6 +411,186 @@ static hipError_t bounce_copy(xmpi_comm* c, void* dst, const void* src, size_t b
   return launch_p2p_pull(pa, (int)gx, s);
 }
 
+// A blocking call waits for its stream (polling: the wake-up latency of hipStreamSynchronize is a visible share of a small
+// collective), serving the peers meanwhile.  by_word: the closing block of the (last) kernel writes the call's number into a
+// pinned word (dsync_status bytes 16..23): no event between the kernel and this thread.  (The kernel itself gives up on a
+// dead peer -- abort flag, XMPI_TIMEOUT_S -- and still writes the word.)
+static int wait_blocking(xmpi_comm* c, hipStream_t stream, bool by_word, uint64_t done_id) {
+  Backoff bo;
+  bo.idle = idle_hook;
+  bo.idle_arg = c;
+  if (by_word) {
+    const volatile uint64_t* done = (const volatile uint64_t*)(c->dsync_status + 4);
+    // Safety valve, off the fast path: once the wait is long, ask the stream now and then -- a stream that is idle (or broken)
+    // while the word is still missing must not hang the caller.
+    unsigned spins = 0;
+    while (__atomic_load_n((const uint64_t*)done, __ATOMIC_ACQUIRE) != done_id) {
+      bo.pause();
+      if ((++spins & 0x3fff) == 0) {
+        const hipError_t e = hipStreamQuery(stream);
+        if (e == hipErrorNotReady) {
+          (void)hipGetLastError();
+          continue;
+        }
+        if (e != hipSuccess) return hip_fail(e, "hipStreamQuery", __FILE__, __LINE__);
+        if (__atomic_load_n((const uint64_t*)done, __ATOMIC_ACQUIRE) != done_id) {
+          set_last_error("collective: the stream drained but the closing block never reported (internal)");
+          return XMPI_ERR_STATE;
+        }
+      }
+    }
+    return XMPI_OK;
+  }
+  hipEvent_t fin = ev_get(c, false);
+  if (!fin) return XMPI_ERR_HIP;
+  XMPI_HIP(hipEventRecord(fin, stream));
+  for (;;) {
+    const hipError_t e = hipEventQuery(fin);
+    if (e == hipSuccess) break;
+    if (e != hipErrorNotReady) return hip_fail(e, "hipEventQuery", __FILE__, __LINE__);
+    (void)hipGetLastError();
+    bo.pause();
+  }
+  ev_put(c, fin, false);
+  return XMPI_OK;
+}
+
+// the kernels of one rank share the page's epoch counter, ticket and slots: one at a time.  On one stream that is
+// stream order; a launch on another stream than the previous one waits for it.
+// (The event is recorded when the stream CHANGES, at the tail of the previous stream -- not behind every launch: an event
+// per collective costs the queue a packet and was visible in the small-message figures.)
+static int order_behind_last(xmpi_comm* c, hipStream_t stream, bool capturing) {
+  if (capturing || !c->dsync_last_stream || c->dsync_last_stream == stream) return XMPI_OK;
+  hipStreamCaptureStatus pc = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(c->dsync_last_stream, &pc);
+  (void)hipGetLastError();
+  if (pc == hipStreamCaptureStatusNone) {  // (a capturing stream runs nothing until its graph is launched: dsync_graph_launched)
+    XMPI_HIP(hipEventRecord(c->dsync_order_ev, c->dsync_last_stream));
+    XMPI_HIP(hipStreamWaitEvent(stream, c->dsync_order_ev, 0));
+  }
+  return XMPI_OK;
+}
+
+// ---- LL small collectives (ll.hip): the payload is pushed into the peers' flag allocations, nothing is registered,
+// announced or translated; one kernel, one one-way hop.  Whether a call goes this way is decided by dsync_collective from the
+// arguments and the job's layout only (the same on every rank); what kind of memory a rank passes is this rank's business.
+static int dsync_ll(xmpi_comm* c, int coll, int root, const void* sendbuf, void* recvbuf, size_t count, int dtype, int op,
+                    hipStream_t stream, bool blocking, bool capturing) {
+  const int N = c->size, me = c->rank;
+  const size_t unit = count * xmpi_dtype_size((xmpi_dtype)dtype);
+  const size_t recv_bytes = coll == COLL_ALLGATHER ? unit * (size_t)N : unit;
+  const bool reads = coll != COLL_BCAST || me == root;           // this rank's send buffer is read
+  const bool writes = (coll != COLL_REDUCE || me == root) && !(coll == COLL_BCAST && me == root);  // its receive buffer is written
+  std::vector<void*> lent;
+  auto fail = [&](int rc) {
+    for (void* p : lent) (void)heap_free(p);
+    c->ctl->set_abort(rc);
+    return rc;
+  };
+  auto on_gpu = [&](const void* p, size_t bytes) {
+    BufRef ref;
+    return zc_export(c, p, bytes, &ref) || is_device_pointer(p);
+  };
+  const void* send = sendbuf;
+  void* recv = recvbuf;
+  void* out_tmp = nullptr;   // a stand-in whose contents go home to recvbuf
+  bool host_out = false;     // ... or the result lies in the pinned block
+  if (reads && !on_gpu(sendbuf, unit)) {  // a host slice: through pinned memory the kernel reads itself, or a stand-in
+    if (capturing) {
+      set_last_error("graph capture needs device buffers");
+      return XMPI_ERR_ARG;
+    }
+    if (blocking && host_bounce_ready(c)) {
+      memcpy(c->host_bounce, sendbuf, unit);
+      send = c->host_bounce_dev;
+      c->host_bounce_calls++;
+    } else {
+      void* tmp = heap_alloc(c->device, unit);
+      if (!tmp) return fail(XMPI_ERR_NOMEM);
+      lent.push_back(tmp);
+      XMPI_HIP(hipMemcpyAsync(tmp, sendbuf, unit, hipMemcpyDefault, stream));
+      send = tmp;
+    }
+  }
+  if (writes && !on_gpu(recvbuf, recv_bytes)) {
+    if (capturing) {
+      set_last_error("graph capture needs device buffers");
+      return XMPI_ERR_ARG;
+    }
+    if (blocking && recv_bytes <= xmpi_comm::kHostBounce && c->dsync_status_dev && host_bounce_ready(c)) {
+      recv = c->host_bounce_dev + xmpi_comm::kHostBounce;
+      host_out = true;
+      c->host_bounce_calls++;
+    } else {
+      out_tmp = heap_alloc(c->device, recv_bytes);
+      if (!out_tmp) return fail(XMPI_ERR_NOMEM);
+      lent.push_back(out_tmp);
+      recv = out_tmp;
+    }
+  }
+  if (!writes) recv = const_cast<void*>(send);  // (never written; the launcher wants a pointer)
+  if (!reads) send = recv;
+  int rc = order_behind_last(c, stream, capturing);
+  if (rc != XMPI_OK) return fail(rc);
+
+  DsyncLLArgs a;
+  memset(&a, 0, sizeof a);
+  for (int p = 0; p < N; p++) a.page[p] = c->peer_page[p];
+  a.me = me;
+  a.n = N;
+  a.coll = coll == COLL_ALLREDUCE ? LL_ALLREDUCE : coll == COLL_REDUCE ? LL_REDUCE : coll == COLL_BCAST ? LL_BCAST : LL_ALLGATHER;
+  a.root = root;
+  a.epoch_floor = c->dsync_base;
+  a.host_epoch = c->dsync_status_dev ? (uint64_t*)(c->dsync_status_dev + 2) : nullptr;
+  const uint64_t done_id = ++c->dsync_done_seq;
+  uint64_t* const done_dev = (blocking && c->dsync_status_dev) ? (uint64_t*)(c->dsync_status_dev + 4) : nullptr;
+  a.host_done = done_dev;
+  a.done_value = done_id;
+  a.send = send;
+  a.recv = recv;
+  a.bytes = unit;
+  a.abort_word = c->dsync_abort_dev;
+  a.status = c->dsync_status_dev;
+  a.spin_limit = c->timeout_s > 0 ? (uint64_t)c->timeout_s * 100000000ull : 0;
+  hipEvent_t pstart = nullptr, pstop = nullptr;
+  const bool sampled = !capturing && c->prof_on && (c->prof_seq[PROF_ZCOPY]++ % (uint64_t)std::max<long>(1, c->prof_every)) == 0;
+  if (sampled) {
+    pstart = ev_get(c, true);
+    pstop = ev_get(c, true);
+    if (!pstart || !pstop) return fail(XMPI_ERR_HIP);
+  }
+  ++c->dsync_epoch;
+  XMPI_HIP(launch_dsync_ll(a, dtype, op, stream, pstart, pstop));
+  c->dsync_launches++;
+  c->dsync_ll_launches++;
+  if (!capturing) c->dsync_last_stream = stream;
+  const size_t traffic = 2 * unit * (size_t)N;  // (own payload read, N-1 pushes of twice its size ... : a latency path, not a bandwidth one)
+  if (pstart) c->dsync_prof_pending.push_back({pstart, pstop, traffic});
+  if (!blocking) {
+    if (out_tmp) XMPI_HIP(hipMemcpyAsync(recvbuf, out_tmp, recv_bytes, hipMemcpyDefault, stream));
+    if (!lent.empty()) {
+      xmpi_comm::DsyncDeferred d;
+      if (hipEventCreateWithFlags(&d.done, hipEventDisableTiming) != hipSuccess) return fail(XMPI_ERR_HIP);
+      XMPI_HIP(hipEventRecord(d.done, stream));
+      d.bufs = lent;
+      c->dsync_deferred.push_back(d);
+    }
+    return XMPI_OK;
+  }
+  rc = wait_blocking(c, stream, done_dev != nullptr, done_id);
+  if (rc != XMPI_OK) return fail(rc);
+  if (host_out) {
+    memcpy(recvbuf, c->host_bounce + xmpi_comm::kHostBounce, recv_bytes);
+  } else if (out_tmp) {
+    XMPI_HIP(hipMemcpyAsync(recvbuf, out_tmp, recv_bytes, hipMemcpyDefault, stream));
+    XMPI_HIP(hipStreamSynchronize(stream));
+  }
+  for (void* p : lent) (void)heap_free(p);
+  lent.clear();
+  dsync_prof_harvest(c);
+  return dsync_check(c);
+}
+
 bool dsync_usable(const xmpi_comm* c) { return c->dsync_ok && c->dsync && c->size > 1; }
 
 // blocks a kernel of this rank may keep waiting at once: the kernels of all ranks on one GPU spin together, so with
@@ -435,7 +621,8 @@ bool dsync_takes(const xmpi_comm* c, int coll, int algo) {
   switch (algo) {
     case XMPI_ALGO_AUTO: return c->zero_copy != 0;
     case XMPI_ALGO_ZCOPY:
-    case XMPI_ALGO_ZPUSH: return true;
+    case XMPI_ALGO_ZPUSH:
+    case XMPI_ALGO_LL: return true;
     case XMPI_ALGO_RING: return coll == COLL_ALLREDUCE || coll == COLL_ALLGATHER;  // the stepped kernels (sched.hip)
     case XMPI_ALGO_RHD: return coll == COLL_ALLREDUCE;
     case XMPI_ALGO_TREE: return coll == COLL_BCAST;
@@ -489,7 +676,15 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
 
   // the schedule: what the caller named, or the library's own table
   int split_pref = -1, unroll = (int)std::max<long>(1, std::min<long>(2, c->dsync_unroll));
-  if (algo == XMPI_ALGO_AUTO) tuned_choice(c, coll, send_bytes, &algo, &split_pref, &unroll);
+  if (algo == XMPI_ALGO_AUTO) {
+    tuned_choice(c, coll, send_bytes, &algo, &split_pref, &unroll);
+    // untuned: short messages go as {data, flag} lines (ll.hip) -- one one-way hop instead of two round trips
+    if (algo == XMPI_ALGO_AUTO && c->zero_copy && send_bytes <= (size_t)std::max<long>(0, c->ll_bytes)) algo = XMPI_ALGO_LL;
+  }
+  if (algo == XMPI_ALGO_LL) {
+    if (send_bytes <= kLLMaxPayload) return dsync_ll(c, coll, root, sendbuf, recvbuf, count, dtype, op, stream, blocking, capturing);
+    algo = XMPI_ALGO_ZCOPY;  // named, but too long for the slots: the fold (the same decision on every rank)
+  }
   if (algo == XMPI_ALGO_RHD && (N & (N - 1)) != 0) algo = XMPI_ALGO_RING;  // halving needs a power of two
   const bool stepped = (algo == XMPI_ALGO_RING && (coll == COLL_ALLREDUCE || coll == COLL_ALLGATHER)) ||
                        (algo == XMPI_ALGO_RHD && coll == COLL_ALLREDUCE) || (algo == XMPI_ALGO_TREE && coll == COLL_BCAST);
@@ -566,19 +761,8 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
   rc = await_acks(c, need);
   if (rc) return fail(rc);
 
-  // the kernels of one rank share the page's epoch counter, ticket and slots: one at a time.  On one stream that is
-  // stream order; a launch on another stream than the previous one waits for it (an event behind every launch).
-  // (The event is recorded when the stream CHANGES, at the tail of the previous stream -- not behind every launch: an event
-  // per collective costs the queue a packet and was visible in the small-message figures.)
-  if (!capturing && c->dsync_last_stream && c->dsync_last_stream != stream) {
-    hipStreamCaptureStatus pc = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(c->dsync_last_stream, &pc);
-    (void)hipGetLastError();
-    if (pc == hipStreamCaptureStatusNone) {  // (a capturing stream runs nothing until its graph is launched: dsync_graph_launched)
-      XMPI_HIP(hipEventRecord(c->dsync_order_ev, c->dsync_last_stream));
-      XMPI_HIP(hipStreamWaitEvent(stream, c->dsync_order_ev, 0));
-    }
-  }
+  rc = order_behind_last(c, stream, capturing);
+  if (rc) return fail(rc);
 
   // 3. the kernel(s)
   DsyncArgs a;
@@ -822,46 +1006,8 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     return XMPI_OK;
   }
 
-  // blocking call: wait for the stream (polling: the wake-up latency of hipStreamSynchronize is a visible share
-  // of a small collective), serving the peers meanwhile
-  Backoff bo;
-  bo.idle = idle_hook;
-  bo.idle_arg = c;
-  if (done_dev) {
-    // the closing block of the (last) kernel writes the call's number into a pinned word: no event between the kernel and this
-    // thread.  (The kernel itself gives up on a dead peer -- abort flag, XMPI_TIMEOUT_S -- and still writes the word.)
-    const volatile uint64_t* done = (const volatile uint64_t*)(c->dsync_status + 4);
-    // Safety valve, off the fast path: once the wait is long, ask the stream now and then -- a stream that is idle (or broken)
-    // while the word is still missing must not hang the caller.
-    unsigned spins = 0;
-    while (__atomic_load_n((const uint64_t*)done, __ATOMIC_ACQUIRE) != done_id) {
-      bo.pause();
-      if ((++spins & 0x3fff) == 0) {
-        const hipError_t e = hipStreamQuery(stream);
-        if (e == hipErrorNotReady) {
-          (void)hipGetLastError();
-          continue;
-        }
-        if (e != hipSuccess) return fail(hip_fail(e, "hipStreamQuery", __FILE__, __LINE__));
-        if (__atomic_load_n((const uint64_t*)done, __ATOMIC_ACQUIRE) != done_id) {
-          set_last_error("collective: the stream drained but the closing block never reported (internal)");
-          return fail(XMPI_ERR_STATE);
-        }
-      }
-    }
-  } else {
-    hipEvent_t fin = ev_get(c, false);
-    if (!fin) return fail(XMPI_ERR_HIP);
-    XMPI_HIP(hipEventRecord(fin, stream));
-    for (;;) {
-      const hipError_t e = hipEventQuery(fin);
-      if (e == hipSuccess) break;
-      if (e != hipErrorNotReady) return fail(hip_fail(e, "hipEventQuery", __FILE__, __LINE__));
-      (void)hipGetLastError();
-      bo.pause();
-    }
-    ev_put(c, fin, false);
-  }
+  rc = wait_blocking(c, stream, done_dev != nullptr, done_id);
+  if (rc != XMPI_OK) return fail(rc);
   if (host_out) {
     memcpy(recvbuf, c->host_bounce + xmpi_comm::kHostBounce, recv_bytes);
   } else if (out_src) {

@@ -105,7 +105,10 @@ struct DsyncPage {
 //   [kBoxOff, +8 KiB)         P2PBox box[kDsyncRanks][kP2PBoxes]: box[p][b] is written by rank p only -- a message p sends here
 //   [kAckOff, +8 KiB)         P2PAck ack[kDsyncRanks][kP2PBoxes]: ack[q][b] is written by rank q only -- q's verdict on the
 //                             message this rank put into box b of q's page
-constexpr size_t kDsyncPageBytes = 1u << 20;
+//   [kLLHereOff, +1 KiB)      uint64_t here[kDsyncRanks][8]: here[p][0] is written by rank p only -- "rank p has started epoch e"
+//                             (the LL broadcast, whose data alone does not tell every rank that every other has arrived)
+//   [kLLOff, +2 MiB)          the LL slots (below): slot[p][parity] is written by rank p only
+constexpr size_t kDsyncPageBytes = 4u << 20;
 constexpr int kStepSlots = 2048;
 constexpr size_t kStepOff = 65536;
 constexpr int kP2PBoxes = 8;  // messages in flight per ordered rank pair (stream-ordered Send / Receive)
@@ -138,7 +141,26 @@ struct P2PGo {
   uint64_t pad[1];
 };
 constexpr size_t kGoOff = kTakenOff + sizeof(uint64_t) * kDsyncRanks * kP2PBoxes;
-static_assert(kGoOff + sizeof(P2PGo) * kP2PGoSlots <= kDsyncPageBytes, "flag allocation");
+constexpr size_t kLLHereOff = 768u << 10;
+static_assert(kGoOff + sizeof(P2PGo) * kP2PGoSlots <= kLLHereOff, "flag allocation");
+
+// ---- LL ("low latency") small collectives (ll.hip) -----------------------------------------------------------------------
+// The data IS the flag.  A rank pushes its payload straight into a slot of every peer's flag allocation as 16-byte lines
+//   { data[0..3], flag, data[4..7], flag }      flag = low 32 bits of the collective's epoch
+// written as two 8-byte system-scope stores (8 bytes are atomic everywhere: a half is either the old line or the new one),
+// polls its OWN slots until every line it needs carries this epoch's flag, and folds locally in rank order -- one one-way
+// hop; no announce, no remote read, no translation, no "done" exchange (kdev.h dsync_begin / dsync_end cost two round trips
+// between peers), and the user buffers need not be registered: only their owner's kernel touches them.  What the reference
+// does per message is one message + one ack (network.go:562-571); this is the message alone.
+// Slots are double-buffered by the parity of the epoch.  Rank X may overwrite slot[X][e & 1] of rank Y at epoch e because Y
+// has finished reading epoch e-2: X has finished epoch e-1, EVERY device-synchronised collective completes on a rank only
+// after every peer has started it (the LL forms: a line or a `here` word from everybody; the others: dsync_begin), and Y
+// started e-1 after it finished e-2 (the kernels of one rank run one at a time).  tests/ll_sim.py checks exactly this.
+constexpr size_t kLLOff = 1u << 20;
+constexpr size_t kLLSlotBytes = 64u << 10;          // lines of one (source rank, parity)
+constexpr size_t kLLMaxPayload = kLLSlotBytes / 2;  // 32 KiB per rank
+static_assert(kLLHereOff + 64 * kDsyncRanks <= kLLOff, "flag allocation");
+static_assert(kLLOff + kLLSlotBytes * 2 * kDsyncRanks <= kDsyncPageBytes, "flag allocation");
 
 // what a block of the kernel moves: the fold of the source ranks' buffers (rank order) -> the destination ranks'
 struct DsyncSeg {
@@ -172,6 +194,25 @@ struct DsyncArgs {
   int32_t pad;
   DsyncSeg seg[kDsyncRanks];
 };
+
+enum DsyncLLColl : int32_t { LL_ALLREDUCE = 0, LL_REDUCE = 1, LL_BCAST = 2, LL_ALLGATHER = 3 };
+struct DsyncLLArgs {
+  DsyncPage* page[kDsyncRanks];  // [me]: own flag allocation, others: the peers' as mapped here
+  int32_t me, n;
+  int32_t coll, root;            // DsyncLLColl
+  uint64_t epoch_floor;          // as DsyncArgs: epoch = max(page.epoch_now, epoch_floor) + 1, counted on the device
+  uint64_t* host_epoch;
+  uint64_t* host_done;
+  uint64_t done_value;
+  const void* send;              // this rank's buffers: any memory its own GPU can address
+  void* recv;
+  uint64_t bytes;                // payload per rank (allgather: one rank's block), <= kLLMaxPayload
+  const int32_t* abort_word;
+  uint32_t* status;
+  uint64_t spin_limit;
+};
+hipError_t launch_dsync_ll(const DsyncLLArgs& a, int dtype, int op, hipStream_t stream, hipEvent_t ev_start = nullptr,
+                           hipEvent_t ev_stop = nullptr);
 
 // grid_x blocks per segment (the caller bounds it: every block spins until the peers arrive, so the kernels of
 // all ranks sharing a GPU must be resident together); unroll = 16-byte packets per lane per source in flight

@@ -1,0 +1,280 @@
+// ll.hip -- the LL ("low latency") small collectives: the payload travels as {data, flag} lines pushed into the peers'
+// flag allocations, every rank folds locally in rank order.  One one-way hop per collective; protocol and slot
+// layout: kernels.h (kLLOff ...).
+//
+// What it bypasses: the rendezvous of the zero-copy forms (kdev.h dsync_begin / dsync_end) -- announce -> wait ->
+// translate -> remote READ -> done exchange: two round trips between peers per collective whatever its size.  The
+// reference's per-message cost is one message and one ack (network.go:562-571); a reference user's allreduce is N-1
+// of those per rank (helloworld.go:53-81) plus a host-side sum in rank order -- that sum, bit for bit, is what the fold
+// below computes (oracle/xmpi_oracle.c reduce_ranks).
+//
+// Ordering needs nothing but 8-byte atomicity of stores: a half-line {4 data bytes, flag} is written by ONE 8-byte
+// system-scope store and read by a system-scope load past the caches, so a reader sees either the old half (old flag)
+// or the new one, never a mix.  No fence, no cache maintenance, no second hop.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include "kdev.h"
+#include "kernels.h"
+
+namespace xmpi {
+namespace {
+
+#define XMPI_LAUNCH(kern, grid, block, stream, es, ee, ...)                                  \
+  do {                                                                                       \
+    if ((es) || (ee)) hipExtLaunchKernelGGL(kern, grid, block, 0, stream, es, ee, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__);                      \
+  } while (0)
+
+__device__ __forceinline__ char* ll_slot(DsyncPage* page, int src, uint32_t parity) {
+  return reinterpret_cast<char*>(page) + kLLOff + ((size_t)src * 2 + parity) * kLLSlotBytes;
+}
+__device__ __forceinline__ uint64_t* ll_here(DsyncPage* page, int src) {
+  return reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(page) + kLLHereOff + (size_t)src * 64);
+}
+
+// one line = 8 payload bytes: two 8-byte stores, each carrying its own copy of the flag
+__device__ __forceinline__ void ll_store(char* line, uint64_t data, uint32_t flag) {
+  st_sys64(reinterpret_cast<uint64_t*>(line), (uint64_t)(uint32_t)data | ((uint64_t)flag << 32));
+  st_sys64(reinterpret_cast<uint64_t*>(line) + 1, (data >> 32) | ((uint64_t)flag << 32));
+}
+
+// `valid` (1..8) bytes of this rank's own buffer, the rest zero
+__device__ __forceinline__ uint64_t load8(const char* p, uint32_t valid) {
+  if (valid == 8 && (reinterpret_cast<uintptr_t>(p) & 7u) == 0) return *reinterpret_cast<const uint64_t*>(p);
+  uint64_t v = 0;
+  for (uint32_t i = 0; i < valid; i++) v |= (uint64_t)(uint8_t)p[i] << (8 * i);
+  return v;
+}
+__device__ __forceinline__ void store8(char* p, uint64_t v, uint32_t valid) {
+  if (valid == 8 && (reinterpret_cast<uintptr_t>(p) & 7u) == 0) {
+    *reinterpret_cast<uint64_t*>(p) = v;
+    return;
+  }
+  for (uint32_t i = 0; i < valid; i++) p[i] = (char)(v >> (8 * i));
+}
+
+template <typename T, int OP>
+__device__ __forceinline__ uint64_t combine8(uint64_t a, uint64_t b) {
+  constexpr int N = 8 / sizeof(T);
+  union {
+    uint64_t u;
+    T e[N];
+  } x, y, r;
+  x.u = a;
+  y.u = b;
+#pragma unroll
+  for (int i = 0; i < N; i++) r.e[i] = combine_any<T, OP>(x.e[i], y.e[i]);
+  return r.u;
+}
+
+struct LLShared {
+  uint64_t epoch;
+  uint32_t fail, last;
+};
+
+__device__ __forceinline__ void ll_begin(const DsyncLLArgs& a, LLShared& sh) {
+  if (threadIdx.x == 0) {
+    // the epoch is counted on the device, as in kdev.h dsync_begin: a captured launch that is replayed keeps counting
+    const uint64_t seen = ld_sys64(&a.page[a.me]->epoch_now);
+    sh.epoch = (seen > a.epoch_floor ? seen : a.epoch_floor) + 1;
+    sh.fail = DSYNC_OK;
+  }
+  __syncthreads();
+}
+
+// "I have started epoch e", to every peer (collectives whose data does not reach everybody: broadcast, reduce)
+__device__ __forceinline__ void ll_say_here(const DsyncLLArgs& a, uint64_t epoch) {
+  const int t = threadIdx.x;
+  if (blockIdx.x == 0 && t < a.n && t != a.me) st_sys64(ll_here(a.page[t], a.me), epoch);
+}
+__device__ __forceinline__ void ll_wait_here(const DsyncLLArgs& a, LLShared& sh) {
+  const int t = threadIdx.x;
+  if (blockIdx.x == 0 && t < a.n && t != a.me) {
+    const uint32_t why = spin_until(ll_here(a.page[a.me], t), sh.epoch, a.abort_word, a.spin_limit);
+    if (why != DSYNC_OK) atomicMax(&sh.fail, why);
+  }
+}
+
+// Lines `idx` of the slots of the ranks in `want` (bit per rank), polled until they carry this epoch's flag; out[p] = the
+// 8 payload bytes of rank p's line.  All loads of a round are in flight together.  false: gave up (sh.fail says why).
+__device__ __forceinline__ bool ll_gather(const DsyncLLArgs& a, LLShared& sh, uint32_t want, uint32_t parity, uint32_t flag,
+                                          size_t idx, uint64_t (&out)[kDsyncRanks]) {
+  DsyncPage* mine = a.page[a.me];
+  pack_t v[kDsyncRanks];
+#pragma unroll
+  for (int p = 0; p < kDsyncRanks; p++) v[p] = pack_t{0u, 0u, 0u, 0u};
+  uint32_t pending = want;
+  uint64_t t0 = 0;
+  for (uint32_t k = 0; pending; k++) {
+#pragma unroll
+    for (int p = 0; p < kDsyncRanks; p++)
+      if (pending >> p & 1u) ld_sys128_issue(v[p], reinterpret_cast<const pack_t*>(ll_slot(mine, p, parity) + idx * 16));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int p = 0; p < kDsyncRanks; p += 4)  // (the loads' results may be used from here on)
+      asm volatile("" : "+v"(v[p]), "+v"(v[p + 1]), "+v"(v[p + 2]), "+v"(v[p + 3]));
+#pragma unroll
+    for (int p = 0; p < kDsyncRanks; p++)
+      if ((pending >> p & 1u) && v[p].y == flag && v[p].w == flag) {
+        out[p] = ((uint64_t)v[p].z << 32) | v[p].x;
+        pending &= ~(1u << p);
+      }
+    if (!pending) break;
+    if (k == 0) t0 = wall_clock64();
+    __builtin_amdgcn_s_sleep(1);
+    if ((k & 127u) == 127u) {
+      uint32_t why = DSYNC_OK;
+      if (a.abort_word && __hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) why = DSYNC_ABORTED;
+      else if (a.spin_limit && wall_clock64() - t0 > a.spin_limit) why = DSYNC_TIMEOUT;
+      if (why != DSYNC_OK) {
+        atomicMax(&sh.fail, why);
+        return false;
+      }
+    }
+  }
+  return true;
+}
+
+// Every wave's stores have left; the block that finishes last advances the epoch and tells the host.  No exchange with the
+// peers: nobody reads this rank's buffers, and the slots are safe by the parity argument (kernels.h).
+__device__ __forceinline__ void ll_end(const DsyncLLArgs& a, LLShared& sh) {
+  DsyncPage* mine = a.page[a.me];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  if (gridDim.x > 1) {
+    if (sh.fail != DSYNC_OK) __hip_atomic_fetch_max(&mine->failword, sh.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // (system scope: the result may lie in pinned host memory)
+    if (__hip_atomic_fetch_add(&mine->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) != gridDim.x - 1) return;
+    __hip_atomic_store(&mine->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t f = __hip_atomic_exchange(&mine->failword, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (f > sh.fail) sh.fail = f;
+  }
+  st_sys64(&mine->epoch_now, sh.epoch);
+  if (a.host_epoch) st_sys64(a.host_epoch, sh.epoch);
+  if (sh.fail != DSYNC_OK && a.status) __hip_atomic_store(a.status, sh.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // the blocking caller's word, last (release: the result is where the caller -- host or a later kernel -- will read it)
+  if (a.host_done) __hip_atomic_store(a.host_done, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// allreduce / reduce: thread i owns payload bytes [8 i, 8 i + 8)
+template <typename T, int OP>
+__global__ __launch_bounds__(kBlock) void ll_reduce_kernel(DsyncLLArgs a) {
+  __shared__ LLShared sh;
+  ll_begin(a, sh);
+  const int me = a.me, n = a.n;
+  const uint64_t epoch = sh.epoch;
+  const uint32_t parity = (uint32_t)(epoch & 1u), flag = (uint32_t)epoch ? (uint32_t)epoch : 1u;
+  const bool to_all = a.coll == LL_ALLREDUCE;
+  if (!to_all) ll_say_here(a, epoch);
+  const size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (idx * 8 < a.bytes) {
+    const uint32_t valid = a.bytes - idx * 8 >= 8 ? 8u : (uint32_t)(a.bytes - idx * 8);
+    const uint64_t mine8 = load8(reinterpret_cast<const char*>(a.send) + idx * 8, valid);
+    if (to_all) {
+#pragma unroll
+      for (int d = 1; d < kDsyncRanks; d++) {  // (start with the next rank: the ranks do not all hit rank 0's page first)
+        const int p = (me + d) % n;
+        if (d < n) ll_store(ll_slot(a.page[p], me, parity) + idx * 16, mine8, flag);
+      }
+    } else if (me != a.root) {
+      ll_store(ll_slot(a.page[a.root], me, parity) + idx * 16, mine8, flag);
+    }
+    if (to_all || me == a.root) {
+      uint64_t x[kDsyncRanks];
+      const uint32_t everyone = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
+      if (ll_gather(a, sh, everyone & ~(1u << me), parity, flag, idx, x)) {
+        uint64_t acc = me == 0 ? mine8 : x[0];
+#pragma unroll
+        for (int p = 1; p < kDsyncRanks; p++)
+          if (p < n) acc = combine8<T, OP>(acc, p == me ? mine8 : x[p]);
+        store8(reinterpret_cast<char*>(a.recv) + idx * 8, acc, valid);
+      }
+    }
+  }
+  if (!to_all) ll_wait_here(a, sh);
+  ll_end(a, sh);
+}
+
+// broadcast / allgather: bytes only
+__global__ __launch_bounds__(kBlock) void ll_copy_kernel(DsyncLLArgs a) {
+  __shared__ LLShared sh;
+  ll_begin(a, sh);
+  const int me = a.me, n = a.n;
+  const uint64_t epoch = sh.epoch;
+  const uint32_t parity = (uint32_t)(epoch & 1u), flag = (uint32_t)epoch ? (uint32_t)epoch : 1u;
+  const bool gather = a.coll == LL_ALLGATHER;
+  if (!gather) ll_say_here(a, epoch);
+  const size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (idx * 8 < a.bytes) {
+    const uint32_t valid = a.bytes - idx * 8 >= 8 ? 8u : (uint32_t)(a.bytes - idx * 8);
+    if (gather || me == a.root) {
+      const uint64_t mine8 = load8(reinterpret_cast<const char*>(a.send) + idx * 8, valid);
+#pragma unroll
+      for (int d = 1; d < kDsyncRanks; d++) {
+        const int p = (me + d) % n;
+        if (d < n) ll_store(ll_slot(a.page[p], me, parity) + idx * 16, mine8, flag);
+      }
+      if (gather) store8(reinterpret_cast<char*>(a.recv) + (size_t)me * a.bytes + idx * 8, mine8, valid);
+    }
+    if (gather) {
+      uint64_t x[kDsyncRanks];
+      const uint32_t everyone = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
+      if (ll_gather(a, sh, everyone & ~(1u << me), parity, flag, idx, x)) {
+#pragma unroll
+        for (int p = 0; p < kDsyncRanks; p++)
+          if (p < n && p != me) store8(reinterpret_cast<char*>(a.recv) + (size_t)p * a.bytes + idx * 8, x[p], valid);
+      }
+    } else if (me != a.root) {
+      uint64_t x[kDsyncRanks];
+      if (ll_gather(a, sh, 1u << a.root, parity, flag, idx, x)) {
+        uint64_t got = 0;
+#pragma unroll
+        for (int p = 0; p < kDsyncRanks; p++)
+          if (p == a.root) got = x[p];
+        store8(reinterpret_cast<char*>(a.recv) + idx * 8, got, valid);
+      }
+    }
+  }
+  if (!gather) ll_wait_here(a, sh);
+  ll_end(a, sh);
+}
+
+template <typename T>
+hipError_t ll_op(const DsyncLLArgs& a, int op, dim3 grid, hipStream_t s, hipEvent_t es, hipEvent_t ee) {
+  switch (op) {
+    case OP_SUM: XMPI_LAUNCH((ll_reduce_kernel<T, OP_SUM>), grid, dim3(kBlock), s, es, ee, a); break;
+    case OP_PROD: XMPI_LAUNCH((ll_reduce_kernel<T, OP_PROD>), grid, dim3(kBlock), s, es, ee, a); break;
+    case OP_MIN: XMPI_LAUNCH((ll_reduce_kernel<T, OP_MIN>), grid, dim3(kBlock), s, es, ee, a); break;
+    case OP_MAX: XMPI_LAUNCH((ll_reduce_kernel<T, OP_MAX>), grid, dim3(kBlock), s, es, ee, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_dsync_ll(const DsyncLLArgs& a, int dtype, int op, hipStream_t s, hipEvent_t es, hipEvent_t ee) {
+  if (a.n < 2 || a.n > kDsyncRanks || a.me < 0 || a.me >= a.n || a.root < 0 || a.root >= a.n || a.bytes == 0 ||
+      a.bytes > kLLMaxPayload || !a.send || !a.recv)
+    return hipErrorInvalidValue;
+  const dim3 grid((unsigned)((a.bytes + 8 * kBlock - 1) / (8 * kBlock)));
+  if (a.coll == LL_BCAST || a.coll == LL_ALLGATHER) {
+    XMPI_LAUNCH(ll_copy_kernel, grid, dim3(kBlock), s, es, ee, a);
+    return hipGetLastError();
+  }
+  if (a.coll != LL_ALLREDUCE && a.coll != LL_REDUCE) return hipErrorInvalidValue;
+  switch (dtype) {
+    case DT_U8: return ll_op<uint8_t>(a, op, grid, s, es, ee);
+    case DT_I32: return ll_op<int32_t>(a, op, grid, s, es, ee);
+    case DT_I64: return ll_op<int64_t>(a, op, grid, s, es, ee);
+    case DT_F16: return ll_op<_Float16>(a, op, grid, s, es, ee);
+    case DT_F32: return ll_op<float>(a, op, grid, s, es, ee);
+    case DT_F64: return ll_op<double>(a, op, grid, s, es, ee);
+    case DT_BF16: return ll_op<bf16_t>(a, op, grid, s, es, ee);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace xmpi

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libxmpi.so")
 # enums of include/xmpi.h
 U8, I32, I64, F16, F32, F64, BF16 = range(7)
 SUM, PROD, MIN, MAX = range(4)
-ALGO_AUTO, ALGO_RING, ALGO_RHD, ALGO_DIRECT, ALGO_TREE, ALGO_ZCOPY, ALGO_ZPUSH = range(7)
+ALGO_AUTO, ALGO_RING, ALGO_RHD, ALGO_DIRECT, ALGO_TREE, ALGO_ZCOPY, ALGO_ZPUSH, ALGO_LL = range(8)
 COLL_ALLREDUCE, COLL_ALLGATHER, COLL_BCAST, COLL_REDUCE = range(4)
 PAT_UNIFORM, PAT_INDEX, PAT_CONST, PAT_SIGNED = range(4)
 PROF_REDUCE2, PROF_REDUCEN, PROF_COPY, PROF_PEER, PROF_ZCOPY = range(5)

@@ -1122,6 +1122,202 @@ def sc_sched(comm, args):
     assert out.tobytes() == want.tobytes()
 
 
+def bcast_case(comm, dtype, count, root, algo, seed=40, what="bcast"):
+    rank = comm.rank()
+    es = xmpi.DTYPE_SIZE[dtype]
+    buf = comm.alloc(count * es)
+    comm.fill(buf, count, dtype, xmpi.PAT_UNIFORM, seed + rank)
+    comm.bcast(buf, count, dtype, root, algo)
+    got = buf.download(xmpi.NUMPY_DTYPE[dtype], count)
+    want = oracle.fill(count, dtype, xmpi.PAT_UNIFORM, seed + root)
+    assert got.tobytes() == want.tobytes(), f"{what} root={root} {xmpi.DTYPE_NAME[dtype]} n={count} algo={algo}"
+    buf.free()
+
+
+def reduce_case(comm, dtype, count, root, algo, op=xmpi.SUM, pat=xmpi.PAT_SIGNED, exact=True, what="reduce"):
+    rank, size = comm.rank(), comm.size()
+    es = xmpi.DTYPE_SIZE[dtype]
+    send, recv = comm.alloc(count * es), comm.alloc(count * es)
+    comm.fill(send, count, dtype, pat, 70 + rank)
+    comm.memset(recv, 0x3C, count * es)
+    comm.reduce(send, recv if rank == root else None, count, dtype, op, root, algo)
+    if rank == root:
+        ins = [oracle.fill(count, dtype, pat, 70 + r) for r in range(size)]
+        check_reduced(recv.download(xmpi.NUMPY_DTYPE[dtype], count), ins, dtype, op, exact, f"{what} root={root} algo={algo}")
+    else:
+        assert recv.download(np.uint8, count * es).tobytes() == bytes([0x3C]) * (count * es), "reduce wrote a non-root's buffer"
+    send.free()
+    recv.free()
+
+
+def sc_ll(comm, args):
+    """The LL small collectives (ll.hip): {data, flag} lines pushed into the peers' flag allocations, local rank-order fold --
+    every dtype and operator up to the slot limit, ragged tails, odd alignments, in place, every root; long runs of
+    broadcasts from one root with ranks that dawdle (a slot must not be overwritten under a slow reader); LL and
+    zero-copy collectives mixed on one stream without a host wait; graph replays; host slices; unregistered memory."""
+    import time
+    rank, size = comm.rank(), comm.size()
+    L = xmpi.ALGO_LL
+    if comm.get_param("dsync") != 1:  # ranks that meet on the host: the name means the library's own choice
+        allreduce_case(comm, xmpi.F32, 1000, L, exact=True)
+        allgather_case(comm, xmpi.I64, 100, L)
+        bcast_case(comm, xmpi.U8, 37, size - 1, L)
+        return
+    maxb = comm.get_param("ll_max_bytes")
+    ll_default = comm.get_param("ll_bytes")
+    l0 = comm.get_param("dsync_ll_launches")
+    nrun = 0
+    for dtype in (xmpi.F32, xmpi.I64, xmpi.F16, xmpi.F64, xmpi.I32, xmpi.U8, xmpi.BF16):
+        es = xmpi.DTYPE_SIZE[dtype]
+        for count in args.get("counts", [1, 2, 3, 7, 17, 255, 1000, 4099, maxb // es - 1, maxb // es]):
+            if count * es <= maxb:
+                allreduce_case(comm, dtype, count, L, exact=True)
+                nrun += 1
+    for op in (xmpi.PROD, xmpi.MIN, xmpi.MAX):
+        for dtype in (xmpi.F32, xmpi.I32, xmpi.F16, xmpi.BF16, xmpi.I64, xmpi.F64, xmpi.U8):
+            allreduce_case(comm, dtype, 3001, L, op=op, pattern=xmpi.PAT_SIGNED, exact=True)
+            nrun += 1
+    allreduce_case(comm, xmpi.F32, 4001, L, pattern=xmpi.PAT_SIGNED, inplace=True, misalign=1, exact=True)
+    allreduce_case(comm, xmpi.F16, 3011, L, misalign=3, exact=True)
+    allreduce_case(comm, xmpi.U8, 13, L, misalign=1, inplace=True, exact=True)
+    allreduce_case(comm, xmpi.I64, 1003, L, pattern=xmpi.PAT_UNIFORM, inplace=True, misalign=1, op=xmpi.PROD, exact=True)
+    allreduce_case(comm, xmpi.I64, 4097 if 4097 * 8 <= maxb else 1000, L, pattern=xmpi.PAT_CONST, exact=True)  # x_r = r+1 -> N(N+1)/2
+    nrun += 5
+    assert comm.get_param("dsync_ll_launches") == l0 + nrun, "a named LL allreduce went another way"
+    # named, but too long for the slots: the fold (still rank order)
+    allreduce_case(comm, xmpi.F32, maxb // 4 + 1, L, exact=True)
+    assert comm.get_param("dsync_ll_launches") == l0 + nrun
+    for dtype in (xmpi.I64, xmpi.U8, xmpi.F32):
+        es = xmpi.DTYPE_SIZE[dtype]
+        for count in (1, 5, 13, 1000, 4099, maxb // es):
+            if count * es <= maxb:
+                allgather_case(comm, dtype, count, L)
+    allgather_case(comm, xmpi.I64, 1001, L, inplace=True)
+    allgather_case(comm, xmpi.U8, 1001, L, inplace=True)
+    for root in range(size):
+        for dtype, count in ((xmpi.U8, 1), (xmpi.U8, 37), (xmpi.I64, 4096), (xmpi.F32, 1001), (xmpi.F16, maxb // 2)):
+            bcast_case(comm, dtype, count, root, L)
+        reduce_case(comm, xmpi.F32, 4001, root, L)
+        reduce_case(comm, xmpi.I64, 1, root, L, pat=xmpi.PAT_UNIFORM)
+        reduce_case(comm, xmpi.F16, 5001, root, L, op=xmpi.MAX)
+        reduce_case(comm, xmpi.BF16, 333, root, L, op=xmpi.PROD)
+    # -- many broadcasts from one root, enqueued back to back, while one rank after the other dawdles: a root that ran more
+    #    than one epoch ahead of a reader would overwrite a slot under it (the `here` words are what stops it)
+    st = comm.stream_create()
+    comm.set_param("ll_bytes", maxb)
+    K, n = 24, 1500
+    bufs = [comm.alloc(n * 8) for _ in range(K)]
+    for rounds in range(2):
+        root = (size - 1) if rounds else 0
+        for k in range(K):
+            comm.fill(bufs[k], n, xmpi.I64, xmpi.PAT_UNIFORM, 5000 + 100 * k + rank)
+        comm.sync()
+        for k in range(K):
+            if (k % size) == rank and k % 3 == 0:
+                time.sleep(0.002)
+            comm.bcast_on_stream(bufs[k], n, xmpi.I64, root, st)
+        comm.stream_sync(st)
+        for k in range(K):
+            want = oracle.fill(n, xmpi.I64, xmpi.PAT_UNIFORM, 5000 + 100 * k + root)
+            assert bufs[k].download(np.int64, n).tobytes() == want.tobytes(), f"broadcast {k} of a run from root {root}"
+    # -- reduces to one root likewise (the non-roots never hear from the root except through `here`)
+    outs = [comm.alloc(n * 8) for _ in range(K)]
+    for k in range(K):
+        comm.fill(bufs[k], n, xmpi.I64, xmpi.PAT_UNIFORM, 9000 + 100 * k + rank)
+    comm.sync()
+    for k in range(K):
+        if (k % size) == rank and k % 2 == 0:
+            time.sleep(0.002)
+        comm.reduce_on_stream(bufs[k], outs[k] if rank == 1 % size else None, n, xmpi.I64, xmpi.SUM, 1 % size, st)
+    comm.stream_sync(st)
+    if rank == 1 % size:
+        for k in range(K):
+            want = oracle.reduce_ranks([oracle.fill(n, xmpi.I64, xmpi.PAT_UNIFORM, 9000 + 100 * k + r) for r in range(size)], xmpi.I64, xmpi.SUM)
+            assert outs[k].download(np.int64, n).tobytes() == want.tobytes(), f"reduce {k} of a run"
+    # -- LL and zero-copy collectives alternate on one stream, each consuming the other's result (int64: exact, wraps like Go)
+    m_small, m_big = 1000, 70001
+    a, b = comm.alloc(m_big * 8), comm.alloc(m_big * 8)
+    comm.fill(a, m_big, xmpi.I64, xmpi.PAT_CONST, 0)  # all ones
+    comm.sync()
+    e0 = comm.get_param("dsync_ll_launches")
+    reps = 6
+    for k in range(reps):
+        comm.allreduce_on_stream(a, b, m_small, xmpi.I64, xmpi.SUM, st)   # LL: the head of b = size * head of a
+        comm.allreduce_on_stream(b, a, m_big, xmpi.I64, xmpi.SUM, st)     # fold: a = size * b everywhere
+        comm.bcast_on_stream(a, m_small, xmpi.I64, k % size, st)         # LL
+        comm.allgather_on_stream(a, b, m_small // size, xmpi.I64, st)    # LL: b's head = a's heads (all equal)
+    comm.stream_sync(st)
+    assert comm.get_param("dsync_ll_launches") == e0 + 3 * reps, "AUTO did not take the LL path below ll_bytes"
+    # head: h -> size*h (into b) -> size*(size*h) (into a); tail of a: t -> size * b_tail where b's tail is never written after fill
+    bt = b.download(np.int64, m_big)
+    at = a.download(np.int64, m_big)
+    with np.errstate(over="ignore"):
+        want_head = np.uint64(size) ** np.uint64(2 * reps)
+    assert np.all(at[:m_small].view(np.uint64) == want_head), "LL / fold chain: head"
+    assert np.all(bt[: (m_small // size) * size].view(np.uint64) == want_head), "LL allgather behind a broadcast"
+    a.free()
+    b.free()
+    # -- a captured graph of LL collectives, replayed (the epoch -- and with it the slots' parity and the flag -- is counted
+    #    on the device), ordinary launches in between
+    m = 1200
+    g1, g2 = comm.alloc(m * 8), comm.alloc(m * 8)
+    comm.fill(g1, m, xmpi.I64, xmpi.PAT_CONST, 0)
+    comm.sync()
+    comm.graph_begin(st)
+    comm.allreduce_on_stream(g1, g2, m, xmpi.I64, xmpi.SUM, st)
+    comm.bcast_on_stream(g2, m, xmpi.I64, size - 1, st)
+    comm.allreduce_on_stream(g2, g1, m, xmpi.I64, xmpi.SUM, st)
+    graph = comm.graph_end(st)
+    for k in range(5):
+        comm.graph_launch(graph, st)
+        if k == 2:
+            comm.allreduce_on_stream(g1, g1, m, xmpi.I64, xmpi.MAX, st)  # an ordinary launch between two replays
+    comm.stream_sync(st)
+    assert np.all(g1.download(np.int64, m).view(np.uint64) == np.uint64(size) ** np.uint64(10)), "graph replays of LL collectives"
+    comm.graph_destroy(graph)
+    g1.free()
+    g2.free()
+    comm.set_param("ll_bytes", ll_default)
+    # -- host slices (what the reference's callers pass) and device memory nobody registered
+    for count in (1, 1000, maxb // 4):
+        x = oracle.fill(count, xmpi.F32, xmpi.PAT_SIGNED, 5 + rank)
+        out = np.zeros_like(x)
+        comm.allreduce(x, out, count, xmpi.F32, xmpi.SUM, L)
+        want = oracle.reduce_ranks([oracle.fill(count, xmpi.F32, xmpi.PAT_SIGNED, 5 + r) for r in range(size)], xmpi.F32, 0)
+        assert out.tobytes() == want.tobytes(), f"LL allreduce of host slices n={count}"
+        comm.allreduce(x, x, count, xmpi.F32, xmpi.SUM, L)
+        assert x.tobytes() == want.tobytes(), f"LL allreduce of a host slice in place n={count}"
+    y = oracle.fill(777, xmpi.I64, xmpi.PAT_UNIFORM, 11 + rank)
+    comm.bcast(y, 777, xmpi.I64, size // 2, L)
+    assert y.tobytes() == oracle.fill(777, xmpi.I64, xmpi.PAT_UNIFORM, 11 + size // 2).tobytes(), "LL bcast of a host slice"
+    z = np.zeros(100 * size, dtype=np.int64)
+    comm.allgather(y[:100].copy(), z, 100, xmpi.I64, L)
+    assert z.tobytes() == np.tile(y[:100], size).tobytes(), "LL allgather of host slices"
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    n = 3001
+    src, dst = ctypes.c_void_p(0), ctypes.c_void_p(0)
+    comm.sync()
+    assert hip.hipMalloc(ctypes.byref(src), ctypes.c_size_t(n * 4)) == 0
+    assert hip.hipMalloc(ctypes.byref(dst), ctypes.c_size_t(n * 4)) == 0
+    comm.fill(src.value, n, xmpi.F32, xmpi.PAT_SIGNED, 900 + rank)
+    comm.set_param("ll_bytes", maxb)
+    b0 = comm.get_param("dsync_bounced")
+    comm.allreduce_on_stream(src.value, dst.value, n, xmpi.F32, xmpi.SUM, st)
+    comm.stream_sync(st)
+    out = np.empty(n, dtype=np.float32)
+    xmpi._check(xmpi.lib().xmpi_memcpy(comm.handle, out.ctypes.data, dst.value, n * 4), "download")
+    want = oracle.reduce_ranks([oracle.fill(n, xmpi.F32, xmpi.PAT_SIGNED, 900 + r) for r in range(size)], xmpi.F32, xmpi.SUM)
+    assert out.tobytes() == want.tobytes(), "LL allreduce of unregistered device memory"
+    assert comm.get_param("dsync_bounced") == b0, "LL lines need no registered stand-in"
+    comm.set_param("ll_bytes", ll_default)
+    comm.barrier()
+    assert hip.hipFree(src) == 0 and hip.hipFree(dst) == 0
+    comm.stream_destroy(st)
+    for x in bufs + outs:
+        x.free()
+
+
 def sc_split(comm, args):
     """The meet / body / done form of the zero-copy collectives, forced for every size (dsync_split_bytes = 1): the same
     bits as the one-kernel form, rank order, in place, odd alignments; mixed freely with one-kernel collectives."""
@@ -1309,6 +1505,7 @@ def sc_tune(comm, args):
 
 
 SCENARIOS = {
+    "ll": sc_ll,
     "sched": sc_sched,
     "split": sc_split,
     "multistream": sc_multistream,

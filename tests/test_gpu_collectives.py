@@ -195,6 +195,18 @@ def test_stepped_kernels(size):
     run_ranks("sched", size, args, timeout=900)
 
 
+@pytest.mark.parametrize("size", [2, 3, 4, 5, 8])
+def test_ll_small_collectives(size):
+    """LL lines (ll.hip): allreduce / reduce / bcast / allgather in one one-way hop, bit-identical to the rank-order oracle"""
+    args = {} if size in (2, 8) else {"counts": [1, 3, 17, 1000, 4099]}
+    run_ranks("ll", size, args, timeout=900)
+
+
+def test_ll_named_with_ranks_as_threads():
+    """ranks that meet on the host: XMPI_ALGO_LL means the library's own choice"""
+    run_threads("ll", 3)
+
+
 def test_staged_schedules_between_processes():
     """XMPI_DSYNC=0: RING / RHD / TREE between processes are the host-driven step tables again"""
     run_ranks("allreduce_small", 4, {"counts": [1, 4099, 65536 + 5], "dtypes": [4, 2]}, timeout=600, env={"XMPI_DSYNC": "0"})
