@@ -567,9 +567,6 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
     if (c->p2p_tickets) (void)hipFree(c->p2p_tickets);
     if (c->p2p_done) (void)hipHostFree(c->p2p_done);
     if (c->p2p_cmd) (void)hipHostFree(c->p2p_cmd);
-  if (c->p2p_bounce) (void)hipHostFree(c->p2p_bounce);
-  c->p2p_bounce = c->p2p_bounce_dev = nullptr;
-    if (c->p2p_bounce) (void)hipHostFree(c->p2p_bounce);
     if (c->p2p_rec) (void)hipFree(c->p2p_rec);
     if (c->dev_words) (void)hipFree(c->dev_words);
     (void)hipGetLastError();
@@ -800,6 +797,8 @@ int xmpi_finalize(xmpi_comm* c) {
   if (c->p2p_tickets) (void)hipFree(c->p2p_tickets);
   if (c->p2p_done) (void)hipHostFree(c->p2p_done);
   if (c->p2p_cmd) (void)hipHostFree(c->p2p_cmd);
+  if (c->p2p_bounce) (void)hipHostFree(c->p2p_bounce);  // (engine.cpp p2p_recv: device -> host slice through pinned memory)
+  c->p2p_bounce = c->p2p_bounce_dev = nullptr;
   if (c->p2p_rec) (void)hipFree(c->p2p_rec);
   if (c->window) pool_release(c->window);  // exported memory is never given back by the runtime: the next communicator reuses it
   if (c->temp) (void)hipFree(c->temp);
@@ -1463,6 +1462,7 @@ int xmpi_set_param(xmpi_comm* c, const char* name, long value) {
   else if (n == "dsync_grid") c->dsync_grid_cap = std::max<long>(0, value);
   else if (n == "dsync_unroll") c->dsync_unroll = std::max<long>(1, std::min<long>(2, value));
   else if (n == "dsync_tiles") c->dsync_tiles = std::max<long>(1, value);
+  else if (n == "p2p_grid_cap") c->p2p_grid_cap = std::max<long>(0, std::min<long>(value, 4096));
   else if (n == "ll_bytes") c->ll_bytes = std::max<long>(0, std::min<long>((long)kLLMaxPayload, value));  // untuned AUTO: LL lines up to here
   else if (n == "dsync_split_bytes") c->dsync_split_bytes = std::max<long>(0, value);  // 0: always one kernel
   else if (n == "sched_channels") c->sched_channels = std::max<long>(0, value);
@@ -1508,6 +1508,7 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
   if (n == "dsync_sharers") return c->dsync_sharers;
   if (n == "dsync_unroll") return c->dsync_unroll;
   if (n == "dsync_tiles") return c->dsync_tiles;
+  if (n == "p2p_grid_cap") return c->p2p_grid_cap;
   if (n == "ll_bytes") return c->ll_bytes;
   if (n == "ll_max_bytes") return (long)kLLMaxPayload;
   if (n == "dsync_ll_launches") return (long)c->dsync_ll_launches;
@@ -1618,6 +1619,7 @@ int xmpi_link_probe(xmpi_comm* c, int peer, size_t bytes, int engine, int iters,
   ev_put(c, a, true);
   ev_put(c, b, true);
   *gbps = ms > 0 ? (double)bytes * iters / (ms * 1e-3) / 1e9 : 0.0;
+  if (bytes >= ((size_t)1 << 20)) c->link_gbps[peer] = std::max(c->link_gbps[peer], *gbps);  // (sizes the pull kernel's grid)
   return XMPI_OK;
 }
 
@@ -1862,7 +1864,7 @@ int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
                              {XMPI_ALGO_ZCOPY, 1, u0},
                              {XMPI_ALGO_ZPUSH, 0, u0},
                              {XMPI_ALGO_RING, 0, u0}};
-  cands.push_back({(c->size & (c->size - 1)) == 0 ? XMPI_ALGO_RHD : -1, 0, u0});  // (-1: a place holder -- candidate numbers are fixed)
+  cands.push_back({XMPI_ALGO_RHD, 0, u0});
   cands.push_back({XMPI_ALGO_LL, 0, u0});                                          // candidate 6
   const long keep_split = c->dsync_split_bytes, keep_unroll = c->dsync_unroll;
   const bool keep_tuned = c->tuned;
@@ -1961,9 +1963,9 @@ int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
 int xmpi_sched_dump(int sched, int size, int rank, int root, int pieces, size_t count, size_t elem_size, int nchan, int channel,
                     char* out, size_t cap) {
   if (size < 1 || size > kMaxRanks || rank < 0 || rank >= size || root < 0 || root >= size || elem_size < 1 || nchan < 1 ||
-      nchan > kMaxSchedChannels || channel < 0 || channel >= nchan || sched < SCHED_RING_ALLREDUCE || sched > SCHED_TREE_BCAST)
+      nchan > kMaxSchedChannels || channel < 0 || channel >= nchan || sched < SCHED_RING_ALLREDUCE || sched > SCHED_TREE_REDUCE ||
+      (sched == SCHED_TREE_REDUCE && pieces > 127))  // (a step number must fit the low byte of a flag word)
     return XMPI_ERR_ARG;
-  if (sched == SCHED_RHD_ALLREDUCE && (size & (size - 1)) != 0) return XMPI_ERR_UNSUPPORTED;
   DsyncSchedArgs a;
   memset(&a, 0, sizeof a);
   a.d.me = rank;

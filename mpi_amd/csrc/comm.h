@@ -121,6 +121,8 @@ struct xmpi_comm {
   uint64_t* p2p_done_dev = nullptr;
   uint64_t p2p_done_next = 0;
   std::atomic<uint64_t> p2p_pull_next{0};
+  long p2p_grid_cap = 0;             // blocks of the pull kernel; 0 = from where the payload lies (engine.cpp p2p_pull_cap)
+  double link_gbps[xmpi::kMaxRanks] = {0};  // what xmpi_link_probe measured towards each peer (best of its calls)
   long p2p_kernel_ack = 1;           // blocking Receive: one kernel copies AND acks (0: hipMemcpyAsync / copy kernel + event + host ack)
   long p2p_agent_us = 40;            // ... by a kernel that stays this long after a message (the receive agent, sched.hip): the next
                                      // Receive hands it a command instead of launching again (0: one launch per message)

@@ -625,7 +625,7 @@ bool dsync_takes(const xmpi_comm* c, int coll, int algo) {
     case XMPI_ALGO_LL: return true;
     case XMPI_ALGO_RING: return coll == COLL_ALLREDUCE || coll == COLL_ALLGATHER;  // the stepped kernels (sched.hip)
     case XMPI_ALGO_RHD: return coll == COLL_ALLREDUCE;
-    case XMPI_ALGO_TREE: return coll == COLL_BCAST;
+    case XMPI_ALGO_TREE: return coll == COLL_BCAST || coll == COLL_REDUCE;
     default: return false;
   }
 }
@@ -685,9 +685,9 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     if (send_bytes <= kLLMaxPayload) return dsync_ll(c, coll, root, sendbuf, recvbuf, count, dtype, op, stream, blocking, capturing);
     algo = XMPI_ALGO_ZCOPY;  // named, but too long for the slots: the fold (the same decision on every rank)
   }
-  if (algo == XMPI_ALGO_RHD && (N & (N - 1)) != 0) algo = XMPI_ALGO_RING;  // halving needs a power of two
   const bool stepped = (algo == XMPI_ALGO_RING && (coll == COLL_ALLREDUCE || coll == COLL_ALLGATHER)) ||
-                       (algo == XMPI_ALGO_RHD && coll == COLL_ALLREDUCE) || (algo == XMPI_ALGO_TREE && coll == COLL_BCAST);
+                       (algo == XMPI_ALGO_RHD && coll == COLL_ALLREDUCE) ||
+                       (algo == XMPI_ALGO_TREE && (coll == COLL_BCAST || coll == COLL_REDUCE));
   const bool push = algo == XMPI_ALGO_ZPUSH;
 
   // 1. buffers the peers can map.  Anything else -- host memory, device memory that was never registered --
@@ -739,6 +739,17 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     r.recv = r.tmp_recv;
     if (!zc_export(c, r.recv, recv_bytes, &r.rref)) return fail(XMPI_ERR_HIP);
     c->dsync_bounced++;
+  }
+
+  // binary-tree reduce: an inner node that is not the root accumulates its subtree's partial result in a block the parent
+  // can read (sched_steps.h SCHED_TREE_REDUCE); the caller's receive buffer means nothing there
+  if (stepped && coll == COLL_REDUCE && me != root && 2 * ((me - root + N) % N) + 1 < N) {
+    if (capturing) return no_standin();
+    void* acc = heap_alloc(c->device, send_bytes);
+    if (!acc) return fail(XMPI_ERR_NOMEM);
+    lent.push_back(acc);
+    r.recv = acc;
+    if (!zc_export(c, r.recv, send_bytes, &r.rref)) return fail(XMPI_ERR_HIP);
   }
 
   // where the result of a stand-in goes home from (step 4), and how: a host slice of a blocking call comes out through pinned
@@ -855,12 +866,18 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
       sa.sched = SCHED_RHD_ALLREDUCE;
       step_bytes = send_bytes / 2;
       traffic = 5 * (send_bytes - send_bytes / (size_t)N);  // halving: 3 x (S/2 + S/4 + ...), doubling: 2 x the same
+      if ((N & (N - 1)) != 0) traffic += 3 * send_bytes;     // (no power of two: the fold-in / fold-out steps, at most)
     } else {
-      sa.sched = SCHED_TREE_BCAST;
+      sa.sched = coll == COLL_BCAST ? SCHED_TREE_BCAST : SCHED_TREE_REDUCE;
       const size_t piece = (size_t)std::max<long>(4096, c->tree_piece_bytes);
       sa.pieces = (int)std::min<size_t>(32, std::max<size_t>(1, (send_bytes + piece - 1) / piece));
       step_bytes = (send_bytes + (size_t)sa.pieces - 1) / (size_t)sa.pieces;
-      traffic = me == root ? 0 : 2 * send_bytes;
+      if (coll == COLL_BCAST) {
+        traffic = me == root ? 0 : 2 * send_bytes;
+      } else {  // 2 reads + 1 write per child
+        const int v = (me - root + N) % N;
+        traffic = 3 * send_bytes * (size_t)((2 * v + 1 < N) + (2 * v + 2 < N));
+      }
     }
     const size_t tiles = std::max<size_t>(1, (step_bytes + kSchedTileBytes - 1) / kSchedTileBytes);
     long workers = c->sched_grid > 0 ? c->sched_grid : (long)std::min<size_t>(tiles, (size_t)dsync_block_cap(c));
@@ -1127,7 +1144,7 @@ int dsync_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest,
   }
   P2PArgs a;
   p2p_fill(c, &a, dest, tag, dtype);
-  a.seq = ((c->dsync_tag & 0xffffffffull) << 32) | ++c->p2p_out_seq[dest];
+  a.seq = ((c->dsync_tag & 0xffffffffull) << 32) | (c->p2p_out_seq[dest] + 1);  // (consumed below, once the kernel is enqueued)
   a.bytes = bytes;
   a.gen = ref.gen;
   a.slot = (uint64_t)slot;
@@ -1136,7 +1153,13 @@ int dsync_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest,
   const int ds = p2p_done_slot(c, &id);
   a.host_done = c->p2p_done_dev + 4 * ds;
   a.done_value = id;
-  XMPI_HIP(launch_p2p_send(a, stream));
+  if (launch_p2p_send(a, stream) != hipSuccess) {
+    // message n was never posted: its number must not be consumed (message n + 8 would wait for its ack for ever)
+    const int rc = hip_fail(hipGetLastError(), "p2p send kernel", __FILE__, __LINE__);
+    for (void* p : lent) (void)heap_free(p);
+    return rc;
+  }
+  ++c->p2p_out_seq[dest];
   c->p2p_pending.push_back({ds, id, lent});
   return XMPI_OK;
 }
@@ -1152,7 +1175,9 @@ int dsync_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, in
   p2p_fill(c, &a, src, tag, dtype);
   a.bytes = cap_bytes;
   a.buf = buf;
-  a.op_id = ++c->p2p_op_id;
+  // unique per PAGE, not per communicator: the page is pooled and never cleared, a later communicator's first receive must
+  // not match the go record an earlier one left behind (the communicator number is what a.seq carries as well)
+  a.op_id = ((c->dsync_tag & 0xffffffffull) << 32) | (++c->p2p_op_id & 0xffffffffull);
   uint64_t id = 0;
   const int ds = p2p_done_slot(c, &id);
   a.host_done = c->p2p_done_dev + 4 * ds;

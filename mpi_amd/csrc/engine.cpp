@@ -729,6 +729,21 @@ int await_ack(xmpi_comm* c, MailEntry* m, int dest, int tag) {
 
 }  // namespace
 
+// Blocks of the pull kernel (sched.hip p2p_pull_kernel: 16 KiB in flight per block).  What bounds a message is the memory
+// it comes out of: the sender's HBM when both ranks sit on one GPU -- the whole chip may pull (1024 blocks: 16 MiB went from
+// 680 GB/s with 128 blocks to what the copy kernels reach) -- or ONE link when they do not: blocks beyond bandwidth x latency
+// in flight add nothing but contention, so the cap follows the rate xmpi_link_probe measured for this pair (link_gbps; the
+// nominal 64 GB/s per direction until it has run) at ~4 us of round trip, with a margin of 2.  "p2p_grid_cap" overrides.
+static long p2p_pull_cap(const xmpi_comm* c, int peer) {
+  if (c->p2p_grid_cap > 0) return c->p2p_grid_cap;
+  const RankInfo* a = c->ctl->info(c->rank);
+  const RankInfo* b = c->ctl->info(peer);
+  if (strncmp(a->busid, b->busid, sizeof a->busid) == 0) return 1024;
+  const double gbps = c->link_gbps[peer] > 0 ? c->link_gbps[peer] : 64.0;
+  const long blocks = (long)(2.0 * gbps * 1e9 * 4e-6 / 16384.0) + 1;
+  return std::max<long>(16, std::min<long>(blocks, 256));
+}
+
 constexpr size_t kP2PBounceBytes = (size_t)256 << 10;  // device -> host slice through pinned memory up to this length
 
 // ---- the receive agent: a copy-and-ack kernel that lingers (sched.hip p2p_agent_kernel) ------------------------------------
@@ -736,7 +751,11 @@ constexpr size_t kP2PBounceBytes = (size_t)256 << 10;  // device -> host slice t
 // caller launches the ordinary kernel (the agent could not be started).
 static bool agent_submit(xmpi_comm* c, void* dst, const void* from, size_t bytes, MailEntry* m) {
   if (c->p2p_agent_us <= 0 || !c->p2p_cmd_dev || !c->p2p_rec || !c->ctl_dev || bytes == 0 || bytes > ((size_t)512 << 10)) return false;  // (longer messages: the ordinary kernel's wide grid)
-  std::lock_guard<std::mutex> g(c->agent_mu);
+  // One command at a time.  The reference promises concurrent Receives on different {peer, tag} (mpi.go:121-125): a Receive
+  // that finds the agent busy with somebody else's message does not queue up behind it -- the launch-per-message kernel on
+  // this call's own stream serves it in parallel.
+  std::unique_lock<std::mutex> g(c->agent_mu, std::try_to_lock);
+  if (!g.owns_lock()) return false;
   volatile uint64_t* cmd = c->p2p_cmd;
   const uint64_t seq = ++c->agent_seq;
   const uint64_t mail_off = (uint64_t)((char*)&m->state - (char*)c->ctl->base());
@@ -772,7 +791,8 @@ static bool agent_submit(xmpi_comm* c, void* dst, const void* from, size_t bytes
     return false;
   }
   Backoff bo;
-  for (;;) {
+  const double t0 = now_seconds();
+  for (unsigned spins = 1;; spins++) {
     if (__atomic_load_n((const uint64_t*)&cmd[6], __ATOMIC_ACQUIRE) == seq) break;  // copied and acknowledged
     if (__atomic_load_n((const uint64_t*)&cmd[7], __ATOMIC_ACQUIRE) != 0) {  // the agent had gone (its patience ran out)
       if (__atomic_load_n((const uint64_t*)&cmd[6], __ATOMIC_ACQUIRE) == seq) break;
@@ -780,6 +800,29 @@ static bool agent_submit(xmpi_comm* c, void* dst, const void* from, size_t bytes
       if (!launch()) {  // (cannot happen after a launch that worked; give the message to the ordinary kernel)
         __atomic_store_n((uint64_t*)&cmd[0], 0, __ATOMIC_RELEASE);
         --c->agent_seq;
+        return false;
+      }
+    }
+    // Off the fast path, now and then: an agent that faulted (an unmapped payload), a queue that was torn down or a job that
+    // was aborted must not leave this thread spinning with the lock held.  The stream is idle only when the agent has ended:
+    // if it ended without serving this command and without saying "gone", it is broken -- the ordinary kernel takes over
+    // (and reports whatever is wrong with the payload through its own error path).
+    if ((spins & 0xfff) == 0) {
+      bool give_up = c->ctl->aborted() || (c->timeout_s > 0 && now_seconds() - t0 > (double)c->timeout_s);
+      if (!give_up) {
+        const hipError_t e = hipStreamQuery(c->agent_stream);
+        if (e != hipErrorNotReady) {
+          (void)hipGetLastError();
+          give_up = __atomic_load_n((const uint64_t*)&cmd[6], __ATOMIC_ACQUIRE) != seq &&
+                    __atomic_load_n((const uint64_t*)&cmd[7], __ATOMIC_ACQUIRE) == 0;
+        } else {
+          (void)hipGetLastError();
+        }
+      }
+      if (give_up) {
+        if (__atomic_load_n((const uint64_t*)&cmd[6], __ATOMIC_ACQUIRE) == seq) break;
+        __atomic_store_n((uint64_t*)&cmd[0], 0, __ATOMIC_RELEASE);  // the doorbell is withdrawn: nobody may act on it any more
+        c->agent_running = false;
         return false;
       }
     }
@@ -1282,8 +1325,8 @@ int p2p_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int 
         pa.mail_state = (uint32_t*)(mdev + ((char*)&m->state - (char*)m));
         pa.mail_status = (int32_t*)(mdev + ((char*)&m->status - (char*)m));
         pa.mail_done_value = MAIL_DONE;
-        long gx = (long)((bytes + 16383) >> 14);  // a 16 KiB tile per block and pass, at most 128 blocks: a message is not a collective
-        gx = std::max<long>(1, std::min<long>(gx, 128));
+        long gx = (long)((bytes + 16383) >> 14);  // a 16 KiB tile per block and pass; how many blocks: p2p_pull_cap
+        gx = std::max<long>(1, std::min<long>(gx, p2p_pull_cap(c, src)));
         hipError_t e = launch_p2p_pull(pa, (int)gx, lease.s);
         if (e != hipSuccess) rc = hip_fail(e, "p2p pull kernel", __FILE__, __LINE__);
         bo.n = 0;

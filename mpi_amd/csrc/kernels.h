@@ -130,7 +130,7 @@ constexpr size_t kAckOff = kBoxOff + sizeof(P2PBox) * kDsyncRanks * kP2PBoxes;
 //   [kTakenOff, +1 KiB)   uint64_t taken[kDsyncRanks][kP2PBoxes]: number of the last message consumed from box b of rank p
 //   [kGoOff, +2 KiB)      P2PGo go[kP2PGoSlots]: what block 0 of a receive kernel found, for its other blocks
 constexpr size_t kTakenOff = kAckOff + sizeof(P2PAck) * kDsyncRanks * kP2PBoxes;
-constexpr int kP2PGoSlots = 16;
+constexpr int kP2PGoSlots = 64;  // >= the operations that may be outstanding at once (xmpi_comm::kP2PDoneSlots): a record is never reused under a waiter
 struct P2PGo {
   uint64_t id;      // written last: the receive operation this belongs to
   uint64_t src;     // payload address as mapped here
@@ -252,9 +252,10 @@ hipError_t launch_dsync_done(const DsyncArgs& a, const DsyncResolved* res, hipSt
 // included) and writes only local memory; the flag says "my step k is in my buffer".
 enum DsyncSched : int32_t {
   SCHED_RING_ALLREDUCE = 1,  // reduce-scatter + allgather round each channel's ring, 2(N-1) steps
-  SCHED_RHD_ALLREDUCE = 2,   // recursive halving + doubling, 2 log2 N steps (N a power of two)
+  SCHED_RHD_ALLREDUCE = 2,   // recursive halving + doubling, 2 log2 N steps; N no power of two: a fold-in and a fold-out step more
   SCHED_RING_ALLGATHER = 3,  // N steps (the first is the local copy of the own block)
   SCHED_TREE_BCAST = 4,      // binary tree rooted at `root`, the buffer cut into `pieces` pipelined pieces
+  SCHED_TREE_REDUCE = 5,     // the same tree upwards: every node folds its children's partial results into its own, piece by piece
 };
 constexpr int kMaxSchedChannels = 8;
 struct DsyncSchedArgs {
@@ -290,7 +291,8 @@ struct P2PArgs {
   uint64_t spin_limit;
   uint64_t* host_done;   // pinned host: [0] = done flag (written last), [1] = status, [2] = bytes received; may be null
   uint64_t done_value;   // what to write into host_done[0]
-  uint64_t op_id;        // receive: number of this operation (go slot = op_id % kP2PGoSlots), never 0
+  uint64_t op_id;        // receive: (communicator number << 32) | number of this operation -- unique per PAGE, which outlives
+                         // communicators and is never cleared; go slot = op_id % kP2PGoSlots
 };
 hipError_t launch_p2p_send(const P2PArgs& a, hipStream_t stream);
 // the copy of a blocking Receive the host has already matched: dst = src, then the acks (see sched.hip)

@@ -342,15 +342,24 @@ __global__ __launch_bounds__(kBlock) void p2p_recv_kernel(P2PArgs a) {
       int found = -1;
       const uint64_t t0 = wall_clock64();
       for (uint32_t k = 1;; k++) {
-        uint64_t best = ~0ull;
+        uint64_t best = ~0ull, best_taken = 0;
         for (int b = 0; b < kP2PBoxes; b++) {  // the oldest unconsumed message with this tag
           const uint64_t s = __hip_atomic_load(&boxes[b].seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-          if ((s >> 32) != (a.comm_tag & 0xffffffffull) || s <= ld_sys64(&taken[b]) || s >= best) continue;  // not this communicator's / consumed
+          const uint64_t tk = ld_sys64(&taken[b]);
+          if ((s >> 32) != (a.comm_tag & 0xffffffffull) || s <= tk || s >= best) continue;  // not this communicator's / consumed
           if ((int32_t)(uint32_t)ld_sys64(&boxes[b].tag) != a.tag) continue;
           best = s;
+          best_taken = tk;
           found = b;
         }
-        if (found >= 0) break;
+        if (found >= 0) {
+          // claim it: receives for the same (source, tag) enqueued on DIFFERENT streams run concurrently and may both have
+          // picked this box -- the compare-and-swap lets one of them have it, the other looks again
+          uint64_t expect = best_taken;
+          if (__hip_atomic_compare_exchange_strong(&taken[found], &expect, best, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+          found = -1;
+          continue;
+        }
         __builtin_amdgcn_s_sleep(1);
         if ((k & 63u) == 0) {
           if (a.abort_word && __hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
@@ -374,7 +383,6 @@ __global__ __launch_bounds__(kBlock) void p2p_recv_kernel(P2PArgs a) {
           src = translate(a.comm_tag, a.table, a.my_page, a.peer, ld_sys64(&box->slot), ld_sys64(&box->gen), ld_sys64(&box->off));
           if (!src) status = 0x100u + DSYNC_UNMAPPED;
         }
-        st_sys64(&taken[found], seq);
       }
       s_src = src;
       s_bytes = bytes;
@@ -390,12 +398,29 @@ __global__ __launch_bounds__(kBlock) void p2p_recv_kernel(P2PArgs a) {
         __hip_atomic_store(&go->id, a.op_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       }
     } else {
-      while (__hip_atomic_load(&go->id, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != a.op_id) __builtin_amdgcn_s_sleep(1);
-      s_src = ld_sys64(&go->src);
-      s_bytes = ld_sys64(&go->bytes);
-      s_status = ld_sys64(&go->status);
-      s_seq = ld_sys64(&go->seq);
-      s_box = (int)(int64_t)ld_sys64(&go->box);
+      // (block 0 always writes the record -- also when it gave up: this wait needs no clock of its own, only the job's abort
+      // flag in case block 0 never became resident)
+      uint32_t why = DSYNC_OK;
+      for (uint32_t k = 1; __hip_atomic_load(&go->id, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != a.op_id; k++) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((k & 1023u) == 0 && a.abort_word && __hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
+          why = DSYNC_ABORTED;
+          break;
+        }
+      }
+      if (why == DSYNC_OK) {
+        s_src = ld_sys64(&go->src);
+        s_bytes = ld_sys64(&go->bytes);
+        s_status = ld_sys64(&go->status);
+        s_seq = ld_sys64(&go->seq);
+        s_box = (int)(int64_t)ld_sys64(&go->box);
+      } else {  // copy nothing; the ticket below is still taken (block 0, if it ever runs, must not wait for this one)
+        s_src = 0;
+        s_bytes = 0;
+        s_status = 0x100u + why;
+        s_seq = 0;
+        s_box = -1;
+      }
     }
   }
   __syncthreads();

@@ -34,16 +34,23 @@ XMPI_HD void chunk_bytes(uint64_t count, uint32_t es, int parts, int j, uint64_t
   *hi = (b < count ? b : count) * es;
 }
 
+// recursive halving + doubling runs among the P = 2^l <= n ranks that are left when the first 2 (n - P) ranks have paired up
+XMPI_HD int rhd_levels(int n) {
+  int l = 0;
+  while ((2 << l) <= n) l++;
+  return l;
+}
+
 XMPI_HD int sched_nsteps(const DsyncSchedArgs& a) {
   const int n = a.d.n;
   switch (a.sched) {
     case SCHED_RING_ALLREDUCE: return 2 * (n - 1);
     case SCHED_RHD_ALLREDUCE: {
-      int l = 0;
-      while ((1 << l) < n) l++;
-      return 2 * l;
+      const int l = rhd_levels(n);
+      return 2 * l + ((1 << l) == n ? 0 : 2);  // no power of two: a fold-in step in front, a fold-out step behind
     }
     case SCHED_RING_ALLGATHER: return n;
+    case SCHED_TREE_REDUCE: return 2 * a.pieces;  // per piece: one sub-step per child
     default: return a.pieces;
   }
 }
@@ -103,16 +110,52 @@ XMPI_HD void sched_step(const DsyncSchedArgs& a, const uint64_t* send, const uin
     return;
   }
   if (a.sched == SCHED_RHD_ALLREDUCE) {
-    int l = 0;
-    while ((1 << l) < n) l++;
-    // the ranges: R_0 = the buffer, R_{k+1} = the half of R_k this rank keeps at halving step k
-    const int level = g <= l ? g - 1 : 2 * l - g;  // halving step k = g-1; doubling undoes level 2l-g
-    uint64_t lo = 0, hi = a.count * es;
+    // n = P + R with P = 2^l: the first 2R ranks pair up (2j, 2j+1).  Step 1 (only when R > 0): the odd one folds its even
+    // neighbour's input into its own -- (x_2j op x_2j+1), lower rank first -- and the even one sits out; the P ranks that are
+    // left (virtual rank v: 2v+1 for v < R, v + R otherwise) halve and double as a power of two does; in a last step the even
+    // ranks fetch the result from their neighbours.  With R > 0 every rank's accumulator is its RECEIVE buffer from step 1 on
+    // (an unpaired rank copies its input there), so the halving steps never read a send buffer.
+    const int l = rhd_levels(n);
+    const int P = 1 << l, R = n - P, off = R ? 1 : 0;
+    const bool idle = me < 2 * R && (me & 1) == 0;
+    const int vr = me < 2 * R ? me / 2 : me - R;
+    const uint64_t whole = a.count * es;
+    if (R && g == 1) {
+      if (idle) return;
+      st->lo = 0;
+      st->hi = whole;
+      if (me < 2 * R) {
+        st->ns = 2;
+        st->A = send[me - 1];
+        st->B = send[me];
+      } else {
+        st->A = send[me];
+        st->ns = st->A == st->D ? 0 : 1;
+      }
+      const int v1 = vr ^ (P >> 1);
+      st->sig[0] = v1 < R ? 2 * v1 + 1 : v1 + R;
+      return;
+    }
+    if (R && g == 2 * l + 2) {
+      if (!idle) return;
+      st->wait_rank = me + 1;
+      st->wait_val = (uint32_t)(2 * l + 1);
+      st->ns = 1;
+      st->A = recv[me + 1];
+      st->lo = 0;
+      st->hi = whole;
+      return;
+    }
+    if (idle) return;
+    const int k = g - off;  // 1 ... 2l: the step among the P ranks
+    // the ranges: R_0 = the buffer, R_{j+1} = the half of R_j this rank keeps at halving step j
+    const int level = k <= l ? k - 1 : 2 * l - k;  // halving step j = k-1; doubling undoes level 2l-k
+    uint64_t lo = 0, hi = whole;
     uint64_t klo = 0, khi = 0, olo = 0, ohi = 0;  // kept half / other half at `level`
-    for (int k = 0; k <= level; k++) {
-      const int d = n >> (k + 1);
+    for (int j = 0; j <= level; j++) {
+      const int d = P >> (j + 1);
       const uint64_t mid = lo + (((hi - lo) / 2) & ~(uint64_t)15);
-      if (me & d) {
+      if (vr & d) {
         klo = mid, khi = hi, olo = lo, ohi = mid;
       } else {
         klo = lo, khi = mid, olo = mid, ohi = hi;
@@ -120,16 +163,20 @@ XMPI_HD void sched_step(const DsyncSchedArgs& a, const uint64_t* send, const uin
       lo = klo;
       hi = khi;
     }
-    const int p = me ^ (n >> (level + 1));
+    const int vp = vr ^ (P >> (level + 1));
+    const int p = vp < R ? 2 * vp + 1 : vp + R;
     if (g >= 2) {
       st->wait_rank = p;
       st->wait_val = (uint32_t)(g - 1);
     }
-    if (g < 2 * l) {
-      const int nlevel = g + 1 <= l ? g : 2 * l - g - 1;
-      st->sig[0] = me ^ (n >> (nlevel + 1));
+    if (k < 2 * l) {
+      const int nlevel = k + 1 <= l ? k : 2 * l - k - 1;
+      const int vn = vr ^ (P >> (nlevel + 1));
+      st->sig[0] = vn < R ? 2 * vn + 1 : vn + R;
+    } else if (me < 2 * R) {
+      st->sig[0] = me - 1;  // my even neighbour fetches the result
     }
-    if (g <= l) {  // halving: my half of the partner's accumulator joins mine
+    if (k <= l) {  // halving: my half of the partner's accumulator joins mine
       st->ns = 2;
       st->lo = klo;
       st->hi = khi;
@@ -141,6 +188,33 @@ XMPI_HD void sched_step(const DsyncSchedArgs& a, const uint64_t* send, const uin
       st->hi = ohi;
       st->A = recv[p];
     }
+    return;
+  }
+  if (a.sched == SCHED_TREE_REDUCE) {
+    // The binary tree of the broadcast, upwards: node v (relative to the root) folds its children's partial results into its
+    // own -- (x_v op T(2v+1)) op T(2v+2) -- piece by piece: sub-step 1 of a piece takes the first child, sub-step 2 the second.
+    // A leaf's partial result is its input, complete when it announces itself; an inner node's lies in its receive buffer (the
+    // root's: the result; anybody else's: a registered block dsync.cpp lends it) and is announced piece by piece, after the
+    // second sub-step.  Step numbers: 2 * piece + sub-step (1-based).
+    const int v = (me - a.root + n) % n;
+    const int piece = (g - 1) / 2, sub = (g - 1) % 2;
+    const int cv = 2 * v + 1 + sub;
+    uint64_t lo, hi;
+    chunk_bytes(a.count * es, 1, a.pieces, piece, &lo, &hi);
+    if (cv < n) {
+      const int c = (cv + a.root) % n;
+      const bool child_inner = 2 * cv + 1 < n;
+      if (child_inner) {
+        st->wait_rank = c;
+        st->wait_val = (uint32_t)(2 * (piece + 1));
+      }
+      st->ns = 2;
+      st->lo = lo;
+      st->hi = hi;
+      st->A = child_inner ? recv[c] : send[c];
+      st->B = sub == 0 ? send[me] : recv[me];
+    }
+    if (sub == 1 && v != 0 && 2 * v + 1 < n) st->sig[0] = ((v - 1) / 2 + a.root) % n;
     return;
   }
   // SCHED_TREE_BCAST: piece g of the buffer comes from the parent and is announced to the children

@@ -184,7 +184,7 @@ std::string Network::accept_peers(int n) {
   const int ls = ::socket(res->ai_family, res->ai_socktype, 0);
   int one = 1;
   setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
-  if (ls < 0 || ::bind(ls, res->ai_addr, res->ai_addrlen) != 0 || ::listen(ls, n) != 0) {
+  if (ls < 0 || ::bind(ls, res->ai_addr, res->ai_addrlen) != 0 || ::listen(ls, n + 16) != 0) {
     freeaddrinfo(res);
     if (ls >= 0) ::close(ls);
     return std::string("error listening: ") + strerror(errno);
@@ -210,8 +210,9 @@ std::string Network::accept_peers(int n) {
       break;
     }
     setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
-    {  // a client that connects and then says nothing must not hold Init past its timeout (30 s when there is none)
-      const double left = Timeout > 0 ? std::max(0.05, Timeout - (now_s() - t0)) : 30.0;
+    {  // A real peer says hello the moment it is connected (dial_peers below; network.go:318).  The accept loop is serial, so
+       // a connection that says nothing holds up every peer in the backlog: it gets two seconds, not the job's timeout.
+      const double left = std::min(2.0, Timeout > 0 ? std::max(0.05, Timeout - (now_s() - t0)) : 2.0);
       timeval tv{(time_t)left, (suseconds_t)((left - (double)(time_t)left) * 1e6)};
       setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
     }
@@ -219,7 +220,10 @@ std::string Network::accept_peers(int n) {
     std::string pw;
     int64_t id = -1;
     if (!read_gob_value(fd, &in, kMaxHandshakeBytes) || !gobwire::parse_initial(in.data(), in.size(), &pw, &id)) {
-      ::close(fd);  // a stray connection (a port scanner, a rank of another job): not this job's problem -- keep listening
+      // a stray connection (a port scanner, a rank of another job): not this job's problem -- keep listening.  The reference
+      // fails Init here ("error decoding initial message", network.go:242-246); the deviation is logged, not silent.
+      fprintf(stderr, "mpi: rank %d dropped a connection on %s whose first message was not a handshake\n", rank_, Addr.c_str());
+      ::close(fd);
       continue;
     }
     const std::string bad = check_peer(pw, id, n);

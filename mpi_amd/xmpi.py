@@ -149,7 +149,7 @@ def plan_text(coll: int, algo: int, size: int, rank: int, root: int, count: int,
     return buf.value.decode()
 
 
-SCHED_RING_ALLREDUCE, SCHED_RHD_ALLREDUCE, SCHED_RING_ALLGATHER, SCHED_TREE_BCAST = 1, 2, 3, 4
+SCHED_RING_ALLREDUCE, SCHED_RHD_ALLREDUCE, SCHED_RING_ALLGATHER, SCHED_TREE_BCAST, SCHED_TREE_REDUCE = 1, 2, 3, 4, 5
 
 
 def sched_text(sched: int, size: int, rank: int, root: int, pieces: int, count: int, elem_size: int, nchan: int,

@@ -1110,7 +1110,29 @@ def sc_sched(comm, args):
                     want = oracle.fill(count, dtype, xmpi.PAT_UNIFORM, 40 + root)
                     assert got.tobytes() == want.tobytes(), f"tree bcast root={root} {xmpi.DTYPE_NAME[dtype]} n={count} piece={piece}"
                     buf.free()
+            # the same tree upwards (SCHED_TREE_REDUCE): an inner node folds its children's partial results into its own,
+            # piece by piece; a non-root's receive buffer is never written
+            for root in sorted({0, size - 1, size // 2}):
+                for dtype, count, pat, op in ((xmpi.F32, 100003, xmpi.PAT_SIGNED, xmpi.SUM), (xmpi.I64, 4099, xmpi.PAT_UNIFORM, xmpi.SUM),
+                                             (xmpi.F16, 5001, xmpi.PAT_UNIFORM, xmpi.SUM), (xmpi.F64, 1, xmpi.PAT_SIGNED, xmpi.SUM),
+                                             (xmpi.BF16, 3001, xmpi.PAT_SIGNED, xmpi.MAX), (xmpi.I32, 70001, xmpi.PAT_SIGNED, xmpi.MIN),
+                                             (xmpi.U8, 37, xmpi.PAT_UNIFORM, xmpi.SUM), (xmpi.F32, (1 << 20) + 9, xmpi.PAT_SIGNED, xmpi.SUM)):
+                    exact = size <= 2 or dtype not in FLOATS or op != xmpi.SUM or (dtype == xmpi.F16 and pat == xmpi.PAT_UNIFORM)
+                    reduce_case(comm, dtype, count, root, xmpi.ALGO_TREE, op=op, pat=pat, exact=exact, what=f"tree reduce piece={piece}")
         comm.set_param("tree_piece_bytes", 256 << 10)
+        # tree reduce in place at the root, and with a misaligned root buffer
+        root = size // 2
+        n = 50021
+        buf = comm.alloc(n * 4 + 4)
+        comm.fill(buf.at(4), n, xmpi.F32, xmpi.PAT_SIGNED, 70 + rank)
+        comm.reduce(buf.at(4), buf.at(4) if rank == root else None, n, xmpi.F32, xmpi.SUM, root, xmpi.ALGO_TREE)
+        ins = [oracle.fill(n, xmpi.F32, xmpi.PAT_SIGNED, 70 + r) for r in range(size)]
+        got = buf.download(np.float32, n, byte_offset=4)
+        if rank == root:
+            check_reduced(got, ins, xmpi.F32, xmpi.SUM, size <= 2, "tree reduce in place at the root")
+        else:
+            assert got.tobytes() == ins[rank].tobytes(), "tree reduce modified a non-root's input"
+        buf.free()
     comm.set_param("sched_channels", 0)
     comm.set_param("sched_grid", 0)
     assert comm.get_param("dsync_sched_launches") > l0, "the stepped kernels did not run"

@@ -1,5 +1,5 @@
 """Executes the step programs of the stepped kernels (mpi_amd/csrc/sched.hip: ring allreduce, recursive halving +
-doubling, ring allgather, binary-tree broadcast) on the CPU: every rank's program comes from the function the kernel
+doubling -- for any number of ranks --, ring allgather, binary-tree broadcast and reduce) on the CPU: every rank's program comes from the function the kernel
 itself calls (`xmpi_sched_dump` -> sched_steps.h `sched_step`), every worker (a block of the kernel) of every rank is a
 little sequential machine -- wait for the flag, move its tiles element by element, raise the flags -- and a seeded
 random scheduler interleaves all of them at the granularity of ONE element moved, with ranks and workers running at
@@ -58,6 +58,10 @@ def run(sched, size, count, es=4, nchan=1, gx=2, tile=16, root=0, pieces=1, inpl
     if sched == xmpi.SCHED_TREE_BCAST:
         recv = [np.array([(i * 31 + 7) if r == root else -1 for i in range(count)], dtype=object) for r in range(size)]
         send = recv  # one buffer
+    elif sched == xmpi.SCHED_TREE_REDUCE:
+        # only the root's receive buffer is the caller's (in place: its send buffer); an inner node's is the accumulator the
+        # library lends it (dsync.cpp), a leaf's is never touched
+        recv = [send[r] if (inplace and r == root) else np.array([-1] * nelem_recv, dtype=object) for r in range(size)]
     elif inplace:
         recv = send
     else:
@@ -148,4 +152,6 @@ def expected(sched, size, count, orig, root=0):
     if sched == xmpi.SCHED_RING_ALLGATHER:
         cat = [orig[r][i] for r in range(size) for i in range(count)]
         return [cat] * size
+    if sched == xmpi.SCHED_TREE_REDUCE:
+        return [[sum(orig[r][i] for r in range(size)) for i in range(count)] if q == root else None for q in range(size)]
     return [list(orig[root])] * size

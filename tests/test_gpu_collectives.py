@@ -187,10 +187,11 @@ def test_cfg5_allreduce_f16_large():
     run_ranks("fullsize", 8, {"which": "cfg5", "count": "auto"}, timeout=900)
 
 
-@pytest.mark.parametrize("size", [2, 3, 4, 8])
+@pytest.mark.parametrize("size", [2, 3, 4, 5, 6, 8])
 def test_stepped_kernels(size):
-    """ring allreduce / allgather, recursive halving + doubling (ring when the ranks are no power of two), binary-tree
-    broadcast: every step inside ONE kernel per rank, released by flag words between the peers' kernels"""
+    """ring allreduce / allgather, recursive halving + doubling (any number of ranks: a fold-in and a fold-out step when it
+    is no power of two), binary-tree broadcast and reduce: every step inside ONE kernel per rank, released by flag words
+    between the peers' kernels"""
     args = {} if size in (2, 8) else {"shapes": [(0, 0), (2, 3)], "counts": [1, 4099, 65536 + 5]}
     run_ranks("sched", size, args, timeout=900)
 

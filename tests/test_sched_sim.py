@@ -11,6 +11,8 @@ def check(sched, size, count, **kw):
     recv, orig = sim.run(sched, size, count, **kw)
     want = sim.expected(sched, size, count, orig, root)
     for r in range(size):
+        if want[r] is None:  # (a rank whose receive buffer means nothing: the non-roots of a reduce)
+            continue
         got = list(recv[r])
         assert got == want[r], f"rank {r}: sched {sched} N={size} count={count} {kw}: first diff at " \
                                f"{next(i for i in range(len(got)) if got[i] != want[r][i])}"
@@ -25,16 +27,32 @@ def test_ring_allreduce(size, inplace):
         check(xmpi.SCHED_RING_ALLREDUCE, size, count, nchan=nchan, gx=gx, inplace=inplace, seed=100 + seed, bias=seed % size)
 
 
-@pytest.mark.parametrize("size", [2, 4, 8, 16])
+@pytest.mark.parametrize("size", [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
 @pytest.mark.parametrize("inplace", [False, True])
 def test_recursive_halving_doubling(size, inplace):
+    """any number of ranks: with no power of two the first 2 (N - 2^l) ranks pair up in a fold-in step, the even ones sit
+    out the halving and doubling and fetch the result in a fold-out step"""
     for seed, (count, gx) in enumerate([(1, 1), (size, 2), (53, 3), (64, 4), (131, 5)]):
         check(xmpi.SCHED_RHD_ALLREDUCE, size, count, gx=gx, inplace=inplace, seed=seed)
         check(xmpi.SCHED_RHD_ALLREDUCE, size, count, gx=gx, inplace=inplace, seed=50 + seed, bias=(seed * 3) % size)
 
 
-def test_halving_needs_a_power_of_two():
-    assert xmpi.lib().xmpi_sched_dump(xmpi.SCHED_RHD_ALLREDUCE, 6, 0, 0, 1, 100, 4, 1, 0, None, 0) == xmpi.ERR_UNSUPPORTED
+def test_halving_step_counts():
+    for n, steps in ((2, 2), (3, 4), (4, 4), (5, 6), (6, 6), (7, 6), (8, 6), (9, 8), (16, 8)):
+        for rank in range(n):
+            text = xmpi.sched_text(xmpi.SCHED_RHD_ALLREDUCE, n, rank, 0, 1, 1000, 4, 1, 0)
+            assert len(text.strip().split("\n")) == steps, (n, rank)
+
+
+@pytest.mark.parametrize("size", [2, 3, 4, 5, 6, 7, 8, 9, 12, 13, 16])
+@pytest.mark.parametrize("inplace", [False, True])
+def test_tree_reduce(size, inplace):
+    """every node folds its children's partial results into its own, piece by piece; only the root's receive buffer counts"""
+    for seed, (count, pieces, gx) in enumerate([(1, 1, 1), (40, 1, 2), (100, 4, 2), (257, 8, 3)]):
+        for root in {0, size - 1, size // 2}:
+            check(xmpi.SCHED_TREE_REDUCE, size, count, pieces=pieces, gx=gx, root=root, inplace=inplace, seed=seed)
+            check(xmpi.SCHED_TREE_REDUCE, size, count, pieces=pieces, gx=gx, root=root, inplace=inplace, seed=seed + 20,
+                  bias=(root + 1) % size)
 
 
 @pytest.mark.parametrize("size", [2, 3, 4, 7, 8])
@@ -90,6 +108,7 @@ def test_tuner_decision_function():
 def test_sched_dump_rejects_bad_arguments():
     L = xmpi.lib()
     assert L.xmpi_sched_dump(9, 4, 0, 0, 1, 100, 4, 1, 0, None, 0) == xmpi.ERR_ARG      # no such schedule
+    assert L.xmpi_sched_dump(5, 4, 0, 0, 128, 100, 4, 1, 0, None, 0) == xmpi.ERR_ARG    # more pieces than step numbers
     assert L.xmpi_sched_dump(1, 4, 4, 0, 1, 100, 4, 1, 0, None, 0) == xmpi.ERR_ARG      # rank out of range
     assert L.xmpi_sched_dump(1, 4, 0, 0, 1, 100, 4, 9, 0, None, 0) == xmpi.ERR_ARG      # more channels than the kernel has
     assert L.xmpi_sched_dump(4, 5, 0, 7, 1, 100, 1, 1, 0, None, 0) == xmpi.ERR_ARG      # root out of range

@@ -193,4 +193,8 @@ def test_init_survives_strangers_on_its_port():
         x.join()
     assert all(p.returncode == 0 for p in procs), outs
     for rank, out in enumerate(outs):
-        assert sorted(out.strip().split("\n")) == _hello_lines(rank, 2)
+        lines = out.strip().split("\n")
+        dropped = [ln for ln in lines if ln.startswith("mpi: rank") and "dropped a connection" in ln]
+        assert sorted(ln for ln in lines if ln not in dropped) == _hello_lines(rank, 2)
+        # where this backend does not do what the reference does (fail Init: network.go:242-246) it says so
+        assert len(dropped) == (3 if rank == 0 else 0), out
