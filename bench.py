@@ -326,6 +326,7 @@ def rank_main(job: Job, grank: int):
             zd = [comm.alloc(per * es) for _ in range(R)]
             for k, b in enumerate(zs):
                 comm.fill(b, per, dtype, xmpi.PAT_UNIFORM, 77 + k)
+            iso_slots = {"sources": [(b.ptr >> 12) & 15 for b in zs], "destinations": [(b.ptr >> 12) & 15 for b in zd]}
             for j in range(6):
                 comm.reduce_local_multi(zd, zs, per, dtype, xmpi.SUM)
             for b in zs + zd:
@@ -340,7 +341,7 @@ def rank_main(job: Job, grank: int):
             n_i, ms_i, by_i = comm.prof_get(xmpi.PROF_REDUCE2)
             iso_name = "reduce2_kernel (one ring-step chunk, GPU otherwise idle)"
         comm.prof_enable(False)
-        iso = {"kernel": iso_name, "bytes_per_launch": by_i / n_i,
+        iso = {"kernel": iso_name, "bytes_per_launch": by_i / n_i, "slots": locals().get("iso_slots"),
                "avg_launch_us": ms_i * 1e3 / n_i, "achieved": by_i / (ms_i * 1e-3) / 1e9, "unit": "GB/s",
                "frac": by_i / (ms_i * 1e-3) / 1e9 / HBM_PEAK_GBPS}
     comm.barrier()
@@ -349,7 +350,8 @@ def rank_main(job: Job, grank: int):
     # one GPU does not, whatever --gpus says)
     transport = ("xGMI (one rank per GPU)" if ndev_used == R else
                  "intra-HBM (all ranks share one GPU)" if ndev_used == 1 else f"mixed: {R} ranks on {ndev_used} GPUs (intra-HBM + xGMI)")
-    out = {"form": form, "link": link, "transport": transport, "devices": ndev_used, "dsync": comm.get_param("dsync"), "t_step": t_step, "prof": prof, "tune": tune, "best": best, "best_ring": best_ring, "parity": parity,
+    slot = lambda b: (b.ptr >> 12) & 15  # noqa: E731 -- the 4 KiB slot of the 64 KiB frame a block starts in (heap.cpp colouring)
+    out = {"slots": {"send": slot(send), "recv": slot(recv)}, "form": form, "link": link, "transport": transport, "devices": ndev_used, "dsync": comm.get_param("dsync"), "t_step": t_step, "prof": prof, "tune": tune, "best": best, "best_ring": best_ring, "parity": parity,
            "algo": algo, "nbytes": nbytes, "count": count, "iso": iso, "parity_failures": parity_failures,
            "shared_stream": comm.get_param("shared_stream"), "slot_bytes": comm.get_param("slot_bytes"),
            "zero_copy_probe": {"dsync": "ok: ranks meet on the device", "host": "device rendezvous failed, host rendezvous ok",
@@ -411,7 +413,9 @@ def rank_main(job: Job, grank: int):
                     for b in sizes:
                         cnt = b // es
                         sub.allreduce(s2, d2, cnt, dtype, xmpi.SUM, xmpi.ALGO_AUTO)
-                        it = 20 if b <= (1 << 20) else (5 if b <= (64 << 20) else 3)
+                        # (the same method as the headline: a.steps launches inside ONE native call between two rendezvous; with 3
+                        # the start-up of the batch showed as a 10 % gap between the 8-rank row and `value`, r03)
+                        it = max(10, a.steps)
                         t = timed(sub, None, it, batch=lambda k, c=cnt: sub.allreduce_repeat(s2, d2, c, dtype, xmpi.SUM, xmpi.ALGO_AUTO, k))
                         if grank == 0:
                             table.append({"ranks": r2, "bytes": b, "us": t * 1e6, "algbw_GBps": b / t / 1e9,
@@ -833,7 +837,8 @@ def main():
                         "busbw_frac_of_one_link": busbw / XGMI_LINK_GBPS, "link_probe": r0["link"], "meaningful": meaningful}
     if (args.gpus > 1 or job.procs > 1) and not args.no_probe:
         line["zero_copy_probe"] = r0["zero_copy_probe"]
-    extras_out = {"autotune": r0["tune"], "parity_failures": r0["parity_failures"], "other_kernels": others,
+    extras_out = {"timed_buffer_slots": {str(g): job.result[g].get("slots") for g in sorted(job.result)},
+                  "autotune": r0["tune"], "parity_failures": r0["parity_failures"], "other_kernels": others,
                   "roofline_isolated": r0["iso"], "extras": r0["extras"], "roofline_note": roof.pop("note", None),
                   "traffic_source": roof.pop("traffic_source", None), "kernel_detail": roof.pop("kernel_detail", None)}
     if args.gpus == 1 and not args.no_cpu and job.proc_rank == 0:
@@ -848,6 +853,10 @@ def main():
         rp = production_roofline(job.production)
         if rp:
             line["roofline_production"] = rp
+            # the layout a real node runs (one process per rank, ranks meet on the device, the library's own schedule): the
+            # same metric as `value`, first-class.  `value` stays the threads layout (the driver's contract since round 1)
+            line["value_production"] = rp.get("algbw_GBps")
+            line["value_production_exact"] = rp.get("exact")
     if job.mp_sweep is not None:
         extras_out["extras"]["multiprocess_sweep"] = job.mp_sweep
     if job.cfg3 is not None:

@@ -26,8 +26,8 @@ HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wextra"]
 
-LIB_SOURCES = ["kernels.hip", "sched.hip", "ll.hip", "engine.cpp", "api.cpp", "ctl.cpp", "plan.cpp", "zcopy.cpp", "heap.cpp", "dsync.cpp"]
-LIB_HEADERS = ["kernels.h", "kdev.h", "sched_steps.h", "comm.h", "ctl.h", "plan.h", os.path.join("..", "..", "include", "xmpi.h")]
+LIB_SOURCES = ["kernels.hip", "sched.hip", "ll.hip", "engine.cpp", "api.cpp", "ctl.cpp", "plan.cpp", "zcopy.cpp", "heap.cpp", "dsync.cpp", "trace.cpp"]
+LIB_HEADERS = ["kernels.h", "kdev.h", "sched_steps.h", "comm.h", "ctl.h", "plan.h", "trace.h", os.path.join("..", "..", "include", "xmpi.h")]
 
 
 MANIFEST = os.path.join(ROOT, "mpi_amd", ".build_manifest.json")
@@ -104,7 +104,7 @@ def build_lib(force: bool = False) -> str:
         _record(obj, d)
     link = _digest(objs, "link")
     if force or jobs or _stale(LIB, link):
-        _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB, "-lpthread", "-lrt"])
+        _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB, "-lpthread", "-lrt", "-ldl"])
         _record(LIB, _digest(objs, "link"))
     return LIB
 
@@ -172,6 +172,42 @@ def build_oracle(force: bool = False) -> list[str]:
     return outs
 
 
+TSAN_BIN = os.path.join(ROOT, "tests", "tsan_host_bin")
+TSAN_HOST_SOURCES = [s for s in LIB_SOURCES if s.endswith(".cpp")]
+
+
+def build_tsan(force: bool = False) -> str:
+    """tests/tsan_host_bin: the library's host sources (ctl.cpp, engine.cpp, heap.cpp, api.cpp, ...) compiled with
+    -fsanitize=thread and driven by tests/tsan_host_driver.cpp with the ranks as threads (test infrastructure: the shared-memory
+    protocols of the code that ships, raced under the sanitizer on the CPU).  The kernel objects are the library's own."""
+    build_lib(False)
+    objdir = os.path.join(ROOT, "mpi_amd", "csrc", "obj_tsan")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, h) for h in LIB_HEADERS]
+    flags = [f"--offload-arch={ARCH}", "-O1", "-g", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fsanitize=thread", "-Wall", "-Wextra"]
+    driver = os.path.join(ROOT, "tests", "tsan_host_driver.cpp")
+    objs, jobs = [], []
+    for path in [os.path.join(CSRC, s) for s in TSAN_HOST_SOURCES] + [driver]:
+        obj = os.path.join(objdir, os.path.splitext(os.path.basename(path))[0] + ".o")
+        objs.append(obj)
+        d = _digest([path] + headers, " ".join(flags))
+        if force or _stale(obj, d):
+            jobs.append((subprocess.Popen([HIPCC, *flags, "-c", path, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True),
+                         obj, d, path))
+    for proc, obj, d, path in jobs:
+        out, _ = proc.communicate()
+        if proc.returncode != 0:
+            sys.stderr.write(f"hipcc -fsanitize=thread {path}:\n{out}")
+            raise RuntimeError("build failed: tsan " + os.path.basename(path))
+        _record(obj, d)
+    kernel_objs = [os.path.join(OBJDIR, os.path.splitext(s)[0] + ".o") for s in LIB_SOURCES if s.endswith(".hip")]
+    link = _digest(objs + kernel_objs, "tsan link")
+    if force or jobs or _stale(TSAN_BIN, link):
+        _run([HIPCC, f"--offload-arch={ARCH}", "-fsanitize=thread", *objs, *kernel_objs, "-o", TSAN_BIN, "-lpthread", "-lrt", "-ldl"])
+        _record(TSAN_BIN, link)
+    return TSAN_BIN
+
+
 def build_all(force: bool = False) -> None:
     build_lib(force)
     build_host(force)
@@ -179,5 +215,8 @@ def build_all(force: bool = False) -> None:
 
 
 if __name__ == "__main__":
-    build_all("--force" in sys.argv)
-    print("built:", LIB)
+    if "--tsan" in sys.argv:
+        print("built:", build_tsan("--force" in sys.argv))
+    else:
+        build_all("--force" in sys.argv)
+        print("built:", LIB)

@@ -371,6 +371,7 @@ static int collective(xmpi_comm* c, int coll, int algo, int root, const void* se
     set_last_error("null buffer");
     return XMPI_ERR_ARG;
   }
+  RoctxRange range("xmpi:%s algo=%s bytes=%zu rank=%d/%d", coll_name(coll), algo_name(algo), count * es, c->rank, c->size);
   std::lock_guard<std::mutex> g(c->coll_mu);
   // Zero-copy first (zcopy.cpp): when every rank's buffers are registered HBM one kernel per rank does
   // the whole collective in place.  Whether that holds is decided collectively, so either every rank
@@ -606,6 +607,8 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   }
   c->dsync = env_long("XMPI_DSYNC", 1) ? 1 : 0;
   c->dsync_split_bytes = std::max<long>(0, env_long("XMPI_DSYNC_SPLIT_BYTES", 4 << 20));
+  c->xcd_check = env_long("XMPI_XCD_CHECK", 1) ? 1 : 0;
+  c->body_sys = env_long("XMPI_BODY_SYS", -1);  // -1: decided by the XCD probe (dsync_prepare)
   c->ll_bytes = env_long("XMPI_LL_BYTES", -1);  // -1: decided when the job's layout is known (dsync_connect)
   c->sched_channels = std::max<long>(0, env_long("XMPI_SCHED_CHANNELS", 0));
   c->sched_grid = std::max<long>(0, env_long("XMPI_SCHED_GRID", 0));
@@ -708,6 +711,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   (void)hipGetLastError();
   c->p2p_kernel_ack = env_long("XMPI_P2P_KERNEL_ACK", 1) ? 1 : 0;
   c->p2p_agent_us = std::max<long>(0, env_long("XMPI_P2P_AGENT_US", 40));
+  c->p2p_grid_cap = std::max<long>(0, std::min<long>(env_long("XMPI_P2P_GRID_CAP", 0), 4096));
   if (hipHostMalloc((void**)&c->p2p_cmd, 64, hipHostMallocMapped) == hipSuccess) {
     memset(c->p2p_cmd, 0, 64);
     void* dev = nullptr;
@@ -1465,6 +1469,9 @@ int xmpi_set_param(xmpi_comm* c, const char* name, long value) {
   else if (n == "p2p_grid_cap") c->p2p_grid_cap = std::max<long>(0, std::min<long>(value, 4096));
   else if (n == "ll_bytes") c->ll_bytes = std::max<long>(0, std::min<long>((long)kLLMaxPayload, value));  // untuned AUTO: LL lines up to here
   else if (n == "dsync_split_bytes") c->dsync_split_bytes = std::max<long>(0, value);  // 0: always one kernel
+  else if (n == "xcd_check") c->xcd_check = value ? 1 : 0;
+  else if (n == "body_sys") c->body_sys = value ? 1 : 0;
+  else if (n == "xcds") c->xcds = (int)std::max<long>(0, std::min<long>(value, 32));  // (tests: a GPU with more XCDs than it has)
   else if (n == "sched_channels") c->sched_channels = std::max<long>(0, value);
   else if (n == "sched_grid") c->sched_grid = std::max<long>(0, value);
   else if (n == "tree_piece_bytes") c->tree_piece_bytes = std::max<long>(4096, value);
@@ -1514,6 +1521,13 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
   if (n == "dsync_ll_launches") return (long)c->dsync_ll_launches;
   if (n == "dsync_grid") return c->dsync_grid_cap;
   if (n == "dsync_split_bytes") return c->dsync_split_bytes;
+  if (n == "xcd_check") return c->xcd_check;
+  if (n == "body_sys") return c->body_sys;
+  if (n == "xcds") return c->xcds;
+  if (n == "xcd_probe_mask") return (long)c->xcd_probe_mask;
+  if (n == "xcd_short") return (long)c->xcd_short;
+  if (n == "xcd_meet_mask") return c->dsync_status ? (long)__atomic_load_n(c->dsync_status + 6, __ATOMIC_RELAXED) : -1;
+  if (n == "xcd_done_mask") return c->dsync_status ? (long)__atomic_load_n(c->dsync_status + 7, __ATOMIC_RELAXED) : -1;
   if (n == "dsync_split_launches") return (long)c->dsync_split_launches;
   if (n == "dsync_sched_launches") return (long)c->dsync_sched_launches;
   if (n == "sched_channels") return c->sched_channels;

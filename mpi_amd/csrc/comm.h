@@ -17,6 +17,7 @@
 #include "../../include/xmpi.h"
 #include "ctl.h"
 #include "kernels.h"
+#include "trace.h"
 #include "plan.h"
 
 namespace xmpi {
@@ -160,6 +161,11 @@ struct xmpi_comm {
   long tune_mask = -1;  // candidates xmpi_tune may time (bit per candidate; see xmpi_set_param "tune_mask")
   uint32_t* dsync_status = nullptr;          // pinned host word a kernel writes its first failure to ...
   uint32_t* dsync_status_dev = nullptr;      // ... and its device address
+  int xcds = 0;                  // XCDs of this rank's GPU as a 1024-block probe grid found them (0: not probed)
+  uint32_t xcd_probe_mask = 0;   // XCDs a grid of kXcdBlocks one-wave blocks reached at start-up (what the meet / done kernels are)
+  long xcd_check = 1;            // the split form's done kernel fails the collective when meet or done missed an XCD; XMPI_XCD_CHECK
+  long body_sys = 0;             // split form: data kernel with system-scope loads / stores (no L2 assumption); XMPI_BODY_SYS
+  uint64_t xcd_short = 0;        // split collectives whose meet or done kernel missed an XCD (reported whether checked or not)
   int dsync_sharers = 1;         // ranks of this job on this rank's GPU (bounds the grid: their kernels spin together)
   long dsync_grid_cap = 0;       // blocks per kernel; 0 = 1024 / sharers
   long dsync_unroll = 1;         // 16-byte packets per lane per source in flight (2 = deeper, for links)

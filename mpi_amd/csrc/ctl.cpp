@@ -12,7 +12,10 @@
 
 #include <cerrno>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -90,6 +93,22 @@ static std::string shm_name(const std::string& key) {
   for (char c : key) n += (isalnum((unsigned char)c) || c == '-' || c == '_' || c == '.') ? c : '_';
   if (n.size() > 200) n.resize(200);
   return n;
+}
+
+// XMPI_CTL_SHARE_MAPPING=1: ranks hosted by threads of ONE process address the block through one mapping (the creator's)
+// instead of one mmap each.  What a thread sanitizer needs -- it tells accesses apart by virtual address, so the atomics of
+// two ranks meet in its eyes only when both use the same one (tests/tsan_host_driver.cpp); off otherwise (every communicator
+// registers its own mapping with the GPU).
+struct SharedMapping {
+  void* base = nullptr;
+  size_t bytes = 0;
+  int refs = 0;
+};
+static std::mutex g_shared_mu;
+static std::map<std::string, SharedMapping> g_shared;
+static bool share_mappings() {
+  static const bool on = getenv("XMPI_CTL_SHARE_MAPPING") && atoi(getenv("XMPI_CTL_SHARE_MAPPING")) != 0;
+  return on;
 }
 
 // Control blocks of jobs that died without finalising (kill -9, a crash) would otherwise pile up in
@@ -188,12 +207,30 @@ int Ctl::join(const std::string& key, int rank, int size, const CtlConfig& cfg, 
     h->bar_gen.store(0);
     h->magic.store(kCtlMagic, std::memory_order_release);
     creator = true;
+    if (share_mappings()) {
+      std::lock_guard<std::mutex> g(g_shared_mu);
+      g_shared[name] = SharedMapping{base, bytes, 1};
+    }
   } else {
     Backoff bo;
     for (;;) {
       if (now_seconds() - t0 > timeout_s) {
         *err = "timed out waiting for rank 0 to create " + name;
         return XMPI_ERR_TIMEOUT;
+      }
+      if (share_mappings()) {  // rank 0 is a thread of this process: its mapping
+        {
+          std::lock_guard<std::mutex> g(g_shared_mu);
+          auto it = g_shared.find(name);
+          if (it != g_shared.end() && it->second.bytes == bytes) {
+            it->second.refs++;
+            base = it->second.base;
+          }
+        }
+        if (base) break;
+        timespec ts{0, 200000};
+        nanosleep(&ts, nullptr);
+        continue;
       }
       int fd = shm_open(name.c_str(), O_RDWR, 0600);
       if (fd < 0) {
@@ -292,6 +329,14 @@ int Ctl::join(const std::string& key, int rank, int size, const CtlConfig& cfg, 
 Ctl::~Ctl() {
   if (base_) {
     if (creator_) shm_unlink(name_.c_str());
+    if (share_mappings()) {
+      std::lock_guard<std::mutex> g(g_shared_mu);
+      auto it = g_shared.find(name_);
+      if (it != g_shared.end() && it->second.base == base_) {
+        if (--it->second.refs > 0) return;  // another rank of this process still uses the mapping
+        g_shared.erase(it);
+      }
+    }
     munmap(base_, bytes_);
   }
 }

@@ -133,6 +133,28 @@ int dsync_connect(xmpi_comm* c) {
     if (hipHostGetDevicePointer(&dev, c->dsync_status, 0) == hipSuccess) c->dsync_status_dev = (uint32_t*)dev;
   }
   (void)hipGetLastError();
+  // The split form acquires / releases once per XCD from kXcdBlocks one-wave blocks and counts on the dispatcher dealing them
+  // round the XCDs.  Nothing promises that, so look: how many XCDs the GPU has (a grid that fills it) and which ones a grid of
+  // kXcdBlocks reaches (status words 8, 9: pinned, zeroed above).  If the small grid misses one, the data kernel runs in its
+  // system-scope form from the start (body_sys) -- and the done kernel checks every launch anyway (xcd_check).
+  if (c->dsync_status_dev) {
+    bool ok = launch_xcc_probe(c->dsync_status_dev + 8, 1024, c->local_stream) == hipSuccess;
+    for (int k = 0; ok && k < 4; k++) {  // the small grid a few times: the answer must not depend on where the dispatcher stood
+      __atomic_store_n(c->dsync_status + 10, 0u, __ATOMIC_RELAXED);
+      ok = launch_xcc_probe(c->dsync_status_dev + 10, kXcdBlocks, c->local_stream) == hipSuccess &&
+           hipStreamSynchronize(c->local_stream) == hipSuccess;
+      const uint32_t m = __atomic_load_n(c->dsync_status + 10, __ATOMIC_RELAXED);
+      c->xcd_probe_mask = k == 0 ? m : (c->xcd_probe_mask & m);
+    }
+    if (ok) c->xcds = __builtin_popcount(__atomic_load_n(c->dsync_status + 8, __ATOMIC_RELAXED));
+    (void)hipGetLastError();
+    const bool covered = c->xcds > 0 && __builtin_popcount(c->xcd_probe_mask) >= c->xcds;
+    if (c->body_sys < 0) c->body_sys = (c->xcds > 0 && !covered) ? 1 : 0;
+    if (c->xcds > 0 && !covered)
+      fprintf(stderr, "xmpi: rank %d: a %d-block grid reaches XCDs %#x of %d -- split collectives use system-scope loads / stores\n",
+              c->rank, kXcdBlocks, c->xcd_probe_mask, c->xcds);
+  }
+  if (c->body_sys < 0) c->body_sys = 0;
   // Every block of the kernel spins until the peers' kernels have started: the kernels of all ranks on this GPU
   // must be resident at once, in at most half of its 8192 wave slots (4 waves per block).
   c->dsync_sharers = std::max(1, sharers);
@@ -479,6 +501,8 @@ static int dsync_ll(xmpi_comm* c, int coll, int root, const void* sendbuf, void*
   const int N = c->size, me = c->rank;
   const size_t unit = count * xmpi_dtype_size((xmpi_dtype)dtype);
   const size_t recv_bytes = coll == COLL_ALLGATHER ? unit * (size_t)N : unit;
+  RoctxRange range("xmpi:dsync %s form=ll bytes=%zu epoch=%llu %s", coll_name(coll), unit, (unsigned long long)c->dsync_epoch + 1,
+                   blocking ? "blocking" : "enqueued");
   const bool reads = coll != COLL_BCAST || me == root;           // this rank's send buffer is read
   const bool writes = (coll != COLL_REDUCE || me == root) && !(coll == COLL_BCAST && me == root);  // its receive buffer is written
   std::vector<void*> lent;
@@ -689,6 +713,8 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
                        (algo == XMPI_ALGO_RHD && coll == COLL_ALLREDUCE) ||
                        (algo == XMPI_ALGO_TREE && (coll == COLL_BCAST || coll == COLL_REDUCE));
   const bool push = algo == XMPI_ALGO_ZPUSH;
+  RoctxRange range("xmpi:dsync %s algo=%s bytes=%zu epoch=%llu %s", coll_name(coll), algo_name(algo), send_bytes,
+                   (unsigned long long)c->dsync_epoch + 1, blocking ? "blocking" : capturing ? "captured" : "enqueued");
 
   // 1. buffers the peers can map.  Anything else -- host memory, device memory that was never registered --
   //    is stood in for by a block of a registered arena (one local copy in, one out); the collective itself is
@@ -800,6 +826,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
   a.my_recv = r.recv;
   a.abort_word = c->dsync_abort_dev;
   a.status = c->dsync_status_dev;
+  a.xcc_need = (c->xcd_check && !c->body_sys) ? c->xcds : 0;  // (body_sys: the data kernel needs no L2 to have been acquired)
   a.spin_limit = c->timeout_s > 0 ? (uint64_t)c->timeout_s * 100000000ull : 0;  // wall_clock64 ticks at 100 MHz
   const uint32_t everyone = N >= 32 ? 0xffffffffu : ((1u << N) - 1u);
   const size_t al = std::max<size_t>(1, 16 / es);
@@ -825,10 +852,12 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     a.done_value = done_id;
     const bool split = a.nseg > 0 && c->dsync_res &&
                        (split_pref >= 0 ? split_pref != 0 : (c->dsync_split_bytes > 0 && bytes_moved >= (size_t)c->dsync_split_bytes));
+    RoctxRange lr("xmpi:launch %s nsrc=%d bytes=%zu epoch=%llu", split ? (c->body_sys ? "meet/body(sys)/done" : "meet/body/done") : "fold",
+                  nsrc, bytes_moved, (unsigned long long)c->dsync_epoch);
     if (split) {
       XMPI_HIP(launch_dsync_meet(a, c->dsync_res, stream));
-      XMPI_HIP(launch_dsync_body(c->dsync_res, a.nseg, packets + 1, nsrc, kdtype, kop, bytes_moved, stream, sampled ? pstart : nullptr,
-                                 sampled ? pstop : nullptr));
+      XMPI_HIP(launch_dsync_body(c->dsync_res, a.nseg, packets + 1, nsrc, kdtype, kop, bytes_moved, c->body_sys != 0, stream,
+                                 sampled ? pstart : nullptr, sampled ? pstop : nullptr));
       XMPI_HIP(launch_dsync_done(a, c->dsync_res, stream));
       c->dsync_launches += 3;
       c->dsync_split_launches++;
@@ -894,7 +923,11 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     if (!prof_events()) return fail(XMPI_ERR_HIP);
     sa.d.host_done = done_k;
     sa.d.done_value = done_id;
-    XMPI_HIP(launch_dsync_sched(sa, dtype, op, gx, stream, sampled ? pstart : nullptr, sampled ? pstop : nullptr));
+    {
+      RoctxRange lr("xmpi:launch sched=%d channels=%d workers=%d pieces=%d epoch=%llu", sa.sched, nchan, gx, sa.pieces,
+                    (unsigned long long)c->dsync_epoch);
+      XMPI_HIP(launch_dsync_sched(sa, dtype, op, gx, stream, sampled ? pstart : nullptr, sampled ? pstop : nullptr));
+    }
     c->dsync_launches++;
     c->dsync_sched_launches++;
     rc = XMPI_OK;
@@ -1111,6 +1144,7 @@ int dsync_p2p_reap(xmpi_comm* c) {
 }
 
 int dsync_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, int tag, hipStream_t stream) {
+  RoctxRange range("xmpi:send_on_stream dest=%d tag=%d bytes=%zu", dest, tag, bytes);
   if (!stream) stream = c->local_stream;
   dsync_service(c);
   if ((int)c->p2p_pending.size() >= xmpi_comm::kP2PDoneSlots - 2) {  // completion words are a ring: do not lap it
@@ -1165,6 +1199,7 @@ int dsync_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest,
 }
 
 int dsync_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int tag, hipStream_t stream) {
+  RoctxRange range("xmpi:recv_on_stream src=%d tag=%d capacity=%zu", src, tag, cap_bytes);
   if (!stream) stream = c->local_stream;
   dsync_service(c);
   if ((int)c->p2p_pending.size() >= xmpi_comm::kP2PDoneSlots - 2) {
@@ -1223,6 +1258,11 @@ int dsync_check(xmpi_comm* c) {
     rc = XMPI_ERR_TIMEOUT;
   } else if (st == DSYNC_UNMAPPED) {
     set_last_error("collective: a peer's buffer is not mapped here (registration freed while in use?)");
+    rc = XMPI_ERR_STATE;
+  } else if (st == DSYNC_XCD) {
+    c->xcd_short++;
+    set_last_error("collective: the meet / done kernels of the split form did not reach every XCD's L2 (masks in xcd_meet_mask / "
+                   "xcd_done_mask); set XMPI_BODY_SYS=1");
     rc = XMPI_ERR_STATE;
   } else {
     set_last_error("collective: the job was aborted while the kernel waited for a peer");

@@ -612,6 +612,7 @@ struct Exec {
 
 int run_plan(xmpi_comm* c, const Plan& plan, const void* sendbuf, void* recvbuf, int dtype, int op) {
   if (plan.steps.empty()) return XMPI_OK;
+  RoctxRange range("xmpi:run_plan steps=%zu", plan.steps.size());
   {
     const int src = ensure_streams(c);
     if (src != XMPI_OK) return src;
@@ -852,6 +853,7 @@ void p2p_agent_stop(xmpi_comm* c) {
 int p2p_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, int tag, bool wait_ack) {
   // {dest,tag} unique among concurrent sends (mpi.go:121-125; the reference panics at
   // network.go:469, here it is an error code the Go shim turns into mpi.TagExists)
+  RoctxRange range("xmpi:send dest=%d tag=%d bytes=%zu", dest, tag, bytes);
   TagGuard tg(c, &c->send_tags, dest, tag);
   if (!tg.held) {
     set_last_error("tag " + std::to_string(tag) + " already in use sending to " + std::to_string(dest));
@@ -1111,6 +1113,7 @@ int p2p_probe(xmpi_comm* c, int src, int tag, size_t* bytes, int* dtype) {
 }
 
 int p2p_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int tag, size_t* got_bytes) {
+  RoctxRange range("xmpi:recv src=%d tag=%d capacity=%zu", src, tag, cap_bytes);
   TagGuard tg(c, &c->recv_tags, src, tag);
   if (!tg.held) {
     set_last_error("tag " + std::to_string(tag) + " already in use receiving from " + std::to_string(src));

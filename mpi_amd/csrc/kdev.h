@@ -126,6 +126,9 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {  // the value is the
   return ((uint64_t)hi << 32) | lo;
 }
 
+// the XCD (accelerator complex die) this wave runs on: HW_REG_XCC_ID (hardware register 20), bits 3..0
+__device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 15u; }
+
 // Wait until *p >= want.  0 = it did; otherwise why not (the job was aborted / the wait outlasted spin_limit).
 __device__ uint32_t spin_until(const uint64_t* p, uint64_t want, const int32_t* abort_word, uint64_t spin_limit) {
   if (ld_sys64(p) >= want) return DSYNC_OK;
@@ -224,8 +227,9 @@ __device__ void dsync_begin(const DsyncArgs& a, DsyncShared& sh) {
   __syncthreads();
 }
 
-// true in the block that finished last (after it has exchanged "done" with every peer)
-__device__ void dsync_end(const DsyncArgs& a, DsyncShared& sh) {
+// The block that finishes last exchanges "done" with every peer.  xcd_guard (the done kernel of the split form): the masks of
+// XCDs the meet and the done kernel's blocks ran on are collected, reported (status[6], status[7]) and -- xcc_need -- checked.
+__device__ void dsync_end(const DsyncArgs& a, DsyncShared& sh, bool xcd_guard = false) {
   const int t = threadIdx.x, me = a.me, n = a.n;
   DsyncPage* mine = a.page[me];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left
@@ -244,6 +248,16 @@ __device__ void dsync_end(const DsyncArgs& a, DsyncShared& sh) {
     __hip_atomic_store(&mine->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t f = __hip_atomic_exchange(&mine->failword, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (f > sh.fail) sh.fail = f;
+    if (xcd_guard) {
+      const uint32_t m = __hip_atomic_exchange(&mine->xcc_meet, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t d = __hip_atomic_exchange(&mine->xcc_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.status) {
+        __hip_atomic_store(a.status + 6, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(a.status + 7, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      if (a.xcc_need > 0 && (__builtin_popcount(m) < a.xcc_need || __builtin_popcount(d) < a.xcc_need) && sh.fail == DSYNC_OK)
+        sh.fail = DSYNC_XCD;
+    }
   }
   __syncthreads();
   uint32_t why = DSYNC_OK;
@@ -285,6 +299,13 @@ __device__ __forceinline__ void sys128_wait(pack_t (&v)[U]) {
   if constexpr (U == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0])::"memory");
   else if constexpr (U == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1])::"memory");
   else asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])::"memory");
+}
+// any number of packets: one wait, then every register passes through an (empty) volatile statement behind it
+template <int U>
+__device__ __forceinline__ void sys128_wait_n(pack_t* v) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int k = 0; k < U; k++) asm volatile("" : "+v"(v[k])::"memory");
 }
 // one element, same scope (the ragged ends of a tile, buffers at odd alignments)
 template <typename T>

@@ -91,7 +91,9 @@ struct DsyncPage {
   uint64_t epoch_now;             // epoch of the last kernel of this rank that has ended (written by its closing block):
                                   // the next kernel's epoch is derived from it ON THE DEVICE, so a captured hipGraph
                                   // that replays the same launch keeps counting
-  uint32_t pad[12];
+  uint32_t xcc_meet, xcc_done;    // split form: the XCDs the meet / done kernel's blocks of the running collective ran on (one bit
+                                  // each, HW_REG_XCC_ID); the closing block of the done kernel reads and clears both
+  uint32_t pad[10];
   // what this rank's kernels have looked up in the host's translation table (DsyncArgs::table) so far: the host
   // never writes device memory for this (a copy would need a hardware queue -- possibly the one a waiting kernel
   // occupies), the kernels fill the cache themselves and re-fetch when the registration number differs
@@ -171,7 +173,9 @@ struct DsyncSeg {
   uint32_t pad;
 };
 
-enum DsyncStatus : uint32_t { DSYNC_OK = 0, DSYNC_TIMEOUT = 1, DSYNC_ABORTED = 2, DSYNC_UNMAPPED = 3 };
+// DSYNC_XCD: the split form's meet or done kernel did not have a block on every XCD (DsyncArgs::xcc_need) -- the acquire / release
+// once per L2 it relies on did not happen everywhere, the result cannot be trusted
+enum DsyncStatus : uint32_t { DSYNC_OK = 0, DSYNC_TIMEOUT = 1, DSYNC_ABORTED = 2, DSYNC_UNMAPPED = 3, DSYNC_XCD = 4 };
 
 struct DsyncArgs {
   DsyncPage* page[kDsyncRanks];  // [me]: own page, others: the peers' pages as mapped here
@@ -191,7 +195,8 @@ struct DsyncArgs {
   uint32_t* status;           // host memory the GPU can write: first failure (DsyncStatus), may be null
   uint64_t spin_limit;        // wall-clock ticks (100 MHz) a wait may last, 0 = for ever
   int32_t nseg;               // gridDim.y; 0 = synchronise only
-  int32_t pad;
+  int32_t xcc_need;           // split form: XCDs the meet and the done kernel must each have covered (0 = not checked); the masks
+                              // they saw go to status[6] / status[7]
   DsyncSeg seg[kDsyncRanks];
 };
 
@@ -241,8 +246,15 @@ struct DsyncResolved {
 };
 hipError_t launch_dsync_meet(const DsyncArgs& a, DsyncResolved* out, hipStream_t stream);
 // nsrc_hint: sources per segment when it is the same for all (unrolled loads), 0 = read it from the table
+// sys: every load and store of the data kernel at system scope (sc0 sc1: nothing is served from or left in an L2) -- the form
+// that does not depend on the meet / done kernels having reached every XCD's L2
 hipError_t launch_dsync_body(const DsyncResolved* res, int nseg, size_t max_packets, int nsrc_hint, int dtype, int op,
-                             size_t traffic_bytes, hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                             size_t traffic_bytes, bool sys, hipStream_t stream, hipEvent_t ev_start = nullptr,
+                             hipEvent_t ev_stop = nullptr);
+// *mask_out (device or pinned host word, zeroed by the caller) |= 1 << XCC_ID of every block of a `blocks` x one-wave grid:
+// which XCDs a grid of that size reaches on this device (blocks = 1024: the XCDs the device has)
+hipError_t launch_xcc_probe(uint32_t* mask_out, int blocks, hipStream_t stream);
+constexpr int kXcdBlocks = 16;  // blocks of the meet / done kernels
 hipError_t launch_dsync_done(const DsyncArgs& a, const DsyncResolved* res, hipStream_t stream);
 
 // ---- stepped collectives in ONE kernel per rank (sched.hip): ring, recursive halving / doubling, binary tree ------------

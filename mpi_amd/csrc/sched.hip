@@ -31,9 +31,15 @@ namespace {
 // split form: meet
 // =====================================================================================================================
 
-// one-wave blocks of the meet and done kernels: consecutive blocks are dealt round the 8 XCDs, two rounds so that every
-// XCD's L2 is acquired / released even if one block lands beside another
-constexpr int kXcdBlocks = 16;
+// one-wave blocks of the meet and done kernels (kXcdBlocks = 16): consecutive blocks are dealt round the 8 XCDs, two rounds so
+// that every XCD's L2 is acquired / released even if one block lands beside another.  HIP promises nothing about where a block
+// runs, so every block records the XCD it found itself on (HW_REG_XCC_ID) and the done kernel's closing block checks that
+// both kernels reached all of them (DsyncArgs::xcc_need; DSYNC_XCD otherwise).
+
+// which XCDs a grid of one-wave blocks reaches
+__global__ __launch_bounds__(64) void xcc_probe_kernel(uint32_t* mask) {
+  if (threadIdx.x == 0) __hip_atomic_fetch_or(mask, 1u << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // A few blocks (at least one per XCD): announce (block 0), wait for every peer, acquire at system scope -- each block for the L2
 // of the XCD it runs on, so that the data kernel behind this one cannot be served a stale line of a peer's input -- and
@@ -42,6 +48,8 @@ constexpr int kXcdBlocks = 16;
 __global__ __launch_bounds__(64) void dsync_meet_kernel(DsyncArgs a, DsyncResolved* out) {
   __shared__ DsyncShared sh;
   dsync_begin(a, sh);
+  // this block has acquired the L2 of the XCD it runs on
+  if (threadIdx.x == 0) __hip_atomic_fetch_or(&a.page[a.me]->xcc_meet, 1u << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const int me = a.me, n = a.n;
     out->epoch = sh.epoch;
@@ -95,9 +103,52 @@ __global__ __launch_bounds__(kBlock) void dsync_body_kernel(const DsyncResolved*
   // the last block exchanging "done" (two launches instead of three), made every one-tile block wait for HBM to
   // acknowledge its stores before it could give its wave slots back -- 4.2 ms instead of 0.95 (r03 session 3).  The done
   // kernel's few blocks release once per XCD instead.
+  // MODE 3 is the form that assumes none of this: every load and store at system scope (sc0 sc1 -- never served from a line
+  // of an L2 that predates the peer's store, written through), for a machine whose dispatcher does not deal the meet / done
+  // kernels' blocks round the XCDs (xmpi_set_param "body_sys"; chosen by itself when the probe at start-up says so).
   if (fail != DSYNC_OK) return;
   const int t = threadIdx.x;
   constexpr size_t N = 16 / sizeof(T);
+  if constexpr (MODE == 3) {
+    if (vec) {
+      const size_t npack = count / N;
+      const size_t stride = (size_t)gridDim.x * kBlock;
+      for (size_t i = (size_t)blockIdx.x * kBlock + t; i < npack; i += stride) {
+        pack_t acc;
+        if constexpr (NSRC > 0) {
+          pack_t v[NSRC];
+#pragma unroll
+          for (int k = 0; k < NSRC; k++) ld_sys128_issue(v[k], reinterpret_cast<const pack_t*>(sp[k]) + i);
+          sys128_wait_n<NSRC>(v);
+          acc = v[0];
+#pragma unroll
+          for (int k = 1; k < NSRC; k++) acc = combine16<T, OP>(acc, v[k]);
+        } else {
+          pack_t v[1];
+          ld_sys128_issue(v[0], reinterpret_cast<const pack_t*>(g->src[0]) + i);
+          sys128_wait_n<1>(v);
+          acc = v[0];
+          for (int k = 1; k < nsrc; k++) {
+            ld_sys128_issue(v[0], reinterpret_cast<const pack_t*>(g->src[k]) + i);
+            sys128_wait_n<1>(v);
+            acc = combine16<T, OP>(acc, v[0]);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < kDsyncRanks; k++)
+          if (k < ndst) st_sys128(reinterpret_cast<pack_t*>(dp[k]) + i, acc);
+      }
+    }
+    const size_t first = vec ? (count / N) * N : 0;  // ragged tail, or everything when a buffer is not 16-byte aligned
+    const size_t lanes = vec ? (size_t)kBlock : (size_t)gridDim.x * kBlock;
+    if (!vec || blockIdx.x == 0)
+      for (size_t i = first + (vec ? 0 : (size_t)blockIdx.x * kBlock) + t; i < count; i += lanes) {
+        T acc = ld_sys_elem(reinterpret_cast<const T*>(g->src[0]) + i);
+        for (int k = 1; k < nsrc; k++) acc = combine_any<T, OP>(acc, ld_sys_elem(reinterpret_cast<const T*>(g->src[k]) + i));
+        for (int k = 0; k < ndst; k++) st_sys_elem(reinterpret_cast<T*>(g->dst[k]) + i, acc);
+      }
+    return;
+  }
   if (vec) {
     const size_t npack = count / N;
     const size_t stride = (size_t)gridDim.x * kBlock;
@@ -144,9 +195,11 @@ __global__ __launch_bounds__(64) void dsync_done_kernel(DsyncArgs a, const Dsync
   if (threadIdx.x == 0) {
     sh.epoch = res->epoch;
     sh.fail = res->fail;
+    // (dsync_end releases: the L2 of the XCD this block runs on is written back)
+    __hip_atomic_fetch_or(&a.page[a.me]->xcc_done, 1u << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-  dsync_end(a, sh);
+  dsync_end(a, sh, true);
 }
 
 // =====================================================================================================================
@@ -581,7 +634,8 @@ template <typename T, int OP>
 hipError_t body_go(const DsyncResolved* res, dim3 grid, int nsrc_hint, int mode, hipStream_t s, hipEvent_t es, hipEvent_t ee) {
 #define XMPI_BODY(NS)                                                                                         \
   do {                                                                                                        \
-    if (mode != 0) XMPI_LAUNCH((dsync_body_kernel<T, OP, NS, 2>), grid, dim3(kBlock), s, es, ee, res);        \
+    if (mode == 3) XMPI_LAUNCH((dsync_body_kernel<T, OP, NS, 3>), grid, dim3(kBlock), s, es, ee, res);        \
+    else if (mode != 0) XMPI_LAUNCH((dsync_body_kernel<T, OP, NS, 2>), grid, dim3(kBlock), s, es, ee, res);   \
     else XMPI_LAUNCH((dsync_body_kernel<T, OP, NS, 0>), grid, dim3(kBlock), s, es, ee, res);                  \
     return hipGetLastError();                                                                                 \
   } while (0)
@@ -626,14 +680,14 @@ hipError_t launch_dsync_meet(const DsyncArgs& a, DsyncResolved* out, hipStream_t
 }
 
 hipError_t launch_dsync_body(const DsyncResolved* res, int nseg, size_t max_packets, int nsrc_hint, int dtype, int op,
-                             size_t traffic_bytes, hipStream_t s, hipEvent_t es, hipEvent_t ee) {
+                             size_t traffic_bytes, bool sys, hipStream_t s, hipEvent_t es, hipEvent_t ee) {
   if (nseg < 1 || nseg > kDsyncRanks || !res) return hipErrorInvalidValue;
   size_t gx = (max_packets + kBlock - 1) / kBlock;
   if (gx < 1) gx = 1;
   if (gx > 0x3fffffu) gx = 0x3fffffu;
   const dim3 grid((unsigned)gx, (unsigned)nseg);
   // launches that stream more than the caches hold use non-temporal loads and stores (kernels.hip kernel_mode_for)
-  const int mode = get_kernel_mode() >= 0 ? get_kernel_mode() : (traffic_bytes >= (size_t)(48u << 20) ? 2 : 0);
+  const int mode = sys ? 3 : get_kernel_mode() >= 0 ? get_kernel_mode() : (traffic_bytes >= (size_t)(48u << 20) ? 2 : 0);
   switch (dtype) {
     case DT_U8: return body_op<uint8_t>(res, grid, nsrc_hint, op, mode, s, es, ee);
     case DT_I32: return body_op<int32_t>(res, grid, nsrc_hint, op, mode, s, es, ee);
@@ -644,6 +698,12 @@ hipError_t launch_dsync_body(const DsyncResolved* res, int nseg, size_t max_pack
     case DT_BF16: return body_op<bf16_t>(res, grid, nsrc_hint, op, mode, s, es, ee);
     default: return hipErrorInvalidValue;
   }
+}
+
+hipError_t launch_xcc_probe(uint32_t* mask_out, int blocks, hipStream_t s) {
+  if (!mask_out || blocks < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(xcc_probe_kernel, dim3((unsigned)blocks), dim3(64), 0, s, mask_out);
+  return hipGetLastError();
 }
 
 hipError_t launch_dsync_done(const DsyncArgs& a, const DsyncResolved* res, hipStream_t s) {

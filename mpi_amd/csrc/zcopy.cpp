@@ -585,6 +585,7 @@ static int zc_run(xmpi_comm* c, int coll, int root, const void* sendbuf, void* r
 
 int zero_copy_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void* recvbuf, size_t count,
                          int dtype, int op, bool push, bool* done, int iters) {
+  RoctxRange range("xmpi:zcopy(host rendezvous) %s count=%zu x%d", coll_name(coll), count, iters);
   const int rc = zc_run(c, coll, root, sendbuf, recvbuf, count, dtype, op, push, done, iters);
   if (rc != XMPI_OK) c->ctl->set_abort(rc);  // peers waiting in a barrier stop waiting
   return rc;

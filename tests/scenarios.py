@@ -1396,8 +1396,38 @@ def sc_split(comm, args):
     comm.stream_destroy(st)
     g1.free()
     g2.free()
-    comm.set_param("dsync_split_bytes", 4 << 20)
     assert comm.get_param("dsync_split_launches") > l0, "the split form did not run"
+    # the assumption under the form: the few blocks of the meet and the done kernel reach EVERY XCD's L2.  Every launch above was
+    # checked on the device (xcd_check: a miss fails the collective); these are the masks of the last one
+    xc = comm.get_param("xcds")
+    assert xc >= 1, "the XCD probe did not run"
+    if comm.get_param("xcd_check") == 1 and comm.get_param("body_sys") == 0:
+        for which in ("xcd_meet_mask", "xcd_done_mask", "xcd_probe_mask"):
+            m = comm.get_param(which)
+            assert bin(m).count("1") == xc, f"{which} = {m:#x}: {xc} XCDs"
+    assert comm.get_param("xcd_short") == 0
+    # ... and the data kernel that does not need it (system-scope loads and stores): the same bits
+    comm.set_param("body_sys", 1)
+    for dtype in (xmpi.F32, xmpi.I64, xmpi.F16, xmpi.F64, xmpi.I32, xmpi.U8, xmpi.BF16):
+        for count in (1, 17, 4099, 65536 + 5):
+            allreduce_case(comm, dtype, count, Z, exact=True)
+    allreduce_case(comm, xmpi.F32, (3 << 20) + 7, Z, pattern=xmpi.PAT_SIGNED, inplace=True, exact=True)
+    allreduce_case(comm, xmpi.F16, 30011, Z, misalign=3, exact=True)
+    for op in (xmpi.PROD, xmpi.MIN, xmpi.MAX):
+        allreduce_case(comm, xmpi.F32, 3001, Z, op=op, pattern=xmpi.PAT_SIGNED, exact=True)
+    allgather_case(comm, xmpi.I64, (1 << 18) + 3, Z)
+    comm.set_param("body_sys", 0)
+    comm.set_param("dsync_split_bytes", 4 << 20)
+    if args.get("trip"):  # a device with one XCD more than it has: the guard must refuse the result, on every rank
+        comm.set_param("dsync_split_bytes", 1)
+        comm.set_param("xcds", xc + 1)
+        try:
+            allreduce_case(comm, xmpi.F32, 4099, Z, exact=True)
+        except xmpi.XmpiError as e:
+            assert "XCD" in str(e), str(e)
+            assert comm.get_param("xcd_short") == 1
+            return
+        raise AssertionError("the XCD guard let a short launch pass")
 
 
 def sc_multistream(comm, args):

@@ -45,6 +45,12 @@ def test_bench_json_contract():
     assert rp["exact"] is True and "device" in rp["layout"] and rp["ms_per_step"] > 0 and rp["avg_launch_us"] > 0, rp
     assert 0 < rp["frac"] < 1.2 and abs(rp["frac"] - rp["achieved_all_ranks"] / rp["peak"]) < 1e-9
     assert rp["fused_ms_per_step"] > 0 and rp["split_ms_per_step"] > 0
+    # ... whose algbw is a first-class figure of the line (the layout a real node runs), exact like `value`
+    assert d["value_production_exact"] is True
+    assert abs(d["value_production"] - d["config"]["bytes_per_rank"] / rp["ms_per_step"] / 1e6) < 1e-3 * d["value_production"]
+    with open(os.path.join(ROOT, d["extras_file"])) as f:
+        slots = json.load(f)["timed_buffer_slots"]
+    assert len(slots) == r and all(0 <= v["send"] < 16 and 0 <= v["recv"] < 16 for v in slots.values())
     assert os.path.exists(os.path.join(ROOT, d["extras_file"]))
 
 

@@ -220,6 +220,11 @@ def test_split_form(size):
     run_ranks("split", size, timeout=600)
 
 
+def test_split_form_xcd_guard_trips():
+    """the done kernel refuses a collective whose meet / done blocks did not reach as many XCDs as it was told the GPU has"""
+    run_ranks("split", 2, {"counts": [4099], "trip": 1}, timeout=300)
+
+
 @pytest.mark.parametrize("size", [2, 4])
 def test_collectives_on_several_streams(size):
     run_ranks("multistream", size, timeout=300)
