@@ -118,6 +118,7 @@ class Job:
         # (the library's own default is to wait for ever, like the reference's blocking calls)
         os.environ.setdefault("XMPI_TIMEOUT_S", "120")
         self.result = {}
+        self.bufs = {}  # rank -> (send, recv) of the timed region (ranks hosted by this process)
         self.errors = []
         self.lock = threading.Lock()
 
@@ -206,6 +207,8 @@ def rank_main(job: Job, grank: int):
         print(f"[bench] rank {grank}: send {send.ptr:#x} (4 KiB slot {(send.ptr >> 12) & 15}) recv {recv.ptr:#x} (slot {(recv.ptr >> 12) & 15})", file=sys.stderr)
     comm.fill(send, count, dtype, xmpi.PAT_UNIFORM, seed0 + grank)
     comm.memset(recv, 0, nbytes)
+    with job.lock:
+        job.bufs[grank] = (send, recv)
 
     dsync_can = comm.get_param("dsync") == 1  # one rank per (process, GPU): the ranks may meet on the device
     ndev_used = len({job.device_of(r) for r in range(R)})
@@ -322,17 +325,43 @@ def rank_main(job: Job, grank: int):
         if algo in (xmpi.ALGO_ZCOPY, xmpi.ALGO_AUTO) and prof[xmpi.PROF_ZCOPY][0]:  # the same N-source, N-destination launch, all operands local
             nz, _, bz = prof[xmpi.PROF_ZCOPY]
             per = int(bz / nz / (2 * R * es)) if nz else chunk  # elements one launch of the timed region folded
-            zs = [comm.alloc(per * es) for _ in range(R)]
-            zd = [comm.alloc(per * es) for _ in range(R)]
-            for k, b in enumerate(zs):
-                comm.fill(b, per, dtype, xmpi.PAT_UNIFORM, 77 + k)
-            iso_slots = {"sources": [(b.ptr >> 12) & 15 for b in zs], "destinations": [(b.ptr >> 12) & 15 for b in zd]}
+            # ON THE TIMED REGION'S OWN BUFFERS when this process hosts every rank: the same launch by rank 0 alone, everybody else
+            # parked.  (r04, scripts/r04_gap.py: the SAME kernel on another set of sixteen 256 MiB buffers of the same process runs
+            # up to 20 % faster or slower -- 693 vs 832 us with sources and destinations of one set swapped, 693 vs 783 fresh set vs
+            # timed set on one box, 813 vs 814 on the next; where the sets lie in physical HBM, which the library cannot see.  A
+            # pair "in the collective / isolated" on different buffers compares placements, not launch paths: round 3's 750 vs 686.)
+            same = len(job.bufs) == R and per == count
+            fresh = None
+            if same:
+                zs, zd = [job.bufs[k][0] for k in range(R)], [job.bufs[k][1] for k in range(R)]
+            else:
+                zs = [comm.alloc(per * es) for _ in range(R)]
+                zd = [comm.alloc(per * es) for _ in range(R)]
+                for k, b in enumerate(zs):
+                    comm.fill(b, per, dtype, xmpi.PAT_UNIFORM, 77 + k)
+            iso_slots = {"sources": [(b.ptr >> 12) & 15 for b in zs], "destinations": [(b.ptr >> 12) & 15 for b in zd], "timed_buffers": same}
             for j in range(6):
                 comm.reduce_local_multi(zd, zs, per, dtype, xmpi.SUM)
-            for b in zs + zd:
-                b.free()
             n_i, ms_i, by_i = comm.prof_get(xmpi.PROF_ZCOPY)
-            iso_name = "reduce_n_multi_kernel (R local sources -> R local destinations, GPU otherwise idle)"
+            if not same:
+                for b in zs + zd:
+                    b.free()
+            elif not a.no_extras:  # the spread between buffer sets: a fresh set, and the same with the roles swapped
+                fs = [comm.alloc(per * es) for _ in range(R)]
+                fd = [comm.alloc(per * es) for _ in range(R)]
+                for k, b in enumerate(fs):
+                    comm.fill(b, per, dtype, xmpi.PAT_UNIFORM, 77 + k)
+                fresh = {}
+                for name, dd, ss in (("fresh_set_us", fd, fs), ("fresh_set_roles_swapped_us", fs, fd)):
+                    comm.prof_reset()
+                    for j in range(6):
+                        comm.reduce_local_multi(dd, ss, per, dtype, xmpi.SUM)
+                    n_f, ms_f, _ = comm.prof_get(xmpi.PROF_ZCOPY)
+                    fresh[name] = ms_f * 1e3 / max(1, n_f)
+                for b in fs + fd:
+                    b.free()
+            iso_name = ("reduce_n_multi_kernel (the timed region's own R sources -> R destinations, launched by rank 0 alone, GPU otherwise idle)"
+                        if same else "reduce_n_multi_kernel (R local sources -> R local destinations on fresh buffers, GPU otherwise idle)")
         else:
             for j in range(24):  # walk the chunks: operands are cold, as they are inside the collective
                 k = j % R
@@ -341,7 +370,7 @@ def rank_main(job: Job, grank: int):
             n_i, ms_i, by_i = comm.prof_get(xmpi.PROF_REDUCE2)
             iso_name = "reduce2_kernel (one ring-step chunk, GPU otherwise idle)"
         comm.prof_enable(False)
-        iso = {"kernel": iso_name, "bytes_per_launch": by_i / n_i, "slots": locals().get("iso_slots"),
+        iso = {"kernel": iso_name, "bytes_per_launch": by_i / n_i, "slots": locals().get("iso_slots"), "other_buffer_sets": locals().get("fresh"),
                "avg_launch_us": ms_i * 1e3 / n_i, "achieved": by_i / (ms_i * 1e-3) / 1e9, "unit": "GB/s",
                "frac": by_i / (ms_i * 1e-3) / 1e9 / HBM_PEAK_GBPS}
     comm.barrier()

@@ -730,16 +730,18 @@ int await_ack(xmpi_comm* c, MailEntry* m, int dest, int tag) {
 
 }  // namespace
 
-// Blocks of the pull kernel (sched.hip p2p_pull_kernel: 16 KiB in flight per block).  What bounds a message is the memory
-// it comes out of: the sender's HBM when both ranks sit on one GPU -- the whole chip may pull (1024 blocks: 16 MiB went from
-// 680 GB/s with 128 blocks to what the copy kernels reach) -- or ONE link when they do not: blocks beyond bandwidth x latency
-// in flight add nothing but contention, so the cap follows the rate xmpi_link_probe measured for this pair (link_gbps; the
-// nominal 64 GB/s per direction until it has run) at ~4 us of round trip, with a margin of 2.  "p2p_grid_cap" overrides.
-static long p2p_pull_cap(const xmpi_comm* c, int peer) {
+// Blocks of the pull kernel (sched.hip p2p_pull_kernel: 16 KiB in flight per block; every block acquires before and releases
+// after its share -- a cache operation each).  What bounds a message is the memory it comes out of.  Sender and receiver on ONE
+// GPU: the sender's HBM, but the per-block cache operations cost more than extra blocks bring -- 16 MiB, half round trip, r04:
+// 32 blocks 28.9 us, 64 23.6, 128 25.2, 256 34.0, 512 50.8, 1024 92.2 (1 MiB: 11.0 with 32, 12.2 with 64 and more) -- so one
+// block per 256 KiB, at least 16, at most 512.  Different GPUs: ONE link; blocks beyond bandwidth x latency in flight add
+// nothing but contention, so the cap follows the rate xmpi_link_probe measured for this pair (link_gbps; the nominal 64 GB/s
+// per direction until it has run) at ~4 us of round trip, with a margin of 2.  "p2p_grid_cap" / XMPI_P2P_GRID_CAP override.
+static long p2p_pull_cap(const xmpi_comm* c, int peer, size_t bytes) {
   if (c->p2p_grid_cap > 0) return c->p2p_grid_cap;
   const RankInfo* a = c->ctl->info(c->rank);
   const RankInfo* b = c->ctl->info(peer);
-  if (strncmp(a->busid, b->busid, sizeof a->busid) == 0) return 1024;
+  if (strncmp(a->busid, b->busid, sizeof a->busid) == 0) return std::max<long>(16, std::min<long>((long)(bytes >> 18), 512));
   const double gbps = c->link_gbps[peer] > 0 ? c->link_gbps[peer] : 64.0;
   const long blocks = (long)(2.0 * gbps * 1e9 * 4e-6 / 16384.0) + 1;
   return std::max<long>(16, std::min<long>(blocks, 256));
@@ -1329,7 +1331,7 @@ int p2p_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int 
         pa.mail_status = (int32_t*)(mdev + ((char*)&m->status - (char*)m));
         pa.mail_done_value = MAIL_DONE;
         long gx = (long)((bytes + 16383) >> 14);  // a 16 KiB tile per block and pass; how many blocks: p2p_pull_cap
-        gx = std::max<long>(1, std::min<long>(gx, p2p_pull_cap(c, src)));
+        gx = std::max<long>(1, std::min<long>(gx, p2p_pull_cap(c, src, bytes)));
         hipError_t e = launch_p2p_pull(pa, (int)gx, lease.s);
         if (e != hipSuccess) rc = hip_fail(e, "p2p pull kernel", __FILE__, __LINE__);
         bo.n = 0;

@@ -3,6 +3,8 @@ C ABI through mpi_amd.xmpi and checks its own results against the CPU oracle.  O
 test box all ranks share device 0 (functional test of the real multi-process hipIpc path)."""
 from __future__ import annotations
 
+import os
+import sys
 import threading
 
 import numpy as np
@@ -1426,7 +1428,10 @@ def sc_split(comm, args):
         except xmpi.XmpiError as e:
             assert "XCD" in str(e), str(e)
             assert comm.get_param("xcd_short") == 1
-            return
+            # the job is aborted now (a collective failed: nobody may trust the buffers): nothing to meet the peers in any more
+            print(f"rank {rank}/{size} split: ok (the guard refused the launch)")
+            sys.stdout.flush()
+            os._exit(0)
         raise AssertionError("the XCD guard let a short launch pass")
 
 
