@@ -1521,6 +1521,7 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
   if (n == "dsync_ll_launches") return (long)c->dsync_ll_launches;
   if (n == "dsync_grid") return c->dsync_grid_cap;
   if (n == "dsync_split_bytes") return c->dsync_split_bytes;
+  if (n == "roctx") return roctx_enabled() ? 1 : 0;  // named ranges for the profilers are on (trace.h)
   if (n == "xcd_check") return c->xcd_check;
   if (n == "body_sys") return c->body_sys;
   if (n == "xcds") return c->xcds;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One command for an 8-GPU MI355X node: the SCALE line plus the link roofline and per-rank kernel evidence.
-# Run from the repo root; writes under profiles/r03_8gpu/ (small files only).
-#   bash scripts/r03_profile_8gpu.sh [N=8]
+# Run from the repo root; writes under profiles/r04_8gpu/ (small files only).
+#   bash scripts/profile_8gpu.sh [N=8]
 # 1. bench.py --gpus N under torch.distributed.run (one process per GPU, ranks meet on the device): the compact JSON line with
 #    value = algbw @ 256 MiB f32, busbw, `xgmi` {link_probe taken before anything is tuned: SDMA vs copy kernel, write / read /
 #    both directions; wire GB/s per rank and per link against 76.8 / 153 GB/s; frac_of_link_peak}, `config.tuned` = what the
@@ -12,14 +12,19 @@
 #    kernel_stats.csv PER RANK); and the Send / Receive ping-pong between GPU 0 and GPU 1 (half round trip, through the C ABI).
 # 3. BASELINE cfg 5 on the links: examples/cfg5_sweep (fp16, ring vs halving vs the library's choice, 1 MiB ... 1 GiB).
 # 4. the ring kernel's channel count on real links: 1, 2, all.
+# 5. (round 4) FIRST of all: the GPU suite's split-form tests -- on real links this is where the XCD guard's masks and the
+#    system-scope data kernel meet another GPU's memory for the first time; then the split form with and without body_sys, small
+#    collectives with and without LL lines, and a marker trace (named ranges between the kernels).
 set -x
 N=${1:-8}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-O=$ROOT/profiles/r03_8gpu
+O=$ROOT/profiles/r04_8gpu
 mkdir -p $O
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0 XMPI_TIMEOUT_S=120
 BIN=$ROOT/mpi_amd/bin
 cd $ROOT
+timeout 1200 python -m pytest tests/test_gpu_collectives.py -k "split_form or sched or ll_" -x -q > $O/pytest_split_sched_ll.log 2>&1; echo "pytest rc=$?"
+tail -n 5 $O/pytest_split_sched_ll.log
 LAUNCH="python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 29533"
 timeout 1500 $LAUNCH bench.py --gpus $N --steps 20 --warmup 5 > $O/bench_n$N.json 2> $O/bench_n$N.err
 cp bench_extras.json $O/bench_n${N}_extras.json 2>/dev/null
@@ -33,7 +38,15 @@ XMPI_BASEPORT=7280 timeout 300 $BIN/xmpirun 4 $BIN/cfg3_allgather 2097152 20 > $
 for ch in 1 2 0; do
   XMPI_SCHED_CHANNELS=$ch XMPI_BASEPORT=7300 timeout 600 $BIN/xmpirun $N $BIN/allreduce_bench 268435456 20 5 ring > $O/ring_channels_${ch}_n$N.json 2>> $O/prod.err
 done
+for SYS in 0 1; do
+  XMPI_BODY_SYS=$SYS XMPI_BASEPORT=7320 timeout 600 $BIN/xmpirun $N $BIN/allreduce_bench 268435456 20 5 split > $O/split_body_sys${SYS}_n$N.json 2>> $O/prod.err
+done
+for LL in 0 32768; do
+  XMPI_LL_BYTES=$LL XMPI_BASEPORT=7340 timeout 300 $BIN/xmpirun $N $BIN/coll_sweep 1048576 200 > $O/coll_sweep_n${N}_ll$LL.json 2>> $O/prod.err
+done
 cd /tmp
+XMPI_BASEPORT=7360 timeout 300 rocprofv3 --marker-trace --kernel-trace --output-format csv -d $O/markers -- $BIN/xmpirun $N $BIN/coll_sweep 1048576 20 > $O/coll_sweep_under_marker_trace.json 2> $O/markers.err
+for f in $O/markers/*/*marker_api_trace.csv; do head -n 120 $f > $O/marker_trace_$(basename $f | cut -d_ -f1)_head.txt; done
 for m in auto ring rhd; do
   XMPI_BASEPORT=7400 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$m -- $BIN/xmpirun $N $BIN/allreduce_bench 268435456 20 5 $m \
       > $O/prod_${m}_under_rocprof.json 2> $O/stats_$m.err

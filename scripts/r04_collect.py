@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Copies what scripts/r03_profile.sh left in gpurun_out/r03/ (scratch) into profiles/r03/ (tracked): the JSON lines and text
+"""Copies what scripts/r04_profile.sh left in gpurun_out/r04/ (scratch) into profiles/r04/ (tracked): the JSON lines and text
 files as they are, one kernel_stats.csv per profiled process renamed by rank (processes in PID order = ranks in launch order),
 the PMC summaries; and rewrites profiles/pmc_traffic.json (what bench.py reads for `roofline.traffic`) from this run's passes."""
 import glob
@@ -9,17 +9,16 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "r03")
-DST = os.path.join(ROOT, "profiles", "r03")
+SRC = os.path.join(ROOT, "gpurun_out", "r04")
+DST = os.path.join(ROOT, "profiles", "r04")
 
 
 def main():
     if not os.path.isdir(SRC):
-        sys.exit(f"{SRC}: run scripts/r03_profile.sh through gpurun first")
+        sys.exit(f"{SRC}: run scripts/r04_profile.sh through gpurun first")
     os.makedirs(DST, exist_ok=True)
-    keep = ("host_slices_through_ctypes.txt", "bench_n1_uncoloured_fast_box.json", "bench_n1_default_fast_box.json")  # from other calls
-    for f in glob.glob(os.path.join(DST, "*")):
-        if os.path.basename(f) not in keep:
+    for f in glob.glob(os.path.join(DST, "*")):  # (the directories -- cpx/, guard/ -- are other calls' evidence: kept)
+        if os.path.isfile(f):
             os.remove(f)
     for f in sorted(glob.glob(os.path.join(SRC, "*.json")) + glob.glob(os.path.join(SRC, "*.txt"))):
         if os.path.getsize(f):
@@ -47,6 +46,8 @@ def main():
                              "WRITE_SIZE_KiB_mean": row["WRITE_SIZE_KiB_mean"], "algorithmic_bytes_per_launch": want[k][1]})
     old = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     old["rows"] = rows
+    old["round"] = 4
+    old["source"] = old["source"].replace("r03_profile", "r04_profile")
     json.dump(old, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
     print(len(os.listdir(DST)), "files in", DST)
     for r in rows:

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 evidence on one MI355X (run through gpurun from the repo root); everything lands in gpurun_out/r03/:
+# Round-4 evidence on one MI355X (run through gpurun from the repo root); everything lands in gpurun_out/r04/:
 #   1. the default bench line (N=1: 8 ranks as threads of one process; roofline_production from 8 processes)
 #   2. rocprofv3 --kernel-trace --stats of the N=1 line's command (reduce_n_multi_kernel)
 #   3. THE PRODUCTION LAYOUT: one OS process per rank, 8 x 256 MiB f32 (examples/allreduce_bench under the launcher), modes
@@ -8,10 +8,12 @@
 #   4. PMC traffic (separate --pmc passes, kernel-trace only) of the N=1 command and of the production layout
 #   5. what a collective costs the caller's other streams (scripts/overlap_probe.hip, 2 processes); BASELINE cfg 5 with one
 #      process per rank (examples/cfg5_sweep); the production program at 2 / 4 processes and at 16 MiB / 1 MiB
+#   6. (round 4) small collectives with and without LL lines; the split form with the system-scope data kernel; roctx ranges
+#      under rocprofv3 --marker-trace; the fold on different buffer sets (scripts/r04_gap.py)
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
-O=$GRAFT_REPO_ROOT/gpurun_out/r03
+O=$GRAFT_REPO_ROOT/gpurun_out/r04
 rm -rf $O; mkdir -p $O
 BIN=$GRAFT_REPO_ROOT/mpi_amd/bin
 timeout 600 python bench.py > $O/bench_n1_default.json 2> $O/bench_n1_default.err
@@ -50,6 +52,15 @@ XMPI_HOST_LANES=0 XMPI_BASEPORT=8150 timeout 100 $BIN/xmpirun 2 $BIN/bounce --ho
 # blocking vs enqueued collectives, 1 KiB ... 1 MiB (completion word instead of an event)
 XMPI_BASEPORT=8200 timeout 100 $BIN/xmpirun 2 $BIN/coll_sweep 1048576 200 > $O/coll_sweep_2proc.json 2>> $O/prod.err
 XMPI_BASEPORT=8250 timeout 100 $BIN/xmpirun 8 $BIN/coll_sweep 1048576 200 > $O/coll_sweep_8proc.json 2>> $O/prod.err
+# round 4: LL lines on / off, the system-scope data kernel, named ranges, buffer sets
+for N in 2 8; do for LL in 0 32768; do
+  XMPI_LL_BYTES=$LL XMPI_BASEPORT=$((8300 + N * 10 + LL / 8192)) timeout 100 $BIN/xmpirun $N $BIN/coll_sweep 1048576 200 > $O/coll_sweep_${N}proc_ll$LL.json 2>> $O/prod.err
+done; done
+XMPI_BODY_SYS=1 XMPI_BASEPORT=8400 timeout 200 $PROD split > $O/prod_8proc_256MiB_body_sys.json 2>> $O/prod.err
+XMPI_BODY_SYS=1 XMPI_BASEPORT=8420 timeout 200 $BIN/xmpirun 2 $BIN/allreduce_bench 268435456 20 5 split > $O/prod_2proc_256MiB_body_sys.json 2>> $O/prod.err
+XMPI_BASEPORT=8440 timeout 200 rocprofv3 --marker-trace --kernel-trace --output-format csv -d $O/markers -- $BIN/xmpirun 2 $BIN/coll_sweep 1048576 20 > $O/coll_sweep_under_marker_trace.json 2> $O/markers.err
+for f in $O/markers/*/*marker_api_trace.csv; do head -n 120 $f > $O/marker_trace_$(basename $f | cut -d_ -f1)_head.txt; done
+timeout 200 python $GRAFT_REPO_ROOT/scripts/r04_gap.py 256 > $O/gap_buffer_sets.json 2>> $O/prod.err
 cd $GRAFT_REPO_ROOT
 python scripts/pmc_summary.py $O/fetch_n1 $O/write_n1 reduce_n_multi > $O/pmc_bench_zcopy.json
 python scripts/pmc_summary.py $O/fetch_prod $O/write_prod dsync_ > $O/pmc_prod.json 2>> $O/prod.err

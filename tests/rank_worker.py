@@ -56,6 +56,8 @@ def main():
     try:
         for k, v in args.get("params", {}).items():
             comm.set_param(k, v)
+        for k, v in args.get("expect_params", {}).items():
+            assert comm.get_param(k) == v, f"{k} = {comm.get_param(k)}, expected {v}"
         scenarios.SCENARIOS[name](comm, args)
         comm.barrier()
     except BaseException:

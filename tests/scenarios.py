@@ -916,6 +916,29 @@ def sc_fullsize(comm, args):
     comm.copy_local(out, send, count * es)
     comm.allreduce(out, out, count, dtype, xmpi.SUM, xmpi.ALGO_ZCOPY)
     assert comm.count_mismatch(out, ref, count * es) == 0, f"{which}: in-place zero-copy differs"
+    if comm.get_param("dsync") == 1:
+        # the split form at full size: every launch's meet / done blocks reached every XCD (checked on the device), and its
+        # system-scope data kernel (the form that needs no such coverage) gives the same bits
+        assert comm.get_param("xcd_short") == 0
+        comm.set_param("dsync_split_bytes", 1)
+        comm.set_param("body_sys", 1)
+        comm.memset(out, 0, count * es)
+        comm.allreduce(send, out, count, dtype, xmpi.SUM, xmpi.ALGO_ZCOPY)
+        assert comm.count_mismatch(out, ref, count * es) == 0, f"{which}: split form with the system-scope data kernel differs"
+        comm.set_param("body_sys", 0)
+        comm.set_param("dsync_split_bytes", 4 << 20)
+        # binary-tree reduce (the stepped kernel) to the last rank, and LL's refusal of a long message (it names the fold then)
+        root = size - 1
+        comm.memset(out, 0, count * es)
+        comm.reduce(send, out if rank == root else None, count, dtype, xmpi.SUM, root, xmpi.ALGO_TREE)
+        if rank == root:
+            if dtype == xmpi.F16:
+                assert comm.count_mismatch(out, ref, count * es) == 0, f"{which}: tree reduce not bit-identical"
+            else:
+                assert comm.diff_rel(out, ref, count, dtype) <= 1e-6, f"{which}: tree reduce beyond 1e-6 * sum|x|"
+        comm.memset(out, 0, count * es)
+        comm.allreduce(send, out, count, dtype, xmpi.SUM, xmpi.ALGO_LL)
+        assert comm.count_mismatch(out, ref, count * es) == 0, f"{which}: XMPI_ALGO_LL above its limit is not the fold"
 
 
 def np_hash(seed: int, idx: np.ndarray) -> np.ndarray:

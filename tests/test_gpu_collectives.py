@@ -220,6 +220,15 @@ def test_split_form(size):
     run_ranks("split", size, timeout=600)
 
 
+def test_roctx_ranges_on():
+    """XMPI_ROCTX=1: the marker library is found at run time (nothing links it) and every collective / launch / message pushes and
+    pops its range; the results are what they are without"""
+    run_ranks("allreduce_small", 2, {"counts": [1, 4099, 65536 + 5], "dtypes": [4, 3], "expect_params": {"roctx": 1}}, timeout=300,
+              env={"XMPI_ROCTX": "1"})
+    run_ranks("bounce", 2, timeout=300, env={"XMPI_ROCTX": "1"})
+    run_ranks("allreduce_small", 2, {"counts": [17], "dtypes": [4], "expect_params": {"roctx": 0}}, timeout=300, env={"XMPI_ROCTX": "0"})
+
+
 def test_split_form_xcd_guard_trips():
     """the done kernel refuses a collective whose meet / done blocks did not reach as many XCDs as it was told the GPU has"""
     run_ranks("split", 2, {"counts": [4099], "trip": 1}, timeout=300)
