@@ -1458,6 +1458,129 @@ def sc_split(comm, args):
         raise AssertionError("the XCD guard let a short launch pass")
 
 
+def sc_soak(comm, args):
+    """A long seeded random walk over everything the device-synchronised path offers, every result checked against the oracle:
+    collectives of every kind in every form (LL lines, one-kernel fold, meet / body / done with either data kernel, push-only,
+    ring / halving / tree kernels), blocking and stream-ordered on two streams, Send / Receive rings between them, parameters
+    flipped between calls.  What the single-form tests cannot see is what one form leaves behind for the next on the shared,
+    never-cleared flag page: epochs, slot parities, tickets, step words, boxes.  Every rank draws the same sequence."""
+    import random
+    rank, size = comm.rank(), comm.size()
+    rng = random.Random(args.get("seed", 20260921))
+    dev = comm.get_param("dsync") == 1
+    steps = args.get("steps", 200)
+    A = xmpi
+    streams = [comm.stream_create(), comm.stream_create()] if dev else []
+    pending = []  # (kind, buffers ..., expected) of stream-ordered collectives not yet looked at
+    pending_send = []
+    dtypes = (A.F32, A.I64, A.F16, A.F64, A.I32, A.U8, A.BF16)
+
+    def pick_count():
+        r = rng.random()
+        if r < 0.35:
+            return rng.choice([1, 2, 3, 17, 255, 256, 257, 1000])
+        if r < 0.7:
+            return rng.randrange(1, 9000)
+        if r < 0.93:
+            return rng.randrange(9000, 300000)
+        return rng.randrange(300000, (3 << 20))
+
+    def drain():
+        for st in streams:
+            comm.stream_sync(st)
+        for what, recv, count, dtype, ins, op, exact in pending:
+            got = recv.download(A.NUMPY_DTYPE[dtype], count)
+            check_reduced(got, ins, dtype, op, exact, what)
+            recv.free()
+        pending.clear()
+
+    done = {}
+    for k in range(steps):
+        kind = rng.choice(["allreduce"] * 5 + ["allgather", "bcast", "reduce", "p2p", "stream_allreduce", "stream_allreduce", "params"])
+        done[kind] = done.get(kind, 0) + 1
+        dtype = rng.choice(dtypes)
+        count = pick_count()
+        es = A.DTYPE_SIZE[dtype]
+        if kind == "params" and dev:
+            comm.set_param("dsync_split_bytes", rng.choice([0, 1, 65536, 4 << 20]))
+            comm.set_param("body_sys", rng.choice([0, 0, 1]))
+            comm.set_param("ll_bytes", rng.choice([0, 1024, 8192, 32768]))
+            comm.set_param("dsync_unroll", rng.choice([1, 2]))
+            continue
+        if kind == "allreduce":
+            algos = [A.ALGO_AUTO, A.ALGO_ZCOPY, A.ALGO_ZPUSH, A.ALGO_RING, A.ALGO_LL] + ([A.ALGO_RHD] if dev or size & (size - 1) == 0 else [])
+            algo = rng.choice(algos)
+            op = rng.choice([A.SUM, A.SUM, A.SUM, A.PROD, A.MIN, A.MAX])
+            pat = rng.choice([A.PAT_UNIFORM, A.PAT_SIGNED])
+            inplace = rng.random() < 0.3 and algo != A.ALGO_ZPUSH
+            mis = rng.choice([0, 0, 0, 1, 3])
+            rank_order = algo in (A.ALGO_AUTO, A.ALGO_ZCOPY, A.ALGO_ZPUSH, A.ALGO_LL) or size <= 2
+            if not rank_order and op == A.PROD and dtype in FLOATS:
+                op = A.SUM  # (products in another order: the stated tolerance is for sums)
+            exact = rank_order or op in (A.MIN, A.MAX) or dtype in (A.I64, A.I32, A.U8) or (dtype in (A.F16, A.BF16) and pat == A.PAT_UNIFORM and op == A.SUM)
+            allreduce_case(comm, dtype, count, algo, op=op, pattern=pat, inplace=inplace, seed0=3000 + k, exact=exact, misalign=mis)
+        elif kind == "allgather":
+            allgather_case(comm, rng.choice([A.I64, A.U8, A.F32]), min(count, 200000), rng.choice([A.ALGO_AUTO, A.ALGO_RING, A.ALGO_ZCOPY, A.ALGO_LL]),
+                           inplace=rng.random() < 0.3)
+        elif kind == "bcast":
+            bcast_case(comm, dtype, count, rng.randrange(size), rng.choice([A.ALGO_AUTO, A.ALGO_TREE, A.ALGO_ZCOPY, A.ALGO_LL]), seed=40 + k)
+        elif kind == "reduce":
+            algo = rng.choice([A.ALGO_AUTO, A.ALGO_TREE, A.ALGO_ZCOPY, A.ALGO_LL])
+            pat = rng.choice([A.PAT_UNIFORM, A.PAT_SIGNED])
+            exact = algo != A.ALGO_TREE or size <= 2 or dtype in (A.I64, A.I32, A.U8) or (dtype in (A.F16, A.BF16) and pat == A.PAT_UNIFORM)
+            reduce_case(comm, dtype, min(count, 500000), rng.randrange(size), algo, pat=pat, exact=exact)
+        elif kind == "p2p" and size > 1:
+            # a ring of blocking messages: even ranks send first, odd ranks receive first (rendezvous sends: no cycle may form)
+            n = min(count, 400000)
+            tag = 500 + (k % 7)
+            nxt, prv = (rank + 1) % size, (rank + size - 1) % size
+            out, inn = comm.alloc(n * es), comm.alloc(n * es)
+            comm.fill(out, n, dtype, A.PAT_SIGNED, 9000 + k * 16 + rank)
+            comm.memset(inn, 0, n * es)
+            first_send = rank % 2 == 0 and not (size % 2 == 1 and rank == size - 1)
+            if first_send:
+                comm.send(out, n, dtype, nxt, tag)
+                comm.recv(inn, n, dtype, prv, tag)
+            else:
+                comm.recv(inn, n, dtype, prv, tag)
+                comm.send(out, n, dtype, nxt, tag)
+            want = oracle.fill(n, dtype, A.PAT_SIGNED, 9000 + k * 16 + prv)
+            assert inn.download(A.NUMPY_DTYPE[dtype], n).tobytes() == want.tobytes(), f"soak step {k}: message from {prv}"
+            out.free()
+            inn.free()
+        elif kind == "stream_allreduce" and dev:
+            # enqueued, not waited for: the next operations (any form, any stream) run right behind it
+            st = rng.choice(streams)
+            n = min(count, 250000)
+            send, recv = comm.alloc(n * es), comm.alloc(n * es)
+            comm.fill(send, n, dtype, A.PAT_UNIFORM, 5000 + k * 16 + rank)
+            comm.allreduce_on_stream(send, recv, n, dtype, A.SUM, st)
+            ins = [oracle.fill(n, dtype, A.PAT_UNIFORM, 5000 + k * 16 + r) for r in range(size)]
+            pending.append((f"soak step {k}: stream-ordered allreduce {A.DTYPE_NAME[dtype]} n={n}", recv, n, dtype, ins, A.SUM, True))
+            if len(pending) >= 6 or rng.random() < 0.25:
+                drain()
+            # (send is read by peers until the collective is over: freed by the drain's successor -- kept alive in the tuple's closure)
+            pending_send.append(send)
+        if k % 50 == 49:
+            drain()
+            for b in pending_send:
+                b.free()
+            pending_send.clear()
+    drain()
+    for b in pending_send:
+        b.free()
+    for st in streams:
+        comm.stream_destroy(st)
+    if dev:
+        assert comm.get_param("xcd_short") == 0
+        comm.set_param("dsync_split_bytes", 4 << 20)
+        comm.set_param("body_sys", 0)
+    if rank == 0:
+        forms = {k: comm.get_param(k) for k in ("dsync_launches", "dsync_ll_launches", "dsync_split_launches", "dsync_sched_launches",
+                                               "p2p_direct_count", "p2p_agent_served", "zc_seq")}
+        print(f"soak: {steps} steps {done}; {forms}")
+
+
 def sc_multistream(comm, args):
     """Device-synchronised collectives of one rank on DIFFERENT streams with no host synchronisation between them (a
     stream-ordered one on a user stream, a blocking one on the communicator's stream right behind it, another user
@@ -1587,6 +1710,7 @@ def sc_tune(comm, args):
 SCENARIOS = {
     "ll": sc_ll,
     "sched": sc_sched,
+    "soak": sc_soak,
     "split": sc_split,
     "multistream": sc_multistream,
     "p2p_stream": sc_p2p_stream,

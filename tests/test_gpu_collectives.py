@@ -220,6 +220,17 @@ def test_split_form(size):
     run_ranks("split", size, timeout=600)
 
 
+@pytest.mark.parametrize("size,seed", [(2, 1), (3, 2), (5, 3), (8, 4)])
+def test_soak_every_form_mixed(size, seed):
+    """a seeded random walk over every collective in every form, blocking and stream-ordered, with Send / Receive rings between
+    them and parameters flipped between calls: what one form leaves on the shared flag page for the next"""
+    run_ranks("soak", size, {"seed": seed, "steps": 600 if size < 8 else 300}, timeout=900)
+
+
+def test_soak_threads_layout():
+    run_threads("soak", 4, {"seed": 9, "steps": 200})
+
+
 def test_roctx_ranges_on():
     """XMPI_ROCTX=1: the marker library is found at run time (nothing links it) and every collective / launch / message pushes and
     pops its range; the results are what they are without"""
