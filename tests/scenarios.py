@@ -1496,7 +1496,8 @@ def sc_soak(comm, args):
 
     done = {}
     for k in range(steps):
-        kind = rng.choice(["allreduce"] * 5 + ["allgather", "bcast", "reduce", "p2p", "stream_allreduce", "stream_allreduce", "params"])
+        kind = rng.choice(["allreduce"] * 5 + ["allgather", "bcast", "reduce", "p2p", "stream_allreduce", "stream_allreduce", "params",
+                           "stream_p2p", "nonblocking", "host_slices", "graph"])
         done[kind] = done.get(kind, 0) + 1
         dtype = rng.choice(dtypes)
         count = pick_count()
@@ -1561,6 +1562,89 @@ def sc_soak(comm, args):
                 drain()
             # (send is read by peers until the collective is over: freed by the drain's successor -- kept alive in the tuple's closure)
             pending_send.append(send)
+        elif kind == "stream_p2p" and dev and size > 1:
+            # the stream-ordered pair as a ring on ONE stream per rank: even ranks send first, odd ranks receive first -- a waiting
+            # kernel holds its stream AND the hardware queue under it, and two streams of a process may share a queue (the
+            # harness gives every process two: GPU_MAX_HW_QUEUES), so "the receive is on another stream" promises nothing:
+            # with send and receive on two streams this very walk deadlocked, every rank's receive queued behind its own send
+            drain()
+            n = min(count, 100000)
+            tag = 700 + (k % 5)
+            nxt, prv = (rank + 1) % size, (rank + size - 1) % size
+            out, inn = comm.alloc(n * es), comm.alloc(n * es)
+            comm.fill(out, n, dtype, A.PAT_SIGNED, 11000 + k * 16 + rank)
+            comm.memset(inn, 0, n * es)
+            st = streams[k % 2]
+            if rank % 2 == 0:
+                comm.send_on_stream(out, n, dtype, nxt, tag, st)
+                comm.recv_on_stream(inn, n, dtype, prv, tag, st)
+            else:
+                comm.recv_on_stream(inn, n, dtype, prv, tag, st)
+                comm.send_on_stream(out, n, dtype, nxt, tag, st)
+            comm.stream_sync(st)
+            want = oracle.fill(n, dtype, A.PAT_SIGNED, 11000 + k * 16 + prv)
+            assert inn.download(A.NUMPY_DTYPE[dtype], n).tobytes() == want.tobytes(), f"soak step {k}: stream-ordered message from {prv}"
+            out.free()
+            inn.free()
+        elif kind == "nonblocking":
+            # two collectives handed to the communicator's worker, a blocking one issued behind them (it runs after them)
+            n = min(count, 120000)
+            s1, r1 = comm.alloc(n * es), comm.alloc(n * es)
+            g1, g2 = comm.alloc(n * 8), comm.alloc(n * 8 * size)
+            comm.fill(s1, n, dtype, A.PAT_UNIFORM, 13000 + k * 16 + rank)
+            comm.fill(g1, n, A.I64, A.PAT_INDEX, rank)
+            q1 = comm.iallreduce(s1, r1, n, dtype, A.SUM, A.ALGO_AUTO)
+            q2 = comm.iallgather(g1, g2, n, A.I64)
+            allreduce_case(comm, A.I32, 1 + n // 7, A.ALGO_AUTO, seed0=13500 + k, exact=True)
+            comm.request_wait(q2)
+            comm.request_wait(q1)
+            ins = [oracle.fill(n, dtype, A.PAT_UNIFORM, 13000 + k * 16 + r) for r in range(size)]
+            check_reduced(r1.download(A.NUMPY_DTYPE[dtype], n), ins, dtype, A.SUM, True, f"soak step {k}: iallreduce")
+            want = oracle.allgather([oracle.fill(n, A.I64, A.PAT_INDEX, r) for r in range(size)], A.I64)
+            assert g2.download(np.int64, n * size).tobytes() == want.tobytes(), f"soak step {k}: iallgather"
+            for b in (s1, r1, g1, g2):
+                b.free()
+        elif kind == "host_slices":
+            # what the reference's callers pass: host memory on both sides of a collective and of a message
+            n = min(count, 70000)
+            x = oracle.fill(n, dtype, A.PAT_UNIFORM, 15000 + k * 16 + rank)
+            y = np.zeros_like(x)
+            comm.allreduce(x, y, n, dtype, A.SUM, A.ALGO_AUTO)
+            ins = [oracle.fill(n, dtype, A.PAT_UNIFORM, 15000 + k * 16 + r) for r in range(size)]
+            check_reduced(y, ins, dtype, A.SUM, True, f"soak step {k}: allreduce of host slices")
+            if size > 1:
+                nxt, prv = (rank + 1) % size, (rank + size - 1) % size
+                z = np.zeros_like(x)
+                if rank % 2 == 0 and not (size % 2 == 1 and rank == size - 1):
+                    comm.send(x, n, dtype, nxt, 900)
+                    comm.recv(z, n, dtype, prv, 900)
+                else:
+                    comm.recv(z, n, dtype, prv, 900)
+                    comm.send(x, n, dtype, nxt, 900)
+                assert z.tobytes() == ins[prv].tobytes(), f"soak step {k}: host slice from {prv}"
+        elif kind == "graph" and dev:
+            # a captured pair of collectives replayed a few times between everything else (the epoch is counted on the device)
+            drain()
+            m = min(count, 50000)
+            g1, g2 = comm.alloc(m * 8), comm.alloc(m * 8)
+            comm.fill(g1, m, A.I64, A.PAT_CONST, 0)
+            st = streams[k % 2]
+            comm.graph_begin(st)
+            comm.allreduce_on_stream(g1, g2, m, A.I64, A.SUM, st)
+            comm.allreduce_on_stream(g2, g1, m, A.I64, A.SUM, st)
+            graph = comm.graph_end(st)
+            reps = rng.choice([1, 2, 3])
+            first = int(g1.download(np.int64, 1)[0])
+            for _ in range(reps):
+                comm.graph_launch(graph, st)
+            comm.stream_sync(st)
+            want = np.uint64(first)
+            for _ in range(2 * reps):
+                want = want * np.uint64(size)
+            assert np.all(g1.download(np.int64, m).view(np.uint64) == want), f"soak step {k}: graph replays"
+            comm.graph_destroy(graph)
+            g1.free()
+            g2.free()
         if k % 50 == 49:
             drain()
             for b in pending_send:
