@@ -6,6 +6,18 @@
 
 #include "kernels.h"
 
+// ---- the few constructs a host compiler cannot take, behind names ------------------------------------------------------
+// tests/devsim/ compiles THESE kernel sources for the CPU (lanes as threads, under ThreadSanitizer) to race the flag protocols
+// of the code that ships instead of a model of them; it defines XMPI_DEVSIM and supplies its own versions of the four macros
+// and of the system-scope packet accessors further down.  Nothing else in the kernels knows about it.
+#ifndef XMPI_DEVSIM
+#define XMPI_SHARED(T, name) __shared__ T name
+// this wave's memory operations have completed (stores: acknowledged by where they were written to)
+#define XMPI_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define XMPI_REGS_DEFINED4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+#define XMPI_REG_DEFINED(a) asm volatile("" : "+v"(a)::"memory")
+#endif
+
 namespace xmpi {
 namespace {
 
@@ -232,7 +244,7 @@ __device__ void dsync_begin(const DsyncArgs& a, DsyncShared& sh) {
 __device__ void dsync_end(const DsyncArgs& a, DsyncShared& sh, bool xcd_guard = false) {
   const int t = threadIdx.x, me = a.me, n = a.n;
   DsyncPage* mine = a.page[me];
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left
+  XMPI_DRAIN();  // this wave's stores have left
   __syncthreads();
   if (t == 0) {
     // a block that gave up (its own wait timed out, the job was aborted) says so where the closing block looks:
@@ -285,6 +297,7 @@ __device__ void dsync_end(const DsyncArgs& a, DsyncShared& sh, bool xcd_guard = 
 // loads.  (The alternative -- ordinary accesses bracketed by release / acquire fences -- writes back and invalidates a
 // whole L2 per block per step: 2.64 ms for the 8 x 256 MiB ring where the data alone needs 1.7, r03 session 1.)
 // The loads are asynchronous inline assembly: sys128_wait() is what makes their results usable.
+#ifndef XMPI_DEVSIM
 __device__ __forceinline__ void ld_sys128_issue(pack_t& v, const pack_t* p) {
   asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(v) : "v"(p) : "memory");
 }
@@ -300,12 +313,13 @@ __device__ __forceinline__ void sys128_wait(pack_t (&v)[U]) {
   else if constexpr (U == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1])::"memory");
   else asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])::"memory");
 }
+#endif
 // any number of packets: one wait, then every register passes through an (empty) volatile statement behind it
 template <int U>
 __device__ __forceinline__ void sys128_wait_n(pack_t* v) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  XMPI_DRAIN();
 #pragma unroll
-  for (int k = 0; k < U; k++) asm volatile("" : "+v"(v[k])::"memory");
+  for (int k = 0; k < U; k++) XMPI_REG_DEFINED(v[k]);
 }
 // one element, same scope (the ragged ends of a tile, buffers at odd alignments)
 template <typename T>

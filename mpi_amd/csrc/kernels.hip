@@ -624,7 +624,7 @@ __global__ void signal_kernel(uint64_t* flag, uint64_t value) {
 // trips, so the deeper variant is for links); NSRC == 0: any number, one load at a time.
 template <typename T, int OP, int NSRC, int U>
 __global__ __launch_bounds__(kBlock) void dsync_fold_kernel(DsyncArgs a) {
-  __shared__ DsyncShared sh;
+  XMPI_SHARED(DsyncShared, sh);
   dsync_begin(a, sh);
   if (sh.fail == DSYNC_OK && a.nseg > 0) {
     const DsyncSeg& g = a.seg[blockIdx.y];

@@ -110,10 +110,10 @@ __device__ __forceinline__ bool ll_gather(const DsyncLLArgs& a, LLShared& sh, ui
 #pragma unroll
     for (int p = 0; p < kDsyncRanks; p++)
       if (pending >> p & 1u) ld_sys128_issue(v[p], reinterpret_cast<const pack_t*>(ll_slot(mine, p, parity) + idx * 16));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    XMPI_DRAIN();
 #pragma unroll
     for (int p = 0; p < kDsyncRanks; p += 4)  // (the loads' results may be used from here on)
-      asm volatile("" : "+v"(v[p]), "+v"(v[p + 1]), "+v"(v[p + 2]), "+v"(v[p + 3]));
+      XMPI_REGS_DEFINED4(v[p], v[p + 1], v[p + 2], v[p + 3]);
 #pragma unroll
     for (int p = 0; p < kDsyncRanks; p++)
       if ((pending >> p & 1u) && v[p].y == flag && v[p].w == flag) {
@@ -140,7 +140,7 @@ __device__ __forceinline__ bool ll_gather(const DsyncLLArgs& a, LLShared& sh, ui
 // peers: nobody reads this rank's buffers, and the slots are safe by the parity argument (kernels.h).
 __device__ __forceinline__ void ll_end(const DsyncLLArgs& a, LLShared& sh) {
   DsyncPage* mine = a.page[a.me];
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  XMPI_DRAIN();
   __syncthreads();
   if (threadIdx.x != 0) return;
   if (gridDim.x > 1) {
@@ -161,7 +161,7 @@ __device__ __forceinline__ void ll_end(const DsyncLLArgs& a, LLShared& sh) {
 // allreduce / reduce: thread i owns payload bytes [8 i, 8 i + 8)
 template <typename T, int OP>
 __global__ __launch_bounds__(kBlock) void ll_reduce_kernel(DsyncLLArgs a) {
-  __shared__ LLShared sh;
+  XMPI_SHARED(LLShared, sh);
   ll_begin(a, sh);
   const int me = a.me, n = a.n;
   const uint64_t epoch = sh.epoch;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kBlock) void ll_reduce_kernel(DsyncLLArgs a) {
 
 // broadcast / allgather: bytes only
 __global__ __launch_bounds__(kBlock) void ll_copy_kernel(DsyncLLArgs a) {
-  __shared__ LLShared sh;
+  XMPI_SHARED(LLShared, sh);
   ll_begin(a, sh);
   const int me = a.me, n = a.n;
   const uint64_t epoch = sh.epoch;

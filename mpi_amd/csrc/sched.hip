@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64) void xcc_probe_kernel(uint32_t* mask) {
 // block 0 translates the peers' buffers and leaves what the data kernel needs in ordinary device memory (the kernel
 // boundary publishes it).  No completion exchange here: the done kernel does it.
 __global__ __launch_bounds__(64) void dsync_meet_kernel(DsyncArgs a, DsyncResolved* out) {
-  __shared__ DsyncShared sh;
+  XMPI_SHARED(DsyncShared, sh);
   dsync_begin(a, sh);
   // this block has acquired the L2 of the XCD it runs on
   if (threadIdx.x == 0) __hip_atomic_fetch_or(&a.page[a.me]->xcc_meet, 1u << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void dsync_body_kernel(const DsyncResolved*
 // =====================================================================================================================
 
 __global__ __launch_bounds__(64) void dsync_done_kernel(DsyncArgs a, const DsyncResolved* res) {
-  __shared__ DsyncShared sh;
+  XMPI_SHARED(DsyncShared, sh);
   if (threadIdx.x == 0) {
     sh.epoch = res->epoch;
     sh.fail = res->fail;
@@ -280,8 +280,8 @@ __device__ void range_apply(uint64_t D, uint64_t A, uint64_t B, size_t rlo, size
 
 template <typename T, int OP>
 __global__ __launch_bounds__(kBlock) void dsync_sched_kernel(DsyncSchedArgs a) {
-  __shared__ DsyncShared sh;
-  __shared__ SchedStep st;
+  XMPI_SHARED(DsyncShared, sh);
+  XMPI_SHARED(SchedStep, st);
   dsync_begin(a.d, sh);
   const int t = threadIdx.x, me = a.d.me;
   const uint32_t W = gridDim.x * gridDim.y, w = blockIdx.y * gridDim.x + blockIdx.x;
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(kBlock) void dsync_sched_kernel(DsyncSchedArgs a) {
       const uint64_t D = st.D, A = st.A, B = st.B, lo = st.lo, hi = st.hi;
       if (ns == 2) range_apply<T, OP, 2>(D, A, B, lo, hi, w, W);
       else if (ns == 1) range_apply<uint8_t, OP_SUM, 1>(D, A, A, lo, hi, w, W);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      XMPI_DRAIN();
       __syncthreads();
       if (t == 0 && (st.sig[0] >= 0 || st.sig[1] >= 0)) {
         // every wave has waited for the acknowledgements of its (written-through) stores: the flag may follow them
@@ -382,9 +382,12 @@ __global__ __launch_bounds__(64) void p2p_send_kernel(P2PArgs a) {
 // Block 0 finds the box of (peer -> me) that carries this tag, checks it, translates where the payload lives and
 // tells the other blocks (go record); everybody copies; the block that finishes last answers the sender and the host.
 __global__ __launch_bounds__(kBlock) void p2p_recv_kernel(P2PArgs a) {
-  __shared__ uint64_t s_src, s_bytes, s_status, s_seq;
-  __shared__ int s_box;
-  __shared__ uint32_t s_last;
+  XMPI_SHARED(uint64_t, s_src);
+  XMPI_SHARED(uint64_t, s_bytes);
+  XMPI_SHARED(uint64_t, s_status);
+  XMPI_SHARED(uint64_t, s_seq);
+  XMPI_SHARED(int, s_box);
+  XMPI_SHARED(uint32_t, s_last);
   const int t = threadIdx.x;
   P2PGo* go = p2p_go(a.my_page) + (a.op_id % kP2PGoSlots);
   if (t == 0) {
@@ -480,7 +483,7 @@ __global__ __launch_bounds__(kBlock) void p2p_recv_kernel(P2PArgs a) {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // the payload as the sender left it, not a stale line
   const uint64_t src = s_src, bytes = s_status ? 0 : s_bytes;
   if (bytes) copy_span(reinterpret_cast<char*>(a.buf), reinterpret_cast<const char*>(src), bytes);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  XMPI_DRAIN();
   __syncthreads();
   if (t == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
@@ -502,11 +505,11 @@ __global__ __launch_bounds__(kBlock) void p2p_recv_kernel(P2PArgs a) {
 // where the SENDER's host thread polls (its mail entry in the shared control block, over PCIe) and the completion word
 // where this rank's host thread polls.  No event, no host hop between the copy and the ack (network.go:616-624).
 __global__ __launch_bounds__(kBlock) void p2p_pull_kernel(P2PPullArgs a) {
-  __shared__ uint32_t s_last;
+  XMPI_SHARED(uint32_t, s_last);
   const int t = threadIdx.x;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // the payload as the sender left it, not a stale line
   copy_span(reinterpret_cast<char*>(a.dst), reinterpret_cast<const char*>(a.src), a.bytes);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  XMPI_DRAIN();
   __syncthreads();
   if (t == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
@@ -539,8 +542,13 @@ __global__ __launch_bounds__(kBlock) void p2p_pull_kernel(P2PPullArgs a) {
 // halves carry the expected number.  cmd[6] = number of the last command served; cmd[7] = "gone" (the number the agent was
 // waiting for, plus one).
 __global__ __launch_bounds__(kBlock) void p2p_agent_kernel(P2PAgentArgs a) {
-  __shared__ uint64_t s_src, s_dst, s_bytes, s_mail, s_seq;
-  __shared__ uint32_t s_go, s_last;
+  XMPI_SHARED(uint64_t, s_src);
+  XMPI_SHARED(uint64_t, s_dst);
+  XMPI_SHARED(uint64_t, s_bytes);
+  XMPI_SHARED(uint64_t, s_mail);
+  XMPI_SHARED(uint64_t, s_seq);
+  XMPI_SHARED(uint32_t, s_go);
+  XMPI_SHARED(uint32_t, s_last);
   const int t = threadIdx.x;
   // device memory: [0] what block 0 tells the other blocks: (launch << 40 | n) << 1 | go for its n-th word to them (the record
   // outlives launches: the launch number keeps a stale word of the launch before from being taken for this one's),
@@ -601,7 +609,7 @@ __global__ __launch_bounds__(kBlock) void p2p_agent_kernel(P2PAgentArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // the payload as the sender left it, not a stale line
     if (wide) copy_span(reinterpret_cast<char*>(s_dst), reinterpret_cast<const char*>(s_src), s_bytes);
     else copy_span(reinterpret_cast<char*>(s_dst), reinterpret_cast<const char*>(s_src), s_bytes, 0, 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    XMPI_DRAIN();
     __syncthreads();
     if (t == 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
