@@ -762,9 +762,11 @@ static bool agent_submit(xmpi_comm* c, void* dst, const void* from, size_t bytes
   volatile uint64_t* cmd = c->p2p_cmd;
   const uint64_t seq = ++c->agent_seq;
   const uint64_t mail_off = (uint64_t)((char*)&m->state - (char*)c->ctl->base());
-  cmd[1] = (uint64_t)(uintptr_t)from;
-  cmd[2] = (uint64_t)(uintptr_t)dst;
-  cmd[3] = (mail_off & 0xffffffffull) | (seq << 32);
+  // (the agent polls all four words while they are written and takes them only when [0] and [3] both carry this number:
+  // every word is an atomic store, so that the words it reads early are merely old, never torn)
+  __atomic_store_n((uint64_t*)&cmd[1], (uint64_t)(uintptr_t)from, __ATOMIC_RELAXED);
+  __atomic_store_n((uint64_t*)&cmd[2], (uint64_t)(uintptr_t)dst, __ATOMIC_RELAXED);
+  __atomic_store_n((uint64_t*)&cmd[3], (mail_off & 0xffffffffull) | (seq << 32), __ATOMIC_RELEASE);
   __atomic_store_n((uint64_t*)&cmd[0], 1ull | ((uint64_t)bytes << 2) | (seq << 24), __ATOMIC_RELEASE);  // the doorbell last
   auto launch = [&]() -> bool {
     if (!c->agent_stream) c->agent_stream = stream_acquire(c->device);

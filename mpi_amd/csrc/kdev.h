@@ -313,6 +313,8 @@ __device__ __forceinline__ void sys128_wait(pack_t (&v)[U]) {
   else if constexpr (U == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1])::"memory");
   else asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])::"memory");
 }
+#else
+#include <devsim/sys128.h>  // tests/devsim: the same three accessors for a host compiler
 #endif
 // any number of packets: one wait, then every register passes through an (empty) volatile statement behind it
 template <int U>
@@ -320,6 +322,7 @@ __device__ __forceinline__ void sys128_wait_n(pack_t* v) {
   XMPI_DRAIN();
 #pragma unroll
   for (int k = 0; k < U; k++) XMPI_REG_DEFINED(v[k]);
+  (void)v;
 }
 // one element, same scope (the ragged ends of a tile, buffers at odd alignments)
 template <typename T>

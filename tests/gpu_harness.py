@@ -17,6 +17,8 @@ def run_ranks(scenario: str, size: int, args: dict | None = None, timeout: float
     e.setdefault("GPU_MAX_HW_QUEUES", "2")  # the ranks of a test share one GPU and its hardware queues (see launcher/xmpirun.cpp)
     e.setdefault("XMPI_TEST_DUMP_AFTER", str(max(30.0, timeout - 30.0)))  # a rank that hangs says where before it is killed
     e.update(env or {})
+    if e.get("XMPI_DEVSIM_LIB"):  # the CPU suite's tests/devsim runs: every rank on a virtual device of its own
+        e.setdefault("DEVSIM_DEVICES", str(size))
     procs = []
     for r in range(size):
         cmd = [sys.executable, os.path.join(ROOT, "tests", "rank_worker.py"), scenario, str(r), str(size), key,
@@ -55,6 +57,8 @@ def run_threads(scenario: str, size: int, args: dict | None = None, timeout: flo
     e = dict(os.environ)
     e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     e.setdefault("XMPI_TIMEOUT_S", "60")
+    if e.get("XMPI_DEVSIM_LIB"):
+        e.setdefault("DEVSIM_DEVICES", "1")  # (the threads layout: ranks that share a device)
     cmd = [sys.executable, os.path.join(ROOT, "tests", "rank_worker.py"), "--threads", scenario, str(size), json.dumps(args or {})]
     p = subprocess.run(cmd, cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
     assert p.returncode == 0, f"scenario {scenario} with {size} rank threads failed\n{p.stdout[-6000:]}"

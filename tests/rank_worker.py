@@ -8,13 +8,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def _binding():
+    """mpi_amd.xmpi -- bound to libxmpi.so, or, for the CPU suite's tests/devsim runs ONLY, to the stand-in the test named
+    (the same sources compiled for the host over a simulated HIP runtime; the product binding has no such switch)"""
+    from mpi_amd import xmpi
+    if os.environ.get("XMPI_DEVSIM_LIB"):
+        xmpi.LIB_PATH = os.environ["XMPI_DEVSIM_LIB"]
+    return xmpi
+
+
 def threads_main():
     """python tests/rank_worker.py --threads <scenario> <size> [json]: every rank a thread of this process"""
     import threading
     import uuid
     name, size = sys.argv[2], int(sys.argv[3])
     args = json.loads(sys.argv[4]) if len(sys.argv) > 4 else {}
-    from mpi_amd import xmpi
+    xmpi = _binding()
     from tests import scenarios
     key = f"th{os.getpid()}-{uuid.uuid4().hex[:8]}"
     errors = []
@@ -50,7 +59,7 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["XMPI_TEST_DUMP_AFTER"]), exit=False)
     args = json.loads(sys.argv[5]) if len(sys.argv) > 5 else {}
-    from mpi_amd import xmpi
+    xmpi = _binding()
     from tests import scenarios
     comm = xmpi.Comm(rank, size, args.get("device", -1), key)
     try:

@@ -3,6 +3,7 @@ C ABI through mpi_amd.xmpi and checks its own results against the CPU oracle.  O
 test box all ranks share device 0 (functional test of the real multi-process hipIpc path)."""
 from __future__ import annotations
 
+import ctypes
 import os
 import sys
 import threading
@@ -69,6 +70,12 @@ def allreduce_case(comm, dtype, count, algo, op=xmpi.SUM, pattern=xmpi.PAT_UNIFO
         assert again.tobytes() == ins[rank].tobytes(), "sendbuf was modified"
         recv.free()
     send.free()
+
+
+def _hip_runtime():
+    """the HIP runtime the library under test allocates from: ROCm's -- or, in the CPU suite's tests/devsim runs, the stand-in
+    library itself (it carries the simulated runtime; memory from the real one would mean nothing to it)"""
+    return ctypes.CDLL(os.environ.get("XMPI_DEVSIM_LIB") or "libamdhip64.so")
 
 
 def sc_allreduce_small(comm, args):
@@ -299,7 +306,7 @@ def sc_zero_copy(comm, args):
     # device memory from another allocator (here: plain hipMalloc) on ONE rank: staged until it is registered,
     # zero-copy while it is, staged again after deregistration
     import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
+    hip = _hip_runtime()
     count = 20011
     send, mine = comm.alloc(count * 4), comm.alloc(count * 4)
     foreign = ctypes.c_void_p(0)
@@ -1051,7 +1058,7 @@ def sc_stream_ordered(comm, args):
         g2.free()
         # device memory of another allocator, never registered: copied through a registered block on the same stream
         import ctypes
-        hip = ctypes.CDLL("libamdhip64.so")
+        hip = _hip_runtime()
         n = 30011
         src, dst = ctypes.c_void_p(0), ctypes.c_void_p(0)
         comm.sync()
@@ -1341,7 +1348,7 @@ def sc_ll(comm, args):
     comm.allgather(y[:100].copy(), z, 100, xmpi.I64, L)
     assert z.tobytes() == np.tile(y[:100], size).tobytes(), "LL allgather of host slices"
     import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
+    hip = _hip_runtime()
     n = 3001
     src, dst = ctypes.c_void_p(0), ctypes.c_void_p(0)
     comm.sync()
@@ -1749,7 +1756,7 @@ def sc_p2p_stream(comm, args):
             assert e.code == (xmpi.ERR_TRUNCATE if tag == 7 else xmpi.ERR_ARG), e
     # the job goes on; a payload in memory the receiver cannot map (plain hipMalloc) travels through a registered block
     import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
+    hip = _hip_runtime()
     src = ctypes.c_void_p(0)
     comm.sync()
     assert hip.hipMalloc(ctypes.byref(src), ctypes.c_size_t(40000)) == 0
@@ -1791,7 +1798,98 @@ def sc_tune(comm, args):
         print("tuned allreduce table:", [int(v) for v in table[:24]], "split:", [int(v) for v in table[48:72]], flush=True)
 
 
+def sc_devices(comm, args):
+    """One process per DEVICE (north_star's layout; rank i <-> device i): what only exists there -- peer access between
+    devices, cross-device mappings of the windows and flag pages, the cross-device branch of the pull kernel's grid, the link
+    probe -- and every form of the collectives across it.  Runs wherever the runtime shows >= size devices: an 8-GPU node, or
+    the CPU suite's tests/devsim (virtual devices; the reference's counterpart is one process per host, network.go:163-263)."""
+    rank, size = comm.rank(), comm.size()
+    assert comm.device() == rank, f"rank {rank} is on device {comm.device()}"
+    assert comm.get_param("dsync") == 1, "ranks on different devices do not meet on the device"
+    assert comm.get_param("dsync_sharers") == 1, f"{comm.get_param('dsync_sharers')} ranks think they share device {comm.device()}"
+    # the link probe, both directions, kernel and copy engine (rates mean nothing on virtual devices: that it runs and is > 0)
+    for engine in (0, 1):
+        for direction in (0, 1):
+            if rank < 2:
+                assert comm.link_probe(1 - rank, 1 << 20, engine, 3, direction) > 0
+            comm.barrier()
+    for k, v in args.get("expect_params", {}).items():
+        assert comm.get_param(k) == v, f"{k} = {comm.get_param(k)}, expected {v}"
+    own_choice = comm.get_param("body_sys")  # 1: xmpi_init's probe grid missed an XCD, the L2-free data kernel is the only safe one
+    comm.set_param("xcd_check", 1)
+    forms = [("one kernel", {"dsync_split_bytes": 0, "ll_bytes": 0}, xmpi.ALGO_ZCOPY),
+             ("push only", {"dsync_split_bytes": 0, "ll_bytes": 0}, xmpi.ALGO_ZPUSH),
+             ("meet / body / done", {"dsync_split_bytes": 1, "ll_bytes": 0, "body_sys": 0}, xmpi.ALGO_ZCOPY),
+             ("meet / body / done, system-scope data", {"dsync_split_bytes": 1, "ll_bytes": 0, "body_sys": 1}, xmpi.ALGO_ZCOPY),
+             ("LL lines", {"dsync_split_bytes": 0, "ll_bytes": comm.get_param("ll_max_bytes")}, xmpi.ALGO_LL),
+             ("ring kernel", {}, xmpi.ALGO_RING), ("halving kernel", {}, xmpi.ALGO_RHD), ("auto", {"ll_bytes": 4096}, xmpi.ALGO_AUTO)]
+    for what, params, algo in forms:
+        if own_choice == 1 and params.get("body_sys") == 0:
+            continue
+        for k, v in params.items():
+            comm.set_param(k, v)
+        for count in args.get("counts", (1, 300, 4099, 70001)):
+            if algo == xmpi.ALGO_LL and count * 8 > comm.get_param("ll_max_bytes"):
+                continue
+            allreduce_case(comm, xmpi.I64, count, algo, exact=True)
+            allreduce_case(comm, xmpi.F32, count, algo, exact=algo not in (xmpi.ALGO_RING, xmpi.ALGO_RHD))
+    comm.set_param("body_sys", own_choice)
+    comm.set_param("dsync_split_bytes", 0)
+    for root in sorted({0, size // 2, size - 1}):
+        for algo in (xmpi.ALGO_AUTO, xmpi.ALGO_TREE):
+            bcast_case(comm, xmpi.I64, 20011, root, algo, what="bcast across devices")
+            reduce_case(comm, xmpi.I64, 20011, root, algo, what="reduce across devices")
+    for algo in (xmpi.ALGO_RING, xmpi.ALGO_DIRECT, xmpi.ALGO_ZCOPY):
+        allgather_case(comm, xmpi.I64, 4099, algo)
+    # Send / Receive across devices: short (mail slots / agent), long (the pull kernel, grid from the link rate)
+    for nbytes in (8, 4096, 1 << 20, (3 << 20) + 24):
+        n = nbytes // 8
+        tag = 70 + (nbytes & 15)
+        buf = comm.alloc(nbytes)
+        right, left = (rank + 1) % size, (rank - 1) % size
+        if rank % 2 == 0:
+            comm.fill(buf, n, xmpi.I64, xmpi.PAT_INDEX, rank)
+            comm.send(buf, n, xmpi.I64, right, tag)
+            got_from = None
+            if size % 2 == 1 and rank == 0:  # (odd ring: rank 0's left neighbour is even as well)
+                got_from = left
+        else:
+            got_from = left
+        if got_from is not None:
+            inb = comm.alloc(nbytes)
+            comm.recv(inb, n, xmpi.I64, got_from, tag)
+            got = inb.download(np.int64, n)
+            assert got.tobytes() == oracle.fill(n, xmpi.I64, xmpi.PAT_INDEX, got_from).tobytes(), f"{nbytes} bytes from {got_from}"
+            inb.free()
+        buf.free()
+        comm.barrier()
+    assert comm.get_param("xcd_short") == 0
+
+
+def sc_xcd_flaky(comm, args):
+    """A dispatcher that now and then deals a small grid round fewer XCDs than the GPU has (tests/devsim, DEVSIM_XCD_MAP=flaky;
+    no MI355X we met does this): the split form's guard must refuse THAT collective -- the rank whose launch fell short says so,
+    the job is aborted, its peers see a failed collective -- and never hand back a buffer nobody may trust."""
+    rank, size = comm.rank(), comm.size()
+    comm.set_param("xcd_check", 1)
+    comm.set_param("body_sys", 0)
+    comm.set_param("dsync_split_bytes", 1)
+    comm.set_param("ll_bytes", 0)
+    try:
+        for k in range(400):
+            allreduce_case(comm, xmpi.I64, 4099 + k, xmpi.ALGO_ZCOPY, exact=True)
+    except xmpi.XmpiError as e:
+        mine = comm.get_param("xcd_short") == 1
+        assert ("XCD" in str(e)) == mine or not mine, str(e)
+        print(f"rank {rank}/{size} xcd_flaky: ok ({'the guard refused the launch' if mine else 'a peer refused, the job was aborted'})")
+        sys.stdout.flush()
+        os._exit(0)
+    raise AssertionError("400 split collectives under a dispatcher that misses an XCD one small grid in eight, and no refusal")
+
+
 SCENARIOS = {
+    "xcd_flaky": sc_xcd_flaky,
+    "devices": sc_devices,
     "ll": sc_ll,
     "sched": sc_sched,
     "soak": sc_soak,

@@ -1,0 +1,132 @@
+"""The library WHOLE on the CPU: its host sources and its gfx950 kernel sources (kernels.hip, sched.hip, ll.hip, kdev.h -- the
+files that ship, unchanged) compiled by clang++ as C++ over tests/devsim, a HIP runtime with N virtual devices whose kernels run
+as threads (blocks) and fibers (lanes) and whose device memory is shared memory that another process maps at another address.
+
+Two things no 1-GPU box can show ("nothing with hipGetDeviceCount() > 1 has ever executed", "nothing races the actual
+atomics"):
+  * one process per DEVICE -- rank i on device i, peer access, cross-device IPC mappings, the cross-device branches of the host
+    code -- under the scenarios of the GPU suite (tests/scenarios.py, every result against the oracle);
+  * the device-side protocols (dsync_begin / dsync_end, meet / body / done, LL lines, the stepped ring / halving / tree kernels,
+    the Send / Receive kernels and the receive agent) under ThreadSanitizer, with the kernels' data stores as PLAIN stores: a
+    reader that no chain of flag words has ordered behind them is reported.
+
+What it cannot show stays with the GPU suite: cache maintenance, s_waitcnt, write-through -- everything about WHEN a store
+becomes visible rather than in which order the protocol allows it to be looked at -- and every rate.  No GPU involved; nothing
+here is product code (the product has no switch that leads here: tests/rank_worker.py points the binding at the stand-in)."""
+import os
+import subprocess
+
+import pytest
+
+from tests.gpu_harness import run_ranks, run_threads
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def devsim_lib():
+    from tests.devsim import build
+    path = build.build_lib()
+    old = os.environ.get("XMPI_DEVSIM_LIB")
+    os.environ["XMPI_DEVSIM_LIB"] = path  # (run_ranks hands the environment on to the rank processes)
+    yield path
+    if old is None:
+        del os.environ["XMPI_DEVSIM_LIB"]
+    else:
+        os.environ["XMPI_DEVSIM_LIB"] = old
+
+
+@pytest.fixture(scope="module")
+def plain_bin():
+    from tests.devsim import build
+    return build.build_driver(False)
+
+
+@pytest.fixture(scope="module")
+def tsan_bin():
+    from tests.devsim import build
+    return build.build_driver(True)
+
+
+def run(binp, *args, **env):
+    e = dict(os.environ, TSAN_OPTIONS="exitcode=66 halt_on_error=0 report_signal_unsafe=0", **{k: str(v) for k, v in env.items()})
+    e.pop("XMPI_DEVSIM_LIB", None)
+    return subprocess.run([binp, *args], capture_output=True, text=True, timeout=900, env=e, cwd="/tmp")
+
+
+# ---- under the sanitizer: ranks as threads, every rank on a device of its own ----------------------------------------------------
+def test_the_sanitizer_sees_the_kernels_stores(tsan_bin):
+    """a rank that reads its receive buffer while the collective is still in flight: reported, with the kernel's store named"""
+    r = run(tsan_bin, "--seed-race", "2")
+    assert r.returncode == 66 and "ThreadSanitizer: data race" in r.stderr, r.stderr[-3000:]
+    assert "dsync_fold_kernel" in r.stderr, r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("ranks,fuzz", [(2, 0), (3, 5), (5, 0), (8, 9)])
+def test_device_protocols_are_race_free(tsan_bin, ranks, fuzz):
+    """every form of every collective, stream-ordered and blocking Send / Receive, the agent, graphs: results right, nothing
+    reported (fuzz: lanes and threads give way at random before system-scope accesses)"""
+    r = run(tsan_bin, str(ranks), "1", DEVSIM_FUZZ=fuzz)
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-6000:]
+    assert r.returncode == 0 and "devsim driver ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("xcd_map,fuzz", [("rr", 1), ("continue", 2), ("pairs", 3)])
+def test_driver_under_perturbed_schedules(plain_bin, xcd_map, fuzz):
+    """the same walk without the sanitizer (its 5-10x), 8 ranks, two rounds, other dispatch orders round the XCDs"""
+    r = run(plain_bin, "8", "2", DEVSIM_FUZZ=fuzz, DEVSIM_XCD_MAP=xcd_map)
+    assert r.returncode == 0 and "devsim driver ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
+# ---- one PROCESS per device: the GPU suite's scenarios ---------------------------------------------------------------------------
+@pytest.mark.parametrize("size", [2, 3, 5, 8])
+def test_one_process_per_device(devsim_lib, size):
+    """rank i <-> device i: peer access, cross-device mappings, link probe, every form of the collectives, Send / Receive"""
+    run_ranks("devices", size, timeout=600)
+
+
+SCENARIOS = [
+    ("allreduce_small", 8, None),
+    ("allreduce_small", 3, {"counts": [1, 1000, 4099], "dtypes": [4, 2, 3]}),
+    ("allgather", 4, None),
+    ("bcast_reduce", 7, None),
+    ("nonblocking", 4, None),
+    ("bounce", 2, None),
+    ("helloworld", 4, None),
+    ("p2p_semantics", 2, None),
+    ("stream_ordered", 4, None),
+    ("ll", 5, None),
+    ("split", 4, {"counts": [1, 17, 4099]}),
+    ("multistream", 4, None),
+    ("p2p_stream", 4, None),
+    ("soak", 3, None),
+    ("lifecycle_stress", 2, None),
+]
+
+
+@pytest.mark.parametrize("scenario,size,args", SCENARIOS, ids=[f"{s}-{n}" for s, n, _ in SCENARIOS])
+def test_gpu_scenarios_on_virtual_devices(devsim_lib, scenario, size, args):
+    run_ranks(scenario, size, args, timeout=600)
+
+
+def test_ranks_that_share_a_device(devsim_lib):
+    """the threads layout (one process, one device, pid-equal peers) through the same stand-in"""
+    run_threads("allreduce_small", 4, {"counts": [1, 4099], "dtypes": [4, 2]})
+
+
+# ---- dispatchers that do not deal small grids round every XCD ----------------------------------------------------------------------
+def test_a_dispatcher_that_never_reaches_one_xcd(devsim_lib):
+    """the 16-block probe grid of xmpi_init misses an XCD: the split form takes the system-scope data kernel by itself"""
+    run_ranks("split", 2, {"counts": [4099]}, timeout=600, env={"DEVSIM_XCD_MAP": "small_miss"})
+    run_ranks("devices", 3, {"counts": [4099], "expect_params": {"body_sys": 1}}, timeout=600, env={"DEVSIM_XCD_MAP": "small_miss"})
+
+
+def test_the_guard_trips_on_virtual_devices(devsim_lib):
+    run_ranks("split", 2, {"counts": [4099], "trip": 1}, timeout=600)
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_a_dispatcher_that_misses_an_xcd_now_and_then(devsim_lib, seed):
+    """the probe passes, a later launch falls short: that collective is refused and the job aborted, no rank returns a result"""
+    outs = run_ranks("xcd_flaky", 3, timeout=600, env={"DEVSIM_XCD_MAP": "flaky", "DEVSIM_FUZZ": str(seed)})
+    assert any("the guard refused the launch" in o for o in outs), "\n".join(outs)
