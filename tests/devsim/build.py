@@ -2,10 +2,12 @@
 
   tests/devsim/libxmpi_devsim.so   the library's host sources + its gfx950 kernel sources, compiled by clang++ AS C++ against
                                    tests/devsim/include (a HIP runtime with N virtual devices, kernels as threads / fibers)
+  tests/devsim/libxmpi_devsim_traffic.so  the same, the kernel sources with every load / store traced (--traffic): which device's
+                                   memory the kernels of which device touch, in bytes
   tests/devsim/devsim_tsan_bin     the same objects with -fsanitize=thread + tests/devsim/driver.cpp (ranks as threads,
                                    every rank on a device of its own)
 
-`python -m tests.devsim.build [--tsan] [--force]`.  Nothing here needs hipcc's device side or a GPU.
+`python -m tests.devsim.build [--tsan | --driver | --traffic] [--force]`.  Nothing here needs hipcc's device side or a GPU.
 """
 from __future__ import annotations
 
@@ -22,6 +24,7 @@ INC = os.path.join(HERE, "include")
 LIB = os.path.join(HERE, "libxmpi_devsim.so")
 TSAN_BIN = os.path.join(HERE, "devsim_tsan_bin")
 PLAIN_BIN = os.path.join(HERE, "devsim_bin")
+TRAFFIC_LIB = os.path.join(HERE, "libxmpi_devsim_traffic.so")
 
 
 def _clang() -> str:
@@ -57,6 +60,8 @@ def _objects(tag: str, flags: list[str], extra: list[str], force: bool) -> tuple
         obj = os.path.join(objdir, os.path.splitext(os.path.basename(path))[0] + ".o")
         objs.append(obj)
         fl = flags + (["-mllvm", "-tsan-instrument-func-entry-exit=0"] if "-fsanitize=thread" in flags and _flat(path) else [])
+        if tag == "traffic" and path.endswith(".hip"):  # every load / store of the kernels calls a hook of runtime.cpp
+            fl = fl + ["-DDEVSIM_TRACED", "-fsanitize-coverage=func,trace-pc-guard,trace-loads,trace-stores"]
         d = b._digest([path] + headers, " ".join(fl))
         if force or b._stale(obj, d):
             jobs.append((subprocess.Popen([cxx, *fl, "-c", path, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True),
@@ -84,6 +89,16 @@ def build_lib(force: bool = False) -> str:
     return LIB
 
 
+def build_traffic_lib(force: bool = False) -> str:
+    """the stand-in with the kernels' loads and stores counted per owning device (runtime.cpp, DEVSIM_TRAFFIC=1)"""
+    objs, rebuilt = _objects("traffic", _flags("-O2"), [], force)
+    link = b._digest(objs, "devsim traffic link")
+    if force or rebuilt or b._stale(TRAFFIC_LIB, link):
+        b._run([_clang(), "-shared", "-fPIC", *objs, "-o", TRAFFIC_LIB, "-lpthread", "-lrt", "-ldl"])
+        b._record(TRAFFIC_LIB, link)
+    return TRAFFIC_LIB
+
+
 def build_driver(tsan: bool, force: bool = False) -> str:
     driver = os.path.join(HERE, "driver.cpp")
     if tsan:
@@ -103,6 +118,8 @@ if __name__ == "__main__":
     force = "--force" in sys.argv
     if "--tsan" in sys.argv:
         print("built:", build_driver(True, force))
+    elif "--traffic" in sys.argv:
+        print("built:", build_traffic_lib(force))
     elif "--driver" in sys.argv:
         print("built:", build_driver(False, force))
     else:

@@ -67,45 +67,63 @@ inline void launch(void (*kern)(KArgs...), dim3 grid, dim3 block, hipStream_t st
 // ---- atomics ------------------------------------------------------------------------------------------------------------
 constexpr int ld_order(int o) { return o == __ATOMIC_RELAXED ? __ATOMIC_ACQUIRE : o; }
 constexpr int st_order(int o) { return o == __ATOMIC_RELAXED ? __ATOMIC_RELEASE : o; }
+// build.py --traffic (-DDEVSIM_TRACED): the kernels' plain loads and stores are traced by the compiler; the atomics below are
+// kept out of that trace (it sees atomic loads and stores, not read-modify-writes) and reported by hand, every one once
+void flag_touch(const void* p, unsigned bytes, int store);
+#ifdef DEVSIM_TRACED
+#define DEVSIM_FLAG_FN inline __attribute__((noinline, no_sanitize("coverage")))
+#define DEVSIM_FLAG_TOUCH(p, bytes, store) ::devsim::flag_touch(p, bytes, store)
+#else
+#define DEVSIM_FLAG_FN inline
+#define DEVSIM_FLAG_TOUCH(p, bytes, store) ((void)0)
+#endif
 template <typename T>
-inline T a_load(const T* p, int order) {
+DEVSIM_FLAG_FN T a_load(const T* p, int order) {
   sync_point();
+  DEVSIM_FLAG_TOUCH(p, sizeof(T), 0);
   return __atomic_load_n(p, ld_order(order));
 }
 template <typename T, typename V>
-inline void a_store(T* p, V v, int order) {
+DEVSIM_FLAG_FN void a_store(T* p, V v, int order) {
   sync_point();
+  DEVSIM_FLAG_TOUCH(p, sizeof(T), 1);
   __atomic_store_n(p, (T)v, st_order(order));
 }
 template <typename T, typename V>
-inline T a_fetch_add(T* p, V v) {
+DEVSIM_FLAG_FN T a_fetch_add(T* p, V v) {
   sync_point();
+  DEVSIM_FLAG_TOUCH(p, sizeof(T), 1);
   return __atomic_fetch_add(p, (T)v, __ATOMIC_SEQ_CST);
 }
 template <typename T, typename V>
-inline T a_fetch_or(T* p, V v) {
+DEVSIM_FLAG_FN T a_fetch_or(T* p, V v) {
   sync_point();
+  DEVSIM_FLAG_TOUCH(p, sizeof(T), 1);
   return __atomic_fetch_or(p, (T)v, __ATOMIC_SEQ_CST);
 }
 template <typename T, typename V>
-inline T a_exchange(T* p, V v) {
+DEVSIM_FLAG_FN T a_exchange(T* p, V v) {
   sync_point();
+  DEVSIM_FLAG_TOUCH(p, sizeof(T), 1);
   return __atomic_exchange_n(p, (T)v, __ATOMIC_SEQ_CST);
 }
 template <typename T, typename V>
-inline T a_fetch_max(T* p, V v) {
+DEVSIM_FLAG_FN T a_fetch_max(T* p, V v) {
   sync_point();
+  DEVSIM_FLAG_TOUCH(p, sizeof(T), 1);
   T old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
   while (old < (T)v && !__atomic_compare_exchange_n(p, &old, (T)v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {
   }
   return old;
 }
 template <typename T, typename V>
-inline bool a_cas(T* p, T* expect, V desired) {
+DEVSIM_FLAG_FN bool a_cas(T* p, T* expect, V desired) {
   sync_point();
+  DEVSIM_FLAG_TOUCH(p, sizeof(T), 1);
   return __atomic_compare_exchange_n(p, expect, (T)desired, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
 }
-inline double a_add_double(double* p, double v) {
+DEVSIM_FLAG_FN double a_add_double(double* p, double v) {
+  DEVSIM_FLAG_TOUCH(p, 8, 1);
   uint64_t* q = reinterpret_cast<uint64_t*>(p);
   uint64_t old = __atomic_load_n(q, __ATOMIC_SEQ_CST);
   for (;;) {

@@ -21,6 +21,7 @@
 #include <dirent.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <condition_variable>
 #include <cstdio>
@@ -158,6 +159,7 @@ struct Alloc {
   int refs;           // KIND_IPC: opens of the same handle
 };
 std::mutex g_mem_mu;
+std::atomic<uint64_t> g_alloc_version{1};  // bumped whenever the table changes (the traffic counters' per-thread lookup cache)
 std::map<uintptr_t, Alloc>& allocs() {
   static auto* m = new std::map<uintptr_t, Alloc>;
   return *m;
@@ -174,6 +176,114 @@ Alloc* find_alloc_locked(const void* p) {
   --it;
   Alloc& a = it->second;
   return ((uintptr_t)p < (uintptr_t)a.base + a.bytes) ? &a : nullptr;
+}
+
+// ---- traffic accounting (DEVSIM_TRAFFIC=1) ---------------------------------------------------------------------------------------
+// Which device's memory the kernels of which device read and wrote, in bytes: build.py --traffic compiles the kernel sources
+// with -fsanitize-coverage=trace-loads,trace-stores, every load / store of theirs calls a hook below, the hook looks the address
+// up in the allocation table (device memory and IPC mappings: the owning device; pinned / registered host memory: "host"; the
+// rest -- stacks, shared variables -- is not memory traffic).  Copies by the runtime (hipMemcpyAsync: the copy engines) count as
+// a read of the source and a write of the destination by the stream's device.  What a link would carry is row != column.
+constexpr int kOwnerHost = 16;
+std::atomic<uint64_t> g_traffic[3][16][kOwnerHost + 1][2];  // [0 payload, 1 flag pages, 2 small blocks][executing device][owner][0 load, 1 store]
+bool traffic_on() {
+  static const bool on = env_long("DEVSIM_TRAFFIC", 0) != 0;
+  return on;
+}
+// DEVSIM_TRAFFIC=2: also by kernel name, printed when the process ends (local / remote / host, data and flag words)
+std::mutex g_by_kernel_mu;
+std::map<std::string, std::array<uint64_t, 12>>& by_kernel() {
+  static auto* m = new std::map<std::string, std::array<uint64_t, 12>>;
+  return *m;
+}
+void print_by_kernel() {
+  std::lock_guard<std::mutex> g(g_by_kernel_mu);
+  for (auto& kv : by_kernel()) {
+    const auto& v = kv.second;
+    fprintf(stderr, "devsim[%d] traffic %-28s payload: local %llu/%llu remote %llu/%llu host+tables %llu/%llu  flag pages: local %llu/%llu remote %llu/%llu - %llu/%llu (loads/stores)\n",
+            (int)getpid(), kv.first.c_str(), (unsigned long long)v[0], (unsigned long long)v[1], (unsigned long long)v[2], (unsigned long long)v[3],
+            (unsigned long long)v[4], (unsigned long long)v[5], (unsigned long long)v[6], (unsigned long long)v[7], (unsigned long long)v[8],
+            (unsigned long long)v[9], (unsigned long long)v[10], (unsigned long long)v[11]);
+  }
+}
+struct TrafficLocal {
+  uint64_t n[3][kOwnerHost + 1][2] = {};
+  bool dirty = false;
+  uintptr_t lo = 1, hi = 0;  // the range the last lookup fell into (an allocation, or the gap between two)
+  int owner = -1, cat = 0;
+  uint64_t version = 0;
+};
+thread_local TrafficLocal tl_traffic;
+
+// owner of the address (-1: not memory a link or an HBM channel would see) and, in *cat, what it is: 0 payload (the windows, the
+// heaps of xmpi_malloc, whatever a caller allocated: blocks of 256 KiB and more), 1 a flag page (the allocations the library asks
+// for as uncached / fine-grained: flag words, boxes, LL lines), 2 a small block of device memory (pointer tables and status
+// words every lane of a kernel reads: a scalar load from a cache on the GPU, counted per lane here)
+int traffic_owner(uintptr_t a, int* cat) {
+  TrafficLocal& t = tl_traffic;
+  const uint64_t v = g_alloc_version.load(std::memory_order_acquire);
+  if (t.version == v && a >= t.lo && a < t.hi) {
+    *cat = t.cat;
+    return t.owner;
+  }
+  std::lock_guard<std::mutex> g(g_mem_mu);
+  auto& m = allocs();
+  auto it = m.upper_bound(a);
+  uintptr_t lo = 0, hi = ~(uintptr_t)0;
+  int owner = -1, c = 0;
+  if (it != m.end()) hi = it->first;
+  if (it != m.begin()) {
+    --it;
+    const Alloc& al = it->second;
+    const uintptr_t end = (uintptr_t)al.base + al.bytes;
+    if (a < end) {
+      lo = (uintptr_t)al.base;
+      hi = end;
+      owner = (al.kind == KIND_DEVICE || al.kind == KIND_IPC) ? al.device : kOwnerHost;
+      c = owner == kOwnerHost ? 0 : (al.flags & (hipDeviceMallocUncached | hipDeviceMallocFinegrained)) ? 1 : al.bytes < ((size_t)256 << 10) ? 2 : 0;
+    } else {
+      lo = end;
+    }
+  }
+  t.lo = lo;
+  t.hi = hi;
+  t.owner = owner;
+  t.cat = c;
+  t.version = g_alloc_version.load(std::memory_order_acquire);
+  *cat = c;
+  return owner;
+}
+inline void traffic_count(const void* p, size_t bytes, int store) {
+  int cat = 0;
+  const int owner = traffic_owner((uintptr_t)p, &cat);
+  if (owner < 0) return;
+  tl_traffic.n[cat][owner][store] += bytes;
+  tl_traffic.dirty = true;
+}
+void traffic_flush(int device, const char* kernel = nullptr) {
+  TrafficLocal& t = tl_traffic;
+  if (!t.dirty) return;
+  static const bool named = env_long("DEVSIM_TRAFFIC", 0) >= 2;
+  if (named) {
+    std::string name = kernel ? kernel : "(copy)";
+    const size_t lt = name.find('<');
+    if (lt != std::string::npos) name.resize(lt);
+    while (!name.empty() && name[0] == '(' && kernel) name.erase(0, 1);
+    std::lock_guard<std::mutex> g(g_by_kernel_mu);
+    if (by_kernel().empty()) atexit(print_by_kernel);
+    auto& v = by_kernel()[name];
+    for (int f = 0; f < 3; f++)
+      for (int o = 0; o <= kOwnerHost; o++)
+        for (int k = 0; k < 2; k++) v[(size_t)((f == 1 ? 6 : 0) + (f == 2 ? 4 : o == kOwnerHost ? 4 : o == device ? 0 : 2) + k)] += t.n[f][o][k];
+  }
+  for (int f = 0; f < 3; f++)
+    for (int o = 0; o <= kOwnerHost; o++)
+      for (int k = 0; k < 2; k++)
+        if (t.n[f][o][k]) {
+          g_traffic[f][device][o][k].fetch_add(t.n[f][o][k], std::memory_order_relaxed);
+          t.n[f][o][k] = 0;
+        }
+  t.dirty = false;
 }
 
 void unlink_own_objects() {
@@ -208,6 +318,7 @@ struct IpcHandle {
   uint64_t magic;
   int32_t pid, device;
   uint64_t id, bytes, offset;
+  uint32_t flags;  // of the allocation (uncached / fine-grained: the library's flag pages)
 };
 static_assert(sizeof(IpcHandle) <= sizeof(hipIpcMemHandle_t), "handle");
 
@@ -541,6 +652,7 @@ void run_kernel(const KernelLaunch& k, int device) {
       if (b >= nblocks) break;
       runner.run_block(k, (unsigned)b, xcc_for((unsigned)b, (unsigned)nblocks, start, launch_no));
     }
+    traffic_flush(device, k.name);
     tl_runner = nullptr;
   };
   const size_t threads = std::min(nblocks, (size_t)cfg().resident);
@@ -751,6 +863,7 @@ hipError_t hipExtMallocWithFlags(void** ptr, size_t bytes, unsigned flags) {
   {
     std::lock_guard<std::mutex> g(g_mem_mu);
     allocs()[(uintptr_t)p] = a;
+    g_alloc_version.fetch_add(1);
   }
   g_device_bytes.fetch_add(len);
   *ptr = p;
@@ -771,6 +884,7 @@ hipError_t hipFree(void* ptr) {
   {
     std::lock_guard<std::mutex> g(g_mem_mu);
     allocs().erase((uintptr_t)ptr);
+    g_alloc_version.fetch_add(1);
   }
   shm_unlink(shm_name((int)getpid(), a.id).c_str());
   munmap(a.base, a.bytes);
@@ -789,6 +903,7 @@ hipError_t hipHostMalloc(void** ptr, size_t bytes, unsigned flags) {
   Alloc a{(char*)p, len, tl_device, KIND_PINNED, flags, 0, (int)getpid(), 1};
   std::lock_guard<std::mutex> g(g_mem_mu);
   allocs()[(uintptr_t)p] = a;
+  g_alloc_version.fetch_add(1);
   *ptr = p;
   return hipSuccess;
 }
@@ -801,6 +916,7 @@ hipError_t hipHostFree(void* ptr) {
     if (it == allocs().end() || it->second.kind != KIND_PINNED) return fail(hipErrorInvalidValue);
     a = it->second;
     allocs().erase(it);
+    g_alloc_version.fetch_add(1);
   }
   munmap(a.base, a.bytes);
   return hipSuccess;
@@ -819,6 +935,7 @@ hipError_t hipHostRegister(void* ptr, size_t bytes, unsigned flags) {
   }
   if (find_alloc_locked((char*)ptr + bytes - 1)) return fail(hipErrorHostMemoryAlreadyRegistered);
   allocs()[(uintptr_t)ptr] = Alloc{(char*)ptr, bytes, tl_device, KIND_REGISTERED, flags, 0, (int)getpid(), 1};
+  g_alloc_version.fetch_add(1);
   return hipSuccess;
 }
 hipError_t hipHostUnregister(void* ptr) {
@@ -827,6 +944,7 @@ hipError_t hipHostUnregister(void* ptr) {
   if (it == allocs().end() || it->second.kind != KIND_REGISTERED) return fail(hipErrorHostMemoryNotRegistered);
   if (--it->second.refs > 0) return hipSuccess;
   allocs().erase(it);
+  g_alloc_version.fetch_add(1);
   return hipSuccess;
 }
 hipError_t hipHostGetDevicePointer(void** dev, void* host, unsigned) {
@@ -880,7 +998,15 @@ hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKin
     auto stage = std::make_shared<std::vector<char>>((const char*)src, (const char*)src + bytes);
     op.fn = [dst, stage] { memcpy(dst, stage->data(), stage->size()); };
   } else {
-    op.fn = [dst, src, bytes] { memcpy(dst, src, bytes); };
+    const int dev = s->device;
+    op.fn = [dst, src, bytes, dev] {
+      memcpy(dst, src, bytes);
+      if (traffic_on()) {
+        traffic_count(src, bytes, 0);
+        traffic_count(dst, bytes, 1);
+        traffic_flush(dev);
+      }
+    };
     wait = !is_tracked(dst);  // pageable destination: the call returns when the bytes are there
   }
   enqueue(s, std::move(op));
@@ -916,7 +1042,7 @@ hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* handle, void* ptr) {
   std::lock_guard<std::mutex> g(g_mem_mu);
   Alloc* a = find_alloc_locked(ptr);
   if (!a || a->kind != KIND_DEVICE) return fail(hipErrorInvalidValue);
-  IpcHandle h{kIpcMagic, (int32_t)getpid(), a->device, a->id, a->bytes, (uint64_t)((char*)ptr - a->base)};
+  IpcHandle h{kIpcMagic, (int32_t)getpid(), a->device, a->id, a->bytes, (uint64_t)((char*)ptr - a->base), a->flags};
   memset(handle, 0, sizeof *handle);
   memcpy(handle, &h, sizeof h);
   return hipSuccess;
@@ -949,7 +1075,8 @@ hipError_t hipIpcOpenMemHandle(void** ptr, hipIpcMemHandle_t handle, unsigned fl
   close(fd);
   if (p == MAP_FAILED) return fail(hipErrorOutOfMemory);
   std::lock_guard<std::mutex> g(g_mem_mu);
-  allocs()[(uintptr_t)p] = Alloc{(char*)p, (size_t)h.bytes, h.device, KIND_IPC, 0, h.id, h.pid, 1};
+  allocs()[(uintptr_t)p] = Alloc{(char*)p, (size_t)h.bytes, h.device, KIND_IPC, h.flags, h.id, h.pid, 1};
+  g_alloc_version.fetch_add(1);
   *ptr = (char*)p + h.offset;
   return hipSuccess;
 }
@@ -960,6 +1087,7 @@ hipError_t hipIpcCloseMemHandle(void* ptr) {
   if (--a->refs > 0) return hipSuccess;
   munmap(a->base, a->bytes);
   allocs().erase((uintptr_t)a->base);
+  g_alloc_version.fetch_add(1);
   return hipSuccess;
 }
 
@@ -1114,3 +1242,47 @@ hipError_t hipGraphExecDestroy(hipGraphExec_t exec) {
 }
 
 }  // extern "C"
+
+
+// ---- traffic accounting: the hooks the traced kernel sources call, and what a test reads ------------------------------------------------
+namespace devsim {
+namespace {
+inline void traced(const void* p, size_t bytes, int store) {
+  if (tl_runner && traffic_on()) traffic_count(p, bytes, store);  // (only the lanes of a kernel: the launchers share the file)
+}
+}  // namespace
+void flag_touch(const void* p, unsigned bytes, int store) {
+  if (tl_runner && traffic_on()) traffic_count(p, bytes, store);
+}
+}  // namespace devsim
+extern "C" {
+void __sanitizer_cov_load1(uint8_t* p) { devsim::traced(p, 1, 0); }
+void __sanitizer_cov_load2(uint16_t* p) { devsim::traced(p, 2, 0); }
+void __sanitizer_cov_load4(uint32_t* p) { devsim::traced(p, 4, 0); }
+void __sanitizer_cov_load8(uint64_t* p) { devsim::traced(p, 8, 0); }
+void __sanitizer_cov_load16(__uint128_t* p) { devsim::traced(p, 16, 0); }
+void __sanitizer_cov_store1(uint8_t* p) { devsim::traced(p, 1, 1); }
+void __sanitizer_cov_store2(uint16_t* p) { devsim::traced(p, 2, 1); }
+void __sanitizer_cov_store4(uint32_t* p) { devsim::traced(p, 4, 1); }
+void __sanitizer_cov_store8(uint64_t* p) { devsim::traced(p, 8, 1); }
+void __sanitizer_cov_store16(__uint128_t* p) { devsim::traced(p, 16, 1); }
+void __sanitizer_cov_trace_pc_guard(uint32_t*) {}
+void __sanitizer_cov_trace_pc_guard_init(uint32_t*, uint32_t*) {}
+
+// out[3][17][2]: bytes the kernels (and copies) of `device` in THIS process loaded from / stored to each owner (0..15 devices,
+// 16 host) -- [0] payload, [1] the library's flag pages (flag words, boxes, LL lines; a polling lane counts every look), [2] small
+// blocks (tables)
+void devsim_traffic_read(int device, uint64_t* out) {
+  for (int f = 0; f < 3; f++)
+    for (int o = 0; o <= devsim::kOwnerHost; o++)
+      for (int k = 0; k < 2; k++)
+        out[(f * (devsim::kOwnerHost + 1) + o) * 2 + k] = devsim::g_traffic[f][device & 15][o][k].load(std::memory_order_relaxed);
+}
+void devsim_traffic_reset(void) {
+  for (auto& f : devsim::g_traffic)
+    for (auto& d : f)
+      for (auto& o : d)
+        for (auto& k : o) k.store(0, std::memory_order_relaxed);
+}
+int devsim_traffic_enabled(void) { return devsim::traffic_on() ? 1 : 0; }
+}

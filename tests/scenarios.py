@@ -1887,7 +1887,160 @@ def sc_xcd_flaky(comm, args):
     raise AssertionError("400 split collectives under a dispatcher that misses an XCD one small grid in eight, and no refusal")
 
 
+def _traffic(comm):
+    """(reset, read) of tests/devsim's traffic counters: read() -> the matrix [executing device][owner, 16 = host][load, store] in
+    bytes, gathered over the ranks (one process per device: every process counts its own kernels)"""
+    rt = _hip_runtime()
+    assert rt.devsim_traffic_enabled() == 1, "the traffic scenario needs tests/devsim's traced library and DEVSIM_TRAFFIC=1"
+    size = comm.size()
+
+    def reset():
+        comm.barrier()
+        rt.devsim_traffic_reset()
+        comm.barrier()
+
+    def read():
+        rt.hipDeviceSynchronize()  # (a blocking collective returns when its closing block says so: the other blocks' counts land when the kernel ends)
+        comm.barrier()
+        row = np.zeros(3 * 17 * 2, dtype=np.uint64)
+        rt.devsim_traffic_read(ctypes.c_int(comm.device()), row.ctypes.data_as(ctypes.c_void_p))
+        everybody = np.zeros(size * row.size, dtype=np.int64)
+        comm.allgather(row.view(np.int64), everybody, row.size, xmpi.I64, xmpi.ALGO_DIRECT)
+        return everybody.reshape(size, 3, 17, 2)
+    return reset, read
+
+
+def sc_traffic(comm, args):
+    """What would cross the links, counted: one process per virtual device, every load and store of the kernels traced
+    (tests/devsim, build --traffic).  For every schedule of the allreduce (and allgather, bcast, reduce, Send / Receive) on S bytes
+    per rank: the payload bytes device i reads from / writes to device j's memory against what the schedule's plan says that
+    link carries -- to the byte -- and the bytes every device's HBM serves (its own kernels' plus what the
+    peers read and write there) against section 5's algorithmic figure.  The library's flag pages (flag words, boxes, LL lines)
+    and its small tables are counted apart: their remote STORES are what a link carries on top of the payload; their loads are
+    lanes polling their own page.  The reference has no counterpart: its Send writes whole gob frames to one TCP connection
+    per peer (network.go:518-571)."""
+    import json
+    rank, size = comm.rank(), comm.size()
+    reset, read = _traffic(comm)
+    count = args.get("count", size * 2 * 4096)  # int64: every chunk, half and quarter of it whole 16-byte packets
+    S = count * 8
+    c = S // size  # one rank's chunk
+    pow2 = size & (size - 1) == 0
+    report = {}
+    pairs = [(i, j) for i in range(size) for j in range(size) if i != j]
+
+    def run(name, fn, plan=None):
+        """plan(i, j) -> (loads, stores) of payload device i is planned to do in device j's memory; None: only reported"""
+        reset()
+        fn()
+        both = read()
+        m, flags, tables = both[:, 0], both[:, 1], both[:, 2]
+        if plan is not None:
+            for i, j in pairs:
+                want = plan(i, j)
+                for k in (0, 1):
+                    assert int(m[i, j, k]) == want[k], (f"{name}: device {i} {'stores to' if k else 'loads from'} device {j}: "
+                                                        f"{int(m[i, j, k])} payload bytes, plan {want[k]}\n{m[:, :size, k]}")
+        into = [[int(m[i, j, 0] + m[j, i, 1]) for j in range(size)] for i in range(size)]  # payload INTO device i FROM device j, by either end's doing
+        hbm = [int(m[i, i].sum() + sum(m[j, i].sum() for j in range(size) if j != i)) for i in range(size)]  # served by device i's memory
+        report[name] = {
+            "remote_loads": int(sum(m[i, j, 0] for i, j in pairs)), "remote_stores": int(sum(m[i, j, 1] for i, j in pairs)),
+            "links_used": sum(1 for i, j in pairs if into[i][j] > 0), "busiest_link_direction": max(into[i][j] for i, j in pairs),
+            "hbm_per_device_max": max(hbm), "hbm_per_device_min": min(hbm), "host_bytes": int(m[:, 16].sum()),
+            "flag_page_remote_stores": int(sum(flags[i, j, 1] for i, j in pairs)), "flag_page_remote_loads": int(sum(flags[i, j, 0] for i, j in pairs)),
+            "flag_page_local_loads": int(sum(flags[i, i, 0] for i in range(size))), "table_loads_per_lane": int(tables[:, :, 0].sum())}
+        return m
+
+    send, recv = comm.alloc(S), comm.alloc(S * size)
+    comm.fill(send, count, xmpi.I64, xmpi.PAT_INDEX, rank)
+
+    def allreduce(algo, **params):
+        def fn():
+            for k, v in params.items():
+                comm.set_param(k, v)
+            comm.allreduce(send, recv, count, xmpi.I64, xmpi.SUM, algo)
+        return fn
+
+    one = {"dsync_split_bytes": 0, "ll_bytes": 0}
+    # the zero-copy fold: rank i reduces chunk i out of everybody's send buffer and writes it into everybody's receive buffer --
+    # S / N each way over EVERY link (xGMI is point to point: all seven links of a GPU carry an equal share at once)
+    for name, params in (("allreduce fold, one kernel", one), ("allreduce fold, meet / body / done", {"dsync_split_bytes": 1, "ll_bytes": 0, "body_sys": 0}),
+                         ("allreduce fold, system-scope data kernel", {"dsync_split_bytes": 1, "ll_bytes": 0, "body_sys": 1})):
+        m = run(name, allreduce(xmpi.ALGO_ZCOPY, **params), lambda i, j: (c, c))
+        for i in range(size):
+            assert int(m[i, i].sum()) == 2 * c, f"{name}: device {i} moved {int(m[i, i].sum())} bytes of its own memory, plan {2 * c}"
+        assert report[name]["hbm_per_device_max"] == 2 * S == report[name]["hbm_per_device_min"]  # N reads + N writes per element of a chunk (section 5)
+    comm.set_param("body_sys", 0)
+    # push only: chunk j of my buffer into rank j's scratch, then my reduced chunk into everybody's receive buffer; no remote load
+    run("allreduce push only", allreduce(xmpi.ALGO_ZPUSH, **one), lambda i, j: (0, 2 * c))
+    # ring, one kernel per rank: 2 (N - 1) / N x S per rank, loads only.  The channels are different Hamiltonian cycles (Walecki's
+    # decomposition, plan.cpp), so that the rings together use every link instead of one neighbour's: with the default channels
+    # nobody's busiest link carries more than its share of a single ring would
+    m = run("allreduce ring kernel", allreduce(xmpi.ALGO_RING, **one))
+    # (a channel's share of the buffer is whole 16 KiB tiles: which piece a rank never has to fetch differs by a tile per channel)
+    ragged = 2 * 8 * 16384
+    for i in range(size):
+        assert abs(int(sum(m[i, j, 0] for j in range(size) if j != i)) - 2 * (size - 1) * c) <= ragged, f"ring: device {i} loaded {m[i, :size, 0]}"
+    assert report["allreduce ring kernel"]["remote_loads"] == size * 2 * (size - 1) * c, "the rings together moved more than 2 (N - 1) / N x S per rank"
+    assert report["allreduce ring kernel"]["remote_stores"] == 0
+    assert report["allreduce ring kernel"]["busiest_link_direction"] <= 2 * (size - 1) * c
+    # recursive halving + doubling: S / 2 + S / 4 + ... each way; the partner at distance N / 2 alone carries S
+    m = run("allreduce halving kernel", allreduce(xmpi.ALGO_RHD, **one))
+    if pow2:
+        for i, j in pairs:
+            d = i ^ j
+            want = 2 * S * d // size if d & (d - 1) == 0 else 0  # distance d: a block of S * d / N, once halving, once doubling
+            assert int(m[i, j, 0]) == want, f"halving: device {i} loads {int(m[i, j, 0])} from device {j}, plan {want}"
+    # allgather
+    run("allgather fold", lambda: comm.allgather(send, recv, count, xmpi.I64, xmpi.ALGO_ZCOPY), lambda i, j: (0, S))
+    m = run("allgather ring kernel", lambda: comm.allgather(send, recv, count, xmpi.I64, xmpi.ALGO_RING))
+    for i in range(size):
+        assert int(sum(m[i, j, 0] for j in range(size) if j != i)) == (size - 1) * S
+    run("allgather direct (step tables, copy engine)", lambda: comm.allgather(send, recv, count, xmpi.I64, xmpi.ALGO_DIRECT))
+    # bcast / reduce, root 0
+    def bcast_with(push_bytes):
+        def fn():
+            comm.set_param("zc_bcast_push_bytes", push_bytes)
+            comm.bcast(recv, count, xmpi.I64, 0, xmpi.ALGO_AUTO)
+        return fn
+    run("bcast, root pushes", bcast_with(S), lambda i, j: (0, S if i == 0 else 0))
+    if size > 2:  # above zc_bcast_push_bytes: the root scatters, everybody forwards its chunk -- the root's links carry 2 S / N, not S
+        run("bcast, scatter + allgather", bcast_with(0), lambda i, j: (0, 0 if j == 0 else 2 * c if i == 0 else c))
+    comm.set_param("zc_bcast_push_bytes", 256 << 10)
+    m = run("bcast tree kernel", lambda: comm.bcast(recv, count, xmpi.I64, 0, xmpi.ALGO_TREE))
+    assert report["bcast tree kernel"]["remote_loads"] == (size - 1) * S and report["bcast tree kernel"]["remote_stores"] == 0
+    assert all(int(m[0, j, 0]) == 0 for j in range(1, size)), "the root of a bcast read from somebody"
+    run("reduce fold (chunks, then to the root)", lambda: comm.reduce(send, recv if rank == 0 else None, count, xmpi.I64, xmpi.SUM, 0, xmpi.ALGO_AUTO),
+        lambda i, j: (c, c if (j == 0 and i != 0) else 0))
+    m = run("reduce tree kernel", lambda: comm.reduce(send, recv if rank == 0 else None, count, xmpi.I64, xmpi.SUM, 0, xmpi.ALGO_TREE))
+    assert report["reduce tree kernel"]["remote_loads"] == (size - 1) * S and report["reduce tree kernel"]["remote_stores"] == 0
+
+    # Send / Receive 0 -> 1: the receiver pulls the payload out of the sender's memory, once; nobody else moves a byte
+    def p2p():
+        if rank == 0:
+            comm.send(send, count, xmpi.I64, 1, 5)
+        elif rank == 1:
+            comm.recv(recv, count, xmpi.I64, 0, 5)
+    run("Send / Receive 0 -> 1", p2p, lambda i, j: (S if (i, j) == (1, 0) else 0, 0))
+    # LL lines: 16 KiB per rank as {8 bytes of data, 8 of flag} lines into every peer's flag page -- 2 S per peer, one way, no load
+    n_ll = 2048
+    if n_ll * 8 <= comm.get_param("ll_max_bytes"):
+        def ll():
+            comm.set_param("ll_bytes", comm.get_param("ll_max_bytes"))
+            comm.allreduce(send, recv, n_ll, xmpi.I64, xmpi.SUM, xmpi.ALGO_LL)
+        run("allreduce LL lines (16 KiB)", ll, lambda i, j: (0, 0))
+        r = report["allreduce LL lines (16 KiB)"]
+        assert r["flag_page_remote_loads"] == 0, "an LL collective read a peer's memory"
+        assert r["flag_page_remote_stores"] == size * (size - 1) * 2 * n_ll * 8, r
+        comm.set_param("ll_bytes", 0)
+    send.free()
+    recv.free()
+    if rank == 0:
+        print("TRAFFIC " + json.dumps({"ranks": size, "bytes_per_rank": S, "chunk": c, "schedules": report}), flush=True)
+
+
 SCENARIOS = {
+    "traffic": sc_traffic,
     "xcd_flaky": sc_xcd_flaky,
     "devices": sc_devices,
     "ll": sc_ll,

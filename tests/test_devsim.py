@@ -114,6 +114,25 @@ def test_ranks_that_share_a_device(devsim_lib):
     run_threads("allreduce_small", 4, {"counts": [1, 4099], "dtypes": [4, 2]})
 
 
+# ---- what the links would carry -----------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def traffic_lib():
+    from tests.devsim import build
+    return build.build_traffic_lib()
+
+
+@pytest.mark.parametrize("size,count", [(2, 0), (3, 0), (4, 0), (5, 0), (8, 262144)])
+def test_link_traffic_follows_the_plan(traffic_lib, size, count):
+    """every load and store of the kernels traced, one process per virtual device: the payload bytes device i moves in device
+    j's memory are the schedule's plan to the byte -- fold: S / N each way over every link; push-only 2 S / N stores; ring
+    2 (N - 1) / N x S per rank over the Walecki cycles; halving S x d / N per partner; allgather, bcast (both forms), reduce,
+    tree kernels, Send / Receive = one pull; LL = 2 S of lines per peer and no remote load -- and each device's memory serves
+    2 S per allreduce by the fold (N reads + N writes per element of its chunk)"""
+    outs = run_ranks("traffic", size, {"count": count} if count else None, timeout=600,
+                     env={"XMPI_DEVSIM_LIB": traffic_lib, "DEVSIM_TRAFFIC": "1"})
+    assert any(line.startswith("TRAFFIC ") for o in outs for line in o.splitlines())
+
+
 # ---- dispatchers that do not deal small grids round every XCD ----------------------------------------------------------------------
 def test_a_dispatcher_that_never_reaches_one_xcd(devsim_lib):
     """the 16-block probe grid of xmpi_init misses an XCD: the split form takes the system-scope data kernel by itself"""
