@@ -843,7 +843,7 @@ void p2p_agent_stop(xmpi_comm* c) {
   if (!c->agent_running || !c->p2p_cmd) return;
   volatile uint64_t* cmd = c->p2p_cmd;
   const uint64_t seq = ++c->agent_seq;
-  cmd[3] = seq << 32;
+  __atomic_store_n((uint64_t*)&cmd[3], seq << 32, __ATOMIC_RELEASE);  // (polled by the agent while it is written: atomic, like agent_submit's)
   __atomic_store_n((uint64_t*)&cmd[0], 2ull | (seq << 24), __ATOMIC_RELEASE);
   Backoff bo;
   const double t0 = now_seconds();

@@ -78,6 +78,16 @@ def test_driver_under_perturbed_schedules(plain_bin, xcd_map, fuzz):
     assert r.returncode == 0 and "devsim driver ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
 
 
+def test_no_collective_needs_two_of_its_blocks_resident(plain_bin):
+    """DEVSIM_RESIDENT=1: the blocks of a launch run ONE AFTER THE OTHER.  Every collective kernel still completes -- its blocks wait
+    for peers' blocks and for blocks before them, never for a block behind them -- so no grid cap is load-bearing for progress
+    (what a GPU shared by eight processes, or one with fewer free wave slots than the grid, relies on).  The one exception is
+    by design and named: the lingering receive agent's 8 blocks wait for block 0's word (p2p_block, left out here)."""
+    r = run(plain_bin, "3", "1", "fold", "split", "ll", "sched", "bcast", "reduce", "allgather", "stream", "graph", "p2p_stream",
+            DEVSIM_RESIDENT=1)
+    assert r.returncode == 0 and "devsim driver ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
 # ---- one PROCESS per device: the GPU suite's scenarios ---------------------------------------------------------------------------
 @pytest.mark.parametrize("size", [2, 3, 5, 8])
 def test_one_process_per_device(devsim_lib, size):
