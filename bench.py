@@ -125,8 +125,8 @@ class Job:
     def device_of(self, grank: int) -> int:
         if "XMPI_BENCH_DEVICE" in os.environ:  # rehearsal of the multi-process launch on a 1-GPU box
             return int(os.environ["XMPI_BENCH_DEVICE"])
-        if self.procs > 1:
-            return self.local_rank
+        if self.procs > 1:  # one node: the local rank of the process that hosts `grank` (NOT this process' own: every rank is asked about)
+            return grank // self.ranks_per_proc
         return grank * self.args.gpus // self.ranks  # lone process: ranks spread over the visible GPUs
 
     def my_ranks(self):
@@ -383,7 +383,8 @@ def rank_main(job: Job, grank: int):
     out = {"slots": {"send": slot(send), "recv": slot(recv)}, "form": form, "link": link, "transport": transport, "devices": ndev_used, "dsync": comm.get_param("dsync"), "t_step": t_step, "prof": prof, "tune": tune, "best": best, "best_ring": best_ring, "parity": parity,
            "algo": algo, "nbytes": nbytes, "count": count, "iso": iso, "parity_failures": parity_failures,
            "shared_stream": comm.get_param("shared_stream"), "slot_bytes": comm.get_param("slot_bytes"),
-           "zero_copy_probe": {"dsync": "ok: ranks meet on the device", "host": "device rendezvous failed, host rendezvous ok",
+           "zero_copy_probe": {"dsync": "ok: ranks meet on the device" if comm.get_param("dsync") == 1 else "ok (ranks that share a process meet on the host)",
+                               "host": "device rendezvous failed, host rendezvous ok",
                                "failed": "failed: staged schedules only", "not run": "ok"}[job.probe] if zc_ok else "failed: staged schedules only"}
 
     # ---- untimed extras: what the next round needs to tune blind multi-GPU runs -----------------------
@@ -907,7 +908,10 @@ def write_extras(obj) -> str:
     """everything that is not the contract line: bench_extras.json beside bench.py, and a copy in gpurun_out/ when present"""
     name = "bench_extras.json"
     where = []
-    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+    dirs = (ROOT, os.path.join(ROOT, "gpurun_out"))
+    if os.environ.get("XMPI_BENCH_EXTRAS_DIR"):  # (a run that must not touch the checkout: the CPU suite's rehearsals)
+        dirs = (os.environ["XMPI_BENCH_EXTRAS_DIR"],)
+    for d in dirs:
         if os.path.isdir(d):
             try:
                 with open(os.path.join(d, name), "w") as f:

@@ -124,6 +124,83 @@ def test_ranks_that_share_a_device(devsim_lib):
     run_threads("allreduce_small", 4, {"counts": [1, 4099], "dtypes": [4, 2]})
 
 
+# ---- the product's own executables: launcher + C++ front end + example programs, one process per virtual GPU -----------------------------
+@pytest.fixture()
+def stage(devsim_lib, tmp_path):
+    """the binaries under mpi_amd/bin resolve libxmpi.so through their RUNPATH; LD_LIBRARY_PATH comes first: a directory whose
+    libxmpi.so IS the stand-in puts the executables that ship on virtual devices, unchanged"""
+    os.symlink(devsim_lib, tmp_path / "libxmpi.so")
+    return dict(os.environ, LD_LIBRARY_PATH=str(tmp_path), XMPI_TIMEOUT_S="60")
+
+
+def launch(env, ranks, prog, *args, port):
+    binp = os.path.join(ROOT, "mpi_amd", "bin")
+    e = dict(env, XMPI_NGPUS=str(ranks), DEVSIM_DEVICES=str(ranks), XMPI_BASEPORT=str(port))
+    e.pop("XMPI_DEVSIM_LIB", None)
+    r = subprocess.run([os.path.join(binp, "xmpirun"), str(ranks), os.path.join(binp, prog), *args], capture_output=True, text=True,
+                       timeout=600, cwd=ROOT, env=e)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+def test_reference_examples_one_process_per_gpu(stage):
+    """the reference's two programs (examples/helloworld/helloworld.go:33-82, examples/bounce/bounce.go:37-153) as the C++ front end
+    runs them, under the launcher that replaces gompirun.go:46-93, rank i on GPU i"""
+    out = launch(stage, 4, "helloworld", port=7600)
+    for me in range(4):
+        for other in range(4):
+            want = (f"I'm just node {me} talking to myself" if other == me else f"Hello node {me}, I'm node {other}")
+            assert f'I, node {me}, received a message: "{want}"' in out, out
+    out = launch(stage, 2, "bounce", port=7620)
+    assert "Number of nodes =  2" in out and "Average float64 trip time" in out, out
+
+
+def test_collective_programs_one_process_per_gpu(stage):
+    """every schedule by name at 8 ranks on 8 GPUs (the tuner included), cfg 3 and cfg 5 at small sizes: exact, and nobody
+    shares a device"""
+    import json
+    d = json.loads(launch(stage, 8, "allreduce_bench", "65536", "2", "1", "auto", "fused", "split", "ring", "rhd", port=7640).strip().split("\n")[-1])
+    assert d["ranks"] == 8 and d["sharers"] == 1 and d["exact"] is True and d["xcd_short"] == 0, d
+    assert [r["mode"] for r in d["rows"]] == ["auto", "fused", "split", "ring", "rhd"] and all(r["us_per_step"] > 0 for r in d["rows"])
+    d = json.loads(launch(stage, 4, "cfg3_allgather", "32768", "2", port=7660).strip().split("\n")[-1])
+    assert d["exact"] is True and d["ranks"] == 4 and d["ring"]["bit_exact_and_in_place"] and d["auto"]["bit_exact_and_in_place"], d
+    d = json.loads(launch(stage, 8, "cfg5_sweep", str(1 << 18), "2", port=7680).strip().split("\n")[-1])
+    assert d["all_bit_identical"] is True, d
+    out = launch(stage, 4, "allreduce", port=7700)
+    assert "every result exact" in out, out
+
+
+# ---- the driver's own multi-GPU command --------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("gpus", [8, 4, 2])
+def test_the_scale_command_on_virtual_gpus(devsim_lib, gpus, tmp_path):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N
+    --steps K --warmup W` -- the command the driver runs on an 8-GPU node and no 1-GPU box can (bench.py binds through ctypes:
+    tests/devsim/site/usercustomize.py on PYTHONPATH puts every process of it, the zero-copy probe's children included, on the
+    stand-in).  A quarter MiB per rank instead of 256: the line's shape and the path, not a rate.  Found this way: every process
+    took all ranks to be on ITS device, so an 8-GPU line would have said "intra-HBM" and left the xgmi block out."""
+    import json
+    import sys
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "tests", "devsim", "site"), XMPI_DEVSIM_LIB=devsim_lib, DEVSIM_DEVICES=str(gpus),
+               XMPI_TIMEOUT_S="60", XMPI_BENCH_EXTRAS_DIR=str(tmp_path))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+                        "--master-port", str(29600 + gpus), os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1",
+                        "--size-mib", "0.25", "--no-cpu"], capture_output=True, text=True, timeout=900, cwd=str(tmp_path), env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 alone prints, one line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == gpus and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong" and d["higher_is_better"] is True
+    assert d["config"]["ranks"] == 8 and d["config"]["ranks_per_gpu"] == 8 // gpus
+    assert d["parity"]["ok"] is True and d["parity_failures"] == 0 and d["value"] > 0
+    assert d["xgmi"]["link_probe"] and d["xgmi"]["meaningful"] is (gpus == 8)
+    assert d["zero_copy_probe"].startswith("ok")
+    if gpus == 8:  # north_star's layout: one rank per GPU, ranks meet on the device, the library's tuner chose the schedule
+        assert d["config"]["transport"] == "xGMI (one rank per GPU)" and d["ranks_meet"] == "on the device (dsync)"
+        assert d["roofline"]["kernel"].startswith("dsync_") and d["config"]["tuned"]
+    else:
+        assert d["config"]["transport"].startswith(f"mixed: 8 ranks on {gpus} GPUs")
+
+
 # ---- what the links would carry -----------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def traffic_lib():
