@@ -1645,7 +1645,7 @@ int xmpi_ctl_selftest(const char* job_key, int rank, int size, int rounds) {
   CtlConfig cfg{2, 8, 8u << 20, 2, 4u << 20, 1};  // (host lanes requested)
   std::string err;
   Ctl* ctl = nullptr;
-  int rc = Ctl::join(job_key ? job_key : "selftest", rank, size, cfg, 30.0, &ctl, &err);
+  int rc = Ctl::join(job_key ? job_key : "selftest", rank, size, cfg, (double)env_long("XMPI_INIT_TIMEOUT_S", 30), &ctl, &err);
   if (rc != XMPI_OK) {
     set_last_error("ctl selftest: " + err);
     return rc;

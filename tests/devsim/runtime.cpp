@@ -1054,6 +1054,15 @@ hipError_t hipIpcOpenMemHandle(void** ptr, hipIpcMemHandle_t handle, unsigned fl
   memcpy(&h, &handle, sizeof h);
   if (h.magic != kIpcMagic) return fail(hipErrorInvalidHandle);
   if (h.pid == (int32_t)getpid()) return fail(hipErrorInvalidContext);  // HIP does not open a handle in the process that made it
+  {  // DEVSIM_FAIL_IPC_OPEN=<n>[@<device>]: the n-th open (of the process on that device) fails -- a node whose driver refuses the mapping
+    static std::atomic<long> calls{0};
+    static const char* spec = getenv("DEVSIM_FAIL_IPC_OPEN");
+    if (spec) {
+      long n = 0;
+      int dev = -1;
+      if (sscanf(spec, "%ld@%d", &n, &dev) >= 1 && (dev < 0 || dev == tl_device) && calls.fetch_add(1) + 1 == n) return fail(hipErrorInvalidValue);
+    }
+  }
   if (h.device != tl_device && !(flags & hipIpcMemLazyEnablePeerAccess)) {
     std::lock_guard<std::mutex> g(g_peer_mu);
     if (!g_peer[tl_device][h.device]) return fail(hipErrorPeerAccessNotEnabled);

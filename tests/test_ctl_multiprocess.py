@@ -57,7 +57,7 @@ def test_missing_rank_times_out_cleanly():
     """only rank 1 of 2 shows up: it must give up with an error, not hang (30 s join timeout is
     shortened here through the creator never appearing -> XMPI_ERR_TIMEOUT)"""
     key = f"lonely-{uuid.uuid4().hex[:8]}"
-    env = dict(os.environ)
+    env = dict(os.environ, XMPI_INIT_TIMEOUT_S="4")  # (the bootstrap's own clock, api.cpp: default 60 s)
     p = subprocess.Popen([sys.executable, "-c", WORKER, key, "1", "2", "1"], stdout=subprocess.PIPE,
                          stderr=subprocess.STDOUT, text=True, env=env)
     out, _ = p.communicate(timeout=120)

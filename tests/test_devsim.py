@@ -23,6 +23,19 @@ from tests.gpu_harness import run_ranks, run_threads
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _everything_built():
+    """the four artefacts side by side (a cold build of each is ~1 min of clang++ on the kernel templates; nothing when current)"""
+    import sys
+    jobs = [subprocess.Popen([sys.executable, "-m", "tests.devsim.build", *flag], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            for flag in ([], ["--tsan"], ["--traffic"])]
+    for j in jobs:
+        out, _ = j.communicate()
+        assert j.returncode == 0, out[-4000:]
+    from tests.devsim import build
+    build.build_driver(False)  # (shares the library's objects)
+
+
 @pytest.fixture(scope="module")
 def devsim_lib():
     from tests.devsim import build
@@ -119,6 +132,16 @@ def test_gpu_scenarios_on_virtual_devices(devsim_lib, scenario, size, args):
     run_ranks(scenario, size, args, timeout=600)
 
 
+def test_a_peer_mapping_the_driver_refuses_fails_loudly(devsim_lib):
+    """rank 1's first hipIpcOpenMemHandle fails (what `hipIpcGetMemHandle: invalid argument` looks like from the other side when a
+    node's driver lacks dmabuf IPC): xmpi_init returns an error that names the call -- on that rank at once, on its peer when the
+    bootstrap's clock runs out -- and nobody hangs or carries on without the mapping"""
+    with pytest.raises(AssertionError) as e:
+        run_ranks("helloworld", 2, timeout=120, env={"DEVSIM_FAIL_IPC_OPEN": "1@1", "XMPI_INIT_TIMEOUT_S": "5", "XMPI_TIMEOUT_S": "10"})
+    text = str(e.value)
+    assert "hipIpcOpenMemHandle" in text and "killed after timeout" not in text, text[-3000:]
+
+
 def test_ranks_that_share_a_device(devsim_lib):
     """the threads layout (one process, one device, pid-equal peers) through the same stand-in"""
     run_threads("allreduce_small", 4, {"counts": [1, 4099], "dtypes": [4, 2]})
@@ -199,6 +222,38 @@ def test_the_scale_command_on_virtual_gpus(devsim_lib, gpus, tmp_path):
         assert d["roofline"]["kernel"].startswith("dsync_") and d["config"]["tuned"]
     else:
         assert d["config"]["transport"].startswith(f"mixed: 8 ranks on {gpus} GPUs")
+
+
+def test_the_8gpu_script_rehearsal(stage, devsim_lib, tmp_path):
+    """scripts/profile_8gpu.sh -- the one command for the day an 8-GPU node exists -- with XMPI_8GPU_REHEARSAL=1 (small sizes, no
+    rocprofv3, no GPU suite): every other command line of it as written, on 8 virtual GPUs; every file it leaves parses, every
+    result in them is exact, every mode it names ran, nobody shares a device"""
+    import glob
+    import json
+    env = dict(stage, PYTHONPATH=os.path.join(ROOT, "tests", "devsim", "site"), XMPI_DEVSIM_LIB=devsim_lib, DEVSIM_DEVICES="8", XMPI_NGPUS="8",
+               XMPI_8GPU_REHEARSAL="1", XMPI_8GPU_OUT=str(tmp_path / "out"))
+    r = subprocess.run(["bash", os.path.join(ROOT, "scripts", "profile_8gpu.sh"), "8"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = str(tmp_path / "out")
+    line = json.loads(open(os.path.join(out, "bench_n8.json")).read().strip().split("\n")[-1])
+    assert line["n_gpus"] == 8 and line["xgmi"]["meaningful"] is True and line["parity"]["ok"] is True
+    json.load(open(os.path.join(out, "bench_n8_extras.json")))
+    seen = set()
+    for f in glob.glob(os.path.join(out, "*.json")):
+        name = os.path.basename(f)
+        if name.startswith("bench_n8"):
+            continue
+        d = json.loads(open(f).read().strip().split("\n")[-1])
+        assert d.get("exact", d.get("all_bit_identical")) is True, (name, d)
+        if "sharers" in d:
+            assert d["sharers"] == 1 and d["xcd_short"] == 0, (name, d)
+            seen |= {row["mode"] for row in d["rows"]}
+        if name.startswith("split_body_sys"):
+            assert d["body_sys"] == int(name[len("split_body_sys")])
+        if name == "cfg5_n8.json":
+            assert d["rows"], d
+    assert seen == {"auto", "fused", "fused2", "split", "zpush", "ring", "rhd"}, seen
+    assert open(os.path.join(out, "prod.err")).read().strip() == ""
 
 
 # ---- what the links would carry -----------------------------------------------------------------------------------------------------------
