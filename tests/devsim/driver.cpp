@@ -12,6 +12,8 @@
 //
 // usage: devsim_tsan_bin <ranks> <rounds> [scenario ...]      scenarios: fold split ll sched bcast reduce allgather
 //                                                             stream graph p2p_stream p2p_block (default: all)
+//        devsim_tsan_bin --shared <ranks> <rounds> [...]     every rank on device 0: the ranks meet on the HOST (zcopy.cpp's rendezvous,
+//                                                             one launch folds everybody's chunks; the step tables through the windows)
 //        devsim_tsan_bin --seed-race <ranks>                  the same allreduce with a rank that reads its result back before
 //                                                             the collective has completed: the sanitizer must report it
 // exit 0 = every result was right; the sanitizer reports on stderr and turns the exit code into 66 (TSAN_OPTIONS=exitcode=66)
@@ -35,6 +37,7 @@ namespace {
 std::atomic<int> g_bad{0};
 std::set<std::string> g_only;
 bool g_seed_race = false;
+bool g_shared = false;  // --shared: every rank on device 0 (ranks that share a process AND a GPU: they meet on the host, zcopy.cpp)
 
 bool wants(const char* name) { return g_only.empty() || g_only.count(name) > 0; }
 
@@ -123,9 +126,10 @@ void rank_main(const std::string& key, int rank, int size, int rounds) {
   Rank R;
   R.rank = rank;
   R.size = size;
-  CHECK(xmpi_init(rank, size, rank, key.c_str(), &R.c));
+  CHECK(xmpi_init(rank, size, g_shared ? 0 : rank, key.c_str(), &R.c));
   xmpi_comm* c = R.c;
-  if (xmpi_get_param(c, "dsync") != 1) {
+  const bool dev = !g_shared;  // the ranks meet on the device
+  if (dev && xmpi_get_param(c, "dsync") != 1) {
     fprintf(stderr, "rank %d: the ranks do not meet on the device (dsync = %ld): nothing of interest would run\n", rank, xmpi_get_param(c, "dsync"));
     g_bad.fetch_add(1);
     return;
@@ -171,7 +175,7 @@ void rank_main(const std::string& key, int rank, int size, int rounds) {
       (void)R.expect_sum_i64(4099, salt, "fold in place");
     }
     // ---- meet / body / done (the split form), with the plain and the system-scope data kernel -----------------------------
-    if (wants("split")) {
+    if (wants("split") && dev) {
       CHECK(xmpi_set_param(c, "dsync_split_bytes", 1));  // always split
       CHECK(xmpi_set_param(c, "ll_bytes", 0));
       for (int sys = 0; sys < 2; sys++) {
@@ -186,7 +190,7 @@ void rank_main(const std::string& key, int rank, int size, int rounds) {
       CHECK(xmpi_set_param(c, "dsync_split_bytes", 4 << 20));
     }
     // ---- LL lines ---------------------------------------------------------------------------------------------------------------
-    if (wants("ll")) {
+    if (wants("ll") && dev) {
       for (size_t n : {(size_t)1, (size_t)33, (size_t)257, (size_t)4096}) {
         allreduce_case(R, n, XMPI_ALGO_LL, ++salt, "LL allreduce");
         allreduce_case(R, n, XMPI_ALGO_LL, ++salt, "LL allreduce");  // (both parities)
@@ -225,7 +229,8 @@ void rank_main(const std::string& key, int rank, int size, int rounds) {
         allreduce_case(R, n, XMPI_ALGO_RING, ++salt, "ring kernel");
         allreduce_case(R, n, XMPI_ALGO_RHD, ++salt, "halving kernel");
       }
-      if (xmpi_get_param(c, "dsync_sched_launches") <= 0) {
+      if (!dev) allreduce_case(R, 40001, XMPI_ALGO_DIRECT, ++salt, "direct step table");
+      if (dev && xmpi_get_param(c, "dsync_sched_launches") <= 0) {
         fprintf(stderr, "rank %d: the stepped kernels never ran\n", rank);
         g_bad.fetch_add(1);
       }
@@ -270,7 +275,7 @@ void rank_main(const std::string& key, int rank, int size, int rounds) {
       }
     }
     // ---- stream-ordered collectives on a stream of the caller's, and a captured graph replayed ---------------------------------
-    if (wants("stream") || wants("graph")) {
+    if ((wants("stream") || wants("graph")) && dev) {
       void* s = xmpi_stream_create(c);
       if (!s) {
         fprintf(stderr, "rank %d: xmpi_stream_create: %s\n", rank, xmpi_last_error());
@@ -301,7 +306,7 @@ void rank_main(const std::string& key, int rank, int size, int rounds) {
       CHECK(xmpi_stream_destroy(c, s));
     }
     // ---- stream-ordered Send / Receive: a ring on ONE stream per rank (even ranks send first) ---------------------------------------
-    if (wants("p2p_stream") && size > 1) {
+    if (wants("p2p_stream") && size > 1 && dev) {
       void* s = xmpi_stream_create(c);
       const int next = (rank + 1) % size, prev = (rank + size - 1) % size;
       for (size_t n : {(size_t)1, (size_t)300, (size_t)9001}) {  // (9001 x 8 bytes: a receive kernel of several blocks)
@@ -370,12 +375,15 @@ int main(int argc, char** argv) {
   if (argc > 1 && std::string(argv[1]) == "--seed-race") {
     g_seed_race = true;
     a = 2;
+  } else if (argc > 1 && std::string(argv[1]) == "--shared") {
+    g_shared = true;
+    a = 2;
   }
   const int size = argc > a ? atoi(argv[a]) : 2, rounds = argc > a + 1 ? atoi(argv[a + 1]) : 1;
   for (int k = a + 2; k < argc; k++) g_only.insert(argv[k]);
   if (size < 2 || size > 8) return 2;
   setenv("XMPI_CTL_SHARE_MAPPING", "1", 1);
-  setenv("DEVSIM_DEVICES", std::to_string(size).c_str(), 1);
+  setenv("DEVSIM_DEVICES", g_shared ? "1" : std::to_string(size).c_str(), 1);
   setenv("XMPI_TIMEOUT_S", "120", 0);
   setenv("XMPI_HOST_LANES", "0", 0);
   const std::string key = "devsim-" + std::to_string((int)getpid());
@@ -386,6 +394,6 @@ int main(int argc, char** argv) {
     fprintf(stderr, "devsim driver: %d failure(s)\n", g_bad.load());
     return 1;
   }
-  printf("devsim driver ok: %d ranks as threads on %d virtual devices, %d round(s)\n", size, size, rounds);
+  printf("devsim driver ok: %d ranks as threads on %d virtual device%s, %d round(s)\n", size, g_shared ? 1 : size, g_shared ? "" : "s", rounds);
   return 0;
 }

@@ -84,6 +84,16 @@ def test_device_protocols_are_race_free(tsan_bin, ranks, fuzz):
     assert r.returncode == 0 and "devsim driver ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
 
 
+@pytest.mark.parametrize("ranks,fuzz", [(4, 3), (8, 5)])
+def test_ranks_that_share_a_gpu_are_race_free(tsan_bin, ranks, fuzz):
+    """--shared: every rank a thread on device 0 -- bench.py's N = 1 layout.  They meet on the HOST (zcopy.cpp's rendezvous and
+    group launch: reduce_n_multi_kernel folds everybody's chunks, one launch), ring / halving / direct run as host-driven step
+    tables through the windows, Send / Receive through the agent: under the sanitizer, nothing reported"""
+    r = run(tsan_bin, "--shared", str(ranks), "1", DEVSIM_FUZZ=fuzz)
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-6000:]
+    assert r.returncode == 0 and "devsim driver ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
 @pytest.mark.parametrize("xcd_map,fuzz", [("rr", 1), ("continue", 2), ("pairs", 3)])
 def test_driver_under_perturbed_schedules(plain_bin, xcd_map, fuzz):
     """the same walk without the sanitizer (its 5-10x), 8 ranks, two rounds, other dispatch orders round the XCDs"""
