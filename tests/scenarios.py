@@ -2039,7 +2039,46 @@ def sc_traffic(comm, args):
         print("TRAFFIC " + json.dumps({"ranks": size, "bytes_per_rank": S, "chunk": c, "schedules": report}), flush=True)
 
 
+def sc_peer_dies(comm, args):
+    """The last rank leaves without a word (os._exit after a collective that worked) -- a process that crashed.  The reference's
+    peers see their TCP connection fail (network.go:518-571: Send / Receive return the error); here nobody is told, so every wait
+    has a clock: the survivors' next collective and a Receive from the dead rank must come back with an ERROR within the no-progress
+    limit (XMPI_TIMEOUT_S), the kernels that were waiting must have ended (the device is usable afterwards), nothing hangs."""
+    import time
+    rank, size = comm.rank(), comm.size()
+    allreduce_case(comm, xmpi.I64, 4099, xmpi.ALGO_AUTO, exact=True)
+    comm.barrier()
+    if rank == size - 1:
+        sys.stdout.flush()
+        os._exit(0)
+    limit = comm.get_param("timeout_s")
+    assert 0 < limit <= 30, "the test sets XMPI_TIMEOUT_S"
+    buf, out = comm.alloc(4099 * 8), comm.alloc(4099 * 8)
+    comm.fill(buf, 4099, xmpi.I64, xmpi.PAT_INDEX, rank)
+    t0 = time.time()
+    what = args.get("what", "allreduce")
+    try:
+        if what == "recv":
+            comm.recv(out, 4099, xmpi.I64, size - 1, 3)
+        else:
+            comm.set_param("dsync_split_bytes", 1 if what == "split" else 0)
+            comm.set_param("ll_bytes", comm.get_param("ll_max_bytes") if what == "ll" else 0)
+            n = 512 if what == "ll" else 4099
+            comm.allreduce(buf, out, n, xmpi.I64, xmpi.SUM, {"ring": xmpi.ALGO_RING, "ll": xmpi.ALGO_LL}.get(what, xmpi.ALGO_ZCOPY))
+    except xmpi.XmpiError as e:
+        took = time.time() - t0
+        assert took < 3 * limit + 10, f"{what}: the error took {took:.0f} s with a limit of {limit} s"
+        # the device still works: a local kernel on the same buffers, checked
+        comm.fill(out, 16, xmpi.I64, xmpi.PAT_INDEX, 7)
+        assert out.download(np.int64, 16).tobytes() == oracle.fill(16, xmpi.I64, xmpi.PAT_INDEX, 7).tobytes()
+        print(f"rank {rank}/{size} peer_dies[{what}]: ok (error after {took:.1f} s: {str(e)[:100]})")
+        sys.stdout.flush()
+        os._exit(0)  # (the job is broken: no finalize barrier to meet the dead rank in)
+    raise AssertionError(f"{what} with a dead peer returned without an error")
+
+
 SCENARIOS = {
+    "peer_dies": sc_peer_dies,
     "traffic": sc_traffic,
     "xcd_flaky": sc_xcd_flaky,
     "devices": sc_devices,

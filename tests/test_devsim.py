@@ -152,6 +152,14 @@ def test_a_peer_mapping_the_driver_refuses_fails_loudly(devsim_lib):
     assert "hipIpcOpenMemHandle" in text and "killed after timeout" not in text, text[-3000:]
 
 
+@pytest.mark.parametrize("what", ["allreduce", "split", "ring", "ll", "recv"])
+def test_a_peer_that_dies_is_an_error_not_a_hang(devsim_lib, what):
+    """the last of 3 ranks exits without a word; the survivors' next collective (one kernel / meet-body-done / ring kernel / LL
+    lines) or Receive from it returns an error within the no-progress limit, the waiting kernels have ended, the device works"""
+    outs = run_ranks("peer_dies", 3, {"what": what}, timeout=120, env={"XMPI_TIMEOUT_S": "4"})
+    assert sum("ok (error after" in o for o in outs) == 2, "\n".join(outs)
+
+
 def test_ranks_that_share_a_device(devsim_lib):
     """the threads layout (one process, one device, pid-equal peers) through the same stand-in"""
     run_threads("allreduce_small", 4, {"counts": [1, 4099], "dtypes": [4, 2]})

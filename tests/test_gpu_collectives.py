@@ -268,3 +268,12 @@ def test_library_tuner_from_the_environment():
 def test_library_tuner_threads():
     """ranks that meet on the host have one schedule: nothing to tune, AUTO unchanged"""
     run_threads("tune", 3)
+
+
+@pytest.mark.parametrize("what", ["allreduce", "recv"])
+def test_a_peer_that_dies_is_an_error_not_a_hang(what):
+    """rank 1 of 2 exits without a word after a collective that worked: rank 0's next allreduce (its kernel waits for a flag word
+    that will never come) / Receive returns an error within the no-progress limit, the kernel has ended, the GPU still works
+    (the reference's peers get a TCP error: network.go:518-571)"""
+    outs = run_ranks("peer_dies", 2, {"what": what}, timeout=120, env={"XMPI_TIMEOUT_S": "5"})
+    assert sum("ok (error after" in o for o in outs) == 1, "\n".join(outs)
