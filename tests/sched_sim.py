@@ -74,7 +74,7 @@ def run(sched, size, count, es=4, nchan=1, gx=2, tile=16, root=0, pieces=1, inpl
     class Worker:
         def __init__(self, rank, w):
             self.rank, self.w = rank, w
-            self.prog = program(sched, size, rank, root, pieces, count, es, nchan, w // gx)
+            self.prog = program(sched, size, rank, root, pieces, count, es, nchan, w % nchan)  # (sched.hip: w = x * channels + channel)
             self.pc = 0
             self.phase = "wait"
             self.todo = None
