@@ -11,7 +11,7 @@
 // have no upstream counterpart (mpi.go:130).
 //
 // usage: devsim_tsan_bin <ranks> <rounds> [scenario ...]      scenarios: fold split ll sched bcast reduce allgather
-//                                                             stream graph p2p_stream p2p_block (default: all)
+//                                                             walk stream graph p2p_stream p2p_block (default: all)
 //        devsim_tsan_bin --shared <ranks> <rounds> [...]     every rank on device 0: the ranks meet on the HOST (zcopy.cpp's rendezvous,
 //                                                             one launch folds everybody's chunks; the step tables through the windows)
 //        devsim_tsan_bin --seed-race <ranks>                  the same allreduce with a rank that reads its result back before
@@ -273,6 +273,85 @@ void rank_main(const std::string& key, int rank, int size, int rounds) {
               break;
             }
       }
+    }
+    // ---- a seeded random walk over the forms (DEVSIM_WALK=<steps>, default 40): what one form leaves behind on the never-cleared flag
+    // page -- epochs, slot parities, step words, tickets -- for the next, under the sanitizer.  Every rank draws the same sequence.
+    if (wants("walk") && dev) {
+      uint64_t x = 0x9E3779B97F4A7C15ull * (uint64_t)(round + 1) + (uint64_t)(getenv("DEVSIM_FUZZ") ? atol(getenv("DEVSIM_FUZZ")) : 0);
+      auto draw = [&](uint64_t n) {
+        x ^= x << 13;
+        x ^= x >> 7;
+        x ^= x << 17;
+        return (size_t)(x % n);
+      };
+      const int steps = getenv("DEVSIM_WALK") ? atoi(getenv("DEVSIM_WALK")) : 40;
+      void* ws = xmpi_stream_create(c);
+      const size_t sizes[] = {1, 17, 300, 2051, 4099, 20011};
+      for (int k = 0; k < steps && g_bad.load() == 0; k++) {
+        const size_t form = draw(12), n = sizes[draw(6)];
+        CHECK(xmpi_set_param(c, "dsync_split_bytes", form == 1 || form == 2 ? 1 : 0));
+        CHECK(xmpi_set_param(c, "body_sys", form == 2 ? 1 : 0));
+        CHECK(xmpi_set_param(c, "ll_bytes", form == 3 ? xmpi_get_param(c, "ll_max_bytes") : 0));
+        switch (form) {
+          case 0: allreduce_case(R, n, XMPI_ALGO_ZCOPY, ++salt, "walk: fold"); break;
+          case 1: allreduce_case(R, n, XMPI_ALGO_ZCOPY, ++salt, "walk: split"); break;
+          case 2: allreduce_case(R, n, XMPI_ALGO_ZCOPY, ++salt, "walk: split, system scope"); break;
+          case 3: allreduce_case(R, n > 4096 ? 257 : n, XMPI_ALGO_LL, ++salt, "walk: LL"); break;
+          case 4: allreduce_case(R, n, XMPI_ALGO_RING, ++salt, "walk: ring kernel"); break;
+          case 5: allreduce_case(R, n, XMPI_ALGO_RHD, ++salt, "walk: halving kernel"); break;
+          case 6: allreduce_case(R, n, XMPI_ALGO_ZPUSH, ++salt, "walk: push-only"); break;
+          case 7:
+          case 8: {
+            const int root = (int)draw((uint64_t)size), algo = form == 7 ? (int)XMPI_ALGO_TREE : (int)XMPI_ALGO_AUTO;
+            R.fill_i64(n, ++salt);
+            CHECK(xmpi_reduce(c, R.send, R.recv, n, XMPI_I64, XMPI_SUM, root, algo));
+            if (rank == root) (void)R.expect_sum_i64(n, salt, "walk: reduce");
+            break;
+          }
+          case 9: {
+            const int root = (int)draw((uint64_t)size), algo = draw(2) ? (int)XMPI_ALGO_TREE : (int)XMPI_ALGO_AUTO;
+            R.fill_i64(n, ++salt);
+            if (rank == root) (void)xmpi_memcpy(c, R.recv, R.send, n * 8);
+            else (void)xmpi_memset(c, R.recv, 0xEE, n * 8);
+            CHECK(xmpi_bcast(c, R.recv, n, XMPI_I64, root, algo));
+            R.download(n * 8);
+            for (size_t i = 0; i < n; i++)
+              if (((const int64_t*)R.host.data())[i] != in_i64(root, i, salt)) {
+                fprintf(stderr, "rank %d: walk: bcast algo %d from %d: element %zu\n", rank, algo, root, i);
+                g_bad.fetch_add(1);
+                break;
+              }
+            break;
+          }
+          case 10: {
+            const int algo = draw(2) ? (int)XMPI_ALGO_RING : (int)XMPI_ALGO_AUTO;
+            const size_t m = n > 4099 ? 4099 : n;
+            R.fill_i64(m, ++salt);
+            CHECK(xmpi_allgather(c, R.send, R.recv, m, XMPI_I64, algo));
+            R.download(m * 8 * (size_t)size);
+            for (int r = 0; r < size; r++)
+              for (size_t i = 0; i < m; i++)
+                if (((const int64_t*)R.host.data())[(size_t)r * m + i] != in_i64(r, i, salt)) {
+                  fprintf(stderr, "rank %d: walk: allgather algo %d: block %d element %zu\n", rank, algo, r, i);
+                  g_bad.fetch_add(1);
+                  r = size;
+                  break;
+                }
+            break;
+          }
+          default: {  // two collectives back to back on a stream, the second reading what the first wrote
+            R.fill_i64(n, ++salt);
+            CHECK(xmpi_allreduce_on_stream(c, R.send, R.recv, n, XMPI_I64, XMPI_SUM, ws));
+            CHECK(xmpi_allreduce_on_stream(c, R.recv, R.recv, n, XMPI_I64, XMPI_MAX, ws));  // (everybody holds the same: MAX leaves it)
+            CHECK(xmpi_stream_sync(c, ws));
+            (void)R.expect_sum_i64(n, salt, "walk: two on a stream");
+            break;
+          }
+        }
+      }
+      CHECK(xmpi_set_param(c, "dsync_split_bytes", 4 << 20));
+      CHECK(xmpi_set_param(c, "body_sys", 0));
+      CHECK(xmpi_stream_destroy(c, ws));
     }
     // ---- stream-ordered collectives on a stream of the caller's, and a captured graph replayed ---------------------------------
     if ((wants("stream") || wants("graph")) && dev) {
