@@ -114,10 +114,48 @@ def build_driver(tsan: bool, force: bool = False) -> str:
     return out
 
 
+MUTANT_BIN = os.path.join(HERE, "devsim_tsan_mutant_bin")
+# (what is cut out, what goes in its place): the stepped kernels' wait for the previous step's flag word of the peer
+MUTATION = ("const uint32_t why = dsync_spin(step_flags(mine) + (size_t)wait_rank * kStepSlots + w, (sh.epoch << 8) | st.wait_val, a.d);",
+            "const uint32_t why = DSYNC_OK;  /* MUTANT: the step does not wait for its peer */")
+
+
+def build_mutant(force: bool = False) -> str:
+    """the sanitizer driver with ONE wait taken out of a copy of sched.hip (the ring / halving / tree kernels no longer wait for the
+    peer's step): what the harness must find.  The copy lives under obj_mutant/ and is never anything but a test's input."""
+    objs, _ = _objects("tsan", _flags("-O1", "-fsanitize=thread"), [os.path.join(HERE, "driver.cpp")], force)
+    objdir = os.path.join(HERE, "obj_mutant")
+    os.makedirs(objdir, exist_ok=True)
+    src = os.path.join(b.CSRC, "sched.hip")
+    text = open(src).read()
+    assert text.count(MUTATION[0]) == 1, "sched.hip no longer holds the line the mutant removes: update tests/devsim/build.py MUTATION"
+    mutated = os.path.join(objdir, "sched_mutant.hip")
+    new_text = text.replace(MUTATION[0], MUTATION[1])
+    if not os.path.exists(mutated) or open(mutated).read() != new_text:
+        with open(mutated, "w") as f:
+            f.write(new_text)
+    obj = os.path.join(objdir, "sched.o")
+    fl = _flags("-O1", "-fsanitize=thread") + ["-mllvm", "-tsan-instrument-func-entry-exit=0"]
+    d = b._digest([mutated] + _headers(), " ".join(fl))
+    rebuilt = False
+    if force or b._stale(obj, d):
+        b._run([_clang(), *fl, "-c", mutated, "-o", obj])
+        b._record(obj, d)
+        rebuilt = True
+    link_objs = [obj if os.path.basename(o) == "sched.o" else o for o in objs]
+    link = b._digest(link_objs, "devsim mutant link")
+    if force or rebuilt or b._stale(MUTANT_BIN, link):
+        b._run([_clang(), "-fsanitize=thread", *link_objs, "-o", MUTANT_BIN, "-lpthread", "-lrt", "-ldl"])
+        b._record(MUTANT_BIN, link)
+    return MUTANT_BIN
+
+
 if __name__ == "__main__":
     force = "--force" in sys.argv
     if "--tsan" in sys.argv:
         print("built:", build_driver(True, force))
+    elif "--mutant" in sys.argv:
+        print("built:", build_mutant(force))
     elif "--traffic" in sys.argv:
         print("built:", build_traffic_lib(force))
     elif "--driver" in sys.argv:

@@ -75,6 +75,16 @@ def test_the_sanitizer_sees_the_kernels_stores(tsan_bin):
     assert "dsync_fold_kernel" in r.stderr, r.stderr[-3000:]
 
 
+def test_the_sanitizer_finds_a_wait_taken_out_of_a_kernel(tsan_bin):
+    """mutation: a COPY of sched.hip in which the stepped kernels no longer wait for the peer's step flag (tests/devsim/build.py
+    MUTATION; the product source is untouched) -- the harness must say so: data races between a step's loads and the peer's
+    written-through stores, in the ring / halving kernels, and wrong results"""
+    from tests.devsim import build
+    r = run(build.build_mutant(), "4", "1", "sched")
+    assert r.returncode != 0 and "ThreadSanitizer: data race" in r.stderr, r.stderr[-3000:]
+    assert "st_sys128" in r.stderr and "ld_sys128_issue" in r.stderr, r.stderr[-3000:]
+
+
 @pytest.mark.parametrize("ranks,fuzz", [(2, 0), (3, 5), (5, 0), (8, 9)])
 def test_device_protocols_are_race_free(tsan_bin, ranks, fuzz):
     """every form of every collective, stream-ordered and blocking Send / Receive, the agent, graphs: results right, nothing
