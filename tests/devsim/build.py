@@ -114,40 +114,64 @@ def build_driver(tsan: bool, force: bool = False) -> str:
     return out
 
 
-MUTANT_BIN = os.path.join(HERE, "devsim_tsan_mutant_bin")
-# (what is cut out, what goes in its place): the stepped kernels' wait for the previous step's flag word of the peer
-MUTATION = ("const uint32_t why = dsync_spin(step_flags(mine) + (size_t)wait_rank * kStepSlots + w, (sh.epoch << 8) | st.wait_val, a.d);",
-            "const uint32_t why = DSYNC_OK;  /* MUTANT: the step does not wait for its peer */")
+# Mutants: the sanitizer driver with ONE wait taken out of a COPY of the kernel sources (never anything but a test's input; the
+# product source is untouched).  name -> (file the line is in, what is cut out, what goes in its place)
+MUTATIONS = {
+    # the stepped kernels no longer wait for the previous step's flag word of the peer
+    "step": ("sched.hip",
+             "const uint32_t why = dsync_spin(step_flags(mine) + (size_t)wait_rank * kStepSlots + w, (sh.epoch << 8) | st.wait_val, a.d);",
+             "const uint32_t why = DSYNC_OK;  /* MUTANT: the step does not wait for its peer */"),
+    # the closing block no longer waits for the peers' "done": the caller is told its buffers are final while peers still store into them
+    "done": ("kdev.h",
+             "if (sh.fail == DSYNC_OK) why = dsync_spin(&mine->done[t][0], sh.epoch, a);",
+             "/* MUTANT: nobody waits for the peers' done */"),
+}
 
 
-def build_mutant(force: bool = False) -> str:
-    """the sanitizer driver with ONE wait taken out of a copy of sched.hip (the ring / halving / tree kernels no longer wait for the
-    peer's step): what the harness must find.  The copy lives under obj_mutant/ and is never anything but a test's input."""
+def mutant_bin(name: str) -> str:
+    return os.path.join(HERE, f"devsim_tsan_mutant_{name}_bin")
+
+
+def build_mutant(name: str = "step", force: bool = False) -> str:
+    fname, cut, put = MUTATIONS[name]
     objs, _ = _objects("tsan", _flags("-O1", "-fsanitize=thread"), [os.path.join(HERE, "driver.cpp")], force)
-    objdir = os.path.join(HERE, "obj_mutant")
+    objdir = os.path.join(HERE, "obj_mutant", name)
     os.makedirs(objdir, exist_ok=True)
-    src = os.path.join(b.CSRC, "sched.hip")
-    text = open(src).read()
-    assert text.count(MUTATION[0]) == 1, "sched.hip no longer holds the line the mutant removes: update tests/devsim/build.py MUTATION"
-    mutated = os.path.join(objdir, "sched_mutant.hip")
-    new_text = text.replace(MUTATION[0], MUTATION[1])
-    if not os.path.exists(mutated) or open(mutated).read() != new_text:
-        with open(mutated, "w") as f:
-            f.write(new_text)
-    obj = os.path.join(objdir, "sched.o")
+    text = open(os.path.join(b.CSRC, fname)).read()
+    assert text.count(cut) == 1, f"{fname} no longer holds the line mutant '{name}' removes: update tests/devsim/build.py MUTATIONS"
+    # a header's mutant needs every file that includes it beside it (quoted includes look there first)
+    copies = {fname: text.replace(cut, put)}
+    units = [fname] if fname.endswith(".hip") else [s for s in b.LIB_SOURCES if s.endswith(".hip")]
+    for u in units:
+        copies.setdefault(u, open(os.path.join(b.CSRC, u)).read())
+    for f, t in copies.items():
+        path = os.path.join(objdir, f)
+        if not os.path.exists(path) or open(path).read() != t:
+            with open(path, "w") as fh:
+                fh.write(t)
     fl = _flags("-O1", "-fsanitize=thread") + ["-mllvm", "-tsan-instrument-func-entry-exit=0"]
-    d = b._digest([mutated] + _headers(), " ".join(fl))
-    rebuilt = False
-    if force or b._stale(obj, d):
-        b._run([_clang(), *fl, "-c", mutated, "-o", obj])
+    jobs, rebuilt, swapped = [], False, {}
+    for u in units:
+        src = os.path.join(objdir, u)
+        obj = os.path.join(objdir, os.path.splitext(u)[0] + ".o")
+        swapped[os.path.splitext(u)[0] + ".o"] = obj
+        d = b._digest([os.path.join(objdir, f) for f in sorted(copies)] + _headers(), " ".join(fl) + u)
+        if force or b._stale(obj, d):
+            jobs.append((subprocess.Popen([_clang(), *fl, "-c", src, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True), obj, d, u))
+    for proc, obj, d, u in jobs:
+        out, _ = proc.communicate()
+        if proc.returncode != 0:
+            sys.stderr.write(f"clang++ mutant {name} {u}:\n{out}")
+            raise RuntimeError("build failed: devsim mutant " + u)
         b._record(obj, d)
         rebuilt = True
-    link_objs = [obj if os.path.basename(o) == "sched.o" else o for o in objs]
-    link = b._digest(link_objs, "devsim mutant link")
-    if force or rebuilt or b._stale(MUTANT_BIN, link):
-        b._run([_clang(), "-fsanitize=thread", *link_objs, "-o", MUTANT_BIN, "-lpthread", "-lrt", "-ldl"])
-        b._record(MUTANT_BIN, link)
-    return MUTANT_BIN
+    link_objs = [swapped.get(os.path.basename(o), o) for o in objs]
+    out = mutant_bin(name)
+    link = b._digest(link_objs, "devsim mutant link " + name)
+    if force or rebuilt or b._stale(out, link):
+        b._run([_clang(), "-fsanitize=thread", *link_objs, "-o", out, "-lpthread", "-lrt", "-ldl"])
+        b._record(out, link)
+    return out
 
 
 if __name__ == "__main__":
@@ -155,7 +179,7 @@ if __name__ == "__main__":
     if "--tsan" in sys.argv:
         print("built:", build_driver(True, force))
     elif "--mutant" in sys.argv:
-        print("built:", build_mutant(force))
+        print("built:", [build_mutant(m, force) for m in MUTATIONS])
     elif "--traffic" in sys.argv:
         print("built:", build_traffic_lib(force))
     elif "--driver" in sys.argv:

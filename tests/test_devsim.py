@@ -29,6 +29,9 @@ def _everything_built():
     import sys
     jobs = [subprocess.Popen([sys.executable, "-m", "tests.devsim.build", *flag], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
             for flag in ([], ["--tsan"], ["--traffic"])]
+    out, _ = jobs[1].communicate()  # the mutants swap single objects of the sanitizer build: they start when it is there
+    assert jobs[1].returncode == 0, out[-4000:]
+    jobs[1] = subprocess.Popen([sys.executable, "-m", "tests.devsim.build", "--mutant"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     for j in jobs:
         out, _ = j.communicate()
         assert j.returncode == 0, out[-4000:]
@@ -75,14 +78,16 @@ def test_the_sanitizer_sees_the_kernels_stores(tsan_bin):
     assert "dsync_fold_kernel" in r.stderr, r.stderr[-3000:]
 
 
-def test_the_sanitizer_finds_a_wait_taken_out_of_a_kernel(tsan_bin):
-    """mutation: a COPY of sched.hip in which the stepped kernels no longer wait for the peer's step flag (tests/devsim/build.py
-    MUTATION; the product source is untouched) -- the harness must say so: data races between a step's loads and the peer's
-    written-through stores, in the ring / halving kernels, and wrong results"""
+@pytest.mark.parametrize("mutant,scenario,where", [("step", "sched", ("st_sys128", "ld_sys128_issue")), ("done", "fold", ("hipMemcpyAsync",))])
+def test_the_sanitizer_finds_a_wait_taken_out_of_a_kernel(tsan_bin, mutant, scenario, where):
+    """mutation: COPIES of the kernel sources with one wait removed (tests/devsim/build.py MUTATIONS; the product source is
+    untouched) -- `step`: the stepped kernels no longer wait for the peer's step flag (races between a step's loads and the
+    peer's written-through stores); `done`: the closing block no longer waits for the peers' "done" (the caller reads / refills
+    buffers the peers' kernels still store into).  The harness must say so, in those places"""
     from tests.devsim import build
-    r = run(build.build_mutant(), "4", "1", "sched")
+    r = run(build.build_mutant(mutant), "4", "1", scenario)
     assert r.returncode != 0 and "ThreadSanitizer: data race" in r.stderr, r.stderr[-3000:]
-    assert "st_sys128" in r.stderr and "ld_sys128_issue" in r.stderr, r.stderr[-3000:]
+    assert all(w in r.stderr for w in where), r.stderr[-3000:]
 
 
 @pytest.mark.parametrize("ranks,fuzz", [(2, 0), (3, 5), (5, 0), (8, 9)])
