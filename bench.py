@@ -860,10 +860,18 @@ def main():
         line["roofline_isolated"] = {k: r0["iso"][k] for k in ("avg_launch_us", "achieved", "frac")}
     if meaningful or r0["link"]:
         # per rank 2(R-1)/R x S bytes leave (and arrive) per allreduce; the full-mesh schedules spread them over the R-1
-        # links of a GPU, a ring channel puts its share on one.  153 GB/s per link is both directions together (76.8 each way)
+        # links of a GPU, a ring channel puts its share on one.  153 GB/s per link is both directions together (76.8 each way).
+        # What the BUSIEST link direction carries, by schedule, in units of S -- counted on virtual devices, every load and store
+        # of the kernels traced (tests/devsim; asserted to the byte in the CPU suite): the fold and push-only
+        # 2 / R; the ring kernel 2 (R - 1) / R over its channels (R - 2 Walecki rings on an even mesh); halving + doubling 1.
+        sched = str(r0["tune"].get("algo") or r0["best"]["algo"])
+        ring_channels = (R - 2) if (R >= 4 and R % 2 == 0) else max(1, sum(1 for d in range(1, R) if np.gcd(d, R) == 1))
+        share = {"ring": 2.0 * (R - 1) / R / min(8, ring_channels), "rhd": 1.0}.get(sched, 2.0 / R) if R > 1 else 0.0
         line["xgmi"] = {"per_link_peak_GBps": XGMI_LINK_GBPS, "wire_GBps_per_rank_each_direction": busbw,
                         "wire_GBps_per_link_each_direction_if_spread": busbw / max(1, R - 1),
-                        "frac_of_link_peak": busbw / max(1, R - 1) / (XGMI_LINK_GBPS / 2),
+                        "schedule": sched, "busiest_link_direction_bytes_over_S": share,
+                        "busiest_link_direction_GBps": share * S / t / 1e9,
+                        "frac_of_link_peak": share * S / t / 1e9 / (XGMI_LINK_GBPS / 2),
                         "busbw_frac_of_one_link": busbw / XGMI_LINK_GBPS, "link_probe": r0["link"], "meaningful": meaningful}
     if (args.gpus > 1 or job.procs > 1) and not args.no_probe:
         line["zero_copy_probe"] = r0["zero_copy_probe"]

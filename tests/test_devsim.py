@@ -253,6 +253,9 @@ def test_the_scale_command_on_virtual_gpus(devsim_lib, gpus, tmp_path):
     if gpus == 8:  # north_star's layout: one rank per GPU, ranks meet on the device, the library's tuner chose the schedule
         assert d["config"]["transport"] == "xGMI (one rank per GPU)" and d["ranks_meet"] == "on the device (dsync)"
         assert d["roofline"]["kernel"].startswith("dsync_") and d["config"]["tuned"]
+        x = d["xgmi"]  # the link figure follows the schedule that was timed (what its busiest link direction carries)
+        assert x["busiest_link_direction_bytes_over_S"] == {"ring": 1.75 / 6, "rhd": 1.0}.get(x["schedule"], 0.25), x
+        assert abs(x["frac_of_link_peak"] - x["busiest_link_direction_bytes_over_S"] * d["config"]["bytes_per_rank"] / (d["ms_per_step"] * 1e-3) / 76.5e9) < 1e-9
     else:
         assert d["config"]["transport"].startswith(f"mixed: 8 ranks on {gpus} GPUs")
 
