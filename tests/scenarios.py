@@ -1970,6 +1970,8 @@ def sc_traffic(comm, args):
         for i in range(size):
             assert int(m[i, i].sum()) == 2 * c, f"{name}: device {i} moved {int(m[i, i].sum())} bytes of its own memory, plan {2 * c}"
         assert report[name]["hbm_per_device_max"] == 2 * S == report[name]["hbm_per_device_min"]  # N reads + N writes per element of a chunk (section 5)
+        # what the rendezvous costs a link: the announcement (6 words + the epoch) and the "done" word -- 64 bytes per ordered pair, no remote flag LOAD
+        assert report[name]["flag_page_remote_stores"] == 64 * size * (size - 1) and report[name]["flag_page_remote_loads"] == 0, report[name]
     comm.set_param("body_sys", 0)
     # push only: chunk j of my buffer into rank j's scratch, then my reduced chunk into everybody's receive buffer; no remote load
     run("allreduce push only", allreduce(xmpi.ALGO_ZPUSH, **one), lambda i, j: (0, 2 * c))
