@@ -46,10 +46,22 @@ int main(int argc, char** argv) {
     for (int w = 0; w < 5; w++)
       if (mpi::Error err = mpi::Allreduce(mpi::Span(send, n), mpi::Span(recv, n))) return fail("allreduce", err);
     mpi::Barrier();
+    const long ag0 = xmpi_get_param(gpu->Handle(), "dsync_ll_agent"), wt0 = xmpi_get_param(gpu->Handle(), "agent_ll_wait_ns");
     double t0 = now_us();
     for (int i = 0; i < k; i++)
       if (mpi::Error err = mpi::Allreduce(mpi::Span(send, n), mpi::Span(recv, n))) return fail("allreduce", err);
     const double blocking_us = (now_us() - t0) / k;
+    // of which: between the command to the lingering LL agent and its answer (when it ran them: ll.hip ll_agent_kernel)
+    const long ag = xmpi_get_param(gpu->Handle(), "dsync_ll_agent") - ag0;
+    const double agent_wait_us = ag > 0 ? (double)(xmpi_get_param(gpu->Handle(), "agent_ll_wait_ns") - wt0) / 1e3 / (double)ag : 0.0;
+    {  // the blocking calls' result (whoever ran them: a launched kernel or a lingering agent), then garbage for the enqueued ones to overwrite
+      const size_t m = n < got.size() ? n : got.size();
+      if (mpi::Error err = gpu->Memcpy(got.data(), recv, m * 4)) return fail("download", err);
+      for (size_t i = 0; i < m; i++)
+        if (got[i] != (float)(size * (size + 1) / 2) + (float)size * (float)(i % 7)) bad++;
+      std::vector<float> junk(m, -1.0f);
+      if (mpi::Error err = gpu->Memcpy(recv, junk.data(), m * 4)) return fail("upload", err);
+    }
     mpi::Barrier();
     t0 = now_us();
     for (int i = 0; i < k; i++)
@@ -63,15 +75,18 @@ int main(int argc, char** argv) {
     // max over ranks of both figures
     std::vector<double> mine = {blocking_us, queued_us}, worst(2);
     if (mpi::Error err = mpi::Allreduce(mpi::Slice(mine), mpi::Into(&worst), XMPI_MAX)) return fail("allreduce(max)", err);
-    char row[256];
-    snprintf(row, sizeof row, "%s{\"bytes\": %zu, \"blocking_us\": %.2f, \"queued_us\": %.2f, \"queued_busbw_GBps\": %.3f}",
-             rows.empty() ? "" : ", ", bytes, worst[0], worst[1], (double)bytes / worst[1] / 1e3 * 2.0 * (size - 1) / size);
+    char row[384];
+    snprintf(row, sizeof row, "%s{\"bytes\": %zu, \"blocking_us\": %.2f, \"queued_us\": %.2f, \"queued_busbw_GBps\": %.3f, \"by_agent\": %ld, \"agent_wait_us\": %.2f}",
+             rows.empty() ? "" : ", ", bytes, worst[0], worst[1], (double)bytes / worst[1] / 1e3 * 2.0 * (size - 1) / size, ag, agent_wait_us);
     rows += row;
   }
   mpi::Barrier();
   if (rank == 0)
-    printf("{\"ranks\": %d, \"one_process_per_rank\": true, \"meet\": \"%s\", \"exact\": %s, \"rows\": [%s]}\n", size,
-           on_device ? "on the device (flag words in HBM)" : "on the host (control block)", bad ? "false" : "true", rows.c_str());
+    printf("{\"ranks\": %d, \"one_process_per_rank\": true, \"meet\": \"%s\", \"exact\": %s, \"ll_collectives\": %ld, \"run_by_the_ll_agent\": %ld, "
+           "\"ll_agent_launches\": %ld, \"rows\": [%s]}\n", size,
+           on_device ? "on the device (flag words in HBM)" : "on the host (control block)", bad ? "false" : "true",
+           xmpi_get_param(gpu->Handle(), "dsync_ll_launches"), xmpi_get_param(gpu->Handle(), "dsync_ll_agent"),
+           xmpi_get_param(gpu->Handle(), "ll_agent_launches"), rows.c_str());
   gpu->StreamDestroy(st);
   gpu->Free(send);
   gpu->Free(recv);

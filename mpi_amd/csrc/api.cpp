@@ -61,6 +61,7 @@ static int use_device(const xmpi_comm* c) {
     }                                          \
     int _rc = ::xmpi::use_device(c);           \
     if (_rc) return _rc;                       \
+    (c)->api_calls.fetch_add(1, std::memory_order_relaxed); \
   } while (0)
 
 // no-progress limit of a steady-state wait: XMPI_TIMEOUT_S, or for ever
@@ -308,6 +309,7 @@ static void worker_main(xmpi_comm* c) {
       c->wq.pop_front();
     }
     g_last_error.clear();
+    c->api_calls.fetch_add(1, std::memory_order_relaxed);  // (before the job takes coll_mu: whoever holds it next has seen this -- dsync.cpp dsync_ll)
     const int rc = job.first();
     {
       std::lock_guard<std::mutex> l(job.second->mu);
@@ -610,6 +612,8 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   c->xcd_check = env_long("XMPI_XCD_CHECK", 1) ? 1 : 0;
   c->body_sys = env_long("XMPI_BODY_SYS", -1);  // -1: decided by the XCD probe (dsync_prepare)
   c->ll_bytes = env_long("XMPI_LL_BYTES", -1);  // -1: decided when the job's layout is known (dsync_connect)
+  c->agent_ll = env_long("XMPI_AGENT_LL", 1) ? 1 : 0;
+  c->agent_ll_bytes = std::max<long>(0, std::min<long>((long)kLLMaxPayload, env_long("XMPI_AGENT_LL_BYTES", 4096)));
   c->sched_channels = std::max<long>(0, env_long("XMPI_SCHED_CHANNELS", 0));
   c->sched_grid = std::max<long>(0, env_long("XMPI_SCHED_GRID", 0));
   c->tree_piece_bytes = std::max<long>(4096, env_long("XMPI_TREE_PIECE_BYTES", 256 << 10));
@@ -712,10 +716,14 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   c->p2p_kernel_ack = env_long("XMPI_P2P_KERNEL_ACK", 1) ? 1 : 0;
   c->p2p_agent_us = std::max<long>(0, env_long("XMPI_P2P_AGENT_US", 40));
   c->p2p_grid_cap = std::max<long>(0, std::min<long>(env_long("XMPI_P2P_GRID_CAP", 0), 4096));
-  if (hipHostMalloc((void**)&c->p2p_cmd, 64, hipHostMallocMapped) == hipSuccess) {
-    memset(c->p2p_cmd, 0, 64);
+  if (hipHostMalloc((void**)&c->p2p_cmd, 128, hipHostMallocMapped) == hipSuccess) {  // (two records: the receive agent's, the LL agent's)
+    memset(c->p2p_cmd, 0, 128);
     void* dev = nullptr;
-    if (hipHostGetDevicePointer(&dev, c->p2p_cmd, 0) == hipSuccess) c->p2p_cmd_dev = (uint64_t*)dev;
+    if (hipHostGetDevicePointer(&dev, c->p2p_cmd, 0) == hipSuccess) {
+      c->p2p_cmd_dev = (uint64_t*)dev;
+      c->ll_cmd = c->p2p_cmd + 8;
+      c->ll_cmd_dev = c->p2p_cmd_dev + 8;
+    }
   } else {
     c->p2p_cmd = nullptr;
   }
@@ -768,6 +776,7 @@ int xmpi_finalize(xmpi_comm* c) {
   if (c->finalized) return XMPI_OK;
   stop_worker(c);  // outstanding non-blocking collectives complete first
   p2p_agent_stop(c);  // the receive agent (if it still lingers) is told to go
+  ll_agent_stop(c);   // ... and the LL agent
   XMPI_TRACE_STEP(c->rank, "finalize: device sync");
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
@@ -794,6 +803,7 @@ int xmpi_finalize(xmpi_comm* c) {
   }
   for (hipStream_t s : c->p2p_streams) stream_release(c->device, s);
   if (c->agent_stream) stream_release(c->device, c->agent_stream);
+  if (c->ll_agent_stream) stream_release(c->device, c->ll_agent_stream);
   for (hipEvent_t e : c->ev_free) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev_timed_free) (void)hipEventDestroy(e);
   if (!c->ctl->aborted()) (void)c->ctl->barrier(wait_limit(c));
@@ -1468,6 +1478,8 @@ int xmpi_set_param(xmpi_comm* c, const char* name, long value) {
   else if (n == "dsync_tiles") c->dsync_tiles = std::max<long>(1, value);
   else if (n == "p2p_grid_cap") c->p2p_grid_cap = std::max<long>(0, std::min<long>(value, 4096));
   else if (n == "ll_bytes") c->ll_bytes = std::max<long>(0, std::min<long>((long)kLLMaxPayload, value));  // untuned AUTO: LL lines up to here
+  else if (n == "agent_ll") c->agent_ll = value ? 1 : 0;  // blocking LL collectives by the lingering agent (no launch)
+  else if (n == "agent_ll_bytes") c->agent_ll_bytes = std::max<long>(0, std::min<long>((long)kLLMaxPayload, value));
   else if (n == "dsync_split_bytes") c->dsync_split_bytes = std::max<long>(0, value);  // 0: always one kernel
   else if (n == "xcd_check") c->xcd_check = value ? 1 : 0;
   else if (n == "body_sys") c->body_sys = value ? 1 : 0;
@@ -1519,6 +1531,11 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
   if (n == "ll_bytes") return c->ll_bytes;
   if (n == "ll_max_bytes") return (long)kLLMaxPayload;
   if (n == "dsync_ll_launches") return (long)c->dsync_ll_launches;
+  if (n == "agent_ll") return c->agent_ll;
+  if (n == "agent_ll_bytes") return c->agent_ll_bytes;
+  if (n == "dsync_ll_agent") return (long)c->dsync_ll_agent;
+  if (n == "ll_agent_launches") return (long)c->ll_agent_launches;
+  if (n == "agent_ll_wait_ns") return (long)c->agent_ll_wait_ns;  // command written -> answer seen, summed over dsync_ll_agent calls
   if (n == "dsync_grid") return c->dsync_grid_cap;
   if (n == "dsync_split_bytes") return c->dsync_split_bytes;
   if (n == "roctx") return roctx_enabled() ? 1 : 0;  // named ranges for the profilers are on (trace.h)

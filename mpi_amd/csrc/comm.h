@@ -177,6 +177,19 @@ struct xmpi_comm {
   uint64_t dsync_launches = 0, dsync_bounced = 0;  // diagnostics: kernels; buffers stood in for by arena blocks
   long ll_bytes = 0;             // untuned AUTO: collectives up to this many bytes per rank go as LL lines (ll.hip); XMPI_LL_BYTES
   uint64_t dsync_ll_launches = 0;  // ... collectives that did
+  long agent_ll = 1;             // a BLOCKING LL collective of up to agent_ll_bytes per rank is handed to the lingering agent
+  long agent_ll_bytes = 4096;    // (sched.hip p2p_agent_kernel, kind 3) instead of being launched; XMPI_AGENT_LL, XMPI_AGENT_LL_BYTES
+  uint64_t dsync_ll_agent = 0;   // ... collectives the agent ran
+  uint64_t* ll_cmd = nullptr;    // the LL agent's command record (pinned host, 8 words: the second half of p2p_cmd's allocation)
+  uint64_t* ll_cmd_dev = nullptr;
+  uint64_t ll_agent_seq = 0;     // number of the last command written (callers hold coll_mu)
+  bool ll_agent_running = false; // launched and not yet known to have gone
+  hipStream_t ll_agent_stream = nullptr;
+  uint64_t ll_agent_launches = 0;
+  uint64_t agent_ll_wait_ns = 0; // diagnostics: time between writing a command and seeing its answer, summed
+  std::atomic<uint64_t> api_calls{0};  // public entry points taken on this communicator (XMPI_ENTER) ...
+  uint64_t agent_quiet_at = ~0ull;     // ... and its value when the agent last ran a collective: the NEXT call knows that nothing
+                                       // was enqueued through the library in between without asking the streams
   uint64_t dsync_split_launches = 0, dsync_sched_launches = 0;  // ... collectives run as meet / body / done; as a stepped kernel
   xmpi::DsyncEntry* dsync_table = nullptr;            // [kMaxRanks][kDsyncArenas], pinned host memory the kernels read
   const xmpi::DsyncEntry* dsync_table_dev = nullptr;  // ... as the GPU addresses it
@@ -252,6 +265,9 @@ int p2p_wait(xmpi_comm* c, int dest, int tag);
 int p2p_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int tag, size_t* got_bytes);
 int p2p_probe(xmpi_comm* c, int src, int tag, size_t* bytes, int* dtype);
 void p2p_agent_stop(xmpi_comm* c);
+// consecutive: the previous call into the library on this communicator was a collective the agent ran (its epoch + 1 is this one's)
+bool agent_submit_ll(xmpi_comm* c, const void* send, void* recv, size_t bytes, int ll_coll, int root, int dtype, int op, bool consecutive);
+void ll_agent_stop(xmpi_comm* c);
 // zcopy.cpp.  *done = false: some rank's buffers are not registered HBM -- every rank saw that and
 // the caller runs the staged schedule instead (no rank is left behind: the decision is collective).
 int zero_copy_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void* recvbuf, size_t count,

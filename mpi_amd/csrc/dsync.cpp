@@ -554,6 +554,34 @@ static int dsync_ll(xmpi_comm* c, int coll, int root, const void* sendbuf, void*
   }
   if (!writes) recv = const_cast<void*>(send);  // (never written; the launcher wants a pointer)
   if (!reads) send = recv;
+  const int ll_coll = coll == COLL_ALLREDUCE ? LL_ALLREDUCE : coll == COLL_REDUCE ? LL_REDUCE : coll == COLL_BCAST ? LL_BCAST : LL_ALLGATHER;
+  // A blocking call -- the only kind the reference's API has (mpi.go:47-48) -- is launch + kernel + completion word, and the
+  // launch is half of it.  The agent that lingers behind Receives (sched.hip p2p_agent_kernel) runs the same lines without
+  // one: the command goes through pinned memory, the answer comes back the same way.  Only when the stream the call would have
+  // been enqueued on is idle and nothing this communicator enqueued elsewhere is still running (the agent cannot wait for a
+  // stream; the launched kernel is ordered behind both), nothing is being profiled per dispatch, and no stand-in needs a copy
+  // on the stream first.
+  // (the streams are not asked when the previous call into the library on this communicator was itself a collective the agent
+  // ran: it found them idle, and nothing has been enqueued through the library since)
+  const uint64_t calls = c->api_calls.load(std::memory_order_relaxed);
+  auto idle = [](hipStream_t s) { return hipStreamQuery(s) == hipSuccess; };
+  const bool consecutive = calls == c->agent_quiet_at + 1;
+  if (blocking && !capturing && lent.empty() && c->agent_ll && unit <= (size_t)std::max<long>(0, c->agent_ll_bytes) && !c->prof_on &&
+      (consecutive ||
+       (idle(stream) && (!c->dsync_last_stream || c->dsync_last_stream == stream || idle(c->dsync_last_stream))))) {
+    ++c->dsync_epoch;
+    const double t_cmd = now_seconds();
+    if (agent_submit_ll(c, send, recv, unit, ll_coll, root, dtype, op, consecutive)) {
+      c->agent_ll_wait_ns += (uint64_t)((now_seconds() - t_cmd) * 1e9);
+      c->agent_quiet_at = calls;
+      c->dsync_ll_launches++;  // (an LL collective, whoever ran its lines)
+      c->dsync_ll_agent++;
+      if (host_out) memcpy(recvbuf, c->host_bounce + xmpi_comm::kHostBounce, recv_bytes);
+      return dsync_check(c);
+    }
+    --c->dsync_epoch;
+  }
+  (void)hipGetLastError();
   int rc = order_behind_last(c, stream, capturing);
   if (rc != XMPI_OK) return fail(rc);
 
@@ -562,7 +590,7 @@ static int dsync_ll(xmpi_comm* c, int coll, int root, const void* sendbuf, void*
   for (int p = 0; p < N; p++) a.page[p] = c->peer_page[p];
   a.me = me;
   a.n = N;
-  a.coll = coll == COLL_ALLREDUCE ? LL_ALLREDUCE : coll == COLL_REDUCE ? LL_REDUCE : coll == COLL_BCAST ? LL_BCAST : LL_ALLGATHER;
+  a.coll = ll_coll;
   a.root = root;
   a.epoch_floor = c->dsync_base;
   a.host_epoch = c->dsync_status_dev ? (uint64_t*)(c->dsync_status_dev + 2) : nullptr;

@@ -851,6 +851,105 @@ void p2p_agent_stop(xmpi_comm* c) {
   c->agent_running = false;
 }
 
+// ---- the LL agent: a one-block kernel that lingers behind a blocking small collective (ll.hip ll_agent_kernel) -------------
+// The command record and the conversation are the receive agent's (above); the caller holds coll_mu (dsync.cpp dsync_ll), so
+// there is one command at a time by construction.  true: the agent ran the collective and everything it wrote is visible;
+// false: not taken (no agent, broken, job aborted) -- nothing has happened that a launched LL kernel of the same epoch would
+// not repeat line for line.
+bool agent_submit_ll(xmpi_comm* c, const void* send, void* recv, size_t bytes, int ll_coll, int root, int dtype, int op, bool consecutive) {
+  if (c->p2p_agent_us <= 0 || !c->ll_cmd_dev || !c->dsync_ok || !c->dpage || c->size < 2 || c->size > kDsyncRanks || bytes == 0 ||
+      bytes > kLLMaxPayload)
+    return false;
+  volatile uint64_t* cmd = c->ll_cmd;
+  const uint64_t seq = ++c->ll_agent_seq;
+  const uint64_t meta = (uint64_t)(ll_coll & 3) | ((uint64_t)(root & 7) << kAgentLLRootShift) |
+                        ((uint64_t)(dtype & 7) << kAgentLLDtypeShift) | ((uint64_t)(op & 3) << kAgentLLOpShift) |
+                        ((uint64_t)(consecutive ? 1 : 0) << kAgentLLConsecutiveShift);
+  // (the agent polls all four words while they are written and takes them only when [0] and [3] both carry this number: every
+  // word is an atomic store, so that the words it reads early are merely old, never torn)
+  __atomic_store_n((uint64_t*)&cmd[1], (uint64_t)(uintptr_t)send, __ATOMIC_RELAXED);
+  __atomic_store_n((uint64_t*)&cmd[2], (uint64_t)(uintptr_t)recv, __ATOMIC_RELAXED);
+  __atomic_store_n((uint64_t*)&cmd[3], meta | (seq << 32), __ATOMIC_RELEASE);
+  __atomic_store_n((uint64_t*)&cmd[0], 1ull | ((uint64_t)bytes << 2) | (seq << 24), __ATOMIC_RELEASE);  // the doorbell last
+  auto launch = [&]() -> bool {
+    if (!c->ll_agent_stream) c->ll_agent_stream = stream_acquire(c->device);
+    if (!c->ll_agent_stream) return false;
+    __atomic_store_n((uint64_t*)&cmd[7], 0, __ATOMIC_RELEASE);
+    LLAgentArgs a;
+    memset(&a, 0, sizeof a);
+    a.cmd = c->ll_cmd_dev;
+    a.seq0 = seq;
+    a.patience_ticks = (uint64_t)c->p2p_agent_us * 100;  // wall_clock64 runs at 100 MHz
+    for (int p = 0; p < c->size; p++) a.ll.page[p] = c->peer_page[p];
+    a.ll.me = c->rank;
+    a.ll.n = c->size;
+    a.ll.epoch_floor = c->dsync_base;
+    a.ll.host_epoch = c->dsync_status_dev ? (uint64_t*)(c->dsync_status_dev + 2) : nullptr;
+    a.ll.abort_word = c->dsync_abort_dev;
+    a.ll.status = c->dsync_status_dev;
+    a.ll.spin_limit = c->timeout_s > 0 ? (uint64_t)c->timeout_s * 100000000ull : 0;
+    if (launch_ll_agent(a, c->ll_agent_stream) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    c->ll_agent_running = true;
+    c->ll_agent_launches++;
+    return true;
+  };
+  auto withdraw = [&]() {
+    __atomic_store_n((uint64_t*)&cmd[0], 0, __ATOMIC_RELEASE);  // nobody may act on it any more
+    --c->ll_agent_seq;
+    return false;
+  };
+  if (!c->ll_agent_running && !launch()) return withdraw();
+  Backoff bo;
+  bo.idle = [](void* p) { dsync_service((xmpi_comm*)p); };  // (a peer may be waiting for this rank to map a buffer before it can start)
+  bo.idle_arg = c;
+  const double t0 = now_seconds();
+  for (unsigned spins = 1;; spins++) {
+    if (__atomic_load_n((const uint64_t*)&cmd[6], __ATOMIC_ACQUIRE) == seq) break;  // done
+    if (__atomic_load_n((const uint64_t*)&cmd[7], __ATOMIC_ACQUIRE) != 0) {  // the agent had gone (its patience ran out)
+      if (__atomic_load_n((const uint64_t*)&cmd[6], __ATOMIC_ACQUIRE) == seq) break;
+      c->ll_agent_running = false;
+      if (!launch()) return withdraw();
+    }
+    // Off the fast path, now and then: an agent that faulted, a queue that was torn down -- the stream is idle only when the
+    // agent has ended; if it ended without serving this command and without saying "gone", it is broken and the launched kernel
+    // takes over.  A dead PEER is the agent's own business (ll_gather gives up within the no-progress limit and says why);
+    // this thread allows it that limit and a little more.
+    if ((spins & 0xfff) == 0) {
+      bool give_up = c->timeout_s > 0 && now_seconds() - t0 > (double)c->timeout_s + 5.0;
+      if (!give_up) {
+        const hipError_t e = hipStreamQuery(c->ll_agent_stream);
+        (void)hipGetLastError();
+        if (e != hipErrorNotReady)
+          give_up = __atomic_load_n((const uint64_t*)&cmd[6], __ATOMIC_ACQUIRE) != seq && __atomic_load_n((const uint64_t*)&cmd[7], __ATOMIC_ACQUIRE) == 0;
+      }
+      if (give_up) {
+        if (__atomic_load_n((const uint64_t*)&cmd[6], __ATOMIC_ACQUIRE) == seq) break;
+        c->ll_agent_running = false;
+        __atomic_store_n((uint64_t*)&cmd[0], 0, __ATOMIC_RELEASE);
+        return false;  // (the number stays consumed: a relaunch starts at the next one)
+      }
+    }
+    bo.pause();
+  }
+  return true;
+}
+
+// a lingering LL agent is told to go and waited for (finalize; nothing else needs it: it goes by itself)
+void ll_agent_stop(xmpi_comm* c) {
+  if (!c->ll_agent_running || !c->ll_cmd) return;
+  volatile uint64_t* cmd = c->ll_cmd;
+  const uint64_t seq = ++c->ll_agent_seq;
+  __atomic_store_n((uint64_t*)&cmd[3], seq << 32, __ATOMIC_RELEASE);
+  __atomic_store_n((uint64_t*)&cmd[0], 2ull | (seq << 24), __ATOMIC_RELEASE);
+  Backoff bo;
+  const double t0 = now_seconds();
+  while (__atomic_load_n((const uint64_t*)&cmd[7], __ATOMIC_ACQUIRE) == 0 && now_seconds() - t0 < 5.0) bo.pause();
+  c->ll_agent_running = false;
+}
+
 // wait_ack = false is the reference author's intended Send (commented out at mpi.go:132-152): return
 // once the payload has left the caller's buffer; p2p_wait() later collects the receiver's confirmation
 // and frees the {dest, tag} pair.

@@ -219,6 +219,24 @@ struct DsyncLLArgs {
 hipError_t launch_dsync_ll(const DsyncLLArgs& a, int dtype, int op, hipStream_t stream, hipEvent_t ev_start = nullptr,
                            hipEvent_t ev_stop = nullptr);
 
+// The LL AGENT (ll.hip ll_agent_kernel): a one-block kernel that lingers behind a BLOCKING small collective and runs the next
+// one without a launch.  The host writes a 32-byte command into pinned memory (as engine.cpp agent_submit does for the receive
+// agent, sched.hip p2p_agent_kernel):
+//   w0 = doorbell (1 = an LL collective, 2 = stop) | bytes per rank << 2 (22 bits) | seq << 24     w1 = send buffer
+//   w2 = receive buffer            w3 = collective (DsyncLLColl) | root << 2 | dtype << 5 | operation << 8 | consecutive << 10 | seq << 32
+// consecutive: no kernel of this rank has touched the page's epoch since the collective this agent ran last (the host knows: the
+// previous call into the library on this communicator was that collective) -- the epoch is the last one plus one, no load.
+// cmd[6] = number of the last command served, cmd[7] = "gone" (the number it was waiting for, plus one).
+struct LLAgentArgs {
+  uint64_t* cmd;            // pinned host memory, 8 words, 64-byte aligned
+  uint64_t seq0;            // the number of the first command this launch serves
+  uint64_t patience_ticks;  // wall_clock64 ticks (100 MHz) the agent waits for a command
+  DsyncLLArgs ll;           // the communicator's fields: page, me, n, epoch_floor, host_epoch, abort_word, status, spin_limit
+};
+constexpr uint32_t kAgentLLRootShift = 2, kAgentLLDtypeShift = 5, kAgentLLOpShift = 8, kAgentLLConsecutiveShift = 10;
+constexpr int kLLAgentBlock = 512;  // lanes of the agent's one block: 4 KiB per rank is one line per lane
+hipError_t launch_ll_agent(const LLAgentArgs& a, hipStream_t stream);
+
 // grid_x blocks per segment (the caller bounds it: every block spins until the peers arrive, so the kernels of
 // all ranks sharing a GPU must be resident together); unroll = 16-byte packets per lane per source in flight
 hipError_t launch_dsync_fold(const DsyncArgs& a, int nsrc, int dtype, int op, int grid_x, int unroll, hipStream_t stream,

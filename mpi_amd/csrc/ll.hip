@@ -68,10 +68,61 @@ __device__ __forceinline__ uint64_t combine8(uint64_t a, uint64_t b) {
   return r.u;
 }
 
+// the ranks' lines in rank order: ((x0 op x1) op x2) ... -- the host-side sum of a reference user (helloworld.go:53-81), bit for bit
+template <typename T, int OP>
+__device__ __forceinline__ uint64_t fold_ranks(const uint64_t (&x)[kDsyncRanks], uint64_t mine8, int me, int n) {
+  uint64_t acc = me == 0 ? mine8 : x[0];
+#pragma unroll
+  for (int p = 1; p < kDsyncRanks; p++)
+    if (p < n) acc = combine8<T, OP>(acc, p == me ? mine8 : x[p]);
+  return acc;
+}
+// dtype and operation fixed at compile time (the launched kernels: one instantiation each) ...
+template <typename T, int OP>
+struct LLFoldStatic {
+  __device__ __forceinline__ uint64_t operator()(const uint64_t (&x)[kDsyncRanks], uint64_t mine8, int me, int n) const {
+    return fold_ranks<T, OP>(x, mine8, me, n);
+  }
+};
+// ... or read from the command (the agent: one kernel for everything; one uniform branch per line)
+struct LLFoldRuntime {
+  int dtype, op;
+  template <typename T>
+  __device__ __forceinline__ uint64_t with(const uint64_t (&x)[kDsyncRanks], uint64_t mine8, int me, int n) const {
+    switch (op) {
+      case OP_SUM: return fold_ranks<T, OP_SUM>(x, mine8, me, n);
+      case OP_PROD: return fold_ranks<T, OP_PROD>(x, mine8, me, n);
+      case OP_MIN: return fold_ranks<T, OP_MIN>(x, mine8, me, n);
+      default: return fold_ranks<T, OP_MAX>(x, mine8, me, n);
+    }
+  }
+  __device__ __forceinline__ uint64_t operator()(const uint64_t (&x)[kDsyncRanks], uint64_t mine8, int me, int n) const {
+    switch (dtype) {
+      case DT_U8: return with<uint8_t>(x, mine8, me, n);
+      case DT_I32: return with<int32_t>(x, mine8, me, n);
+      case DT_I64: return with<int64_t>(x, mine8, me, n);
+      case DT_F16: return with<_Float16>(x, mine8, me, n);
+      case DT_F32: return with<float>(x, mine8, me, n);
+      case DT_F64: return with<double>(x, mine8, me, n);
+      default: return with<bf16_t>(x, mine8, me, n);
+    }
+  }
+};
+
 struct LLShared {
   uint64_t epoch;
   uint32_t fail, last;
 };
+
+// what one call asks for (the launched kernels: fields of their argument; the agent: its command)
+struct LLCall {
+  const void* send;
+  void* recv;
+  uint64_t bytes;
+  int32_t coll, root;
+};
+
+// `a` below: the fields of DsyncLLArgs that belong to the COMMUNICATOR (page, me, n, epoch_floor, abort_word, spin_limit)
 
 __device__ __forceinline__ void ll_begin(const DsyncLLArgs& a, LLShared& sh) {
   if (threadIdx.x == 0) {
@@ -136,6 +187,78 @@ __device__ __forceinline__ bool ll_gather(const DsyncLLArgs& a, LLShared& sh, ui
   return true;
 }
 
+// A line (payload bytes [8 idx, 8 idx + 8)) in two halves: PUSH this rank's bytes to whoever needs them, COLLECT the peers'.
+// A launched kernel's lane does one after the other for its one line; the agent's lanes own several lines each and push them
+// ALL before they collect the first (one exchange with the peers per call, not one per line).  Nothing is kept between the
+// halves: a line's own bytes are read again (in place works: a line is overwritten by its own collect only).
+
+// allreduce / reduce
+__device__ __forceinline__ void ll_reduce_push(const DsyncLLArgs& a, const LLCall& q, uint32_t parity, uint32_t flag, size_t idx) {
+  const int me = a.me, n = a.n;
+  if (q.coll != LL_ALLREDUCE && me == q.root) return;
+  const uint32_t valid = q.bytes - idx * 8 >= 8 ? 8u : (uint32_t)(q.bytes - idx * 8);
+  const uint64_t mine8 = load8(reinterpret_cast<const char*>(q.send) + idx * 8, valid);
+  if (q.coll == LL_ALLREDUCE) {
+#pragma unroll
+    for (int d = 1; d < kDsyncRanks; d++) {  // (start with the next rank: the ranks do not all hit rank 0's page first)
+      const int p = (me + d) % n;
+      if (d < n) ll_store(ll_slot(a.page[p], me, parity) + idx * 16, mine8, flag);
+    }
+  } else {
+    ll_store(ll_slot(a.page[q.root], me, parity) + idx * 16, mine8, flag);
+  }
+}
+// ... gather, fold in rank order, store
+template <typename F>
+__device__ __forceinline__ void ll_reduce_collect(const DsyncLLArgs& a, const LLCall& q, LLShared& sh, uint32_t parity, uint32_t flag,
+                                                  size_t idx, F fold) {
+  const int me = a.me, n = a.n;
+  if (q.coll != LL_ALLREDUCE && me != q.root) return;
+  const uint32_t valid = q.bytes - idx * 8 >= 8 ? 8u : (uint32_t)(q.bytes - idx * 8);
+  const uint64_t mine8 = load8(reinterpret_cast<const char*>(q.send) + idx * 8, valid);
+  uint64_t x[kDsyncRanks];
+  const uint32_t everyone = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
+  if (ll_gather(a, sh, everyone & ~(1u << me), parity, flag, idx, x))
+    store8(reinterpret_cast<char*>(q.recv) + idx * 8, fold(x, mine8, me, n), valid);
+}
+
+// broadcast / allgather: bytes only
+__device__ __forceinline__ void ll_copy_push(const DsyncLLArgs& a, const LLCall& q, uint32_t parity, uint32_t flag, size_t idx) {
+  const int me = a.me, n = a.n;
+  const bool gather = q.coll == LL_ALLGATHER;
+  if (!gather && me != q.root) return;
+  const uint32_t valid = q.bytes - idx * 8 >= 8 ? 8u : (uint32_t)(q.bytes - idx * 8);
+  const uint64_t mine8 = load8(reinterpret_cast<const char*>(q.send) + idx * 8, valid);
+#pragma unroll
+  for (int d = 1; d < kDsyncRanks; d++) {
+    const int p = (me + d) % n;
+    if (d < n) ll_store(ll_slot(a.page[p], me, parity) + idx * 16, mine8, flag);
+  }
+  if (gather) store8(reinterpret_cast<char*>(q.recv) + (size_t)me * q.bytes + idx * 8, mine8, valid);
+}
+__device__ __forceinline__ void ll_copy_collect(const DsyncLLArgs& a, const LLCall& q, LLShared& sh, uint32_t parity, uint32_t flag,
+                                                size_t idx) {
+  const int me = a.me, n = a.n;
+  const uint32_t valid = q.bytes - idx * 8 >= 8 ? 8u : (uint32_t)(q.bytes - idx * 8);
+  uint64_t x[kDsyncRanks];
+  if (q.coll == LL_ALLGATHER) {
+    const uint32_t everyone = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
+    if (ll_gather(a, sh, everyone & ~(1u << me), parity, flag, idx, x)) {
+#pragma unroll
+      for (int p = 0; p < kDsyncRanks; p++)
+        if (p < n && p != me) store8(reinterpret_cast<char*>(q.recv) + (size_t)p * q.bytes + idx * 8, x[p], valid);
+    }
+  } else if (me != q.root) {
+    if (ll_gather(a, sh, 1u << q.root, parity, flag, idx, x)) {
+      uint64_t got = 0;
+#pragma unroll
+      for (int p = 0; p < kDsyncRanks; p++)
+        if (p == q.root) got = x[p];
+      store8(reinterpret_cast<char*>(q.recv) + idx * 8, got, valid);
+    }
+  }
+}
+
 // Every wave's stores have left; the block that finishes last advances the epoch and tells the host.  No exchange with the
 // peers: nobody reads this rank's buffers, and the slots are safe by the parity argument (kernels.h).
 __device__ __forceinline__ void ll_end(const DsyncLLArgs& a, LLShared& sh) {
@@ -163,35 +286,15 @@ template <typename T, int OP>
 __global__ __launch_bounds__(kBlock) void ll_reduce_kernel(DsyncLLArgs a) {
   XMPI_SHARED(LLShared, sh);
   ll_begin(a, sh);
-  const int me = a.me, n = a.n;
   const uint64_t epoch = sh.epoch;
   const uint32_t parity = (uint32_t)(epoch & 1u), flag = (uint32_t)epoch ? (uint32_t)epoch : 1u;
+  const LLCall q{a.send, a.recv, a.bytes, a.coll, a.root};
   const bool to_all = a.coll == LL_ALLREDUCE;
   if (!to_all) ll_say_here(a, epoch);
   const size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (idx * 8 < a.bytes) {
-    const uint32_t valid = a.bytes - idx * 8 >= 8 ? 8u : (uint32_t)(a.bytes - idx * 8);
-    const uint64_t mine8 = load8(reinterpret_cast<const char*>(a.send) + idx * 8, valid);
-    if (to_all) {
-#pragma unroll
-      for (int d = 1; d < kDsyncRanks; d++) {  // (start with the next rank: the ranks do not all hit rank 0's page first)
-        const int p = (me + d) % n;
-        if (d < n) ll_store(ll_slot(a.page[p], me, parity) + idx * 16, mine8, flag);
-      }
-    } else if (me != a.root) {
-      ll_store(ll_slot(a.page[a.root], me, parity) + idx * 16, mine8, flag);
-    }
-    if (to_all || me == a.root) {
-      uint64_t x[kDsyncRanks];
-      const uint32_t everyone = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
-      if (ll_gather(a, sh, everyone & ~(1u << me), parity, flag, idx, x)) {
-        uint64_t acc = me == 0 ? mine8 : x[0];
-#pragma unroll
-        for (int p = 1; p < kDsyncRanks; p++)
-          if (p < n) acc = combine8<T, OP>(acc, p == me ? mine8 : x[p]);
-        store8(reinterpret_cast<char*>(a.recv) + idx * 8, acc, valid);
-      }
-    }
+    ll_reduce_push(a, q, parity, flag, idx);
+    ll_reduce_collect(a, q, sh, parity, flag, idx, LLFoldStatic<T, OP>{});
   }
   if (!to_all) ll_wait_here(a, sh);
   ll_end(a, sh);
@@ -201,44 +304,113 @@ __global__ __launch_bounds__(kBlock) void ll_reduce_kernel(DsyncLLArgs a) {
 __global__ __launch_bounds__(kBlock) void ll_copy_kernel(DsyncLLArgs a) {
   XMPI_SHARED(LLShared, sh);
   ll_begin(a, sh);
-  const int me = a.me, n = a.n;
   const uint64_t epoch = sh.epoch;
   const uint32_t parity = (uint32_t)(epoch & 1u), flag = (uint32_t)epoch ? (uint32_t)epoch : 1u;
+  const LLCall q{a.send, a.recv, a.bytes, a.coll, a.root};
   const bool gather = a.coll == LL_ALLGATHER;
   if (!gather) ll_say_here(a, epoch);
   const size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (idx * 8 < a.bytes) {
-    const uint32_t valid = a.bytes - idx * 8 >= 8 ? 8u : (uint32_t)(a.bytes - idx * 8);
-    if (gather || me == a.root) {
-      const uint64_t mine8 = load8(reinterpret_cast<const char*>(a.send) + idx * 8, valid);
-#pragma unroll
-      for (int d = 1; d < kDsyncRanks; d++) {
-        const int p = (me + d) % n;
-        if (d < n) ll_store(ll_slot(a.page[p], me, parity) + idx * 16, mine8, flag);
-      }
-      if (gather) store8(reinterpret_cast<char*>(a.recv) + (size_t)me * a.bytes + idx * 8, mine8, valid);
-    }
-    if (gather) {
-      uint64_t x[kDsyncRanks];
-      const uint32_t everyone = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
-      if (ll_gather(a, sh, everyone & ~(1u << me), parity, flag, idx, x)) {
-#pragma unroll
-        for (int p = 0; p < kDsyncRanks; p++)
-          if (p < n && p != me) store8(reinterpret_cast<char*>(a.recv) + (size_t)p * a.bytes + idx * 8, x[p], valid);
-      }
-    } else if (me != a.root) {
-      uint64_t x[kDsyncRanks];
-      if (ll_gather(a, sh, 1u << a.root, parity, flag, idx, x)) {
-        uint64_t got = 0;
-#pragma unroll
-        for (int p = 0; p < kDsyncRanks; p++)
-          if (p == a.root) got = x[p];
-        store8(reinterpret_cast<char*>(a.recv) + idx * 8, got, valid);
-      }
-    }
+    ll_copy_push(a, q, parity, flag, idx);
+    ll_copy_collect(a, q, sh, parity, flag, idx);
   }
   if (!gather) ll_wait_here(a, sh);
   ll_end(a, sh);
+}
+
+// The LL AGENT.  A blocking call -- the only kind the reference's API has (mpi.go:47-48) -- is launch + kernel + completion
+// word, and the launch is about half of it (1 KiB, 2 processes: 10.9 us blocking against 4.9 us enqueued).  So the kernel that
+// served a blocking small collective does not end at once: it watches a command record in pinned host memory for `patience`
+// (tens of microseconds), and the host thread of the NEXT blocking small collective writes {send, recv, bytes, what} there
+// instead of launching (kernels.h LLAgentArgs; the idea and the record are the receive agent's, sched.hip p2p_agent_kernel).
+// One block of kLLAgentBlock lanes: lane t owns lines t, t + 512, ... (dsync.cpp dsync_ll sends payloads up to agent_ll_bytes this
+// way; a round of lines costs a load from the flag allocation past the caches, ~2 us -- 4 KiB is one round, and beyond that the
+// launched kernel's many blocks are faster: 16 KiB took 24 us with 256 lanes against 11.8 launched).  It waits for
+// the PEERS inside a collective, as the launched kernel would, within the same no-progress limit; between collectives it waits
+// for the HOST only, and only for its patience.  dtype and operation come with the command: one kernel, the fold chosen by a
+// uniform branch per line.
+__global__ __launch_bounds__(kLLAgentBlock) void ll_agent_kernel(LLAgentArgs a) {
+  XMPI_SHARED(LLShared, sh);
+  XMPI_SHARED(uint64_t, s_send);
+  XMPI_SHARED(uint64_t, s_recv);
+  XMPI_SHARED(uint64_t, s_bytes);
+  XMPI_SHARED(uint32_t, s_meta);
+  XMPI_SHARED(uint32_t, s_go);
+  const int t = threadIdx.x;
+  uint64_t seq = a.seq0, prev_epoch = 0;  // (lane 0's: the epoch of the last collective this launch ran)
+  for (;;) {
+    if (t == 0) {
+      uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+      bool have = false;
+      const uint64_t t0 = wall_clock64();
+      for (;;) {
+        pack_t v[2];
+        ld_sys128_issue(v[0], reinterpret_cast<const pack_t*>(a.cmd));
+        ld_sys128_issue(v[1], reinterpret_cast<const pack_t*>(a.cmd) + 1);
+        sys128_wait<2>(v);
+        w0 = ((uint64_t)v[0].y << 32) | v[0].x;
+        w1 = ((uint64_t)v[0].w << 32) | v[0].z;
+        w2 = ((uint64_t)v[1].y << 32) | v[1].x;
+        w3 = ((uint64_t)v[1].w << 32) | v[1].z;
+        have = (w0 & 3u) != 0 && (w0 >> 24) == (seq & 0xffffffffffull) && (w3 >> 32) == (seq & 0xffffffffull);
+        if (have || wall_clock64() - t0 > a.patience_ticks) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (have && (w0 & 3u) == 1) {
+        s_send = w1;
+        s_recv = w2;
+        s_bytes = (w0 >> 2) & 0x3fffffu;
+        s_meta = (uint32_t)w3;
+        s_go = 1;
+      } else {  // told to stop, or nothing came in time: say so -- the next blocking collective launches the agent again
+        s_go = 0;
+        __hip_atomic_store(&a.cmd[7], seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    __syncthreads();
+    if (!s_go) return;
+    if (t == 0) {  // (ll_begin, but for the epoch of a call that follows one of this agent's directly: no load from the page)
+      uint64_t e;
+      if ((s_meta >> kAgentLLConsecutiveShift & 1u) && prev_epoch) {
+        e = prev_epoch + 1;
+      } else {
+        const uint64_t seen = ld_sys64(&a.ll.page[a.ll.me]->epoch_now);
+        e = (seen > a.ll.epoch_floor ? seen : a.ll.epoch_floor) + 1;
+      }
+      prev_epoch = e;
+      sh.epoch = e;
+      sh.fail = DSYNC_OK;
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // this call's send buffer as its owner left it, not a line of the call before
+    const uint32_t meta = s_meta;
+    const LLCall q{reinterpret_cast<const void*>(s_send), reinterpret_cast<void*>(s_recv), s_bytes, (int32_t)(meta & 3u),
+                   (int32_t)((meta >> kAgentLLRootShift) & 7u)};
+    const LLFoldRuntime fold{(int)((meta >> kAgentLLDtypeShift) & 7u), (int)((meta >> kAgentLLOpShift) & 3u)};
+    const uint64_t epoch = sh.epoch;
+    const uint32_t parity = (uint32_t)(epoch & 1u), flag = (uint32_t)epoch ? (uint32_t)epoch : 1u;
+    const bool to_all = q.coll == LL_ALLREDUCE || q.coll == LL_ALLGATHER;
+    if (!to_all) ll_say_here(a.ll, epoch);
+    if (q.coll == LL_ALLREDUCE || q.coll == LL_REDUCE) {  // every line of this lane goes out before the first is waited for
+      for (size_t idx = (size_t)t; idx * 8 < q.bytes; idx += kLLAgentBlock) ll_reduce_push(a.ll, q, parity, flag, idx);
+      for (size_t idx = (size_t)t; idx * 8 < q.bytes; idx += kLLAgentBlock) ll_reduce_collect(a.ll, q, sh, parity, flag, idx, fold);
+    } else {
+      for (size_t idx = (size_t)t; idx * 8 < q.bytes; idx += kLLAgentBlock) ll_copy_push(a.ll, q, parity, flag, idx);
+      for (size_t idx = (size_t)t; idx * 8 < q.bytes; idx += kLLAgentBlock) ll_copy_collect(a.ll, q, sh, parity, flag, idx);
+    }
+    if (!to_all) ll_wait_here(a.ll, sh);
+    XMPI_DRAIN();
+    __syncthreads();
+    if (t == 0) {  // what ll_end does for a launched kernel of one block; the answer goes where the host polls: cmd[6]
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // (system scope: the result may lie in pinned host memory, or be copied out by DMA)
+      st_sys64(&a.ll.page[a.ll.me]->epoch_now, epoch);
+      if (a.ll.host_epoch) st_sys64(a.ll.host_epoch, epoch);
+      if (sh.fail != DSYNC_OK && a.ll.status) __hip_atomic_store(a.ll.status, sh.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&a.cmd[6], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    seq++;
+    __syncthreads();
+  }
 }
 
 template <typename T>
@@ -275,6 +447,12 @@ hipError_t launch_dsync_ll(const DsyncLLArgs& a, int dtype, int op, hipStream_t 
     case DT_BF16: return ll_op<bf16_t>(a, op, grid, s, es, ee);
     default: return hipErrorInvalidValue;
   }
+}
+
+hipError_t launch_ll_agent(const LLAgentArgs& a, hipStream_t s) {
+  if (!a.cmd || a.ll.n < 2 || a.ll.n > kDsyncRanks || a.ll.me < 0 || a.ll.me >= a.ll.n) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ll_agent_kernel, dim3(1), dim3(kLLAgentBlock), 0, s, a);
+  return hipGetLastError();
 }
 
 }  // namespace xmpi

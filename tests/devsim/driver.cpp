@@ -107,16 +107,19 @@ struct Rank {
   }
 };
 
-void allreduce_case(Rank& R, size_t count, int algo, int salt, const char* what) {
+// idle_first: the call finds its stream idle (what lets the LL agent take a blocking small collective: ll.hip ll_agent_kernel)
+void allreduce_case(Rank& R, size_t count, int algo, int salt, const char* what, bool idle_first = false) {
   const int rank = R.rank;
   if (salt & 1) {
     R.fill_i64(count, salt);
     (void)xmpi_memset(R.c, R.recv, 0xEE, count * 8);
+    if (idle_first) (void)xmpi_sync(R.c);
     CHECK(xmpi_allreduce(R.c, R.send, R.recv, count, XMPI_I64, XMPI_SUM, algo));
     (void)R.expect_sum_i64(count, salt, what);
   } else {
     R.fill_f32(count, salt);
     (void)xmpi_memset(R.c, R.recv, 0xEE, count * 4);
+    if (idle_first) (void)xmpi_sync(R.c);
     CHECK(xmpi_allreduce(R.c, R.send, R.recv, count, XMPI_F32, XMPI_SUM, algo));
     (void)R.expect_sum_f32(count, salt, what);
   }
@@ -222,6 +225,66 @@ void rank_main(const std::string& key, int rank, int size, int rounds) {
             r = size;
             break;
           }
+    }
+    // ---- the same lines run by the lingering LL agent: blocking calls that find their stream idle ------------------------------
+    if (wants("ll") && dev && xmpi_get_param(c, "agent_ll") == 1 && xmpi_get_param(c, "p2p_agent_us") > 0) {
+      CHECK(xmpi_set_param(c, "agent_ll_bytes", 32768));
+      const long ag0 = xmpi_get_param(c, "dsync_ll_agent");
+      long expect = 0;
+      for (size_t n : {(size_t)1, (size_t)33, (size_t)257, (size_t)4096}) {
+        allreduce_case(R, n, XMPI_ALGO_LL, ++salt, "LL agent allreduce", true);
+        allreduce_case(R, n, XMPI_ALGO_LL, ++salt, "LL agent allreduce", true);
+        allreduce_case(R, n, XMPI_ALGO_LL, ++salt, "LL allreduce, launched or by the agent");  // (whichever: the stream may be busy)
+        expect += 2;
+      }
+      for (int root = 0; root < size; root++) {
+        R.fill_i64(300, ++salt);
+        if (rank == root) (void)xmpi_memcpy(c, R.recv, R.send, 300 * 8);
+        else (void)xmpi_memset(c, R.recv, 0xEE, 300 * 8);
+        (void)xmpi_sync(c);
+        CHECK(xmpi_bcast(c, R.recv, 300, XMPI_I64, root, XMPI_ALGO_LL));
+        R.download(300 * 8);
+        for (size_t i = 0; i < 300; i++)
+          if (((const int64_t*)R.host.data())[i] != in_i64(root, i, salt)) {
+            fprintf(stderr, "rank %d: LL agent bcast from %d: element %zu\n", rank, root, i);
+            g_bad.fetch_add(1);
+            break;
+          }
+        R.fill_i64(300, ++salt);
+        (void)xmpi_sync(c);
+        CHECK(xmpi_reduce(c, R.send, R.recv, 300, XMPI_I64, XMPI_SUM, root, XMPI_ALGO_LL));
+        if (rank == root) (void)R.expect_sum_i64(300, salt, "LL agent reduce");
+        expect += 2;
+        if (rank == root) usleep(300);  // (the others' agents wait for this rank inside the next collective; its own has gone)
+      }
+      {  // back to back, nothing in between: the agent counts the epochs itself (no load from the page); then a launched kernel moves it
+        R.fill_i64(64, ++salt);
+        (void)xmpi_sync(c);
+        for (int i = 0; i < 6; i++) {
+          CHECK(xmpi_allreduce(c, R.send, R.recv, 64, XMPI_I64, XMPI_SUM, XMPI_ALGO_LL));
+          CHECK(xmpi_allreduce(c, R.recv, R.send, 64, XMPI_I64, XMPI_SUM, XMPI_ALGO_LL));
+        }
+        expect += 12;
+        CHECK(xmpi_allreduce(c, R.send, R.recv, 64, XMPI_I64, XMPI_SUM, XMPI_ALGO_ZCOPY));  // launched: the 13th
+        CHECK(xmpi_allreduce(c, R.recv, R.send, 64, XMPI_I64, XMPI_SUM, XMPI_ALGO_LL));     // the 14th, wherever it ran
+        CHECK(xmpi_allreduce(c, R.send, R.recv, 64, XMPI_I64, XMPI_SUM, XMPI_ALGO_LL));     // the 15th
+        R.download(64 * 8);
+        for (size_t i = 0; i < 64; i++) {
+          uint64_t want = 0;
+          for (int r = 0; r < size; r++) want += (uint64_t)in_i64(r, i, salt);
+          for (int k = 0; k < 14; k++) want *= (uint64_t)size;
+          if (((const uint64_t*)R.host.data())[i] != want) {
+            fprintf(stderr, "rank %d: LL agent, back to back: element %zu\n", rank, i);
+            g_bad.fetch_add(1);
+            break;
+          }
+        }
+      }
+      if (xmpi_get_param(c, "dsync_ll_agent") - ag0 < expect) {
+        fprintf(stderr, "rank %d: the LL agent ran %ld of %ld blocking collectives\n", rank, xmpi_get_param(c, "dsync_ll_agent") - ag0, expect);
+        g_bad.fetch_add(1);
+      }
+      CHECK(xmpi_set_param(c, "agent_ll_bytes", 4096));
     }
     // ---- the stepped kernels: ring, recursive halving + doubling (any N) --------------------------------------------------------
     if (wants("sched")) {

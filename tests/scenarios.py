@@ -1204,6 +1204,123 @@ def reduce_case(comm, dtype, count, root, algo, op=xmpi.SUM, pat=xmpi.PAT_SIGNED
     recv.free()
 
 
+def _ll_agent_section(comm, maxb):
+    """The LL agent (ll.hip ll_agent_kernel): a BLOCKING small LL collective is run by a kernel that lingers behind the one
+    before -- no launch.  Every dtype and operation (the fold is chosen at run time there), every collective and root, payloads
+    of one line up to the slot limit (16 lines per lane), host slices; the agent gone (its patience over) and launched again;
+    blocking calls between enqueued ones without a host wait; the switch off."""
+    import time
+    rank, size = comm.rank(), comm.size()
+    L = xmpi.ALGO_LL
+    if comm.get_param("agent_ll") != 1 or comm.get_param("p2p_agent_us") <= 0:
+        return
+    ab = comm.get_param("agent_ll_bytes")
+    served = lambda: comm.get_param("dsync_ll_agent")
+
+    def reduce_once(dtype, count, op, pattern, seed, root=None, expect_agent=True):
+        es = xmpi.DTYPE_SIZE[dtype]
+        send, recv = comm.alloc(count * es), comm.alloc(count * es)
+        comm.fill(send, count, dtype, pattern, seed + rank)
+        comm.memset(recv, 0xA5, count * es)
+        comm.sync()  # (the agent takes a call only when the stream it would have been enqueued on is idle)
+        g0 = served()
+        if root is None:
+            comm.allreduce(send, recv, count, dtype, op, L)
+        else:
+            comm.reduce(send, recv if rank == root else None, count, dtype, op, root, L)
+        assert served() == g0 + (1 if expect_agent else 0), f"LL agent: {'not ' if expect_agent else ''}taken ({xmpi.DTYPE_NAME[dtype]} n={count})"
+        if root is None or rank == root:
+            ins = [oracle.fill(count, dtype, pattern, seed + r) for r in range(size)]
+            check_reduced(recv.download(xmpi.NUMPY_DTYPE[dtype], count), ins, dtype, op, True,
+                          f"LL agent {'allreduce' if root is None else 'reduce'} {xmpi.DTYPE_NAME[dtype]} n={count} op={op}")
+        send.free()
+        recv.free()
+
+    k = 0
+    for dtype in (xmpi.F32, xmpi.I64, xmpi.F16, xmpi.F64, xmpi.I32, xmpi.U8, xmpi.BF16):
+        for op in (xmpi.SUM, xmpi.PROD, xmpi.MIN, xmpi.MAX):
+            k += 1
+            reduce_once(dtype, (1, 7, 129, ab // xmpi.DTYPE_SIZE[dtype])[k % 4], op, xmpi.PAT_SIGNED, 3000 + 20 * k)
+    reduce_once(xmpi.F32, ab // 4 + 1, xmpi.SUM, xmpi.PAT_UNIFORM, 4000, expect_agent=False)  # above the limit: launched
+    comm.set_param("agent_ll_bytes", maxb)
+    for count in (maxb // 8, maxb // 8 - 1, 257, 256):  # sixteen lines per lane; a ragged last round
+        reduce_once(xmpi.I64, count, xmpi.SUM, xmpi.PAT_UNIFORM, 4100 + count)
+    reduce_once(xmpi.U8, maxb - 3, xmpi.MAX, xmpi.PAT_UNIFORM, 4200)
+    for root in range(size):
+        reduce_once(xmpi.F32, 1001, xmpi.SUM, xmpi.PAT_SIGNED, 4300 + root, root=root)
+        time.sleep(0.002 if root == rank else 0)  # one rank late, the others' agents wait in the collective; every agent's patience over
+        n = 777
+        b = comm.alloc(n * 8)
+        comm.fill(b, n, xmpi.I64, xmpi.PAT_UNIFORM, 4400 + 10 * root + rank)
+        comm.sync()
+        g0 = served()
+        comm.bcast(b, n, xmpi.I64, root, L)
+        assert served() == g0 + 1
+        assert b.download(np.int64, n).tobytes() == oracle.fill(n, xmpi.I64, xmpi.PAT_UNIFORM, 4400 + 10 * root + root).tobytes(), "LL agent bcast"
+        out = comm.alloc(n * 8 * size)
+        comm.sync()
+        comm.allgather(b, out, n, xmpi.I64, L)  # (every rank holds the root's block now)
+        assert served() == g0 + 2
+        assert out.download(np.int64, n * size).tobytes() == np.tile(oracle.fill(n, xmpi.I64, xmpi.PAT_UNIFORM, 4400 + 10 * root + root), size).tobytes(), "LL agent allgather"
+        b.free()
+        out.free()
+    # host slices: in through pinned memory the agent reads itself, out the same way
+    for count in (1, 1000):
+        x = oracle.fill(count, xmpi.F32, xmpi.PAT_SIGNED, 50 + rank)
+        out = np.zeros_like(x)
+        g0 = served()
+        comm.allreduce(x, out, count, xmpi.F32, xmpi.SUM, L)
+        want = oracle.reduce_ranks([oracle.fill(count, xmpi.F32, xmpi.PAT_SIGNED, 50 + r) for r in range(size)], xmpi.F32, 0)
+        assert out.tobytes() == want.tobytes(), f"LL agent allreduce of host slices n={count}"
+        assert served() == g0 + 1
+    # blocking calls between enqueued ones, no host wait in between: whoever runs a collective, they run one at a time and in order
+    st = comm.stream_create()
+    m = 500
+    a, b2 = comm.alloc(m * 8), comm.alloc(m * 8)
+    comm.fill(a, m, xmpi.I64, xmpi.PAT_CONST, 0)  # all ones
+    comm.sync()
+    reps = 8
+    for i in range(reps):
+        comm.allreduce_on_stream(a, b2, m, xmpi.I64, xmpi.SUM, st)  # enqueued: b2 = size * a
+        comm.stream_sync(st) if i % 2 else None
+        comm.allreduce(b2, a, m, xmpi.I64, xmpi.SUM, L)             # blocking (the agent when st is idle, a launch behind it otherwise)
+    comm.stream_sync(st)
+    with np.errstate(over="ignore"):
+        want = np.uint64(size) ** np.uint64(2 * reps)
+    assert np.all(a.download(np.int64, m).view(np.uint64) == want), "LL agent between enqueued collectives"
+    a.free()
+    b2.free()
+    # back to back with nothing in between: the agent is told that the epoch is its last one plus one and does not read the page;
+    # a launched kernel in between moves the epoch under it -- the next call says so (the host knows what it called last)
+    m = 300
+    a, b2 = comm.alloc(m * 8), comm.alloc(m * 8)
+    comm.fill(a, m, xmpi.I64, xmpi.PAT_CONST, 0)  # all ones
+    comm.sync()
+    g0 = served()
+    for i in range(10):
+        comm.allreduce(a, b2, m, xmpi.I64, xmpi.SUM, L)
+        comm.allreduce(b2, a, m, xmpi.I64, xmpi.SUM, L)
+    assert served() == g0 + 20, "back-to-back blocking collectives: all by the agent"
+    comm.allreduce_on_stream(a, b2, m, xmpi.I64, xmpi.SUM, st)  # launched: size^21
+    comm.stream_sync(st)
+    comm.allreduce(b2, a, m, xmpi.I64, xmpi.SUM, L)              # the agent, told to read the epoch: size^22
+    comm.allreduce(a, b2, m, xmpi.I64, xmpi.SUM, L)              # ... and to count again: size^23
+    comm.bcast(b2, m, xmpi.I64, size - 1, L)
+    comm.allreduce(b2, a, m, xmpi.I64, xmpi.SUM, L)              # size^24
+    with np.errstate(over="ignore"):
+        want = np.uint64(size) ** np.uint64(24)
+    assert np.all(a.download(np.int64, m).view(np.uint64) == want), "LL agent: epochs counted by the agent, a launched kernel in between"
+    a.free()
+    b2.free()
+    comm.stream_destroy(st)
+    # the switch
+    comm.set_param("agent_ll", 0)
+    reduce_once(xmpi.F32, 100, xmpi.SUM, xmpi.PAT_UNIFORM, 4500, expect_agent=False)
+    comm.set_param("agent_ll", 1)
+    comm.set_param("agent_ll_bytes", ab)
+    reduce_once(xmpi.F32, 100, xmpi.SUM, xmpi.PAT_UNIFORM, 4600)
+
+
 def sc_ll(comm, args):
     """The LL small collectives (ll.hip): {data, flag} lines pushed into the peers' flag allocations, local rank-order fold --
     every dtype and operator up to the slot limit, ragged tails, odd alignments, in place, every root; long runs of
@@ -1255,6 +1372,7 @@ def sc_ll(comm, args):
         reduce_case(comm, xmpi.I64, 1, root, L, pat=xmpi.PAT_UNIFORM)
         reduce_case(comm, xmpi.F16, 5001, root, L, op=xmpi.MAX)
         reduce_case(comm, xmpi.BF16, 333, root, L, op=xmpi.PROD)
+    _ll_agent_section(comm, maxb)
     # -- many broadcasts from one root, enqueued back to back, while one rank after the other dawdles: a root that ran more
     #    than one epoch ahead of a reader would overwrite a slot under it (the `here` words are what stops it)
     st = comm.stream_create()
