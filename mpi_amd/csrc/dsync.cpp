@@ -162,7 +162,11 @@ int dsync_connect(xmpi_comm* c) {
   // GPU it runs on to itself, as on a node with one rank per GPU): 4.9 / 6.1 / 6.4 us enqueued at 1 / 4 / 16 KiB against
   // 8.9 / 8.8 / 9.4 for the fold; eight processes time-slicing ONE GPU: 45 / 56 / 65 against 47 / 47 / 42 (their polling lanes
   // compete with each other's stores for the one memory system) -- so ranks that share a GPU keep LL to 1 KiB.
-  if (c->ll_bytes < 0) c->ll_bytes = c->dsync_sharers > 2 ? 1024 : 8192;
+  // With the LL agent (ll.hip ll_agent_kernel) a BLOCKING call of up to 4 KiB needs no launch at all: eight processes on one GPU,
+  // blocking allreduce 7.9 / 9.2 us at 1 / 4 KiB against 38 / 45 launched (no kernel, so nothing for eight processes' queues to be
+  // time-sliced over) -- worth the 12 % an ENQUEUED 4 KiB LL collective loses to the fold there.  (The choice must not depend on
+  // how a rank calls -- a blocking rank and an enqueueing one have to run the same protocol -- so it is one limit for both.)
+  if (c->ll_bytes < 0) c->ll_bytes = c->dsync_sharers > 2 ? ((c->agent_ll && c->p2p_agent_us > 0) ? 4096 : 1024) : 8192;
   c->ll_bytes = std::min<long>(c->ll_bytes, (long)kLLMaxPayload);
   // epochs of this communicator: above whatever earlier communicators left in ANY rank's (pooled, uncleared) page;
   // the same number on every rank.  It also tags the translations this communicator's kernels cache in the page.

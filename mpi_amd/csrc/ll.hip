@@ -39,19 +39,43 @@ __device__ __forceinline__ void ll_store(char* line, uint64_t data, uint32_t fla
   st_sys64(reinterpret_cast<uint64_t*>(line) + 1, (data >> 32) | ((uint64_t)flag << 32));
 }
 
-// `valid` (1..8) bytes of this rank's own buffer, the rest zero
+// `valid` (1..8) bytes of this rank's own buffer, the rest zero.  SYS: past the caches, both ways (system-scope loads, stores
+// written through) -- for the agent, which lingers across calls: its CU's L1 and its XCD's L2 may hold the send buffer as it was a
+// call ago, and what it stores must be in memory before it answers.  A launched kernel has its boundaries for that; the agent
+// would need an L2 invalidate before and a write-back after every call (fences at system scope: about a microsecond each).
+// (tests/devsim: plain accesses either way -- under its sanitizer the buffers' bytes must stay DATA, so that a reader no chain of
+// flag words has ordered behind the agent's stores is a reported race; what a cache holds is not modelled there.)
+#ifdef XMPI_DEVSIM
+#define XMPI_LL_SYS(SYS) false
+#else
+#define XMPI_LL_SYS(SYS) SYS
+#endif
+template <bool SYS>
 __device__ __forceinline__ uint64_t load8(const char* p, uint32_t valid) {
-  if (valid == 8 && (reinterpret_cast<uintptr_t>(p) & 7u) == 0) return *reinterpret_cast<const uint64_t*>(p);
+  if (valid == 8 && (reinterpret_cast<uintptr_t>(p) & 7u) == 0) {
+    if constexpr (XMPI_LL_SYS(SYS)) return ld_sys64(reinterpret_cast<const uint64_t*>(p));
+    else return *reinterpret_cast<const uint64_t*>(p);
+  }
   uint64_t v = 0;
-  for (uint32_t i = 0; i < valid; i++) v |= (uint64_t)(uint8_t)p[i] << (8 * i);
+  for (uint32_t i = 0; i < valid; i++) {
+    uint8_t b;
+    if constexpr (XMPI_LL_SYS(SYS)) b = __hip_atomic_load(reinterpret_cast<const uint8_t*>(p) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else b = (uint8_t)p[i];
+    v |= (uint64_t)b << (8 * i);
+  }
   return v;
 }
+template <bool SYS>
 __device__ __forceinline__ void store8(char* p, uint64_t v, uint32_t valid) {
   if (valid == 8 && (reinterpret_cast<uintptr_t>(p) & 7u) == 0) {
-    *reinterpret_cast<uint64_t*>(p) = v;
+    if constexpr (XMPI_LL_SYS(SYS)) st_sys64(reinterpret_cast<uint64_t*>(p), v);
+    else *reinterpret_cast<uint64_t*>(p) = v;
     return;
   }
-  for (uint32_t i = 0; i < valid; i++) p[i] = (char)(v >> (8 * i));
+  for (uint32_t i = 0; i < valid; i++) {
+    if constexpr (XMPI_LL_SYS(SYS)) __hip_atomic_store(reinterpret_cast<uint8_t*>(p) + i, (uint8_t)(v >> (8 * i)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else p[i] = (char)(v >> (8 * i));
+  }
 }
 
 template <typename T, int OP>
@@ -193,11 +217,12 @@ __device__ __forceinline__ bool ll_gather(const DsyncLLArgs& a, LLShared& sh, ui
 // halves: a line's own bytes are read again (in place works: a line is overwritten by its own collect only).
 
 // allreduce / reduce
+template <bool SYS>
 __device__ __forceinline__ void ll_reduce_push(const DsyncLLArgs& a, const LLCall& q, uint32_t parity, uint32_t flag, size_t idx) {
   const int me = a.me, n = a.n;
   if (q.coll != LL_ALLREDUCE && me == q.root) return;
   const uint32_t valid = q.bytes - idx * 8 >= 8 ? 8u : (uint32_t)(q.bytes - idx * 8);
-  const uint64_t mine8 = load8(reinterpret_cast<const char*>(q.send) + idx * 8, valid);
+  const uint64_t mine8 = load8<SYS>(reinterpret_cast<const char*>(q.send) + idx * 8, valid);
   if (q.coll == LL_ALLREDUCE) {
 #pragma unroll
     for (int d = 1; d < kDsyncRanks; d++) {  // (start with the next rank: the ranks do not all hit rank 0's page first)
@@ -209,33 +234,35 @@ __device__ __forceinline__ void ll_reduce_push(const DsyncLLArgs& a, const LLCal
   }
 }
 // ... gather, fold in rank order, store
-template <typename F>
+template <bool SYS, typename F>
 __device__ __forceinline__ void ll_reduce_collect(const DsyncLLArgs& a, const LLCall& q, LLShared& sh, uint32_t parity, uint32_t flag,
                                                   size_t idx, F fold) {
   const int me = a.me, n = a.n;
   if (q.coll != LL_ALLREDUCE && me != q.root) return;
   const uint32_t valid = q.bytes - idx * 8 >= 8 ? 8u : (uint32_t)(q.bytes - idx * 8);
-  const uint64_t mine8 = load8(reinterpret_cast<const char*>(q.send) + idx * 8, valid);
+  const uint64_t mine8 = load8<SYS>(reinterpret_cast<const char*>(q.send) + idx * 8, valid);
   uint64_t x[kDsyncRanks];
   const uint32_t everyone = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
   if (ll_gather(a, sh, everyone & ~(1u << me), parity, flag, idx, x))
-    store8(reinterpret_cast<char*>(q.recv) + idx * 8, fold(x, mine8, me, n), valid);
+    store8<SYS>(reinterpret_cast<char*>(q.recv) + idx * 8, fold(x, mine8, me, n), valid);
 }
 
 // broadcast / allgather: bytes only
+template <bool SYS>
 __device__ __forceinline__ void ll_copy_push(const DsyncLLArgs& a, const LLCall& q, uint32_t parity, uint32_t flag, size_t idx) {
   const int me = a.me, n = a.n;
   const bool gather = q.coll == LL_ALLGATHER;
   if (!gather && me != q.root) return;
   const uint32_t valid = q.bytes - idx * 8 >= 8 ? 8u : (uint32_t)(q.bytes - idx * 8);
-  const uint64_t mine8 = load8(reinterpret_cast<const char*>(q.send) + idx * 8, valid);
+  const uint64_t mine8 = load8<SYS>(reinterpret_cast<const char*>(q.send) + idx * 8, valid);
 #pragma unroll
   for (int d = 1; d < kDsyncRanks; d++) {
     const int p = (me + d) % n;
     if (d < n) ll_store(ll_slot(a.page[p], me, parity) + idx * 16, mine8, flag);
   }
-  if (gather) store8(reinterpret_cast<char*>(q.recv) + (size_t)me * q.bytes + idx * 8, mine8, valid);
+  if (gather) store8<SYS>(reinterpret_cast<char*>(q.recv) + (size_t)me * q.bytes + idx * 8, mine8, valid);
 }
+template <bool SYS>
 __device__ __forceinline__ void ll_copy_collect(const DsyncLLArgs& a, const LLCall& q, LLShared& sh, uint32_t parity, uint32_t flag,
                                                 size_t idx) {
   const int me = a.me, n = a.n;
@@ -246,7 +273,7 @@ __device__ __forceinline__ void ll_copy_collect(const DsyncLLArgs& a, const LLCa
     if (ll_gather(a, sh, everyone & ~(1u << me), parity, flag, idx, x)) {
 #pragma unroll
       for (int p = 0; p < kDsyncRanks; p++)
-        if (p < n && p != me) store8(reinterpret_cast<char*>(q.recv) + (size_t)p * q.bytes + idx * 8, x[p], valid);
+        if (p < n && p != me) store8<SYS>(reinterpret_cast<char*>(q.recv) + (size_t)p * q.bytes + idx * 8, x[p], valid);
     }
   } else if (me != q.root) {
     if (ll_gather(a, sh, 1u << q.root, parity, flag, idx, x)) {
@@ -254,7 +281,7 @@ __device__ __forceinline__ void ll_copy_collect(const DsyncLLArgs& a, const LLCa
 #pragma unroll
       for (int p = 0; p < kDsyncRanks; p++)
         if (p == q.root) got = x[p];
-      store8(reinterpret_cast<char*>(q.recv) + idx * 8, got, valid);
+      store8<SYS>(reinterpret_cast<char*>(q.recv) + idx * 8, got, valid);
     }
   }
 }
@@ -293,8 +320,8 @@ __global__ __launch_bounds__(kBlock) void ll_reduce_kernel(DsyncLLArgs a) {
   if (!to_all) ll_say_here(a, epoch);
   const size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (idx * 8 < a.bytes) {
-    ll_reduce_push(a, q, parity, flag, idx);
-    ll_reduce_collect(a, q, sh, parity, flag, idx, LLFoldStatic<T, OP>{});
+    ll_reduce_push<false>(a, q, parity, flag, idx);
+    ll_reduce_collect<false>(a, q, sh, parity, flag, idx, LLFoldStatic<T, OP>{});
   }
   if (!to_all) ll_wait_here(a, sh);
   ll_end(a, sh);
@@ -311,8 +338,8 @@ __global__ __launch_bounds__(kBlock) void ll_copy_kernel(DsyncLLArgs a) {
   if (!gather) ll_say_here(a, epoch);
   const size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (idx * 8 < a.bytes) {
-    ll_copy_push(a, q, parity, flag, idx);
-    ll_copy_collect(a, q, sh, parity, flag, idx);
+    ll_copy_push<false>(a, q, parity, flag, idx);
+    ll_copy_collect<false>(a, q, sh, parity, flag, idx);
   }
   if (!gather) ll_wait_here(a, sh);
   ll_end(a, sh);
@@ -382,7 +409,7 @@ __global__ __launch_bounds__(kLLAgentBlock) void ll_agent_kernel(LLAgentArgs a) 
       sh.fail = DSYNC_OK;
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // this call's send buffer as its owner left it, not a line of the call before
+    // (no fence here and none at the end: this call's buffers are read and written past the caches -- load8 / store8 <true>)
     const uint32_t meta = s_meta;
     const LLCall q{reinterpret_cast<const void*>(s_send), reinterpret_cast<void*>(s_recv), s_bytes, (int32_t)(meta & 3u),
                    (int32_t)((meta >> kAgentLLRootShift) & 7u)};
@@ -392,18 +419,17 @@ __global__ __launch_bounds__(kLLAgentBlock) void ll_agent_kernel(LLAgentArgs a) 
     const bool to_all = q.coll == LL_ALLREDUCE || q.coll == LL_ALLGATHER;
     if (!to_all) ll_say_here(a.ll, epoch);
     if (q.coll == LL_ALLREDUCE || q.coll == LL_REDUCE) {  // every line of this lane goes out before the first is waited for
-      for (size_t idx = (size_t)t; idx * 8 < q.bytes; idx += kLLAgentBlock) ll_reduce_push(a.ll, q, parity, flag, idx);
-      for (size_t idx = (size_t)t; idx * 8 < q.bytes; idx += kLLAgentBlock) ll_reduce_collect(a.ll, q, sh, parity, flag, idx, fold);
+      for (size_t idx = (size_t)t; idx * 8 < q.bytes; idx += kLLAgentBlock) ll_reduce_push<true>(a.ll, q, parity, flag, idx);
+      for (size_t idx = (size_t)t; idx * 8 < q.bytes; idx += kLLAgentBlock) ll_reduce_collect<true>(a.ll, q, sh, parity, flag, idx, fold);
     } else {
-      for (size_t idx = (size_t)t; idx * 8 < q.bytes; idx += kLLAgentBlock) ll_copy_push(a.ll, q, parity, flag, idx);
-      for (size_t idx = (size_t)t; idx * 8 < q.bytes; idx += kLLAgentBlock) ll_copy_collect(a.ll, q, sh, parity, flag, idx);
+      for (size_t idx = (size_t)t; idx * 8 < q.bytes; idx += kLLAgentBlock) ll_copy_push<true>(a.ll, q, parity, flag, idx);
+      for (size_t idx = (size_t)t; idx * 8 < q.bytes; idx += kLLAgentBlock) ll_copy_collect<true>(a.ll, q, sh, parity, flag, idx);
     }
     if (!to_all) ll_wait_here(a.ll, sh);
     XMPI_DRAIN();
     __syncthreads();
     if (t == 0) {  // what ll_end does for a launched kernel of one block; the answer goes where the host polls: cmd[6]
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // (system scope: the result may lie in pinned host memory, or be copied out by DMA)
-      st_sys64(&a.ll.page[a.ll.me]->epoch_now, epoch);
+      st_sys64(&a.ll.page[a.ll.me]->epoch_now, epoch);  // (every lane's written-through stores were acknowledged before the barrier above)
       if (a.ll.host_epoch) st_sys64(a.ll.host_epoch, epoch);
       if (sh.fail != DSYNC_OK && a.ll.status) __hip_atomic_store(a.ll.status, sh.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_store(&a.cmd[6], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
