@@ -897,6 +897,13 @@ def main():
             line["value_production_exact"] = rp.get("exact")
     if job.mp_sweep is not None:
         extras_out["extras"]["multiprocess_sweep"] = job.mp_sweep
+        try:  # the compact line carries the small end: what one BLOCKING allreduce of 1 KiB costs a caller (every call of the
+            # reference's API blocks, mpi.go:47-48), one process per rank, and how many of them the lingering LL agent ran
+            r1k = job.mp_sweep["rows"][0]
+            line["small_allreduce_us"] = {"bytes": r1k["bytes"], "ranks": job.mp_sweep["ranks"], "blocking": round(r1k["blocking_us"], 1),
+                                          "enqueued": round(r1k["queued_us"], 1), "by_ll_agent": r1k.get("by_agent")}
+        except (KeyError, IndexError, TypeError):
+            pass
     if job.cfg3 is not None:
         extras_out["extras"]["cfg3_allgather_i64_16MiB_4ranks_one_process_per_rank"] = job.cfg3
     if job.cfg5 is not None:

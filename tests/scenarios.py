@@ -1313,6 +1313,11 @@ def _ll_agent_section(comm, maxb):
     a.free()
     b2.free()
     comm.stream_destroy(st)
+    # who runs a rank's lines is that rank's business: the odd ranks launch, the even ranks' agents serve -- one protocol
+    comm.set_param("agent_ll", 1 - rank % 2)
+    for i in range(4):
+        reduce_once(xmpi.I64, (1, 64, 500, 512)[i], xmpi.SUM, xmpi.PAT_UNIFORM, 4700 + 10 * i, expect_agent=rank % 2 == 0)
+        reduce_once(xmpi.F32, 300, xmpi.MAX, xmpi.PAT_SIGNED, 4750 + 10 * i, root=i % size, expect_agent=rank % 2 == 0)
     # the switch
     comm.set_param("agent_ll", 0)
     reduce_once(xmpi.F32, 100, xmpi.SUM, xmpi.PAT_UNIFORM, 4500, expect_agent=False)
@@ -1631,6 +1636,8 @@ def sc_soak(comm, args):
             comm.set_param("dsync_split_bytes", rng.choice([0, 1, 65536, 4 << 20]))
             comm.set_param("body_sys", rng.choice([0, 0, 1]))
             comm.set_param("ll_bytes", rng.choice([0, 1024, 8192, 32768]))
+            comm.set_param("agent_ll", rng.choice([1, 1, 0]))  # blocking LL collectives: by the lingering agent, or launched
+            comm.set_param("agent_ll_bytes", rng.choice([1024, 4096, 32768]))
             comm.set_param("dsync_unroll", rng.choice([1, 2]))
             continue
         if kind == "allreduce":
