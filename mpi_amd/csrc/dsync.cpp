@@ -560,8 +560,9 @@ static int dsync_ll(xmpi_comm* c, int coll, int root, const void* sendbuf, void*
   if (!reads) send = recv;
   const int ll_coll = coll == COLL_ALLREDUCE ? LL_ALLREDUCE : coll == COLL_REDUCE ? LL_REDUCE : coll == COLL_BCAST ? LL_BCAST : LL_ALLGATHER;
   // A blocking call -- the only kind the reference's API has (mpi.go:47-48) -- is launch + kernel + completion word, and the
-  // launch is half of it.  The agent that lingers behind Receives (sched.hip p2p_agent_kernel) runs the same lines without
-  // one: the command goes through pinned memory, the answer comes back the same way.  Only when the stream the call would have
+  // launch is half of it.  The LL agent (ll.hip ll_agent_kernel: a one-block kernel that lingers behind the previous blocking small
+  // collective, as the receive agent does behind a Receive) runs the same lines without one: the command goes through pinned
+  // memory, the answer comes back the same way.  Only when the stream the call would have
   // been enqueued on is idle and nothing this communicator enqueued elsewhere is still running (the agent cannot wait for a
   // stream; the launched kernel is ordered behind both), nothing is being profiled per dispatch, and no stand-in needs a copy
   // on the stream first.

@@ -20,6 +20,10 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_n1 
 XMPI_BASEPORT=7100 timeout 200 $PROD auto fused split ring rhd > $O/prod_8proc_256MiB.json 2> $O/prod.err
 XMPI_BASEPORT=7150 timeout 200 $BIN/xmpirun 8 $BIN/allreduce_bench 1048576 200 10 auto ring rhd > $O/prod_8proc_1MiB.json 2>> $O/prod.err
 XMPI_BASEPORT=7200 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_prod_ring -- $PROD ring > $O/prod_ring_under_rocprof.json 2> $O/stats_prod_ring.err
+# the LL agent under the profiler: a handful of ll_agent_kernel launches serve the blocking small collectives, the enqueued ones are ll_reduce_kernel launches
+XMPI_BASEPORT=7250 XMPI_LL_BYTES=32768 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_agent -- $BIN/xmpirun 2 $BIN/coll_sweep 65536 300 > $O/coll_sweep_2proc_under_rocprof.json 2> $O/stats_agent.err
+XMPI_BASEPORT=7300 timeout 200 $BIN/xmpirun 2 $BIN/coll_sweep 1048576 300 > $O/coll_sweep_2proc.json 2>> $O/prod.err
+XMPI_BASEPORT=7350 timeout 200 $BIN/xmpirun 8 $BIN/coll_sweep 1048576 300 > $O/coll_sweep_8proc.json 2>> $O/prod.err
 cd $GRAFT_REPO_ROOT
 find $O -name "*.csv" ! -name "*kernel_stats.csv" -delete; find $O -name "*.db" -delete
 cut -c1-400 $O/bench_n1.json; echo; cut -c1-600 $O/prod_8proc_256MiB.json; echo; du -sh $O
