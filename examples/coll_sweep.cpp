@@ -62,6 +62,21 @@ int main(int argc, char** argv) {
       std::vector<float> junk(m, -1.0f);
       if (mpi::Error err = gpu->Memcpy(recv, junk.data(), m * 4)) return fail("upload", err);
     }
+    // ... and the same call on HOST slices -- what a program written against the reference passes (helloworld.go:58, bounce.go:96:
+    // Go slices): in through pinned memory the kernel reads itself, out the same way (PCIe-inclusive; never the bench's `value`)
+    double host_us = 0.0;
+    if (bytes <= ((size_t)64 << 10)) {
+      std::vector<float> hx(x.begin(), x.begin() + (long)n), hy(n);
+      for (int w = 0; w < 3; w++)
+        if (mpi::Error err = mpi::Allreduce(mpi::Slice(hx), mpi::Into(&hy))) return fail("allreduce(host slices)", err);
+      mpi::Barrier();
+      t0 = now_us();
+      for (int i = 0; i < k; i++)
+        if (mpi::Error err = mpi::Allreduce(mpi::Slice(hx), mpi::Into(&hy))) return fail("allreduce(host slices)", err);
+      host_us = (now_us() - t0) / k;
+      for (size_t i = 0; i < n; i++)
+        if (hy[i] != (float)(size * (size + 1) / 2) + (float)size * (float)(i % 7)) bad++;
+    }
     mpi::Barrier();
     t0 = now_us();
     for (int i = 0; i < k; i++)
@@ -73,11 +88,11 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < m; i++)
       if (got[i] != (float)(size * (size + 1) / 2) + (float)size * (float)(i % 7)) bad++;
     // max over ranks of both figures
-    std::vector<double> mine = {blocking_us, queued_us}, worst(2);
+    std::vector<double> mine = {blocking_us, queued_us, host_us}, worst(3);
     if (mpi::Error err = mpi::Allreduce(mpi::Slice(mine), mpi::Into(&worst), XMPI_MAX)) return fail("allreduce(max)", err);
     char row[384];
-    snprintf(row, sizeof row, "%s{\"bytes\": %zu, \"blocking_us\": %.2f, \"queued_us\": %.2f, \"queued_busbw_GBps\": %.3f, \"by_agent\": %ld, \"agent_wait_us\": %.2f}",
-             rows.empty() ? "" : ", ", bytes, worst[0], worst[1], (double)bytes / worst[1] / 1e3 * 2.0 * (size - 1) / size, ag, agent_wait_us);
+    snprintf(row, sizeof row, "%s{\"bytes\": %zu, \"blocking_us\": %.2f, \"queued_us\": %.2f, \"queued_busbw_GBps\": %.3f, \"by_agent\": %ld, \"agent_wait_us\": %.2f, \"host_slices_blocking_us\": %.2f}",
+             rows.empty() ? "" : ", ", bytes, worst[0], worst[1], (double)bytes / worst[1] / 1e3 * 2.0 * (size - 1) / size, ag, agent_wait_us, worst[2]);
     rows += row;
   }
   mpi::Barrier();

@@ -69,7 +69,7 @@ typedef enum {
                            longer messages, or ranks that meet on the host: the same as ZCOPY / AUTO.
                            A BLOCKING call of up to agent_ll_bytes (4 KiB; XMPI_AGENT_LL_BYTES) that finds its
                            stream idle is not even launched: a one-block kernel that lingers behind the one
-                           before (XMPI_P2P_AGENT_US) takes it from a command record in pinned memory
+                           before (XMPI_LL_AGENT_US, default 40) takes it from a command record in pinned memory
                            (XMPI_AGENT_LL=0: always launch) -- every call of the reference's API is blocking,
                            mpi.go:47-48                                                                      */
   XMPI_ALGO_COUNT = 8

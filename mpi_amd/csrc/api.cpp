@@ -715,6 +715,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   (void)hipGetLastError();
   c->p2p_kernel_ack = env_long("XMPI_P2P_KERNEL_ACK", 1) ? 1 : 0;
   c->p2p_agent_us = std::max<long>(0, env_long("XMPI_P2P_AGENT_US", 40));
+  c->ll_agent_us = std::max<long>(0, env_long("XMPI_LL_AGENT_US", c->p2p_agent_us));
   c->p2p_grid_cap = std::max<long>(0, std::min<long>(env_long("XMPI_P2P_GRID_CAP", 0), 4096));
   if (hipHostMalloc((void**)&c->p2p_cmd, 128, hipHostMallocMapped) == hipSuccess) {  // (two records: the receive agent's, the LL agent's)
     memset(c->p2p_cmd, 0, 128);
@@ -1479,6 +1480,7 @@ int xmpi_set_param(xmpi_comm* c, const char* name, long value) {
   else if (n == "p2p_grid_cap") c->p2p_grid_cap = std::max<long>(0, std::min<long>(value, 4096));
   else if (n == "ll_bytes") c->ll_bytes = std::max<long>(0, std::min<long>((long)kLLMaxPayload, value));  // untuned AUTO: LL lines up to here
   else if (n == "agent_ll") c->agent_ll = value ? 1 : 0;  // blocking LL collectives by the lingering agent (no launch)
+  else if (n == "ll_agent_us") c->ll_agent_us = std::max<long>(0, value);
   else if (n == "agent_ll_bytes") c->agent_ll_bytes = std::max<long>(0, std::min<long>((long)kLLMaxPayload, value));
   else if (n == "dsync_split_bytes") c->dsync_split_bytes = std::max<long>(0, value);  // 0: always one kernel
   else if (n == "xcd_check") c->xcd_check = value ? 1 : 0;
@@ -1533,6 +1535,7 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
   if (n == "dsync_ll_launches") return (long)c->dsync_ll_launches;
   if (n == "agent_ll") return c->agent_ll;
   if (n == "agent_ll_bytes") return c->agent_ll_bytes;
+  if (n == "ll_agent_us") return c->ll_agent_us;
   if (n == "dsync_ll_agent") return (long)c->dsync_ll_agent;
   if (n == "ll_agent_launches") return (long)c->ll_agent_launches;
   if (n == "agent_ll_wait_ns") return (long)c->agent_ll_wait_ns;  // command written -> answer seen, summed over dsync_ll_agent calls

@@ -166,7 +166,7 @@ int dsync_connect(xmpi_comm* c) {
   // blocking allreduce 7.9 / 9.2 us at 1 / 4 KiB against 38 / 45 launched (no kernel, so nothing for eight processes' queues to be
   // time-sliced over) -- worth the 12 % an ENQUEUED 4 KiB LL collective loses to the fold there.  (The choice must not depend on
   // how a rank calls -- a blocking rank and an enqueueing one have to run the same protocol -- so it is one limit for both.)
-  if (c->ll_bytes < 0) c->ll_bytes = c->dsync_sharers > 2 ? ((c->agent_ll && c->p2p_agent_us > 0) ? 4096 : 1024) : 8192;
+  if (c->ll_bytes < 0) c->ll_bytes = c->dsync_sharers > 2 ? ((c->agent_ll && c->ll_agent_us > 0) ? 4096 : 1024) : 8192;
   c->ll_bytes = std::min<long>(c->ll_bytes, (long)kLLMaxPayload);
   // epochs of this communicator: above whatever earlier communicators left in ANY rank's (pooled, uncleared) page;
   // the same number on every rank.  It also tags the translations this communicator's kernels cache in the page.

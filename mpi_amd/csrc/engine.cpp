@@ -857,7 +857,7 @@ void p2p_agent_stop(xmpi_comm* c) {
 // false: not taken (no agent, broken, job aborted) -- nothing has happened that a launched LL kernel of the same epoch would
 // not repeat line for line.
 bool agent_submit_ll(xmpi_comm* c, const void* send, void* recv, size_t bytes, int ll_coll, int root, int dtype, int op, bool consecutive) {
-  if (c->p2p_agent_us <= 0 || !c->ll_cmd_dev || !c->dsync_ok || !c->dpage || c->size < 2 || c->size > kDsyncRanks || bytes == 0 ||
+  if (c->ll_agent_us <= 0 || !c->ll_cmd_dev || !c->dsync_ok || !c->dpage || c->size < 2 || c->size > kDsyncRanks || bytes == 0 ||
       bytes > kLLMaxPayload)
     return false;
   volatile uint64_t* cmd = c->ll_cmd;
@@ -879,7 +879,7 @@ bool agent_submit_ll(xmpi_comm* c, const void* send, void* recv, size_t bytes, i
     memset(&a, 0, sizeof a);
     a.cmd = c->ll_cmd_dev;
     a.seq0 = seq;
-    a.patience_ticks = (uint64_t)c->p2p_agent_us * 100;  // wall_clock64 runs at 100 MHz
+    a.patience_ticks = (uint64_t)c->ll_agent_us * 100;  // wall_clock64 runs at 100 MHz
     for (int p = 0; p < c->size; p++) a.ll.page[p] = c->peer_page[p];
     a.ll.me = c->rank;
     a.ll.n = c->size;

@@ -1212,7 +1212,7 @@ def _ll_agent_section(comm, maxb):
     import time
     rank, size = comm.rank(), comm.size()
     L = xmpi.ALGO_LL
-    if comm.get_param("agent_ll") != 1 or comm.get_param("p2p_agent_us") <= 0:
+    if comm.get_param("agent_ll") != 1 or comm.get_param("ll_agent_us") <= 0:
         return
     ab = comm.get_param("agent_ll_bytes")
     served = lambda: comm.get_param("dsync_ll_agent")
