@@ -28,6 +28,7 @@ int main(int argc, char** argv) {
   const int rank = mpi::Rank(), size = mpi::Size();
   const size_t max_bytes = argc > 1 ? (size_t)atoll(argv[1]) : (size_t)16 << 20;
   const int iters = argc > 2 ? atoi(argv[2]) : 200;
+  const size_t factor = argc > 3 && atoi(argv[3]) >= 2 ? (size_t)atoi(argv[3]) : 4;  // sizes 1 KiB, x factor, ...
   mpi::XGMI* gpu = mpi::DefaultBackend();
   const size_t nmax = max_bytes / 4;
   float* send = (float*)gpu->Malloc(max_bytes);
@@ -40,7 +41,7 @@ int main(int argc, char** argv) {
   const bool on_device = xmpi_get_param(gpu->Handle(), "dsync") == 1;
   std::string rows;
   int bad = 0;
-  for (size_t bytes = 1024; bytes <= max_bytes; bytes *= 4) {
+  for (size_t bytes = 1024; bytes <= max_bytes; bytes *= factor) {
     const size_t n = bytes / 4;
     const int k = bytes >= ((size_t)4 << 20) ? iters / 10 + 2 : iters;
     for (int w = 0; w < 5; w++)

@@ -613,7 +613,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   c->body_sys = env_long("XMPI_BODY_SYS", -1);  // -1: decided by the XCD probe (dsync_prepare)
   c->ll_bytes = env_long("XMPI_LL_BYTES", -1);  // -1: decided when the job's layout is known (dsync_connect)
   c->agent_ll = env_long("XMPI_AGENT_LL", 1) ? 1 : 0;
-  c->agent_ll_bytes = std::max<long>(0, std::min<long>((long)kLLMaxPayload, env_long("XMPI_AGENT_LL_BYTES", 4096)));
+  c->agent_ll_bytes = std::max<long>(0, std::min<long>((long)kLLMaxPayload, env_long("XMPI_AGENT_LL_BYTES", 8192)));
   c->sched_channels = std::max<long>(0, env_long("XMPI_SCHED_CHANNELS", 0));
   c->sched_grid = std::max<long>(0, env_long("XMPI_SCHED_GRID", 0));
   c->tree_piece_bytes = std::max<long>(4096, env_long("XMPI_TREE_PIECE_BYTES", 256 << 10));

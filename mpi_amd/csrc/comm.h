@@ -178,7 +178,7 @@ struct xmpi_comm {
   long ll_bytes = 0;             // untuned AUTO: collectives up to this many bytes per rank go as LL lines (ll.hip); XMPI_LL_BYTES
   uint64_t dsync_ll_launches = 0;  // ... collectives that did
   long agent_ll = 1;             // a BLOCKING LL collective of up to agent_ll_bytes per rank is handed to the lingering LL agent
-  long agent_ll_bytes = 4096;    // (ll.hip ll_agent_kernel) instead of being launched; XMPI_AGENT_LL, XMPI_AGENT_LL_BYTES
+  long agent_ll_bytes = 8192;    // (ll.hip ll_agent_kernel) instead of being launched; XMPI_AGENT_LL, XMPI_AGENT_LL_BYTES
   long ll_agent_us = 40;         // how long that kernel lingers after a collective; XMPI_LL_AGENT_US (default: XMPI_P2P_AGENT_US's value)
   uint64_t dsync_ll_agent = 0;   // ... collectives the agent ran
   uint64_t* ll_cmd = nullptr;    // the LL agent's command record (pinned host, 8 words: the second half of p2p_cmd's allocation)

@@ -284,7 +284,7 @@ void rank_main(const std::string& key, int rank, int size, int rounds) {
         fprintf(stderr, "rank %d: the LL agent ran %ld of %ld blocking collectives\n", rank, xmpi_get_param(c, "dsync_ll_agent") - ag0, expect);
         g_bad.fetch_add(1);
       }
-      CHECK(xmpi_set_param(c, "agent_ll_bytes", 4096));
+      CHECK(xmpi_set_param(c, "agent_ll_bytes", 8192));
     }
     // ---- the stepped kernels: ring, recursive halving + doubling (any N) --------------------------------------------------------
     if (wants("sched")) {

@@ -1324,6 +1324,16 @@ def _ll_agent_section(comm, maxb):
     comm.set_param("agent_ll", 1)
     comm.set_param("agent_ll_bytes", ab)
     reduce_once(xmpi.F32, 100, xmpi.SUM, xmpi.PAT_UNIFORM, 4600)
+    # host slices: half the limit (the one block reads them across PCIe)
+    for count, by_agent in ((ab // 8, True), (ab // 8 + 1, False)):
+        x = oracle.fill(count, xmpi.F32, xmpi.PAT_SIGNED, 70 + rank)
+        out = np.zeros_like(x)
+        comm.sync()
+        g0 = served()
+        comm.allreduce(x, out, count, xmpi.F32, xmpi.SUM, L)
+        assert served() == g0 + (1 if by_agent else 0), f"host slices of {count * 4} bytes, agent_ll_bytes {ab}"
+        want = oracle.reduce_ranks([oracle.fill(count, xmpi.F32, xmpi.PAT_SIGNED, 70 + r) for r in range(size)], xmpi.F32, 0)
+        assert out.tobytes() == want.tobytes(), f"LL allreduce of host slices n={count}"
 
 
 def sc_ll(comm, args):
