@@ -862,7 +862,7 @@ bool agent_submit_ll(xmpi_comm* c, const void* send, void* recv, size_t bytes, i
     return false;
   volatile uint64_t* cmd = c->ll_cmd;
   const uint64_t seq = ++c->ll_agent_seq;
-  const uint64_t meta = (uint64_t)(ll_coll & 3) | ((uint64_t)(root & 7) << kAgentLLRootShift) |
+  const uint64_t meta = (uint64_t)(ll_coll & 3) | ((uint64_t)(root & 15) << kAgentLLRootShift) |
                         ((uint64_t)(dtype & 7) << kAgentLLDtypeShift) | ((uint64_t)(op & 3) << kAgentLLOpShift) |
                         ((uint64_t)(consecutive ? 1 : 0) << kAgentLLConsecutiveShift);
   // (the agent polls all four words while they are written and takes them only when [0] and [3] both carry this number: every

@@ -223,7 +223,7 @@ hipError_t launch_dsync_ll(const DsyncLLArgs& a, int dtype, int op, hipStream_t 
 // one without a launch.  The host writes a 32-byte command into pinned memory (as engine.cpp agent_submit does for the receive
 // agent, sched.hip p2p_agent_kernel):
 //   w0 = doorbell (1 = an LL collective, 2 = stop) | bytes per rank << 2 (22 bits) | seq << 24     w1 = send buffer
-//   w2 = receive buffer            w3 = collective (DsyncLLColl) | root << 2 | dtype << 5 | operation << 8 | consecutive << 10 | seq << 32
+//   w2 = receive buffer            w3 = collective (DsyncLLColl) | root << 2 | dtype << 6 | operation << 9 | consecutive << 11 | seq << 32
 // consecutive: no kernel of this rank has touched the page's epoch since the collective this agent ran last (the host knows: the
 // previous call into the library on this communicator was that collective) -- the epoch is the last one plus one, no load.
 // cmd[6] = number of the last command served, cmd[7] = "gone" (the number it was waiting for, plus one).
@@ -233,7 +233,8 @@ struct LLAgentArgs {
   uint64_t patience_ticks;  // wall_clock64 ticks (100 MHz) the agent waits for a command
   DsyncLLArgs ll;           // the communicator's fields: page, me, n, epoch_floor, host_epoch, abort_word, status, spin_limit
 };
-constexpr uint32_t kAgentLLRootShift = 2, kAgentLLDtypeShift = 5, kAgentLLOpShift = 8, kAgentLLConsecutiveShift = 10;
+constexpr uint32_t kAgentLLRootShift = 2, kAgentLLDtypeShift = 6, kAgentLLOpShift = 9, kAgentLLConsecutiveShift = 11;  // root: 4 bits (kDsyncRanks = 16)
+static_assert(kDsyncRanks <= 16, "an LL command names its root in four bits");
 constexpr int kLLAgentBlock = 512;  // lanes of the agent's one block: 4 KiB per rank is one line per lane
 hipError_t launch_ll_agent(const LLAgentArgs& a, hipStream_t stream);
 

@@ -92,27 +92,29 @@ __device__ __forceinline__ uint64_t combine8(uint64_t a, uint64_t b) {
   return r.u;
 }
 
-// the ranks' lines in rank order: ((x0 op x1) op x2) ... -- the host-side sum of a reference user (helloworld.go:53-81), bit for bit
-template <typename T, int OP>
-__device__ __forceinline__ uint64_t fold_ranks(const uint64_t (&x)[kDsyncRanks], uint64_t mine8, int me, int n) {
-  uint64_t acc = me == 0 ? mine8 : x[0];
+// the ranks' lines in rank order: ((x0 op x1) op x2) ... -- the host-side sum of a reference user (helloworld.go:53-81), bit for bit.
+// x(p) = rank p's line (never asked for p == me)
+template <typename T, int OP, typename X>
+__device__ __forceinline__ uint64_t fold_ranks(X x, uint64_t mine8, int me, int n) {
+  uint64_t acc = me == 0 ? mine8 : x(0);
 #pragma unroll
   for (int p = 1; p < kDsyncRanks; p++)
-    if (p < n) acc = combine8<T, OP>(acc, p == me ? mine8 : x[p]);
+    if (p < n) acc = combine8<T, OP>(acc, p == me ? mine8 : x(p));
   return acc;
 }
 // dtype and operation fixed at compile time (the launched kernels: one instantiation each) ...
 template <typename T, int OP>
 struct LLFoldStatic {
-  __device__ __forceinline__ uint64_t operator()(const uint64_t (&x)[kDsyncRanks], uint64_t mine8, int me, int n) const {
+  template <typename X>
+  __device__ __forceinline__ uint64_t operator()(X x, uint64_t mine8, int me, int n) const {
     return fold_ranks<T, OP>(x, mine8, me, n);
   }
 };
 // ... or read from the command (the agent: one kernel for everything; one uniform branch per line)
 struct LLFoldRuntime {
   int dtype, op;
-  template <typename T>
-  __device__ __forceinline__ uint64_t with(const uint64_t (&x)[kDsyncRanks], uint64_t mine8, int me, int n) const {
+  template <typename T, typename X>
+  __device__ __forceinline__ uint64_t with(X x, uint64_t mine8, int me, int n) const {
     switch (op) {
       case OP_SUM: return fold_ranks<T, OP_SUM>(x, mine8, me, n);
       case OP_PROD: return fold_ranks<T, OP_PROD>(x, mine8, me, n);
@@ -120,7 +122,8 @@ struct LLFoldRuntime {
       default: return fold_ranks<T, OP_MAX>(x, mine8, me, n);
     }
   }
-  __device__ __forceinline__ uint64_t operator()(const uint64_t (&x)[kDsyncRanks], uint64_t mine8, int me, int n) const {
+  template <typename X>
+  __device__ __forceinline__ uint64_t operator()(X x, uint64_t mine8, int me, int n) const {
     switch (dtype) {
       case DT_U8: return with<uint8_t>(x, mine8, me, n);
       case DT_I32: return with<int32_t>(x, mine8, me, n);
@@ -244,7 +247,7 @@ __device__ __forceinline__ void ll_reduce_collect(const DsyncLLArgs& a, const LL
   uint64_t x[kDsyncRanks];
   const uint32_t everyone = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
   if (ll_gather(a, sh, everyone & ~(1u << me), parity, flag, idx, x))
-    store8<SYS>(reinterpret_cast<char*>(q.recv) + idx * 8, fold(x, mine8, me, n), valid);
+    store8<SYS>(reinterpret_cast<char*>(q.recv) + idx * 8, fold([&x](int p) { return x[p]; }, mine8, me, n), valid);
 }
 
 // broadcast / allgather: bytes only
@@ -345,6 +348,147 @@ __global__ __launch_bounds__(kBlock) void ll_copy_kernel(DsyncLLArgs a) {
   ll_end(a, sh);
 }
 
+// The agent's lanes own up to kLLAgentRounds lines each (lane t: lines t, t + kLLAgentBlock, ...).  What a lane keeps between the
+// phases of a collective lives in LDS, indexed by the round: its own lines, and the peers' lines of the pair of rounds in hand.
+constexpr int kLLAgentRounds = (int)(kLLMaxPayload / 8 / kLLAgentBlock);
+static_assert((size_t)kLLAgentRounds * kLLAgentBlock * 8 == kLLMaxPayload && kLLAgentRounds % 2 == 0, "the agent's lanes cover a full slot in whole pairs of rounds");
+struct LLAgentLds {
+  uint64_t mine[kLLAgentRounds][kLLAgentBlock];  // 32 KiB
+  uint64_t got[2][kDsyncRanks - 1][kLLAgentBlock];  // 120 KiB: rank p's line at [p < me ? p : p - 1] (nobody gathers its own)
+};
+static_assert(sizeof(LLAgentLds) + 256 <= 160u * 1024, "the agent's block has one CU's LDS to itself");
+
+// ll_gather for TWO lines of a lane at once (every wait for loads past the caches costs about a microsecond, so the lines are waited
+// for in pairs); the payloads go to lds.got[0 / 1][rank, own left out][lane]
+__device__ __forceinline__ bool ll_gather2(const DsyncLLArgs& a, LLShared& sh, uint32_t want, int base, uint32_t parity, uint32_t flag,
+                                           size_t idx0, size_t idx1, bool two, LLAgentLds& lds) {
+  // (eight ranks at a time, `base` = the first: two lines of sixteen ranks in flight would be 128 registers of loads alone)
+  constexpr int G = 8;
+  static_assert(kDsyncRanks % G == 0, "rank groups");
+  DsyncPage* mine = a.page[a.me];
+  const int t = threadIdx.x;
+  pack_t v0[G], v1[G];
+#pragma unroll
+  for (int p = 0; p < G; p++) v0[p] = v1[p] = pack_t{0u, 0u, 0u, 0u};
+  uint32_t pend0 = (want >> base) & ((1u << G) - 1u), pend1 = two ? pend0 : 0u;
+  uint64_t t0 = 0;
+  for (uint32_t k = 0; pend0 | pend1; k++) {
+#pragma unroll
+    for (int p = 0; p < G; p++)
+      if (pend0 >> p & 1u) ld_sys128_issue(v0[p], reinterpret_cast<const pack_t*>(ll_slot(mine, base + p, parity) + idx0 * 16));
+#pragma unroll
+    for (int p = 0; p < G; p++)
+      if (pend1 >> p & 1u) ld_sys128_issue(v1[p], reinterpret_cast<const pack_t*>(ll_slot(mine, base + p, parity) + idx1 * 16));
+    XMPI_DRAIN();
+#pragma unroll
+    for (int p = 0; p < G; p += 4) {  // (the loads' results may be used from here on)
+      XMPI_REGS_DEFINED4(v0[p], v0[p + 1], v0[p + 2], v0[p + 3]);
+      XMPI_REGS_DEFINED4(v1[p], v1[p + 1], v1[p + 2], v1[p + 3]);
+    }
+#pragma unroll
+    for (int p = 0; p < G; p++) {
+      const int rank = base + p, at = rank < a.me ? rank : rank - 1;
+      if ((pend0 >> p & 1u) && v0[p].y == flag && v0[p].w == flag) {
+        lds.got[0][at][t] = ((uint64_t)v0[p].z << 32) | v0[p].x;
+        pend0 &= ~(1u << p);
+      }
+      if ((pend1 >> p & 1u) && v1[p].y == flag && v1[p].w == flag) {
+        lds.got[1][at][t] = ((uint64_t)v1[p].z << 32) | v1[p].x;
+        pend1 &= ~(1u << p);
+      }
+    }
+    if (!(pend0 | pend1)) break;
+    if (k == 0) t0 = wall_clock64();
+    __builtin_amdgcn_s_sleep(1);
+    if ((k & 127u) == 127u) {
+      uint32_t why = DSYNC_OK;
+      if (a.abort_word && __hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) why = DSYNC_ABORTED;
+      else if (a.spin_limit && wall_clock64() - t0 > a.spin_limit) why = DSYNC_TIMEOUT;
+      if (why != DSYNC_OK) {
+        atomicMax(&sh.fail, why);
+        return false;
+      }
+    }
+  }
+  return true;
+}
+
+__device__ __forceinline__ uint32_t ll_valid(uint64_t bytes, size_t idx) { return bytes - idx * 8 >= 8 ? 8u : (uint32_t)(bytes - idx * 8); }
+
+// One collective by the agent's one block.  Every dependent trip to memory past the caches is about a microsecond, so they are
+// overlapped: (A) ALL of the lane's own lines are loaded at once and kept, (B) all are pushed, (C) the peers' lines are waited for
+// two rounds at a time.  (One line after the other, own bytes read twice, a round more cost ~2.5 us: 8 KiB took 10.3 us, 16 KiB 16.0
+// against 12.2 launched.)
+template <typename F>
+__device__ __forceinline__ void ll_agent_collective(const DsyncLLArgs& a, LLShared& sh, const LLCall& q, uint32_t parity, uint32_t flag,
+                                                    F fold, LLAgentLds& lds) {
+  const int t = threadIdx.x, me = a.me, n = a.n;
+  const size_t nlines = (size_t)((q.bytes + 7) / 8);
+  const char* send = reinterpret_cast<const char*>(q.send);
+  char* recv = reinterpret_cast<char*>(q.recv);
+  const bool reduces = q.coll == LL_ALLREDUCE || q.coll == LL_REDUCE;
+  const bool pushes = q.coll == LL_ALLREDUCE || q.coll == LL_ALLGATHER || (q.coll == LL_REDUCE && me != q.root) || (q.coll == LL_BCAST && me == q.root);
+  const uint32_t everyone = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
+  const uint32_t want = (q.coll == LL_ALLREDUCE || q.coll == LL_ALLGATHER || (q.coll == LL_REDUCE && me == q.root)) ? (everyone & ~(1u << me))
+                        : (q.coll == LL_BCAST && me != q.root)                                                       ? (1u << q.root)
+                                                                                                                     : 0u;
+  // (A) this lane's own lines, all loads in flight together
+  if (pushes || (reduces && want)) {
+    uint64_t mine[kLLAgentRounds];
+#pragma unroll
+    for (int r = 0; r < kLLAgentRounds; r++) {
+      const size_t idx = (size_t)t + (size_t)r * kLLAgentBlock;
+      mine[r] = idx < nlines ? load8<true>(send + idx * 8, ll_valid(q.bytes, idx)) : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < kLLAgentRounds; r++) lds.mine[r][t] = mine[r];  // (read back by this lane only: no barrier)
+  }
+  // (B) out they go
+  if (pushes) {
+    for (int r = 0; r < kLLAgentRounds; r++) {
+      const size_t idx = (size_t)t + (size_t)r * kLLAgentBlock;
+      if (idx >= nlines) break;
+      const uint64_t mine8 = lds.mine[r][t];
+      if (q.coll == LL_REDUCE) {
+        ll_store(ll_slot(a.page[q.root], me, parity) + idx * 16, mine8, flag);
+      } else {
+#pragma unroll
+        for (int d = 1; d < kDsyncRanks; d++) {  // (start with the next rank: the ranks do not all hit rank 0's page first)
+          const int p = (me + d) % n;
+          if (d < n) ll_store(ll_slot(a.page[p], me, parity) + idx * 16, mine8, flag);
+        }
+      }
+      if (q.coll == LL_ALLGATHER) store8<true>(recv + (size_t)me * q.bytes + idx * 8, mine8, ll_valid(q.bytes, idx));
+    }
+  }
+  // (C) the peers' lines, two rounds per wait
+  if (!want) return;
+  for (int r = 0; r < kLLAgentRounds; r += 2) {
+    const size_t idx0 = (size_t)t + (size_t)r * kLLAgentBlock;
+    if (idx0 >= nlines) break;
+    const bool two = idx0 + kLLAgentBlock < nlines;
+    bool ok = true;
+    for (int base = 0; base < kDsyncRanks && ok; base += 8)
+      if ((want >> base) & 0xffu) ok = ll_gather2(a, sh, want, base, parity, flag, idx0, idx0 + kLLAgentBlock, two, lds);
+    if (!ok) return;
+    for (int j = 0; j < (two ? 2 : 1); j++) {
+      const size_t idx = idx0 + (size_t)j * kLLAgentBlock;
+      const uint32_t valid = ll_valid(q.bytes, idx);
+      auto x = [&lds, j, t, me](int p) { return lds.got[j][p < me ? p : p - 1][t]; };
+      if (reduces) {
+        store8<true>(recv + idx * 8, fold(x, lds.mine[r + j][t], me, n), valid);
+      } else if (q.coll == LL_ALLGATHER) {
+#pragma unroll
+        for (int p = 0; p < kDsyncRanks; p++)
+          if (p < n && p != me) store8<true>(recv + (size_t)p * q.bytes + idx * 8, x(p), valid);
+      } else {
+        const uint64_t got = x(q.root);
+        store8<true>(recv + idx * 8, got, valid);
+      }
+    }
+  }
+}
+
 // The LL AGENT.  A blocking call -- the only kind the reference's API has (mpi.go:47-48) -- is launch + kernel + completion
 // word, and the launch is about half of it (1 KiB, 2 processes: 10.9 us blocking against 4.9 us enqueued).  So the kernel that
 // served a blocking small collective does not end at once: it watches a command record in pinned host memory for `patience`
@@ -363,6 +507,7 @@ __global__ __launch_bounds__(kLLAgentBlock) void ll_agent_kernel(LLAgentArgs a) 
   XMPI_SHARED(uint64_t, s_bytes);
   XMPI_SHARED(uint32_t, s_meta);
   XMPI_SHARED(uint32_t, s_go);
+  XMPI_SHARED(LLAgentLds, s_lds);  // 152 KiB: the lanes' own lines of the call in hand, the peers' lines of two rounds
   const int t = threadIdx.x;
   uint64_t seq = a.seq0, prev_epoch = 0;  // (lane 0's: the epoch of the last collective this launch ran)
   for (;;) {
@@ -412,19 +557,13 @@ __global__ __launch_bounds__(kLLAgentBlock) void ll_agent_kernel(LLAgentArgs a) 
     // (no fence here and none at the end: this call's buffers are read and written past the caches -- load8 / store8 <true>)
     const uint32_t meta = s_meta;
     const LLCall q{reinterpret_cast<const void*>(s_send), reinterpret_cast<void*>(s_recv), s_bytes, (int32_t)(meta & 3u),
-                   (int32_t)((meta >> kAgentLLRootShift) & 7u)};
+                   (int32_t)((meta >> kAgentLLRootShift) & 15u)};
     const LLFoldRuntime fold{(int)((meta >> kAgentLLDtypeShift) & 7u), (int)((meta >> kAgentLLOpShift) & 3u)};
     const uint64_t epoch = sh.epoch;
     const uint32_t parity = (uint32_t)(epoch & 1u), flag = (uint32_t)epoch ? (uint32_t)epoch : 1u;
     const bool to_all = q.coll == LL_ALLREDUCE || q.coll == LL_ALLGATHER;
     if (!to_all) ll_say_here(a.ll, epoch);
-    if (q.coll == LL_ALLREDUCE || q.coll == LL_REDUCE) {  // every line of this lane goes out before the first is waited for
-      for (size_t idx = (size_t)t; idx * 8 < q.bytes; idx += kLLAgentBlock) ll_reduce_push<true>(a.ll, q, parity, flag, idx);
-      for (size_t idx = (size_t)t; idx * 8 < q.bytes; idx += kLLAgentBlock) ll_reduce_collect<true>(a.ll, q, sh, parity, flag, idx, fold);
-    } else {
-      for (size_t idx = (size_t)t; idx * 8 < q.bytes; idx += kLLAgentBlock) ll_copy_push<true>(a.ll, q, parity, flag, idx);
-      for (size_t idx = (size_t)t; idx * 8 < q.bytes; idx += kLLAgentBlock) ll_copy_collect<true>(a.ll, q, sh, parity, flag, idx);
-    }
+    ll_agent_collective(a.ll, sh, q, parity, flag, fold, s_lds);
     if (!to_all) ll_wait_here(a.ll, sh);
     XMPI_DRAIN();
     __syncthreads();

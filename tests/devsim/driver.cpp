@@ -523,7 +523,7 @@ int main(int argc, char** argv) {
   }
   const int size = argc > a ? atoi(argv[a]) : 2, rounds = argc > a + 1 ? atoi(argv[a + 1]) : 1;
   for (int k = a + 2; k < argc; k++) g_only.insert(argv[k]);
-  if (size < 2 || size > 8) return 2;
+  if (size < 2 || size > 16) return 2;  // (kMaxRanks)
   setenv("XMPI_CTL_SHARE_MAPPING", "1", 1);
   setenv("DEVSIM_DEVICES", g_shared ? "1" : std::to_string(size).c_str(), 1);
   setenv("XMPI_TIMEOUT_S", "120", 0);

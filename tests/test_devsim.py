@@ -116,6 +116,16 @@ def test_driver_under_perturbed_schedules(plain_bin, xcd_map, fuzz):
     assert r.returncode == 0 and "devsim driver ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
 
 
+@pytest.mark.parametrize("ranks,fuzz", [(9, 3), (12, 4), (16, 5)])
+def test_more_than_eight_ranks(plain_bin, ranks, fuzz):
+    """The library's limit is 16 ranks (kMaxRanks); every GPU box we met has one GPU and the GPU suite stops at 8.  The driver's
+    whole walk with 9 / 12 / 16 ranks, each on a virtual device of its own: the generic (not N-templated) fold, rings and halving
+    over more than eight ranks, roots above 7, the LL agent gathering its peers in two groups of eight.  (Found this way: the LL
+    agent's command named its root in three bits -- a broadcast from rank 8 came from rank 0.)"""
+    r = run(plain_bin, str(ranks), "1", DEVSIM_FUZZ=fuzz)
+    assert r.returncode == 0 and "devsim driver ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
 def test_no_collective_needs_two_of_its_blocks_resident(plain_bin):
     """DEVSIM_RESIDENT=1: the blocks of a launch run ONE AFTER THE OTHER.  Every collective kernel still completes -- its blocks wait
     for peers' blocks and for blocks before them, never for a block behind them -- so no grid cap is load-bearing for progress
