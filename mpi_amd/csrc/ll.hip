@@ -475,23 +475,16 @@ __device__ __forceinline__ void ll_agent_collective(const DsyncLLArgs& a, LLShar
       const size_t idx = idx0 + (size_t)j * kLLAgentBlock;
       const uint32_t valid = ll_valid(q.bytes, idx);
       auto x = [&lds, j, t, me](int p) { return lds.got[j][p < me ? p : p - 1][t]; };
-      if (q.coll == LL_ALLGATHER) {
+      if (reduces) {
+        store8<true>(recv + idx * 8, fold(x, lds.mine[r + j][t], me, n), valid);
+      } else if (q.coll == LL_ALLGATHER) {
 #pragma unroll
         for (int p = 0; p < kDsyncRanks; p++)
           if (p < n && p != me) store8<true>(recv + (size_t)p * q.bytes + idx * 8, x(p), valid);
-      } else {  // one result per line: kept (where the lane's own line was) until every pair is in -- see (D)
-        lds.mine[r + j][t] = reduces ? fold(x, lds.mine[r + j][t], me, n) : x(q.root);
+      } else {
+        const uint64_t got = x(q.root);
+        store8<true>(recv + idx * 8, got, valid);
       }
-    }
-  }
-  // (D) the results, all stores in flight together.  (Stored pair by pair, the wait for the next pair's loads -- s_waitcnt vmcnt(0):
-  // loads and stores share the counter on this chip -- also waited for the last pair's written-through stores to be acknowledged:
-  // 3.3 us a pair instead of one; 32 KiB 19 us.)
-  if (q.coll != LL_ALLGATHER) {
-    for (int r = 0; r < kLLAgentRounds; r++) {
-      const size_t idx = (size_t)t + (size_t)r * kLLAgentBlock;
-      if (idx >= nlines) break;
-      store8<true>(recv + idx * 8, lds.mine[r][t], ll_valid(q.bytes, idx));
     }
   }
 }
