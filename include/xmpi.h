@@ -67,7 +67,7 @@ typedef enum {
                            locally in rank order -- one one-way hop, nothing registered, announced or read
                            remotely (the reference: one message + one ack per Send, network.go:562-571);
                            longer messages, or ranks that meet on the host: the same as ZCOPY / AUTO.
-                           A BLOCKING call of up to agent_ll_bytes (8 KiB, host slices 4 KiB; XMPI_AGENT_LL_BYTES) that finds its
+                           A BLOCKING call of up to agent_ll_bytes (8 KiB; XMPI_AGENT_LL_BYTES) that finds its
                            stream idle is not even launched: a one-block kernel that lingers behind the one
                            before (XMPI_LL_AGENT_US, default 40) takes it from a command record in pinned memory
                            (XMPI_AGENT_LL=0: always launch) -- every call of the reference's API is blocking,

@@ -571,10 +571,10 @@ static int dsync_ll(xmpi_comm* c, int coll, int root, const void* sendbuf, void*
   const uint64_t calls = c->api_calls.load(std::memory_order_relaxed);
   auto idle = [](hipStream_t s) { return hipStreamQuery(s) == hipSuccess; };
   const bool consecutive = calls == c->agent_quiet_at + 1;
-  // up to agent_ll_bytes: 8 KiB is two rounds of lines per lane (10.3 us blocking against 12.2 launched, 2 processes; 16 KiB: 16.0
-  // against 12.2 -- the launched kernel's many blocks win); half of that when a buffer is a host slice in pinned memory (the one
-  // block reads it across PCIe: 8 KiB 15.4 against 14.7) -- scripts/r04_agent_limit.sh
-  const size_t agent_limit = (size_t)std::max<long>(0, c->agent_ll_bytes) / ((send != sendbuf || host_out) ? 2 : 1);
+  // up to agent_ll_bytes (8 KiB: a lane's two rounds of lines are waited for together -- blocking 8.8 us against 11.7 launched,
+  // 2 processes; host slices 10.0 against 13.8; at 16 KiB it is a tie, 12.1 / 11.7, and beyond the launched kernel's many blocks
+  // win) -- scripts/r04_agent_limit.sh
+  const size_t agent_limit = (size_t)std::max<long>(0, c->agent_ll_bytes);
   if (blocking && !capturing && lent.empty() && c->agent_ll && unit <= agent_limit && !c->prof_on &&
       (consecutive ||
        (idle(stream) && (!c->dsync_last_stream || c->dsync_last_stream == stream || idle(c->dsync_last_stream))))) {

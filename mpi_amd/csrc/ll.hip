@@ -418,7 +418,9 @@ __device__ __forceinline__ uint32_t ll_valid(uint64_t bytes, size_t idx) { retur
 // One collective by the agent's one block.  Every dependent trip to memory past the caches is about a microsecond, so they are
 // overlapped: (A) ALL of the lane's own lines are loaded at once and kept, (B) all are pushed, (C) the peers' lines are waited for
 // two rounds at a time.  (One line after the other, own bytes read twice, a round more cost ~2.5 us: 8 KiB took 10.3 us, 16 KiB 16.0
-// against 12.2 launched.)
+// against 12.2 launched; this way a PAIR of rounds more costs ~1.7 us: 8 KiB 8.8, 16 KiB 12.1.  Keeping the results back and
+// storing them all at the end -- so that no wait for loads also waits for the last pair's written-through stores -- measured
+// worse, not better: 10.3 / 14.8 on a box whose launched figures were 9 % up.)
 template <typename F>
 __device__ __forceinline__ void ll_agent_collective(const DsyncLLArgs& a, LLShared& sh, const LLCall& q, uint32_t parity, uint32_t flag,
                                                     F fold, LLAgentLds& lds) {

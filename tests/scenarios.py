@@ -1324,8 +1324,8 @@ def _ll_agent_section(comm, maxb):
     comm.set_param("agent_ll", 1)
     comm.set_param("agent_ll_bytes", ab)
     reduce_once(xmpi.F32, 100, xmpi.SUM, xmpi.PAT_UNIFORM, 4600)
-    # host slices: half the limit (the one block reads them across PCIe)
-    for count, by_agent in ((ab // 8, True), (ab // 8 + 1, False)):
+    # host slices: in and out through pinned memory, the same limit
+    for count, by_agent in ((ab // 4, True), (ab // 4 + 1, False)):
         x = oracle.fill(count, xmpi.F32, xmpi.PAT_SIGNED, 70 + rank)
         out = np.zeros_like(x)
         comm.sync()
