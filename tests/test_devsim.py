@@ -159,6 +159,10 @@ SCENARIOS = [
     ("p2p_stream", 4, None),
     ("soak", 3, None),
     ("lifecycle_stress", 2, None),
+    # more ranks than any GPU box of ours could hold (the library's limit is 16): one process per virtual device
+    ("ll", 9, {"counts": [1, 17, 1000]}),
+    ("devices", 12, None),
+    ("bcast_reduce", 11, None),
 ]
 
 
