@@ -52,6 +52,11 @@ done
 for LL in 0 32768; do
   XMPI_LL_BYTES=$LL XMPI_BASEPORT=7340 timeout 300 $BIN/xmpirun $N $BIN/coll_sweep $CS > $O/coll_sweep_n${N}_ll$LL.json 2>> $O/prod.err
 done
+# the LL agent over links: blocking small collectives launched (0) / by the lingering kernel up to its default limit (8192) / up to the
+# slot limit (32768) -- where its limit lies on a node is one of the things only a node can say
+for AG in 0 8192 32768; do
+  XMPI_LL_BYTES=32768 XMPI_AGENT_LL_BYTES=$AG XMPI_BASEPORT=7350 timeout 300 $BIN/xmpirun $N $BIN/coll_sweep 32768 ${CS##* } 2 > $O/coll_sweep_n${N}_agent$AG.json 2>> $O/prod.err
+done
 if [ "$REH" = 1 ]; then python scripts/show_bench.py $O/bench_n$N.json | head -40; exit 0; fi
 cd /tmp
 XMPI_BASEPORT=7360 timeout 300 rocprofv3 --marker-trace --kernel-trace --output-format csv -d $O/markers -- $BIN/xmpirun $N $BIN/coll_sweep ${CS%% *} 20 > $O/coll_sweep_under_marker_trace.json 2> $O/markers.err
