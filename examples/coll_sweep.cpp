@@ -28,6 +28,7 @@ int main(int argc, char** argv) {
   const int rank = mpi::Rank(), size = mpi::Size();
   const size_t max_bytes = argc > 1 ? (size_t)atoll(argv[1]) : (size_t)16 << 20;
   const int iters = argc > 2 ? atoi(argv[2]) : 200;
+  const double think_us = getenv("COLL_SWEEP_THINK_US") ? atof(getenv("COLL_SWEEP_THINK_US")) : 0.0;
   const size_t factor = argc > 3 && atoi(argv[3]) >= 2 ? (size_t)atoi(argv[3]) : 4;  // sizes 1 KiB, x factor, ...
   mpi::XGMI* gpu = mpi::DefaultBackend();
   const size_t nmax = max_bytes / 4;
@@ -48,10 +49,17 @@ int main(int argc, char** argv) {
       if (mpi::Error err = mpi::Allreduce(mpi::Span(send, n), mpi::Span(recv, n))) return fail("allreduce", err);
     mpi::Barrier();
     const long ag0 = xmpi_get_param(gpu->Handle(), "dsync_ll_agent"), wt0 = xmpi_get_param(gpu->Handle(), "agent_ll_wait_ns");
-    double t0 = now_us();
-    for (int i = 0; i < k; i++)
+    double t0 = now_us(), thought = 0.0;
+    for (int i = 0; i < k; i++) {
       if (mpi::Error err = mpi::Allreduce(mpi::Span(send, n), mpi::Span(recv, n))) return fail("allreduce", err);
-    const double blocking_us = (now_us() - t0) / k;
+      if (think_us > 0) {  // the caller's own work between two collectives (COLL_SWEEP_THINK_US): not part of the figure
+        const double w0 = now_us();
+        while (now_us() - w0 < think_us) {
+        }
+        thought += now_us() - w0;
+      }
+    }
+    const double blocking_us = (now_us() - t0 - thought) / k;
     // of which: between the command to the lingering LL agent and its answer (when it ran them: ll.hip ll_agent_kernel)
     const long ag = xmpi_get_param(gpu->Handle(), "dsync_ll_agent") - ag0;
     const double agent_wait_us = ag > 0 ? (double)(xmpi_get_param(gpu->Handle(), "agent_ll_wait_ns") - wt0) / 1e3 / (double)ag : 0.0;

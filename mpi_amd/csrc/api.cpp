@@ -612,7 +612,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   c->xcd_check = env_long("XMPI_XCD_CHECK", 1) ? 1 : 0;
   c->body_sys = env_long("XMPI_BODY_SYS", -1);  // -1: decided by the XCD probe (dsync_prepare)
   c->ll_bytes = env_long("XMPI_LL_BYTES", -1);  // -1: decided when the job's layout is known (dsync_connect)
-  c->agent_ll = env_long("XMPI_AGENT_LL", 1) ? 1 : 0;
+  c->agent_ll = std::max<long>(0, std::min<long>(env_long("XMPI_AGENT_LL", 1), 2));
   c->agent_ll_bytes = std::max<long>(0, std::min<long>((long)kLLMaxPayload, env_long("XMPI_AGENT_LL_BYTES", 8192)));
   c->sched_channels = std::max<long>(0, env_long("XMPI_SCHED_CHANNELS", 0));
   c->sched_grid = std::max<long>(0, env_long("XMPI_SCHED_GRID", 0));
@@ -1479,7 +1479,7 @@ int xmpi_set_param(xmpi_comm* c, const char* name, long value) {
   else if (n == "dsync_tiles") c->dsync_tiles = std::max<long>(1, value);
   else if (n == "p2p_grid_cap") c->p2p_grid_cap = std::max<long>(0, std::min<long>(value, 4096));
   else if (n == "ll_bytes") c->ll_bytes = std::max<long>(0, std::min<long>((long)kLLMaxPayload, value));  // untuned AUTO: LL lines up to here
-  else if (n == "agent_ll") c->agent_ll = value ? 1 : 0;  // blocking LL collectives by the lingering agent (no launch)
+  else if (n == "agent_ll") c->agent_ll = value < 0 ? 0 : std::min<long>(value, 2);  // blocking LL collectives by the lingering agent (no launch); 2: start it outside bursts too
   else if (n == "ll_agent_us") c->ll_agent_us = std::max<long>(0, value);
   else if (n == "agent_ll_bytes") c->agent_ll_bytes = std::max<long>(0, std::min<long>((long)kLLMaxPayload, value));
   else if (n == "dsync_split_bytes") c->dsync_split_bytes = std::max<long>(0, value);  // 0: always one kernel

@@ -187,6 +187,7 @@ struct xmpi_comm {
   bool ll_agent_running = false; // launched and not yet known to have gone
   hipStream_t ll_agent_stream = nullptr;
   uint64_t ll_agent_launches = 0;
+  double ll_last_blocking_s = 0; // when the last BLOCKING LL collective of this communicator returned (either way): bursts start the agent
   uint64_t agent_ll_wait_ns = 0; // diagnostics: time between writing a command and seeing its answer, summed
   std::atomic<uint64_t> api_calls{0};  // public entry points taken on this communicator (XMPI_ENTER) ...
   uint64_t agent_quiet_at = ~0ull;     // ... and its value when the agent last ran a collective: the NEXT call knows that nothing
@@ -267,7 +268,9 @@ int p2p_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int 
 int p2p_probe(xmpi_comm* c, int src, int tag, size_t* bytes, int* dtype);
 void p2p_agent_stop(xmpi_comm* c);
 // consecutive: the previous call into the library on this communicator was a collective the agent ran (its epoch + 1 is this one's)
-bool agent_submit_ll(xmpi_comm* c, const void* send, void* recv, size_t bytes, int ll_coll, int root, int dtype, int op, bool consecutive);
+// may_launch: an agent that is not there may be started for this call (the caller's calls come in a burst)
+bool agent_submit_ll(xmpi_comm* c, const void* send, void* recv, size_t bytes, int ll_coll, int root, int dtype, int op, bool consecutive,
+                     bool may_launch);
 void ll_agent_stop(xmpi_comm* c);
 // zcopy.cpp.  *done = false: some rank's buffers are not registered HBM -- every rank saw that and
 // the caller runs the staged schedule instead (no rank is left behind: the decision is collective).

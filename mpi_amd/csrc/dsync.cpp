@@ -580,8 +580,10 @@ static int dsync_ll(xmpi_comm* c, int coll, int root, const void* sendbuf, void*
        (idle(stream) && (!c->dsync_last_stream || c->dsync_last_stream == stream || idle(c->dsync_last_stream))))) {
     ++c->dsync_epoch;
     const double t_cmd = now_seconds();
-    if (agent_submit_ll(c, send, recv, unit, ll_coll, root, dtype, op, consecutive)) {
-      c->agent_ll_wait_ns += (uint64_t)((now_seconds() - t_cmd) * 1e9);
+    const bool burst = c->agent_ll >= 2 || (t_cmd - c->ll_last_blocking_s) * 1e6 < (double)c->ll_agent_us;  // (agent_ll 2: tests -- start it whatever the caller's pace)
+    if (agent_submit_ll(c, send, recv, unit, ll_coll, root, dtype, op, consecutive, burst)) {
+      c->ll_last_blocking_s = now_seconds();
+      c->agent_ll_wait_ns += (uint64_t)((c->ll_last_blocking_s - t_cmd) * 1e9);
       c->agent_quiet_at = calls;
       c->dsync_ll_launches++;  // (an LL collective, whoever ran its lines)
       c->dsync_ll_agent++;
@@ -640,6 +642,7 @@ static int dsync_ll(xmpi_comm* c, int coll, int root, const void* sendbuf, void*
   }
   rc = wait_blocking(c, stream, done_dev != nullptr, done_id);
   if (rc != XMPI_OK) return fail(rc);
+  c->ll_last_blocking_s = now_seconds();
   if (host_out) {
     memcpy(recvbuf, c->host_bounce + xmpi_comm::kHostBounce, recv_bytes);
   } else if (out_tmp) {
@@ -1095,6 +1098,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
 
   rc = wait_blocking(c, stream, done_dev != nullptr, done_id);
   if (rc != XMPI_OK) return fail(rc);
+  c->ll_last_blocking_s = now_seconds();
   if (host_out) {
     memcpy(recvbuf, c->host_bounce + xmpi_comm::kHostBounce, recv_bytes);
   } else if (out_src) {

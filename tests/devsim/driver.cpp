@@ -227,8 +227,10 @@ void rank_main(const std::string& key, int rank, int size, int rounds) {
           }
     }
     // ---- the same lines run by the lingering LL agent: blocking calls that find their stream idle ------------------------------
-    if (wants("ll") && dev && xmpi_get_param(c, "agent_ll") == 1 && xmpi_get_param(c, "ll_agent_us") > 0) {
+    if (wants("ll") && dev && xmpi_get_param(c, "agent_ll") >= 1 && xmpi_get_param(c, "ll_agent_us") > 0) {
       CHECK(xmpi_set_param(c, "agent_ll_bytes", 32768));
+      // (by default the agent is started for a burst of blocking calls only; 2: whenever it is not there, however slowly the sanitizer runs)
+      CHECK(xmpi_set_param(c, "agent_ll", 2));
       const long ag0 = xmpi_get_param(c, "dsync_ll_agent");
       long expect = 0;
       for (size_t n : {(size_t)1, (size_t)33, (size_t)257, (size_t)4096}) {
@@ -285,6 +287,7 @@ void rank_main(const std::string& key, int rank, int size, int rounds) {
         g_bad.fetch_add(1);
       }
       CHECK(xmpi_set_param(c, "agent_ll_bytes", 8192));
+      CHECK(xmpi_set_param(c, "agent_ll", 1));
     }
     // ---- the stepped kernels: ring, recursive halving + doubling (any N) --------------------------------------------------------
     if (wants("sched")) {

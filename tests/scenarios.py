@@ -1212,10 +1212,14 @@ def _ll_agent_section(comm, maxb):
     import time
     rank, size = comm.rank(), comm.size()
     L = xmpi.ALGO_LL
-    if comm.get_param("agent_ll") != 1 or comm.get_param("ll_agent_us") <= 0:
+    if comm.get_param("agent_ll") < 1 or comm.get_param("ll_agent_us") <= 0:
         return
     ab = comm.get_param("agent_ll_bytes")
     served = lambda: comm.get_param("dsync_ll_agent")
+    # The agent is started for a BURST of blocking calls only (the previous one returned less than its patience ago); a test that
+    # looks at every call's path cannot depend on how long a fill and a download take in between: agent_ll = 2 starts it whenever
+    # it is not there.  (Not a long patience instead: whatever shares the lingering kernel's hardware queue waits for it to go.)
+    comm.set_param("agent_ll", 2)
 
     def reduce_once(dtype, count, op, pattern, seed, root=None, expect_agent=True):
         es = xmpi.DTYPE_SIZE[dtype]
@@ -1314,14 +1318,14 @@ def _ll_agent_section(comm, maxb):
     b2.free()
     comm.stream_destroy(st)
     # who runs a rank's lines is that rank's business: the odd ranks launch, the even ranks' agents serve -- one protocol
-    comm.set_param("agent_ll", 1 - rank % 2)
+    comm.set_param("agent_ll", 2 * (1 - rank % 2))
     for i in range(4):
         reduce_once(xmpi.I64, (1, 64, 500, 512)[i], xmpi.SUM, xmpi.PAT_UNIFORM, 4700 + 10 * i, expect_agent=rank % 2 == 0)
         reduce_once(xmpi.F32, 300, xmpi.MAX, xmpi.PAT_SIGNED, 4750 + 10 * i, root=i % size, expect_agent=rank % 2 == 0)
     # the switch
     comm.set_param("agent_ll", 0)
     reduce_once(xmpi.F32, 100, xmpi.SUM, xmpi.PAT_UNIFORM, 4500, expect_agent=False)
-    comm.set_param("agent_ll", 1)
+    comm.set_param("agent_ll", 2)
     comm.set_param("agent_ll_bytes", ab)
     reduce_once(xmpi.F32, 100, xmpi.SUM, xmpi.PAT_UNIFORM, 4600)
     # host slices: in and out through pinned memory, the same limit
@@ -1334,6 +1338,18 @@ def _ll_agent_section(comm, maxb):
         assert served() == g0 + (1 if by_agent else 0), f"host slices of {count * 4} bytes, agent_ll_bytes {ab}"
         want = oracle.reduce_ranks([oracle.fill(count, xmpi.F32, xmpi.PAT_SIGNED, 70 + r) for r in range(size)], xmpi.F32, 0)
         assert out.tobytes() == want.tobytes(), f"LL allreduce of host slices n={count}"
+    # the burst rule itself (agent_ll = 1, the default): a call that comes later than the agent's patience after the one before is
+    # launched -- the agent has gone by then, and starting it again would cost this call more than the ordinary kernel does
+    comm.set_param("agent_ll", 1)
+    time.sleep(0.05)
+    comm.sync()
+    n0 = comm.get_param("ll_agent_launches")
+    x = oracle.fill(64, xmpi.I64, xmpi.PAT_UNIFORM, 90 + rank)
+    out = np.zeros_like(x)
+    comm.allreduce(x, out, 64, xmpi.I64, xmpi.SUM, L)
+    want = oracle.reduce_ranks([oracle.fill(64, xmpi.I64, xmpi.PAT_UNIFORM, 90 + r) for r in range(size)], xmpi.I64, 0)
+    assert out.tobytes() == want.tobytes()
+    assert comm.get_param("ll_agent_launches") == n0, "a call outside a burst started the agent"
 
 
 def sc_ll(comm, args):
@@ -1646,7 +1662,7 @@ def sc_soak(comm, args):
             comm.set_param("dsync_split_bytes", rng.choice([0, 1, 65536, 4 << 20]))
             comm.set_param("body_sys", rng.choice([0, 0, 1]))
             comm.set_param("ll_bytes", rng.choice([0, 1024, 8192, 32768]))
-            comm.set_param("agent_ll", rng.choice([1, 1, 0]))  # blocking LL collectives: by the lingering agent, or launched
+            comm.set_param("agent_ll", rng.choice([2, 1, 0]))  # blocking LL collectives: by the lingering agent (started whenever / in bursts), or launched
             comm.set_param("agent_ll_bytes", rng.choice([1024, 4096, 32768]))
             comm.set_param("dsync_unroll", rng.choice([1, 2]))
             continue
