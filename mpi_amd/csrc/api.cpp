@@ -1479,7 +1479,7 @@ int xmpi_set_param(xmpi_comm* c, const char* name, long value) {
   else if (n == "dsync_tiles") c->dsync_tiles = std::max<long>(1, value);
   else if (n == "p2p_grid_cap") c->p2p_grid_cap = std::max<long>(0, std::min<long>(value, 4096));
   else if (n == "ll_bytes") c->ll_bytes = std::max<long>(0, std::min<long>((long)kLLMaxPayload, value));  // untuned AUTO: LL lines up to here
-  else if (n == "agent_ll") c->agent_ll = value < 0 ? 0 : std::min<long>(value, 2);  // blocking LL collectives by the lingering agent (no launch); 2: start it outside bursts too
+  else if (n == "agent_ll") c->agent_ll = value < 0 ? 0 : std::min<long>(value, 2);  // blocking LL collectives by the lingering agent (no launch); (2 = 1)
   else if (n == "ll_agent_us") c->ll_agent_us = std::max<long>(0, value);
   else if (n == "agent_ll_bytes") c->agent_ll_bytes = std::max<long>(0, std::min<long>((long)kLLMaxPayload, value));
   else if (n == "dsync_split_bytes") c->dsync_split_bytes = std::max<long>(0, value);  // 0: always one kernel

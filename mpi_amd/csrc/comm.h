@@ -187,11 +187,12 @@ struct xmpi_comm {
   bool ll_agent_running = false; // launched and not yet known to have gone
   hipStream_t ll_agent_stream = nullptr;
   uint64_t ll_agent_launches = 0;
-  double ll_last_blocking_s = 0; // when the last BLOCKING LL collective of this communicator returned (either way): bursts start the agent
   uint64_t agent_ll_wait_ns = 0; // diagnostics: time between writing a command and seeing its answer, summed
   std::atomic<uint64_t> api_calls{0};  // public entry points taken on this communicator (XMPI_ENTER) ...
-  uint64_t agent_quiet_at = ~0ull;     // ... and its value when the agent last ran a collective: the NEXT call knows that nothing
-                                       // was enqueued through the library in between without asking the streams
+  uint64_t agent_quiet_at = ~0ull;     // ... and its value when a BLOCKING device-synchronised collective last returned (whoever ran it):
+                                       // the NEXT call knows that nothing was enqueued through the library in between without asking
+                                       // the streams (hipStreamQuery of a stream whose last kernel is still retiring costs ~10 us)
+  uint64_t agent_epoch_at = ~0ull;     // ... and when the AGENT last ran one: the next call's epoch is that one's plus one
   uint64_t dsync_split_launches = 0, dsync_sched_launches = 0;  // ... collectives run as meet / body / done; as a stepped kernel
   xmpi::DsyncEntry* dsync_table = nullptr;            // [kMaxRanks][kDsyncArenas], pinned host memory the kernels read
   const xmpi::DsyncEntry* dsync_table_dev = nullptr;  // ... as the GPU addresses it

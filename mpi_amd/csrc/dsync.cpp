@@ -570,21 +570,24 @@ static int dsync_ll(xmpi_comm* c, int coll, int root, const void* sendbuf, void*
   // ran: it found them idle, and nothing has been enqueued through the library since)
   const uint64_t calls = c->api_calls.load(std::memory_order_relaxed);
   auto idle = [](hipStream_t s) { return hipStreamQuery(s) == hipSuccess; };
-  const bool consecutive = calls == c->agent_quiet_at + 1;
+  const bool quiet = calls == c->agent_quiet_at + 1, consecutive = calls == c->agent_epoch_at + 1;
   // up to agent_ll_bytes (8 KiB: a lane's two rounds of lines are waited for together -- blocking 8.8 us against 11.7 launched,
   // 2 processes; host slices 10.0 against 13.8; at 16 KiB it is a tie, 12.1 / 11.7, and beyond the launched kernel's many blocks
   // win) -- scripts/r04_agent_limit.sh
   const size_t agent_limit = (size_t)std::max<long>(0, c->agent_ll_bytes);
   if (blocking && !capturing && lent.empty() && c->agent_ll && unit <= agent_limit && !c->prof_on &&
-      (consecutive ||
+      (quiet ||
        (idle(stream) && (!c->dsync_last_stream || c->dsync_last_stream == stream || idle(c->dsync_last_stream))))) {
     ++c->dsync_epoch;
     const double t_cmd = now_seconds();
-    const bool burst = c->agent_ll >= 2 || (t_cmd - c->ll_last_blocking_s) * 1e6 < (double)c->ll_agent_us;  // (agent_ll 2: tests -- start it whatever the caller's pace)
-    if (agent_submit_ll(c, send, recv, unit, ll_coll, root, dtype, op, consecutive, burst)) {
-      c->ll_last_blocking_s = now_seconds();
-      c->agent_ll_wait_ns += (uint64_t)((c->ll_last_blocking_s - t_cmd) * 1e9);
-      c->agent_quiet_at = calls;
+    // An agent that has gone is started again, whatever the caller's pace.  Tried and measured (scripts/r04_agent_patience.sh, 2
+    // processes, 1 KiB, the caller's own work between two calls 100 / 500 us, patience 40): starting it only for a BURST of calls --
+    // the previous one less than a patience ago -- and launching the ordinary kernel otherwise: 25.4 / 25.3 us per call, against
+    // 14.4 / 21.5 with the agent started by every call (a launch into a GPU that has been idle for 100 us costs more than one into a
+    // busy GPU; the agent's launch overlaps with the command already lying in its record) and 7.5 inside its patience.
+    if (agent_submit_ll(c, send, recv, unit, ll_coll, root, dtype, op, consecutive, true)) {
+      c->agent_ll_wait_ns += (uint64_t)((now_seconds() - t_cmd) * 1e9);
+      c->agent_quiet_at = c->agent_epoch_at = calls;
       c->dsync_ll_launches++;  // (an LL collective, whoever ran its lines)
       c->dsync_ll_agent++;
       if (host_out) memcpy(recvbuf, c->host_bounce + xmpi_comm::kHostBounce, recv_bytes);
@@ -642,7 +645,7 @@ static int dsync_ll(xmpi_comm* c, int coll, int root, const void* sendbuf, void*
   }
   rc = wait_blocking(c, stream, done_dev != nullptr, done_id);
   if (rc != XMPI_OK) return fail(rc);
-  c->ll_last_blocking_s = now_seconds();
+  c->agent_quiet_at = calls;  // (the kernel's last act was the word this call waited for; everything before it on the streams is over)
   if (host_out) {
     memcpy(recvbuf, c->host_bounce + xmpi_comm::kHostBounce, recv_bytes);
   } else if (out_tmp) {
@@ -1098,7 +1101,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
 
   rc = wait_blocking(c, stream, done_dev != nullptr, done_id);
   if (rc != XMPI_OK) return fail(rc);
-  c->ll_last_blocking_s = now_seconds();
+  c->agent_quiet_at = c->api_calls.load(std::memory_order_relaxed);  // (as in dsync_ll: the next blocking small collective need not ask the streams)
   if (host_out) {
     memcpy(recvbuf, c->host_bounce + xmpi_comm::kHostBounce, recv_bytes);
   } else if (out_src) {

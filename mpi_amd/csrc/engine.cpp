@@ -862,11 +862,7 @@ bool agent_submit_ll(xmpi_comm* c, const void* send, void* recv, size_t bytes, i
       bytes > kLLMaxPayload)
     return false;
   volatile uint64_t* cmd = c->ll_cmd;
-  // An agent that said it went is not launched again for a caller whose calls come further apart than its patience: the launch
-  // would be this call's anyway, and finding out that the agent has gone, launching it and waiting for its first poll costs more
-  // than the ordinary kernel (2 processes, 1 KiB, 100 / 500 us of the caller's own work between calls: 14.4 / 21.5 us against
-  // 10-11 launched -- scripts/r04_agent_patience.sh).  may_launch: the previous blocking small collective ended less than the
-  // agent's patience ago -- a burst, which is what the agent is for.
+  // (may_launch = false: an agent that has gone is not started for this call -- the caller launches the ordinary kernel)
   if (c->ll_agent_running && __atomic_load_n((const uint64_t*)&cmd[7], __ATOMIC_ACQUIRE) != 0) c->ll_agent_running = false;
   if (!c->ll_agent_running && !may_launch) return false;
   const uint64_t seq = ++c->ll_agent_seq;

@@ -229,7 +229,6 @@ void rank_main(const std::string& key, int rank, int size, int rounds) {
     // ---- the same lines run by the lingering LL agent: blocking calls that find their stream idle ------------------------------
     if (wants("ll") && dev && xmpi_get_param(c, "agent_ll") >= 1 && xmpi_get_param(c, "ll_agent_us") > 0) {
       CHECK(xmpi_set_param(c, "agent_ll_bytes", 32768));
-      // (by default the agent is started for a burst of blocking calls only; 2: whenever it is not there, however slowly the sanitizer runs)
       CHECK(xmpi_set_param(c, "agent_ll", 2));
       const long ag0 = xmpi_get_param(c, "dsync_ll_agent");
       long expect = 0;
