@@ -269,9 +269,7 @@ int p2p_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int 
 int p2p_probe(xmpi_comm* c, int src, int tag, size_t* bytes, int* dtype);
 void p2p_agent_stop(xmpi_comm* c);
 // consecutive: the previous call into the library on this communicator was a collective the agent ran (its epoch + 1 is this one's)
-// may_launch: an agent that is not there may be started for this call (the caller's calls come in a burst)
-bool agent_submit_ll(xmpi_comm* c, const void* send, void* recv, size_t bytes, int ll_coll, int root, int dtype, int op, bool consecutive,
-                     bool may_launch);
+bool agent_submit_ll(xmpi_comm* c, const void* send, void* recv, size_t bytes, int ll_coll, int root, int dtype, int op, bool consecutive);
 void ll_agent_stop(xmpi_comm* c);
 // zcopy.cpp.  *done = false: some rank's buffers are not registered HBM -- every rank saw that and
 // the caller runs the staged schedule instead (no rank is left behind: the decision is collective).

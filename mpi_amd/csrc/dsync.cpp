@@ -585,7 +585,7 @@ static int dsync_ll(xmpi_comm* c, int coll, int root, const void* sendbuf, void*
     // the previous one less than a patience ago -- and launching the ordinary kernel otherwise: 25.4 / 25.3 us per call, against
     // 14.4 / 21.5 with the agent started by every call (a launch into a GPU that has been idle for 100 us costs more than one into a
     // busy GPU; the agent's launch overlaps with the command already lying in its record) and 7.5 inside its patience.
-    if (agent_submit_ll(c, send, recv, unit, ll_coll, root, dtype, op, consecutive, true)) {
+    if (agent_submit_ll(c, send, recv, unit, ll_coll, root, dtype, op, consecutive)) {
       c->agent_ll_wait_ns += (uint64_t)((now_seconds() - t_cmd) * 1e9);
       c->agent_quiet_at = c->agent_epoch_at = calls;
       c->dsync_ll_launches++;  // (an LL collective, whoever ran its lines)

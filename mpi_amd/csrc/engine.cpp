@@ -856,15 +856,12 @@ void p2p_agent_stop(xmpi_comm* c) {
 // there is one command at a time by construction.  true: the agent ran the collective and everything it wrote is visible;
 // false: not taken (no agent, broken, job aborted) -- nothing has happened that a launched LL kernel of the same epoch would
 // not repeat line for line.
-bool agent_submit_ll(xmpi_comm* c, const void* send, void* recv, size_t bytes, int ll_coll, int root, int dtype, int op, bool consecutive,
-                     bool may_launch) {
+bool agent_submit_ll(xmpi_comm* c, const void* send, void* recv, size_t bytes, int ll_coll, int root, int dtype, int op, bool consecutive) {
   if (c->ll_agent_us <= 0 || !c->ll_cmd_dev || !c->dsync_ok || !c->dpage || c->size < 2 || c->size > kDsyncRanks || bytes == 0 ||
       bytes > kLLMaxPayload)
     return false;
   volatile uint64_t* cmd = c->ll_cmd;
-  // (may_launch = false: an agent that has gone is not started for this call -- the caller launches the ordinary kernel)
-  if (c->ll_agent_running && __atomic_load_n((const uint64_t*)&cmd[7], __ATOMIC_ACQUIRE) != 0) c->ll_agent_running = false;
-  if (!c->ll_agent_running && !may_launch) return false;
+  if (c->ll_agent_running && __atomic_load_n((const uint64_t*)&cmd[7], __ATOMIC_ACQUIRE) != 0) c->ll_agent_running = false;  // it said it went: started again below
   const uint64_t seq = ++c->ll_agent_seq;
   const uint64_t meta = (uint64_t)(ll_coll & 3) | ((uint64_t)(root & 15) << kAgentLLRootShift) |
                         ((uint64_t)(dtype & 7) << kAgentLLDtypeShift) | ((uint64_t)(op & 3) << kAgentLLOpShift) |
