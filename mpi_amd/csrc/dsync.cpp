@@ -161,7 +161,7 @@ int dsync_connect(xmpi_comm* c) {
   // Untuned AUTO sends messages up to ll_bytes per rank as LL lines (ll.hip).  Measured with 2 processes (each kernel has the
   // GPU it runs on to itself, as on a node with one rank per GPU): 4.9 / 6.1 / 6.4 us enqueued at 1 / 4 / 16 KiB against
   // 8.9 / 8.8 / 9.4 for the fold; eight processes time-slicing ONE GPU: 45 / 56 / 65 against 47 / 47 / 42 (their polling lanes
-  // compete with each other's stores for the one memory system) -- so ranks that share a GPU keep LL to 1 KiB.
+  // compete with each other's stores for the one memory system) -- so ranks that share a GPU would keep LL to 1 KiB, were it not for the agent:
   // With the LL agent (ll.hip ll_agent_kernel) a BLOCKING call of up to 4 KiB needs no launch at all: eight processes on one GPU,
   // blocking allreduce 7.9 / 9.2 us at 1 / 4 KiB against 38 / 45 launched (no kernel, so nothing for eight processes' queues to be
   // time-sliced over) -- worth the 12 % an ENQUEUED 4 KiB LL collective loses to the fold there.  (The choice must not depend on
