@@ -122,6 +122,10 @@ MUTATIONS = {
              "const uint32_t why = dsync_spin(step_flags(mine) + (size_t)wait_rank * kStepSlots + w, (sh.epoch << 8) | st.wait_val, a.d);",
              "const uint32_t why = DSYNC_OK;  /* MUTANT: the step does not wait for its peer */"),
     # the closing block no longer waits for the peers' "done": the caller is told its buffers are final while peers still store into them
+    # the LL agent answers its caller before its lanes have met: the caller reads a receive buffer the agent's other lanes still store into
+    "agent": ("ll.hip",
+              "    __syncthreads();\n    if (t == 0) {  // what ll_end does for a launched kernel of one block",
+              "    /* MUTANT: lane 0 does not wait for the block's other lanes */\n    if (t == 0) {  // what ll_end does for a launched kernel of one block"),
     "done": ("kdev.h",
              "if (sh.fail == DSYNC_OK) why = dsync_spin(&mine->done[t][0], sh.epoch, a);",
              "/* MUTANT: nobody waits for the peers' done */"),

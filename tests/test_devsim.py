@@ -78,12 +78,14 @@ def test_the_sanitizer_sees_the_kernels_stores(tsan_bin):
     assert "dsync_fold_kernel" in r.stderr, r.stderr[-3000:]
 
 
-@pytest.mark.parametrize("mutant,scenario,where", [("step", "sched", ("st_sys128", "ld_sys128_issue")), ("done", "fold", ("hipMemcpyAsync",))])
+@pytest.mark.parametrize("mutant,scenario,where", [("step", "sched", ("st_sys128", "ld_sys128_issue")), ("done", "fold", ("hipMemcpyAsync",)),
+                                                   ("agent", "ll", ("ll_agent_collective", "hipMemcpyAsync"))])
 def test_the_sanitizer_finds_a_wait_taken_out_of_a_kernel(tsan_bin, mutant, scenario, where):
     """mutation: COPIES of the kernel sources with one wait removed (tests/devsim/build.py MUTATIONS; the product source is
     untouched) -- `step`: the stepped kernels no longer wait for the peer's step flag (races between a step's loads and the
     peer's written-through stores); `done`: the closing block no longer waits for the peers' "done" (the caller reads / refills
-    buffers the peers' kernels still store into).  The harness must say so, in those places"""
+    buffers the peers' kernels still store into); `agent`: the LL agent's lane 0 answers its caller without waiting for the block's
+    other lanes (the caller downloads a receive buffer they still store into).  The harness must say so, in those places"""
     from tests.devsim import build
     r = run(build.build_mutant(mutant), "4", "1", scenario)
     assert r.returncode != 0 and "ThreadSanitizer: data race" in r.stderr, r.stderr[-3000:]
