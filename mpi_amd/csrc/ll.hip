@@ -42,7 +42,8 @@ __device__ __forceinline__ void ll_store(char* line, uint64_t data, uint32_t fla
 // `valid` (1..8) bytes of this rank's own buffer, the rest zero.  SYS: past the caches, both ways (system-scope loads, stores
 // written through) -- for the agent, which lingers across calls: its CU's L1 and its XCD's L2 may hold the send buffer as it was a
 // call ago, and what it stores must be in memory before it answers.  A launched kernel has its boundaries for that; the agent
-// would need an L2 invalidate before and a write-back after every call (fences at system scope: about a microsecond each).
+// would need an L2 invalidate before and a write-back after every call (fences at system scope -- its first form had them: the
+// two ways measured within noise of each other at 1-4 KiB; this one asks nothing of what else the L2 holds).
 // (tests/devsim: plain accesses either way -- under its sanitizer the buffers' bytes must stay DATA, so that a reader no chain of
 // flag words has ordered behind the agent's stores is a reported race; what a cache holds is not modelled there.)
 #ifdef XMPI_DEVSIM
@@ -214,18 +215,16 @@ __device__ __forceinline__ bool ll_gather(const DsyncLLArgs& a, LLShared& sh, ui
   return true;
 }
 
-// A line (payload bytes [8 idx, 8 idx + 8)) in two halves: PUSH this rank's bytes to whoever needs them, COLLECT the peers'.
-// A launched kernel's lane does one after the other for its one line; the agent's lanes own several lines each and push them
-// ALL before they collect the first (one exchange with the peers per call, not one per line).  Nothing is kept between the
-// halves: a line's own bytes are read again (in place works: a line is overwritten by its own collect only).
+// The launched kernels' line (payload bytes [8 idx, 8 idx + 8)), one per lane, in two halves: PUSH this rank's bytes to whoever
+// needs them, COLLECT the peers'.  Nothing is kept between the halves: a line's own bytes are read again (in place works: a line
+// is overwritten by its own collect only).  (The agent's lanes own several lines each: ll_agent_collective below.)
 
 // allreduce / reduce
-template <bool SYS>
 __device__ __forceinline__ void ll_reduce_push(const DsyncLLArgs& a, const LLCall& q, uint32_t parity, uint32_t flag, size_t idx) {
   const int me = a.me, n = a.n;
   if (q.coll != LL_ALLREDUCE && me == q.root) return;
   const uint32_t valid = q.bytes - idx * 8 >= 8 ? 8u : (uint32_t)(q.bytes - idx * 8);
-  const uint64_t mine8 = load8<SYS>(reinterpret_cast<const char*>(q.send) + idx * 8, valid);
+  const uint64_t mine8 = load8<false>(reinterpret_cast<const char*>(q.send) + idx * 8, valid);
   if (q.coll == LL_ALLREDUCE) {
 #pragma unroll
     for (int d = 1; d < kDsyncRanks; d++) {  // (start with the next rank: the ranks do not all hit rank 0's page first)
@@ -237,35 +236,33 @@ __device__ __forceinline__ void ll_reduce_push(const DsyncLLArgs& a, const LLCal
   }
 }
 // ... gather, fold in rank order, store
-template <bool SYS, typename F>
+template <typename F>
 __device__ __forceinline__ void ll_reduce_collect(const DsyncLLArgs& a, const LLCall& q, LLShared& sh, uint32_t parity, uint32_t flag,
                                                   size_t idx, F fold) {
   const int me = a.me, n = a.n;
   if (q.coll != LL_ALLREDUCE && me != q.root) return;
   const uint32_t valid = q.bytes - idx * 8 >= 8 ? 8u : (uint32_t)(q.bytes - idx * 8);
-  const uint64_t mine8 = load8<SYS>(reinterpret_cast<const char*>(q.send) + idx * 8, valid);
+  const uint64_t mine8 = load8<false>(reinterpret_cast<const char*>(q.send) + idx * 8, valid);
   uint64_t x[kDsyncRanks];
   const uint32_t everyone = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
   if (ll_gather(a, sh, everyone & ~(1u << me), parity, flag, idx, x))
-    store8<SYS>(reinterpret_cast<char*>(q.recv) + idx * 8, fold([&x](int p) { return x[p]; }, mine8, me, n), valid);
+    store8<false>(reinterpret_cast<char*>(q.recv) + idx * 8, fold([&x](int p) { return x[p]; }, mine8, me, n), valid);
 }
 
 // broadcast / allgather: bytes only
-template <bool SYS>
 __device__ __forceinline__ void ll_copy_push(const DsyncLLArgs& a, const LLCall& q, uint32_t parity, uint32_t flag, size_t idx) {
   const int me = a.me, n = a.n;
   const bool gather = q.coll == LL_ALLGATHER;
   if (!gather && me != q.root) return;
   const uint32_t valid = q.bytes - idx * 8 >= 8 ? 8u : (uint32_t)(q.bytes - idx * 8);
-  const uint64_t mine8 = load8<SYS>(reinterpret_cast<const char*>(q.send) + idx * 8, valid);
+  const uint64_t mine8 = load8<false>(reinterpret_cast<const char*>(q.send) + idx * 8, valid);
 #pragma unroll
   for (int d = 1; d < kDsyncRanks; d++) {
     const int p = (me + d) % n;
     if (d < n) ll_store(ll_slot(a.page[p], me, parity) + idx * 16, mine8, flag);
   }
-  if (gather) store8<SYS>(reinterpret_cast<char*>(q.recv) + (size_t)me * q.bytes + idx * 8, mine8, valid);
+  if (gather) store8<false>(reinterpret_cast<char*>(q.recv) + (size_t)me * q.bytes + idx * 8, mine8, valid);
 }
-template <bool SYS>
 __device__ __forceinline__ void ll_copy_collect(const DsyncLLArgs& a, const LLCall& q, LLShared& sh, uint32_t parity, uint32_t flag,
                                                 size_t idx) {
   const int me = a.me, n = a.n;
@@ -276,7 +273,7 @@ __device__ __forceinline__ void ll_copy_collect(const DsyncLLArgs& a, const LLCa
     if (ll_gather(a, sh, everyone & ~(1u << me), parity, flag, idx, x)) {
 #pragma unroll
       for (int p = 0; p < kDsyncRanks; p++)
-        if (p < n && p != me) store8<SYS>(reinterpret_cast<char*>(q.recv) + (size_t)p * q.bytes + idx * 8, x[p], valid);
+        if (p < n && p != me) store8<false>(reinterpret_cast<char*>(q.recv) + (size_t)p * q.bytes + idx * 8, x[p], valid);
     }
   } else if (me != q.root) {
     if (ll_gather(a, sh, 1u << q.root, parity, flag, idx, x)) {
@@ -284,7 +281,7 @@ __device__ __forceinline__ void ll_copy_collect(const DsyncLLArgs& a, const LLCa
 #pragma unroll
       for (int p = 0; p < kDsyncRanks; p++)
         if (p == q.root) got = x[p];
-      store8<SYS>(reinterpret_cast<char*>(q.recv) + idx * 8, got, valid);
+      store8<false>(reinterpret_cast<char*>(q.recv) + idx * 8, got, valid);
     }
   }
 }
@@ -323,8 +320,8 @@ __global__ __launch_bounds__(kBlock) void ll_reduce_kernel(DsyncLLArgs a) {
   if (!to_all) ll_say_here(a, epoch);
   const size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (idx * 8 < a.bytes) {
-    ll_reduce_push<false>(a, q, parity, flag, idx);
-    ll_reduce_collect<false>(a, q, sh, parity, flag, idx, LLFoldStatic<T, OP>{});
+    ll_reduce_push(a, q, parity, flag, idx);
+    ll_reduce_collect(a, q, sh, parity, flag, idx, LLFoldStatic<T, OP>{});
   }
   if (!to_all) ll_wait_here(a, sh);
   ll_end(a, sh);
@@ -341,8 +338,8 @@ __global__ __launch_bounds__(kBlock) void ll_copy_kernel(DsyncLLArgs a) {
   if (!gather) ll_say_here(a, epoch);
   const size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (idx * 8 < a.bytes) {
-    ll_copy_push<false>(a, q, parity, flag, idx);
-    ll_copy_collect<false>(a, q, sh, parity, flag, idx);
+    ll_copy_push(a, q, parity, flag, idx);
+    ll_copy_collect(a, q, sh, parity, flag, idx);
   }
   if (!gather) ll_wait_here(a, sh);
   ll_end(a, sh);
