@@ -587,7 +587,9 @@ static int dsync_ll(xmpi_comm* c, int coll, int root, const void* sendbuf, void*
     // busy GPU; the agent's launch overlaps with the command already lying in its record) and 7.5 inside its patience.
     if (agent_submit_ll(c, send, recv, unit, ll_coll, root, dtype, op, consecutive)) {
       c->agent_ll_wait_ns += (uint64_t)((now_seconds() - t_cmd) * 1e9);
-      c->agent_quiet_at = c->agent_epoch_at = calls;
+      // (only when no other thread has entered the library on this communicator meanwhile: what it goes on to enqueue is not
+      // this call's to vouch for)
+      if (c->api_calls.load(std::memory_order_relaxed) == calls) c->agent_quiet_at = c->agent_epoch_at = calls;
       c->dsync_ll_launches++;  // (an LL collective, whoever ran its lines)
       c->dsync_ll_agent++;
       if (host_out) memcpy(recvbuf, c->host_bounce + xmpi_comm::kHostBounce, recv_bytes);
@@ -645,7 +647,9 @@ static int dsync_ll(xmpi_comm* c, int coll, int root, const void* sendbuf, void*
   }
   rc = wait_blocking(c, stream, done_dev != nullptr, done_id);
   if (rc != XMPI_OK) return fail(rc);
-  c->agent_quiet_at = calls;  // (the kernel's last act was the word this call waited for; everything before it on the streams is over)
+  // (the kernel's last act was the word this call waited for; everything before it on the streams is over -- unless another thread
+  // has entered the library meanwhile)
+  if (c->api_calls.load(std::memory_order_relaxed) == calls) c->agent_quiet_at = calls;
   if (host_out) {
     memcpy(recvbuf, c->host_bounce + xmpi_comm::kHostBounce, recv_bytes);
   } else if (out_tmp) {
@@ -734,6 +738,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
   const size_t recv_bytes = (coll == COLL_ALLGATHER) ? send_bytes * (size_t)N : send_bytes;
   const bool recv_significant = (coll != COLL_REDUCE) || me == root;
   if (!stream) stream = c->local_stream;
+  const uint64_t calls_at_entry = c->api_calls.load(std::memory_order_relaxed);  // (dsync_ll's shortcut: see agent_quiet_at)
   dsync_service(c);
   reap_deferred(c, false);
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -1101,7 +1106,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
 
   rc = wait_blocking(c, stream, done_dev != nullptr, done_id);
   if (rc != XMPI_OK) return fail(rc);
-  c->agent_quiet_at = c->api_calls.load(std::memory_order_relaxed);  // (as in dsync_ll: the next blocking small collective need not ask the streams)
+  if (c->api_calls.load(std::memory_order_relaxed) == calls_at_entry) c->agent_quiet_at = calls_at_entry;  // (as in dsync_ll: the next blocking small collective need not ask the streams)
   if (host_out) {
     memcpy(recvbuf, c->host_bounce + xmpi_comm::kHostBounce, recv_bytes);
   } else if (out_src) {
