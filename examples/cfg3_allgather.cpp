@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "mpi.hpp"
+#include "xmpi_test.h"  // xmpi_fill_pattern: the inputs the CPU oracle can reproduce
 
 static double now_us() {
   return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();

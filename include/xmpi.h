@@ -72,7 +72,17 @@ typedef enum {
                            before (XMPI_LL_AGENT_US, default 40) takes it from a command record in pinned memory
                            (XMPI_AGENT_LL=0: always launch) -- every call of the reference's API is blocking,
                            mpi.go:47-48                                                                      */
-  XMPI_ALGO_COUNT = 8
+  /* The PUSH forms of the stepped kernels (one process per GPU): the same schedules, pairs, chunks and association as
+   * RING / RHD / TREE -- bit-identical results -- but every payload byte crosses its link as a posted STORE: a step reads only
+   * this rank's memory (its input and what peers stored here), combines, and stores the result into the PEER's receive buffer
+   * or the landing block the peer lends (in-place ring allreduce: one buffer's worth of registered memory per rank; halving:
+   * about as much; tree reduce: one per child) -- the reference's one-way message (network.go:562-571) without the ack, where
+   * RING / RHD / TREE load every byte over the link (a round trip per packet).  With ranks that meet on the host: the same
+   * as RING / RHD / TREE.  xmpi_tune times both forms. */
+  XMPI_ALGO_RING_PUSH = 8, /* allreduce, allgather */
+  XMPI_ALGO_RHD_PUSH = 9,  /* allreduce            */
+  XMPI_ALGO_TREE_PUSH = 10, /* bcast, reduce       */
+  XMPI_ALGO_COUNT = 11
 } xmpi_algo;
 
 /* error codes */
@@ -319,11 +329,6 @@ int xmpi_diff_stats(xmpi_comm* comm, const void* a, const void* b, size_t count,
  * rule |delta_i| <= tol * sum_r |x_r,i| of BASELINE.md for a whole buffer on the device. */
 int xmpi_diff_rel(xmpi_comm* comm, const void* a, const void* b, size_t count, xmpi_dtype dtype,
                   double* max_rel);
-/* Fill with the deterministic test pattern shared with the CPU oracle (oracle/xmpi_oracle.c
- * `oracle_fill`): see DESIGN.md "synthetic inputs". */
-int xmpi_fill_pattern(xmpi_comm* comm, void* buf, size_t count, xmpi_dtype dtype, int pattern,
-                      uint64_t seed);
-
 /* ---- tuning / introspection ------------------------------------------------------------- */
 
 /* name in {"channels","piece_bytes","copy_engine","signal","timeout_s","fifo_depth"...};
@@ -333,16 +338,15 @@ long xmpi_get_param(const xmpi_comm* comm, const char* name);
 
 /* The library's own schedule table.  xmpi_tune times, on this job's real layout and links, the schedules it offers
  * for an allreduce (one zero-copy kernel with 1 or 2 packets in flight, the meet / body / done form, the push-only
- * form, the ring kernel, the halving kernel) and an allgather, for message sizes 1 KiB ... max_bytes (x4 steps), lets
+ * form, the ring and the halving kernel each in its pull and its push form, LL lines) and an allgather, for message sizes 1 KiB ... max_bytes (x4 steps), lets
  * every rank see the slowest rank's figures and keeps the winner per size class: XMPI_ALGO_AUTO (and the
  * stream-ordered forms) consult that table from then on, so a Go or C caller gets the schedule a benchmark would pick.
  * Collective (same max_bytes on every rank); a few hundred milliseconds.  The table is readable through
  * xmpi_get_param("tune_algo_<collective>_<class>") (collective 0 = allreduce, 1 = allgather; class k = messages of
  * [2^(k+8), 2^(k+9)) bytes per rank; -1 = built-in rule), "tune_split_..." (1 = meet / body / done), "tune_unroll_...".
- * xmpi_tune_decide is the decision it applies to one row of (max-over-ranks) mean times in microseconds, <= 0 = not
- * run: the fastest, except that candidate 0 (the default) stays unless beaten by more than `margin` (host logic only). */
+ * Per row of (max-over-ranks) mean times the fastest candidate wins, except that the default stays unless beaten by more
+ * than 3 % (noise must not flip the schedule). */
 int xmpi_tune(xmpi_comm* comm, size_t max_bytes);
-int xmpi_tune_decide(const double* mean_us, int n, double margin);
 
 /* Kernel profiling: when enabled every reduction / copy kernel launch is bracketed by HIP
  * events on the stream it runs on.  kind: 0 = reduce2, 1 = reduceN, 2 = copy kernel,
@@ -357,32 +361,6 @@ int xmpi_prof_get(xmpi_comm* comm, int kind, uint64_t* launches, double* total_m
  * peer must not be inside a collective; call it on both ranks of a pair for the bidirectional rate. */
 int xmpi_link_probe(xmpi_comm* comm, int peer, size_t bytes, int engine, int iters, int direction,
                     double* gbps);
-
-/* Host-only self-test of the control plane shared by the ranks of a job (no GPU call): every rank
- * of `size` calls it with the same key; exercises join, barriers, pipe counters, the mail-entry
- * states (with the direct-pull offer), the zero-copy buffer descriptors and the retire logs for
- * `rounds` rounds.  Used by the CPU test-suite with plain OS processes. */
-int xmpi_ctl_selftest(const char* job_key, int rank, int size, int rounds);
-
-/* Schedule introspection (host logic only, no GPU needed): writes the step table the executor
- * would run for (coll, algo, size, rank, count) as text into out; returns needed length. */
-int xmpi_plan_dump(int coll, int algo, int size, int rank, int root, size_t count,
-                   size_t elem_size, int channels, size_t piece_elems, char* out, size_t cap);
-
-/* The step program of a stepped kernel (ring allreduce = 1, recursive halving + doubling = 2, ring allgather = 3,
- * binary-tree bcast = 4) for one rank and ring channel, as text, from the very function the kernel runs (host logic only,
- * no GPU needed: the CPU test-suite executes all ranks' programs under random interleavings).  Returns the needed length. */
-int xmpi_sched_dump(int sched, int size, int rank, int root, int pieces, size_t count, size_t elem_size, int nchan,
-                    int channel, char* out, size_t cap);
-
-/* Chunk j of a count-element buffer cut for `size` ranks the way the zero-copy collectives cut it
- * (16-byte aligned boundaries): element offset and length.  Host logic only. */
-int xmpi_zc_chunk(size_t count, size_t elem_size, int size, int j, size_t* elem_off, size_t* elem_cnt);
-
-/* Host-only self-test of xmpi_malloc's block bookkeeping (no GPU call): `rounds` random allocate /
- * free operations on a synthetic arena; 0 = blocks never overlapped, stayed aligned and coalesced
- * back into one free block, otherwise the number of the failed check. */
-int xmpi_heap_selftest(uint64_t seed, int rounds);
 
 size_t xmpi_dtype_size(xmpi_dtype dtype);
 

@@ -27,7 +27,8 @@ ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wextra"]
 
 LIB_SOURCES = ["kernels.hip", "sched.hip", "ll.hip", "engine.cpp", "api.cpp", "ctl.cpp", "plan.cpp", "zcopy.cpp", "heap.cpp", "dsync.cpp", "trace.cpp"]
-LIB_HEADERS = ["kernels.h", "kdev.h", "sched_steps.h", "comm.h", "ctl.h", "plan.h", "trace.h", os.path.join("..", "..", "include", "xmpi.h")]
+LIB_HEADERS = ["kernels.h", "kdev.h", "sched_steps.h", "comm.h", "ctl.h", "plan.h", "trace.h", os.path.join("..", "..", "include", "xmpi.h"),
+               os.path.join("..", "..", "include", "xmpi_test.h")]
 
 
 MANIFEST = os.path.join(ROOT, "mpi_amd", ".build_manifest.json")
@@ -119,7 +120,8 @@ def build_host(force: bool = False) -> list[str]:
     net_cpp = os.path.join(host_dir, "network.cpp")
     if os.path.exists(mpi_cpp):
         deps = [mpi_cpp, net_cpp, os.path.join(host_dir, "mpi.hpp"), os.path.join(host_dir, "network.hpp"),
-                os.path.join(host_dir, "gobwire.hpp"), os.path.join(ROOT, "include", "xmpi.h")]
+                os.path.join(host_dir, "gobwire.hpp"), os.path.join(ROOT, "include", "xmpi.h"),
+                os.path.join(ROOT, "include", "xmpi_test.h")]
         if force or _newer(HOSTLIB, deps):
             _run(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wextra", "-shared", *inc, mpi_cpp, net_cpp, "-o", HOSTLIB,
                   "-L", os.path.dirname(LIB), "-lxmpi", "-Wl,-rpath,$ORIGIN", "-lpthread"], HOSTLIB, deps)

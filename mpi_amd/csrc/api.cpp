@@ -393,6 +393,10 @@ static int collective(xmpi_comm* c, int coll, int algo, int root, const void* se
     if (zrc != XMPI_OK || done) return zrc;
   }
   if (zc_algo) algo = XMPI_ALGO_AUTO;  // (LL lines need ranks that meet on the device: with the others it names the fold)
+  // (the push forms are forms of the stepped KERNELS: the host-driven step tables have one form, which pushes into the windows)
+  if (algo == XMPI_ALGO_RING_PUSH) algo = XMPI_ALGO_RING;
+  if (algo == XMPI_ALGO_RHD_PUSH) algo = XMPI_ALGO_RHD;
+  if (algo == XMPI_ALGO_TREE_PUSH) algo = XMPI_ALGO_TREE;
   PlanParams pp;
   pp.coll = coll;
   pp.algo = algo;
@@ -1491,7 +1495,8 @@ int xmpi_set_param(xmpi_comm* c, const char* name, long value) {
   else if (n == "tree_piece_bytes") c->tree_piece_bytes = std::max<long>(4096, value);
   else if (n == "tuned") c->tuned = value != 0;  // 0: AUTO forgets the table of xmpi_tune
   else if (n == "tune_mask") c->tune_mask = value;  // bit k = 0: xmpi_tune leaves candidate k out (1 other unroll, 2 meet / body / done,
-                                                    // 3 push-only, 4 ring kernel, 5 halving kernel); the default form always runs
+                                                    // 3 push-only, 4 ring kernel, 5 halving kernel, 6 LL lines, 7 ring kernel push form,
+                                                    // 8 halving kernel push form); the default form always runs
   else if (n == "kernel_mode") set_kernel_mode((int)value);  // process-wide
   else if (n == "grid_cap") set_grid_cap((int)value);        // process-wide
   else return XMPI_ERR_ARG;
@@ -1551,6 +1556,7 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
   if (n == "xcd_done_mask") return c->dsync_status ? (long)__atomic_load_n(c->dsync_status + 7, __ATOMIC_RELAXED) : -1;
   if (n == "dsync_split_launches") return (long)c->dsync_split_launches;
   if (n == "dsync_sched_launches") return (long)c->dsync_sched_launches;
+  if (n == "dsync_land_bytes") return (long)c->dsync_land_bytes;
   if (n == "sched_channels") return c->sched_channels;
   if (n == "sched_grid") return c->sched_grid;
   if (n == "tree_piece_bytes") return c->tree_piece_bytes;
@@ -1901,6 +1907,10 @@ int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
                              {XMPI_ALGO_RING, 0, u0}};
   cands.push_back({XMPI_ALGO_RHD, 0, u0});
   cands.push_back({XMPI_ALGO_LL, 0, u0});                                          // candidate 6
+  // the push forms of the stepped kernels (sched_steps.h): the same schedules with every payload byte STORED over its link
+  // instead of loaded -- which of the two a link moves faster is the machine's to say
+  cands.push_back({XMPI_ALGO_RING_PUSH, 0, u0});                                   // candidate 7
+  cands.push_back({XMPI_ALGO_RHD_PUSH, 0, u0});                                    // candidate 8
   const long keep_split = c->dsync_split_bytes, keep_unroll = c->dsync_unroll;
   const bool keep_tuned = c->tuned;
   c->tuned = false;
@@ -1921,7 +1931,7 @@ int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
         for (size_t k = 0; k < cands.size() && rc == XMPI_OK; k++) {
           const Cand& cd = cands[k];
           if (cd.algo < 0) continue;
-          if (coll == COLL_ALLGATHER && (cd.algo == XMPI_ALGO_ZPUSH || cd.algo == XMPI_ALGO_RHD || cd.unroll != u0)) continue;
+          if (coll == COLL_ALLGATHER && (cd.algo == XMPI_ALGO_ZPUSH || cd.algo == XMPI_ALGO_RHD || cd.algo == XMPI_ALGO_RHD_PUSH || cd.unroll != u0)) continue;
           if (cd.algo == XMPI_ALGO_LL && per_rank > kLLMaxPayload) continue;
           if (k > 0 && !((c->tune_mask >> k) & 1)) continue;  // a schedule the caller has ruled out on this machine (never the default)
           rc = xmpi_barrier(c);
@@ -1993,19 +2003,23 @@ int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
 
 // The step program a stepped kernel (sched.hip) runs on `rank` for ring channel `channel`, as text -- produced by the very
 // function the kernel calls (sched_steps.h).  One line per step:
-//   g wait=<rank>:<value> sig=<rank>,<rank>:<value> ns=<0|1|2> D=<rank>.<s|r><+offset> A=... B=... lo=<byte> hi=<byte>
+//   g wait=<rank>:<value> sig=<rank>,<rank>:<value> nmv=<moves> then per move
+//   | ns=<1|2|3> D=<ref> D2=<ref> A=<ref> B=<ref> C=<ref> lo=<byte> hi=<byte>        ref = <rank>.<s|r|l><+offset> or -
+// (s = send buffer, r = receive buffer, l = landing block).  form: 0 = pull, 1 = push; in_place: every rank's send buffer is its
+// receive buffer (what decides whether a push-form ring lands in the receive buffers or in landing blocks).
 // (host logic only; tests/sched_sim.py executes all ranks' programs on the CPU).  Returns the needed length.
-int xmpi_sched_dump(int sched, int size, int rank, int root, int pieces, size_t count, size_t elem_size, int nchan, int channel,
-                    char* out, size_t cap) {
+int xmpi_sched_dump(int sched, int form, int in_place, int size, int rank, int root, int pieces, size_t count, size_t elem_size, int nchan,
+                    int channel, char* out, size_t cap) {
   if (size < 1 || size > kMaxRanks || rank < 0 || rank >= size || root < 0 || root >= size || elem_size < 1 || nchan < 1 ||
       nchan > kMaxSchedChannels || channel < 0 || channel >= nchan || sched < SCHED_RING_ALLREDUCE || sched > SCHED_TREE_REDUCE ||
-      (sched == SCHED_TREE_REDUCE && pieces > 127))  // (a step number must fit the low byte of a flag word)
+      form < 0 || form > 1 || (sched == SCHED_TREE_REDUCE && pieces > 127))  // (a step number must fit the low byte of a flag word)
     return XMPI_ERR_ARG;
   DsyncSchedArgs a;
   memset(&a, 0, sizeof a);
   a.d.me = rank;
   a.d.n = size;
   a.sched = sched;
+  a.push = (uint32_t)form;
   a.nchan = nchan;
   a.root = root;
   a.pieces = std::max(1, pieces);
@@ -2016,12 +2030,19 @@ int xmpi_sched_dump(int sched, int size, int rank, int root, int pieces, size_t 
     ring_order(size, ch, &ord);
     for (int i = 0; i < size; i++) a.order[ch][i] = (uint8_t)ord[(size_t)i];
   }
-  // recognisable addresses: rank r's send / receive buffer = ((r+1) << 44) | (kind << 42) | 2^41 (+ a signed offset)
-  uint64_t send[kMaxRanks], recv[kMaxRanks];
+  // recognisable addresses: rank r's send / receive buffer / landing block = ((r+1) << 44) | (kind << 42) | 2^41 (+ a signed offset)
+  uint64_t send[kMaxRanks], recv[kMaxRanks], land[kMaxRanks];
   auto fake = [](int r, int kind) { return ((uint64_t)(r + 1) << 44) | ((uint64_t)kind << 42) | (1ull << 41); };
   for (int r = 0; r < size; r++) {
-    send[r] = fake(r, 0);
+    // in place: the send buffer IS the receive buffer (tree reduce: at the root only -- nobody else has one; allgather: the
+    // rank's block of it)
     recv[r] = fake(r, 1);
+    send[r] = !in_place || sched == SCHED_TREE_BCAST || (sched == SCHED_TREE_REDUCE && r != root) ? fake(r, 0)
+              : sched == SCHED_RING_ALLGATHER           ? recv[r] + (uint64_t)r * count * elem_size
+                                                        : recv[r];
+    DsyncSchedArgs ar = a;
+    ar.d.me = r;
+    land[r] = sched_land_bytes(ar, in_place != 0) ? fake(r, 2) : 0;  // (as dsync.cpp lends them)
   }
   auto show = [&](uint64_t base, char* buf, size_t n) {
     if (!base) {
@@ -2030,20 +2051,29 @@ int xmpi_sched_dump(int sched, int size, int rank, int root, int pieces, size_t 
     }
     const int r = (int)(base >> 44) - 1, kind = (int)((base >> 42) & 3);
     const long long off = (long long)(base - fake(r, kind));
-    snprintf(buf, n, "%d.%c%+lld", r, kind ? 'r' : 's', off);
+    snprintf(buf, n, "%d.%c%+lld", r, "srl?"[kind], off);
   };
   std::string t;
   const int ns = sched_nsteps(a);
   for (int g = 1; g <= ns; g++) {
     SchedStep st;
-    sched_step(a, send, recv, g, channel, &st);
-    char d[48], x[48], y[48], line[320];
-    show(st.D, d, sizeof d);
-    show(st.ns >= 1 ? st.A : 0, x, sizeof x);
-    show(st.ns == 2 ? st.B : 0, y, sizeof y);
-    snprintf(line, sizeof line, "%d wait=%d:%u sig=%d,%d:%u ns=%d D=%s A=%s B=%s lo=%llu hi=%llu\n", g, st.wait_rank, st.wait_val,
-             st.sig[0], st.sig[1], st.sig_val, st.ns, d, x, y, (unsigned long long)st.lo, (unsigned long long)st.hi);
+    sched_step(a, send, recv, land, g, channel, &st);
+    char line[160];
+    snprintf(line, sizeof line, "%d wait=%d:%u sig=%d,%d:%u nmv=%d", g, st.wait_rank, st.wait_val, st.sig[0], st.sig[1], st.sig_val, st.nmv);
     t += line;
+    for (int k = 0; k < st.nmv; k++) {
+      const SchedMove& m = st.mv[k];
+      char d[48], d2[48], x[48], y[48], z[48], mv[400];
+      show(m.D, d, sizeof d);
+      show(m.D2, d2, sizeof d2);
+      show(m.A, x, sizeof x);
+      show(m.ns >= 2 ? m.B : 0, y, sizeof y);
+      show(m.ns >= 3 ? m.C : 0, z, sizeof z);
+      snprintf(mv, sizeof mv, " | ns=%d D=%s D2=%s A=%s B=%s C=%s lo=%llu hi=%llu", m.ns, d, d2, x, y, z, (unsigned long long)m.lo,
+               (unsigned long long)m.hi);
+      t += mv;
+    }
+    t += "\n";
   }
   if (out && cap) {
     const size_t n = std::min(cap - 1, t.size());
@@ -2051,6 +2081,20 @@ int xmpi_sched_dump(int sched, int size, int rank, int root, int pieces, size_t 
     out[n] = 0;
   }
   return (int)std::min<size_t>(t.size() + 1, 0x7fffffff);
+}
+
+size_t xmpi_sched_land_bytes(int sched, int in_place, int size, int rank, int root, size_t count, size_t elem_size) {
+  if (size < 1 || size > kMaxRanks || rank < 0 || rank >= size || root < 0 || root >= size) return 0;
+  DsyncSchedArgs a;
+  memset(&a, 0, sizeof a);
+  a.d.me = rank;
+  a.d.n = size;
+  a.sched = sched;
+  a.push = 1;
+  a.root = root;
+  a.count = count;
+  a.elem_size = (uint32_t)elem_size;
+  return (size_t)sched_land_bytes(a, in_place != 0);
 }
 
 int xmpi_plan_dump(int coll, int algo, int size, int rank, int root, size_t count, size_t elem_size, int channels,

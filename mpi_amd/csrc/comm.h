@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/xmpi.h"
+#include "../../include/xmpi_test.h"
 #include "ctl.h"
 #include "kernels.h"
 #include "trace.h"
@@ -194,6 +195,7 @@ struct xmpi_comm {
                                        // the streams (hipStreamQuery of a stream whose last kernel is still retiring costs ~10 us)
   uint64_t agent_epoch_at = ~0ull;     // ... and when the AGENT last ran one: the next call's epoch is that one's plus one
   uint64_t dsync_split_launches = 0, dsync_sched_launches = 0;  // ... collectives run as meet / body / done; as a stepped kernel
+  uint64_t dsync_land_bytes = 0;   // the landing block this rank lent to its last push-form stepped collective (0: none)
   xmpi::DsyncEntry* dsync_table = nullptr;            // [kMaxRanks][kDsyncArenas], pinned host memory the kernels read
   const xmpi::DsyncEntry* dsync_table_dev = nullptr;  // ... as the GPU addresses it
   uint64_t dsync_seen[xmpi::kMaxRanks] = {0};         // published entries of each peer processed so far

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/xmpi.h"
+#include "../../include/xmpi_test.h"
 
 namespace xmpi {
 

@@ -27,6 +27,7 @@
 
 #include "comm.h"
 #include "kernels.h"
+#include "sched_steps.h"
 
 namespace xmpi {
 
@@ -694,9 +695,12 @@ bool dsync_takes(const xmpi_comm* c, int coll, int algo) {
     case XMPI_ALGO_ZCOPY:
     case XMPI_ALGO_ZPUSH:
     case XMPI_ALGO_LL: return true;
-    case XMPI_ALGO_RING: return coll == COLL_ALLREDUCE || coll == COLL_ALLGATHER;  // the stepped kernels (sched.hip)
-    case XMPI_ALGO_RHD: return coll == COLL_ALLREDUCE;
-    case XMPI_ALGO_TREE: return coll == COLL_BCAST || coll == COLL_REDUCE;
+    case XMPI_ALGO_RING:  // the stepped kernels (sched.hip), pull and push form
+    case XMPI_ALGO_RING_PUSH: return coll == COLL_ALLREDUCE || coll == COLL_ALLGATHER;
+    case XMPI_ALGO_RHD:
+    case XMPI_ALGO_RHD_PUSH: return coll == COLL_ALLREDUCE;
+    case XMPI_ALGO_TREE:
+    case XMPI_ALGO_TREE_PUSH: return coll == COLL_BCAST || coll == COLL_REDUCE;
     default: return false;
   }
 }
@@ -757,9 +761,13 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     if (send_bytes <= kLLMaxPayload) return dsync_ll(c, coll, root, sendbuf, recvbuf, count, dtype, op, stream, blocking, capturing);
     algo = XMPI_ALGO_ZCOPY;  // named, but too long for the slots: the fold (the same decision on every rank)
   }
-  const bool stepped = (algo == XMPI_ALGO_RING && (coll == COLL_ALLREDUCE || coll == COLL_ALLGATHER)) ||
-                       (algo == XMPI_ALGO_RHD && coll == COLL_ALLREDUCE) ||
-                       (algo == XMPI_ALGO_TREE && (coll == COLL_BCAST || coll == COLL_REDUCE));
+  // the push forms of the stepped kernels: the same schedule, the data stored into the peer instead of loaded from it
+  const bool sched_push = algo == XMPI_ALGO_RING_PUSH || algo == XMPI_ALGO_RHD_PUSH || algo == XMPI_ALGO_TREE_PUSH;
+  const int sched_algo = algo == XMPI_ALGO_RING_PUSH ? XMPI_ALGO_RING : algo == XMPI_ALGO_RHD_PUSH ? XMPI_ALGO_RHD
+                         : algo == XMPI_ALGO_TREE_PUSH ? XMPI_ALGO_TREE : algo;
+  const bool stepped = (sched_algo == XMPI_ALGO_RING && (coll == COLL_ALLREDUCE || coll == COLL_ALLGATHER)) ||
+                       (sched_algo == XMPI_ALGO_RHD && coll == COLL_ALLREDUCE) ||
+                       (sched_algo == XMPI_ALGO_TREE && (coll == COLL_BCAST || coll == COLL_REDUCE));
   const bool push = algo == XMPI_ALGO_ZPUSH;
   RoctxRange range("xmpi:dsync %s algo=%s bytes=%zu epoch=%llu %s", coll_name(coll), algo_name(algo), send_bytes,
                    (unsigned long long)c->dsync_epoch + 1, blocking ? "blocking" : capturing ? "captured" : "enqueued");
@@ -817,7 +825,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
 
   // binary-tree reduce: an inner node that is not the root accumulates its subtree's partial result in a block the parent
   // can read (sched_steps.h SCHED_TREE_REDUCE); the caller's receive buffer means nothing there
-  if (stepped && coll == COLL_REDUCE && me != root && 2 * ((me - root + N) % N) + 1 < N) {
+  if (stepped && !sched_push && coll == COLL_REDUCE && me != root && 2 * ((me - root + N) % N) + 1 < N) {
     if (capturing) return no_standin();
     void* acc = heap_alloc(c->device, send_bytes);
     if (!acc) return fail(XMPI_ERR_NOMEM);
@@ -929,9 +937,10 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     sa.count = count;
     sa.elem_size = (uint32_t)es;
     sa.pieces = 1;
+    sa.push = sched_push ? 1u : 0u;
     size_t step_bytes = send_bytes;  // what the largest step of the schedule moves
     int nchan = 1;
-    if (algo == XMPI_ALGO_RING) {
+    if (sched_algo == XMPI_ALGO_RING) {
       sa.sched = coll == COLL_ALLREDUCE ? SCHED_RING_ALLREDUCE : SCHED_RING_ALLGATHER;
       step_bytes = coll == COLL_ALLREDUCE ? (send_bytes + (size_t)N - 1) / (size_t)N : send_bytes;
       // every channel is a different cyclic order of the ranks (plan.cpp ring_order: on an even mesh N-2 directed rings
@@ -939,7 +948,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
       const int avail = std::min(ring_channel_count(N), kMaxSchedChannels);
       nchan = c->sched_channels > 0 ? (int)std::min<long>(c->sched_channels, avail) : (c->dsync_sharers > 1 ? 1 : avail);
       traffic = coll == COLL_ALLREDUCE ? 5 * (size_t)(N - 1) * step_bytes : 2 * (size_t)N * send_bytes;
-    } else if (algo == XMPI_ALGO_RHD) {
+    } else if (sched_algo == XMPI_ALGO_RHD) {
       sa.sched = SCHED_RHD_ALLREDUCE;
       step_bytes = send_bytes / 2;
       traffic = 5 * (send_bytes - send_bytes / (size_t)N);  // halving: 3 x (S/2 + S/4 + ...), doubling: 2 x the same
@@ -955,6 +964,29 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
         const int v = (me - root + N) % N;
         traffic = 3 * send_bytes * (size_t)((2 * v + 1 < N) + (2 * v + 2 < N));
       }
+    }
+    // push form: the block the peers store into where this rank's receive buffer cannot take their data yet (sched_steps.h
+    // sched_land_bytes: in-place ring allreduce -- the receive buffer still is the input; halving -- a region per level; tree
+    // reduce -- a slot per child).  Lent per call from the registered arenas: the peers have mapped those long ago.
+    sa.d.me = me;
+    sa.d.n = N;
+    const size_t land_bytes = (size_t)sched_land_bytes(sa, r.send == r.recv);
+    if (land_bytes) {
+      if (capturing) return no_standin();
+      void* land = heap_alloc(c->device, land_bytes);
+      if (!land) return fail(XMPI_ERR_NOMEM);
+      lent.push_back(land);
+      BufRef lref;
+      if (!zc_export(c, land, land_bytes, &lref)) return fail(XMPI_ERR_HIP);
+      int lslot = 0;
+      rc = publish(c, lref, &lslot, &pi, capturing);
+      if (rc == XMPI_OK) rc = await_acks(c, pi);
+      if (rc) return fail(rc);
+      sa.d.land_gen = lref.gen;
+      sa.d.land_off = lref.offset;
+      sa.d.land_slot = (uint64_t)lslot;
+      sa.d.my_land = land;
+      c->dsync_land_bytes = land_bytes;
     }
     const size_t tiles = std::max<size_t>(1, (step_bytes + kSchedTileBytes - 1) / kSchedTileBytes);
     long workers = c->sched_grid > 0 ? c->sched_grid : (long)std::min<size_t>(tiles, (size_t)dsync_block_cap(c));

@@ -161,6 +161,7 @@ __device__ __forceinline__ uint32_t dsync_spin(const uint64_t* p, uint64_t want,
 struct DsyncShared {
   uint64_t epoch;                                 // of this kernel
   uint64_t send[kDsyncRanks], recv[kDsyncRanks];  // every rank's buffers as addressable from here
+  uint64_t land[kDsyncRanks];                     // ... and its landing block (push forms of the stepped kernels); 0 = it lends none
   uint64_t src[kDsyncRanks], dst[kDsyncRanks];    // this block's segment: sources in rank order, destinations local first
   int nsrc, ndst;
   uint32_t fail, last;
@@ -203,6 +204,7 @@ __device__ void dsync_begin(const DsyncArgs& a, DsyncShared& sh) {
     sh.fail = DSYNC_OK;
     sh.send[me] = (uint64_t)(uintptr_t)a.my_send;
     sh.recv[me] = (uint64_t)(uintptr_t)a.my_recv;
+    sh.land[me] = (uint64_t)(uintptr_t)a.my_land;
     // the epoch is counted on the device (every block reads the same value: only the closing block of a kernel
     // advances it, after all the others have finished), so replaying a captured launch counts on
     const uint64_t seen = ld_sys64(&mine->epoch_now);
@@ -215,21 +217,27 @@ __device__ void dsync_begin(const DsyncArgs& a, DsyncShared& sh) {
       DsyncSlot* out = &a.page[t]->ready[me];
       st_sys64(&out->send_gen, a.send_gen);
       st_sys64(&out->send_off, a.send_off);
-      st_sys64(&out->send_slot, a.send_slot);
       st_sys64(&out->recv_gen, a.recv_gen);
       st_sys64(&out->recv_off, a.recv_off);
-      st_sys64(&out->recv_slot, a.recv_slot);
+      st_sys64(&out->slots, a.send_slot | (a.recv_slot << 8) | (a.land_slot << 16) | (a.land_gen ? 1ull << 24 : 0));
+      if (a.land_gen) {  // (bit 24 of `slots` says whether these two mean anything)
+        st_sys64(&out->land_gen, a.land_gen);
+        st_sys64(&out->land_off, a.land_off);
+      }
       __hip_atomic_store(&out->epoch, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     const DsyncSlot* in = &mine->ready[t];
     uint32_t why = dsync_spin(&in->epoch, epoch, a);
     if (why == DSYNC_OK) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-      const uint64_t s = dsync_translate(a, mine, t, ld_sys64(&in->send_slot), ld_sys64(&in->send_gen), ld_sys64(&in->send_off));
-      const uint64_t r = dsync_translate(a, mine, t, ld_sys64(&in->recv_slot), ld_sys64(&in->recv_gen), ld_sys64(&in->recv_off));
+      const uint64_t slots = ld_sys64(&in->slots), lgen = (slots >> 24 & 1u) ? ld_sys64(&in->land_gen) : 0;
+      const uint64_t s = dsync_translate(a, mine, t, slots & 0xffu, ld_sys64(&in->send_gen), ld_sys64(&in->send_off));
+      const uint64_t r = dsync_translate(a, mine, t, (slots >> 8) & 0xffu, ld_sys64(&in->recv_gen), ld_sys64(&in->recv_off));
+      const uint64_t l = lgen ? dsync_translate(a, mine, t, (slots >> 16) & 0xffu, lgen, ld_sys64(&in->land_off)) : 0;
       sh.send[t] = s;
       sh.recv[t] = r;
-      if (!s || !r) why = DSYNC_UNMAPPED;
+      sh.land[t] = l;
+      if (!s || !r || (lgen && !l)) why = DSYNC_UNMAPPED;
     }
     if (why != DSYNC_OK) atomicMax(&sh.fail, why);
   }

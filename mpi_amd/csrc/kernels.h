@@ -74,9 +74,12 @@ constexpr int kDsyncArenas = 32;  // live allocations of one peer this rank can 
 struct DsyncSlot {
   uint64_t epoch;  // written last, system-scope release: the fields below belong to this collective
   uint64_t send_gen, send_off, recv_gen, recv_off;  // the peer's buffers: registration number + byte offset
-  uint64_t send_slot, recv_slot;                    // ... and the table slot the peer published them under
-  uint64_t pad;
+  uint64_t slots;               // ... and the table slots the peer published them under: send | recv << 8 | landing << 16; bit 24:
+                                // it lends a landing block
+  uint64_t land_gen, land_off;  // the peer's LANDING block (push forms of the stepped kernels: what the peers store into before
+                                // the owner has combined it); written -- and meaningful -- only with bit 24 of `slots`
 };
+static_assert(sizeof(DsyncSlot) == 64, "one announce = one 64-byte record");
 struct DsyncEntry {  // a peer's registration number -> where this process mapped that allocation
   uint64_t gen;      // 0 = free
   uint64_t base, bytes;
@@ -187,8 +190,10 @@ struct DsyncArgs {
   uint64_t done_value;        //   call polls it: no event, no stream query between the kernel and the caller); may be null
   uint64_t send_gen, send_off, recv_gen, recv_off;  // what this rank tells its peers
   uint64_t send_slot, recv_slot;
+  uint64_t land_gen, land_off, land_slot;  // the landing block this rank lends to a push form (land_gen = 0: none)
   const void* my_send;
   void* my_recv;
+  void* my_land;
   uint64_t tag;               // of this communicator: cache entries written under another tag are somebody else's
   const DsyncEntry* table;    // [kDsyncRanks][kDsyncArenas] in pinned host memory, written by the host (dsync_service)
   const int32_t* abort_word;  // host memory the GPU can read (the job's abort flag), may be null
@@ -279,8 +284,14 @@ hipError_t launch_dsync_done(const DsyncArgs& a, const DsyncResolved* res, hipSt
 // ---- stepped collectives in ONE kernel per rank (sched.hip): ring, recursive halving / doubling, binary tree ------------
 // All steps of the schedule run inside the kernel: worker w (a block) owns the tiles T of the buffer with T % W == w on
 // EVERY rank, so step k of worker w depends on step k-1 of worker w of one peer only -- one flag word per (peer, worker)
-// (DsyncPage allocation, `step`).  Data is PULLED: a step reads the peer's buffer (send or receive buffer, in place
-// included) and writes only local memory; the flag says "my step k is in my buffer".
+// (DsyncPage allocation, `step`).  Every schedule has two forms (sched_steps.h):
+//   PULL  a step reads the peer's buffer (send or receive buffer, in place included) and writes only local memory; the flag
+//         says "my step k is in my buffer" -- every payload byte crosses the link as a LOAD (a round trip per packet);
+//   PUSH  a step reads only local memory -- its own input and what the peers have stored here -- combines, and stores the
+//         result into the PEER's memory (its receive buffer, or its landing block where the receive buffer still holds an
+//         operand nobody has read: in place); the flag says "my step k is in YOUR memory" -- every payload byte crosses the
+//         link as a posted STORE, the reference's one-way message (network.go:562-571) without the ack.
+// Both forms combine the same operands in the same association: their results are bit-identical.
 enum DsyncSched : int32_t {
   SCHED_RING_ALLREDUCE = 1,  // reduce-scatter + allgather round each channel's ring, 2(N-1) steps
   SCHED_RHD_ALLREDUCE = 2,   // recursive halving + doubling, 2 log2 N steps; N no power of two: a fold-in and a fold-out step more
@@ -294,7 +305,8 @@ struct DsyncSchedArgs {
   int32_t sched, nchan; // nchan = gridDim.y: ring channels (each a different cyclic order of the ranks)
   int32_t root, pieces;
   uint64_t count;       // elements (allgather: per rank)
-  uint32_t elem_size, pad;
+  uint32_t elem_size;
+  uint32_t push;        // 1 = the push form
   uint8_t order[kMaxSchedChannels][kDsyncRanks];  // order[c][i]: the rank at position i of channel c's ring
 };
 hipError_t launch_dsync_sched(const DsyncSchedArgs& a, int dtype, int op, int grid_x, hipStream_t stream,

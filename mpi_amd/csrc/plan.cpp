@@ -6,6 +6,7 @@
 #include <unordered_map>
 
 #include "../../include/xmpi.h"
+#include "../../include/xmpi_test.h"
 
 namespace xmpi {
 namespace {

@@ -2,10 +2,12 @@
 //
 //   * the SPLIT form of the zero-copy collectives (meet / body / done: three launches, only two blocks ever wait);
 //   * the STEPPED schedules north_star names -- ring allreduce (reduce-scatter + allgather over several ring
-//     channels), recursive halving + doubling, ring allgather, binary-tree broadcast -- each as ONE kernel per
-//     rank that runs every step itself, step k of a worker released by a flag word the peer's worker wrote
-//     after its step k-1 (no host between the steps: what engine.cpp does with a host progress loop, an event
-//     and a counter in /dev/shm per step);
+//     channels), recursive halving + doubling, ring allgather, binary-tree broadcast and reduce -- each as ONE
+//     kernel per rank that runs every step itself, step k of a worker released by a flag word the peer's worker
+//     wrote after its step k-1 (no host between the steps: what engine.cpp does with a host progress loop, an
+//     event and a counter in /dev/shm per step); each in a PULL form (a step loads the peer's memory) and a PUSH
+//     form (a step stores into the peer's memory: the reference's one-way message, network.go:562-571) --
+//     sched_steps.h;
 //   * stream-ordered Send / Receive: the reference's message + ack (network.go:562-571, 616-624) as two
 //     64-byte records in the flag allocations and one pull of the payload.
 //
@@ -206,19 +208,23 @@ __global__ __launch_bounds__(64) void dsync_done_kernel(DsyncArgs a, const Dsync
 // stepped schedules
 // =====================================================================================================================
 
-// One tile: D[x] = A[x] (NS == 1) or A[x] op B[x] (NS == 2) for the byte offsets x in [lo, hi) -- multiples of
-// sizeof(T); all three are addressed with the SAME offset.  vec: the three bases are 16-byte aligned.
-// A is what a peer's kernel may have written a moment ago and D is what a peer's kernel will read next: both go
-// straight to memory at system scope (kdev.h ld_sys128_issue / st_sys128: no fence, no cache maintenance per step).
-// B is this rank's own data (its input, or what THIS block stored in an earlier step): an ordinary non-temporal load.
+// One tile: D[x] (and D2[x], when there is a second destination) = A[x] (NS == 1), A[x] op B[x] (NS == 2) or
+// C[x] op (A[x] op B[x]) (NS == 3) for the byte offsets x in [lo, hi) -- multiples of sizeof(T); every base is addressed with
+// the SAME offset.  vec: all bases are 16-byte aligned.
+// A and C are what a peer's kernel may have written a moment ago -- into ITS memory (pull form) or into this rank's (push
+// form) -- and D / D2 are what a peer's kernel, or a later step of this one, will read next: all of them go straight to memory
+// at system scope (kdev.h ld_sys128_issue / st_sys128: no fence, no cache maintenance per step).  B is this rank's own data (its
+// input, or what THIS block stored in an earlier step): an ordinary non-temporal load.
 template <typename T, int OP, int NS>
-__device__ __forceinline__ void tile_apply(char* D, const char* A, const char* B, size_t lo, size_t hi, bool vec) {
+__device__ __forceinline__ void tile_apply(char* D, char* D2, const char* A, const char* B, const char* C, size_t lo, size_t hi, bool vec) {
   const int t = threadIdx.x;
   constexpr size_t ES = sizeof(T);
   auto one = [&](size_t x) {
     T v = ld_sys_elem(reinterpret_cast<const T*>(A + x));
-    if constexpr (NS == 2) v = combine_any<T, OP>(v, *reinterpret_cast<const T*>(B + x));
+    if constexpr (NS >= 2) v = combine_any<T, OP>(v, *reinterpret_cast<const T*>(B + x));
+    if constexpr (NS == 3) v = combine_any<T, OP>(ld_sys_elem(reinterpret_cast<const T*>(C + x)), v);
     st_sys_elem(reinterpret_cast<T*>(D + x), v);
+    if (D2) st_sys_elem(reinterpret_cast<T*>(D2 + x), v);
   };
   if (vec) {
     const size_t plo = (lo + 15) & ~(size_t)15, phi = hi & ~(size_t)15;
@@ -227,28 +233,38 @@ __device__ __forceinline__ void tile_apply(char* D, const char* A, const char* B
         constexpr int U = (int)(kSchedTileBytes / 16 / kBlock);
         const pack_t* pa = reinterpret_cast<const pack_t*>(A + plo) + t;
         const pack_t* pb = reinterpret_cast<const pack_t*>(B + plo) + t;
+        const pack_t* pc = reinterpret_cast<const pack_t*>(C + plo) + t;
         pack_t* pd = reinterpret_cast<pack_t*>(D + plo) + t;
-        pack_t va[U], vb[U];
+        pack_t* pd2 = reinterpret_cast<pack_t*>(D2 + plo) + t;
+        pack_t va[U], vb[U], vc[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
           ld_sys128_issue(va[u], pa + u * kBlock);
-          if constexpr (NS == 2) vb[u] = ldp<2>(pb + u * kBlock);
+          if constexpr (NS == 3) ld_sys128_issue(vc[u], pc + u * kBlock);
+          if constexpr (NS >= 2) vb[u] = ldp<2>(pb + u * kBlock);
         }
         sys128_wait<U>(va);
+        if constexpr (NS == 3) sys128_wait<U>(vc);
 #pragma unroll
         for (int u = 0; u < U; u++) {
-          if constexpr (NS == 2) va[u] = combine16<T, OP>(va[u], vb[u]);
+          if constexpr (NS >= 2) va[u] = combine16<T, OP>(va[u], vb[u]);
+          if constexpr (NS == 3) va[u] = combine16<T, OP>(vc[u], va[u]);
           st_sys128(pd + u * kBlock, va[u]);
+          if (D2) st_sys128(pd2 + u * kBlock, va[u]);
         }
       } else {
         for (size_t x = plo + (size_t)t * 16; x < phi; x += (size_t)kBlock * 16) {
-          pack_t v[1];
+          pack_t v[1], c[1];
           ld_sys128_issue(v[0], reinterpret_cast<const pack_t*>(A + x));
+          if constexpr (NS == 3) ld_sys128_issue(c[0], reinterpret_cast<const pack_t*>(C + x));
           pack_t w;
-          if constexpr (NS == 2) w = ldp<2>(reinterpret_cast<const pack_t*>(B + x));
+          if constexpr (NS >= 2) w = ldp<2>(reinterpret_cast<const pack_t*>(B + x));
           sys128_wait<1>(v);
-          if constexpr (NS == 2) v[0] = combine16<T, OP>(v[0], w);
+          if constexpr (NS == 3) sys128_wait<1>(c);
+          if constexpr (NS >= 2) v[0] = combine16<T, OP>(v[0], w);
+          if constexpr (NS == 3) v[0] = combine16<T, OP>(c[0], v[0]);
           st_sys128(reinterpret_cast<pack_t*>(D + x), v[0]);
+          if (D2) st_sys128(reinterpret_cast<pack_t*>(D2 + x), v[0]);
         }
       }
       // the elements before the first and after the last whole packet (fewer than 16 bytes each)
@@ -265,16 +281,18 @@ __device__ __forceinline__ void tile_apply(char* D, const char* A, const char* B
 // worker w of W: the tiles ti of [rlo, rhi) with ti % W == w (tile = kSchedTileBytes of the buffer, counted from
 // the start of the BUFFER, not of the range: the same bytes belong to the same worker on every rank at every step)
 template <typename T, int OP, int NS>
-__device__ void range_apply(uint64_t D, uint64_t A, uint64_t B, size_t rlo, size_t rhi, uint32_t w, uint32_t W) {
+__device__ void range_apply(const SchedMove& m, uint32_t w, uint32_t W) {
+  const size_t rlo = m.lo, rhi = m.hi;
   if (rlo >= rhi) return;
-  const bool vec = ((D | A | (NS == 2 ? B : A)) & 15u) == 0;
+  const bool vec = ((m.D | m.D2 | m.A | (NS >= 2 ? m.B : 0) | (NS == 3 ? m.C : 0)) & 15u) == 0;
   constexpr size_t TB = kSchedTileBytes;
   const size_t t0 = rlo / TB;
   size_t ti = t0 + (size_t)((w + W - (uint32_t)(t0 % W)) % W);
   for (; ti * TB < rhi; ti += W) {
     const size_t lo = ti * TB > rlo ? ti * TB : rlo;
     const size_t hi = (ti + 1) * TB < rhi ? (ti + 1) * TB : rhi;
-    tile_apply<T, OP, NS>(reinterpret_cast<char*>(D), reinterpret_cast<const char*>(A), reinterpret_cast<const char*>(B), lo, hi, vec);
+    tile_apply<T, OP, NS>(reinterpret_cast<char*>(m.D), reinterpret_cast<char*>(m.D2), reinterpret_cast<const char*>(m.A),
+                          reinterpret_cast<const char*>(m.B), reinterpret_cast<const char*>(m.C), lo, hi, vec);
   }
 }
 
@@ -292,9 +310,9 @@ __global__ __launch_bounds__(kBlock) void dsync_sched_kernel(DsyncSchedArgs a) {
   if (sh.fail == DSYNC_OK) {
     const int nsteps = sched_nsteps(a);
     for (int g = 1; g <= nsteps; g++) {
-      if (t == 0) sched_step(a, sh.send, sh.recv, g, (int)blockIdx.y, &st);
+      if (t == 0) sched_step(a, sh.send, sh.recv, sh.land, g, (int)blockIdx.y, &st);
       __syncthreads();
-      const int wait_rank = st.wait_rank, ns = st.ns;
+      const int wait_rank = st.wait_rank;
       if (wait_rank >= 0) {
         if (t == 0) {
           const uint32_t why = dsync_spin(step_flags(mine) + (size_t)wait_rank * kStepSlots + w, (sh.epoch << 8) | st.wait_val, a.d);
@@ -304,13 +322,17 @@ __global__ __launch_bounds__(kBlock) void dsync_sched_kernel(DsyncSchedArgs a) {
         if (sh.fail != DSYNC_OK) break;
         // (no fence: what the peer's step stored was written through before its flag, and is loaded past the caches)
       }
-      const uint64_t D = st.D, A = st.A, B = st.B, lo = st.lo, hi = st.hi;
-      if (ns == 2) range_apply<T, OP, 2>(D, A, B, lo, hi, w, W);
-      else if (ns == 1) range_apply<uint8_t, OP_SUM, 1>(D, A, A, lo, hi, w, W);
+      for (int k = 0; k < st.nmv; k++) {
+        const SchedMove& m = st.mv[k];
+        if (m.ns == 3) range_apply<T, OP, 3>(m, w, W);
+        else if (m.ns == 2) range_apply<T, OP, 2>(m, w, W);
+        else range_apply<uint8_t, OP_SUM, 1>(m, w, W);
+      }
       XMPI_DRAIN();
       __syncthreads();
       if (t == 0 && (st.sig[0] >= 0 || st.sig[1] >= 0)) {
-        // every wave has waited for the acknowledgements of its (written-through) stores: the flag may follow them
+        // every wave has waited for the acknowledgements of its (written-through) stores -- into this rank's memory or, push
+        // form, into the peer's: the flag may follow them
         const uint64_t val = (sh.epoch << 8) | st.sig_val;
         for (int k = 0; k < 2; k++)
           if (st.sig[k] >= 0) st_sys64(step_flags(a.d.page[st.sig[k]]) + (size_t)me * kStepSlots + w, val);

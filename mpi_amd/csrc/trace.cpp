@@ -1,5 +1,6 @@
 // trace.cpp -- roctx ranges, the marker library resolved at run time (trace.h)
 #include "trace.h"
+#include "../../include/xmpi.h"
 
 #include <dlfcn.h>
 
@@ -56,8 +57,8 @@ const char* coll_name(int coll) {
   return coll >= 0 && coll < 4 ? names[coll] : "?";
 }
 const char* algo_name(int algo) {
-  static const char* const names[] = {"auto", "ring", "rhd", "direct", "tree", "zcopy", "zpush", "ll"};  // xmpi.h xmpi_algo
-  return algo >= 0 && algo < 8 ? names[algo] : "?";
+  static const char* const names[] = {"auto", "ring", "rhd", "direct", "tree", "zcopy", "zpush", "ll", "ring_push", "rhd_push", "tree_push"};  // xmpi.h xmpi_algo
+  return algo >= 0 && algo < XMPI_ALGO_COUNT ? names[algo] : "?";
 }
 
 }  // namespace xmpi

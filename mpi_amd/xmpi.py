@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libxmpi.so")
 # enums of include/xmpi.h
 U8, I32, I64, F16, F32, F64, BF16 = range(7)
 SUM, PROD, MIN, MAX = range(4)
-ALGO_AUTO, ALGO_RING, ALGO_RHD, ALGO_DIRECT, ALGO_TREE, ALGO_ZCOPY, ALGO_ZPUSH, ALGO_LL = range(8)
+ALGO_AUTO, ALGO_RING, ALGO_RHD, ALGO_DIRECT, ALGO_TREE, ALGO_ZCOPY, ALGO_ZPUSH, ALGO_LL, ALGO_RING_PUSH, ALGO_RHD_PUSH, ALGO_TREE_PUSH = range(11)
 COLL_ALLREDUCE, COLL_ALLGATHER, COLL_BCAST, COLL_REDUCE = range(4)
 PAT_UNIFORM, PAT_INDEX, PAT_CONST, PAT_SIGNED = range(4)
 PROF_REDUCE2, PROF_REDUCEN, PROF_COPY, PROF_PEER, PROF_ZCOPY = range(5)
@@ -102,7 +102,8 @@ SYMBOLS = [
     ("xmpi_recv_on_stream", _I, [_P, _P, _Z, _I, _I, _I, _P]),
     ("xmpi_tune", _I, [_P, _Z]),
     ("xmpi_tune_decide", _I, [C.POINTER(C.c_double), _I, C.c_double]),
-    ("xmpi_sched_dump", _I, [_I, _I, _I, _I, _I, _Z, _Z, _I, _I, C.c_char_p, _Z]),
+    ("xmpi_sched_dump", _I, [_I, _I, _I, _I, _I, _I, _I, _Z, _Z, _I, _I, C.c_char_p, _Z]),
+    ("xmpi_sched_land_bytes", _Z, [_I, _I, _I, _I, _I, _Z, _Z]),
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -153,15 +154,21 @@ SCHED_RING_ALLREDUCE, SCHED_RHD_ALLREDUCE, SCHED_RING_ALLGATHER, SCHED_TREE_BCAS
 
 
 def sched_text(sched: int, size: int, rank: int, root: int, pieces: int, count: int, elem_size: int, nchan: int,
-               channel: int) -> str:
-    """Step program of a stepped kernel (sched.hip) for one rank and channel (host logic only: works without a GPU)."""
+               channel: int, push: bool = False, inplace: bool = False) -> str:
+    """Step program of a stepped kernel (sched.hip) for one rank and channel, pull or push form (host logic only: works
+    without a GPU)."""
     L = lib()
-    n = L.xmpi_sched_dump(sched, size, rank, root, pieces, count, elem_size, nchan, channel, None, 0)
+    n = L.xmpi_sched_dump(sched, int(push), int(inplace), size, rank, root, pieces, count, elem_size, nchan, channel, None, 0)
     if n < 0:
         raise XmpiError(n, "xmpi_sched_dump")
     buf = C.create_string_buffer(n + 1)
-    L.xmpi_sched_dump(sched, size, rank, root, pieces, count, elem_size, nchan, channel, buf, n + 1)
+    L.xmpi_sched_dump(sched, int(push), int(inplace), size, rank, root, pieces, count, elem_size, nchan, channel, buf, n + 1)
     return buf.value.decode()
+
+
+def sched_land_bytes(sched: int, size: int, rank: int, root: int, count: int, elem_size: int, inplace: bool = False) -> int:
+    """bytes of the landing block `rank` lends to the push form of a stepped schedule"""
+    return lib().xmpi_sched_land_bytes(sched, int(inplace), size, rank, root, count, elem_size)
 
 
 def tune_decide(mean_us: Sequence[float], margin: float = 0.03) -> int:

@@ -126,6 +126,11 @@ MUTATIONS = {
     "agent": ("ll.hip",
               "    __syncthreads();\n    if (t == 0) {  // what ll_end does for a launched kernel of one block",
               "    /* MUTANT: lane 0 does not wait for the block's other lanes */\n    if (t == 0) {  // what ll_end does for a launched kernel of one block"),
+    # push form of the halving kernel: every level's half lands in ONE region of the partner's landing block instead of a region per
+    # level -- the partner of level k + 1 stores over what the owner may still be folding from level k, and no flag orders the two
+    "land": ("sched_steps.h",
+             "  for (int j = 1; j < k; j++) off += rhd_level_bytes(whole, j);",
+             "  (void)k;  /* MUTANT: every halving level lands in the same region */"),
     "done": ("kdev.h",
              "if (sh.fail == DSYNC_OK) why = dsync_spin(&mine->done[t][0], sh.epoch, a);",
              "/* MUTANT: nobody waits for the peers' done */"),

@@ -125,6 +125,16 @@ void allreduce_case(Rank& R, size_t count, int algo, int salt, const char* what,
   }
 }
 
+// in place: the receive buffer is the input (a push-form ring then lands its partial results in lent landing blocks)
+void allreduce_in_place_case(Rank& R, size_t count, int algo, int salt, const char* what) {
+  const int rank = R.rank;
+  std::vector<int64_t> v(count);
+  for (size_t i = 0; i < count; i++) v[i] = in_i64(rank, i, salt);
+  (void)xmpi_memcpy(R.c, R.recv, v.data(), count * 8);
+  CHECK(xmpi_allreduce(R.c, R.recv, R.recv, count, XMPI_I64, XMPI_SUM, algo));
+  (void)R.expect_sum_i64(count, salt, what);
+}
+
 void rank_main(const std::string& key, int rank, int size, int rounds) {
   Rank R;
   R.rank = rank;
@@ -293,6 +303,12 @@ void rank_main(const std::string& key, int rank, int size, int rounds) {
       for (size_t n : counts) {
         allreduce_case(R, n, XMPI_ALGO_RING, ++salt, "ring kernel");
         allreduce_case(R, n, XMPI_ALGO_RHD, ++salt, "halving kernel");
+        // the push forms: a step stores into the peer's receive buffer / landing block and reads only what landed here
+        allreduce_case(R, n, XMPI_ALGO_RING_PUSH, ++salt, "ring kernel, push");
+        allreduce_case(R, n, XMPI_ALGO_RHD_PUSH, ++salt, "halving kernel, push");
+        allreduce_in_place_case(R, n, XMPI_ALGO_RING_PUSH, ++salt, "ring kernel, push, in place");
+        allreduce_in_place_case(R, n, XMPI_ALGO_RHD_PUSH, ++salt, "halving kernel, push, in place");
+        allreduce_in_place_case(R, n, XMPI_ALGO_RING, ++salt, "ring kernel, in place");
       }
       if (!dev) allreduce_case(R, 40001, XMPI_ALGO_DIRECT, ++salt, "direct step table");
       if (dev && xmpi_get_param(c, "dsync_sched_launches") <= 0) {
@@ -303,7 +319,7 @@ void rank_main(const std::string& key, int rank, int size, int rounds) {
     // ---- broadcast / reduce: binary tree kernels and the fold --------------------------------------------------------------------
     if (wants("bcast") || wants("reduce")) {
       CHECK(xmpi_set_param(c, "tree_piece_bytes", 4096));
-      for (int algo : {(int)XMPI_ALGO_TREE, (int)XMPI_ALGO_AUTO})
+      for (int algo : {(int)XMPI_ALGO_TREE, (int)XMPI_ALGO_TREE_PUSH, (int)XMPI_ALGO_AUTO})
         for (int root : {0, size / 2, size - 1}) {
           const size_t n = 4099;
           R.fill_i64(n, ++salt);
@@ -319,12 +335,12 @@ void rank_main(const std::string& key, int rank, int size, int rounds) {
             }
           R.fill_i64(n, ++salt);
           CHECK(xmpi_reduce(c, R.send, R.recv, n, XMPI_I64, XMPI_SUM, root, algo));
-          if (rank == root) (void)R.expect_sum_i64(n, salt, algo == XMPI_ALGO_TREE ? "tree reduce" : "reduce");
+          if (rank == root) (void)R.expect_sum_i64(n, salt, algo == XMPI_ALGO_TREE ? "tree reduce" : algo == XMPI_ALGO_TREE_PUSH ? "tree reduce, push" : "reduce");
         }
     }
     // ---- allgather: ring kernel and the fold ------------------------------------------------------------------------------------------
     if (wants("allgather")) {
-      for (int algo : {(int)XMPI_ALGO_RING, (int)XMPI_ALGO_AUTO}) {
+      for (int algo : {(int)XMPI_ALGO_RING, (int)XMPI_ALGO_RING_PUSH, (int)XMPI_ALGO_AUTO}) {
         const size_t n = 2051;
         R.fill_i64(n, ++salt);
         CHECK(xmpi_allgather(c, R.send, R.recv, n, XMPI_I64, algo));
@@ -353,7 +369,7 @@ void rank_main(const std::string& key, int rank, int size, int rounds) {
       void* ws = xmpi_stream_create(c);
       const size_t sizes[] = {1, 17, 300, 2051, 4099, 20011};
       for (int k = 0; k < steps && g_bad.load() == 0; k++) {
-        const size_t form = draw(12), n = sizes[draw(6)];
+        const size_t form = draw(15), n = sizes[draw(6)];
         CHECK(xmpi_set_param(c, "dsync_split_bytes", form == 1 || form == 2 ? 1 : 0));
         CHECK(xmpi_set_param(c, "body_sys", form == 2 ? 1 : 0));
         CHECK(xmpi_set_param(c, "ll_bytes", form == 3 ? xmpi_get_param(c, "ll_max_bytes") : 0));
@@ -365,16 +381,20 @@ void rank_main(const std::string& key, int rank, int size, int rounds) {
           case 4: allreduce_case(R, n, XMPI_ALGO_RING, ++salt, "walk: ring kernel"); break;
           case 5: allreduce_case(R, n, XMPI_ALGO_RHD, ++salt, "walk: halving kernel"); break;
           case 6: allreduce_case(R, n, XMPI_ALGO_ZPUSH, ++salt, "walk: push-only"); break;
+          case 12: allreduce_case(R, n, XMPI_ALGO_RING_PUSH, ++salt, "walk: ring kernel, push"); break;
+          case 13: allreduce_case(R, n, XMPI_ALGO_RHD_PUSH, ++salt, "walk: halving kernel, push"); break;
+          case 14: allreduce_in_place_case(R, n, draw(2) ? XMPI_ALGO_RING_PUSH : XMPI_ALGO_RHD_PUSH, ++salt, "walk: push form in place"); break;
           case 7:
           case 8: {
-            const int root = (int)draw((uint64_t)size), algo = form == 7 ? (int)XMPI_ALGO_TREE : (int)XMPI_ALGO_AUTO;
+            const int root = (int)draw((uint64_t)size), algo = form == 7 ? (draw(2) ? (int)XMPI_ALGO_TREE : (int)XMPI_ALGO_TREE_PUSH) : (int)XMPI_ALGO_AUTO;
             R.fill_i64(n, ++salt);
             CHECK(xmpi_reduce(c, R.send, R.recv, n, XMPI_I64, XMPI_SUM, root, algo));
             if (rank == root) (void)R.expect_sum_i64(n, salt, "walk: reduce");
             break;
           }
           case 9: {
-            const int root = (int)draw((uint64_t)size), algo = draw(2) ? (int)XMPI_ALGO_TREE : (int)XMPI_ALGO_AUTO;
+            const int root = (int)draw((uint64_t)size), pick = (int)draw(3);
+            const int algo = pick == 0 ? (int)XMPI_ALGO_TREE : pick == 1 ? (int)XMPI_ALGO_TREE_PUSH : (int)XMPI_ALGO_AUTO;
             R.fill_i64(n, ++salt);
             if (rank == root) (void)xmpi_memcpy(c, R.recv, R.send, n * 8);
             else (void)xmpi_memset(c, R.recv, 0xEE, n * 8);
@@ -389,7 +409,8 @@ void rank_main(const std::string& key, int rank, int size, int rounds) {
             break;
           }
           case 10: {
-            const int algo = draw(2) ? (int)XMPI_ALGO_RING : (int)XMPI_ALGO_AUTO;
+            const int pick = (int)draw(3);
+            const int algo = pick == 0 ? (int)XMPI_ALGO_RING : pick == 1 ? (int)XMPI_ALGO_RING_PUSH : (int)XMPI_ALGO_AUTO;
             const size_t m = n > 4099 ? 4099 : n;
             R.fill_i64(m, ++salt);
             CHECK(xmpi_allgather(c, R.send, R.recv, m, XMPI_I64, algo));

@@ -9,7 +9,10 @@ import uuid
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_ranks(scenario: str, size: int, args: dict | None = None, timeout: float = 300.0, env: dict | None = None):
+def run_ranks(scenario: str, size: int, args: dict | None = None, timeout: float = 300.0, env: dict | None = None,
+              expect_failure: bool = False):
+    """expect_failure: the test WANTS ranks to fail (fault injection) -- the AssertionError is raised all the same, but no
+    post-mortem is left in gpurun_out/ (a fail_*.log there reads as an unexplained failure)"""
     key = f"t{os.getpid()}-{uuid.uuid4().hex[:8]}"
     e = dict(os.environ)
     e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -42,7 +45,7 @@ def run_ranks(scenario: str, size: int, args: dict | None = None, timeout: float
     if failed:
         msg = "\n".join(f"--- rank {i} (exit {procs[i].returncode}) ---\n{outs[i]}" for i in range(size))
         dump = os.path.join(ROOT, "gpurun_out")  # survives the GPU box: post-mortem of intermittent failures
-        if os.path.isdir(dump):
+        if os.path.isdir(dump) and not expect_failure:
             with open(os.path.join(dump, f"fail_{scenario}_{size}_{key}.log"), "w") as f:
                 f.write(msg)
         raise AssertionError(f"scenario {scenario} size {size}: ranks {failed} failed\n{msg}")

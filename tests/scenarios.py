@@ -1113,10 +1113,16 @@ def sc_sched(comm, args):
         comm.set_param("sched_channels", channels)
         comm.set_param("sched_grid", grid)
         for dtype in (xmpi.F32, xmpi.I64, xmpi.F16, xmpi.BF16, xmpi.U8, xmpi.F64, xmpi.I32):
-            for algo in (xmpi.ALGO_RING, xmpi.ALGO_RHD):
+            for algo in (xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_RING_PUSH, xmpi.ALGO_RHD_PUSH):
                 for count in args.get("counts", [1, 17, 4099, 65536 + 5]):
                     allreduce_case(comm, dtype, count, algo)
-        for algo in (xmpi.ALGO_RING, xmpi.ALGO_RHD):
+        # the push form of a schedule folds the same operands in the same association as its pull form: the same bits, on data
+        # where another order shows (f32 / f16 of both signs), out of place and in place
+        for pull, push in ((xmpi.ALGO_RING, xmpi.ALGO_RING_PUSH), (xmpi.ALGO_RHD, xmpi.ALGO_RHD_PUSH)):
+            for dtype, count in ((xmpi.F32, 100003), (xmpi.F16, 70001), (xmpi.F32, (1 << 20) + 1)):
+                for inplace in (False, True):
+                    same_bits_case(comm, dtype, count, pull, push, inplace)
+        for algo in (xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_RING_PUSH, xmpi.ALGO_RHD_PUSH):
             allreduce_case(comm, xmpi.F32, (3 << 20) + 7, algo, pattern=xmpi.PAT_SIGNED)
             allreduce_case(comm, xmpi.F32, (1 << 20) + 1, algo, inplace=True)
             allreduce_case(comm, xmpi.I64, 300007, algo, pattern=xmpi.PAT_UNIFORM, inplace=True, op=xmpi.PROD)
@@ -1126,22 +1132,24 @@ def sc_sched(comm, args):
                 allreduce_case(comm, xmpi.F32, 30011, algo, op=op, pattern=xmpi.PAT_SIGNED)
                 allreduce_case(comm, xmpi.BF16, 3001, algo, op=op, pattern=xmpi.PAT_SIGNED)
             allreduce_case(comm, xmpi.I64, 4097, algo, pattern=xmpi.PAT_CONST)
-        for dtype in (xmpi.I64, xmpi.U8, xmpi.F32):
-            for count in (1, 5, 1000, 4099, (1 << 20) + 3):
-                allgather_case(comm, dtype, count, xmpi.ALGO_RING)
-        allgather_case(comm, xmpi.I64, 70001, xmpi.ALGO_RING, inplace=True)
+        for algo in (xmpi.ALGO_RING, xmpi.ALGO_RING_PUSH):
+            for dtype in (xmpi.I64, xmpi.U8, xmpi.F32):
+                for count in (1, 5, 1000, 4099, (1 << 20) + 3):
+                    allgather_case(comm, dtype, count, algo)
+            allgather_case(comm, xmpi.I64, 70001, algo, inplace=True)
         for piece in (256 << 10, 4096):
             comm.set_param("tree_piece_bytes", piece)
             for root in sorted({0, size - 1, size // 2}):
                 for dtype, count in ((xmpi.U8, 1), (xmpi.U8, 37), (xmpi.I64, 4099), (xmpi.F32, (1 << 20) + 9)):
-                    es = xmpi.DTYPE_SIZE[dtype]
-                    buf = comm.alloc(count * es)
-                    comm.fill(buf, count, dtype, xmpi.PAT_UNIFORM, 40 + rank)
-                    comm.bcast(buf, count, dtype, root, xmpi.ALGO_TREE)
-                    got = buf.download(xmpi.NUMPY_DTYPE[dtype], count)
-                    want = oracle.fill(count, dtype, xmpi.PAT_UNIFORM, 40 + root)
-                    assert got.tobytes() == want.tobytes(), f"tree bcast root={root} {xmpi.DTYPE_NAME[dtype]} n={count} piece={piece}"
-                    buf.free()
+                    for algo in (xmpi.ALGO_TREE, xmpi.ALGO_TREE_PUSH):
+                        es = xmpi.DTYPE_SIZE[dtype]
+                        buf = comm.alloc(count * es)
+                        comm.fill(buf, count, dtype, xmpi.PAT_UNIFORM, 40 + rank)
+                        comm.bcast(buf, count, dtype, root, algo)
+                        got = buf.download(xmpi.NUMPY_DTYPE[dtype], count)
+                        want = oracle.fill(count, dtype, xmpi.PAT_UNIFORM, 40 + root)
+                        assert got.tobytes() == want.tobytes(), f"tree bcast root={root} {xmpi.DTYPE_NAME[dtype]} n={count} piece={piece} algo={algo}"
+                        buf.free()
             # the same tree upwards (SCHED_TREE_REDUCE): an inner node folds its children's partial results into its own,
             # piece by piece; a non-root's receive buffer is never written
             for root in sorted({0, size - 1, size // 2}):
@@ -1150,20 +1158,24 @@ def sc_sched(comm, args):
                                              (xmpi.BF16, 3001, xmpi.PAT_SIGNED, xmpi.MAX), (xmpi.I32, 70001, xmpi.PAT_SIGNED, xmpi.MIN),
                                              (xmpi.U8, 37, xmpi.PAT_UNIFORM, xmpi.SUM), (xmpi.F32, (1 << 20) + 9, xmpi.PAT_SIGNED, xmpi.SUM)):
                     exact = size <= 2 or dtype not in FLOATS or op != xmpi.SUM or (dtype == xmpi.F16 and pat == xmpi.PAT_UNIFORM)
-                    reduce_case(comm, dtype, count, root, xmpi.ALGO_TREE, op=op, pat=pat, exact=exact, what=f"tree reduce piece={piece}")
+                    pull = reduce_case(comm, dtype, count, root, xmpi.ALGO_TREE, op=op, pat=pat, exact=exact, what=f"tree reduce piece={piece}")
+                    push = reduce_case(comm, dtype, count, root, xmpi.ALGO_TREE_PUSH, op=op, pat=pat, exact=exact, what=f"tree reduce (push) piece={piece}")
+                    assert pull == push, f"tree reduce root={root} {xmpi.DTYPE_NAME[dtype]} n={count}: the push form's bits differ from the pull form's"
         comm.set_param("tree_piece_bytes", 256 << 10)
         # tree reduce in place at the root, and with a misaligned root buffer
         root = size // 2
         n = 50021
         buf = comm.alloc(n * 4 + 4)
         comm.fill(buf.at(4), n, xmpi.F32, xmpi.PAT_SIGNED, 70 + rank)
-        comm.reduce(buf.at(4), buf.at(4) if rank == root else None, n, xmpi.F32, xmpi.SUM, root, xmpi.ALGO_TREE)
-        ins = [oracle.fill(n, xmpi.F32, xmpi.PAT_SIGNED, 70 + r) for r in range(size)]
-        got = buf.download(np.float32, n, byte_offset=4)
-        if rank == root:
-            check_reduced(got, ins, xmpi.F32, xmpi.SUM, size <= 2, "tree reduce in place at the root")
-        else:
-            assert got.tobytes() == ins[rank].tobytes(), "tree reduce modified a non-root's input"
+        for algo in (xmpi.ALGO_TREE, xmpi.ALGO_TREE_PUSH):
+            comm.fill(buf.at(4), n, xmpi.F32, xmpi.PAT_SIGNED, 70 + rank)
+            comm.reduce(buf.at(4), buf.at(4) if rank == root else None, n, xmpi.F32, xmpi.SUM, root, algo)
+            ins = [oracle.fill(n, xmpi.F32, xmpi.PAT_SIGNED, 70 + r) for r in range(size)]
+            got = buf.download(np.float32, n, byte_offset=4)
+            if rank == root:
+                check_reduced(got, ins, xmpi.F32, xmpi.SUM, size <= 2, f"tree reduce in place at the root algo={algo}")
+            else:
+                assert got.tobytes() == ins[rank].tobytes(), "tree reduce modified a non-root's input"
         buf.free()
     comm.set_param("sched_channels", 0)
     comm.set_param("sched_grid", 0)
@@ -1189,19 +1201,42 @@ def bcast_case(comm, dtype, count, root, algo, seed=40, what="bcast"):
 
 
 def reduce_case(comm, dtype, count, root, algo, op=xmpi.SUM, pat=xmpi.PAT_SIGNED, exact=True, what="reduce"):
+    """returns the root's result as bytes (None elsewhere)"""
     rank, size = comm.rank(), comm.size()
     es = xmpi.DTYPE_SIZE[dtype]
     send, recv = comm.alloc(count * es), comm.alloc(count * es)
     comm.fill(send, count, dtype, pat, 70 + rank)
     comm.memset(recv, 0x3C, count * es)
     comm.reduce(send, recv if rank == root else None, count, dtype, op, root, algo)
+    out = None
     if rank == root:
         ins = [oracle.fill(count, dtype, pat, 70 + r) for r in range(size)]
-        check_reduced(recv.download(xmpi.NUMPY_DTYPE[dtype], count), ins, dtype, op, exact, f"{what} root={root} algo={algo}")
+        got = recv.download(xmpi.NUMPY_DTYPE[dtype], count)
+        check_reduced(got, ins, dtype, op, exact, f"{what} root={root} algo={algo}")
+        out = got.tobytes()
     else:
         assert recv.download(np.uint8, count * es).tobytes() == bytes([0x3C]) * (count * es), "reduce wrote a non-root's buffer"
     send.free()
     recv.free()
+    return out
+
+
+def same_bits_case(comm, dtype, count, pull, push, inplace):
+    """the same inputs through the pull and the push form of a schedule: bit-identical results on every rank"""
+    rank = comm.rank()
+    es = xmpi.DTYPE_SIZE[dtype]
+    out = []
+    for algo in (pull, push):
+        send = comm.alloc(count * es)
+        recv = send if inplace else comm.alloc(count * es)
+        comm.fill(send, count, dtype, xmpi.PAT_SIGNED, 300 + rank)
+        comm.allreduce(send, recv, count, dtype, xmpi.SUM, algo)
+        out.append(recv.download(np.uint8, count * es).tobytes())
+        if not inplace:
+            recv.free()
+        send.free()
+    assert out[0] == out[1], f"allreduce {xmpi.DTYPE_NAME[dtype]} n={count} inplace={inplace}: algo {push} and algo {pull} differ in " \
+                             f"{sum(a != b for a, b in zip(out[0], out[1]))} bytes"
 
 
 def _ll_agent_section(comm, maxb):
@@ -2117,8 +2152,8 @@ def sc_traffic(comm, args):
         for i in range(size):
             assert int(m[i, i].sum()) == 2 * c, f"{name}: device {i} moved {int(m[i, i].sum())} bytes of its own memory, plan {2 * c}"
         assert report[name]["hbm_per_device_max"] == 2 * S == report[name]["hbm_per_device_min"]  # N reads + N writes per element of a chunk (section 5)
-        # what the rendezvous costs a link: the announcement (6 words + the epoch) and the "done" word -- 64 bytes per ordered pair, no remote flag LOAD
-        assert report[name]["flag_page_remote_stores"] == 64 * size * (size - 1) and report[name]["flag_page_remote_loads"] == 0, report[name]
+        # what the rendezvous costs a link: the announcement (5 words + the epoch) and the "done" word -- 56 bytes per ordered pair, no remote flag LOAD
+        assert report[name]["flag_page_remote_stores"] == 56 * size * (size - 1) and report[name]["flag_page_remote_loads"] == 0, report[name]
     comm.set_param("body_sys", 0)
     # push only: chunk j of my buffer into rank j's scratch, then my reduced chunk into everybody's receive buffer; no remote load
     run("allreduce push only", allreduce(xmpi.ALGO_ZPUSH, **one), lambda i, j: (0, 2 * c))
@@ -2140,11 +2175,39 @@ def sc_traffic(comm, args):
             d = i ^ j
             want = 2 * S * d // size if d & (d - 1) == 0 else 0  # distance d: a block of S * d / N, once halving, once doubling
             assert int(m[i, j, 0]) == want, f"halving: device {i} loads {int(m[i, j, 0])} from device {j}, plan {want}"
+    # the PUSH forms of the stepped kernels: the same bytes over the same links, every one of them as a store
+    m = run("allreduce ring kernel, push", allreduce(xmpi.ALGO_RING_PUSH, **one))
+    for i in range(size):
+        assert abs(int(sum(m[i, j, 1] for j in range(size) if j != i)) - 2 * (size - 1) * c) <= ragged, f"ring push: device {i} stored {m[i, :size, 1]}"
+    r = report["allreduce ring kernel, push"]
+    assert r["remote_stores"] == size * 2 * (size - 1) * c and r["remote_loads"] == 0 and r["flag_page_remote_loads"] == 0, r
+    assert r["busiest_link_direction"] == report["allreduce ring kernel"]["busiest_link_direction"], "push and pull load the links differently"
+    assert comm.get_param("dsync_land_bytes") == 0, "an out-of-place push ring borrowed a landing block"
+
+    # in place: the receive buffer is the input, the partial results land in the landing blocks the ranks lend (one buffer's worth)
+    run("allreduce ring kernel, push, in place", lambda: comm.allreduce(recv, recv, count, xmpi.I64, xmpi.SUM, xmpi.ALGO_RING_PUSH))
+    r = report["allreduce ring kernel, push, in place"]
+    assert r["remote_stores"] == size * 2 * (size - 1) * c and r["remote_loads"] == 0, r
+    assert S <= comm.get_param("dsync_land_bytes") <= S + 32
+    m = run("allreduce halving kernel, push", allreduce(xmpi.ALGO_RHD_PUSH, **one))
+    assert report["allreduce halving kernel, push"]["remote_loads"] == 0
+    assert report["allreduce halving kernel, push"]["remote_stores"] == report["allreduce halving kernel"]["remote_loads"]
+    if pow2:
+        for i, j in pairs:
+            d = i ^ j
+            want = 2 * S * d // size if d & (d - 1) == 0 else 0
+            assert int(m[i, j, 1]) == want, f"halving push: device {i} stores {int(m[i, j, 1])} to device {j}, plan {want}"
     # allgather
     run("allgather fold", lambda: comm.allgather(send, recv, count, xmpi.I64, xmpi.ALGO_ZCOPY), lambda i, j: (0, S))
     m = run("allgather ring kernel", lambda: comm.allgather(send, recv, count, xmpi.I64, xmpi.ALGO_RING))
     for i in range(size):
         assert int(sum(m[i, j, 0] for j in range(size) if j != i)) == (size - 1) * S
+    m = run("allgather ring kernel, push", lambda: comm.allgather(send, recv, count, xmpi.I64, xmpi.ALGO_RING_PUSH))
+    # (which block a rank does NOT send on differs by channel -- the next rank's on that channel's ring -- and a channel's share of
+    # a block is whole tiles: per device within a tile per channel, all devices together to the byte)
+    for i in range(size):
+        assert abs(int(sum(m[i, j, 1] for j in range(size) if j != i)) - (size - 1) * S) <= ragged and int(sum(m[i, j, 0] for j in range(size) if j != i)) == 0
+    assert report["allgather ring kernel, push"]["remote_stores"] == size * (size - 1) * S
     run("allgather direct (step tables, copy engine)", lambda: comm.allgather(send, recv, count, xmpi.I64, xmpi.ALGO_DIRECT))
     # bcast / reduce, root 0
     def bcast_with(push_bytes):
@@ -2159,10 +2222,15 @@ def sc_traffic(comm, args):
     m = run("bcast tree kernel", lambda: comm.bcast(recv, count, xmpi.I64, 0, xmpi.ALGO_TREE))
     assert report["bcast tree kernel"]["remote_loads"] == (size - 1) * S and report["bcast tree kernel"]["remote_stores"] == 0
     assert all(int(m[0, j, 0]) == 0 for j in range(1, size)), "the root of a bcast read from somebody"
+    m = run("bcast tree kernel, push", lambda: comm.bcast(recv, count, xmpi.I64, 0, xmpi.ALGO_TREE_PUSH))
+    assert report["bcast tree kernel, push"]["remote_stores"] == (size - 1) * S and report["bcast tree kernel, push"]["remote_loads"] == 0
+    assert all(int(m[j, 0, 1]) == 0 for j in range(1, size)), "somebody stored into the root of a bcast"
     run("reduce fold (chunks, then to the root)", lambda: comm.reduce(send, recv if rank == 0 else None, count, xmpi.I64, xmpi.SUM, 0, xmpi.ALGO_AUTO),
         lambda i, j: (c, c if (j == 0 and i != 0) else 0))
     m = run("reduce tree kernel", lambda: comm.reduce(send, recv if rank == 0 else None, count, xmpi.I64, xmpi.SUM, 0, xmpi.ALGO_TREE))
     assert report["reduce tree kernel"]["remote_loads"] == (size - 1) * S and report["reduce tree kernel"]["remote_stores"] == 0
+    m = run("reduce tree kernel, push", lambda: comm.reduce(send, recv if rank == 0 else None, count, xmpi.I64, xmpi.SUM, 0, xmpi.ALGO_TREE_PUSH))
+    assert report["reduce tree kernel, push"]["remote_stores"] == (size - 1) * S and report["reduce tree kernel, push"]["remote_loads"] == 0
 
     # Send / Receive 0 -> 1: the receiver pulls the payload out of the sender's memory, once; nobody else moves a byte
     def p2p():

@@ -79,13 +79,16 @@ def test_the_sanitizer_sees_the_kernels_stores(tsan_bin):
 
 
 @pytest.mark.parametrize("mutant,scenario,where", [("step", "sched", ("st_sys128", "ld_sys128_issue")), ("done", "fold", ("hipMemcpyAsync",)),
-                                                   ("agent", "ll", ("ll_agent_collective", "hipMemcpyAsync"))])
+                                                   ("agent", "ll", ("ll_agent_collective", "hipMemcpyAsync")),
+                                                   ("land", "sched", ("st_sys128", "ld_sys128_issue"))])
 def test_the_sanitizer_finds_a_wait_taken_out_of_a_kernel(tsan_bin, mutant, scenario, where):
     """mutation: COPIES of the kernel sources with one wait removed (tests/devsim/build.py MUTATIONS; the product source is
     untouched) -- `step`: the stepped kernels no longer wait for the peer's step flag (races between a step's loads and the
     peer's written-through stores); `done`: the closing block no longer waits for the peers' "done" (the caller reads / refills
     buffers the peers' kernels still store into); `agent`: the LL agent's lane 0 answers its caller without waiting for the block's
-    other lanes (the caller downloads a receive buffer they still store into).  The harness must say so, in those places"""
+    other lanes (the caller downloads a receive buffer they still store into); `land`: the push form of the halving kernel lands
+    every level's half in ONE region of the partner's landing block instead of a region per level (the next level's partner stores
+    over what the owner may still be folding).  The harness must say so, in those places"""
     from tests.devsim import build
     r = run(build.build_mutant(mutant), "4", "1", scenario)
     assert r.returncode != 0 and "ThreadSanitizer: data race" in r.stderr, r.stderr[-3000:]
@@ -156,6 +159,11 @@ SCENARIOS = [
     ("p2p_semantics", 2, None),
     ("stream_ordered", 4, None),
     ("ll", 5, None),
+    # the stepped kernels, pull and push form: every dtype and operator, in place, odd alignments, channels and workers; the push
+    # form's bits against the pull form's
+    ("sched", 4, {"shapes": [(0, 0), (2, 3)], "counts": [1, 17, 4099]}),
+    ("sched", 3, {"shapes": [(1, 2)], "counts": [1, 4099]}),
+    ("sched", 8, {"shapes": [(0, 0)], "counts": [17]}),
     ("split", 4, {"counts": [1, 17, 4099]}),
     ("multistream", 4, None),
     ("p2p_stream", 4, None),
@@ -268,12 +276,28 @@ def test_the_scale_command_on_virtual_gpus(devsim_lib, gpus, tmp_path):
     assert d["zero_copy_probe"].startswith("ok")
     if gpus == 8:  # north_star's layout: one rank per GPU, ranks meet on the device, the library's tuner chose the schedule
         assert d["config"]["transport"] == "xGMI (one rank per GPU)" and d["ranks_meet"] == "on the device (dsync)"
-        assert d["roofline"]["kernel"].startswith("dsync_") and d["config"]["tuned"]
-        x = d["xgmi"]  # the link figure follows the schedule that was timed (what its busiest link direction carries)
-        assert x["busiest_link_direction_bytes_over_S"] == {"ring": 1.75 / 6, "rhd": 1.0}.get(x["schedule"], 0.25), x
-        assert abs(x["frac_of_link_peak"] - x["busiest_link_direction_bytes_over_S"] * d["config"]["bytes_per_rank"] / (d["ms_per_step"] * 1e-3) / 76.5e9) < 1e-9
+        assert d["roofline_hbm"]["kernel"].startswith("dsync_") and d["config"]["tuned"]
+        # the links bound it: `roofline` is the link roofline of the schedule that was timed -- what its busiest link direction carries
+        #  over the step time, against one direction of one link -- recomputable from the line's own fields
+        rf, x = d["roofline"], d["xgmi"]
+        assert rf["bound"] == "xgmi" and rf["peak"] == 76.8 and rf["unit"] == "GB/s" and rf["kernel"] == d["roofline_hbm"]["kernel"]
+        share = {"ring": 1.75 / 6, "ring_push": 1.75 / 6, "rhd": 1.0, "rhd_push": 1.0}.get(rf["schedule"], 0.25)
+        assert rf["busiest_link_direction_bytes_over_S"] == share == x["busiest_link_direction_bytes_over_S"] and rf["schedule"] == x["schedule"], rf
+        assert rf["algorithmic_bytes_per_link_direction"] == share * d["config"]["bytes_per_rank"]
+        assert abs(rf["achieved"] - rf["algorithmic_bytes_per_link_direction"] / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-9
+        assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and abs(x["frac_of_link_peak"] - rf["frac"]) < 1e-12
+        assert rf["peak_measured"] == x["link_probe"]["copy_kernel_write_GBps"] > 0 and abs(rf["frac_of_measured"] - rf["achieved"] / rf["peak_measured"]) < 1e-12
+        # north_star's target is quoted on ring: both forms of the ring kernel timed by name beside the library's choice
+        ring = d["ring"]
+        assert ring["best"] in ("pull", "push") and ring["channels"] == 6
+        for form in ("pull", "push"):
+            r = ring[form]
+            assert r["parity_ok"] is True and r["busbw_GBps"] > 0
+            assert abs(r["frac_of_link_peak"] - 1.75 / 6 * d["config"]["bytes_per_rank"] / (r["ms_per_step"] * 1e-3) / 76.8e9) < 1e-3 * r["frac_of_link_peak"]
+        assert d["cpu_baseline"]["see"].startswith("the N = 1 line")
     else:
         assert d["config"]["transport"].startswith(f"mixed: 8 ranks on {gpus} GPUs")
+        assert d["roofline"]["bound"] == "hbm" and "ring" not in d  # (several ranks per GPU: no link figure stands for the step)
 
 
 def test_the_8gpu_script_rehearsal(stage, devsim_lib, tmp_path):
