@@ -85,6 +85,10 @@ int main(int argc, char** argv) {
       algo = XMPI_ALGO_RING;
     } else if (mode == "rhd") {
       algo = XMPI_ALGO_RHD;
+    } else if (mode == "ring_push") {  // the push forms: every payload byte a posted store over its link
+      algo = XMPI_ALGO_RING_PUSH;
+    } else if (mode == "rhd_push") {
+      algo = XMPI_ALGO_RHD_PUSH;
     } else {
       fprintf(stderr, "unknown mode %s\n", mode.c_str());
       return 1;

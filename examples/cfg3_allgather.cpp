@@ -12,7 +12,7 @@
 #include <vector>
 
 #include "mpi.hpp"
-#include "xmpi_test.h"  // xmpi_fill_pattern: the inputs the CPU oracle can reproduce
+#include "xmpi_test.h"  // xmpi_fill_pattern: deterministic inputs a checker can regenerate
 
 static double now_us() {
   return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -46,7 +46,7 @@ int main(int argc, char** argv) {
   struct Sched {
     const char* name;
     int algo;
-  } scheds[] = {{"ring", XMPI_ALGO_RING}, {"auto", XMPI_ALGO_AUTO}};
+  } scheds[] = {{"ring", XMPI_ALGO_RING}, {"ring_push", XMPI_ALGO_RING_PUSH}, {"auto", XMPI_ALGO_AUTO}};
   std::string rows;
   uint64_t wrong = 0;
   for (const Sched& s : scheds) {

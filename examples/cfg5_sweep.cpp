@@ -16,7 +16,7 @@
 #include <vector>
 
 #include "mpi.hpp"
-#include "xmpi_test.h"  // xmpi_fill_pattern: the inputs the CPU oracle can reproduce
+#include "xmpi_test.h"  // xmpi_fill_pattern: deterministic inputs a checker can regenerate
 
 static double now_us() {
   return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -51,8 +51,11 @@ int main(int argc, char** argv) {
     const char* name;
     int algo;
   };
-  std::vector<Sched> scheds = {{"ring", XMPI_ALGO_RING}, {"auto", XMPI_ALGO_AUTO}};
-  if ((size & (size - 1)) == 0) scheds.insert(scheds.begin() + 1, {"rhd", XMPI_ALGO_RHD});
+  std::vector<Sched> scheds = {{"ring", XMPI_ALGO_RING}, {"ring_push", XMPI_ALGO_RING_PUSH}, {"auto", XMPI_ALGO_AUTO}};
+  if ((size & (size - 1)) == 0) {
+    scheds.insert(scheds.begin() + 2, {"rhd_push", XMPI_ALGO_RHD_PUSH});
+    scheds.insert(scheds.begin() + 2, {"rhd", XMPI_ALGO_RHD});
+  }
   std::string rows;
   int not_identical = 0;
   for (size_t bytes = (size_t)1 << 20; bytes <= max_bytes; bytes *= 4) {

@@ -82,10 +82,27 @@ type Backend struct {
 	Timeout  time.Duration
 	Password string
 	Device   int // 0 (zero value): $XMPI_DEVICE, else rank % visible GPUs; k > 0: GPU k-1
-	Algo     int // xmpi_algo, 0 = auto
+	Algo     int // xmpi_algo, 0 = auto (the library's tuned table); e.g. AlgoRingPush
 
 	comm *C.xmpi_comm
 }
+
+// The schedules a Backend can be told to use by name (xmpi.h xmpi_algo).  The *Push forms are the stepped kernels with every
+// payload byte STORED over its link instead of loaded (bit-identical results): which a node's links move faster is measured by
+// Tune, which times both.
+const (
+	AlgoAuto     = int(C.XMPI_ALGO_AUTO)
+	AlgoRing     = int(C.XMPI_ALGO_RING)
+	AlgoRHD      = int(C.XMPI_ALGO_RHD)
+	AlgoDirect   = int(C.XMPI_ALGO_DIRECT)
+	AlgoTree     = int(C.XMPI_ALGO_TREE)
+	AlgoZcopy    = int(C.XMPI_ALGO_ZCOPY)
+	AlgoZpush    = int(C.XMPI_ALGO_ZPUSH)
+	AlgoLL       = int(C.XMPI_ALGO_LL)
+	AlgoRingPush = int(C.XMPI_ALGO_RING_PUSH)
+	AlgoRHDPush  = int(C.XMPI_ALGO_RHD_PUSH)
+	AlgoTreePush = int(C.XMPI_ALGO_TREE_PUSH)
+)
 
 func status(rc C.int, where string) error {
 	if rc == 0 {
@@ -333,6 +350,11 @@ func (b *Backend) Allgather(send, recv interface{}) error {
 
 // Barrier is a host-side rendezvous of all ranks.
 func (b *Backend) Barrier() error { return status(C.xmpi_barrier(b.comm), "mpi barrier") }
+
+// Degraded reports what Init's vote left the job with: "" when every rank mapped every peer's memory, otherwise which level the job
+// runs at and the first reason a rank gave (the reference's Init returns an error only when the mesh cannot be built,
+// network.go:53-65 -- so does this one; a refused mapping degrades the job instead).
+func (b *Backend) Degraded() string { return C.GoString(C.xmpi_degraded(b.comm)) }
 
 // Tune lets the library time its own schedules on this job's GPUs and links for messages up to maxBytes per rank and keep
 // the winner per size class: Allreduce / Allgather (and the stream-ordered forms) follow that table from then on.  Collective:

@@ -108,6 +108,17 @@ typedef enum {
  * in the sorted -mpi-alladdr list, network.go:94-109).  device < 0 selects rank % ndev. */
 int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** out);
 
+/* The reference's Init returns an error only when the mesh cannot be built (network.go:53-65).  Here a rank that cannot map a
+ * peer's memory -- its HBM window, its (uncached) flag page -- does not fail the job either: inside xmpi_init every rank publishes
+ * what it could map and all of them take the best level EVERYBODY reached: ranks meeting on the device + windows (nothing
+ * degraded); ranks meeting on the host (a flag page nobody could allocate, export or map: the zero-copy collectives with a host
+ * rendezvous, the staged step tables for the rest); no windows (collectives device-synchronised only, Send / Receive out of
+ * registered buffers and host slices, no xmpi_send_nowait).  xmpi_init fails -- on every rank, with the reason -- only when
+ * neither is left.  xmpi_get_param("degraded") is the level as bits (1: the split form's data kernel at system scope, 2: ranks
+ * meet on the host, 4: no windows); this is the text: which level and the first reason a rank gave, "" when nothing is
+ * degraded. */
+const char* xmpi_degraded(const xmpi_comm* comm);
+
 /* Replaces mpi.Finalize -> (*Network).close (mpi.go:102-104, network.go:354-369). */
 int xmpi_finalize(xmpi_comm* comm);
 
@@ -121,8 +132,10 @@ int xmpi_device(const xmpi_comm* comm);
 int xmpi_barrier(xmpi_comm* comm);
 
 const char* xmpi_strerror(int code);
-/* Text of the last failure on this thread ("" if none). */
+/* Text of the last failure on this thread ("" if none): what the reference carries in its `error` values and panic messages
+ * (mpi.go:20-21, network.go:555,611). */
 const char* xmpi_last_error(void);
+/* (no counterpart in the reference) */
 const char* xmpi_version(void);
 
 /* ---- HBM buffers ------------------------------------------------------------------------ */
@@ -137,17 +150,19 @@ const char* xmpi_version(void);
  * these in its DeviceBuffer type. */
 void* xmpi_malloc(xmpi_comm* comm, size_t bytes);
 int xmpi_free(xmpi_comm* comm, void* dptr);
-/* Register / forget device memory that was NOT allocated by xmpi_malloc (e.g. a framework's
+/* (No counterpart in the reference: its payloads are Go values, network.go:539.)
+ * Register / forget device memory that was NOT allocated by xmpi_malloc (e.g. a framework's
  * allocator): [dptr, dptr+bytes) must lie inside one hipMalloc allocation of this rank's device.
  * Deregister before that allocation is freed.  Unregistered buffers still work with every
  * collective -- through the staged (window) path.  Memory of xmpi_malloc is registered as it is
  * (register: no-op, deregister: XMPI_ERR_ARG). */
 int xmpi_register(xmpi_comm* comm, void* dptr, size_t bytes);
 int xmpi_deregister(xmpi_comm* comm, void* dptr);
-/* Blocking copy between any two of {host, this rank's HBM}. */
+/* Blocking copy between any two of {host, this rank's HBM}; fill (no counterpart in the reference: a binding without a HIP
+ * binding of its own -- the cgo shim -- fills and reads DeviceBuffers through these). */
 int xmpi_memcpy(xmpi_comm* comm, void* dst, const void* src, size_t bytes);
 int xmpi_memset(xmpi_comm* comm, void* dst, int byte, size_t bytes);
-/* Wait until every stream of the communicator has drained. */
+/* Wait until every stream of the communicator has drained (no counterpart in the reference). */
 int xmpi_sync(xmpi_comm* comm);
 
 /* ---- point to point --------------------------------------------------------------------- */
@@ -203,15 +218,17 @@ int xmpi_probe(xmpi_comm* comm, int src, int tag, size_t* count, xmpi_dtype* dty
  * control block instead, and there unregistered buffers send every rank to the staged schedules
  * (RING / RHD / DIRECT / TREE through the HBM receive windows), which any rank can also ask for by name. */
 
-/* root's buffer replicated to every rank, bit-exact.  algo: TREE (binary tree) | ZCOPY | AUTO. */
+/* (absent from the reference, mpi.go:130)  root's buffer replicated to every rank, bit-exact.  algo: TREE | TREE_PUSH (binary
+ * tree, pull / push form) | ZCOPY | AUTO. */
 int xmpi_bcast(xmpi_comm* comm, void* buf, size_t count, xmpi_dtype dtype, int root, int algo);
 
-/* recvbuf (significant at root only) = op over ranks of sendbuf.  algo: TREE | DIRECT | ZCOPY | AUTO. */
+/* (absent from the reference, mpi.go:130)  recvbuf (significant at root only) = op over ranks of sendbuf.
+ * algo: TREE | TREE_PUSH | DIRECT | ZCOPY | AUTO. */
 int xmpi_reduce(xmpi_comm* comm, const void* sendbuf, void* recvbuf, size_t count,
                 xmpi_dtype dtype, xmpi_op op, int root, int algo);
 
-/* recvbuf = op over ranks of sendbuf, on every rank (sendbuf == recvbuf allowed).
- * algo: RING | RHD | DIRECT | ZCOPY | AUTO.  DIRECT and ZCOPY sum in rank order 0..N-1 (bit-identical
+/* (absent from the reference: the stub at mpi.go:130)  recvbuf = op over ranks of sendbuf, on every rank (sendbuf == recvbuf
+ * allowed).  algo: RING | RHD | RING_PUSH | RHD_PUSH | DIRECT | ZCOPY | ZPUSH | LL | AUTO.  DIRECT and ZCOPY sum in rank order 0..N-1 (bit-identical
  * to the reference-user composition "gather everything, add on the host in rank order"). */
 int xmpi_allreduce(xmpi_comm* comm, const void* sendbuf, void* recvbuf, size_t count,
                    xmpi_dtype dtype, xmpi_op op, int algo);
@@ -231,9 +248,10 @@ int xmpi_ibcast(xmpi_comm* comm, void* buf, size_t count, xmpi_dtype dtype, int 
                 xmpi_request** req);
 int xmpi_ireduce(xmpi_comm* comm, const void* sendbuf, void* recvbuf, size_t count,
                  xmpi_dtype dtype, xmpi_op op, int root, int algo, xmpi_request** req);
-/* *done = 1 once the operation has completed (xmpi_request_wait will not block). */
+/* The Wait of the sketched pair (mpi.go:132-152), for a collective.
+ * *done = 1 once the operation has completed (xmpi_request_wait will not block). */
 int xmpi_request_test(xmpi_request* req, int* done);
-/* Blocks until the operation completed, returns ITS status and frees the request. */
+/* Blocks until the operation completed, returns ITS status and frees the request (mpi.go:146-152: "Wait blocks until ..."). */
 int xmpi_request_wait(xmpi_request* req);
 
 /* Stream-ordered forms.  The collective is ENQUEUED on `stream` (a hipStream_t passed as void*; NULL = the
@@ -270,14 +288,14 @@ int xmpi_reduce_on_stream(xmpi_comm* comm, const void* sendbuf, void* recvbuf, s
 int xmpi_send_on_stream(xmpi_comm* comm, const void* buf, size_t count, xmpi_dtype dtype, int dest, int tag, void* stream);
 int xmpi_recv_on_stream(xmpi_comm* comm, void* buf, size_t capacity, xmpi_dtype dtype, int src, int tag, void* stream);
 
-/* Streams for callers without a HIP binding of their own (the cgo shim, ctypes): a non-blocking hipStream_t of
+/* (No counterpart in the reference.)  Streams for callers without a HIP binding of their own (the cgo shim, ctypes): a non-blocking hipStream_t of
  * the communicator's device; xmpi_stream_sync waits for everything enqueued on it (NULL = the communicator's
  * own stream) and returns the status of the collectives that ran on it. */
 void* xmpi_stream_create(xmpi_comm* comm);
 int xmpi_stream_destroy(xmpi_comm* comm, void* stream);
 int xmpi_stream_sync(xmpi_comm* comm, void* stream);
 
-/* hipGraph capture: the stream-ordered collectives enqueued on `stream` between xmpi_graph_begin and xmpi_graph_end
+/* (No counterpart in the reference.)  hipGraph capture: the stream-ordered collectives enqueued on `stream` between xmpi_graph_begin and xmpi_graph_end
  * (registered device buffers; call each once before capturing so that everything is mapped) become an executable
  * graph that xmpi_graph_launch replays -- one launch for the whole sequence, the caller's own kernels captured on
  * that stream included.  Every rank captures the same sequence and replays it equally often.  Needs ranks that
@@ -287,28 +305,31 @@ int xmpi_graph_end(xmpi_comm* comm, void* stream, void** graph);
 int xmpi_graph_launch(xmpi_comm* comm, void* graph, void* stream);
 int xmpi_graph_destroy(xmpi_comm* comm, void* graph);
 
-/* The same allreduce `iters` times back to back: the step loop of a benchmark without per-call
+/* (No counterpart in the reference; bounce.go:83-151 loops in Go.)  The same allreduce `iters` times back to back: the step loop of a benchmark without per-call
  * host-language overhead (bench.py hosts several ranks as Python threads, which would otherwise
  * queue for the interpreter lock between steps; a Go or C++ caller has no such cost).  With one process
  * per GPU the steps are enqueued on the communicator's stream and waited for once at the end. */
 int xmpi_allreduce_repeat(xmpi_comm* comm, const void* sendbuf, void* recvbuf, size_t count,
                           xmpi_dtype dtype, xmpi_op op, int algo, int iters);
 
-/* recvbuf[r*count : (r+1)*count] = rank r's sendbuf, bit-exact.  algo: RING | DIRECT | ZCOPY | AUTO. */
+/* (absent from the reference, mpi.go:130; its nearest idiom is the all-to-all of helloworld.go:53-81)
+ * recvbuf[r*count : (r+1)*count] = rank r's sendbuf, bit-exact.  algo: RING | RING_PUSH | DIRECT | ZCOPY | AUTO. */
 int xmpi_allgather(xmpi_comm* comm, const void* sendbuf, void* recvbuf, size_t count,
                    xmpi_dtype dtype, int algo);
 
 /* ---- local kernels (the HBM-bound pieces, exposed for parity tests and rooflines) --------- */
 
-/* dst[i] = a[i] op b[i]  (the per-chunk reduction every ring / halving step runs). */
+/* (No counterpart in the reference: a reference user adds on the host what Receive delivered, the helloworld.go:53-81 idiom.)
+ * dst[i] = a[i] op b[i]  (the per-chunk reduction every ring / halving step runs). */
 int xmpi_reduce_local(xmpi_comm* comm, void* dst, const void* a, const void* b, size_t count,
                       xmpi_dtype dtype, xmpi_op op);
-/* dst[i] = ((src[0][i] op src[1][i]) op src[2][i]) ... strictly left to right, nsrc <= 16. */
+/* dst[i] = ((src[0][i] op src[1][i]) op src[2][i]) ... strictly left to right, nsrc <= 16 -- the order in which a reference
+ * user who received every rank's buffer (helloworld.go:53-81) would add them. */
 int xmpi_reduce_local_n(xmpi_comm* comm, void* dst, const void* const* srcs, int nsrc,
                         size_t count, xmpi_dtype dtype, xmpi_op op);
-/* dst = src through the library's streaming copy kernel. */
+/* dst = src through the library's streaming copy kernel (no counterpart in the reference). */
 int xmpi_copy_local(xmpi_comm* comm, void* dst, const void* src, size_t bytes);
-/* The kernels of the zero-copy collectives, on local buffers: every dsts[k][i] = left-to-right fold
+/* (No counterpart in the reference.)  The kernels of the zero-copy collectives, on local buffers: every dsts[k][i] = left-to-right fold
  * of srcs[.][i] (one pass: nsrc reads + ndst writes per element), and dsts[k] = src. */
 int xmpi_reduce_local_multi(xmpi_comm* comm, void* const* dsts, int ndst, const void* const* srcs,
                             int nsrc, size_t count, xmpi_dtype dtype, xmpi_op op);
@@ -318,25 +339,28 @@ int xmpi_copy_local_multi(xmpi_comm* comm, void* const* dsts, int ndst, const vo
  * floats.Equal of examples/bounce/bounce.go:105,133 for HBM-resident data). */
 int xmpi_count_mismatch(xmpi_comm* comm, const void* a, const void* b, size_t bytes,
                         uint64_t* mismatching_bytes);
-/* sum of the buffer read as little-endian u32 words (mod 2^64) + trailing bytes. */
+/* sum of the buffer read as little-endian u32 words (mod 2^64) + trailing bytes (bounce.go:105's bytes.Equal, as a number two
+ * ranks can compare). */
 int xmpi_checksum(xmpi_comm* comm, const void* buf, size_t bytes, uint64_t* sum);
-/* stats[0] = max_i |a_i - b_i|, stats[1] = sum_i |b_i|, stats[2] = count of i with a NaN
+/* (bounce.go:133's floats.Equal with the differences spelled out)
+ * stats[0] = max_i |a_i - b_i|, stats[1] = sum_i |b_i|, stats[2] = count of i with a NaN
  * mismatch; a, b of dtype F16/BF16/F32/F64; accumulated in double. */
 int xmpi_diff_stats(xmpi_comm* comm, const void* a, const void* b, size_t count,
                     xmpi_dtype dtype, double stats[3]);
-/* *max_rel = max_i |a_i - b_i| / |b_i| (0/0 = 0, x/0 = inf; inf if a NaN sits on one side only), in double.  With
+/* (bounce.go:133 again, relative)  *max_rel = max_i |a_i - b_i| / |b_i| (0/0 = 0, x/0 = inf; inf if a NaN sits on one side only), in double.  With
  * non-negative inputs b_i (a rank-order sum) equals sum_r |x_r,i|, so this evaluates the per-element tolerance
  * rule |delta_i| <= tol * sum_r |x_r,i| of BASELINE.md for a whole buffer on the device. */
 int xmpi_diff_rel(xmpi_comm* comm, const void* a, const void* b, size_t count, xmpi_dtype dtype,
                   double* max_rel);
 /* ---- tuning / introspection ------------------------------------------------------------- */
 
-/* name in {"channels","piece_bytes","copy_engine","signal","timeout_s","fifo_depth"...};
- * see DESIGN.md.  Must be called identically on every rank. */
+/* The reference's only knobs are its flags (flags.go:44-50: addresses, -mpi-inittimeout, protocol, password).  Every name, its
+ * default and who is meant to set it: INTEGRATION.md section 5 (checked against the code by the CPU suite).  xmpi_set_param must
+ * be called identically on every rank; xmpi_get_param also reads the diagnostics listed there. */
 int xmpi_set_param(xmpi_comm* comm, const char* name, long value);
 long xmpi_get_param(const xmpi_comm* comm, const char* name);
 
-/* The library's own schedule table.  xmpi_tune times, on this job's real layout and links, the schedules it offers
+/* (No counterpart in the reference: it has one transport and one schedule.)  The library's own schedule table.  xmpi_tune times, on this job's real layout and links, the schedules it offers
  * for an allreduce (one zero-copy kernel with 1 or 2 packets in flight, the meet / body / done form, the push-only
  * form, the ring and the halving kernel each in its pull and its push form, LL lines) and an allgather, for message sizes 1 KiB ... max_bytes (x4 steps), lets
  * every rank see the slowest rank's figures and keeps the winner per size class: XMPI_ALGO_AUTO (and the
@@ -348,7 +372,8 @@ long xmpi_get_param(const xmpi_comm* comm, const char* name);
  * than 3 % (noise must not flip the schedule). */
 int xmpi_tune(xmpi_comm* comm, size_t max_bytes);
 
-/* Kernel profiling: when enabled every reduction / copy kernel launch is bracketed by HIP
+/* (No counterpart in the reference; bounce.go:140-151 prints wall-clock means.)
+ * Kernel profiling: when enabled every reduction / copy kernel launch is bracketed by HIP
  * events on the stream it runs on.  kind: 0 = reduce2, 1 = reduceN, 2 = copy kernel,
  * 3 = peer copy (hipMemcpyAsync or kernel push), 4 = zero-copy fold / multi-destination copy. */
 int xmpi_prof_enable(xmpi_comm* comm, int on);
@@ -356,12 +381,14 @@ int xmpi_prof_reset(xmpi_comm* comm);
 int xmpi_prof_get(xmpi_comm* comm, int kind, uint64_t* launches, double* total_ms,
                   uint64_t* bytes);
 
-/* Link diagnostic: times `iters` back-to-back copies of `bytes` between this rank's window and the
+/* Link diagnostic -- what examples/bounce is for in the reference (bounce.go:83-151), without a second program: times `iters`
+ * back-to-back copies of `bytes` between this rank's window and the
  * peer's (direction 0 = write to the peer, 1 = read from the peer; engine as "copy_engine").  The
  * peer must not be inside a collective; call it on both ranks of a pair for the bidirectional rate. */
 int xmpi_link_probe(xmpi_comm* comm, int peer, size_t bytes, int engine, int iters, int direction,
                     double* gbps);
 
+/* bytes per element of a dtype, 0 for an unknown one (the reference's payloads carry their type through gob, network.go:539) */
 size_t xmpi_dtype_size(xmpi_dtype dtype);
 
 #ifdef __cplusplus

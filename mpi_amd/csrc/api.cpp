@@ -18,6 +18,7 @@
 namespace xmpi {
 
 static thread_local std::string g_last_error;
+thread_local uint64_t t_api_call = 0;  // the number of the public call this thread is in (XMPI_ENTER)
 
 void set_last_error(const std::string& s) { g_last_error = s; }
 
@@ -61,7 +62,7 @@ static int use_device(const xmpi_comm* c) {
     }                                          \
     int _rc = ::xmpi::use_device(c);           \
     if (_rc) return _rc;                       \
-    (c)->api_calls.fetch_add(1, std::memory_order_relaxed); \
+    ::xmpi::t_api_call = (c)->api_calls.fetch_add(1, std::memory_order_relaxed) + 1; \
   } while (0)
 
 // no-progress limit of a steady-state wait: XMPI_TIMEOUT_S, or for ever
@@ -309,7 +310,7 @@ static void worker_main(xmpi_comm* c) {
       c->wq.pop_front();
     }
     g_last_error.clear();
-    c->api_calls.fetch_add(1, std::memory_order_relaxed);  // (before the job takes coll_mu: whoever holds it next has seen this -- dsync.cpp dsync_ll)
+    t_api_call = c->api_calls.fetch_add(1, std::memory_order_relaxed) + 1;  // (before the job takes coll_mu: whoever holds it next has seen this -- dsync.cpp dsync_ll)
     const int rc = job.first();
     {
       std::lock_guard<std::mutex> l(job.second->mu);
@@ -411,7 +412,7 @@ static int collective(xmpi_comm* c, int coll, int algo, int root, const void* se
   size_t chunk = total;
   if (coll == COLL_ALLREDUCE) chunk = total / (size_t)c->size / (size_t)std::max(1, pp.channels);
   pp.piece_bytes = choose_piece(c, chunk);
-  pp.fuse = c->fuse_ring ? 1 : 0;
+  pp.fuse = 1;  // ring: receive-reduce-send / receive-copy-send as one kernel
   pp.fifo_depth = c->fifo_depth;
   pp.oneshot_bytes = (size_t)std::max<long>(0, c->oneshot_bytes);
   Plan plan;
@@ -472,6 +473,8 @@ size_t xmpi_dtype_size(xmpi_dtype dtype) {
 }
 
 const char* xmpi_version(void) { return "xmpi 0.1 (gfx950, HIP)"; }
+
+const char* xmpi_degraded(const xmpi_comm* c) { return (c && !c->finalized) ? c->degraded_why.c_str() : ""; }
 
 const char* xmpi_last_error(void) { return g_last_error.c_str(); }
 
@@ -551,9 +554,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   c->channels = env_long("XMPI_CHANNELS", 0);  // 0 = one ring channel per available link direction
   c->piece_bytes = env_long("XMPI_PIECE_BYTES", 0);
   c->copy_engine = env_long("XMPI_COPY_ENGINE", 0);
-  c->dep_mode = env_long("XMPI_DEP_MODE", 0) ? 1 : 0;
   c->batch_copies = env_long("XMPI_BATCH_COPIES", 1) ? 1 : 0;
-  c->fuse_ring = env_long("XMPI_FUSE_RING", 1) ? 1 : 0;
   c->oneshot_bytes = std::max<long>(0, env_long("XMPI_ONESHOT_BYTES", 1 << 20));
   c->zero_copy = env_long("XMPI_ZERO_COPY", 1) ? 1 : 0;
   c->zc_bcast_push_bytes = std::max<long>(0, env_long("XMPI_ZC_BCAST_PUSH_BYTES", 256 << 10));
@@ -591,6 +592,8 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   }
   RankInfo* me = ctl->info(rank);
   me->device = device;
+  me->maps = 0;
+  me->maps_why[0] = 0;
   me->window_addr = (uint64_t)(uintptr_t)c->window;
   me->window_bytes = c->window_bytes;
   (void)hipDeviceGetPCIBusId(me->busid, (int)sizeof me->busid, device);
@@ -656,8 +659,14 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
       void* ptr = nullptr;
       e = ipc_open_shared(pi->pid, pi->window_addr, pi->ipc_handle, &ptr);
       if (e != hipSuccess) {
-        hip_fail(e, "hipIpcOpenMemHandle", __FILE__, __LINE__);
-        return fail(XMPI_ERR_HIP);
+        // not the end of the job: this rank says so in the vote below (dsync_connect) and every rank keeps to what does not need
+        // the windows -- the device-synchronised collectives on registered buffers, Send / Receive out of registered buffers
+        // and through the host lanes
+        (void)hipGetLastError();
+        if (!c->window_map_failed)
+          snprintf(me->maps_why, sizeof me->maps_why, "rank %d: hipIpcOpenMemHandle(window of rank %d): %s", rank, p, hipGetErrorString(e));
+        c->window_map_failed = true;
+        continue;
       }
       c->peer_window[p] = (char*)ptr;
       c->peer_opened[p] = true;
@@ -737,7 +746,7 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   else c->p2p_rec = nullptr;
   (void)hipGetLastError();
   XMPI_TRACE_STEP(rank, "init: connecting flag pages");
-  rc = dsync_connect(c);
+  rc = dsync_connect(c, timeout > 0 ? timeout : 3600.0);
   if (rc != XMPI_OK) return fail(rc);
   XMPI_TRACE_STEP(rank, "init: final barrier");
   c->dsync_unroll = env_long("XMPI_DSYNC_UNROLL", c->dsync_sharers > 1 ? 1 : 2);
@@ -1466,10 +1475,8 @@ int xmpi_set_param(xmpi_comm* c, const char* name, long value) {
   else if (n == "piece_bytes") c->piece_bytes = std::max<long>(0, value);
   else if (n == "copy_engine") c->copy_engine = value ? 1 : 0;
   else if (n == "timeout_s") c->timeout_s = value;
-  else if (n == "dep_mode") c->dep_mode = value ? 1 : 0;
   else if (n == "prof_every") c->prof_every = std::max<long>(1, value);
   else if (n == "batch_copies") c->batch_copies = value ? 1 : 0;
-  else if (n == "fuse_ring") c->fuse_ring = value ? 1 : 0;
   else if (n == "oneshot_bytes") c->oneshot_bytes = std::max<long>(0, value);
   else if (n == "zero_copy") c->zero_copy = value ? 1 : 0;
   else if (n == "zc_bcast_push_bytes") c->zc_bcast_push_bytes = std::max<long>(0, value);
@@ -1510,7 +1517,6 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
   if (n == "piece_bytes") return c->piece_bytes;
   if (n == "copy_engine") return c->copy_engine;
   if (n == "timeout_s") return c->timeout_s;
-  if (n == "dep_mode") return c->dep_mode;
   if (n == "zero_copy") return c->zero_copy;
   if (n == "heap_arenas" || n == "heap_reserved" || n == "heap_in_use") {
     size_t a = 0, r = 0, u = 0;
@@ -1557,6 +1563,15 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
   if (n == "dsync_split_launches") return (long)c->dsync_split_launches;
   if (n == "dsync_sched_launches") return (long)c->dsync_sched_launches;
   if (n == "dsync_land_bytes") return (long)c->dsync_land_bytes;
+  // what xmpi_init's vote left the job with: 0 = everything; bit 0 (1): the split form's data kernel runs at system scope (the XCD
+  // probe of THIS rank's GPU); bit 1 (2): the ranks meet on the host (some flag page could not be allocated, exported or mapped);
+  // bit 2 (4): no windows (some window could not be mapped: no staged step tables, no mail slots).  xmpi_degraded() says why.
+  if (n == "degraded") {
+    bool shared_gpu = false;  // (ranks hosted by threads of one process on one GPU meet on the host by design, not by degradation)
+    for (int p = 0; p < c->size; p++) shared_gpu = shared_gpu || c->peer_coloc[p];
+    return (c->body_sys == 1 && c->dsync_ok ? 1 : 0) | ((c->size > 1 && c->dsync && !c->dsync_ok && !shared_gpu) ? 2 : 0) | (c->windows_ok ? 0 : 4);
+  }
+  if (n == "windows_ok") return c->windows_ok ? 1 : 0;
   if (n == "sched_channels") return c->sched_channels;
   if (n == "sched_grid") return c->sched_grid;
   if (n == "tree_piece_bytes") return c->tree_piece_bytes;
@@ -1628,6 +1643,10 @@ int xmpi_link_probe(xmpi_comm* c, int peer, size_t bytes, int engine, int iters,
   XMPI_ENTER(c);
   if (peer < 0 || peer >= c->size || iters < 1 || !gbps) return XMPI_ERR_ARG;
   std::lock_guard<std::mutex> g(c->coll_mu);
+  if (!c->windows_ok) {
+    set_last_error("link probe: it copies between the HBM windows, which this job could not map (xmpi_degraded)");
+    return XMPI_ERR_UNSUPPORTED;
+  }
   {
     const int src = ensure_streams(c);
     if (src != XMPI_OK) return src;
@@ -2110,7 +2129,7 @@ int xmpi_plan_dump(int coll, int algo, int size, int rank, int root, size_t coun
   pp.channels = channels;
   pp.lanes = 2;
   pp.piece_bytes = piece_elems * elem_size;
-  pp.fuse = env_long("XMPI_FUSE_RING", 1) ? 1 : 0;
+  pp.fuse = 1;
   pp.fifo_depth = (int)env_long("XMPI_PLAN_FIFO_DEPTH", 8);
   pp.oneshot_bytes = (size_t)std::max<long>(0, env_long("XMPI_ONESHOT_BYTES", 1 << 20));
   Plan plan;

@@ -60,6 +60,12 @@ struct xmpi_comm {
   size_t window_bytes = 0;
   char* peer_window[xmpi::kMaxRanks] = {nullptr};
   bool peer_opened[xmpi::kMaxRanks] = {false};
+  // What the job agreed it can do (xmpi_init's vote, dsync_connect): a rank that cannot map a peer's window or flag page does not
+  // fail the job -- every rank publishes what it mapped, and all of them take the best level everybody reached (network.go:53-65:
+  // Init returns an error only when the mesh cannot be built).
+  bool windows_ok = true;        // every rank mapped every peer's window: the staged step tables and the mail slots exist
+  bool window_map_failed = false;  // ... this rank could not (before the vote)
+  std::string degraded_why;      // "" = nothing degraded; otherwise which level the job runs at and the first reason a rank gave
 
   // window layout (identical on every rank)
   int lanes = 2, fifo_depth = 8, p2p_depth = 2;
@@ -91,7 +97,6 @@ struct xmpi_comm {
   uint64_t p2p_direct_count = 0, p2p_staged_count = 0, p2p_lane_count = 0;  // receives served each way (diagnostic)
   uint64_t zc_retired_seen[xmpi::kMaxRanks] = {0};      // how far each peer's retire log has been processed
   long oneshot_bytes = 1 << 20;  // direct allreduce up to this size: push everything, fold locally
-  long fuse_ring = 1;    // ring: receive-reduce-send / receive-copy-send as one kernel
   long batch_copies = 1;  // with the copy kernel: all ready SENDs (RECV_COPYs) go out in one launch
   bool shared_stream = false;  // all of the above alias one per-device stream (co-located ranks)
   bool staged_streams = false;  // the per-peer / batch streams exist (made when a staged schedule first runs)
@@ -229,7 +234,6 @@ struct xmpi_comm {
   long copy_engine = 0;  // 0 = hipMemcpyAsync (SDMA / runtime blit), 1 = xmpi copy kernel
   long timeout_s = 0;  // no-progress limit of steady-state waits in seconds; 0 = for ever (the reference blocks indefinitely)
   double last_run_us = 0, last_sync_us = 0;  // timing of the most recent collective (diagnostic)
-  long dep_mode = 0;  // 0 = chain same-rank dependencies with stream events, 1 = wait on the host
 
   // scratch
   void* temp = nullptr;
@@ -271,7 +275,10 @@ int p2p_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int 
 int p2p_probe(xmpi_comm* c, int src, int tag, size_t* bytes, int* dtype);
 void p2p_agent_stop(xmpi_comm* c);
 // consecutive: the previous call into the library on this communicator was a collective the agent ran (its epoch + 1 is this one's)
-bool agent_submit_ll(xmpi_comm* c, const void* send, void* recv, size_t bytes, int ll_coll, int root, int dtype, int op, bool consecutive);
+// 1 = done, 0 = not taken (launch instead), -1 = failed after it was taken (engine.cpp)
+int agent_submit_ll(xmpi_comm* c, const void* send, void* recv, size_t bytes, int ll_coll, int root, int dtype, int op, bool consecutive);
+// the number of the public call this thread is in (XMPI_ENTER: the value its fetch_add of api_calls gave back, plus one)
+extern thread_local uint64_t t_api_call;
 void ll_agent_stop(xmpi_comm* c);
 // zcopy.cpp.  *done = false: some rank's buffers are not registered HBM -- every rank saw that and
 // the caller runs the staged schedule instead (no rank is left behind: the decision is collective).
@@ -294,7 +301,7 @@ hipStream_t stream_acquire(int device);
 void stream_release(int device, hipStream_t s);
 // dsync.cpp
 int dsync_prepare(xmpi_comm* c);
-int dsync_connect(xmpi_comm* c);
+int dsync_connect(xmpi_comm* c, double timeout_s);
 void dsync_finalize(xmpi_comm* c);
 void dsync_stop_helper(xmpi_comm* c);
 void dsync_service(xmpi_comm* c);

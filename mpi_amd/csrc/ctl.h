@@ -14,12 +14,12 @@
 
 namespace xmpi {
 
-constexpr int kMaxRanks = 16;
+constexpr int kMaxRanks = 8;  // one node of eight MI355X, one rank per GPU (the device side is sized by it: kernels.h kDsyncRanks)
 constexpr int kMaxLanes = 4;
 constexpr int kMailEntries = 4;  // concurrent messages per ordered rank pair
 constexpr int kHostLaneSlots = 4;  // pieces of a host-resident payload in flight per mail entry (the host lanes, below)
 constexpr uint64_t kCtlMagic = 0x584D504943544C31ull;  // "XMPICTL1"
-constexpr uint32_t kCtlVersion = 7;  // layout of the block: bump with every change of the structs below
+constexpr uint32_t kCtlVersion = 8;  // layout of the block: bump with every change of the structs below
 
 struct alignas(64) Counter {
   std::atomic<uint64_t> v;
@@ -69,7 +69,7 @@ struct alignas(64) RankInfo {
   std::atomic<int32_t> state;  // 0 absent, 1 joined, 2 window published, 3 left
   int32_t pid;
   int32_t device;
-  int32_t reserved;
+  int32_t maps;  // what this rank could map of its peers' memory (xmpi_init, before the vote): kMapsWindows | kMapsFlags
   uint64_t window_addr;   // device VA in the owner's process (used when peer pid == own pid)
   uint64_t window_bytes;
   uint8_t ipc_handle[64];  // hipIpcMemHandle_t of the window
@@ -77,7 +77,11 @@ struct alignas(64) RankInfo {
   uint64_t flag_addr;       // this rank's flag page (uncached HBM; device-synchronised collectives), 0 = none
   uint64_t flag_epoch;      // the highest epoch an earlier communicator left in that (pooled, never cleared) page
   uint8_t flag_handle[64];  // its hipIpcMemHandle_t
+  char maps_why[96];        // the first mapping this rank could not make, in words ("" = none)
+  int64_t ll_choice;        // the LL limit this rank would choose from what IT sees (ranks on its GPU, its environment): the job
+                            // takes the smallest -- LL or fold is a protocol choice every rank must make alike
 };
+constexpr int32_t kMapsWindows = 1, kMapsFlags = 2;
 
 // What a rank tells its peers about the user buffers of one zero-copy collective.  Two descriptors
 // per rank, used alternately (a rank may publish the next collective's while a slower peer still

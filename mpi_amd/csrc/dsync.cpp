@@ -48,6 +48,13 @@ int dsync_prepare(xmpi_comm* c) {
   RankInfo* me = c->ctl->info(c->rank);
   me->flag_addr = 0;
   if (c->size < 2 || !c->dsync) return XMPI_OK;
+  // a rank without a flag page does not fail the job: every rank sees flag_addr == 0 and keeps to the host-synchronised path;
+  // it says why (xmpi_degraded)
+  auto none = [&](const char* what, hipError_t e) {
+    (void)hipGetLastError();
+    if (!me->maps_why[0]) snprintf(me->maps_why, sizeof me->maps_why, "rank %d: %s: %s", c->rank, what, hipGetErrorString(e));
+    return XMPI_OK;
+  };
   // uncached HBM: the page is polled by this GPU and written by the others; it must never sit in an L2.
   // From the per-process pool (exported memory outlives communicators -- api.cpp), and NOT cleared when it is
   // re-used: clearing is GPU work on a page seven other processes have mapped, and in a crowded GPU (eight ranks
@@ -56,21 +63,21 @@ int dsync_prepare(xmpi_comm* c) {
   bool fresh = false;
   uint64_t last_epoch = 0;
   void* page = pool_acquire(c->device, kPageBytes, 1, &fresh, &last_epoch);
-  if (!page) {
-    (void)hipGetLastError();
-    return XMPI_OK;  // no such memory here: every rank sees flag_addr == 0 and keeps to the host-synchronised path
-  }
-  if (fresh && (hipMemsetAsync(page, 0, kPageBytes, c->local_stream) != hipSuccess || hipStreamSynchronize(c->local_stream) != hipSuccess)) {
-    (void)hipGetLastError();
-    pool_release(page, last_epoch);
-    return XMPI_OK;
+  if (!page) return none("hipExtMallocWithFlags(uncached flag page)", hipGetLastError());
+  if (fresh) {
+    hipError_t e = hipMemsetAsync(page, 0, kPageBytes, c->local_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->local_stream);
+    if (e != hipSuccess) {
+      pool_release(page, last_epoch);
+      return none("hipMemset(flag page)", e);
+    }
   }
   me->flag_epoch = last_epoch;
   hipIpcMemHandle_t h;
-  if (pool_handle(page, &h) != hipSuccess) {
-    (void)hipGetLastError();
+  const hipError_t he = pool_handle(page, &h);
+  if (he != hipSuccess) {
     pool_release(page, last_epoch);
-    return XMPI_OK;
+    return none("hipIpcGetMemHandle(uncached flag page)", he);
   }
   c->dpage = (DsyncPage*)page;
   static_assert(sizeof h <= sizeof me->flag_handle, "ipc handle size");
@@ -79,12 +86,21 @@ int dsync_prepare(xmpi_comm* c) {
   return XMPI_OK;
 }
 
-// Called by xmpi_init once every rank's RankInfo is visible.  Decides -- identically on every rank --
-// whether the job can synchronise on the device, and maps the peers' pages.
-int dsync_connect(xmpi_comm* c) {
+// Called by xmpi_init once every rank's RankInfo is visible.  Maps the peers' flag pages, then the job VOTES: every rank
+// publishes what it could map (the peers' windows: xmpi_init; their flag pages: here), all meet at a barrier, and every rank
+// reads the same answers -- the best level everybody reached:
+//   every flag page mapped by everybody    the ranks meet on the device (this file)
+//   otherwise                              they meet on the host (zcopy.cpp) and the staged step tables serve the rest
+//   some window not mapped                 no staged step tables and no mail slots: every collective takes the device-synchronised
+//                                          path, Send / Receive work out of registered buffers and through the host lanes
+//   neither                                xmpi_init fails -- on EVERY rank, at once, with the reason (the reference's Init returns an
+//                                          error only when the mesh cannot be built, network.go:53-65)
+// xmpi_get_param("degraded") / xmpi_degraded() say which and why.
+int dsync_connect(xmpi_comm* c, double timeout_s) {
   c->dsync_ok = false;
   if (c->size < 2) return XMPI_OK;
   const int N = c->size, mypid = (int)getpid();
+  RankInfo* me = c->ctl->info(c->rank);
   bool usable = true;
   int sharers = 0;
   for (int p = 0; p < N; p++) {
@@ -96,8 +112,8 @@ int dsync_connect(xmpi_comm* c) {
       if (a->pid == b->pid && a->device == b->device) usable = false;  // two ranks on one stream: see the header
     }
   }
-  if (!usable) return XMPI_OK;
-  for (int p = 0; p < N; p++) {
+  bool mapped = usable;
+  for (int p = 0; p < N && mapped; p++) {
     RankInfo* pi = c->ctl->info(p);
     if (p == c->rank) {
       c->peer_page[p] = c->dpage;
@@ -106,11 +122,74 @@ int dsync_connect(xmpi_comm* c) {
     } else {
       void* ptr = nullptr;
       hipError_t e = ipc_open_shared(pi->pid, pi->flag_addr, pi->flag_handle, &ptr);
-      if (e != hipSuccess) return hip_fail(e, "hipIpcOpenMemHandle(flag page)", __FILE__, __LINE__);
+      if (e != hipSuccess) {  // (an uncached allocation of ANOTHER device: nothing promises that the runtime opens it)
+        (void)hipGetLastError();
+        if (!me->maps_why[0])
+          snprintf(me->maps_why, sizeof me->maps_why, "rank %d: hipIpcOpenMemHandle(flag page of rank %d): %s", c->rank, p, hipGetErrorString(e));
+        mapped = false;
+        break;
+      }
       c->peer_page[p] = (DsyncPage*)ptr;
       c->peer_page_opened[p] = true;
     }
   }
+  // Untuned AUTO sends messages up to ll_bytes per rank as LL lines (ll.hip).  Measured with 2 processes (each kernel has the
+  // GPU it runs on to itself, as on a node with one rank per GPU): 4.9 / 6.1 / 6.4 us enqueued at 1 / 4 / 16 KiB against
+  // 8.9 / 8.8 / 9.4 for the fold; eight processes time-slicing ONE GPU: 45 / 56 / 65 against 47 / 47 / 42 (their polling lanes
+  // compete with each other's stores for the one memory system) -- so ranks that share a GPU would keep LL to 1 KiB, were it not for the agent:
+  // With the LL agent (ll.hip ll_agent_kernel) a BLOCKING call of up to 4 KiB needs no launch at all: eight processes on one GPU,
+  // blocking allreduce 7.9 / 9.2 us at 1 / 4 KiB against 38 / 45 launched (no kernel, so nothing for eight processes' queues to be
+  // time-sliced over) -- worth the 12 % an ENQUEUED 4 KiB LL collective loses to the fold there.  (The choice must not depend on
+  // how a rank calls -- a blocking rank and an enqueueing one have to run the same protocol -- so it is one limit for both.)
+  // What this rank sees -- the ranks on ITS GPU, ITS environment -- may differ from what a peer sees (5 ranks on 2 GPUs; a variable
+  // set for one rank): LL or fold is a protocol choice, a rank that folds while its peer sends lines waits for ever.  So every
+  // rank publishes its choice with its vote and the job takes the smallest.
+  c->dsync_sharers = std::max(1, sharers);
+  long mine = c->ll_bytes;
+  if (mine < 0) mine = c->dsync_sharers > 2 ? ((c->agent_ll && c->ll_agent_us > 0) ? 4096 : 1024) : 8192;
+  me->ll_choice = std::min<long>(mine, (long)kLLMaxPayload);
+  me->maps = (c->window_map_failed ? 0 : kMapsWindows) | (mapped ? kMapsFlags : 0);
+  int rc = c->ctl->barrier(timeout_s);  // ---- the vote: everything above is published, everything below is read by all alike
+  if (rc != XMPI_OK) {
+    set_last_error("xmpi_init: a peer did not reach the vote on what the job can map");
+    return rc;
+  }
+  bool all_windows = true, all_flags = usable;
+  std::string why_windows, why_flags;
+  long ll = (long)kLLMaxPayload;
+  for (int p = 0; p < N; p++) {
+    const RankInfo* a = c->ctl->info(p);
+    ll = std::min<long>(ll, (long)a->ll_choice);
+    const std::string why(a->maps_why, strnlen(a->maps_why, sizeof a->maps_why));
+    if (!(a->maps & kMapsWindows)) {
+      all_windows = false;
+      if (why_windows.empty()) why_windows = why.empty() ? "rank " + std::to_string(p) + " could not map a peer's window" : why;
+    }
+    if (usable && !(a->maps & kMapsFlags)) {
+      all_flags = false;
+      if (why_flags.empty()) why_flags = why.empty() ? "rank " + std::to_string(p) + " could not map a peer's flag page" : why;
+    }
+    if (!usable && c->dsync && a->flag_addr == 0 && why_flags.empty() && !why.empty()) why_flags = why;  // (it has no page to offer)
+  }
+  c->ll_bytes = std::max<long>(0, ll);
+  c->windows_ok = all_windows;
+  if (!all_flags)  // what this rank did map is of no use: nobody will write there
+    for (int p = 0; p < N; p++) {
+      if (c->peer_page_opened[p]) ipc_close_shared(c->peer_page[p]);
+      c->peer_page_opened[p] = false;
+      c->peer_page[p] = nullptr;
+    }
+  if (!all_windows && !all_flags) {
+    set_last_error("xmpi_init: the job has no transport left: " + why_windows + (why_flags.empty() ? "" : "; " + why_flags) +
+                   (usable ? "" : "; and the ranks cannot meet on the device (no flag pages, or ranks sharing a stream)"));
+    return XMPI_ERR_HIP;
+  }
+  if (!all_windows)
+    c->degraded_why = "no windows (no staged step tables, no mail slots; collectives: device-synchronised only): " + why_windows;
+  if (!all_flags && !why_flags.empty())
+    c->degraded_why += std::string(c->degraded_why.empty() ? "" : "; ") + "the ranks meet on the host (no device-synchronised collectives): " + why_flags;
+  if (!c->degraded_why.empty() && c->rank == 0) fprintf(stderr, "xmpi: degraded: %s\n", c->degraded_why.c_str());
+  if (!all_flags) return XMPI_OK;
   // the translation table {peer, slot} -> {registration number, where this process mapped it}: pinned host memory
   // the kernels read; the host is its only writer and needs no hardware queue to update it
   if (hipHostMalloc((void**)&c->dsync_table, sizeof(DsyncEntry) * kMaxRanks * kDsyncArenas, hipHostMallocMapped) != hipSuccess)
@@ -156,19 +235,6 @@ int dsync_connect(xmpi_comm* c) {
               c->rank, kXcdBlocks, c->xcd_probe_mask, c->xcds);
   }
   if (c->body_sys < 0) c->body_sys = 0;
-  // Every block of the kernel spins until the peers' kernels have started: the kernels of all ranks on this GPU
-  // must be resident at once, in at most half of its 8192 wave slots (4 waves per block).
-  c->dsync_sharers = std::max(1, sharers);
-  // Untuned AUTO sends messages up to ll_bytes per rank as LL lines (ll.hip).  Measured with 2 processes (each kernel has the
-  // GPU it runs on to itself, as on a node with one rank per GPU): 4.9 / 6.1 / 6.4 us enqueued at 1 / 4 / 16 KiB against
-  // 8.9 / 8.8 / 9.4 for the fold; eight processes time-slicing ONE GPU: 45 / 56 / 65 against 47 / 47 / 42 (their polling lanes
-  // compete with each other's stores for the one memory system) -- so ranks that share a GPU would keep LL to 1 KiB, were it not for the agent:
-  // With the LL agent (ll.hip ll_agent_kernel) a BLOCKING call of up to 4 KiB needs no launch at all: eight processes on one GPU,
-  // blocking allreduce 7.9 / 9.2 us at 1 / 4 KiB against 38 / 45 launched (no kernel, so nothing for eight processes' queues to be
-  // time-sliced over) -- worth the 12 % an ENQUEUED 4 KiB LL collective loses to the fold there.  (The choice must not depend on
-  // how a rank calls -- a blocking rank and an enqueueing one have to run the same protocol -- so it is one limit for both.)
-  if (c->ll_bytes < 0) c->ll_bytes = c->dsync_sharers > 2 ? ((c->agent_ll && c->ll_agent_us > 0) ? 4096 : 1024) : 8192;
-  c->ll_bytes = std::min<long>(c->ll_bytes, (long)kLLMaxPayload);
   // epochs of this communicator: above whatever earlier communicators left in ANY rank's (pooled, uncleared) page;
   // the same number on every rank.  It also tags the translations this communicator's kernels cache in the page.
   uint64_t base = 0;
@@ -537,7 +603,8 @@ static int dsync_ll(xmpi_comm* c, int coll, int root, const void* sendbuf, void*
       void* tmp = heap_alloc(c->device, unit);
       if (!tmp) return fail(XMPI_ERR_NOMEM);
       lent.push_back(tmp);
-      XMPI_HIP(hipMemcpyAsync(tmp, sendbuf, unit, hipMemcpyDefault, stream));
+      const hipError_t ce = hipMemcpyAsync(tmp, sendbuf, unit, hipMemcpyDefault, stream);
+      if (ce != hipSuccess) return fail(hip_fail(ce, "hipMemcpyAsync(stand-in)", __FILE__, __LINE__));
       send = tmp;
     }
   }
@@ -569,7 +636,9 @@ static int dsync_ll(xmpi_comm* c, int coll, int root, const void* sendbuf, void*
   // on the stream first.
   // (the streams are not asked when the previous call into the library on this communicator was itself a collective the agent
   // ran: it found them idle, and nothing has been enqueued through the library since)
-  const uint64_t calls = c->api_calls.load(std::memory_order_relaxed);
+  // THIS call's number (what its XMPI_ENTER drew), not the counter as it stands now: another thread of the communicator may have
+  // entered since -- it waits for coll_mu, is counted already, and what it goes on to enqueue is not this call's to vouch for
+  const uint64_t calls = t_api_call;
   auto idle = [](hipStream_t s) { return hipStreamQuery(s) == hipSuccess; };
   const bool quiet = calls == c->agent_quiet_at + 1, consecutive = calls == c->agent_epoch_at + 1;
   // up to agent_ll_bytes (8 KiB: a lane's two rounds of lines are waited for together -- blocking 8.8 us against 11.7 launched,
@@ -586,7 +655,12 @@ static int dsync_ll(xmpi_comm* c, int coll, int root, const void* sendbuf, void*
     // the previous one less than a patience ago -- and launching the ordinary kernel otherwise: 25.4 / 25.3 us per call, against
     // 14.4 / 21.5 with the agent started by every call (a launch into a GPU that has been idle for 100 us costs more than one into a
     // busy GPU; the agent's launch overlaps with the command already lying in its record) and 7.5 inside its patience.
-    if (agent_submit_ll(c, send, recv, unit, ll_coll, root, dtype, op, consecutive)) {
+    const int took = agent_submit_ll(c, send, recv, unit, ll_coll, root, dtype, op, consecutive);
+    if (took < 0) {  // taken and never answered: the collective has failed, nothing may run for this epoch beside the agent
+      set_last_error("collective: the LL agent did not answer within XMPI_TIMEOUT_S (a peer that never arrived?)");
+      return fail(XMPI_ERR_TIMEOUT);
+    }
+    if (took > 0) {
       c->agent_ll_wait_ns += (uint64_t)((now_seconds() - t_cmd) * 1e9);
       // (only when no other thread has entered the library on this communicator meanwhile: what it goes on to enqueue is not
       // this call's to vouch for)
@@ -629,18 +703,31 @@ static int dsync_ll(xmpi_comm* c, int coll, int root, const void* sendbuf, void*
     if (!pstart || !pstop) return fail(XMPI_ERR_HIP);
   }
   ++c->dsync_epoch;
-  XMPI_HIP(launch_dsync_ll(a, dtype, op, stream, pstart, pstop));
+  {
+    const hipError_t le = launch_dsync_ll(a, dtype, op, stream, pstart, pstop);
+    if (le != hipSuccess) {  // nothing was enqueued: the host's count goes back, the lent blocks too, and the peers -- whose kernels
+      --c->dsync_epoch;      // wait for this rank's lines -- are told through the job's abort flag (fail)
+      return fail(hip_fail(le, "LL kernel launch", __FILE__, __LINE__));
+    }
+  }
   c->dsync_launches++;
   c->dsync_ll_launches++;
   if (!capturing) c->dsync_last_stream = stream;
   const size_t traffic = 2 * unit * (size_t)N;  // (own payload read, N-1 pushes of twice its size ... : a latency path, not a bandwidth one)
   if (pstart) c->dsync_prof_pending.push_back({pstart, pstop, traffic});
   if (!blocking) {
-    if (out_tmp) XMPI_HIP(hipMemcpyAsync(recvbuf, out_tmp, recv_bytes, hipMemcpyDefault, stream));
+    if (out_tmp) {
+      const hipError_t ce = hipMemcpyAsync(recvbuf, out_tmp, recv_bytes, hipMemcpyDefault, stream);
+      if (ce != hipSuccess) return fail(hip_fail(ce, "hipMemcpyAsync(result of a stand-in)", __FILE__, __LINE__));
+    }
     if (!lent.empty()) {
       xmpi_comm::DsyncDeferred d;
       if (hipEventCreateWithFlags(&d.done, hipEventDisableTiming) != hipSuccess) return fail(XMPI_ERR_HIP);
-      XMPI_HIP(hipEventRecord(d.done, stream));
+      const hipError_t re = hipEventRecord(d.done, stream);
+      if (re != hipSuccess) {
+        (void)hipEventDestroy(d.done);
+        return fail(hip_fail(re, "hipEventRecord", __FILE__, __LINE__));
+      }
       d.bufs = lent;
       c->dsync_deferred.push_back(d);
     }
@@ -654,8 +741,9 @@ static int dsync_ll(xmpi_comm* c, int coll, int root, const void* sendbuf, void*
   if (host_out) {
     memcpy(recvbuf, c->host_bounce + xmpi_comm::kHostBounce, recv_bytes);
   } else if (out_tmp) {
-    XMPI_HIP(hipMemcpyAsync(recvbuf, out_tmp, recv_bytes, hipMemcpyDefault, stream));
-    XMPI_HIP(hipStreamSynchronize(stream));
+    hipError_t ce = hipMemcpyAsync(recvbuf, out_tmp, recv_bytes, hipMemcpyDefault, stream);
+    if (ce == hipSuccess) ce = hipStreamSynchronize(stream);
+    if (ce != hipSuccess) return fail(hip_fail(ce, "copy of a stand-in's result", __FILE__, __LINE__));
   }
   for (void* p : lent) (void)heap_free(p);
   lent.clear();
@@ -690,6 +778,7 @@ int dsync_grid(const xmpi_comm* c, size_t packets_per_segment, int nseg, int unr
 // and the arguments only)
 bool dsync_takes(const xmpi_comm* c, int coll, int algo) {
   if (!dsync_usable(c)) return false;
+  if (!c->windows_ok) return true;  // a job without windows has no staged step tables: DIRECT and whatever else names them is the fold
   switch (algo) {
     case XMPI_ALGO_AUTO: return c->zero_copy != 0;
     case XMPI_ALGO_ZCOPY:
@@ -731,6 +820,14 @@ static void tuned_choice(const xmpi_comm* c, int coll, size_t bytes, int* algo, 
   }
 }
 
+// a HIP failure inside a collective that has already borrowed blocks or advanced the epoch: the blocks go back and the peers --
+// whose kernels would wait for this rank -- are told through the job's abort flag (the function's `fail`)
+#define DS_HIP(call)                                                                 \
+  do {                                                                               \
+    const hipError_t _e = (call);                                                    \
+    if (_e != hipSuccess) return fail(::xmpi::hip_fail(_e, #call, __FILE__, __LINE__)); \
+  } while (0)
+
 // One device-synchronised collective, enqueued on `stream`.  blocking: wait for it (the xmpi_allreduce family);
 // otherwise return once it is enqueued (xmpi_*_on_stream).  Every rank of the job takes this path for the same
 // calls (the decision depends on the communicator and the arguments only), so the epochs agree.
@@ -742,7 +839,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
   const size_t recv_bytes = (coll == COLL_ALLGATHER) ? send_bytes * (size_t)N : send_bytes;
   const bool recv_significant = (coll != COLL_REDUCE) || me == root;
   if (!stream) stream = c->local_stream;
-  const uint64_t calls_at_entry = c->api_calls.load(std::memory_order_relaxed);  // (dsync_ll's shortcut: see agent_quiet_at)
+  const uint64_t calls_at_entry = t_api_call;  // (dsync_ll's shortcut: see agent_quiet_at)
   dsync_service(c);
   reap_deferred(c, false);
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -800,10 +897,10 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
       // stream order) -- the runtime's copy out of pageable memory is a staged, synchronous affair of 10 us and more
       if (blocking && send_bytes <= xmpi_comm::kHostBounce && c->p2p_tickets && !is_device_pointer(sendbuf) && host_bounce_ready(c)) {
         memcpy(c->host_bounce, sendbuf, send_bytes);
-        XMPI_HIP(bounce_copy(c, r.tmp_send, c->host_bounce_dev, send_bytes, 0, nullptr, 0, stream));
+        DS_HIP(bounce_copy(c, r.tmp_send, c->host_bounce_dev, send_bytes, 0, nullptr, 0, stream));
         c->host_bounce_calls++;
       } else {
-        XMPI_HIP(hipMemcpyAsync(r.tmp_send, sendbuf, send_bytes, hipMemcpyDefault, stream));
+        DS_HIP(hipMemcpyAsync(r.tmp_send, sendbuf, send_bytes, hipMemcpyDefault, stream));
       }
     }
     r.send = r.tmp_send;
@@ -1006,7 +1103,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     {
       RoctxRange lr("xmpi:launch sched=%d channels=%d workers=%d pieces=%d epoch=%llu", sa.sched, nchan, gx, sa.pieces,
                     (unsigned long long)c->dsync_epoch);
-      XMPI_HIP(launch_dsync_sched(sa, dtype, op, gx, stream, sampled ? pstart : nullptr, sampled ? pstop : nullptr));
+      DS_HIP(launch_dsync_sched(sa, dtype, op, gx, stream, sampled ? pstart : nullptr, sampled ? pstop : nullptr));
     }
     c->dsync_launches++;
     c->dsync_sched_launches++;
@@ -1035,7 +1132,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
       const void* srcs[kMaxRanks];
       for (int p = 0; p < N; p++) srcs[p] = (p == me) ? (const char*)r.send + (size_t)me * cb : (const char*)r.recv + (size_t)p * cb;
       void* d1[1] = {(char*)r.recv + (size_t)me * cb};
-      XMPI_HIP(launch_reduce_n_multi(d1, 1, srcs, N, C, dtype, op, stream));
+      DS_HIP(launch_reduce_n_multi(d1, 1, srcs, N, C, dtype, op, stream));
       traffic += (size_t)(N + 1) * cb;
       memset(a.seg, 0, sizeof a.seg);
       a.nseg = 1;
@@ -1114,7 +1211,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
   if (!capturing) c->dsync_last_stream = stream;
 
   if (host_out) {
-    XMPI_HIP(bounce_copy(c, c->host_bounce_dev + xmpi_comm::kHostBounce, out_src, recv_bytes, 1, done_dev, done_id, stream));
+    DS_HIP(bounce_copy(c, c->host_bounce_dev + xmpi_comm::kHostBounce, out_src, recv_bytes, 1, done_dev, done_id, stream));
     c->host_bounce_calls++;
   }
 
@@ -1125,11 +1222,11 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
   //    peers; the stream-ordered forms take device memory only, where the copy really is asynchronous.)
   if (!blocking) {
     if (pstart) c->dsync_prof_pending.push_back({pstart, pstop, traffic});
-    if (out_src) XMPI_HIP(hipMemcpyAsync(recvbuf, out_src, recv_bytes, hipMemcpyDeviceToDevice, stream));
+    if (out_src) DS_HIP(hipMemcpyAsync(recvbuf, out_src, recv_bytes, hipMemcpyDeviceToDevice, stream));
     if (!lent.empty()) {
       xmpi_comm::DsyncDeferred d;
       if (hipEventCreateWithFlags(&d.done, hipEventDisableTiming) != hipSuccess) return fail(XMPI_ERR_HIP);
-      XMPI_HIP(hipEventRecord(d.done, stream));
+      DS_HIP(hipEventRecord(d.done, stream));
       d.bufs = lent;
       c->dsync_deferred.push_back(d);
     }
@@ -1142,8 +1239,8 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
   if (host_out) {
     memcpy(recvbuf, c->host_bounce + xmpi_comm::kHostBounce, recv_bytes);
   } else if (out_src) {
-    XMPI_HIP(hipMemcpyAsync(recvbuf, out_src, recv_bytes, hipMemcpyDefault, stream));
-    XMPI_HIP(hipStreamSynchronize(stream));
+    DS_HIP(hipMemcpyAsync(recvbuf, out_src, recv_bytes, hipMemcpyDefault, stream));
+    DS_HIP(hipStreamSynchronize(stream));
   }
   for (void* p : lent) (void)heap_free(p);
   lent.clear();

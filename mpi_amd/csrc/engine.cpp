@@ -148,13 +148,10 @@ struct Exec {
     return c->local_stream;
   }
 
-  // dep_mode 0: a step may be enqueued once its dependencies are enqueued (chained with
-  // hipStreamWaitEvent); dep_mode 1: only once they have completed (no stream ever waits on
-  // another, so streams sharing a hardware queue cannot stall each other)
+  // a step may be enqueued once its dependencies are enqueued (chained with hipStreamWaitEvent)
   bool deps_issued(const Step& s) const {
-    const uint8_t need = c->dep_mode == 1 ? 2 : 1;
     for (int d = 0; d < s.ndeps; d++)
-      if (state[(size_t)s.deps[d]] < need) return false;
+      if (state[(size_t)s.deps[d]] < 1) return false;
     return true;
   }
 
@@ -612,6 +609,10 @@ struct Exec {
 
 int run_plan(xmpi_comm* c, const Plan& plan, const void* sendbuf, void* recvbuf, int dtype, int op) {
   if (plan.steps.empty()) return XMPI_OK;
+  if (!c->windows_ok) {  // (api.cpp collective() sends every call of such a job to the device-synchronised path: not reached)
+    set_last_error("the staged step tables need the HBM windows, which this job could not map (xmpi_degraded)");
+    return XMPI_ERR_UNSUPPORTED;
+  }
   RoctxRange range("xmpi:run_plan steps=%zu", plan.steps.size());
   {
     const int src = ensure_streams(c);
@@ -696,6 +697,12 @@ bool withdraw(MailEntry* m) {
   if (!m->state.compare_exchange_strong(expect, MAIL_CLAIMED, std::memory_order_acq_rel)) return false;
   m->pipe.head.v.store(0, std::memory_order_relaxed);
   m->pipe.tail.v.store(0, std::memory_order_relaxed);
+  m->state.store(MAIL_FREE, std::memory_order_release);
+  return true;
+}
+
+// an entry this rank has claimed but not posted goes back
+static bool withdraw_claimed(MailEntry* m) {
   m->state.store(MAIL_FREE, std::memory_order_release);
   return true;
 }
@@ -853,13 +860,14 @@ void p2p_agent_stop(xmpi_comm* c) {
 
 // ---- the LL agent: a one-block kernel that lingers behind a blocking small collective (ll.hip ll_agent_kernel) -------------
 // The command record and the conversation are the receive agent's (above); the caller holds coll_mu (dsync.cpp dsync_ll), so
-// there is one command at a time by construction.  true: the agent ran the collective and everything it wrote is visible;
-// false: not taken (no agent, broken, job aborted) -- nothing has happened that a launched LL kernel of the same epoch would
-// not repeat line for line.
-bool agent_submit_ll(xmpi_comm* c, const void* send, void* recv, size_t bytes, int ll_coll, int root, int dtype, int op, bool consecutive) {
+// there is one command at a time by construction.  1: the agent ran the collective and everything it wrote is visible;
+// 0: not taken (no agent, broken, job aborted) -- nothing has happened that a launched LL kernel of the same epoch would
+// not repeat line for line; -1: the agent took it and never answered within the no-progress limit (+ 5 s) -- the collective has
+// FAILED (the job's abort flag is set): the caller must not launch anything for this epoch beside an agent that may still run.
+int agent_submit_ll(xmpi_comm* c, const void* send, void* recv, size_t bytes, int ll_coll, int root, int dtype, int op, bool consecutive) {
   if (c->ll_agent_us <= 0 || !c->ll_cmd_dev || !c->dsync_ok || !c->dpage || c->size < 2 || c->size > kDsyncRanks || bytes == 0 ||
       bytes > kLLMaxPayload)
-    return false;
+    return 0;
   volatile uint64_t* cmd = c->ll_cmd;
   if (c->ll_agent_running && __atomic_load_n((const uint64_t*)&cmd[7], __ATOMIC_ACQUIRE) != 0) c->ll_agent_running = false;  // it said it went: started again below
   const uint64_t seq = ++c->ll_agent_seq;
@@ -900,7 +908,7 @@ bool agent_submit_ll(xmpi_comm* c, const void* send, void* recv, size_t bytes, i
   auto withdraw = [&]() {
     __atomic_store_n((uint64_t*)&cmd[0], 0, __ATOMIC_RELEASE);  // nobody may act on it any more
     --c->ll_agent_seq;
-    return false;
+    return 0;
   };
   if (!c->ll_agent_running && !launch()) return withdraw();
   Backoff bo;
@@ -919,23 +927,35 @@ bool agent_submit_ll(xmpi_comm* c, const void* send, void* recv, size_t bytes, i
     // takes over.  A dead PEER is the agent's own business (ll_gather gives up within the no-progress limit and says why);
     // this thread allows it that limit and a little more.
     if ((spins & 0xfff) == 0) {
-      bool give_up = c->timeout_s > 0 && now_seconds() - t0 > (double)c->timeout_s + 5.0;
-      if (!give_up) {
-        const hipError_t e = hipStreamQuery(c->ll_agent_stream);
-        (void)hipGetLastError();
-        if (e != hipErrorNotReady)
-          give_up = __atomic_load_n((const uint64_t*)&cmd[6], __ATOMIC_ACQUIRE) != seq && __atomic_load_n((const uint64_t*)&cmd[7], __ATOMIC_ACQUIRE) == 0;
-      }
-      if (give_up) {
-        if (__atomic_load_n((const uint64_t*)&cmd[6], __ATOMIC_ACQUIRE) == seq) break;
+      const hipError_t e = hipStreamQuery(c->ll_agent_stream);
+      (void)hipGetLastError();
+      if (e != hipErrorNotReady && __atomic_load_n((const uint64_t*)&cmd[6], __ATOMIC_ACQUIRE) != seq &&
+          __atomic_load_n((const uint64_t*)&cmd[7], __ATOMIC_ACQUIRE) == 0) {
+        // the stream is idle: the agent has ENDED, without serving this command and without saying "gone" -- broken.  Nothing of it
+        // runs any more, so the launched kernel may take the epoch over.
         c->ll_agent_running = false;
         __atomic_store_n((uint64_t*)&cmd[0], 0, __ATOMIC_RELEASE);
-        return false;  // (the number stays consumed: a relaunch starts at the next one)
+        return 0;  // (the number stays consumed: a relaunch starts at the next one)
+      }
+      if (c->timeout_s > 0 && now_seconds() - t0 > (double)c->timeout_s + 5.0) {
+        if (__atomic_load_n((const uint64_t*)&cmd[6], __ATOMIC_ACQUIRE) == seq) break;
+        // The agent may still be INSIDE the collective (its own clock should have cut its waits short by now): a second kernel for
+        // the same epoch beside it would store into the same slots and answer the same record.  The collective has failed: the
+        // job's abort flag makes the agent's waits end, and nothing reuses the record before it has gone or its stream is idle.
+        c->ctl->set_abort(XMPI_ERR_TIMEOUT);
+        __atomic_store_n((uint64_t*)&cmd[0], 0, __ATOMIC_RELEASE);
+        const double t1 = now_seconds();
+        while (__atomic_load_n((const uint64_t*)&cmd[7], __ATOMIC_ACQUIRE) == 0 && hipStreamQuery(c->ll_agent_stream) == hipErrorNotReady &&
+               now_seconds() - t1 < 10.0)
+          bo.pause();
+        (void)hipGetLastError();
+        c->ll_agent_running = false;
+        return -1;
       }
     }
     bo.pause();
   }
-  return true;
+  return 1;
 }
 
 // a lingering LL agent is told to go and waited for (finalize; nothing else needs it: it goes by itself)
@@ -1050,9 +1070,38 @@ int p2p_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, i
     }
     return await_ack(c, m, dest, tag);
   }
+  // A job that voted its windows away (xmpi_init: a rank could not map one) has no mail slots: a payload the receiver cannot
+  // pull as it lies -- unregistered device memory, a host slice with the host lanes off -- first goes into a registered block of
+  // this rank (one local copy), and THAT is offered.  xmpi_send_nowait needs the slots: not in this mode.
+  struct StandIn {
+    void* p = nullptr;
+    ~StandIn() {
+      if (p) (void)heap_free(p);
+    }
+  } standin;
+  bool dev_now = dev_src;
+  if (!c->windows_ok && bytes > 0) {
+    BufRef probe;
+    if (!wait_ack) {
+      (void)withdraw_claimed(m);
+      set_last_error("send_nowait: this job runs without windows (xmpi_degraded): no mail slots to leave the payload in");
+      return XMPI_ERR_UNSUPPORTED;
+    }
+    if (!(dev_src && zc_export(c, buf, bytes, &probe))) {
+      standin.p = heap_alloc(c->device, bytes);
+      if (!standin.p || hipMemcpyAsync(standin.p, buf, bytes, hipMemcpyDefault, lease.s) != hipSuccess || hipStreamSynchronize(lease.s) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)withdraw_claimed(m);
+        set_last_error("send: no registered block for the payload (this job runs without windows)");
+        return XMPI_ERR_NOMEM;
+      }
+      buf = standin.p;
+      dev_now = true;
+    }
+  }
   // A registered source (xmpi_malloc / xmpi_register) is offered to the receiver, which then copies
   // straight out of it: one pass over the data and one xGMI crossing instead of slot-in + slot-out.
-  const bool offered = wait_ack && dev_src && c->p2p_direct_bytes >= 0 && bytes >= (size_t)std::max<long>(1, c->p2p_direct_bytes) &&
+  const bool offered = wait_ack && dev_now && c->p2p_direct_bytes >= 0 && bytes >= (size_t)std::max<long>(1, c->p2p_direct_bytes) &&
                        zc_export(c, buf, bytes, &m->src);
   m->direct.store(offered ? DIRECT_OFFERED : DIRECT_NONE, std::memory_order_relaxed);
   m->state.store(MAIL_POSTED, std::memory_order_release);
@@ -1078,7 +1127,8 @@ int p2p_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, i
     }
   }
   const bool push = rc == XMPI_OK && m->direct.load(std::memory_order_acquire) != DIRECT_ACCEPTED &&
-                    m->state.load(std::memory_order_acquire) != MAIL_DONE;
+                    m->state.load(std::memory_order_acquire) != MAIL_DONE && (c->windows_ok || bytes == 0);
+  // (no windows: a receiver that could not take the offer has answered with its error -- MAIL_DONE -- and nothing is pushed)
 
   const size_t slot = c->p2p_slot_bytes;
   const uint64_t npieces = push ? (bytes + slot - 1) / slot : 0;
@@ -1474,6 +1524,12 @@ int p2p_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int 
       m->status.store(XMPI_OK, std::memory_order_release);
       m->state.store(MAIL_DONE, std::memory_order_release);  // the ack (network.go:616-624)
       return XMPI_OK;
+    }
+    if (!c->windows_ok && bytes > 0) {  // ... which this job does not have: both sides get the error, the job goes on
+      set_last_error("receive: the sender's buffer cannot be mapped here and this job runs without windows (xmpi_degraded)");
+      m->status.store(XMPI_ERR_UNSUPPORTED, std::memory_order_release);
+      m->state.store(MAIL_DONE, std::memory_order_release);
+      return XMPI_ERR_UNSUPPORTED;
     }
     m->direct.store(DIRECT_DECLINED, std::memory_order_release);  // host destination / not mappable: use the slots
   }

@@ -67,7 +67,7 @@ void set_grid_cap(int cap);
 // that this rank's buffers are ready and where they are, waits until every peer said the same, moves the
 // data straight between the user buffers, and leaves only after every peer has finished reading this
 // rank's input and writing its output.  The host enqueues it on a stream and never polls.
-constexpr int kDsyncRanks = 16;   // = kMaxRanks of ctl.h
+constexpr int kDsyncRanks = 8;    // = kMaxRanks of ctl.h: the machine is one node of eight GPUs, one rank per GPU
 constexpr int kDsyncArenas = 32;  // live allocations of one peer this rank can translate
 
 // written by ONE peer (slot p of rank q's page by rank p), read by the owner's kernels
@@ -238,7 +238,7 @@ struct LLAgentArgs {
   uint64_t patience_ticks;  // wall_clock64 ticks (100 MHz) the agent waits for a command
   DsyncLLArgs ll;           // the communicator's fields: page, me, n, epoch_floor, host_epoch, abort_word, status, spin_limit
 };
-constexpr uint32_t kAgentLLRootShift = 2, kAgentLLDtypeShift = 6, kAgentLLOpShift = 9, kAgentLLConsecutiveShift = 11;  // root: 4 bits (kDsyncRanks = 16)
+constexpr uint32_t kAgentLLRootShift = 2, kAgentLLDtypeShift = 6, kAgentLLOpShift = 9, kAgentLLConsecutiveShift = 11;  // root: 4 bits (kDsyncRanks <= 16)
 static_assert(kDsyncRanks <= 16, "an LL command names its root in four bits");
 constexpr int kLLAgentBlock = 512;  // lanes of the agent's one block: 4 KiB per rank is one line per lane
 hipError_t launch_ll_agent(const LLAgentArgs& a, hipStream_t stream);

@@ -100,6 +100,7 @@ SYMBOLS = [
     ("xmpi_graph_destroy", _I, [_P, _P]),
     ("xmpi_send_on_stream", _I, [_P, _P, _Z, _I, _I, _I, _P]),
     ("xmpi_recv_on_stream", _I, [_P, _P, _Z, _I, _I, _I, _P]),
+    ("xmpi_degraded", C.c_char_p, [_P]),
     ("xmpi_tune", _I, [_P, _Z]),
     ("xmpi_tune_decide", _I, [C.POINTER(C.c_double), _I, C.c_double]),
     ("xmpi_sched_dump", _I, [_I, _I, _I, _I, _I, _I, _I, _Z, _Z, _I, _I, C.c_char_p, _Z]),
@@ -449,6 +450,10 @@ class Comm:
     def memset(self, buf, byte: int, nbytes: int) -> None:
         _check(lib().xmpi_memset(self.handle, _ptr(buf), byte, nbytes), "memset")
 
+    def memcpy(self, dst, src, nbytes: int) -> None:
+        """blocking copy between any two of {host, this rank's HBM}"""
+        _check(lib().xmpi_memcpy(self.handle, _ptr(dst), _ptr(src), nbytes), "memcpy")
+
     def sync(self) -> None:
         _check(lib().xmpi_sync(self.handle), "xmpi_sync")
 
@@ -457,6 +462,10 @@ class Comm:
 
     def get_param(self, name: str) -> int:
         return lib().xmpi_get_param(self.handle, name.encode())
+
+    def degraded(self) -> str:
+        """what xmpi_init's vote left the job with, in words ("" = nothing degraded); get_param("degraded") is the level"""
+        return (lib().xmpi_degraded(self.handle) or b"").decode()
 
     def link_probe(self, peer: int, nbytes: int, engine: int, iters: int = 10, direction: int = 0) -> float:
         out = C.c_double(0)

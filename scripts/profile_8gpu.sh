@@ -1,6 +1,6 @@
 #!/bin/bash
 # One command for an 8-GPU MI355X node: the SCALE line plus the link roofline and per-rank kernel evidence.
-# Run from the repo root; writes under profiles/r04_8gpu/ (small files only).
+# Run from the repo root; writes under profiles/r05_8gpu/ (small files only).
 #   bash scripts/profile_8gpu.sh [N=8]
 # 1. bench.py --gpus N under torch.distributed.run (one process per GPU, ranks meet on the device): the compact JSON line with
 #    value = algbw @ 256 MiB f32, busbw, `xgmi` {link_probe taken before anything is tuned: SDMA vs copy kernel, write / read /
@@ -8,7 +8,8 @@
 #    LIBRARY's tuner (xmpi_tune) chose on these links; bench_extras.json beside it (per-algorithm times, sweeps).
 # 2. the production-layout program on the links: examples/allreduce_bench with every schedule by name -- the library's choice,
 #    the one-kernel fold (1 / 2 packets in flight), meet / body / done, push-only, the ring kernel (all ring channels = all
-#    links), the halving kernel -- at 256 MiB and 1 MiB, plain and under rocprofv3 --kernel-trace --stats (one
+#    links), the halving kernel, and the PUSH forms of both (ring_push / rhd_push: every payload byte a posted store over its link
+#    where ring / rhd load it -- which of the two a link moves faster is the first thing to read) -- at 256 MiB and 1 MiB, plain and under rocprofv3 --kernel-trace --stats (one
 #    kernel_stats.csv PER RANK); and the Send / Receive ping-pong between GPU 0 and GPU 1 (half round trip, through the C ABI).
 # 3. BASELINE cfg 5 on the links: examples/cfg5_sweep (fp16, ring vs halving vs the library's choice, 1 MiB ... 1 GiB).
 # 4. the ring kernel's channel count on real links: 1, 2, all.
@@ -21,7 +22,7 @@
 set -x
 N=${1:-8}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-O=${XMPI_8GPU_OUT:-$ROOT/profiles/r04_8gpu}
+O=${XMPI_8GPU_OUT:-$ROOT/profiles/r05_8gpu}
 mkdir -p $O
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0 XMPI_TIMEOUT_S=${XMPI_TIMEOUT_S:-120}
 BIN=$ROOT/mpi_amd/bin
@@ -37,14 +38,14 @@ LAUNCH="python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-
 XMPI_BENCH_EXTRAS_DIR=$O timeout 1500 $LAUNCH bench.py --gpus $N $BARGS > $O/bench_n$N.json 2> $O/bench_n$N.err
 mv $O/bench_extras.json $O/bench_n${N}_extras.json 2>/dev/null
 tail -c 800 $O/bench_n$N.err
-MODES="auto fused fused2 split zpush ring rhd"
+MODES="auto fused fused2 split zpush ring ring_push rhd rhd_push"
 XMPI_BASEPORT=7100 timeout 600 $BIN/xmpirun $N $BIN/allreduce_bench $L $K $MODES > $O/prod_n${N}_256MiB.json 2> $O/prod.err
 XMPI_BASEPORT=7150 timeout 600 $BIN/xmpirun $N $BIN/allreduce_bench $M $K $MODES > $O/prod_n${N}_16MiB.json 2>> $O/prod.err
 XMPI_BASEPORT=7200 timeout 600 $BIN/xmpirun $N $BIN/allreduce_bench $S $KS $MODES > $O/prod_n${N}_1MiB.json 2>> $O/prod.err
 XMPI_BASEPORT=7250 timeout 900 $BIN/xmpirun $N $BIN/cfg5_sweep $C5 ${K%% *} > $O/cfg5_n$N.json 2>> $O/prod.err
 XMPI_BASEPORT=7280 timeout 300 $BIN/xmpirun 4 $BIN/cfg3_allgather $C3 ${K%% *} > $O/cfg3_4gpu.json 2>> $O/prod.err
 for ch in 1 2 0; do
-  XMPI_SCHED_CHANNELS=$ch XMPI_BASEPORT=7300 timeout 600 $BIN/xmpirun $N $BIN/allreduce_bench $L $K ring > $O/ring_channels_${ch}_n$N.json 2>> $O/prod.err
+  XMPI_SCHED_CHANNELS=$ch XMPI_BASEPORT=7300 timeout 600 $BIN/xmpirun $N $BIN/allreduce_bench $L $K ring ring_push > $O/ring_channels_${ch}_n$N.json 2>> $O/prod.err
 done
 for SYS in 0 1; do
   XMPI_BODY_SYS=$SYS XMPI_BASEPORT=7320 timeout 600 $BIN/xmpirun $N $BIN/allreduce_bench $L $K split > $O/split_body_sys${SYS}_n$N.json 2>> $O/prod.err
@@ -61,7 +62,7 @@ if [ "$REH" = 1 ]; then python scripts/show_bench.py $O/bench_n$N.json | head -4
 cd /tmp
 XMPI_BASEPORT=7360 timeout 300 rocprofv3 --marker-trace --kernel-trace --output-format csv -d $O/markers -- $BIN/xmpirun $N $BIN/coll_sweep ${CS%% *} 20 > $O/coll_sweep_under_marker_trace.json 2> $O/markers.err
 for f in $O/markers/*/*marker_api_trace.csv; do head -n 120 $f > $O/marker_trace_$(basename $f | cut -d_ -f1)_head.txt; done
-for m in auto ring rhd; do
+for m in auto ring ring_push rhd rhd_push; do
   XMPI_BASEPORT=7400 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$m -- $BIN/xmpirun $N $BIN/allreduce_bench $L $K $m \
       > $O/prod_${m}_under_rocprof.json 2> $O/stats_$m.err
 done

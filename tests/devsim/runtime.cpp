@@ -843,6 +843,14 @@ hipError_t hipExtMallocWithFlags(void** ptr, size_t bytes, unsigned flags) {
   if (!ptr) return fail(hipErrorInvalidValue);
   *ptr = nullptr;
   if (bytes == 0) return hipSuccess;
+  // DEVSIM_FAIL_UNCACHED_ALLOC=1[@<device>]: the runtime has no uncached / fine-grained device memory (on that device)
+  if (flags & (hipDeviceMallocUncached | hipDeviceMallocFinegrained)) {
+    static const char* spec = getenv("DEVSIM_FAIL_UNCACHED_ALLOC");
+    if (spec) {
+      const char* at = strchr(spec, '@');
+      if (!at || atoi(at + 1) == tl_device) return fail(hipErrorOutOfMemory);
+    }
+  }
   const size_t page = 4096, len = (bytes + page - 1) / page * page;
   const uint64_t id = g_alloc_id.fetch_add(1);
   const std::string name = shm_name((int)getpid(), id);
@@ -1061,6 +1069,17 @@ hipError_t hipIpcOpenMemHandle(void** ptr, hipIpcMemHandle_t handle, unsigned fl
       long n = 0;
       int dev = -1;
       if (sscanf(spec, "%ld@%d", &n, &dev) >= 1 && (dev < 0 || dev == tl_device) && calls.fetch_add(1) + 1 == n) return fail(hipErrorInvalidValue);
+    }
+    // DEVSIM_FAIL_IPC_KIND=uncached|default[@<device>]: EVERY open of a handle of that kind of memory fails (on that device) -- a
+    // runtime that will not map another device's uncached allocation (the flag pages), or no plain one (the windows, the arenas)
+    static const char* kind = getenv("DEVSIM_FAIL_IPC_KIND");
+    if (kind) {
+      int dev = -1;
+      const char* at = strchr(kind, '@');
+      if (at) dev = atoi(at + 1);
+      const bool uncached = (h.flags & (hipDeviceMallocUncached | hipDeviceMallocFinegrained)) != 0;
+      const bool want_uncached = strncmp(kind, "uncached", 8) == 0;
+      if ((dev < 0 || dev == tl_device) && uncached == want_uncached) return fail(hipErrorInvalidValue);
     }
   }
   if (h.device != tl_device && !(flags & hipIpcMemLazyEnablePeerAccess)) {

@@ -2256,6 +2256,68 @@ def sc_traffic(comm, args):
         print("TRAFFIC " + json.dumps({"ranks": size, "bytes_per_rank": S, "chunk": c, "schedules": report}), flush=True)
 
 
+def sc_degraded(comm, args):
+    """A job that could not map everything (tests/devsim fault injection: flag pages / windows / one rank's first open / no
+    uncached memory): xmpi_init came back with a WORKING communicator at the best level every rank reached -- the level and the
+    reason are readable, every collective by every name still matches the oracle, the reference's two programs still run
+    (helloworld.go:53-81: host strings; a ping-pong out of registered HBM).  The reference: Init fails only when the mesh
+    cannot be built (network.go:53-65)."""
+    rank, size = comm.rank(), comm.size()
+    level = comm.get_param("degraded")
+    assert level == args["expect"], f"degraded = {level} ({comm.degraded()!r}), expected {args['expect']}"
+    assert args.get("why", "") in comm.degraded(), comm.degraded()
+    assert (comm.degraded() == "") == (level & 6 == 0)
+    assert comm.get_param("windows_ok") == (0 if level & 4 else 1) and comm.get_param("dsync") == (0 if level & 2 else 1)
+    sc_allreduce_small(comm, {"counts": [1, 17, 4099], "dtypes": [xmpi.F32, xmpi.I64, xmpi.F16]})
+    allgather_case(comm, xmpi.I64, 4099, xmpi.ALGO_AUTO)
+    allgather_case(comm, xmpi.I64, 1000, xmpi.ALGO_DIRECT)
+    for root in (0, size - 1):
+        bcast_case(comm, xmpi.F32, 5001, root, xmpi.ALGO_AUTO)
+        bcast_case(comm, xmpi.U8, 37, root, xmpi.ALGO_TREE)
+        reduce_case(comm, xmpi.I64, 4099, root, xmpi.ALGO_AUTO, pat=xmpi.PAT_UNIFORM)
+        reduce_case(comm, xmpi.I32, 3001, root, xmpi.ALGO_DIRECT)
+    x = oracle.fill(5000, xmpi.I64, xmpi.PAT_UNIFORM, 5 + rank)  # a host slice in a collective: a registered stand-in
+    out = np.zeros_like(x)
+    comm.allreduce(x, out, 5000, xmpi.I64, xmpi.SUM, xmpi.ALGO_AUTO)
+    want = oracle.reduce_ranks([oracle.fill(5000, xmpi.I64, xmpi.PAT_UNIFORM, 5 + r) for r in range(size)], xmpi.I64, 0)
+    assert out.tobytes() == want.tobytes()
+    sc_helloworld(comm, args)
+    # Send / Receive out of registered HBM (the receiver pulls), into HBM and into a host slice; and out of device memory the
+    # library never registered (without windows: through a registered stand-in on the sender's side)
+    n = 70001
+    peer = rank ^ 1
+    if peer < size:
+        a, b = comm.alloc(n * 4), comm.alloc(n * 4)
+        comm.fill(a, n, xmpi.F32, xmpi.PAT_SIGNED, 900 + rank)
+        host = np.zeros(n, dtype=np.float32)
+        rt = _hip_runtime()
+        raw = ctypes.c_void_p()
+        assert rt.hipMalloc(ctypes.byref(raw), ctypes.c_size_t(n * 4)) == 0
+        comm.memcpy(raw.value, a.ptr, n * 4)
+        want = oracle.fill(n, xmpi.F32, xmpi.PAT_SIGNED, 900 + peer)
+        for dst, src in ((b, a), (host, a), (b, raw.value)):
+            if rank < peer:
+                comm.send(src, n, xmpi.F32, peer, 11)
+                comm.recv(dst, n, xmpi.F32, peer, 12)
+            else:
+                comm.recv(dst, n, xmpi.F32, peer, 11)
+                comm.send(src, n, xmpi.F32, peer, 12)
+            got = host if dst is host else b.download(np.float32, n)
+            assert got.tobytes() == want.tobytes(), "Send / Receive echo differs"
+            comm.memset(b, 0, n * 4)
+            host[:] = 0
+        if level & 4:  # what needs the mail slots says so instead of hanging
+            try:
+                comm.send_nowait(a, n, xmpi.F32, peer, 13)
+                raise AssertionError("send_nowait worked in a job without windows")
+            except xmpi.XmpiError as e:
+                assert e.code == xmpi.ERR_UNSUPPORTED, e
+        comm.barrier()
+        rt.hipFree(raw)
+        a.free()
+        b.free()
+
+
 def sc_peer_dies(comm, args):
     """The last rank leaves without a word (os._exit after a collective that worked) -- a process that crashed.  The reference's
     peers see their TCP connection fail (network.go:518-571: Send / Receive return the error); here nobody is told, so every wait
@@ -2295,6 +2357,7 @@ def sc_peer_dies(comm, args):
 
 
 SCENARIOS = {
+    "degraded": sc_degraded,
     "peer_dies": sc_peer_dies,
     "traffic": sc_traffic,
     "xcd_flaky": sc_xcd_flaky,

@@ -119,7 +119,7 @@ def test_bench_probe_rules_out_a_schedule():
     assert d["zero_copy_probe"].startswith("ok") and d["parity"]["ok"]
     with open(os.path.join(ROOT, d["extras_file"])) as f:
         tune = json.load(f)["autotune"]
-    assert tune["probe_ok"] == ["fused", "rhd", "split", "zpush"], tune
+    assert tune["probe_ok"] == ["fused", "rhd", "rhd_push", "ring_push", "split", "zpush"], tune
     assert 1 not in tune["table_algo"]  # XMPI_ALGO_RING never made it into the table
 
 

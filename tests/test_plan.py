@@ -73,7 +73,7 @@ def test_allreduce_oneshot(n, count, piece, inplace):
             assert got[r].tobytes() == want.tobytes(), f"rank {r}"
 
 
-@pytest.mark.parametrize("size", [1, 2, 3, 8, 16])
+@pytest.mark.parametrize("size", [1, 2, 3, 5, 8])
 @pytest.mark.parametrize("count,es", [(0, 4), (1, 4), (67108864, 4), (4099, 8), (1001, 1), (17, 2), (536870912, 2)])
 def test_zero_copy_chunks_partition_the_buffer(size, count, es):
     """zero-copy collectives: rank j folds / forwards chunk j; the chunks tile [0, count) in rank order,
@@ -219,7 +219,7 @@ def test_headline_plan_shape():
     assert len(plan.steps) == pieces * (2 * n - 1)
 
 
-@pytest.mark.parametrize("n", [4, 6, 8, 16])
+@pytest.mark.parametrize("n", [4, 6, 8])
 def test_ring_channels_use_distinct_links(n):
     """Even N: the N-2 ring channels are the two directions of N/2-1 edge-disjoint Hamiltonian cycles
     (Walecki): every rank sends to N-2 different peers and no directed link carries two channels."""
