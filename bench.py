@@ -403,7 +403,8 @@ def rank_main(job: Job, grank: int):
     transport = ("xGMI (one rank per GPU)" if ndev_used == R else
                  "intra-HBM (all ranks share one GPU)" if ndev_used == 1 else f"mixed: {R} ranks on {ndev_used} GPUs (intra-HBM + xGMI)")
     slot = lambda b: (b.ptr >> 12) & 15  # noqa: E731 -- the 4 KiB slot of the 64 KiB frame a block starts in (heap.cpp colouring)
-    out = {"slots": {"send": slot(send), "recv": slot(recv)}, "form": form, "link": link, "transport": transport, "devices": ndev_used, "dsync": comm.get_param("dsync"), "t_step": t_step, "prof": prof, "tune": tune, "best": best, "best_ring": best_ring, "ring_named": ring_named, "parity": parity,
+    out = {"degraded": {"level": comm.get_param("degraded"), "why": comm.degraded()},
+           "slots": {"send": slot(send), "recv": slot(recv)}, "form": form, "link": link, "transport": transport, "devices": ndev_used, "dsync": comm.get_param("dsync"), "t_step": t_step, "prof": prof, "tune": tune, "best": best, "best_ring": best_ring, "ring_named": ring_named, "parity": parity,
            "algo": algo, "nbytes": nbytes, "count": count, "iso": iso, "parity_failures": parity_failures,
            "shared_stream": comm.get_param("shared_stream"), "slot_bytes": comm.get_param("slot_bytes"),
            "zero_copy_probe": {"dsync": "ok: ranks meet on the device" if comm.get_param("dsync") == 1 else "ok (ranks that share a process meet on the host)",
@@ -728,9 +729,11 @@ def probe_rank(job: Job, grank: int):
 
 def probe_zero_copy(job: Job) -> str:
     """The zero-copy kernels load and store through xGMI-mapped peer memory, and with one process per GPU the ranks
-    meet inside those kernels (flag words in HBM).  On a node this code has not run on before, try that in a job of
-    its own (child processes): if it faults, hangs or gives wrong bits, try again with the ranks meeting on the host
-    (XMPI_DSYNC=0); if that fails too, this run keeps to the staged schedules instead of dying without a result.
+    meet inside those kernels (flag words in HBM).  A MAPPING the runtime refuses is the library's business: xmpi_init votes
+    and runs the job at the best level every rank reached (the line's `degraded`).  What it cannot foresee on a node this code
+    has not run on before is a schedule that faults, hangs or gives wrong bits there: so every schedule is tried in a job of
+    its own (child processes) first; if the one-kernel fold fails with the ranks meeting on the device, once more with them
+    meeting on the host (XMPI_DSYNC=0); if that fails too, this run keeps to the staged schedules instead of dying without a result.
     Returns "dsync" | "host" | "failed"; job.probe_ok = the schedules that worked (the library's tuner is told to leave
     the others out)."""
     for attempt, extra in (("dsync", {}), ("host", {"XMPI_DSYNC": "0"})):
@@ -928,6 +931,8 @@ def main():
                         "busiest_link_direction_GBps": share * S / t / 1e9,
                         "frac_of_link_peak": share * S / t / 1e9 / XGMI_DIR_GBPS,
                         "busbw_frac_of_one_link": busbw / XGMI_LINK_GBPS, "link_probe": r0["link"], "meaningful": meaningful}
+    if r0["degraded"]["level"] & 6:  # what xmpi_init's vote left out (ranks meet on the host / no windows), and the first reason a rank gave
+        line["degraded"] = r0["degraded"]
     if (args.gpus > 1 or job.procs > 1) and not args.no_probe:
         line["zero_copy_probe"] = r0["zero_copy_probe"]
     extras_out = {"timed_buffer_slots": {str(g): job.result[g].get("slots") for g in sorted(job.result)},
