@@ -201,6 +201,8 @@ struct xmpi_comm {
   uint64_t agent_epoch_at = ~0ull;     // ... and when the AGENT last ran one: the next call's epoch is that one's plus one
   uint64_t dsync_split_launches = 0, dsync_sched_launches = 0;  // ... collectives run as meet / body / done; as a stepped kernel
   uint64_t dsync_land_bytes = 0;   // the landing block this rank lent to its last push-form stepped collective (0: none)
+  void* land_block = nullptr;      // ... kept for the next one (a registered arena block; grown when a collective needs more)
+  size_t land_block_bytes = 0;
   xmpi::DsyncEntry* dsync_table = nullptr;            // [kMaxRanks][kDsyncArenas], pinned host memory the kernels read
   const xmpi::DsyncEntry* dsync_table_dev = nullptr;  // ... as the GPU addresses it
   uint64_t dsync_seen[xmpi::kMaxRanks] = {0};         // published entries of each peer processed so far

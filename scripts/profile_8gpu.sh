@@ -31,7 +31,7 @@ if [ "$REH" = 1 ]; then L=131072; M=65536; S=16384; C5=1048576; C3=16384; K="2 1
 else L=268435456; M=16777216; S=1048576; C5=1073741824; C3=2097152; K="20 5"; KS="200 10"; CS="1048576 200"; BARGS="--steps 20 --warmup 5"; fi
 cd $ROOT
 if [ "$REH" != 1 ]; then
-timeout 1200 python -m pytest tests/test_gpu_collectives.py -k "split_form or sched or ll_" -x -q > $O/pytest_split_sched_ll.log 2>&1; echo "pytest rc=$?"
+timeout 1200 python -m pytest tests/test_gpu_collectives.py -k "split_form or stepped or ll_" -x -q > $O/pytest_split_sched_ll.log 2>&1; echo "pytest rc=$?"
 tail -n 5 $O/pytest_split_sched_ll.log
 fi
 LAUNCH="python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 29533"

@@ -310,6 +310,30 @@ void rank_main(const std::string& key, int rank, int size, int rounds) {
         allreduce_in_place_case(R, n, XMPI_ALGO_RHD_PUSH, ++salt, "halving kernel, push, in place");
         allreduce_in_place_case(R, n, XMPI_ALGO_RING, ++salt, "ring kernel, in place");
       }
+      // back to back on the stream, nobody waiting in between: the push forms' landing block is the communicator's, used again by
+      // the next collective while the host has not seen the last one end (the peers store into it only after this rank's next
+      // kernel has announced it)
+      {
+        const size_t n = 4099;
+        R.fill_i64(n, ++salt);
+        CHECK(xmpi_allreduce_repeat(c, R.send, R.recv, n, XMPI_I64, XMPI_SUM, XMPI_ALGO_RHD_PUSH, 3));
+        (void)R.expect_sum_i64(n, salt, "halving kernel, push, three enqueued back to back");
+        std::vector<int64_t> v(n);
+        const int s2 = ++salt;
+        for (size_t i = 0; i < n; i++) v[i] = in_i64(rank, i, s2);
+        (void)xmpi_memcpy(c, R.recv, v.data(), n * 8);
+        CHECK(xmpi_allreduce_repeat(c, R.recv, R.recv, n, XMPI_I64, XMPI_SUM, XMPI_ALGO_RING_PUSH, 2));  // in place: sum, then N x sum
+        R.download(n * 8);
+        for (size_t i = 0; i < n; i++) {
+          int64_t want = 0;
+          for (int r = 0; r < size; r++) want += in_i64(r, i, s2);
+          if (((const int64_t*)R.host.data())[i] != want * size) {
+            fprintf(stderr, "rank %d: ring kernel, push, in place, two enqueued back to back: element %zu\n", rank, i);
+            g_bad.fetch_add(1);
+            break;
+          }
+        }
+      }
       if (!dev) allreduce_case(R, 40001, XMPI_ALGO_DIRECT, ++salt, "direct step table");
       if (dev && xmpi_get_param(c, "dsync_sched_launches") <= 0) {
         fprintf(stderr, "rank %d: the stepped kernels never ran\n", rank);

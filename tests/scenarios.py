@@ -840,10 +840,10 @@ def sc_fullsize(comm, args):
         comm.fill(send, count, xmpi.I64, xmpi.PAT_INDEX, rank)
         for r in range(size):
             comm.fill(want.at(r * count * 8), count, xmpi.I64, xmpi.PAT_INDEX, r)
-        for algo in (xmpi.ALGO_RING, xmpi.ALGO_DIRECT, xmpi.ALGO_ZCOPY):
+        for algo in (xmpi.ALGO_RING, xmpi.ALGO_RING_PUSH, xmpi.ALGO_DIRECT, xmpi.ALGO_ZCOPY):
             comm.memset(recv, 0, count * 8 * size)
             comm.allgather(send, recv, count, xmpi.I64, algo)
-            assert comm.count_mismatch(recv, want, count * 8 * size) == 0
+            assert comm.count_mismatch(recv, want, count * 8 * size) == 0, f"cfg3 algo {algo}"
         # spot-check against the CPU oracle as well: x[i] = (r << 40) | i
         for r in (0, size - 1):
             got = recv.download(np.int64, 1024, byte_offset=(r * count + count - 1024) * 8)
@@ -896,9 +896,16 @@ def sc_fullsize(comm, args):
     mine_sum = np.array([comm.checksum(ref, count * es) & 0x7FFFFFFFFFFFFFFF], dtype=np.int64)
     comm.allgather(mine_sum, sums, 1, xmpi.I64, xmpi.ALGO_DIRECT)
     assert np.all(sums == sums[0]), f"{which}: the ranks' results differ from each other: {sums}"
-    for algo in (xmpi.ALGO_RING, xmpi.ALGO_RHD):
+    pulled = {}
+    for algo in (xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_RING_PUSH, xmpi.ALGO_RHD_PUSH):
         comm.memset(out, 0, count * es)
         comm.allreduce(send, out, count, dtype, xmpi.SUM, algo)
+        # the push form of a schedule at full size: the same bits as its pull form (checksums of the whole buffer)
+        if algo in (xmpi.ALGO_RING, xmpi.ALGO_RHD):
+            pulled[algo] = comm.checksum(out, count * es)
+        elif comm.get_param("dsync") == 1:
+            base = xmpi.ALGO_RING if algo == xmpi.ALGO_RING_PUSH else xmpi.ALGO_RHD
+            assert comm.checksum(out, count * es) == pulled[base], f"{which} algo {algo}: not the bits of algo {base}"
         if dtype == xmpi.F16:
             assert comm.count_mismatch(out, ref, count * es) == 0, f"{which} algo {algo}: not bit-identical"
         else:
@@ -1123,6 +1130,20 @@ def sc_sched(comm, args):
             for dtype, count in ((xmpi.F32, 100003), (xmpi.F16, 70001)) + (() if quick else ((xmpi.F32, (1 << 20) + 1),)):
                 for inplace in (False, True):
                     same_bits_case(comm, dtype, count, pull, push, inplace)
+        # several of them enqueued back to back, nobody waiting in between: the push forms' landing block is used again by the next
+        # collective before the host has seen the last one end
+        for algo in (xmpi.ALGO_RING_PUSH, xmpi.ALGO_RHD_PUSH):
+            n = 200003
+            send, recv = comm.alloc(n * 4), comm.alloc(n * 4)
+            comm.fill(send, n, xmpi.F32, xmpi.PAT_SIGNED, 500 + rank)
+            comm.allreduce_repeat(send, recv, n, xmpi.F32, xmpi.SUM, algo, 4)
+            ins = [oracle.fill(n, xmpi.F32, xmpi.PAT_SIGNED, 500 + r) for r in range(size)]
+            check_reduced(recv.download(np.float32, n), ins, xmpi.F32, xmpi.SUM, size <= 2, f"4 x allreduce algo={algo} enqueued back to back")
+            comm.fill(recv, n, xmpi.F32, xmpi.PAT_CONST, rank)  # x_r = r + 1, in place twice: N (N + 1) / 2, then N times that
+            comm.allreduce_repeat(recv, recv, n, xmpi.F32, xmpi.SUM, algo, 2)
+            assert np.all(recv.download(np.float32, n) == np.float32(size * size * (size + 1) / 2)), f"2 x in-place allreduce algo={algo} back to back"
+            send.free()
+            recv.free()
         for algo in (xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_RING_PUSH, xmpi.ALGO_RHD_PUSH):
             if not quick:
                 allreduce_case(comm, xmpi.F32, (3 << 20) + 7, algo, pattern=xmpi.PAT_SIGNED)

@@ -103,6 +103,39 @@ def test_push_and_pull_build_the_same_terms(size):
                     assert list(pull[r]) == list(pull[0]), "every rank holds the same term"
 
 
+def test_no_push_step_leaves_the_block_it_stores_into():
+    """at the sizes the kernels really run (up to 1 GiB, odd counts, every dtype width, every N): every landing-block address of every
+    step of every rank's push program lies inside the block that rank lends, every receive-buffer address inside the buffer -- from
+    the step function's own output, no simulation (the simulator checks the same at its small sizes)"""
+    import random
+    rng = random.Random(7)
+    cases = [(xmpi.SCHED_RHD_ALLREDUCE, n, c, es, ip) for n in range(2, 9) for c, es, ip in ((1, 4, False), (268435456, 4, True), (536870912, 2, False), (67108864 + 3, 4, True))]
+    for _ in range(60):
+        sched = rng.choice([xmpi.SCHED_RING_ALLREDUCE, xmpi.SCHED_RHD_ALLREDUCE, xmpi.SCHED_TREE_REDUCE, xmpi.SCHED_RING_ALLGATHER, xmpi.SCHED_TREE_BCAST])
+        cases.append((sched, rng.randint(2, 8), rng.choice([1, 3, 17, 4099, rng.randint(1, 1 << 28)]), rng.choice([1, 2, 4, 8]), rng.random() < 0.5))
+    for sched, n, count, es, inplace in cases:
+        root = rng.randrange(n)
+        pieces = rng.choice([1, 3, 32]) if sched in (xmpi.SCHED_TREE_REDUCE, xmpi.SCHED_TREE_BCAST) else 1
+        whole = count * es * (n if sched == xmpi.SCHED_RING_ALLGATHER else 1)
+        lent = [xmpi.sched_land_bytes(sched, n, r, root, count, es, inplace) for r in range(n)]
+        for r in range(n):
+            for st in sim.program(sched, n, r, root, pieces, count, es, 1, 0, True, inplace):
+                for m in st["moves"]:
+                    assert 0 <= m["lo"] < m["hi"] <= whole, (sched, n, count, es, st)
+                    for name in ("D", "D2", "A", "B", "C"):
+                        ref = m[name]
+                        if ref is None:
+                            continue
+                        owner, kind, off = ref
+                        lo, hi = m["lo"] + off, m["hi"] + off
+                        if kind == "l":
+                            assert 0 <= lo and hi <= lent[owner], (sched, n, count, es, inplace, r, st["g"], name, ref, lo, hi, lent[owner])
+                        elif kind == "r":
+                            assert 0 <= lo and hi <= whole, (sched, n, count, es, r, st["g"], name, ref)
+                        else:
+                            assert 0 <= lo and hi <= count * es, (sched, n, count, es, r, st["g"], name, ref)
+
+
 def test_landing_blocks_are_as_small_as_the_plan_says():
     """ring allreduce: none out of place, one buffer in place; halving: less than a buffer (+ one for the fold-in of an odd
     pair), nothing for a rank that sits out; tree reduce: a buffer per child; allgather and bcast: none"""
