@@ -864,6 +864,10 @@ def main():
         for x in r0["extras"].get("busbw_table", {}).get("rows", []):
             if x["bytes"] == min(S, 1 << 30) or x["bytes"] == max(y["bytes"] for y in r0["extras"]["busbw_table"]["rows"]):
                 size_rows[str(x["ranks"])] = {"bytes": x["bytes"], "busbw_GBps": round(x["busbw_GBps"], 2), "algbw_GBps": round(x["algbw_GBps"], 2)}
+                if r0["devices"] == R and 1 < x["ranks"] < R:
+                    # one rank per GPU: the sub-communicators run the untuned library's fold, whose busiest link direction carries 2 S / ranks
+                    # (the full communicator's row is the line's `roofline`)
+                    size_rows[str(x["ranks"])]["frac_of_link_peak"] = round(2.0 / x["ranks"] * x["bytes"] / (x["us"] * 1e-6) / 1e9 / XGMI_DIR_GBPS, 4)
     except (KeyError, ValueError, TypeError):
         pass
     meaningful = r0["devices"] == R

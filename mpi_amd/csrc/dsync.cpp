@@ -923,13 +923,26 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     c->dsync_bounced++;
   }
 
-  // binary-tree reduce: an inner node that is not the root accumulates its subtree's partial result in a block the parent
-  // can read (sched_steps.h SCHED_TREE_REDUCE); the caller's receive buffer means nothing there
+  // The communicator KEEPS one registered block for what a stepped collective needs beside the caller's buffers -- the push forms'
+  // landing block, the pull-form tree reduce's accumulator -- and uses it again for the next one (grown when one needs more): the
+  // peers touch it only between this rank's announce for a collective and its close, and its kernels run one at a time -- so
+  // back-to-back enqueued collectives share one block, where a block lent per call would have each of them take a new one before
+  // the stream has given the last one back (1 GiB fp16, halving push form, 5 enqueued steps: a new 1 GiB arena allocated,
+  // exported and mapped by every peer per step -- 100 ms instead of 9).
+  auto own_block = [&](size_t bytes) -> void* {
+    if (!c->land_block || c->land_block_bytes < bytes) {
+      if (c->land_block) lent.push_back(c->land_block);  // (goes back once THIS collective's kernel -- behind every earlier one -- has passed)
+      c->land_block = heap_alloc(c->device, bytes);
+      c->land_block_bytes = c->land_block ? bytes : 0;
+    }
+    return c->land_block;
+  };
+  // binary-tree reduce, pull form: an inner node that is not the root accumulates its subtree's partial result in a block the
+  // parent can read (sched_steps.h SCHED_TREE_REDUCE); the caller's receive buffer means nothing there
   if (stepped && !sched_push && coll == COLL_REDUCE && me != root && 2 * ((me - root + N) % N) + 1 < N) {
     if (capturing) return no_standin();
-    void* acc = heap_alloc(c->device, send_bytes);
+    void* acc = own_block(send_bytes);
     if (!acc) return fail(XMPI_ERR_NOMEM);
-    lent.push_back(acc);
     r.recv = acc;
     if (!zc_export(c, r.recv, send_bytes, &r.rref)) return fail(XMPI_ERR_HIP);
   }
@@ -1074,19 +1087,9 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     c->dsync_land_bytes = land_bytes;
     if (land_bytes) {
       if (capturing) return no_standin();
-      // The communicator KEEPS its landing block and uses it again for the next push-form collective (grown when one needs more):
-      // the peers store into it only after this rank has announced it for that collective, which its kernel does only after the
-      // kernel of the collective before has ended (the kernels of one rank run one at a time) -- so back-to-back enqueued
-      // collectives share one block, where a block lent per call would have each of them take a new one before the stream has
-      // given the last one back (1 GiB fp16, halving, 5 enqueued steps: a new 1 GiB arena allocated, exported and mapped by
-      // every peer per step -- 100 ms instead of 7).
-      if (!c->land_block || c->land_block_bytes < land_bytes) {
-        if (c->land_block) lent.push_back(c->land_block);  // (goes back once THIS collective's kernel -- behind every earlier one -- has passed)
-        c->land_block = heap_alloc(c->device, land_bytes);
-        c->land_block_bytes = c->land_block ? land_bytes : 0;
-        if (!c->land_block) return fail(XMPI_ERR_NOMEM);
-      }
-      void* land = c->land_block;
+      void* const own = own_block(land_bytes);
+      if (!own) return fail(XMPI_ERR_NOMEM);
+      void* land = own;
       BufRef lref;
       if (!zc_export(c, land, land_bytes, &lref)) return fail(XMPI_ERR_HIP);
       int lslot = 0;

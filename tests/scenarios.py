@@ -1721,7 +1721,7 @@ def sc_soak(comm, args):
             comm.set_param("dsync_unroll", rng.choice([1, 2]))
             continue
         if kind == "allreduce":
-            algos = [A.ALGO_AUTO, A.ALGO_ZCOPY, A.ALGO_ZPUSH, A.ALGO_RING, A.ALGO_LL] + ([A.ALGO_RHD] if dev or size & (size - 1) == 0 else [])
+            algos = [A.ALGO_AUTO, A.ALGO_ZCOPY, A.ALGO_ZPUSH, A.ALGO_RING, A.ALGO_LL, A.ALGO_RING_PUSH] + ([A.ALGO_RHD, A.ALGO_RHD_PUSH] if dev or size & (size - 1) == 0 else [])
             algo = rng.choice(algos)
             op = rng.choice([A.SUM, A.SUM, A.SUM, A.PROD, A.MIN, A.MAX])
             pat = rng.choice([A.PAT_UNIFORM, A.PAT_SIGNED])
@@ -1733,14 +1733,14 @@ def sc_soak(comm, args):
             exact = rank_order or op in (A.MIN, A.MAX) or dtype in (A.I64, A.I32, A.U8) or (dtype in (A.F16, A.BF16) and pat == A.PAT_UNIFORM and op == A.SUM)
             allreduce_case(comm, dtype, count, algo, op=op, pattern=pat, inplace=inplace, seed0=3000 + k, exact=exact, misalign=mis)
         elif kind == "allgather":
-            allgather_case(comm, rng.choice([A.I64, A.U8, A.F32]), min(count, 200000), rng.choice([A.ALGO_AUTO, A.ALGO_RING, A.ALGO_ZCOPY, A.ALGO_LL]),
+            allgather_case(comm, rng.choice([A.I64, A.U8, A.F32]), min(count, 200000), rng.choice([A.ALGO_AUTO, A.ALGO_RING, A.ALGO_RING_PUSH, A.ALGO_ZCOPY, A.ALGO_LL]),
                            inplace=rng.random() < 0.3)
         elif kind == "bcast":
-            bcast_case(comm, dtype, count, rng.randrange(size), rng.choice([A.ALGO_AUTO, A.ALGO_TREE, A.ALGO_ZCOPY, A.ALGO_LL]), seed=40 + k)
+            bcast_case(comm, dtype, count, rng.randrange(size), rng.choice([A.ALGO_AUTO, A.ALGO_TREE, A.ALGO_TREE_PUSH, A.ALGO_ZCOPY, A.ALGO_LL]), seed=40 + k)
         elif kind == "reduce":
-            algo = rng.choice([A.ALGO_AUTO, A.ALGO_TREE, A.ALGO_ZCOPY, A.ALGO_LL])
+            algo = rng.choice([A.ALGO_AUTO, A.ALGO_TREE, A.ALGO_TREE_PUSH, A.ALGO_ZCOPY, A.ALGO_LL])
             pat = rng.choice([A.PAT_UNIFORM, A.PAT_SIGNED])
-            exact = algo != A.ALGO_TREE or size <= 2 or dtype in (A.I64, A.I32, A.U8) or (dtype in (A.F16, A.BF16) and pat == A.PAT_UNIFORM)
+            exact = algo not in (A.ALGO_TREE, A.ALGO_TREE_PUSH) or size <= 2 or dtype in (A.I64, A.I32, A.U8) or (dtype in (A.F16, A.BF16) and pat == A.PAT_UNIFORM)
             reduce_case(comm, dtype, min(count, 500000), rng.randrange(size), algo, pat=pat, exact=exact)
         elif kind == "p2p" and size > 1:
             # a ring of blocking messages: even ranks send first, odd ranks receive first (rendezvous sends: no cycle may form)
