@@ -19,8 +19,19 @@ for f in sys.argv[1:]:
           f"ms/step={r(d['ms_per_step'], 3)} algbw={r(d['algbw_GBps'])} busbw={r(d['busbw_GBps'])}  [{len(txt.split(chr(10))[-1])} bytes]")
     print("   config:", {k: v for k, v in cfg.items() if k != "workload"}, "|", d.get("ranks_meet"))
     ro = d["roofline"]
-    print(f"   roofline: {ro['kernel'][:48]} achieved={r(ro['achieved'])} frac={r(ro['frac'], 3)} launches={ro['launches']} "
-          f"avg_us={r(ro['avg_launch_us'])} bytes/launch={ro['algorithmic_bytes_per_launch']} traffic={ro.get('traffic')}")
+    if ro.get("bound") == "xgmi":  # one rank per GPU: the link roofline of the schedule that was timed
+        print(f"   roofline (LINK): schedule={ro['schedule']} ({ro['direction']}) busiest link direction {r(ro['achieved'])} GB/s of {ro['peak']} = "
+              f"frac {r(ro['frac'], 3)}; measured link {r(ro.get('peak_measured'))} GB/s -> frac_of_measured {r(ro.get('frac_of_measured'), 3)}; "
+              f"{ro['busiest_link_direction_bytes_over_S']:.3f} S per link direction")
+        ro = d.get("roofline_hbm", {})
+    if ro:
+        print(f"   roofline (HBM): {ro['kernel'][:48]} achieved={r(ro['achieved'])} frac={r(ro['frac'], 3)} launches={ro.get('launches')} "
+              f"avg_us={r(ro.get('avg_launch_us'))} bytes/launch={ro.get('algorithmic_bytes_per_launch')} traffic={ro.get('traffic')}")
+    if d.get("degraded"):
+        print("   DEGRADED:", d["degraded"])
+    if d.get("ring"):
+        print("   ring by name (north_star's target: frac_of_link_peak >= 0.7):",
+              {k: ({x: r(y, 3) for x, y in v.items()} if isinstance(v, dict) else v) for k, v in d["ring"].items()})
     for k in ("roofline_production", "roofline_isolated", "xgmi", "busbw_at_size", "cfg5_f16_us", "parity"):
         if d.get(k):
             v = d[k]

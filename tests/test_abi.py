@@ -95,6 +95,56 @@ def test_every_knob_is_in_the_table():
     assert len(env_code) < 60, "knob sprawl"
 
 
+def _split_args(text):
+    """top-level comma split of an argument list (parentheses / brackets / braces nest)"""
+    out, depth, cur = [], 0, ""
+    for ch in text:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur)
+    return out
+
+
+def test_the_go_shim_calls_the_boundary_as_declared():
+    """go/xgmi/xgmi.go has never met a Go compiler (none in the image): what CAN be held to the header without one is -- every
+    C.xmpi_* it calls is declared in include/xmpi.h (not in the test header), with as many arguments as the declaration has
+    parameters; every C.XMPI_* constant exists; braces balance"""
+    go = open(os.path.join(ROOT, "go", "xgmi", "xgmi.go")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "xmpi.h")).read(), flags=re.S)
+    params = {}
+    for m in re.finditer(r"\b(xmpi_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        args = m.group(2).strip()
+        params[m.group(1)] = 0 if args in ("", "void") else len(_split_args(args))
+    calls = 0
+    for m in re.finditer(r"C\.(xmpi_[a-z0-9_]+)\(", go):
+        name = m.group(1)
+        if name in ("xmpi_dtype", "xmpi_op", "xmpi_algo"):  # (conversions to the header's enums)
+            continue
+        assert name in params, f"xgmi.go calls {name}, which include/xmpi.h does not declare"
+        depth, i = 1, m.end()
+        while depth:
+            depth += {"(": 1, ")": -1}.get(go[i], 0)
+            i += 1
+        given = len(_split_args(go[m.end():i - 1]))
+        assert given == params[name], f"xgmi.go calls {name} with {given} arguments, the header declares {params[name]}"
+        calls += 1
+    assert calls >= 40
+    consts = set(re.findall(r"\bC\.(XMPI_[A-Z0-9_]+)", go))
+    assert consts <= set(re.findall(r"\b(XMPI_[A-Z0-9_]+)\b", hdr)), consts - set(re.findall(r"\b(XMPI_[A-Z0-9_]+)\b", hdr))
+    code = re.sub(r"//[^\n]*", "", re.sub(r"/\*.*?\*/", "", go, flags=re.S))
+    code = re.sub(r"\"(?:\\.|[^\"\\])*\"|`[^`]*`|'(?:\\.|[^'\\])'", "", code)
+    for a, b in ("{}", "()", "[]"):
+        assert code.count(a) == code.count(b), f"xgmi.go: {code.count(a)} '{a}' against {code.count(b)} '{b}'"
+
+
 def test_design_describes_head_and_history_lives_in_the_changelog():
     """DESIGN.md is what the next hardware session reads first: what HEAD does, under 30 KB, no round-by-round history (that is
     CHANGELOG.md's), the 8-GPU checklist at the top naming the one script (rehearsed on virtual GPUs by tests/test_devsim.py)"""
