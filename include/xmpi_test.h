@@ -29,9 +29,10 @@ int xmpi_tune_decide(const double* mean_us, int n, double margin);
 int xmpi_ctl_selftest(const char* job_key, int rank, int size, int rounds);
 
 /* Schedule introspection (host logic only, no GPU needed): writes the step table the executor
- * would run for (coll, algo, size, rank, count) as text into out; returns needed length. */
+ * would run for (coll, algo, size, rank, count) as text into out; returns needed length.  fifo_depth 0 / oneshot_bytes
+ * (size_t)-1: the library's defaults (8 slots per pipe; one-shot schedules up to 1 MiB). */
 int xmpi_plan_dump(int coll, int algo, int size, int rank, int root, size_t count,
-                   size_t elem_size, int channels, size_t piece_elems, char* out, size_t cap);
+                   size_t elem_size, int channels, size_t piece_elems, int fifo_depth, size_t oneshot_bytes, char* out, size_t cap);
 
 /* The step program of a stepped kernel (ring allreduce = 1, recursive halving + doubling = 2, ring allgather = 3,
  * binary-tree bcast = 4, binary-tree reduce = 5; form 0 = pull, 1 = push; in_place: the ranks' send buffers are their receive

@@ -2117,7 +2117,7 @@ size_t xmpi_sched_land_bytes(int sched, int in_place, int size, int rank, int ro
 }
 
 int xmpi_plan_dump(int coll, int algo, int size, int rank, int root, size_t count, size_t elem_size, int channels,
-                   size_t piece_elems, char* out, size_t cap) {
+                   size_t piece_elems, int fifo_depth, size_t oneshot_bytes, char* out, size_t cap) {
   PlanParams pp;
   pp.coll = coll;
   pp.algo = (algo == XMPI_ALGO_ZCOPY || algo == XMPI_ALGO_ZPUSH) ? (int)XMPI_ALGO_AUTO : algo;  // the staged fallback
@@ -2130,8 +2130,8 @@ int xmpi_plan_dump(int coll, int algo, int size, int rank, int root, size_t coun
   pp.lanes = 2;
   pp.piece_bytes = piece_elems * elem_size;
   pp.fuse = 1;
-  pp.fifo_depth = (int)env_long("XMPI_PLAN_FIFO_DEPTH", 8);
-  pp.oneshot_bytes = (size_t)std::max<long>(0, env_long("XMPI_ONESHOT_BYTES", 1 << 20));
+  pp.fifo_depth = fifo_depth > 0 ? fifo_depth : 8;  // (0: the library's defaults)
+  pp.oneshot_bytes = oneshot_bytes != (size_t)-1 ? oneshot_bytes : (size_t)1 << 20;
   Plan plan;
   int rc = build_plan(pp, &plan);
   if (rc != XMPI_OK) return rc;

@@ -70,7 +70,7 @@ SYMBOLS = [
     ("xmpi_prof_get", _I, [_P, _I, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     ("xmpi_link_probe", _I, [_P, _I, _Z, _I, _I, _I, C.POINTER(C.c_double)]),
     ("xmpi_ctl_selftest", _I, [C.c_char_p, _I, _I, _I]),
-    ("xmpi_plan_dump", _I, [_I, _I, _I, _I, _I, _Z, _Z, _I, _Z, C.c_char_p, _Z]),
+    ("xmpi_plan_dump", _I, [_I, _I, _I, _I, _I, _Z, _Z, _I, _Z, _I, _Z, C.c_char_p, _Z]),
     ("xmpi_dtype_size", _Z, [_I]),
     ("xmpi_allreduce_repeat", _I, [_P, _P, _P, _Z, _I, _I, _I, _I]),
     ("xmpi_heap_selftest", _I, [C.c_uint64, _I]),
@@ -140,14 +140,15 @@ def _check(rc: int, where: str) -> None:
 
 
 def plan_text(coll: int, algo: int, size: int, rank: int, root: int, count: int, elem_size: int, channels: int,
-              piece_elems: int) -> str:
-    """Step table the executor runs (host logic only: works without a GPU)."""
+              piece_elems: int, fifo_depth: int = 0, oneshot_bytes: int = -1) -> str:
+    """Step table the executor runs (host logic only: works without a GPU).  fifo_depth 0 / oneshot_bytes -1: the defaults."""
     L = lib()
-    n = L.xmpi_plan_dump(coll, algo, size, rank, root, count, elem_size, channels, piece_elems, None, 0)
+    one = oneshot_bytes if oneshot_bytes >= 0 else (1 << 64) - 1
+    n = L.xmpi_plan_dump(coll, algo, size, rank, root, count, elem_size, channels, piece_elems, fifo_depth, one, None, 0)
     if n < 0:
         raise XmpiError(n, "xmpi_plan_dump")
     buf = C.create_string_buffer(n + 1)
-    L.xmpi_plan_dump(coll, algo, size, rank, root, count, elem_size, channels, piece_elems, buf, n + 1)
+    L.xmpi_plan_dump(coll, algo, size, rank, root, count, elem_size, channels, piece_elems, fifo_depth, one, buf, n + 1)
     return buf.value.decode()
 
 

@@ -67,19 +67,8 @@ def get_plans(coll, algo, size, root, count, elem_size, channels, piece_elems, f
               oneshot_bytes: int = 0) -> List[Plan]:
     """Step tables of every rank, built for pipes of `fifo_depth` slots (valid for any deeper FIFO).
     oneshot_bytes = 0 keeps the direct allreduce in its two-phase form whatever the message size."""
-    import os
-    saved = {k: os.environ.get(k) for k in ("XMPI_PLAN_FIFO_DEPTH", "XMPI_ONESHOT_BYTES")}
-    os.environ["XMPI_PLAN_FIFO_DEPTH"] = str(fifo_depth)
-    os.environ["XMPI_ONESHOT_BYTES"] = str(oneshot_bytes)
-    try:
-        return [parse_plan(xmpi.plan_text(coll, algo, size, r, root, count, elem_size, channels, piece_elems))
-                for r in range(size)]
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                del os.environ[k]
-            else:
-                os.environ[k] = v
+    return [parse_plan(xmpi.plan_text(coll, algo, size, r, root, count, elem_size, channels, piece_elems, fifo_depth, oneshot_bytes))
+            for r in range(size)]
 
 
 def np_combine(a: np.ndarray, b: np.ndarray, op: int) -> np.ndarray:
