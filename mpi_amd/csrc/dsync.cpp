@@ -1038,7 +1038,9 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     return XMPI_OK;
   };
 
-  const bool use_push = push && coll == COLL_ALLREDUCE && r.send != r.recv && count % ((size_t)N * al) == 0;
+  const bool use_push = push && coll == COLL_ALLREDUCE;
+  // (out of place with equal chunks the receive buffers are the staging area; otherwise the ranks' own blocks are)
+  const bool push_in_recv = use_push && r.send != r.recv && count % ((size_t)N * al) == 0;
   if (stepped) {
     // ring / recursive halving + doubling / binary tree: ONE kernel per rank runs every step of the schedule, the steps
     // released by flag words between the peers' kernels (sched.hip) -- the schedules north_star names, without a host
@@ -1124,7 +1126,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     c->dsync_launches++;
     c->dsync_sched_launches++;
     rc = XMPI_OK;
-  } else if (use_push) {
+  } else if (push_in_recv) {
     // Write-only variant (XMPI_ALGO_ZPUSH): nothing is READ over xGMI -- loads over a link are round trips, stores are
     // posted.  The receive buffer of rank q is its own staging area: region p (p != q) receives rank p's contribution
     // to chunk q, region q is where q folds them in rank order; then every rank pushes its folded chunk to everybody.
@@ -1159,6 +1161,67 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
       a.seg[0].dst_mask = everyone & ~(1u << me);
       traffic += (size_t)N * cb;
       rc = launch(1, XMPI_U8, XMPI_SUM, cb / 16, (size_t)N * cb);
+    }
+  } else if (use_push && !push_in_recv) {
+    // The same three kernels where the receive buffer cannot be the staging area -- in place (it still is the input), chunks of
+    // unequal length -- with the contributions landing in the communicator's own block instead (own_block; region p of rank q's
+    // block = rank p's contribution to chunk q), announced with the buffers.  Chunks are cut as the fold cuts them (zc_chunk).
+    if (capturing) return no_standin();
+    size_t maxc = 0;
+    for (int q = 0; q < N; q++) {
+      size_t off = 0, cnt = 0;
+      zc_chunk(count, es, N, q, &off, &cnt);
+      maxc = std::max(maxc, cnt * es);
+    }
+    const size_t region = (maxc + 255) / 256 * 256;
+    void* const own = own_block(region * (size_t)N);
+    if (!own) return fail(XMPI_ERR_NOMEM);
+    BufRef lref;
+    if (!zc_export(c, own, region * (size_t)N, &lref)) return fail(XMPI_ERR_HIP);
+    int lslot = 0;
+    rc = publish(c, lref, &lslot, &pi, capturing);
+    if (rc == XMPI_OK) rc = await_acks(c, pi);
+    if (rc) return fail(rc);
+    a.land_gen = lref.gen;
+    a.land_off = lref.offset;
+    a.land_slot = (uint64_t)lslot;
+    a.my_land = own;
+    c->dsync_land_bytes = region * (size_t)N;
+    split_pref = 0;
+    size_t my_off = 0, my_cnt = 0, maxp = 0;
+    zc_chunk(count, es, N, me, &my_off, &my_cnt);
+    for (int q = 0; q < N; q++) {
+      size_t off = 0, cnt = 0;
+      zc_chunk(count, es, N, q, &off, &cnt);
+      if (q == me || cnt == 0) continue;
+      DsyncSeg& g = a.seg[a.nseg++];
+      g.src_off = off * es;             // my contribution to chunk q ...
+      g.dst_off = (size_t)me * region;  // ... into region `me` of rank q's block
+      g.count = cnt * es;
+      g.src_mask = 1u << me;
+      g.dst_mask = 1u << q;
+      g.dst_to_land = 1;
+      maxp = std::max(maxp, cnt * es / 16);
+      traffic += 2 * cnt * es;
+    }
+    rc = launch(1, XMPI_U8, XMPI_SUM, maxp, traffic, /*last=*/false);
+    if (rc == XMPI_OK && my_cnt > 0) {  // every contribution to chunk `me` is local now: the rank-order fold, an ordinary kernel
+      const void* srcs[kMaxRanks];
+      for (int p = 0; p < N; p++) srcs[p] = (p == me) ? (const char*)r.send + my_off * es : (const char*)own + (size_t)p * region;
+      void* d1[1] = {(char*)r.recv + my_off * es};
+      DS_HIP(launch_reduce_n_multi(d1, 1, srcs, N, my_cnt, dtype, op, stream));
+      traffic += (size_t)(N + 1) * my_cnt * es;
+    }
+    if (rc == XMPI_OK) {
+      memset(a.seg, 0, sizeof a.seg);
+      a.nseg = my_cnt > 0 ? 1 : 0;
+      a.seg[0].src_off = a.seg[0].dst_off = my_off * es;  // my folded chunk -> its place in everybody's receive buffer
+      a.seg[0].count = my_cnt * es;
+      a.seg[0].src_mask = 1u << me;
+      a.seg[0].src_from_recv = 1;
+      a.seg[0].dst_mask = everyone & ~(1u << me);
+      traffic += (size_t)N * my_cnt * es;
+      rc = launch(1, XMPI_U8, XMPI_SUM, my_cnt * es / 16, (size_t)N * my_cnt * es);
     }
   } else if (coll == COLL_ALLREDUCE || coll == COLL_REDUCE) {
     size_t off = 0, cnt = 0;

@@ -173,7 +173,7 @@ struct DsyncSeg {
   uint64_t count;             // elements
   uint32_t src_mask, dst_mask;  // ranks whose SEND buffer is read / whose RECEIVE buffer is written
   uint32_t src_from_recv;       // 1: the sources are the ranks' RECEIVE buffers (forwarding what a previous step put there)
-  uint32_t pad;
+  uint32_t dst_to_land;         // 1: the destinations are the ranks' LANDING blocks (push-only allreduce: contributions the owner has not folded yet)
 };
 
 // DSYNC_XCD: the split form's meet or done kernel did not have a block on every XCD (DsyncArgs::xcc_need) -- the acquire / release

@@ -635,7 +635,7 @@ __global__ __launch_bounds__(kBlock) void dsync_fold_kernel(DsyncArgs a) {
         if (g.src_mask >> r & 1u) sh.src[ns++] = (g.src_from_recv ? sh.recv[r] : sh.send[r]) + g.src_off;
       for (int d = 0; d < n; d++) {
         const int r = (me + d) % n;
-        if (g.dst_mask >> r & 1u) sh.dst[nd++] = sh.recv[r] + g.dst_off;
+        if (g.dst_mask >> r & 1u) sh.dst[nd++] = (g.dst_to_land ? sh.land[r] : sh.recv[r]) + g.dst_off;
       }
       sh.nsrc = ns;
       sh.ndst = nd;

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64) void dsync_meet_kernel(DsyncArgs a, DsyncResolv
         if (g.src_mask >> r & 1u) all |= (o.src[ns++] = (g.src_from_recv ? sh.recv[r] : sh.send[r]) + g.src_off);
       for (int d = 0; d < n; d++) {
         const int r = (me + d) % n;
-        if (g.dst_mask >> r & 1u) all |= (o.dst[nd++] = sh.recv[r] + g.dst_off);
+        if (g.dst_mask >> r & 1u) all |= (o.dst[nd++] = (g.dst_to_land ? sh.land[r] : sh.recv[r]) + g.dst_off);
       }
       for (int k = ns; k < kDsyncRanks; k++) o.src[k] = o.src[0];
       for (int k = nd; k < kDsyncRanks; k++) o.dst[k] = o.dst[0];

@@ -180,7 +180,9 @@ void rank_main(const std::string& key, int rank, int size, int rounds) {
       CHECK(xmpi_set_param(c, "dsync_split_bytes", 0));  // never split
       CHECK(xmpi_set_param(c, "ll_bytes", 0));
       for (size_t n : counts) allreduce_case(R, n, XMPI_ALGO_ZCOPY, ++salt, "fold");
-      allreduce_case(R, 4099, XMPI_ALGO_ZPUSH, ++salt, "push-only");
+      allreduce_case(R, 4099, XMPI_ALGO_ZPUSH, ++salt, "push-only");  // (a ragged count: through the communicators' own blocks)
+      allreduce_case(R, (size_t)size * 4096, XMPI_ALGO_ZPUSH, ++salt, "push-only, equal chunks");  // (through the receive buffers)
+      allreduce_in_place_case(R, 40001, XMPI_ALGO_ZPUSH, ++salt, "push-only, in place");
       // in place
       R.fill_i64(4099, ++salt);
       (void)xmpi_memcpy(c, R.recv, R.send, 4099 * 8);

@@ -104,6 +104,13 @@ def sc_allreduce_small(comm, args):
         allreduce_case(comm, xmpi.F32, 40001, algo, pattern=xmpi.PAT_SIGNED, inplace=True, misalign=1)
         allreduce_case(comm, xmpi.I64, 5003, algo, pattern=xmpi.PAT_UNIFORM, inplace=True, misalign=1, op=xmpi.PROD)
         allreduce_case(comm, xmpi.F16, 30011, algo, misalign=3)
+    # push-only (only stores cross a link): out of place with equal chunks the receive buffers are the staging area, otherwise --
+    # in place, ragged counts -- the communicators' own blocks are; rank order either way: bit-exact
+    for count in (1, 17, 4099, 100003, 8 * 4096):
+        for inplace in (False, True):
+            allreduce_case(comm, xmpi.F32, count, xmpi.ALGO_ZPUSH, pattern=xmpi.PAT_SIGNED, inplace=inplace, exact=True)
+    allreduce_case(comm, xmpi.F16, 30011, xmpi.ALGO_ZPUSH, inplace=True, misalign=3, exact=True)
+    allreduce_case(comm, xmpi.I64, 5003, xmpi.ALGO_ZPUSH, op=xmpi.MAX, pattern=xmpi.PAT_SIGNED, inplace=True, exact=True)
     # known answer: x_r[i] = r + 1  =>  every element N(N+1)/2
     n = comm.size()
     buf = comm.alloc(4 * 1024)
@@ -1725,7 +1732,7 @@ def sc_soak(comm, args):
             algo = rng.choice(algos)
             op = rng.choice([A.SUM, A.SUM, A.SUM, A.PROD, A.MIN, A.MAX])
             pat = rng.choice([A.PAT_UNIFORM, A.PAT_SIGNED])
-            inplace = rng.random() < 0.3 and algo != A.ALGO_ZPUSH
+            inplace = rng.random() < 0.3
             mis = rng.choice([0, 0, 0, 1, 3])
             rank_order = algo in (A.ALGO_AUTO, A.ALGO_ZCOPY, A.ALGO_ZPUSH, A.ALGO_LL) or size <= 2
             if not rank_order and op == A.PROD and dtype in FLOATS:
@@ -2180,6 +2187,11 @@ def sc_traffic(comm, args):
     comm.set_param("body_sys", 0)
     # push only: chunk j of my buffer into rank j's scratch, then my reduced chunk into everybody's receive buffer; no remote load
     run("allreduce push only", allreduce(xmpi.ALGO_ZPUSH, **one), lambda i, j: (0, 2 * c))
+    # ... in place: the contributions land in the ranks' own blocks instead of their receive buffers; the same bytes over the same links
+    comm.allreduce(send, recv, count, xmpi.I64, xmpi.SUM, xmpi.ALGO_ZCOPY)
+    _hip_runtime().hipDeviceSynchronize()
+    run("allreduce push only, in place", lambda: comm.allreduce(recv, recv, count, xmpi.I64, xmpi.SUM, xmpi.ALGO_ZPUSH), lambda i, j: (0, 2 * c))
+    assert comm.get_param("dsync_land_bytes") >= S
     # ring, one kernel per rank: 2 (N - 1) / N x S per rank, loads only.  The channels are different Hamiltonian cycles (Walecki's
     # decomposition, plan.cpp), so that the rings together use every link instead of one neighbour's: with the default channels
     # nobody's busiest link carries more than its share of a single ring would
