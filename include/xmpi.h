@@ -58,10 +58,11 @@ typedef enum {
   XMPI_ALGO_ZCOPY = 5,  /* zero-copy: one kernel folds straight out of the peers' registered
                            buffers (rank order) and stores straight into them; no staging  */
   XMPI_ALGO_ZPUSH = 6,  /* zero-copy allreduce that only WRITES over xGMI: contributions are pushed
-                           to the owner of their chunk -- into its receive buffer (out of place, count
-                           divisible by ranks x 16 B) or, with one process per GPU, into the block its
-                           communicator keeps for such things (in place, any count) --, folded locally
-                           in rank order, results pushed back; 3 kernels, one hop each way (the store-only
+                           to the owner of their chunk -- with one process per GPU into the block its
+                           communicator keeps for such things (in place and any count included; ranks that
+                           meet on the host: into its receive buffer, out of place, count divisible by
+                           ranks x 16 B) --, folded locally
+                           in rank order, results pushed back; 2 kernels, one hop each way (the store-only
                            counterpart of ZCOPY); for the other collectives the same as ZCOPY   */
   XMPI_ALGO_LL = 7,     /* low latency, messages up to 32 KiB per rank with one process per GPU: every rank pushes
                            its payload as {data, flag} lines into the peers' flag allocations and folds

@@ -1038,9 +1038,8 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     return XMPI_OK;
   };
 
-  const bool use_push = push && coll == COLL_ALLREDUCE;
-  // (out of place with equal chunks the receive buffers are the staging area; otherwise the ranks' own blocks are)
-  const bool push_in_recv = use_push && r.send != r.recv && count % ((size_t)N * al) == 0;
+  // (under capture the push-only form is the fold: its staging area is a block the communicator may replace later)
+  const bool use_push = push && coll == COLL_ALLREDUCE && !capturing;
   if (stepped) {
     // ring / recursive halving + doubling / binary tree: ONE kernel per rank runs every step of the schedule, the steps
     // released by flag words between the peers' kernels (sched.hip) -- the schedules north_star names, without a host
@@ -1126,47 +1125,12 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     c->dsync_launches++;
     c->dsync_sched_launches++;
     rc = XMPI_OK;
-  } else if (push_in_recv) {
-    // Write-only variant (XMPI_ALGO_ZPUSH): nothing is READ over xGMI -- loads over a link are round trips, stores are
-    // posted.  The receive buffer of rank q is its own staging area: region p (p != q) receives rank p's contribution
-    // to chunk q, region q is where q folds them in rank order; then every rank pushes its folded chunk to everybody.
-    // Two device-synchronised kernels with a plain local fold in between (when kernel 1 ends every peer's contribution
-    // has landed; kernel 3's rendezvous is every peer saying "my fold has read its staging regions").  Needs
-    // out-of-place buffers and equal chunks; otherwise the read-based form below runs.
-    const size_t C = count / (size_t)N, cb = C * es;
-    split_pref = 0;  // (the pushes are small next to the fold; their rendezvous is what orders the three kernels)
-    for (int q = 0; q < N; q++) {
-      if (q == me) continue;
-      DsyncSeg& g = a.seg[a.nseg++];
-      g.src_off = (size_t)q * cb;   // my contribution to chunk q ...
-      g.dst_off = (size_t)me * cb;  // ... into region `me` of rank q's receive buffer
-      g.count = cb;
-      g.src_mask = 1u << me;
-      g.dst_mask = 1u << q;
-    }
-    traffic = 2 * (size_t)(N - 1) * cb;
-    rc = launch(1, XMPI_U8, XMPI_SUM, cb / 16, 2 * (size_t)(N - 1) * cb, /*last=*/false);
-    if (rc == XMPI_OK) {  // all operands of chunk `me` are local now: the rank-order fold is an ordinary kernel
-      const void* srcs[kMaxRanks];
-      for (int p = 0; p < N; p++) srcs[p] = (p == me) ? (const char*)r.send + (size_t)me * cb : (const char*)r.recv + (size_t)p * cb;
-      void* d1[1] = {(char*)r.recv + (size_t)me * cb};
-      DS_HIP(launch_reduce_n_multi(d1, 1, srcs, N, C, dtype, op, stream));
-      traffic += (size_t)(N + 1) * cb;
-      memset(a.seg, 0, sizeof a.seg);
-      a.nseg = 1;
-      a.seg[0].src_off = a.seg[0].dst_off = (size_t)me * cb;  // my folded chunk -> region `me` of everybody's receive buffer
-      a.seg[0].count = cb;
-      a.seg[0].src_mask = 1u << me;
-      a.seg[0].src_from_recv = 1;
-      a.seg[0].dst_mask = everyone & ~(1u << me);
-      traffic += (size_t)N * cb;
-      rc = launch(1, XMPI_U8, XMPI_SUM, cb / 16, (size_t)N * cb);
-    }
-  } else if (use_push && !push_in_recv) {
-    // The same three kernels where the receive buffer cannot be the staging area -- in place (it still is the input), chunks of
-    // unequal length -- with the contributions landing in the communicator's own block instead (own_block; region p of rank q's
-    // block = rank p's contribution to chunk q), announced with the buffers.  Chunks are cut as the fold cuts them (zc_chunk).
-    if (capturing) return no_standin();
+  } else if (use_push) {
+    // Push-only (XMPI_ALGO_ZPUSH): the fold with nothing READ over xGMI -- loads over a link are round trips, stores are posted.
+    // Two device-synchronised kernels: every rank stores its contribution to chunk q into region `me` of rank q's own block
+    // (own_block: the communicator's staging area, announced with the buffers; chunks cut as the fold cuts them, zc_chunk --
+    // so in place and ragged counts work like anything else); then, all of chunk `me` being local, folds it in rank order and
+    // stores the result into its place in everybody's receive buffer.  One hop each way, S / N per link direction and kernel.
     size_t maxc = 0;
     for (int q = 0; q < N; q++) {
       size_t off = 0, cnt = 0;
@@ -1205,23 +1169,23 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
       traffic += 2 * cnt * es;
     }
     rc = launch(1, XMPI_U8, XMPI_SUM, maxp, traffic, /*last=*/false);
-    if (rc == XMPI_OK && my_cnt > 0) {  // every contribution to chunk `me` is local now: the rank-order fold, an ordinary kernel
-      const void* srcs[kMaxRanks];
-      for (int p = 0; p < N; p++) srcs[p] = (p == me) ? (const char*)r.send + my_off * es : (const char*)own + (size_t)p * region;
-      void* d1[1] = {(char*)r.recv + my_off * es};
-      DS_HIP(launch_reduce_n_multi(d1, 1, srcs, N, my_cnt, dtype, op, stream));
-      traffic += (size_t)(N + 1) * my_cnt * es;
-    }
     if (rc == XMPI_OK) {
+      // every contribution to chunk `me` is local now (the first kernel's close: every peer's stores have landed): ONE more kernel
+      // folds them in rank order and stores the result into its place in everybody's receive buffer -- the fold's own kernels
+      // (one kernel, or meet / body / done by size) with local sources.  Its rendezvous doubles as "my buffers may be written";
+      // nobody's block is written again before its owner's next collective has announced it.
       memset(a.seg, 0, sizeof a.seg);
       a.nseg = my_cnt > 0 ? 1 : 0;
-      a.seg[0].src_off = a.seg[0].dst_off = my_off * es;  // my folded chunk -> its place in everybody's receive buffer
-      a.seg[0].count = my_cnt * es;
-      a.seg[0].src_mask = 1u << me;
-      a.seg[0].src_from_recv = 1;
-      a.seg[0].dst_mask = everyone & ~(1u << me);
-      traffic += (size_t)N * my_cnt * es;
-      rc = launch(1, XMPI_U8, XMPI_SUM, my_cnt * es / 16, (size_t)N * my_cnt * es);
+      a.seg[0].src_off = a.seg[0].dst_off = my_off * es;
+      a.seg[0].count = my_cnt;
+      a.seg[0].src_mask = everyone;
+      a.seg[0].src_from_recv = 2;
+      a.seg[0].stage_stride = region;
+      a.seg[0].dst_mask = everyone;
+      split_pref = -1;  // (meet / body / done by size, like the fold it is)
+      const size_t moved = (size_t)(2 * N) * my_cnt * es;
+      traffic += moved;
+      rc = launch(N, dtype, op, my_cnt / al, moved);
     }
   } else if (coll == COLL_ALLREDUCE || coll == COLL_REDUCE) {
     size_t off = 0, cnt = 0;

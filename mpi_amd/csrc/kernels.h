@@ -172,8 +172,11 @@ struct DsyncSeg {
   uint64_t src_off, dst_off;  // byte offsets into the send / receive buffers
   uint64_t count;             // elements
   uint32_t src_mask, dst_mask;  // ranks whose SEND buffer is read / whose RECEIVE buffer is written
-  uint32_t src_from_recv;       // 1: the sources are the ranks' RECEIVE buffers (forwarding what a previous step put there)
+  uint32_t src_from_recv;       // 1: the sources are the ranks' RECEIVE buffers (forwarding what a previous step put there);
+                                // 2: they are all LOCAL -- rank r's contribution lies at stage_stride * r of this rank's landing
+                                // block, this rank's own at src_off of its send buffer (push-only allreduce: the fold of what landed)
   uint32_t dst_to_land;         // 1: the destinations are the ranks' LANDING blocks (push-only allreduce: contributions the owner has not folded yet)
+  uint64_t stage_stride;        // (src_from_recv == 2)
 };
 
 // DSYNC_XCD: the split form's meet or done kernel did not have a block on every XCD (DsyncArgs::xcc_need) -- the acquire / release

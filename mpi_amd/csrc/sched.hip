@@ -63,7 +63,9 @@ __global__ __launch_bounds__(64) void dsync_meet_kernel(DsyncArgs a, DsyncResolv
       int ns = 0, nd = 0;
       uint64_t all = 0;
       for (int r = 0; r < n; r++)
-        if (g.src_mask >> r & 1u) all |= (o.src[ns++] = (g.src_from_recv ? sh.recv[r] : sh.send[r]) + g.src_off);
+        if (g.src_mask >> r & 1u)
+          all |= (o.src[ns++] = g.src_from_recv == 2 ? (r == me ? sh.send[me] + g.src_off : sh.land[me] + (uint64_t)r * g.stage_stride)
+                                                     : (g.src_from_recv ? sh.recv[r] : sh.send[r]) + g.src_off);
       for (int d = 0; d < n; d++) {
         const int r = (me + d) % n;
         if (g.dst_mask >> r & 1u) all |= (o.dst[nd++] = (g.dst_to_land ? sh.land[r] : sh.recv[r]) + g.dst_off);
