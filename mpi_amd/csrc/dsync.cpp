@@ -112,6 +112,16 @@ int dsync_connect(xmpi_comm* c, double timeout_s) {
       if (a->pid == b->pid && a->device == b->device) usable = false;  // two ranks on one stream: see the header
     }
   }
+  // (pinned words the kernels write: word 0 first failure of a kernel, bytes 8..15 epoch of the last kernel that ended, 16..23 the
+  // blocking caller's completion word, words 6..11 XCD masks and probes, word 12 the flag self-test's answer)
+  if (usable && hipHostMalloc((void**)&c->dsync_status, 64, hipHostMallocMapped) == hipSuccess) {
+    memset(c->dsync_status, 0, 64);
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, c->dsync_status, 0) == hipSuccess) c->dsync_status_dev = (uint32_t*)dev;
+  }
+  (void)hipGetLastError();
+  // the job's abort flag, readable by the GPU: a kernel that waits for a dead peer gives up
+  if (c->ctl_dev) c->dsync_abort_dev = (const int32_t*)(c->ctl_dev + ((char*)&c->ctl->header()->abort_code - (char*)c->ctl->base()));
   bool mapped = usable;
   for (int p = 0; p < N && mapped; p++) {
     RankInfo* pi = c->ctl->info(p);
@@ -131,6 +141,29 @@ int dsync_connect(xmpi_comm* c, double timeout_s) {
       }
       c->peer_page[p] = (DsyncPage*)ptr;
       c->peer_page_opened[p] = true;
+    }
+  }
+  // A mapping that OPENS is not yet one that WORKS: an uncached allocation of another device, opened through hipIpc, has to carry
+  // a peer's 8-byte store to the lane that polls it here.  Try it now, with a clock (a few seconds, inside xmpi_init), rather than
+  // find out in the first collective, which by default waits for ever: every rank stores a token into every peer's page and waits
+  // for theirs.  A rank whose words do not arrive votes "flags: no" below, and the job meets on the host.
+  if (mapped && c->dsync_status_dev) {
+    uint64_t token = 0;
+    for (int p = 0; p < N; p++) token = std::max(token, c->ctl->info(p)->flag_epoch);
+    token += 1;  // (above every token an earlier communicator left in these never-cleared pages: dsync_finalize moves the mark on)
+    const double limit_s = std::min(5.0, std::max(1.0, timeout_s / 4));
+    __atomic_store_n(c->dsync_status + 12, 0u, __ATOMIC_RELAXED);
+    hipError_t e = launch_flag_selftest(c->peer_page, c->rank, N, token, (uint64_t)(limit_s * 1e8), c->dsync_abort_dev, c->dsync_status_dev + 12,
+                                        c->local_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->local_stream);
+    const uint32_t seen = __atomic_load_n(c->dsync_status + 12, __ATOMIC_ACQUIRE), all = N >= 32 ? ~0u : (1u << N) - 1u;
+    if (e != hipSuccess || (seen & all) != all) {
+      (void)hipGetLastError();
+      if (!me->maps_why[0]) {
+        if (e != hipSuccess) snprintf(me->maps_why, sizeof me->maps_why, "rank %d: flag self-test: %s", c->rank, hipGetErrorString(e));
+        else snprintf(me->maps_why, sizeof me->maps_why, "rank %d: flag words of ranks %#x never arrived here (%.0f s)", c->rank, all & ~seen, limit_s);
+      }
+      mapped = false;
     }
   }
   // Untuned AUTO sends messages up to ll_bytes per rank as LL lines (ll.hip).  Measured with 2 processes (each kernel has the
@@ -156,6 +189,7 @@ int dsync_connect(xmpi_comm* c, double timeout_s) {
   }
   bool all_windows = true, all_flags = usable;
   std::string why_windows, why_flags;
+  bool why_flags_witness = false;
   long ll = (long)kLLMaxPayload;
   for (int p = 0; p < N; p++) {
     const RankInfo* a = c->ctl->info(p);
@@ -167,7 +201,12 @@ int dsync_connect(xmpi_comm* c, double timeout_s) {
     }
     if (usable && !(a->maps & kMapsFlags)) {
       all_flags = false;
-      if (why_flags.empty()) why_flags = why.empty() ? "rank " + std::to_string(p) + " could not map a peer's flag page" : why;
+      // (a rank that could not OPEN a page is the cause; the ranks whose self-test then waited for its words in vain are its witnesses)
+      const bool witness = why.find("never arrived") != std::string::npos;
+      if (why_flags.empty() || (why_flags_witness && !witness && !why.empty())) {
+        why_flags = why.empty() ? "rank " + std::to_string(p) + " could not map a peer's flag page" : why;
+        why_flags_witness = witness;
+      }
     }
     if (!usable && c->dsync && a->flag_addr == 0 && why_flags.empty() && !why.empty()) why_flags = why;  // (it has no page to offer)
   }
@@ -200,19 +239,11 @@ int dsync_connect(xmpi_comm* c, double timeout_s) {
     XMPI_HIP(hipHostGetDevicePointer(&dev, c->dsync_table, 0));
     c->dsync_table_dev = (const DsyncEntry*)dev;
   }
-  // the job's abort flag, readable by the GPU: a kernel that waits for a dead peer gives up
-  if (c->ctl_dev) c->dsync_abort_dev = (const int32_t*)(c->ctl_dev + ((char*)&c->ctl->header()->abort_code - (char*)c->ctl->base()));
   // split form (sched.hip): what the meet kernel resolves for the data kernel, in ordinary device memory
   if (hipMalloc((void**)&c->dsync_res, sizeof(DsyncResolved)) != hipSuccess)
     return hip_fail(hipGetLastError(), "hipMalloc(resolved table)", __FILE__, __LINE__);
   if (hipEventCreateWithFlags(&c->dsync_order_ev, hipEventDisableTiming) != hipSuccess)
     return hip_fail(hipGetLastError(), "hipEventCreate", __FILE__, __LINE__);
-  if (hipHostMalloc((void**)&c->dsync_status, 64, hipHostMallocMapped) == hipSuccess) {
-    memset(c->dsync_status, 0, 64);  // word 0: first failure of a kernel; bytes 8..15: epoch of the last kernel that ended
-    void* dev = nullptr;
-    if (hipHostGetDevicePointer(&dev, c->dsync_status, 0) == hipSuccess) c->dsync_status_dev = (uint32_t*)dev;
-  }
-  (void)hipGetLastError();
   // The split form acquires / releases once per XCD from kXcdBlocks one-wave blocks and counts on the dispatcher dealing them
   // round the XCDs.  Nothing promises that, so look: how many XCDs the GPU has (a grid that fills it) and which ones a grid of
   // kXcdBlocks reaches (status words 8, 9: pinned, zeroed above).  If the small grid misses one, the data kernel runs in its

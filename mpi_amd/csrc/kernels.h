@@ -281,6 +281,13 @@ hipError_t launch_dsync_body(const DsyncResolved* res, int nseg, size_t max_pack
 // *mask_out (device or pinned host word, zeroed by the caller) |= 1 << XCC_ID of every block of a `blocks` x one-wave grid:
 // which XCDs a grid of that size reaches on this device (blocks = 1024: the XCDs the device has)
 hipError_t launch_xcc_probe(uint32_t* mask_out, int blocks, hipStream_t stream);
+// Do flag words WORK between these ranks?  One wave: lane p stores `token` into word 1 of done[me] in rank p's page and waits (at
+// most spin_limit ticks) for rank p's token in its own page; *seen_out (device-visible host word) = the ranks whose token arrived
+// (bit per rank, own bit set).  A mapping that opens and then does not carry a peer's store to the owner's polling lane -- the way an
+// uncached allocation opened on ANOTHER device could fail -- shows here, inside xmpi_init, instead of as a first collective that
+// never ends.  Tokens grow from communicator to communicator (the pages are never cleared): a stale one never passes.
+hipError_t launch_flag_selftest(DsyncPage* const* page, int me, int n, uint64_t token, uint64_t spin_limit, const int32_t* abort_word,
+                                uint32_t* seen_out, hipStream_t stream);
 constexpr int kXcdBlocks = 16;  // blocks of the meet / done kernels
 hipError_t launch_dsync_done(const DsyncArgs& a, const DsyncResolved* res, hipStream_t stream);
 

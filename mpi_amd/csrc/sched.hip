@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <cstring>
+
 #include "kdev.h"
 #include "kernels.h"
 #include "sched_steps.h"
@@ -41,6 +43,27 @@ namespace {
 // which XCDs a grid of one-wave blocks reaches
 __global__ __launch_bounds__(64) void xcc_probe_kernel(uint32_t* mask) {
   if (threadIdx.x == 0) __hip_atomic_fetch_or(mask, 1u << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+struct FlagSelftestArgs {
+  DsyncPage* page[kDsyncRanks];
+  int32_t me, n;
+  uint64_t token, spin_limit;
+  const int32_t* abort_word;
+  uint32_t* seen;
+};
+__global__ __launch_bounds__(64) void flag_selftest_kernel(FlagSelftestArgs a) {
+  XMPI_SHARED(uint32_t, s_seen);
+  const int t = threadIdx.x;
+  if (t == 0) s_seen = 1u << a.me;
+  __syncthreads();
+  if (t < a.n && t != a.me) {
+    st_sys64(&a.page[t]->done[a.me][1], a.token);
+    if (spin_until(&a.page[a.me]->done[t][1], a.token, a.abort_word, a.spin_limit) == DSYNC_OK)
+      __hip_atomic_fetch_or(&s_seen, 1u << t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __syncthreads();
+  if (t == 0) __hip_atomic_store(a.seen, s_seen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // A few blocks (at least one per XCD): announce (block 0), wait for every peer, acquire at system scope -- each block for the L2
@@ -738,6 +761,22 @@ hipError_t launch_dsync_body(const DsyncResolved* res, int nseg, size_t max_pack
 hipError_t launch_xcc_probe(uint32_t* mask_out, int blocks, hipStream_t s) {
   if (!mask_out || blocks < 1) return hipErrorInvalidValue;
   hipLaunchKernelGGL(xcc_probe_kernel, dim3((unsigned)blocks), dim3(64), 0, s, mask_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_flag_selftest(DsyncPage* const* page, int me, int n, uint64_t token, uint64_t spin_limit, const int32_t* abort_word,
+                                uint32_t* seen_out, hipStream_t s) {
+  if (!page || !seen_out || n < 1 || n > kDsyncRanks || me < 0 || me >= n) return hipErrorInvalidValue;
+  FlagSelftestArgs a;
+  memset(&a, 0, sizeof a);
+  for (int p = 0; p < n; p++) a.page[p] = page[p];
+  a.me = me;
+  a.n = n;
+  a.token = token;
+  a.spin_limit = spin_limit;
+  a.abort_word = abort_word;
+  a.seen = seen_out;
+  hipLaunchKernelGGL(flag_selftest_kernel, dim3(1), dim3(64), 0, s, a);
   return hipGetLastError();
 }
 

@@ -1099,7 +1099,17 @@ hipError_t hipIpcOpenMemHandle(void** ptr, hipIpcMemHandle_t handle, unsigned fl
   }
   const int fd = shm_open(shm_name(h.pid, h.id).c_str(), O_RDWR, 0600);
   if (fd < 0) return fail(hipErrorInvalidHandle);
-  void* p = mmap(nullptr, h.bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_NORESERVE, fd, 0);
+  // DEVSIM_PRIVATE_UNCACHED=1[@<device>]: an uncached allocation of another process opens -- and what this device stores there never
+  // reaches its owner (a private copy): the mapping that "works" and carries nothing, which only trying it can find
+  int map_kind = MAP_SHARED;
+  if (h.flags & (hipDeviceMallocUncached | hipDeviceMallocFinegrained)) {
+    static const char* spec = getenv("DEVSIM_PRIVATE_UNCACHED");
+    if (spec) {
+      const char* at = strchr(spec, '@');
+      if (!at || atoi(at + 1) == tl_device) map_kind = MAP_PRIVATE;
+    }
+  }
+  void* p = mmap(nullptr, h.bytes, PROT_READ | PROT_WRITE, map_kind | MAP_NORESERVE, fd, 0);
   close(fd);
   if (p == MAP_FAILED) return fail(hipErrorOutOfMemory);
   std::lock_guard<std::mutex> g(g_mem_mu);

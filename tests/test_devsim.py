@@ -173,6 +173,9 @@ DEGRADED = [
     ("flag pages", {"DEVSIM_FAIL_IPC_KIND": "uncached"}, 2, "flag page", 4),
     # ... on ONE rank only: the same level for everybody (the vote), nobody waits for a rank that went another way
     ("flag pages, one rank", {"DEVSIM_FAIL_IPC_KIND": "uncached@1"}, 2, "rank 1: hipIpcOpenMemHandle(flag page", 3),
+    # the pages OPEN on rank 0's device and carry nothing (its stores into them never reach their owners): found by trying the flag
+    # words inside xmpi_init, with a clock -- not by a first collective that never ends
+    ("flag pages that carry nothing", {"DEVSIM_PRIVATE_UNCACHED": "1@0"}, 2, "never arrived", 3),
     # no uncached device memory at all (one rank's runtime refuses it): nobody has a use for the others' pages
     ("no uncached memory", {"DEVSIM_FAIL_UNCACHED_ALLOC": "1@2"}, 2, "rank 2: hipExtMallocWithFlags", 4),
     # rank 1's first open -- rank 0's window -- fails: no windows for the job (no staged step tables, no mail slots), the
