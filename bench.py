@@ -218,7 +218,9 @@ def rank_main(job: Job, grank: int):
     other = next((r for r in range(R) if job.device_of(r) != job.device_of(0)), None)
     if other is not None and not a.no_extras:
         probe = {}
-        for eng, name in ((0, "hipMemcpyAsync"), (1, "copy_kernel")):
+        # (2: a kernel that moves data as a step of the stepped kernels does -- system-scope loads / written-through stores: read
+        # against write there is the pull form against the push form)
+        for eng, name in ((0, "hipMemcpyAsync"), (1, "copy_kernel"), (2, "sys_kernel")):
             comm.barrier()
             if grank == 0:
                 probe[name + "_write_GBps"] = comm.link_probe(other, 64 << 20, eng, 10, 0)

@@ -385,7 +385,8 @@ int xmpi_prof_get(xmpi_comm* comm, int kind, uint64_t* launches, double* total_m
 
 /* Link diagnostic -- what examples/bounce is for in the reference (bounce.go:83-151), without a second program: times `iters`
  * back-to-back copies of `bytes` between this rank's window and the
- * peer's (direction 0 = write to the peer, 1 = read from the peer; engine as "copy_engine").  The
+ * peer's (direction 0 = write to the peer, 1 = read from the peer; engine 0 = hipMemcpyAsync, 1 = the library's copy kernel,
+ * 2 = a kernel that moves data the way a step of the ring / halving / tree kernels does: system-scope loads, written-through stores).  The
  * peer must not be inside a collective; call it on both ranks of a pair for the bidirectional rate. */
 int xmpi_link_probe(xmpi_comm* comm, int peer, size_t bytes, int engine, int iters, int direction,
                     double* gbps);

@@ -1662,16 +1662,17 @@ int xmpi_link_probe(xmpi_comm* c, int peer, size_t bytes, int engine, int iters,
   hipStream_t s = c->send_stream[peer] ? c->send_stream[peer] : c->local_stream;
   hipEvent_t a = ev_get(c, true), b = ev_get(c, true);
   if (!a || !b) return XMPI_ERR_HIP;
-  for (int w = 0; w < 2; w++) {
-    if (engine == 1) XMPI_HIP(launch_copy(dst, src, bytes, s));
-    else XMPI_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
-  }
+  // engine 2: the stepped kernels' own accesses -- system-scope loads, written-through stores -- with as many workers as they run
+  const int sys_grid = (int)std::max<long>(1, std::min<long>((long)((bytes + kSchedTileBytes - 1) / kSchedTileBytes), 1024 / std::max(1, c->dsync_sharers)));
+  auto once = [&]() -> hipError_t {
+    if (engine == 2) return launch_sys_copy(dst, src, bytes, sys_grid, s);
+    if (engine == 1) return launch_copy(dst, src, bytes, s);
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s);
+  };
+  for (int w = 0; w < 2; w++) XMPI_HIP(once());
   XMPI_HIP(hipStreamSynchronize(s));
   XMPI_HIP(hipEventRecord(a, s));
-  for (int i = 0; i < iters; i++) {
-    if (engine == 1) XMPI_HIP(launch_copy(dst, src, bytes, s));
-    else XMPI_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
-  }
+  for (int i = 0; i < iters; i++) XMPI_HIP(once());
   XMPI_HIP(hipEventRecord(b, s));
   XMPI_HIP(hipStreamSynchronize(s));
   float ms = 0.f;

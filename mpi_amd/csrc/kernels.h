@@ -323,6 +323,9 @@ hipError_t launch_dsync_sched(const DsyncSchedArgs& a, int dtype, int op, int gr
                               hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // tile bytes of the stepped kernels (what a worker moves per iteration): grid_x = min(cap, ceil(step bytes / this))
 constexpr size_t kSchedTileBytes = 16384;
+// dst = src exactly as a step of the stepped kernels moves data: system-scope loads and written-through stores (sc0 sc1), 16 KiB
+// tiles, `grid_x` workers -- the link probe's third engine: what a link gives the accesses the ring / halving / tree kernels make
+hipError_t launch_sys_copy(void* dst, const void* src, size_t bytes, int grid_x, hipStream_t stream);
 
 // ---- stream-ordered Send / Receive (sched.hip) ---------------------------------------------------------------------------
 // The sender's kernel puts {seq, tag, dtype, bytes, where the payload is} into box (seq-1) % kP2PBoxes of the receiver's

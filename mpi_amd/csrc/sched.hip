@@ -321,6 +321,9 @@ __device__ void range_apply(const SchedMove& m, uint32_t w, uint32_t W) {
   }
 }
 
+// one move of a step as a kernel of its own (xmpi_link_probe engine 2)
+__global__ __launch_bounds__(kBlock) void sys_copy_kernel(SchedMove m) { range_apply<uint8_t, OP_SUM, 1>(m, blockIdx.x, gridDim.x); }
+
 template <typename T, int OP>
 __global__ __launch_bounds__(kBlock) void dsync_sched_kernel(DsyncSchedArgs a) {
   XMPI_SHARED(DsyncShared, sh);
@@ -803,6 +806,19 @@ hipError_t launch_dsync_sched(const DsyncSchedArgs& a, int dtype, int op, int gr
     case DT_BF16: return sched_op<bf16_t>(a, op, grid, s, es, ee);
     default: return hipErrorInvalidValue;
   }
+}
+
+hipError_t launch_sys_copy(void* dst, const void* src, size_t bytes, int grid_x, hipStream_t s) {
+  if (!dst || !src || grid_x < 1) return hipErrorInvalidValue;
+  SchedMove m;
+  memset(&m, 0, sizeof m);
+  m.ns = 1;
+  m.D = (uint64_t)(uintptr_t)dst;
+  m.A = (uint64_t)(uintptr_t)src;
+  m.lo = 0;
+  m.hi = bytes;
+  hipLaunchKernelGGL(sys_copy_kernel, dim3((unsigned)grid_x), dim3(kBlock), 0, s, m);
+  return hipGetLastError();
 }
 
 hipError_t launch_p2p_pull(const P2PPullArgs& a, int grid_x, hipStream_t s) {

@@ -431,6 +431,13 @@ def sc_bounce(comm, args):
     msg = comm.alloc(maxlen)
     rcv = comm.alloc(maxlen)
     comm.fill(msg, maxlen, xmpi.U8, xmpi.PAT_UNIFORM, 1 + rank)
+    # what bounce measures, by the library's own probe: every engine (copy engine, copy kernel, the stepped kernels' system-scope
+    # accesses), write to the peer and read from it
+    for engine in (0, 1, 2):
+        for direction in (0, 1):
+            if even:
+                assert comm.link_probe(peer, 4 << 20, engine, 3, direction) > 0
+            comm.barrier()
     for length in BOUNCE_LENGTHS:
         for dtype, count in ((xmpi.U8, length), (xmpi.F64, length // 8)):
             nbytes = count * xmpi.DTYPE_SIZE[dtype]
@@ -2019,8 +2026,8 @@ def sc_devices(comm, args):
     assert comm.device() == rank, f"rank {rank} is on device {comm.device()}"
     assert comm.get_param("dsync") == 1, "ranks on different devices do not meet on the device"
     assert comm.get_param("dsync_sharers") == 1, f"{comm.get_param('dsync_sharers')} ranks think they share device {comm.device()}"
-    # the link probe, both directions, kernel and copy engine (rates mean nothing on virtual devices: that it runs and is > 0)
-    for engine in (0, 1):
+    # the link probe, both directions, copy engine and both kernels (rates mean nothing on virtual devices: that it runs and is > 0)
+    for engine in (0, 1, 2):
         for direction in (0, 1):
             if rank < 2:
                 assert comm.link_probe(1 - rank, 1 << 20, engine, 3, direction) > 0
@@ -2291,6 +2298,22 @@ def sc_traffic(comm, args):
         print("TRAFFIC " + json.dumps({"ranks": size, "bytes_per_rank": S, "chunk": c, "schedules": report}), flush=True)
 
 
+def sc_linkprobe(comm, args):
+    """xmpi_link_probe between ranks 0 and 1, every engine and direction, as one JSON line (scripts: what a link -- or, with both
+    ranks on one GPU, its HBM -- gives hipMemcpyAsync, the copy kernel and the stepped kernels' system-scope accesses)"""
+    import json
+    rank = comm.rank()
+    out = {}
+    for engine, name in ((0, "hipMemcpyAsync"), (1, "copy_kernel"), (2, "sys_kernel")):
+        for direction, dn in ((0, "write"), (1, "read")):
+            comm.barrier()
+            if rank == 0:
+                out[f"{name}_{dn}_GBps"] = round(comm.link_probe(1, args.get("bytes", 64 << 20), engine, args.get("iters", 10), direction), 1)
+            comm.barrier()
+    if rank == 0:
+        print("LINKPROBE " + json.dumps({"ranks_share_gpu": comm.get_param("dsync_sharers") > 1, "bytes": args.get("bytes", 64 << 20), **out}), flush=True)
+
+
 def sc_degraded(comm, args):
     """A job that could not map everything (tests/devsim fault injection: flag pages / windows / one rank's first open / no
     uncached memory): xmpi_init came back with a WORKING communicator at the best level every rank reached -- the level and the
@@ -2393,6 +2416,7 @@ def sc_peer_dies(comm, args):
 
 
 SCENARIOS = {
+    "linkprobe": sc_linkprobe,
     "degraded": sc_degraded,
     "peer_dies": sc_peer_dies,
     "traffic": sc_traffic,
