@@ -894,20 +894,29 @@ def main():
         line["roofline_isolated"] = {k: r0["iso"][k] for k in ("avg_launch_us", "achieved", "frac")}
     ring_channels = (R - 2) if (R >= 4 and R % 2 == 0) else max(1, sum(1 for d in range(1, R) if np.gcd(d, R) == 1))
     ring_share = 2.0 * (R - 1) / R / min(8, ring_channels) if R > 1 else 0.0
-    if meaningful and R > 1:
+    ndev = r0["devices"]
+    mixed_share = None
+    if 1 < ndev < R and r0["best"]["algo"] in ("auto (library)", "zcopy", "direct"):
+        # Several ranks per GPU (--gpus 2 / 4): the one-hop schedules (the zero-copy fold with its host rendezvous, DIRECT) move
+        # S / R between every ordered pair of RANKS twice (contribution in, result out), so a directed GPU pair -- one link -- carries
+        # 2 x (R / ndev)^2 x S / R = 2 R / ndev^2 x S: at 2 GPUs FOUR times S through the one link between them.  That link, not
+        # either GPU's HBM, bounds the step.
+        mixed_share = 2.0 * R / (ndev * ndev)
+    if (meaningful and R > 1) or mixed_share:
         # One rank per GPU: the LINKS bound the collective, not the HBM of any one GPU -- `roofline` is the link
         # roofline of the schedule that was timed, the kernel's HBM figure moves to `roofline_hbm`.  achieved = what the BUSIEST
         # link direction carries per step (the schedule's share of S, counted on virtual devices and asserted to the byte in the CPU
         # suite: DESIGN section 8) / the step time; peak = one direction of one link, nominal; peak_measured = what the copy kernel
         # wrote over one link in the probe before the timed region.
         sched = str(r0["tune"].get("algo") or r0["best"]["algo"])
-        share = {"ring": ring_share, "ring_push": ring_share, "rhd": 1.0, "rhd_push": 1.0}.get(sched, 2.0 / R)
+        share = mixed_share or {"ring": ring_share, "ring_push": ring_share, "rhd": 1.0, "rhd_push": 1.0}.get(sched, 2.0 / R)
         measured = (r0["link"] or {}).get("copy_kernel_write_GBps")
         ach = share * S / t / 1e9
         line["roofline_hbm"] = roof
         line["roofline"] = {"bound": "xgmi", "kernel": roof["kernel"], "schedule": sched, "unit": "GB/s", "achieved": ach, "peak": XGMI_DIR_GBPS,
                             "frac": ach / XGMI_DIR_GBPS, "peak_measured": measured, "frac_of_measured": (ach / measured) if measured else None,
                             "busiest_link_direction_bytes_over_S": share, "algorithmic_bytes_per_link_direction": share * S,
+                            "ranks_per_gpu": R // ndev,
                             "traffic": None, "direction": "stores" if sched in ("ring_push", "rhd_push", "zpush") else
                                                           "loads" if sched in ("ring", "rhd") else "loads and stores (S / R each per link)"}
     if r0.get("ring_named"):

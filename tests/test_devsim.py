@@ -317,7 +317,12 @@ def test_the_scale_command_on_virtual_gpus(devsim_lib, gpus, tmp_path):
         assert d["cpu_baseline"]["see"].startswith("the N = 1 line")
     else:
         assert d["config"]["transport"].startswith(f"mixed: 8 ranks on {gpus} GPUs")
-        assert d["roofline"]["bound"] == "hbm" and "ring" not in d  # (several ranks per GPU: no link figure stands for the step)
+        # several ranks per GPU: the one link between a pair of GPUs carries 2 R / gpus^2 x S per direction (at 2 GPUs: 4 S) -- that, not
+        # an HBM, bounds the step; the HBM figure stays beside it
+        rf = d["roofline"]
+        assert rf["bound"] == "xgmi" and rf["busiest_link_direction_bytes_over_S"] == 2.0 * 8 / gpus ** 2 and rf["ranks_per_gpu"] == 8 // gpus, rf
+        assert abs(rf["achieved"] - rf["algorithmic_bytes_per_link_direction"] / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-9
+        assert d["roofline_hbm"]["bound"] == "hbm" and "ring" not in d
 
 
 def test_the_8gpu_script_rehearsal(stage, devsim_lib, tmp_path):
