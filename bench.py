@@ -804,7 +804,11 @@ def main():
     n2, ms2, b2 = r0["prof"][xmpi.PROF_REDUCE2]
     nn, msn, bn = r0["prof"][xmpi.PROF_REDUCEN]
     nz, msz, bz = r0["prof"][xmpi.PROF_ZCOPY]
-    if nz and msz >= max(ms2, msn) and r0["best"]["algo"] == "zpush":
+    if nz and msz >= max(ms2, msn) and r0["best"]["algo"] == "zpush" and r0["dsync"] == 1:
+        kname, launches, ms, by = ("dsync_fold_kernel<uint8_t,SUM,1> (push-only, kernel 1: contributions stored into the peers' own blocks) + "
+                                   f"dsync_fold_kernel / dsync_body_kernel<float,SUM,{R}> with local sources (kernel 2: rank-order fold of what landed, "
+                                   "stored into every receive buffer); bytes and time summed over the two"), nz, msz, bz
+    elif nz and msz >= max(ms2, msn) and r0["best"]["algo"] == "zpush":
         kname, launches, ms, by = ("zero-copy push pipeline: copy_batch_kernel (contributions into the peers' receive buffers) + "
                                    f"reduce_n_multi_kernel<float,SUM,{R}> (local rank-order fold) + copy_multi_kernel (results to "
                                    "all peers); bytes and time summed over the three"), nz, msz, bz
