@@ -245,6 +245,15 @@ def test_split_form_xcd_guard_trips():
     run_ranks("split", 2, {"counts": [4099], "trip": 1}, timeout=300)
 
 
+@pytest.mark.parametrize("size,env,level", [(2, {}, 0), (3, {}, 0), (4, {"XMPI_DSYNC": "1"}, 0)])
+def test_init_vote_on_a_healthy_machine(size, env, level):
+    """xmpi_init's vote (windows, flag pages tried with the self-test kernel, the LL limit) on real hardware: nothing degraded, and
+    what the degraded levels rely on -- every collective by every name, helloworld, Send / Receive out of registered, host and never
+    registered device memory -- works here (tests/scenarios.py sc_degraded; the fault injections themselves run on virtual devices
+    in the CPU suite)"""
+    run_ranks("degraded", size, {"expect": level, "why": ""}, timeout=300, env=env)
+
+
 @pytest.mark.parametrize("size", [2, 4])
 def test_collectives_on_several_streams(size):
     run_ranks("multistream", size, timeout=300)
