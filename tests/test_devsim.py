@@ -151,7 +151,7 @@ SCENARIOS = [
     ("ll", 5, None),
     # the stepped kernels, pull and push form: every dtype and operator, in place, odd alignments, channels and workers; the push
     # form's bits against the pull form's
-    ("sched", 4, {"shapes": [(0, 0), (2, 3)], "counts": [1, 17, 4099]}),
+    ("sched", 4, {"shapes": [(0, 0), (2, 3)], "counts": [1, 17, 4099], "quick": 1}),
     ("sched", 3, {"shapes": [(1, 2)], "counts": [1, 4099], "quick": 1}),
     ("sched", 8, {"shapes": [(0, 0)], "counts": [17], "quick": 1}),
     ("split", 4, {"counts": [1, 17, 4099]}),
