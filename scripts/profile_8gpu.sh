@@ -58,7 +58,7 @@ done
 for AG in 0 8192 32768; do
   XMPI_LL_BYTES=32768 XMPI_AGENT_LL_BYTES=$AG XMPI_BASEPORT=7350 timeout 300 $BIN/xmpirun $N $BIN/coll_sweep 32768 ${CS##* } 2 > $O/coll_sweep_n${N}_agent$AG.json 2>> $O/prod.err
 done
-if [ "$REH" = 1 ]; then python scripts/show_bench.py $O/bench_n$N.json | head -40; exit 0; fi
+if [ "$REH" = 1 ]; then python scripts/show_bench.py $O/bench_n$N.json | head -40; python scripts/first_hour_report.py $O; exit 0; fi
 cd /tmp
 XMPI_BASEPORT=7360 timeout 300 rocprofv3 --marker-trace --kernel-trace --output-format csv -d $O/markers -- $BIN/xmpirun $N $BIN/coll_sweep ${CS%% *} 20 > $O/coll_sweep_under_marker_trace.json 2> $O/markers.err
 for f in $O/markers/*/*marker_api_trace.csv; do head -n 120 $f > $O/marker_trace_$(basename $f | cut -d_ -f1)_head.txt; done
@@ -70,4 +70,5 @@ cd $ROOT
 find $O -name "*.csv" ! -name "*kernel_stats.csv" -delete; find $O -name "*.db" -delete
 find $O -name "*kernel_stats.csv" | head -40
 python scripts/show_bench.py $O/bench_n$N.json 2>/dev/null | head -40
+python scripts/first_hour_report.py $O   # the same files in the order DESIGN.md section 0 reads them
 du -sh $O

@@ -331,6 +331,7 @@ def test_the_8gpu_script_rehearsal(stage, devsim_lib, tmp_path):
     result in them is exact, every mode it names ran, nobody shares a device"""
     import glob
     import json
+    import sys
     env = dict(stage, PYTHONPATH=os.path.join(ROOT, "tests", "devsim", "site"), XMPI_DEVSIM_LIB=devsim_lib, DEVSIM_DEVICES="8", XMPI_NGPUS="8",
                XMPI_8GPU_REHEARSAL="1", XMPI_8GPU_OUT=str(tmp_path / "out"))
     r = subprocess.run(["bash", os.path.join(ROOT, "scripts", "profile_8gpu.sh"), "8"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
@@ -355,6 +356,12 @@ def test_the_8gpu_script_rehearsal(stage, devsim_lib, tmp_path):
             assert d["rows"], d
     assert seen == {"auto", "fused", "fused2", "split", "zpush", "ring", "ring_push", "rhd", "rhd_push"}, seen
     assert open(os.path.join(out, "prod.err")).read().strip() == ""
+    # ... and the one-screen reading of it names what the first hour on a node has to look at
+    rep = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "first_hour_report.py"), out], capture_output=True, text=True, timeout=120)
+    assert rep.returncode == 0, rep.stderr[-2000:]
+    for needle in ("degraded: no", "link roofline: schedule", "link probe sys_kernel", "the tuner chose", "ring by name, pull", "ring by name, push",
+                   "ring_push", "rhd_push", "XCD masks meet / done 0xff / 0xff", "link bound", "cfg 5"):
+        assert needle in rep.stdout, (needle, rep.stdout[-3000:])
 
 
 # ---- what the links would carry -----------------------------------------------------------------------------------------------------------
