@@ -63,7 +63,8 @@ typedef enum {
                            meet on the host: into its receive buffer, out of place, count divisible by
                            ranks x 16 B) --, folded locally
                            in rank order, results pushed back; 2 kernels, one hop each way (the store-only
-                           counterpart of ZCOPY); for the other collectives the same as ZCOPY   */
+                           counterpart of ZCOPY); reduce: the same with the results stored to the root
+                           only; allgather and bcast are store-only as ZCOPY runs them        */
   XMPI_ALGO_LL = 7,     /* low latency, messages up to 32 KiB per rank with one process per GPU: every rank pushes
                            its payload as {data, flag} lines into the peers' flag allocations and folds
                            locally in rank order -- one one-way hop, nothing registered, announced or read

@@ -1070,7 +1070,7 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
   };
 
   // (under capture the push-only form is the fold: its staging area is a block the communicator may replace later)
-  const bool use_push = push && coll == COLL_ALLREDUCE && !capturing;
+  const bool use_push = push && (coll == COLL_ALLREDUCE || coll == COLL_REDUCE) && !capturing;
   if (stepped) {
     // ring / recursive halving + doubling / binary tree: ONE kernel per rank runs every step of the schedule, the steps
     // released by flag words between the peers' kernels (sched.hip) -- the schedules north_star names, without a host
@@ -1212,9 +1212,9 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
       a.seg[0].src_mask = everyone;
       a.seg[0].src_from_recv = 2;
       a.seg[0].stage_stride = region;
-      a.seg[0].dst_mask = everyone;
+      a.seg[0].dst_mask = coll == COLL_REDUCE ? (1u << root) : everyone;  // (reduce: the folded chunks meet in the root's buffer)
       split_pref = -1;  // (meet / body / done by size, like the fold it is)
-      const size_t moved = (size_t)(2 * N) * my_cnt * es;
+      const size_t moved = (size_t)(N + (coll == COLL_REDUCE ? 1 : N)) * my_cnt * es;
       traffic += moved;
       rc = launch(N, dtype, op, my_cnt / al, moved);
     }

@@ -111,6 +111,9 @@ def sc_allreduce_small(comm, args):
             allreduce_case(comm, xmpi.F32, count, xmpi.ALGO_ZPUSH, pattern=xmpi.PAT_SIGNED, inplace=inplace, exact=True)
     allreduce_case(comm, xmpi.F16, 30011, xmpi.ALGO_ZPUSH, inplace=True, misalign=3, exact=True)
     allreduce_case(comm, xmpi.I64, 5003, xmpi.ALGO_ZPUSH, op=xmpi.MAX, pattern=xmpi.PAT_SIGNED, inplace=True, exact=True)
+    for root in sorted({0, comm.size() - 1}):  # ... and reduce: the folded chunks stored to the root only
+        reduce_case(comm, xmpi.F32, 100003, root, xmpi.ALGO_ZPUSH, exact=True, what="push-only reduce")
+        reduce_case(comm, xmpi.I64, 17, root, xmpi.ALGO_ZPUSH, pat=xmpi.PAT_UNIFORM, what="push-only reduce")
     # known answer: x_r[i] = r + 1  =>  every element N(N+1)/2
     n = comm.size()
     buf = comm.alloc(4 * 1024)
