@@ -2014,8 +2014,10 @@ int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
   for (int kk = 0; kk < xmpi_comm::kTuneClasses; kk++) {
     c->tune_split[COLL_REDUCE][kk] = c->tune_algo[COLL_ALLREDUCE][kk] == XMPI_ALGO_ZCOPY ? c->tune_split[COLL_ALLREDUCE][kk] : (int8_t)-1;
     c->tune_split[COLL_BCAST][kk] = -1;
-    // ... and go as LL lines where the allreduce does
-    c->tune_algo[COLL_REDUCE][kk] = c->tune_algo[COLL_BCAST][kk] = c->tune_algo[COLL_ALLREDUCE][kk] == XMPI_ALGO_LL ? (int8_t)XMPI_ALGO_LL : (int8_t)-1;
+    // ... and go as LL lines where the allreduce does; a reduce is push-only where the allreduce is (links that prefer stores)
+    const int8_t ar = c->tune_algo[COLL_ALLREDUCE][kk];
+    c->tune_algo[COLL_BCAST][kk] = ar == XMPI_ALGO_LL ? (int8_t)XMPI_ALGO_LL : (int8_t)-1;
+    c->tune_algo[COLL_REDUCE][kk] = ar == XMPI_ALGO_LL ? (int8_t)XMPI_ALGO_LL : ar == XMPI_ALGO_ZPUSH ? (int8_t)XMPI_ALGO_ZPUSH : (int8_t)-1;
   }
   c->tuned = true;
   return xmpi_barrier(c);
