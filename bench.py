@@ -216,7 +216,7 @@ def rank_main(job: Job, grank: int):
     # ---- the links first (multi-GPU only), before anything is tuned: what one xGMI link gives, per engine ----------
     link = None
     other = next((r for r in range(R) if job.device_of(r) != job.device_of(0)), None)
-    if other is not None and not a.no_extras:
+    if other is not None and not a.no_extras and comm.get_param("windows_ok") == 1:  # (the probe copies between the windows)
         probe = {}
         # (2: a kernel that moves data as a step of the stepped kernels does -- system-scope loads / written-through stores: read
         # against write there is the pull form against the push form)
