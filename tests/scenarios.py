@@ -1222,10 +1222,14 @@ def sc_sched(comm, args):
     assert comm.get_param("dsync_sched_launches") > l0, "the stepped kernels did not run"
     # a host buffer and a never-registered device buffer take the same kernels through registered stand-ins
     x = oracle.fill(5000, xmpi.I64, xmpi.PAT_UNIFORM, 5 + rank)
-    out = np.zeros_like(x)
-    comm.allreduce(x, out, 5000, xmpi.I64, xmpi.SUM, xmpi.ALGO_RING)
     want = oracle.reduce_ranks([oracle.fill(5000, xmpi.I64, xmpi.PAT_UNIFORM, 5 + r) for r in range(size)], xmpi.I64, 0)
-    assert out.tobytes() == want.tobytes()
+    for algo in (xmpi.ALGO_RING, xmpi.ALGO_RING_PUSH, xmpi.ALGO_RHD_PUSH, xmpi.ALGO_ZPUSH):
+        out = np.zeros_like(x)
+        comm.allreduce(x, out, 5000, xmpi.I64, xmpi.SUM, algo)
+        assert out.tobytes() == want.tobytes(), f"host slices, algo {algo}"
+        both = x.copy()  # ... and in place (the stand-in is its own receive buffer: the push forms land in the communicator's block)
+        comm.allreduce(both, both, 5000, xmpi.I64, xmpi.SUM, algo)
+        assert both.tobytes() == want.tobytes(), f"host slice in place, algo {algo}"
 
 
 def bcast_case(comm, dtype, count, root, algo, seed=40, what="bcast"):
