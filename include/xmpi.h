@@ -365,11 +365,13 @@ long xmpi_get_param(const xmpi_comm* comm, const char* name);
 
 /* (No counterpart in the reference: it has one transport and one schedule.)  The library's own schedule table.  xmpi_tune times, on this job's real layout and links, the schedules it offers
  * for an allreduce (one zero-copy kernel with 1 or 2 packets in flight, the meet / body / done form, the push-only
- * form, the ring and the halving kernel each in its pull and its push form, LL lines) and an allgather, for message sizes 1 KiB ... max_bytes (x4 steps), lets
+ * form, the ring and the halving kernel each in its pull and its push form, LL lines), an allgather (fold, ring kernel in both forms,
+ * LL lines), a bcast (fold, tree kernel in both forms, LL lines) and a reduce (the fold's forms, push-only, tree kernel in both
+ * forms, LL lines), for message sizes 1 KiB ... max_bytes (x4 steps), lets
  * every rank see the slowest rank's figures and keeps the winner per size class: XMPI_ALGO_AUTO (and the
  * stream-ordered forms) consult that table from then on, so a Go or C caller gets the schedule a benchmark would pick.
  * Collective (same max_bytes on every rank); a few hundred milliseconds.  The table is readable through
- * xmpi_get_param("tune_algo_<collective>_<class>") (collective 0 = allreduce, 1 = allgather; class k = messages of
+ * xmpi_get_param("tune_algo_<collective>_<class>") (collective 0 = allreduce, 1 = allgather, 2 = bcast, 3 = reduce; class k = messages of
  * [2^(k+8), 2^(k+9)) bytes per rank; -1 = built-in rule), "tune_split_..." (1 = meet / body / done), "tune_unroll_...".
  * Per row of (max-over-ranks) mean times the fastest candidate wins, except that the default stays unless beaten by more
  * than 3 % (noise must not flip the schedule). */

@@ -1503,7 +1503,8 @@ int xmpi_set_param(xmpi_comm* c, const char* name, long value) {
   else if (n == "tuned") c->tuned = value != 0;  // 0: AUTO forgets the table of xmpi_tune
   else if (n == "tune_mask") c->tune_mask = value;  // bit k = 0: xmpi_tune leaves candidate k out (1 other unroll, 2 meet / body / done,
                                                     // 3 push-only, 4 ring kernel, 5 halving kernel, 6 LL lines, 7 ring kernel push form,
-                                                    // 8 halving kernel push form); the default form always runs
+                                                    // 8 halving kernel push form, 9 tree kernel, 10 tree kernel push form); the default
+                                                    // form always runs
   else if (n == "kernel_mode") set_kernel_mode((int)value);  // process-wide
   else if (n == "grid_cap") set_grid_cap((int)value);        // process-wide
   else return XMPI_ERR_ARG;
@@ -1894,7 +1895,7 @@ int xmpi_tune_decide(const double* us, int n, double margin) {
   return best;
 }
 
-// Times the schedules this job's layout offers for allreduce-sum f32 (and allgather) on the real buffers, size class by size
+// Times the schedules this job's layout offers for allreduce-sum f32, allgather, bcast and reduce on the real buffers, size class by size
 // class, lets every rank see the same (max over ranks) figures and fills the table AUTO consults (dsync.cpp tuned_choice).
 // Collective: every rank calls it with the same max_bytes.  With ranks that meet on the host there is nothing to choose.
 int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
@@ -1931,13 +1932,30 @@ int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
   // instead of loaded -- which of the two a link moves faster is the machine's to say
   cands.push_back({XMPI_ALGO_RING_PUSH, 0, u0});                                   // candidate 7
   cands.push_back({XMPI_ALGO_RHD_PUSH, 0, u0});                                    // candidate 8
+  // bcast and reduce: the tree kernels in both forms against the fold's two halves
+  cands.push_back({XMPI_ALGO_TREE, 0, u0});                                        // candidate 9
+  cands.push_back({XMPI_ALGO_TREE_PUSH, 0, u0});                                   // candidate 10
+  // which candidates a collective has: (the fold, LL lines) all four; allreduce every form of the fold and ring / halving in
+  // both forms; allgather the ring; bcast the tree (its fold is one kernel whatever the size); reduce what allreduce has of the
+  // fold, and the tree
+  auto offered = [&](int coll, const Cand& cd) {
+    const bool tree = cd.algo == XMPI_ALGO_TREE || cd.algo == XMPI_ALGO_TREE_PUSH;
+    const bool ring = cd.algo == XMPI_ALGO_RING || cd.algo == XMPI_ALGO_RING_PUSH;
+    const bool rhd = cd.algo == XMPI_ALGO_RHD || cd.algo == XMPI_ALGO_RHD_PUSH;
+    switch (coll) {
+      case COLL_ALLREDUCE: return !tree;
+      case COLL_ALLGATHER: return !tree && !rhd && cd.algo != XMPI_ALGO_ZPUSH && cd.unroll == u0;
+      case COLL_BCAST: return !ring && !rhd && cd.algo != XMPI_ALGO_ZPUSH && cd.unroll == u0 && cd.split == 0;
+      default: return !ring && !rhd && cd.unroll == u0;  // COLL_REDUCE
+    }
+  };
   const long keep_split = c->dsync_split_bytes, keep_unroll = c->dsync_unroll;
   const bool keep_tuned = c->tuned;
   c->tuned = false;
   memset(c->tune_algo, -1, sizeof c->tune_algo);
   memset(c->tune_split, -1, sizeof c->tune_split);
   memset(c->tune_unroll, 0, sizeof c->tune_unroll);
-  for (int coll : {(int)COLL_ALLREDUCE, (int)COLL_ALLGATHER}) {
+  for (int coll : {(int)COLL_ALLREDUCE, (int)COLL_ALLGATHER, (int)COLL_BCAST, (int)COLL_REDUCE}) {
     for (size_t bytes = 1024; bytes <= max_bytes && rc == XMPI_OK; bytes *= 4) {
       const size_t per_rank = coll == COLL_ALLGATHER ? bytes / (size_t)c->size / 16 * 16 : bytes;
       if (per_rank < 16) continue;
@@ -1951,7 +1969,7 @@ int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
         for (size_t k = 0; k < cands.size() && rc == XMPI_OK; k++) {
           const Cand& cd = cands[k];
           if (cd.algo < 0) continue;
-          if (coll == COLL_ALLGATHER && (cd.algo == XMPI_ALGO_ZPUSH || cd.algo == XMPI_ALGO_RHD || cd.algo == XMPI_ALGO_RHD_PUSH || cd.unroll != u0)) continue;
+          if (!offered(coll, cd)) continue;
           if (cd.algo == XMPI_ALGO_LL && per_rank > kLLMaxPayload) continue;
           if (k > 0 && !((c->tune_mask >> k) & 1)) continue;  // a schedule the caller has ruled out on this machine (never the default)
           rc = xmpi_barrier(c);
@@ -1962,7 +1980,7 @@ int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
           double t0 = 0;
           for (int i = -1; i < iters && rc == XMPI_OK; i++) {  // i = -1: a warm-up that also maps whatever is new
             if (i == 0) t0 = now_seconds();
-            rc = dsync_collective(c, coll, 0, send, recv, per_rank / 4, XMPI_F32, XMPI_SUM, c->local_stream,
+            rc = dsync_collective(c, coll, 0, coll == COLL_BCAST ? recv : send, recv, per_rank / 4, XMPI_F32, XMPI_SUM, c->local_stream,
                                   /*blocking=*/i == -1 || i == iters - 1, cd.algo);
           }
           const double t_us = (now_seconds() - t0) / iters * 1e6;
@@ -1977,7 +1995,10 @@ int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
       if (rc != XMPI_OK) break;
       // "the default stays on a tie" -- and the untuned library already runs meet / body / done from dsync_split_bytes on: there
       // candidate 2 is the default, so it is decided with the two swapped
-      const bool split_is_default = coll == COLL_ALLREDUCE && keep_split > 0 && per_rank >= (size_t)keep_split && worst[2] > 0;
+      // (what dsync_split_bytes is compared with: the bytes one rank's kernel moves -- dsync.cpp launch)
+      const size_t moved = coll == COLL_ALLREDUCE ? 2 * per_rank : coll == COLL_REDUCE ? per_rank / (size_t)c->size * (size_t)(c->size + 1)
+                           : coll == COLL_ALLGATHER ? per_rank * (size_t)(c->size + 1) : 0;
+      const bool split_is_default = keep_split > 0 && moved >= (size_t)keep_split && worst[2] > 0;
       if (split_is_default) std::swap(worst[0], worst[2]);
       int best = xmpi_tune_decide(worst.data(), (int)worst.size(), 0.03);
       if (split_is_default && (best == 0 || best == 2)) best = 2 - best;
@@ -2009,15 +2030,6 @@ int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
   if (rc != XMPI_OK) {
     c->tuned = keep_tuned;
     return rc;
-  }
-  // reduce and bcast move like the allreduce's two halves: they inherit the split rule, not the algorithm
-  for (int kk = 0; kk < xmpi_comm::kTuneClasses; kk++) {
-    c->tune_split[COLL_REDUCE][kk] = c->tune_algo[COLL_ALLREDUCE][kk] == XMPI_ALGO_ZCOPY ? c->tune_split[COLL_ALLREDUCE][kk] : (int8_t)-1;
-    c->tune_split[COLL_BCAST][kk] = -1;
-    // ... and go as LL lines where the allreduce does; a reduce is push-only where the allreduce is (links that prefer stores)
-    const int8_t ar = c->tune_algo[COLL_ALLREDUCE][kk];
-    c->tune_algo[COLL_BCAST][kk] = ar == XMPI_ALGO_LL ? (int8_t)XMPI_ALGO_LL : (int8_t)-1;
-    c->tune_algo[COLL_REDUCE][kk] = ar == XMPI_ALGO_LL ? (int8_t)XMPI_ALGO_LL : ar == XMPI_ALGO_ZPUSH ? (int8_t)XMPI_ALGO_ZPUSH : (int8_t)-1;
   }
   c->tuned = true;
   return xmpi_barrier(c);

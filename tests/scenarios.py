@@ -2010,7 +2010,7 @@ def sc_tune(comm, args):
         assert comm.get_param("tuned") == 0
         return
     assert comm.get_param("tuned") == 1
-    table = np.array([comm.get_param(f"tune_{w}_{c}_{k}") for w in ("algo", "split", "unroll") for c in (0, 1) for k in range(24)],
+    table = np.array([comm.get_param(f"tune_{w}_{c}_{k}") for w in ("algo", "split", "unroll") for c in (0, 1, 2, 3) for k in range(24)],
                      dtype=np.int64)
     everybody = np.zeros(table.size * size, dtype=np.int64)
     comm.allgather(table, everybody, table.size, xmpi.I64, xmpi.ALGO_DIRECT)
@@ -2020,8 +2020,17 @@ def sc_tune(comm, args):
         allreduce_case(comm, xmpi.I64, count, xmpi.ALGO_AUTO, exact=True)
         allreduce_case(comm, xmpi.F32, count, xmpi.ALGO_AUTO, exact=False)
         allgather_case(comm, xmpi.I64, count, xmpi.ALGO_AUTO)
+        for root in sorted({0, size - 1}):  # (the tuner measured with root 0: the table holds for any)
+            bcast_case(comm, xmpi.I64, count, root, xmpi.ALGO_AUTO, what="tuned bcast")
+            reduce_case(comm, xmpi.I64, count, root, xmpi.ALGO_AUTO, what="tuned reduce")
+    # every collective has its own measured rows: bcast and reduce choose among the fold, the tree kernels in both forms and LL lines
+    algo_of = lambda coll: table[coll * 24:(coll + 1) * 24]
+    for coll, allowed in ((2, {xmpi.ALGO_ZCOPY, xmpi.ALGO_TREE, xmpi.ALGO_TREE_PUSH, xmpi.ALGO_LL}),
+                          (3, {xmpi.ALGO_ZCOPY, xmpi.ALGO_ZPUSH, xmpi.ALGO_TREE, xmpi.ALGO_TREE_PUSH, xmpi.ALGO_LL})):
+        assert any(v >= 0 for v in algo_of(coll)) and all(int(v) in allowed for v in algo_of(coll) if v >= 0), (coll, algo_of(coll))
     if rank == 0:
-        print("tuned allreduce table:", [int(v) for v in table[:24]], "split:", [int(v) for v in table[48:72]], flush=True)
+        print("tuned allreduce table:", [int(v) for v in table[:24]], "split:", [int(v) for v in table[96:120]], flush=True)
+        print("tuned bcast / reduce tables:", [int(v) for v in algo_of(2)], [int(v) for v in algo_of(3)], flush=True)
 
 
 def sc_devices(comm, args):

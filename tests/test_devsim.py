@@ -159,6 +159,10 @@ SCENARIOS = [
     ("p2p_stream", 4, None),
     ("soak", 3, None),
     ("lifecycle_stress", 2, None),
+    # the library's tuner over all four collectives (times mean nothing here: that every candidate of every collective runs, the
+    # ranks agree on the table, and AUTO follows it to the right result)
+    ("tune", 4, {"max_bytes": 65536}),
+    ("tune", 7, {"max_bytes": 4096}),
 ]
 
 
