@@ -263,6 +263,9 @@ def rank_main(job: Job, grank: int):
                     "split": comm.get_param(f"tune_split_0_{cls}"), "unroll": comm.get_param(f"tune_unroll_0_{cls}"),
                     "table_algo": [comm.get_param(f"tune_algo_0_{k}") for k in range(24)],
                     "table_split": [comm.get_param(f"tune_split_0_{k}") for k in range(24)],
+                    "tables_other": {w: [{**ALGO_NAME, xmpi.ALGO_TREE: "tree", xmpi.ALGO_TREE_PUSH: "tree_push"}.get(comm.get_param(f"tune_algo_{ci}_{k}"), "default")
+                                         for k in range(0, 24, 2)]
+                                     for ci, w in ((1, "allgather"), (2, "bcast"), (3, "reduce"))},  # (per measured size, 1 KiB x4 ...)
                     "probe_ok": sorted(job.probe_ok) if job.probe_ok is not None else None}
         # should the library's choice not reproduce the oracle on this machine: the one-kernel fold (no tuned table, nothing
         # split), then the host-driven schedules

@@ -18,9 +18,15 @@ SHARE = {"auto": None, "fused": 0.25, "fused2": 0.25, "split": 0.25, "zpush": 0.
 
 def last_json(path):
     try:
-        return json.loads(open(path).read().strip().split("\n")[-1])
-    except (OSError, ValueError, IndexError):
+        text = open(path).read().strip()
+    except OSError:
         return None
+    for piece in (text.split("\n")[-1], text):  # one JSON line after whatever was printed before it, or one (indented) document
+        try:
+            return json.loads(piece)
+        except ValueError:
+            pass
+    return None
 
 
 def main():
@@ -48,6 +54,9 @@ def main():
                 verdict = "reads and writes alike" if 0.85 < r / w < 1.18 else ("READS SLOWER: the push forms / push-only should win" if r < w else "writes slower: the pull forms should win")
                 print(f"   link probe {eng:15s} write {w:7.1f}  read {r:7.1f}  both ways {probe.get(eng + '_bidir_each_GBps', 0):7.1f} GB/s  -> {verdict}")
         print("   the tuner chose:", line["config"].get("tuned"))
+        ex = last_json(os.path.join(d, f"bench_n{n}_extras.json")) or {}
+        for coll, row in ((ex.get("autotune") or {}).get("tables_other") or {}).items():
+            print(f"      {coll:9s} 1 KiB, 4 KiB ... :", " ".join(row))
         for form, v in (line.get("ring") or {}).items():
             if isinstance(v, dict) and "frac_of_link_peak" in v:
                 ok = "MEETS" if v["frac_of_link_peak"] >= 0.7 else "below"
