@@ -301,8 +301,10 @@ int xmpi_stream_sync(xmpi_comm* comm, void* stream);
 /* (No counterpart in the reference.)  hipGraph capture: the stream-ordered collectives enqueued on `stream` between xmpi_graph_begin and xmpi_graph_end
  * (registered device buffers; call each once before capturing so that everything is mapped) become an executable
  * graph that xmpi_graph_launch replays -- one launch for the whole sequence, the caller's own kernels captured on
- * that stream included.  Every rank captures the same sequence and replays it equally often.  Needs ranks that
- * meet on the device (one process per GPU); XMPI_ERR_UNSUPPORTED otherwise. */
+ * that stream included.  Every rank captures the same sequence and replays it equally often.  A graph cannot hold a
+ * block the library lends per call: where the schedule table names a push form, its pull form is captured (the same bits);
+ * where it names push-only or the tree reduce, the fold.  Needs ranks that meet on the device (one process per GPU);
+ * XMPI_ERR_UNSUPPORTED otherwise. */
 int xmpi_graph_begin(xmpi_comm* comm, void* stream);
 int xmpi_graph_end(xmpi_comm* comm, void* stream, void** graph);
 int xmpi_graph_launch(xmpi_comm* comm, void* graph, void* stream);

@@ -1505,6 +1505,19 @@ int xmpi_set_param(xmpi_comm* c, const char* name, long value) {
                                                     // 3 push-only, 4 ring kernel, 5 halving kernel, 6 LL lines, 7 ring kernel push form,
                                                     // 8 halving kernel push form, 9 tree kernel, 10 tree kernel push form); the default
                                                     // form always runs
+  else if (n.rfind("tune_", 0) == 0) {  // tune_<algo|split|unroll>_<collective 0..3>_<size class>: a row of the table AUTO follows once
+                                        // "tuned" is 1 -- xmpi_tune's to write; a benchmark or a test standing in for it may
+    int coll = -1, cls = -1;
+    char what[16] = {0};
+    if (sscanf(name, "tune_%15[a-z]_%d_%d", what, &coll, &cls) != 3 || coll < 0 || coll >= 4 || cls < 0 || cls >= xmpi_comm::kTuneClasses ||
+        value < -1 || value >= XMPI_ALGO_COUNT)
+      return XMPI_ERR_ARG;
+    const std::string w = what;
+    if (w == "algo") c->tune_algo[coll][cls] = (int8_t)value;
+    else if (w == "split") c->tune_split[coll][cls] = (int8_t)value;
+    else if (w == "unroll") c->tune_unroll[coll][cls] = (int8_t)value;
+    else return XMPI_ERR_ARG;
+  }
   else if (n == "kernel_mode") set_kernel_mode((int)value);  // process-wide
   else if (n == "grid_cap") set_grid_cap((int)value);        // process-wide
   else return XMPI_ERR_ARG;

@@ -893,9 +893,18 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     algo = XMPI_ALGO_ZCOPY;  // named, but too long for the slots: the fold (the same decision on every rank)
   }
   // the push forms of the stepped kernels: the same schedule, the data stored into the peer instead of loaded from it
-  const bool sched_push = algo == XMPI_ALGO_RING_PUSH || algo == XMPI_ALGO_RHD_PUSH || algo == XMPI_ALGO_TREE_PUSH;
-  const int sched_algo = algo == XMPI_ALGO_RING_PUSH ? XMPI_ALGO_RING : algo == XMPI_ALGO_RHD_PUSH ? XMPI_ALGO_RHD
-                         : algo == XMPI_ALGO_TREE_PUSH ? XMPI_ALGO_TREE : algo;
+  bool sched_push = algo == XMPI_ALGO_RING_PUSH || algo == XMPI_ALGO_RHD_PUSH || algo == XMPI_ALGO_TREE_PUSH;
+  int sched_algo = algo == XMPI_ALGO_RING_PUSH ? XMPI_ALGO_RING : algo == XMPI_ALGO_RHD_PUSH ? XMPI_ALGO_RHD
+                   : algo == XMPI_ALGO_TREE_PUSH ? XMPI_ALGO_TREE : algo;
+  if (capturing) {
+    // A graph cannot hold what is lent per call -- a landing block, the tree reduce's accumulator: replays would use it after it
+    // went back to the arena.  Captured, a push form runs as its pull form (the same operands, order and association: the same
+    // bits) and the tree reduce as the fold -- whatever named them, the caller or the tuner's table.  Every rank captures a
+    // collective or none does (as with push-only below), so every rank decides alike: by the arguments, not by what IT would lend.
+    if (sched_push) algo = sched_algo;
+    sched_push = false;
+    if (sched_algo == XMPI_ALGO_TREE && coll == COLL_REDUCE) algo = sched_algo = XMPI_ALGO_ZCOPY;
+  }
   const bool stepped = (sched_algo == XMPI_ALGO_RING && (coll == COLL_ALLREDUCE || coll == COLL_ALLGATHER)) ||
                        (sched_algo == XMPI_ALGO_RHD && coll == COLL_ALLREDUCE) ||
                        (sched_algo == XMPI_ALGO_TREE && (coll == COLL_BCAST || coll == COLL_REDUCE));

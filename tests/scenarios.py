@@ -1230,6 +1230,74 @@ def sc_sched(comm, args):
         both = x.copy()  # ... and in place (the stand-in is its own receive buffer: the push forms land in the communicator's block)
         comm.allreduce(both, both, 5000, xmpi.I64, xmpi.SUM, algo)
         assert both.tobytes() == want.tobytes(), f"host slice in place, algo {algo}"
+    # hipGraph: the table AUTO follows names a form that lends a block per call (a push form's landing block, the tree reduce's
+    # accumulator) -- which a graph cannot hold.  Captured, the call runs the pull form (same bits) / the fold; replays and the
+    # eager calls around them interleave (one epoch counter), and the eager call's bits are the replay's.
+    st = comm.stream_create()
+    n = 30011
+    a, b, e = comm.alloc(n * 4), comm.alloc(n * 4), comm.alloc(n * 4)
+    ins = [oracle.fill(n, xmpi.F32, xmpi.PAT_SIGNED, 900 + r) for r in range(size)]
+
+    def table(coll, algo):
+        for k in range(24):
+            comm.set_param(f"tune_algo_{coll}_{k}", algo)
+        comm.set_param("tuned", 1)
+
+    for algo, inplace in ((xmpi.ALGO_RING_PUSH, False), (xmpi.ALGO_RING_PUSH, True), (xmpi.ALGO_RHD_PUSH, False), (xmpi.ALGO_RHD_PUSH, True)):
+        table(0, algo)
+        l1 = comm.get_param("dsync_sched_launches")
+        comm.fill(a, n, xmpi.F32, xmpi.PAT_SIGNED, 900 + rank)
+        comm.allreduce(a, e, n, xmpi.F32, xmpi.SUM, xmpi.ALGO_AUTO)  # eager: the push form (and everything mapped before the capture)
+        comm.allreduce_on_stream(a, b, n, xmpi.F32, xmpi.SUM, st)
+        comm.stream_sync(st)
+        assert comm.get_param("dsync_sched_launches") == l1 + 2, "AUTO did not follow the table"
+        comm.memset(b, 0, n * 4)
+        src = b if inplace else a
+        if inplace:
+            comm.memcpy(b, a, n * 4)
+        comm.graph_begin(st)
+        comm.allreduce_on_stream(src, b, n, xmpi.F32, xmpi.SUM, st)
+        graph = comm.graph_end(st)
+        assert comm.get_param("dsync_land_bytes") == 0, "a captured collective borrowed a block"
+        comm.graph_launch(graph, st)
+        comm.stream_sync(st)
+        assert b.download(np.float32, n).tobytes() == e.download(np.float32, n).tobytes(), f"captured algo={algo} inplace={inplace}: not the eager call's bits"
+        if not inplace:  # replay, an eager push-form call behind it, replay again
+            comm.memset(b, 0, n * 4)
+            comm.graph_launch(graph, st)
+            comm.allreduce_on_stream(a, e, n, xmpi.F32, xmpi.SUM, st)
+            comm.graph_launch(graph, st)
+            comm.stream_sync(st)
+            assert b.download(np.float32, n).tobytes() == e.download(np.float32, n).tobytes(), f"replays of algo={algo} around an eager call"
+            check_reduced(b.download(np.float32, n), ins, xmpi.F32, xmpi.SUM, size <= 2, f"captured allreduce algo={algo}")
+        comm.graph_destroy(graph)
+    m = n // 2
+    for algo in (xmpi.ALGO_TREE, xmpi.ALGO_TREE_PUSH):
+        table(3, algo)
+        table(2, algo)
+        root = size - 1
+        comm.fill(a, m, xmpi.I64, xmpi.PAT_UNIFORM, 300 + rank)
+        comm.memset(b, 0, m * 8)
+        comm.reduce(a, e if rank == root else None, m, xmpi.I64, xmpi.SUM, root, xmpi.ALGO_AUTO)  # eager: the tree
+        comm.graph_begin(st)
+        comm.reduce_on_stream(a, b if rank == root else None, m, xmpi.I64, xmpi.SUM, root, st)  # captured: the fold (int64: the same bits)
+        comm.bcast_on_stream(b, m, xmpi.I64, root, st)  # the tree bcast lends nothing: captured as it is
+        graph = comm.graph_end(st)
+        for _ in range(2):
+            comm.graph_launch(graph, st)
+        comm.stream_sync(st)
+        want64 = oracle.reduce_ranks([oracle.fill(m, xmpi.I64, xmpi.PAT_UNIFORM, 300 + r) for r in range(size)], xmpi.I64, 0)
+        assert b.download(np.int64, m).tobytes() == want64.tobytes(), f"captured reduce + bcast under a table that says algo={algo}"
+        if rank == root:
+            assert e.download(np.int64, m).tobytes() == want64.tobytes()
+        comm.graph_destroy(graph)
+    comm.set_param("tuned", 0)
+    for coll in (0, 2, 3):
+        for k in range(24):
+            comm.set_param(f"tune_algo_{coll}_{k}", -1)
+    comm.stream_destroy(st)
+    for x in (a, b, e):
+        x.free()
 
 
 def bcast_case(comm, dtype, count, root, algo, seed=40, what="bcast"):
