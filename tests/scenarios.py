@@ -1230,6 +1230,18 @@ def sc_sched(comm, args):
         both = x.copy()  # ... and in place (the stand-in is its own receive buffer: the push forms land in the communicator's block)
         comm.allreduce(both, both, 5000, xmpi.I64, xmpi.SUM, algo)
         assert both.tobytes() == want.tobytes(), f"host slice in place, algo {algo}"
+    # some ranks in place, the others not (a rank's landing block is its own business: it announces one, or none)
+    n = 40009
+    a, b = comm.alloc(n * 4), comm.alloc(n * 4)
+    ins = [oracle.fill(n, xmpi.F32, xmpi.PAT_SIGNED, 950 + r) for r in range(size)]
+    for algo in (xmpi.ALGO_RING, xmpi.ALGO_RING_PUSH, xmpi.ALGO_RHD, xmpi.ALGO_RHD_PUSH, xmpi.ALGO_ZPUSH, xmpi.ALGO_ZCOPY):
+        comm.fill(a, n, xmpi.F32, xmpi.PAT_SIGNED, 950 + rank)
+        out = a if rank % 2 else b
+        comm.allreduce(a, out, n, xmpi.F32, xmpi.SUM, algo)
+        check_reduced(out.download(np.float32, n), ins, xmpi.F32, xmpi.SUM, size <= 2 or algo in (xmpi.ALGO_ZPUSH, xmpi.ALGO_ZCOPY),
+                      f"allreduce algo={algo}, odd ranks in place")
+    a.free()
+    b.free()
     # hipGraph: the table AUTO follows names a form that lends a block per call (a push form's landing block, the tree reduce's
     # accumulator) -- which a graph cannot hold.  Captured, the call runs the pull form (same bits) / the fold; replays and the
     # eager calls around them interleave (one epoch counter), and the eager call's bits are the replay's.
