@@ -1230,6 +1230,14 @@ def sc_sched(comm, args):
         both = x.copy()  # ... and in place (the stand-in is its own receive buffer: the push forms land in the communicator's block)
         comm.allreduce(both, both, 5000, xmpi.I64, xmpi.SUM, algo)
         assert both.tobytes() == want.tobytes(), f"host slice in place, algo {algo}"
+    for algo in (xmpi.ALGO_TREE, xmpi.ALGO_TREE_PUSH):  # ... and the tree kernels, both directions
+        for root in sorted({0, size - 1}):
+            out = np.zeros_like(x)
+            comm.reduce(x, out if rank == root else None, 5000, xmpi.I64, xmpi.SUM, root, algo)
+            assert rank != root or out.tobytes() == want.tobytes(), f"host slices, tree reduce algo {algo} root {root}"
+            y = x.copy()
+            comm.bcast(y, 5000, xmpi.I64, root, algo)
+            assert y.tobytes() == oracle.fill(5000, xmpi.I64, xmpi.PAT_UNIFORM, 5 + root).tobytes(), f"host slices, tree bcast algo {algo} root {root}"
     # some ranks in place, the others not (a rank's landing block is its own business: it announces one, or none)
     n = 40009
     a, b = comm.alloc(n * 4), comm.alloc(n * 4)
