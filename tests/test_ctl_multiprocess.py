@@ -147,7 +147,7 @@ print("ok")
 def test_step_tables_over_gloo(size):
     """torch.distributed, backend gloo, world_size 2 on the CPU: each process runs ITS rank's step table
     (the one libxmpi's executor runs) with gloo send/recv as the pipes, and checks the oracle."""
-    port = 20000 + (os.getpid() % 20000)
+    port = 20000 + (os.getpid() % 10000)  # (below the ephemeral range: no outgoing connection of another test sits there)
     procs = []
     for r in range(size):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(size), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

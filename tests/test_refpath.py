@@ -13,17 +13,43 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "oracle", "refpath_bin")
 
 
+def free_ports(n):
+    """n TCP ports nobody listens on right now (asked of the kernel, below the ephemeral range's churn where possible)"""
+    import socket
+    ports = []
+    for _ in range(200):
+        p = random.randint(10000, 30000)
+        if p in ports:
+            continue
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            try:
+                s.bind(("", p))
+            except OSError:
+                continue
+        ports.append(p)
+        if len(ports) == n:
+            return ports
+    raise RuntimeError("no free TCP ports")
+
+
 def launch(mode, n, extra=(), timeout=120):
-    base = random.randint(20000, 50000)
-    ports = [f":{base + i}" for i in range(n)]
-    procs = [subprocess.Popen([BIN, mode, *extra, "-mpi-addr", p, "-mpi-alladdr", ",".join(ports)],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for p in ports]
-    outs = []
-    for p in procs:
-        out, _ = p.communicate(timeout=timeout)
-        outs.append(out)
-        assert p.returncode == 0, out
-    return outs
+    for attempt in range(3):  # (a port can still be taken between the check and the rank's listen: another set, not a failure)
+        ports = [f":{p}" for p in free_ports(n)]
+        procs = [subprocess.Popen([BIN, mode, *extra, "-mpi-addr", p, "-mpi-alladdr", ",".join(ports)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for p in ports]
+        outs = []
+        for p in procs:
+            try:
+                out, _ = p.communicate(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                out, _ = p.communicate()
+            outs.append(out)
+        if attempt < 2 and any("listen failed" in o for o in outs):
+            continue
+        for p, out in zip(procs, outs):
+            assert p.returncode == 0, out
+        return outs
 
 
 @pytest.mark.parametrize("n", [1, 2, 4])
