@@ -598,24 +598,60 @@ def rank_main(job: Job, grank: int):
     _ = lead
 
 
+def free_ports(n: int):
+    """n TCP ports nobody listens on right now, below the ephemeral range (where other processes' outgoing connections come and go)"""
+    import random
+    import socket
+    ports = []
+    for _ in range(400):
+        p = random.randint(10000, 30000)
+        if p in ports:
+            continue
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            try:
+                sk.bind(("", p))
+            except OSError:
+                continue
+        ports.append(p)
+        if len(ports) == n:
+            break
+    return [f":{p}" for p in ports]
+
+
+def refpath_ranks(mode: str, ranks: int, args, timeout: int):
+    """`ranks` processes of oracle/refpath_bin on localhost; (outputs, None) or (None, what went wrong).  A port lost between the
+    check and a rank's listen is another set of ports, not a failure."""
+    binp = os.path.join(ROOT, "oracle", "refpath_bin")
+    outs = []
+    for attempt in range(3):
+        ports = free_ports(ranks)
+        procs = [subprocess.Popen([binp, mode, "-mpi-addr", p, "-mpi-alladdr", ",".join(ports), *args],
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for p in ports]
+        outs = []
+        for p in procs:
+            try:
+                outs.append(p.communicate(timeout=timeout)[0])
+            except subprocess.TimeoutExpired:
+                p.kill()
+                outs.append(p.communicate()[0] + " (timed out)")
+        if all(p.returncode == 0 for p in procs):
+            return outs, None
+        if not any("listen failed" in o for o in outs):
+            break
+    return None, next((o for o, p in zip(outs, procs) if p.returncode != 0), "")[-300:]
+
+
 def cpu_baseline(ranks: int, count: int, reps: int = 2):
     """oracle/refpath_bin: the reference's TCP+gob path, `ranks` processes on localhost"""
-    binp = os.path.join(ROOT, "oracle", "refpath_bin")
-    if not os.path.exists(binp):
+    if not os.path.exists(os.path.join(ROOT, "oracle", "refpath_bin")):
         return None
     import resource
-    base = 21000 + (os.getpid() % 20000)
-    ports = [f":{base + i}" for i in range(ranks)]
     ru0 = resource.getrusage(resource.RUSAGE_CHILDREN)
     t0 = time.perf_counter()
-    procs = [subprocess.Popen([binp, "allreduce_f32", "-mpi-addr", p, "-mpi-alladdr", ",".join(ports), str(count), str(reps)],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for p in ports]
-    rows = []
-    for p in procs:
-        out, _ = p.communicate(timeout=900)
-        if p.returncode != 0:
-            return {"error": out[-300:]}
-        rows.append(json.loads(out.strip().split("\n")[-1]))
+    outs, err = refpath_ranks("allreduce_f32", ranks, [str(count), str(reps)], 900)
+    if outs is None:
+        return {"error": err}
+    rows = [json.loads(out.strip().split("\n")[-1]) for out in outs]
     wall = time.perf_counter() - t0
     ru1 = resource.getrusage(resource.RUSAGE_CHILDREN)
     cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
@@ -657,16 +693,11 @@ def multiprocess_sweep(ranks: int):
 
 def cpu_bounce():
     """oracle/refpath_bin bounce: the reference's ping-pong (bounce.go:83-151) over loopback TCP + gob, 2 processes"""
-    binp = os.path.join(ROOT, "oracle", "refpath_bin")
-    if not os.path.exists(binp):
+    if not os.path.exists(os.path.join(ROOT, "oracle", "refpath_bin")):
         return None
-    base = 23000 + (os.getpid() % 20000)
-    ports = [f":{base}", f":{base + 1}"]
-    procs = [subprocess.Popen([binp, "bounce", "-mpi-addr", p, "-mpi-alladdr", ",".join(ports), "10000000", "10"],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for p in ports]
-    outs = [p.communicate(timeout=300)[0] for p in procs]
-    if any(p.returncode != 0 for p in procs):
-        return {"error": outs[0][-300:]}
+    outs, err = refpath_ranks("bounce", 2, ["10000000", "10"], 300)
+    if outs is None:
+        return {"error": err}
     row = json.loads(outs[0].strip().split("\n")[-1])
     lens = (0, 1, 10, 100, 1000, 10**4, 10**5, 10**6, 10**7)
     return [{"bytes": n, "round_trip_us": us, "GBps": 2 * n / (us * 1e-6) / 1e9 if us > 0 else 0.0}
