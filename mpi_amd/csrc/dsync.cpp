@@ -1101,22 +1101,25 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
       // that share no link direction); ranks sharing a GPU have no links to spread over
       const int avail = std::min(ring_channel_count(N), kMaxSchedChannels);
       nchan = c->sched_channels > 0 ? (int)std::min<long>(c->sched_channels, avail) : (c->dsync_sharers > 1 ? 1 : avail);
-      traffic = coll == COLL_ALLREDUCE ? 5 * (size_t)(N - 1) * step_bytes : 2 * (size_t)N * send_bytes;
+      // (reduce-scatter 2 reads + 1 write per step, allgather 1 + 1; the push form reads its own first chunk once more)
+      traffic = coll == COLL_ALLREDUCE ? (5 * (size_t)(N - 1) + (sched_push ? 1 : 0)) * step_bytes : 2 * (size_t)N * send_bytes;
     } else if (sched_algo == XMPI_ALGO_RHD) {
       sa.sched = SCHED_RHD_ALLREDUCE;
       step_bytes = send_bytes / 2;
-      traffic = 5 * (send_bytes - send_bytes / (size_t)N);  // halving: 3 x (S/2 + S/4 + ...), doubling: 2 x the same
+      // halving: 3 x (S/2 + S/4 + ...), doubling: 2 x the same; push form: the landing regions are written and read -- one more
+      traffic = (sched_push ? 6 : 5) * (send_bytes - send_bytes / (size_t)N);
       if ((N & (N - 1)) != 0) traffic += 3 * send_bytes;     // (no power of two: the fold-in / fold-out steps, at most)
     } else {
       sa.sched = coll == COLL_BCAST ? SCHED_TREE_BCAST : SCHED_TREE_REDUCE;
       const size_t piece = (size_t)std::max<long>(4096, c->tree_piece_bytes);
       sa.pieces = (int)std::min<size_t>(32, std::max<size_t>(1, (send_bytes + piece - 1) / piece));
       step_bytes = (send_bytes + (size_t)sa.pieces - 1) / (size_t)sa.pieces;
-      if (coll == COLL_BCAST) {
-        traffic = me == root ? 0 : 2 * send_bytes;
-      } else {  // 2 reads + 1 write per child
-        const int v = (me - root + N) % N;
-        traffic = 3 * send_bytes * (size_t)((2 * v + 1 < N) + (2 * v + 2 < N));
+      const int v = (me - root + N) % N;
+      const size_t children = (size_t)((2 * v + 1 < N) + (2 * v + 2 < N));
+      if (coll == COLL_BCAST) {  // pull: a node reads its parent's piece and writes its own; push: it reads its own and writes each child's
+        traffic = sched_push ? 2 * send_bytes * children : (me == root ? 0 : 2 * send_bytes);
+      } else {  // pull: 2 reads + 1 write per child; push: own input + one slot per child read, one buffer stored (upwards, or the result)
+        traffic = sched_push ? (children + 2) * send_bytes : 3 * send_bytes * children;
       }
     }
     // push form: the block the peers store into where this rank's receive buffer cannot take their data yet (sched_steps.h
