@@ -1814,9 +1814,16 @@ def sc_soak(comm, args):
         pending.clear()
 
     done = {}
+    # what AUTO resolves to: rank order untuned; a "table" step writes rows into the library's schedule table (what xmpi_tune would,
+    # had it measured them fastest) -- then AUTO is whatever the row says, also for the stream-ordered, non-blocking and CAPTURED calls
+    auto_in_order = {0: True, 3: True}  # (allreduce, reduce: is AUTO's fold in rank order?)
+
+    def order_free(dtype, pat, op):
+        return op in (A.MIN, A.MAX) or dtype in (A.I64, A.I32, A.U8) or (dtype in (A.F16, A.BF16) and pat == A.PAT_UNIFORM and op == A.SUM)
+
     for k in range(steps):
         kind = rng.choice(["allreduce"] * 5 + ["allgather", "bcast", "reduce", "p2p", "stream_allreduce", "stream_allreduce", "params",
-                           "stream_p2p", "nonblocking", "host_slices", "graph"])
+                           "stream_p2p", "nonblocking", "host_slices", "graph", "table"])
         done[kind] = done.get(kind, 0) + 1
         dtype = rng.choice(dtypes)
         count = pick_count()
@@ -1829,6 +1836,24 @@ def sc_soak(comm, args):
             comm.set_param("agent_ll_bytes", rng.choice([1024, 4096, 32768]))
             comm.set_param("dsync_unroll", rng.choice([1, 2]))
             continue
+        if kind == "table":
+            if not dev:
+                continue
+            drain()
+            how = rng.choice(["none", "rank order", "anything", "anything"])
+            menu = {0: [-1, A.ALGO_ZCOPY, A.ALGO_ZPUSH, A.ALGO_LL] + ([A.ALGO_RING, A.ALGO_RING_PUSH, A.ALGO_RHD, A.ALGO_RHD_PUSH] if how == "anything" else []),
+                    1: [-1, A.ALGO_ZCOPY, A.ALGO_LL, A.ALGO_RING, A.ALGO_RING_PUSH],
+                    2: [-1, A.ALGO_ZCOPY, A.ALGO_LL, A.ALGO_TREE, A.ALGO_TREE_PUSH],
+                    3: [-1, A.ALGO_ZCOPY, A.ALGO_ZPUSH, A.ALGO_LL] + ([A.ALGO_TREE, A.ALGO_TREE_PUSH] if how == "anything" else [])}
+            for coll in range(4):
+                for cls in range(0, 24, 2):
+                    row = rng.choice(menu[coll]) if how != "none" else -1
+                    for c2 in (cls, cls + 1):
+                        comm.set_param(f"tune_algo_{coll}_{c2}", row)
+                        comm.set_param(f"tune_split_{coll}_{c2}", rng.choice([-1, 0, 1]) if how != "none" else -1)
+            comm.set_param("tuned", 0 if how == "none" else 1)
+            auto_in_order[0] = auto_in_order[3] = how != "anything"
+            continue
         if kind == "allreduce":
             algos = [A.ALGO_AUTO, A.ALGO_ZCOPY, A.ALGO_ZPUSH, A.ALGO_RING, A.ALGO_LL, A.ALGO_RING_PUSH] + ([A.ALGO_RHD, A.ALGO_RHD_PUSH] if dev or size & (size - 1) == 0 else [])
             algo = rng.choice(algos)
@@ -1836,7 +1861,7 @@ def sc_soak(comm, args):
             pat = rng.choice([A.PAT_UNIFORM, A.PAT_SIGNED])
             inplace = rng.random() < 0.3
             mis = rng.choice([0, 0, 0, 1, 3])
-            rank_order = algo in (A.ALGO_AUTO, A.ALGO_ZCOPY, A.ALGO_ZPUSH, A.ALGO_LL) or size <= 2
+            rank_order = algo in (A.ALGO_ZCOPY, A.ALGO_ZPUSH, A.ALGO_LL) or (algo == A.ALGO_AUTO and auto_in_order[0]) or size <= 2
             if not rank_order and op == A.PROD and dtype in FLOATS:
                 op = A.SUM  # (products in another order: the stated tolerance is for sums)
             exact = rank_order or op in (A.MIN, A.MAX) or dtype in (A.I64, A.I32, A.U8) or (dtype in (A.F16, A.BF16) and pat == A.PAT_UNIFORM and op == A.SUM)
@@ -1849,7 +1874,8 @@ def sc_soak(comm, args):
         elif kind == "reduce":
             algo = rng.choice([A.ALGO_AUTO, A.ALGO_TREE, A.ALGO_TREE_PUSH, A.ALGO_ZCOPY, A.ALGO_LL])
             pat = rng.choice([A.PAT_UNIFORM, A.PAT_SIGNED])
-            exact = algo not in (A.ALGO_TREE, A.ALGO_TREE_PUSH) or size <= 2 or dtype in (A.I64, A.I32, A.U8) or (dtype in (A.F16, A.BF16) and pat == A.PAT_UNIFORM)
+            in_order = algo not in (A.ALGO_TREE, A.ALGO_TREE_PUSH) and (algo != A.ALGO_AUTO or auto_in_order[3])
+            exact = in_order or size <= 2 or order_free(dtype, pat, A.SUM)
             reduce_case(comm, dtype, min(count, 500000), rng.randrange(size), algo, pat=pat, exact=exact)
         elif kind == "p2p" and size > 1:
             # a ring of blocking messages: even ranks send first, odd ranks receive first (rendezvous sends: no cycle may form)
@@ -1878,7 +1904,8 @@ def sc_soak(comm, args):
             comm.fill(send, n, dtype, A.PAT_UNIFORM, 5000 + k * 16 + rank)
             comm.allreduce_on_stream(send, recv, n, dtype, A.SUM, st)
             ins = [oracle.fill(n, dtype, A.PAT_UNIFORM, 5000 + k * 16 + r) for r in range(size)]
-            pending.append((f"soak step {k}: stream-ordered allreduce {A.DTYPE_NAME[dtype]} n={n}", recv, n, dtype, ins, A.SUM, True))
+            pending.append((f"soak step {k}: stream-ordered allreduce {A.DTYPE_NAME[dtype]} n={n}", recv, n, dtype, ins, A.SUM,
+                            auto_in_order[0] or size <= 2 or order_free(dtype, A.PAT_UNIFORM, A.SUM)))
             if len(pending) >= 6 or rng.random() < 0.25:
                 drain()
             # (send is read by peers until the collective is over: freed by the drain's successor -- kept alive in the tuple's closure)
@@ -1920,7 +1947,8 @@ def sc_soak(comm, args):
             comm.request_wait(q2)
             comm.request_wait(q1)
             ins = [oracle.fill(n, dtype, A.PAT_UNIFORM, 13000 + k * 16 + r) for r in range(size)]
-            check_reduced(r1.download(A.NUMPY_DTYPE[dtype], n), ins, dtype, A.SUM, True, f"soak step {k}: iallreduce")
+            check_reduced(r1.download(A.NUMPY_DTYPE[dtype], n), ins, dtype, A.SUM, auto_in_order[0] or size <= 2 or order_free(dtype, A.PAT_UNIFORM, A.SUM),
+                          f"soak step {k}: iallreduce")
             want = oracle.allgather([oracle.fill(n, A.I64, A.PAT_INDEX, r) for r in range(size)], A.I64)
             assert g2.download(np.int64, n * size).tobytes() == want.tobytes(), f"soak step {k}: iallgather"
             for b in (s1, r1, g1, g2):
@@ -1932,7 +1960,7 @@ def sc_soak(comm, args):
             y = np.zeros_like(x)
             comm.allreduce(x, y, n, dtype, A.SUM, A.ALGO_AUTO)
             ins = [oracle.fill(n, dtype, A.PAT_UNIFORM, 15000 + k * 16 + r) for r in range(size)]
-            check_reduced(y, ins, dtype, A.SUM, True, f"soak step {k}: allreduce of host slices")
+            check_reduced(y, ins, dtype, A.SUM, auto_in_order[0] or size <= 2 or order_free(dtype, A.PAT_UNIFORM, A.SUM), f"soak step {k}: allreduce of host slices")
             if size > 1:
                 nxt, prv = (rank + 1) % size, (rank + size - 1) % size
                 z = np.zeros_like(x)
@@ -1978,6 +2006,7 @@ def sc_soak(comm, args):
         comm.stream_destroy(st)
     if dev:
         assert comm.get_param("xcd_short") == 0
+        comm.set_param("tuned", 0)
         comm.set_param("dsync_split_bytes", 4 << 20)
         comm.set_param("body_sys", 0)
     if rank == 0:
