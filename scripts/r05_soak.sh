@@ -6,7 +6,7 @@ mkdir -p gpurun_out/r05_soak
 python - <<'PY' > gpurun_out/r05_soak/soak_long.log 2>&1
 import time
 from tests.gpu_harness import run_ranks, run_threads
-for size, seed, steps in ((2, 21, 2500), (3, 22, 2000), (4, 23, 2000), (5, 24, 1500), (6, 25, 1500), (7, 26, 1200), (8, 27, 1200), (8, 28, 1200)):
+for size, seed, steps in ((2, 31, 2500), (3, 32, 2000), (4, 33, 2000), (5, 34, 1500), (6, 35, 1500), (7, 36, 1200), (8, 37, 1200), (8, 38, 1200)):
     t0 = time.time()
     try:
         outs = run_ranks("soak", size, {"seed": seed, "steps": steps}, timeout=600)
