@@ -2507,6 +2507,14 @@ def sc_degraded(comm, args):
         rt.hipFree(raw)
         a.free()
         b.free()
+    # the tuner in a degraded job: nothing to choose where ranks meet on the host; without windows every candidate is a
+    # device-synchronised form and AUTO follows the table as anywhere
+    comm.tune(16384)
+    assert comm.get_param("tuned") == (0 if level & 2 else 1)
+    for count in (1, 300, 5001):
+        allreduce_case(comm, xmpi.I64, count, xmpi.ALGO_AUTO, exact=True)
+        reduce_case(comm, xmpi.I64, count, size - 1, xmpi.ALGO_AUTO, pat=xmpi.PAT_UNIFORM)
+        bcast_case(comm, xmpi.I64, count, 0, xmpi.ALGO_AUTO)
     comm.barrier()  # (every rank: one without a partner -- the last of an odd job -- must not run ahead into finalize)
 
 
