@@ -1552,6 +1552,7 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
   if (n == "dsync_launches") return (long)c->dsync_launches;
   if (n == "dsync_bounced") return (long)c->dsync_bounced;
   if (n == "dsync_sharers") return c->dsync_sharers;
+  if (n == "dsync_sharers_job") return c->dsync_sharers_job;
   if (n == "dsync_unroll") return c->dsync_unroll;
   if (n == "dsync_tiles") return c->dsync_tiles;
   if (n == "p2p_grid_cap") return c->p2p_grid_cap;

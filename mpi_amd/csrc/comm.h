@@ -173,6 +173,7 @@ struct xmpi_comm {
   long body_sys = 0;             // split form: data kernel with system-scope loads / stores (no L2 assumption); XMPI_BODY_SYS
   uint64_t xcd_short = 0;        // split collectives whose meet or done kernel missed an XCD (reported whether checked or not)
   int dsync_sharers = 1;         // ranks of this job on this rank's GPU (bounds the grid: their kernels spin together)
+  int dsync_sharers_job = 1;     // ... on the job's most crowded GPU (the same figure on every rank: what shapes a protocol)
   long dsync_grid_cap = 0;       // blocks per kernel; 0 = 1024 / sharers
   long dsync_unroll = 1;         // 16-byte packets per lane per source in flight (2 = deeper, for links)
   long dsync_tiles = 1;          // tiles (256 lanes x unroll packets) a block walks before the grid grows

@@ -102,11 +102,15 @@ int dsync_connect(xmpi_comm* c, double timeout_s) {
   const int N = c->size, mypid = (int)getpid();
   RankInfo* me = c->ctl->info(c->rank);
   bool usable = true;
-  int sharers = 0;
+  int sharers = 0, sharers_job = 1;
   for (int p = 0; p < N; p++) {
     const RankInfo* a = c->ctl->info(p);
     if (a->flag_addr == 0) usable = false;
     if (strncmp(a->busid, c->ctl->info(c->rank)->busid, sizeof a->busid) == 0) sharers++;
+    int on_its_gpu = 0;  // the most crowded GPU of the job: what every rank must read alike (the stepped kernels' shape)
+    for (int q = 0; q < N; q++)
+      if (strncmp(a->busid, c->ctl->info(q)->busid, sizeof a->busid) == 0) on_its_gpu++;
+    sharers_job = std::max(sharers_job, on_its_gpu);
     for (int q = p + 1; q < N; q++) {
       const RankInfo* b = c->ctl->info(q);
       if (a->pid == b->pid && a->device == b->device) usable = false;  // two ranks on one stream: see the header
@@ -178,6 +182,7 @@ int dsync_connect(xmpi_comm* c, double timeout_s) {
   // set for one rank): LL or fold is a protocol choice, a rank that folds while its peer sends lines waits for ever.  So every
   // rank publishes its choice with its vote and the job takes the smallest.
   c->dsync_sharers = std::max(1, sharers);
+  c->dsync_sharers_job = sharers_job;
   long mine = c->ll_bytes;
   if (mine < 0) mine = c->dsync_sharers > 2 ? ((c->agent_ll && c->ll_agent_us > 0) ? 4096 : 1024) : 8192;
   me->ll_choice = std::min<long>(mine, (long)kLLMaxPayload);
@@ -854,6 +859,13 @@ static void tuned_choice(const xmpi_comm* c, int coll, size_t bytes, int* algo, 
   }
 }
 
+// the call signature the kernels announce and compare (DsyncArgs::sig)
+static inline uint64_t sig_mix(uint64_t h, uint64_t v) {
+  h = (h ^ v) * 0x100000001B3ull;
+  return h ^ (h >> 29);
+}
+static inline uint64_t sig_fold(uint64_t h) { return std::max<uint64_t>(1, (h ^ (h >> 32)) & 0xffffffffull); }
+
 // a HIP failure inside a collective that has already borrowed blocks or advanced the epoch: the blocks go back and the peers --
 // whose kernels would wait for this rank -- are told through the job's abort flag (the function's `fail`)
 #define DS_HIP(call)                                                                 \
@@ -1080,6 +1092,20 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
 
   // (under capture the push-only form is the fold: its staging area is a block the communicator may replace later)
   const bool use_push = push && (coll == COLL_ALLREDUCE || coll == COLL_REDUCE) && !capturing;
+  // What this call is, for the peers to compare with theirs (kdev.h dsync_begin): ranks that are not in the same collective, on the
+  // same schedule, over the same bytes end with an error before any of them has touched another's memory -- instead of a hang, or
+  // of a fold over buffers of different lengths.  (One kernel or meet / body / done is NOT part of it: those mix.)
+  {
+    const bool reduces = coll == COLL_ALLREDUCE || coll == COLL_REDUCE, rooted = coll == COLL_BCAST || coll == COLL_REDUCE;
+    const uint64_t form = stepped ? 16u + 2u * (uint64_t)sched_algo + (sched_push ? 1u : 0u)
+                          : use_push ? 2u
+                          : (coll == COLL_BCAST && !(N <= 2 || send_bytes <= (size_t)std::max<long>(0, c->zc_bcast_push_bytes))) ? 3u : 1u;
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    for (uint64_t v : {(uint64_t)coll + 1, form, (uint64_t)send_bytes, reduces ? (uint64_t)dtype + 1 : 0, reduces ? (uint64_t)op + 1 : 0,
+                       rooted ? (uint64_t)root + 1 : 0})
+      h = sig_mix(h, v);
+    a.sig = sig_fold(h);
+  }
   if (stepped) {
     // ring / recursive halving + doubling / binary tree: ONE kernel per rank runs every step of the schedule, the steps
     // released by flag words between the peers' kernels (sched.hip) -- the schedules north_star names, without a host
@@ -1100,7 +1126,9 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
       // every channel is a different cyclic order of the ranks (plan.cpp ring_order: on an even mesh N-2 directed rings
       // that share no link direction); ranks sharing a GPU have no links to spread over
       const int avail = std::min(ring_channel_count(N), kMaxSchedChannels);
-      nchan = c->sched_channels > 0 ? (int)std::min<long>(c->sched_channels, avail) : (c->dsync_sharers > 1 ? 1 : avail);
+      // (the shape of a stepped kernel -- channels, workers -- is protocol: worker w waits for worker w of its peer.  It follows
+      // the job's most crowded GPU, which every rank reads alike, not this rank's own: 5 ranks on 2 GPUs sit 3 + 2)
+      nchan = c->sched_channels > 0 ? (int)std::min<long>(c->sched_channels, avail) : (c->dsync_sharers_job > 1 ? 1 : avail);
       // (reduce-scatter 2 reads + 1 write per step, allgather 1 + 1; the push form reads its own first chunk once more)
       traffic = coll == COLL_ALLREDUCE ? (5 * (size_t)(N - 1) + (sched_push ? 1 : 0)) * step_bytes : 2 * (size_t)N * send_bytes;
     } else if (sched_algo == XMPI_ALGO_RHD) {
@@ -1146,11 +1174,14 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
       sa.d.my_land = land;
     }
     const size_t tiles = std::max<size_t>(1, (step_bytes + kSchedTileBytes - 1) / kSchedTileBytes);
-    long workers = c->sched_grid > 0 ? c->sched_grid : (long)std::min<size_t>(tiles, (size_t)dsync_block_cap(c));
+    const long job_cap = c->dsync_grid_cap > 0 ? c->dsync_grid_cap : 1024 / std::max(1, c->dsync_sharers_job);
+    long workers = c->sched_grid > 0 ? c->sched_grid : (long)std::min<size_t>(tiles, (size_t)job_cap);
     workers = std::max<long>(1, std::min<long>(workers, kStepSlots));
     nchan = (int)std::max<long>(1, std::min<long>(nchan, workers));
     const int gx = (int)std::max<long>(1, workers / nchan);
     sa.nchan = nchan;
+    // (worker w of a rank waits for worker w of its peer, over the same channels and pieces: the shape is part of the call)
+    sa.d.sig = sig_fold(sig_mix(sig_mix(sig_mix(a.sig, (uint64_t)nchan), (uint64_t)gx), (uint64_t)sa.pieces));
     for (int ch = 0; ch < nchan; ch++) {
       std::vector<int> ord;
       ring_order(N, ch, &ord);
@@ -1523,6 +1554,10 @@ int dsync_check(xmpi_comm* c) {
   } else if (st == DSYNC_UNMAPPED) {
     set_last_error("collective: a peer's buffer is not mapped here (registration freed while in use?)");
     rc = XMPI_ERR_STATE;
+  } else if (st == DSYNC_MISMATCH) {
+    set_last_error("collective: the ranks are not in the same call (collective, schedule, length, dtype, operation or root differ "
+                   "between this rank and a peer); nothing was moved");
+    rc = XMPI_ERR_ARG;
   } else if (st == DSYNC_XCD) {
     c->xcd_short++;
     set_last_error("collective: the meet / done kernels of the split form did not reach every XCD's L2 (masks in xcd_meet_mask / "

@@ -219,7 +219,7 @@ __device__ void dsync_begin(const DsyncArgs& a, DsyncShared& sh) {
       st_sys64(&out->send_off, a.send_off);
       st_sys64(&out->recv_gen, a.recv_gen);
       st_sys64(&out->recv_off, a.recv_off);
-      st_sys64(&out->slots, a.send_slot | (a.recv_slot << 8) | (a.land_slot << 16) | (a.land_gen ? 1ull << 24 : 0));
+      st_sys64(&out->slots, a.send_slot | (a.recv_slot << 8) | (a.land_slot << 16) | (a.land_gen ? 1ull << 24 : 0) | (a.sig << 32));
       if (a.land_gen) {  // (bit 24 of `slots` says whether these two mean anything)
         st_sys64(&out->land_gen, a.land_gen);
         st_sys64(&out->land_off, a.land_off);
@@ -238,6 +238,8 @@ __device__ void dsync_begin(const DsyncArgs& a, DsyncShared& sh) {
       sh.recv[t] = r;
       sh.land[t] = l;
       if (!s || !r || (lgen && !l)) why = DSYNC_UNMAPPED;
+      // the peer is in another call (another collective, schedule, length, type, operation or root): nobody moves anything
+      if ((uint32_t)a.sig && (uint32_t)(slots >> 32) && (uint32_t)(slots >> 32) != (uint32_t)a.sig) why = DSYNC_MISMATCH;
     }
     if (why != DSYNC_OK) atomicMax(&sh.fail, why);
   }

@@ -75,7 +75,7 @@ struct DsyncSlot {
   uint64_t epoch;  // written last, system-scope release: the fields below belong to this collective
   uint64_t send_gen, send_off, recv_gen, recv_off;  // the peer's buffers: registration number + byte offset
   uint64_t slots;               // ... and the table slots the peer published them under: send | recv << 8 | landing << 16; bit 24:
-                                // it lends a landing block
+                                // it lends a landing block; bits 32 ... 63: what call the peer is in (DsyncArgs::sig)
   uint64_t land_gen, land_off;  // the peer's LANDING block (push forms of the stepped kernels: what the peers store into before
                                 // the owner has combined it); written -- and meaningful -- only with bit 24 of `slots`
 };
@@ -181,7 +181,8 @@ struct DsyncSeg {
 
 // DSYNC_XCD: the split form's meet or done kernel did not have a block on every XCD (DsyncArgs::xcc_need) -- the acquire / release
 // once per L2 it relies on did not happen everywhere, the result cannot be trusted
-enum DsyncStatus : uint32_t { DSYNC_OK = 0, DSYNC_TIMEOUT = 1, DSYNC_ABORTED = 2, DSYNC_UNMAPPED = 3, DSYNC_XCD = 4 };
+// DSYNC_MISMATCH: a peer announced another call than this rank's (DsyncArgs::sig: collective, schedule, bytes, dtype, operation, root).
+enum DsyncStatus : uint32_t { DSYNC_OK = 0, DSYNC_TIMEOUT = 1, DSYNC_ABORTED = 2, DSYNC_UNMAPPED = 3, DSYNC_XCD = 4, DSYNC_MISMATCH = 5 };
 
 struct DsyncArgs {
   DsyncPage* page[kDsyncRanks];  // [me]: own page, others: the peers' pages as mapped here
@@ -198,6 +199,9 @@ struct DsyncArgs {
   void* my_recv;
   void* my_land;
   uint64_t tag;               // of this communicator: cache entries written under another tag are somebody else's
+  uint64_t sig;               // low 32 bits: what this call is (collective, schedule, bytes, dtype, operation, root), announced in the
+                              // upper half of DsyncSlot::slots -- a peer that announces another one ends both kernels with
+                              // DSYNC_MISMATCH before either touches the other's memory; 0 = not checked
   const DsyncEntry* table;    // [kDsyncRanks][kDsyncArenas] in pinned host memory, written by the host (dsync_service)
   const int32_t* abort_word;  // host memory the GPU can read (the job's abort flag), may be null
   uint32_t* status;           // host memory the GPU can write: first failure (DsyncStatus), may be null

@@ -2556,7 +2556,56 @@ def sc_peer_dies(comm, args):
     raise AssertionError(f"{what} with a dead peer returned without an error")
 
 
+def sc_mismatch(comm, args):
+    """The ranks are NOT in the same call -- another length, another schedule, another operation, another root, another collective:
+    the reference's peers would block for ever (a Receive nobody sends to, network.go:575-625) or decode garbage; here every kernel
+    announces what call it is in with its buffers, and ranks that differ end with an ERROR -- all of them, at once, before anybody
+    has touched another's memory."""
+    import time
+    rank, size = comm.rank(), comm.size()
+    what = args["what"]
+    n = 40000
+    a, b = comm.alloc((n + 64) * 8), comm.alloc((n + 64) * 8 * (size if what == "collective" else 1))
+    comm.fill(a, n + 64, xmpi.I64, xmpi.PAT_INDEX, rank)
+    comm.memset(b, 0x5A, (n + 64) * 8)
+    allreduce_case(comm, xmpi.I64, 4099, xmpi.ALGO_ZCOPY, exact=True)  # (everything mapped)
+    comm.set_param("ll_bytes", 0)
+    odd = rank == size - 1
+    t0 = time.time()
+    try:
+        if what == "length":
+            comm.allreduce(a, b, n + (16 if odd else 0), xmpi.I64, xmpi.SUM, xmpi.ALGO_ZCOPY)
+        elif what == "schedule":
+            comm.allreduce(a, b, n, xmpi.I64, xmpi.SUM, xmpi.ALGO_RING if odd else xmpi.ALGO_ZCOPY)
+        elif what == "form":
+            comm.allreduce(a, b, n, xmpi.I64, xmpi.SUM, xmpi.ALGO_RING_PUSH if odd else xmpi.ALGO_RING)
+        elif what == "operation":
+            comm.allreduce(a, b, n, xmpi.I64, xmpi.MAX if odd else xmpi.SUM, xmpi.ALGO_RHD)
+        elif what == "root":
+            comm.reduce(a, b, n, xmpi.I64, xmpi.SUM, 0 if odd else 1, xmpi.ALGO_ZCOPY)
+        elif what == "shape":  # one rank was told another grid for the stepped kernels: worker w would wait for a worker that is not there
+            if odd:
+                comm.set_param("sched_grid", 3)
+            comm.allreduce(a, b, n, xmpi.I64, xmpi.SUM, xmpi.ALGO_RING)
+        else:  # "collective"
+            if odd:
+                comm.allgather(a, b, n, xmpi.I64, xmpi.ALGO_ZCOPY)
+            else:
+                comm.allreduce(a, b, n, xmpi.I64, xmpi.SUM, xmpi.ALGO_ZCOPY)
+    except xmpi.XmpiError as e:
+        took = time.time() - t0
+        assert e.code == xmpi.ERR_ARG and "not in the same call" in str(e), e
+        assert took < 5, f"{what}: the error took {took:.1f} s -- somebody waited for a clock"
+        got = b.download(np.uint8, (n + 64) * 8)
+        assert np.all(got == 0x5A), f"{what}: a peer wrote into this rank's buffer although the calls differed"
+        print(f"rank {rank}/{size} mismatch[{what}]: ok (error after {took * 1e3:.0f} ms)")
+        sys.stdout.flush()
+        os._exit(0)  # (the job is aborted: no finalize barrier)
+    raise AssertionError(f"{what}: ranks in different calls returned without an error")
+
+
 SCENARIOS = {
+    "mismatch": sc_mismatch,
     "linkprobe": sc_linkprobe,
     "degraded": sc_degraded,
     "peer_dies": sc_peer_dies,

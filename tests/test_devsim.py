@@ -223,6 +223,20 @@ def test_a_peer_that_dies_is_an_error_not_a_hang(devsim_lib, what):
     assert sum("ok (error after" in o for o in outs) == 2, "\n".join(outs)
 
 
+@pytest.mark.parametrize("what", ["length", "schedule", "form", "operation", "root", "shape", "collective"])
+def test_ranks_in_different_calls_get_an_error_not_a_hang(devsim_lib, what):
+    """every kernel announces the call it is in; ranks that differ all fail at once, and nobody's buffer was written"""
+    outs = run_ranks("mismatch", 3, {"what": what}, timeout=120, env={"XMPI_TIMEOUT_S": "20"})
+    assert sum("ok (error after" in o for o in outs) == 3, "\n".join(outs)
+
+
+def test_the_stepped_kernels_shape_follows_the_most_crowded_gpu(devsim_lib):
+    """5 ranks on 2 GPUs sit 3 + 2: what shapes a protocol (channels, workers of the stepped kernels) is read off the job's most
+    crowded GPU -- the same figure on every rank -- not off the rank's own; every form still right in that layout"""
+    run_ranks("sched", 5, {"shapes": [(0, 0)], "counts": [17, 4099], "quick": 1, "expect_params": {"dsync_sharers_job": 3}}, timeout=600,
+              env={"DEVSIM_DEVICES": "2", "XMPI_NGPUS": "2"})
+
+
 def test_ranks_that_share_a_device(devsim_lib):
     """the threads layout (one process, one device, pid-equal peers) through the same stand-in"""
     run_threads("allreduce_small", 4, {"counts": [1, 4099], "dtypes": [4, 2]})

@@ -286,3 +286,12 @@ def test_a_peer_that_dies_is_an_error_not_a_hang(what):
     (the reference's peers get a TCP error: network.go:518-571)"""
     outs = run_ranks("peer_dies", 2, {"what": what}, timeout=120, env={"XMPI_TIMEOUT_S": "5"})
     assert sum("ok (error after" in o for o in outs) == 1, "\n".join(outs)
+
+
+@pytest.mark.parametrize("what", ["length", "schedule", "form", "root", "shape", "collective"])
+def test_ranks_in_different_calls_get_an_error_not_a_hang(what):
+    """every kernel announces the call it is in (collective, schedule, bytes, dtype, operation, root, the stepped kernels' shape) in
+    the upper half of a word it stores anyway; ranks that differ all end with an error at once -- no hang, no fold over buffers of
+    different lengths -- and nobody's receive buffer was written (the reference: a Receive nobody sends to blocks for ever)"""
+    outs = run_ranks("mismatch", 3, {"what": what}, timeout=120, env={"XMPI_TIMEOUT_S": "20"})
+    assert sum("ok (error after" in o for o in outs) == 3, "\n".join(outs)
