@@ -19,7 +19,7 @@ constexpr int kMaxLanes = 4;
 constexpr int kMailEntries = 4;  // concurrent messages per ordered rank pair
 constexpr int kHostLaneSlots = 4;  // pieces of a host-resident payload in flight per mail entry (the host lanes, below)
 constexpr uint64_t kCtlMagic = 0x584D504943544C31ull;  // "XMPICTL1"
-constexpr uint32_t kCtlVersion = 8;  // layout of the block: bump with every change of the structs below
+constexpr uint32_t kCtlVersion = 9;  // layout of the block: bump with every change of the structs below
 
 struct alignas(64) Counter {
   std::atomic<uint64_t> v;
@@ -93,7 +93,10 @@ struct alignas(64) BufDesc {
   std::atomic<int32_t> verdict;  // after mapping the peers' buffers: 1 = all mapped, -1 = failed
   int32_t in_place;  // 1 = send and receive buffer are the same memory on this rank
   BufRef send, recv;
+  uint32_t sig;      // what call this is (collective, bytes, dtype, operation, root, push-only or not): ranks that publish different
+                     // ones are not in the same call -- an error on every rank, before anything is mapped or moved
 };
+static_assert(sizeof(BufDesc) == 256, "a descriptor is four cache lines");
 
 // Registered allocations a rank has freed since the job began (their `gen`s, in order).  A peer that
 // mapped one must unmap it before it maps anything new of that rank: the runtime may hand the same

@@ -314,6 +314,16 @@ static int zc_run(xmpi_comm* c, int coll, int root, const void* sendbuf, void* r
   mine->ok = ok ? 1 : 0;
   mine->fresh = fresh ? 1 : 0;
   mine->in_place = (sendbuf == recvbuf) ? 1 : 0;
+  {
+    const bool reduces = coll == COLL_ALLREDUCE || coll == COLL_REDUCE, rooted = coll == COLL_BCAST || coll == COLL_REDUCE;
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    for (uint64_t v : {(uint64_t)coll + 1, (uint64_t)(push ? 2 : 1), (uint64_t)send_bytes, reduces ? (uint64_t)dtype + 1 : 0,
+                       reduces ? (uint64_t)op + 1 : 0, rooted ? (uint64_t)root + 1 : 0, (uint64_t)iters}) {
+      h = (h ^ v) * 0x100000001B3ull;
+      h ^= h >> 29;
+    }
+    mine->sig = (uint32_t)(h ^ (h >> 32));
+  }
   mine->verdict.store(0, std::memory_order_relaxed);
   mine->seq.store(seq, std::memory_order_release);
   int rc = c->ctl->barrier(tmo(c));
@@ -332,6 +342,12 @@ static int zc_run(xmpi_comm* c, int coll, int root, const void* sendbuf, void* r
       set_last_error("zero-copy collective: ranks disagree on the collective sequence (mismatched calls?)");
       c->ctl->set_abort(XMPI_ERR_STATE);
       return XMPI_ERR_STATE;
+    }
+    if (d->sig != mine->sig) {  // (every rank reads the same descriptors: every rank returns this)
+      set_last_error("collective: the ranks are not in the same call (collective, length, dtype, operation or root differ between "
+                     "this rank and a peer); nothing was moved");
+      c->ctl->set_abort(XMPI_ERR_ARG);
+      return XMPI_ERR_ARG;
     }
     all_ok = all_ok && d->ok == 1;
     any_fresh = any_fresh || d->fresh == 1;

@@ -65,3 +65,4 @@ def run_threads(scenario: str, size: int, args: dict | None = None, timeout: flo
     cmd = [sys.executable, os.path.join(ROOT, "tests", "rank_worker.py"), "--threads", scenario, str(size), json.dumps(args or {})]
     p = subprocess.run(cmd, cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
     assert p.returncode == 0, f"scenario {scenario} with {size} rank threads failed\n{p.stdout[-6000:]}"
+    return p.stdout

@@ -33,7 +33,8 @@ def threads_main():
             comm = xmpi.Comm(r, size, args.get("device", -1), key)
             for k, v in args.get("params", {}).items():
                 comm.set_param(k, v)
-            scenarios.SCENARIOS[name](comm, args)
+            if scenarios.SCENARIOS[name](comm, args) == "aborted":
+                return  # (the scenario drove the job into an error on purpose: no barrier, no finalize to meet the others in)
             comm.barrier()
             comm.finalize()
         except BaseException:  # noqa: BLE001

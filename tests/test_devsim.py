@@ -230,6 +230,13 @@ def test_ranks_in_different_calls_get_an_error_not_a_hang(devsim_lib, what):
     assert sum("ok (error after" in o for o in outs) == 3, "\n".join(outs)
 
 
+@pytest.mark.parametrize("what", ["length", "operation", "root", "collective"])
+def test_rank_threads_in_different_calls_get_an_error_not_a_hang(devsim_lib, what):
+    """the same where ranks meet on the host: the descriptors they publish carry the call's signature"""
+    out = run_threads("mismatch", 3, {"what": what, "threads": 1}, timeout=120)
+    assert out.count("ok (error after") == 3, out
+
+
 def test_the_stepped_kernels_shape_follows_the_most_crowded_gpu(devsim_lib):
     """5 ranks on 2 GPUs sit 3 + 2: what shapes a protocol (channels, workers of the stepped kernels) is read off the job's most
     crowded GPU -- the same figure on every rank -- not off the rank's own; every form still right in that layout"""

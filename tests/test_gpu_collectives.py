@@ -295,3 +295,10 @@ def test_ranks_in_different_calls_get_an_error_not_a_hang(what):
     different lengths -- and nobody's receive buffer was written (the reference: a Receive nobody sends to blocks for ever)"""
     outs = run_ranks("mismatch", 3, {"what": what}, timeout=120, env={"XMPI_TIMEOUT_S": "20"})
     assert sum("ok (error after" in o for o in outs) == 3, "\n".join(outs)
+
+
+@pytest.mark.parametrize("what", ["length", "collective"])
+def test_rank_threads_in_different_calls_get_an_error_not_a_hang(what):
+    """... and where ranks meet on the host (threads of one process): the descriptors they publish carry the same signature"""
+    out = run_threads("mismatch", 3, {"what": what, "threads": 1}, timeout=120)
+    assert out.count("ok (error after") == 3, out
