@@ -211,7 +211,9 @@ int xmpi_probe(xmpi_comm* comm, int src, int tag, size_t* count, xmpi_dtype* dty
 
 /* ---- collectives (absent from the reference: mpi.go:130 is a commented-out stub, mpi.go:69-71
  *      an unused probe variable; defined here in the reference's delegate style) --------------
- * Called by every rank, in the same order, with the same count / dtype / op / root / algo.
+ * Called by every rank, in the same order, with the same count / dtype / op / root / algo.  Ranks that are not -- where they
+ * meet on the device (above the LL lines' limit) or through the control block -- all get XMPI_ERR_ARG ("not in the same call")
+ * at once and nothing is moved: every kernel announces a signature of its call with its buffers.
  * Blocking: the buffers must be complete when the call is made and may be reused when it returns.
  * ZCOPY and AUTO: the peers' buffers are read and written in place by ONE kernel per rank; floating-point
  * folds are in rank order 0..N-1.  With one process per GPU the ranks meet inside that kernel (flag words
