@@ -2447,6 +2447,46 @@ def sc_linkprobe(comm, args):
         print("LINKPROBE " + json.dumps({"ranks_share_gpu": comm.get_param("dsync_sharers") > 1, "bytes": args.get("bytes", 64 << 20), **out}), flush=True)
 
 
+def sc_rooted_bench(comm, args):
+    """bcast and reduce by every name, timed (scripts/r05_tree.sh): blocking calls back to back, the slowest rank's mean, one JSON
+    line; every result checked once (int64 / f32 uniform halves: exact in any order)"""
+    import json
+    import time
+    rank, size = comm.rank(), comm.size()
+    rows = []
+    for nbytes in args.get("sizes", [1 << 20, 256 << 20]):
+        n = nbytes // 4
+        a, b = comm.alloc(nbytes), comm.alloc(nbytes)
+        iters = args.get("iters", 20 if nbytes <= (16 << 20) else 8)
+        row = {"bytes": nbytes}
+        for coll, forms in (("bcast", (("fold", xmpi.ALGO_ZCOPY), ("tree", xmpi.ALGO_TREE), ("tree_push", xmpi.ALGO_TREE_PUSH))),
+                            ("reduce", (("fold", xmpi.ALGO_ZCOPY), ("push_only", xmpi.ALGO_ZPUSH), ("tree", xmpi.ALGO_TREE), ("tree_push", xmpi.ALGO_TREE_PUSH)))):
+            for name, algo in forms:
+                comm.fill(a, n, xmpi.I32, xmpi.PAT_UNIFORM, 60 + rank)
+                for it in range(-2, iters):
+                    if it == 0:
+                        comm.barrier()
+                        t0 = time.perf_counter()
+                    if coll == "bcast":
+                        comm.bcast(a, n, xmpi.I32, 0, algo)
+                    else:
+                        comm.reduce(a, b, n, xmpi.I32, xmpi.SUM, 0, algo)
+                us = np.array([(time.perf_counter() - t0) / iters * 1e6])
+                worst = np.zeros(1)
+                comm.allreduce(us, worst, 1, xmpi.F64, xmpi.MAX, xmpi.ALGO_AUTO)
+                if coll == "bcast":
+                    assert a.download(np.int32, n).tobytes() == oracle.fill(n, xmpi.I32, xmpi.PAT_UNIFORM, 60).tobytes(), (name, nbytes)
+                elif rank == 0:
+                    want = oracle.reduce_ranks([oracle.fill(n, xmpi.I32, xmpi.PAT_UNIFORM, 60 + r) for r in range(size)], xmpi.I32, 0)
+                    assert b.download(np.int32, n).tobytes() == want.tobytes(), (name, nbytes)
+                row[f"{coll}_{name}_us"] = round(float(worst[0]), 1)
+        rows.append(row)
+        a.free()
+        b.free()
+    if rank == 0:
+        print("ROOTED " + json.dumps({"ranks": size, "ranks_share_gpu": comm.get_param("dsync_sharers") > 1, "rows": rows}), flush=True)
+
+
 def sc_degraded(comm, args):
     """A job that could not map everything (tests/devsim fault injection: flag pages / windows / one rank's first open / no
     uncached memory): xmpi_init came back with a WORKING communicator at the best level every rank reached -- the level and the
@@ -2609,6 +2649,7 @@ def sc_mismatch(comm, args):
 SCENARIOS = {
     "mismatch": sc_mismatch,
     "linkprobe": sc_linkprobe,
+    "rooted_bench": sc_rooted_bench,
     "degraded": sc_degraded,
     "peer_dies": sc_peer_dies,
     "traffic": sc_traffic,
