@@ -2613,7 +2613,8 @@ def sc_mismatch(comm, args):
     odd = rank == size - 1
     t0 = time.time()
     try:
-        if what == "length":
+        if what in ("length", "length_split"):  # (split: the meet kernel finds it, the body kernel moves nothing, the done kernel says so)
+            comm.set_param("dsync_split_bytes", 1 if what == "length_split" else 0)
             comm.allreduce(a, b, n + (16 if odd else 0), xmpi.I64, xmpi.SUM, xmpi.ALGO_ZCOPY)
         elif what == "schedule":
             comm.allreduce(a, b, n, xmpi.I64, xmpi.SUM, xmpi.ALGO_RING if odd else xmpi.ALGO_ZCOPY)

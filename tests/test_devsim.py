@@ -223,7 +223,7 @@ def test_a_peer_that_dies_is_an_error_not_a_hang(devsim_lib, what):
     assert sum("ok (error after" in o for o in outs) == 2, "\n".join(outs)
 
 
-@pytest.mark.parametrize("what", ["length", "schedule", "form", "operation", "root", "shape", "collective"])
+@pytest.mark.parametrize("what", ["length", "length_split", "schedule", "form", "operation", "root", "shape", "collective"])
 def test_ranks_in_different_calls_get_an_error_not_a_hang(devsim_lib, what):
     """every kernel announces the call it is in; ranks that differ all fail at once, and nobody's buffer was written"""
     outs = run_ranks("mismatch", 3, {"what": what}, timeout=120, env={"XMPI_TIMEOUT_S": "20"})

@@ -288,7 +288,7 @@ def test_a_peer_that_dies_is_an_error_not_a_hang(what):
     assert sum("ok (error after" in o for o in outs) == 1, "\n".join(outs)
 
 
-@pytest.mark.parametrize("what", ["length", "schedule", "form", "root", "shape", "collective"])
+@pytest.mark.parametrize("what", ["length", "length_split", "schedule", "form", "root", "shape", "collective"])
 def test_ranks_in_different_calls_get_an_error_not_a_hang(what):
     """every kernel announces the call it is in (collective, schedule, bytes, dtype, operation, root, the stepped kernels' shape) in
     the upper half of a word it stores anyway; ranks that differ all end with an error at once -- no hang, no fold over buffers of
