@@ -175,11 +175,13 @@ int main(int argc, char** argv) {
   if (rank == 0)
     printf("{\"ranks\": %d, \"one_process_per_rank\": true, \"meet\": \"%s\", \"bytes_per_rank\": %zu, \"steps\": %d, \"warmup\": %d, "
            "\"sharers\": %ld, \"xcds\": %ld, \"xcd_probe_mask\": %ld, \"xcd_meet_mask\": %ld, \"xcd_done_mask\": %ld, \"xcd_short\": %ld, "
-           "\"body_sys\": %ld, \"exact\": %s, \"rows\": [%s], \"bounce\": [%s]}\n",
+           "\"body_sys\": %ld, \"degraded\": %ld, \"tune_rejected\": %ld, \"tune_check_ms\": %.1f, \"init_selfcheck_us\": %ld, \"exact\": %s, \"rows\": [%s], "
+           "\"bounce\": [%s]}\n",
            size, on_device ? "on the device (flag words in HBM)" : "on the host (control block)", bytes, steps, warmup,
            xmpi_get_param(c, "dsync_sharers"), xmpi_get_param(c, "xcds"), xmpi_get_param(c, "xcd_probe_mask"),
            xmpi_get_param(c, "xcd_meet_mask"), xmpi_get_param(c, "xcd_done_mask"), xmpi_get_param(c, "xcd_short"),
-           xmpi_get_param(c, "body_sys"), bad ? "false" : "true", rows.c_str(), bounce.c_str());
+           xmpi_get_param(c, "body_sys"), xmpi_get_param(c, "degraded"), xmpi_get_param(c, "tune_rejected"), (double)xmpi_get_param(c, "tune_check_us") / 1e3,
+           xmpi_get_param(c, "init_selfcheck_us"), bad ? "false" : "true", rows.c_str(), bounce.c_str());
   gpu->Free(send);
   gpu->Free(recv);
   mpi::Finalize();

@@ -453,6 +453,325 @@ static int collective(xmpi_comm* c, int coll, int algo, int root, const void* se
   return rc;
 }
 
+
+// ---- the library checks its schedules' ANSWERS on the machine it runs on ------------------------------------------------------
+// The reference's own benchmark verifies every echo before it reports a time (examples/bounce/bounce.go:103-112,131-136), its
+// handshake checks what came back (network.go:343-351).  Here: whoever times a schedule (xmpi_tune) or is about to rely on one
+// untuned (xmpi_init's self-check) first runs it ONCE on patterned inputs -- rank r's send buffer = the counter-based pattern with
+// seed kCheckSeed + r (kernels.hip fill_kernel, pattern 3: signed multiples of 2^-12 below 4 in magnitude: the float32 sum of
+// sixteen of them is exact in EVERY association, so every schedule must produce the same bits) --, compares the receive buffer with
+// the result computed locally (N fills folded with the two-operand kernel: no communication), and votes through the control block.
+const char* const kCandName[xmpi_comm::CAND_COUNT] = {"fold (one kernel)", "fold (one kernel, 2 packets in flight)", "split (meet / body / done)",
+                                                      "push-only", "ring kernel", "halving kernel", "LL lines", "ring kernel, push form",
+                                                      "halving kernel, push form", "tree kernel", "tree kernel, push form"};
+constexpr uint64_t kCheckSeed = 0x7A11D;
+constexpr int kCheckPattern = 3;
+
+static int job_barrier(xmpi_comm* c) {
+  dsync_service(c);
+  Backoff bo;
+  arm(bo, c);
+  return c->ctl->barrier(wait_limit(c), &bo);
+}
+
+// every rank publishes a row, all meet, everybody reads the same maxima
+static int vote_max(xmpi_comm* c, const double* us, const uint64_t* bad, int n, double* us_max, uint64_t* bad_max) {
+  TuneVote* mine = c->ctl->vote(c->rank);
+  for (int k = 0; k < kTuneCands; k++) {
+    mine->us[k] = (us && k < n) ? us[k] : 0.0;
+    mine->bad[k] = (bad && k < n) ? bad[k] : 0;
+  }
+  int rc = job_barrier(c);
+  if (rc != XMPI_OK) return rc;
+  for (int k = 0; k < n; k++) {
+    double u = 0;
+    uint64_t b = 0;
+    for (int p = 0; p < c->size; p++) {
+      const TuneVote* v = c->ctl->vote(p);
+      u = std::max(u, v->us[k]);
+      b = std::max(b, v->bad[k]);
+    }
+    if (us_max) us_max[k] = u;
+    if (bad_max) bad_max[k] = b;
+  }
+  return job_barrier(c);  // nobody writes its next row before everybody has read this one
+}
+
+struct AnswerCheck {
+  xmpi_comm* c = nullptr;
+  char *send = nullptr, *recv = nullptr, *expect = nullptr;
+  size_t cap = 0;          // bytes of each
+  int have_coll = -1;      // what `expect` holds
+  size_t have_bytes = 0;
+  double spent_s = 0;
+
+  int open(xmpi_comm* comm, size_t max_bytes) {
+    c = comm;
+    cap = max_bytes;
+    send = (char*)heap_alloc(c->device, cap);
+    recv = (char*)heap_alloc(c->device, cap);
+    expect = (char*)heap_alloc(c->device, cap);
+    if (!send || !recv || !expect) {
+      close();
+      set_last_error("xmpi_tune: out of device memory");
+      return XMPI_ERR_NOMEM;
+    }
+    XMPI_HIP(launch_fill(send, cap / 4, XMPI_F32, kCheckPattern, kCheckSeed + (uint64_t)c->rank, c->local_stream));
+    XMPI_HIP(hipStreamSynchronize(c->local_stream));
+    return XMPI_OK;
+  }
+  void close() {
+    if (c) {
+      (void)hipStreamSynchronize(c->local_stream);
+      (void)hipGetLastError();
+    }
+    if (send) (void)heap_free(send);
+    if (recv) (void)heap_free(recv);
+    if (expect) (void)heap_free(expect);
+    send = recv = expect = nullptr;
+  }
+  size_t recv_bytes(int coll, size_t per_rank) const { return coll == COLL_ALLGATHER ? per_rank * (size_t)c->size : per_rank; }
+  // `expect` = what `coll` over `per_rank` bytes per rank (root 0) must leave in the receive buffer.  The pattern is a function of
+  // the element's index: a shorter message is a prefix of a longer one's, so the sum and the broadcast are computed once, at `cap`.
+  int expect_for(int coll, size_t per_rank) {
+    const double t0 = now_seconds();
+    hipStream_t s = c->local_stream;
+    const bool sum = coll == COLL_ALLREDUCE || coll == COLL_REDUCE;
+    if (sum && !(have_coll == COLL_ALLREDUCE || have_coll == COLL_REDUCE)) {
+      XMPI_HIP(launch_fill(expect, cap / 4, XMPI_F32, kCheckPattern, kCheckSeed, s));
+      for (int r = 1; r < c->size; r++) {  // (the receive buffer is free between two candidates: the other ranks' inputs pass through it)
+        XMPI_HIP(launch_fill(recv, cap / 4, XMPI_F32, kCheckPattern, kCheckSeed + (uint64_t)r, s));
+        XMPI_HIP(launch_reduce2(expect, expect, recv, cap / 4, XMPI_F32, XMPI_SUM, s));
+      }
+    } else if (coll == COLL_ALLGATHER && !(have_coll == coll && have_bytes == per_rank)) {
+      for (int r = 0; r < c->size; r++)
+        XMPI_HIP(launch_fill(expect + (size_t)r * per_rank, per_rank / 4, XMPI_F32, kCheckPattern, kCheckSeed + (uint64_t)r, s));
+    } else if (coll == COLL_BCAST && have_coll != coll) {
+      XMPI_HIP(launch_fill(expect, cap / 4, XMPI_F32, kCheckPattern, kCheckSeed, s));
+      if (c->rank == 0) XMPI_HIP(launch_fill(recv, cap / 4, XMPI_F32, kCheckPattern, kCheckSeed, s));  // the root's buffer IS the message
+    }
+    have_coll = coll;
+    have_bytes = per_rank;
+    spent_s += now_seconds() - t0;
+    return XMPI_OK;
+  }
+  // before the checked run: whatever an earlier candidate left in the receive buffer must not pass for this one's answer
+  int arm(int coll, size_t per_rank) {
+    const double t0 = now_seconds();
+    // (bcast: the root's buffer is the input; reduce: only the root's is written)
+    const bool untouched = (coll == COLL_BCAST && c->rank == 0) || (coll == COLL_REDUCE && c->rank != 0);
+    if (!untouched) XMPI_HIP(hipMemsetAsync(recv, 0xA5, recv_bytes(coll, per_rank), c->local_stream));
+    spent_s += now_seconds() - t0;
+    return XMPI_OK;
+  }
+  int verdict(int coll, size_t per_rank, uint64_t* bad) {
+    *bad = 0;
+    if (coll == COLL_REDUCE && c->rank != 0) return XMPI_OK;
+    const double t0 = now_seconds();
+    hipStream_t s = c->local_stream;
+    XMPI_HIP(hipMemsetAsync(c->dev_words, 0, 32, s));
+    XMPI_HIP(launch_count_mismatch(recv, expect, recv_bytes(coll, per_rank), c->dev_words, s));
+    XMPI_HIP(hipMemcpyAsync(bad, c->dev_words, 8, hipMemcpyDeviceToHost, s));
+    XMPI_HIP(hipStreamSynchronize(s));
+    spent_s += now_seconds() - t0;
+    return XMPI_OK;
+  }
+};
+
+struct TuneCand {
+  int algo, split, unroll;
+};
+static std::vector<TuneCand> tune_candidates(const xmpi_comm* c) {
+  const int u0 = (int)std::max<long>(1, std::min<long>(2, c->dsync_unroll));
+  // the default comes first (xmpi_tune_decide keeps it on a tie); the order is xmpi_comm::CAND_*
+  return {{XMPI_ALGO_ZCOPY, 0, u0},      {XMPI_ALGO_ZCOPY, 0, 3 - u0}, {XMPI_ALGO_ZCOPY, 1, u0},    {XMPI_ALGO_ZPUSH, 0, u0},
+          {XMPI_ALGO_RING, 0, u0},       {XMPI_ALGO_RHD, 0, u0},       {XMPI_ALGO_LL, 0, u0},
+          // the push forms of the stepped kernels (sched_steps.h): the same schedules with every payload byte STORED over its link
+          // instead of loaded -- which of the two a link moves faster is the machine's to say
+          {XMPI_ALGO_RING_PUSH, 0, u0},  {XMPI_ALGO_RHD_PUSH, 0, u0},
+          // bcast and reduce: the tree kernels in both forms against the fold's two halves
+          {XMPI_ALGO_TREE, 0, u0},       {XMPI_ALGO_TREE_PUSH, 0, u0}};
+}
+// which candidates a collective has: (the fold, LL lines) all four; allreduce every form of the fold and ring / halving in both
+// forms; allgather the ring; bcast the tree (its fold is one kernel whatever the size); reduce what allreduce has of the fold, and
+// the tree
+static bool tune_offered(const xmpi_comm* c, int coll, const TuneCand& cd) {
+  const int u0 = (int)std::max<long>(1, std::min<long>(2, c->dsync_unroll));
+  const bool tree = cd.algo == XMPI_ALGO_TREE || cd.algo == XMPI_ALGO_TREE_PUSH;
+  const bool ring = cd.algo == XMPI_ALGO_RING || cd.algo == XMPI_ALGO_RING_PUSH;
+  const bool rhd = cd.algo == XMPI_ALGO_RHD || cd.algo == XMPI_ALGO_RHD_PUSH;
+  switch (coll) {
+    case COLL_ALLREDUCE: return !tree;
+    case COLL_ALLGATHER: return !tree && !rhd && cd.algo != XMPI_ALGO_ZPUSH && cd.unroll == u0;
+    case COLL_BCAST: return !ring && !rhd && cd.algo != XMPI_ALGO_ZPUSH && cd.unroll == u0 && cd.split == 0;
+    default: return !ring && !rhd && cd.unroll == u0;  // COLL_REDUCE
+  }
+}
+
+// Candidates `ks` of `coll` at `per_rank` bytes per rank: each runs once CHECKED (check: the warm-up that also maps whatever is
+// new), then `iters` times against the clock.  us[k]: mean microseconds (min with what it held when keep_min); bad[k]: bytes of
+// this rank's receive buffer that differ from the expected result.  Collective: every rank passes the same arguments.
+static int tune_measure(xmpi_comm* c, AnswerCheck& chk, const std::vector<TuneCand>& cands, int coll, size_t per_rank, const std::vector<int>& ks,
+                        int iters, bool check, bool keep_min, double* us, uint64_t* bad) {
+  const long keep_split = c->dsync_split_bytes, keep_unroll = c->dsync_unroll;
+  int rc = XMPI_OK;
+  for (size_t j = 0; j < ks.size() && rc == XMPI_OK; j++) {
+    const int k = ks[j];
+    const TuneCand& cd = cands[(size_t)k];
+    rc = job_barrier(c);  // (everybody has left the previous candidate: its receive buffer is this rank's again)
+    if (rc != XMPI_OK) break;
+    // (all candidates run under ONE call number -- the caller's XMPI_ENTER: dsync_ll takes "the previous call was an agent's
+    // collective and this is the next call" for "nothing was enqueued since", which the poison enqueued here would belie)
+    std::lock_guard<std::mutex> g(c->coll_mu);
+    c->dsync_split_bytes = cd.split ? 1 : 0;
+    c->dsync_unroll = cd.unroll;
+    if (check) rc = chk.arm(coll, per_rank);
+    double t0 = now_seconds();
+    for (int i = -1; i < iters && rc == XMPI_OK; i++) {
+      if (i == 0) t0 = now_seconds();
+      rc = dsync_collective(c, coll, 0, coll == COLL_BCAST ? chk.recv : chk.send, chk.recv, per_rank / 4, XMPI_F32, XMPI_SUM, c->local_stream,
+                            /*blocking=*/i == -1 || i == iters - 1, cd.algo);
+      if (i == -1 && check && rc == XMPI_OK) rc = chk.verdict(coll, per_rank, &bad[k]);
+    }
+    if (iters > 0) {
+      const double t_us = (now_seconds() - t0) / iters * 1e6;
+      us[k] = keep_min && us[k] > 0 ? std::min(us[k], t_us) : t_us;
+    }
+    c->dsync_split_bytes = keep_split;
+    c->dsync_unroll = keep_unroll;
+  }
+  return rc;
+}
+
+// What follows from a rejected schedule beyond "AUTO's table leaves it out": the untuned rules must not lead to it either.
+static void apply_rejections(xmpi_comm* c) {
+  uint32_t any = 0;
+  for (int k = 0; k < 4; k++) any |= c->tune_rejected[k];
+  if (any & (1u << xmpi_comm::CAND_LL)) {  // untuned AUTO sends short messages as LL lines
+    c->ll_bytes = 0;
+    c->agent_ll = 0;
+    // (one mechanism -- 8-byte lines stored into the peers' flag allocations -- under all four collectives: wrong for one, trusted for none)
+    for (int k = 0; k < 4; k++) c->tune_rejected[k] |= 1u << xmpi_comm::CAND_LL;
+  }
+  if (any & (1u << xmpi_comm::CAND_SPLIT)) c->dsync_split_bytes = 0;  // ... and large ones as meet / body / done
+}
+
+// The ladder's last rung: no device-synchronised schedule is right for some call on this machine -- the ranks meet on the host from
+// now on (zcopy.cpp's rendezvous through the control block, the staged step tables), as after a flag page that could not be mapped.
+// Collective (the caller's decision came out of a vote).
+static void demote_to_host(xmpi_comm* c, const std::string& reason) {
+  ll_agent_stop(c);
+  (void)hipStreamSynchronize(c->local_stream);
+  (void)hipGetLastError();
+  c->dsync_ok = false;
+  c->tuned = false;
+  c->degraded_why += std::string(c->degraded_why.empty() ? "" : "; ") + "the ranks meet on the host (no device-synchronised collectives): " + reason;
+}
+
+// what a check found: remembered, said (xmpi_degraded, xmpi_last_error, one line on stderr), and acted upon
+static void note_rejections(xmpi_comm* c, const char* who, const std::string& why, bool none_right) {
+  apply_rejections(c);
+  if (why.empty() && !none_right) return;
+  const std::string text = std::string(who) + ": " + why + (why.empty() ? "" : "; ") +
+                           (none_right ? "no schedule left that is right for every call" : "left out of AUTO, refused by name (tune_rejected_<collective>)");
+  c->rejected_why += std::string(c->rejected_why.empty() ? "" : "; ") + text;
+  c->degraded_why += std::string(c->degraded_why.empty() ? "" : "; ") + text;
+  if (none_right) demote_to_host(c, std::string(who) + " found no right schedule for some call");
+  set_last_error(text);
+  if (c->rank == 0) fprintf(stderr, "xmpi: degraded: %s\n", text.c_str());
+}
+
+// xmpi_init's self-check (XMPI_SELFCHECK; default: on when the ranks sit on different GPUs): what UNTUNED AUTO can reach -- LL lines
+// up to ll_bytes, the one-kernel fold, meet / body / done -- runs once, multi-tile, on patterned inputs before the first caller's
+// data does; the other three collectives' folds ride along.  A job that tunes (xmpi_tune, XMPI_AUTOTUNE_BYTES) checks every
+// candidate at every size anyway.  Collective.
+static int init_selfcheck(xmpi_comm* c) {
+  const double t_begin = now_seconds();
+  t_api_call = c->api_calls.fetch_add(1, std::memory_order_relaxed) + 1;  // (as a public call: XMPI_ENTER)
+  // several 4 KiB tiles per rank's chunk at 8 ranks (fold: 4; split: 8 one-tile blocks, one per XCD); bcast just above
+  // zc_bcast_push_bytes, where every rank forwards its chunk
+  const size_t kFold = (size_t)128 << 10, kSplit = (size_t)256 << 10;
+  const size_t kBcast = (size_t)std::max<long>(0, c->zc_bcast_push_bytes) + 16384 <= kSplit * 2 ? (size_t)std::max<long>(0, c->zc_bcast_push_bytes) + 16384 : kSplit;
+  AnswerCheck chk;
+  int rc;
+  {
+    std::lock_guard<std::mutex> g(c->coll_mu);
+    rc = chk.open(c, std::max(kSplit, kBcast));
+  }
+  if (rc != XMPI_OK) return rc;
+  XMPI_TRACE_STEP(c->rank, "self-check: buffers ready");
+  const std::vector<TuneCand> cands = tune_candidates(c);
+  c->tune_running = true;
+  std::string why;
+  bool fold_wrong = false;
+  auto run = [&](int coll, size_t per_rank, std::vector<int> ks, uint64_t* worst_bad) -> int {
+    std::vector<uint64_t> bad(cands.size(), 0);
+    {
+      std::lock_guard<std::mutex> g(c->coll_mu);
+      rc = chk.expect_for(coll, per_rank);
+    }
+    if (rc == XMPI_OK) rc = tune_measure(c, chk, cands, coll, per_rank, ks, 0, true, false, nullptr, bad.data());
+    if (rc == XMPI_OK) rc = vote_max(c, nullptr, bad.data(), (int)cands.size(), nullptr, worst_bad);
+    return rc;
+  };
+  auto reject = [&](int coll, int k, size_t per_rank, uint64_t nbad) {
+    c->tune_rejected[coll] |= 1u << k;
+    char t[200];
+    snprintf(t, sizeof t, "%s: %s gives wrong answers on this machine (%zu B per rank: %llu bytes differ on the worst rank)", coll_name(coll), kCandName[k],
+             per_rank, (unsigned long long)nbad);
+    why += std::string(why.empty() ? "" : "; ") + t;
+  };
+  std::vector<uint64_t> wb(cands.size(), 0);
+  do {
+    // allreduce: LL lines, the one-kernel fold, meet / body / done
+    const size_t ll = (size_t)std::min<long>(c->ll_bytes, 4096) / 16 * 16;
+    if (ll >= 16) {
+      if ((rc = run(COLL_ALLREDUCE, ll, {xmpi_comm::CAND_LL}, wb.data())) != XMPI_OK) break;
+      if (wb[xmpi_comm::CAND_LL]) reject(COLL_ALLREDUCE, xmpi_comm::CAND_LL, ll, wb[xmpi_comm::CAND_LL]);
+    }
+    XMPI_TRACE_STEP(c->rank, "self-check: LL lines done");
+    if ((rc = run(COLL_ALLREDUCE, kFold, {xmpi_comm::CAND_FOLD}, wb.data())) != XMPI_OK) break;
+    XMPI_TRACE_STEP(c->rank, "self-check: fold done");
+    if (wb[xmpi_comm::CAND_FOLD]) {
+      reject(COLL_ALLREDUCE, xmpi_comm::CAND_FOLD, kFold, wb[xmpi_comm::CAND_FOLD]);
+      fold_wrong = true;
+    }
+    if (c->dsync_split_bytes > 0) {
+      if ((rc = run(COLL_ALLREDUCE, kSplit, {xmpi_comm::CAND_SPLIT}, wb.data())) != XMPI_OK) break;
+      if (wb[xmpi_comm::CAND_SPLIT] && !c->body_sys) {  // the ladder's first rung (see xmpi_tune)
+        const uint64_t first = wb[xmpi_comm::CAND_SPLIT];
+        c->body_sys = 1;
+        if ((rc = run(COLL_ALLREDUCE, kSplit, {xmpi_comm::CAND_SPLIT}, wb.data())) != XMPI_OK) break;
+        char t[200];
+        snprintf(t, sizeof t, "allreduce: split gave wrong answers at %zu B per rank (%llu bytes differ on the worst rank); its system-scope data kernel %s",
+                 kSplit, (unsigned long long)first, wb[xmpi_comm::CAND_SPLIT] ? "does too" : "is right and takes over (body_sys)");
+        why += std::string(why.empty() ? "" : "; ") + t;
+        if (wb[xmpi_comm::CAND_SPLIT]) c->body_sys = 0;
+      }
+      if (wb[xmpi_comm::CAND_SPLIT]) reject(COLL_ALLREDUCE, xmpi_comm::CAND_SPLIT, kSplit, wb[xmpi_comm::CAND_SPLIT]);
+    }
+    XMPI_TRACE_STEP(c->rank, "self-check: split done");
+    // the other collectives' folds (other segment tables of the same kernel; bcast above zc_bcast_push_bytes: scatter + allgather)
+    for (int coll : {(int)COLL_REDUCE, (int)COLL_ALLGATHER, (int)COLL_BCAST}) {
+      const size_t per_rank = coll == COLL_ALLGATHER ? kFold / (size_t)c->size / 16 * 16 : coll == COLL_BCAST ? kBcast : kFold;
+      if ((rc = run(coll, per_rank, {xmpi_comm::CAND_FOLD}, wb.data())) != XMPI_OK) break;
+      if (wb[xmpi_comm::CAND_FOLD]) {
+        reject(coll, xmpi_comm::CAND_FOLD, per_rank, wb[xmpi_comm::CAND_FOLD]);
+        fold_wrong = true;
+      }
+    }
+  } while (false);
+  c->tune_running = false;
+  {
+    std::lock_guard<std::mutex> g(c->coll_mu);
+    chk.close();
+  }
+  if (rc != XMPI_OK) return rc;
+  // an untuned job has no table to route round a wrong fold: the one-kernel fold is what every collective's AUTO comes down to
+  note_rejections(c, "xmpi_init self-check", why, fold_wrong);
+  c->selfcheck_ms = (now_seconds() - t_begin) * 1e3;
+  return job_barrier(c);
+}
 }  // namespace xmpi
 
 using namespace xmpi;
@@ -768,10 +1087,26 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
     return fail(rc);
   }
   heap_comm_created();
+  // The ranks sit on different GPUs (or XMPI_SELFCHECK=1): what untuned AUTO can reach is tried on patterned inputs before the
+  // first caller's data goes through it (init_selfcheck above).  A job that tunes right here checks every candidate anyway.
+  const long tune_bytes = env_long("XMPI_AUTOTUNE_BYTES", 0);
+  c->selfcheck = env_long("XMPI_SELFCHECK", -1);
+  if (c->selfcheck < 0) {
+    bool spread = false;
+    for (int p = 0; p < size; p++) spread = spread || strncmp(ctl->info(p)->busid, me->busid, sizeof me->busid) != 0;
+    c->selfcheck = spread ? 1 : 0;
+  }
+  if (c->selfcheck && dsync_usable(c) && !(tune_bytes > 0)) {
+    XMPI_TRACE_STEP(rank, "init: self-check");
+    rc = init_selfcheck(c);
+    if (rc != XMPI_OK) {
+      (void)xmpi_finalize(c);
+      return rc;
+    }
+  }
   // XMPI_AUTOTUNE_BYTES=N: the library times its schedules for messages up to N bytes right here (xmpi_tune), so that a
   // program that knows nothing about tuning gets the schedule a benchmark would pick on this node; every rank sees the
   // same environment, so it is collective.  Default: off (a few hundred milliseconds and 2 x N bytes of HBM per rank).
-  const long tune_bytes = env_long("XMPI_AUTOTUNE_BYTES", 0);
   if (tune_bytes > 0 && size > 1) {
     XMPI_TRACE_STEP(rank, "init: tuning");
     rc = xmpi_tune(c, (size_t)tune_bytes);
@@ -1580,11 +1915,13 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
   if (n == "dsync_land_bytes") return (long)c->dsync_land_bytes;
   // what xmpi_init's vote left the job with: 0 = everything; bit 0 (1): the split form's data kernel runs at system scope (the XCD
   // probe of THIS rank's GPU); bit 1 (2): the ranks meet on the host (some flag page could not be allocated, exported or mapped);
-  // bit 2 (4): no windows (some window could not be mapped: no staged step tables, no mail slots).  xmpi_degraded() says why.
+  // bit 2 (4): no windows (some window could not be mapped: no staged step tables, no mail slots); bit 3 (8): a schedule gave wrong
+  // answers when the library checked it here and was taken out (tune_rejected).  xmpi_degraded() says why.
   if (n == "degraded") {
     bool shared_gpu = false;  // (ranks hosted by threads of one process on one GPU meet on the host by design, not by degradation)
     for (int p = 0; p < c->size; p++) shared_gpu = shared_gpu || c->peer_coloc[p];
-    return (c->body_sys == 1 && c->dsync_ok ? 1 : 0) | ((c->size > 1 && c->dsync && !c->dsync_ok && !shared_gpu) ? 2 : 0) | (c->windows_ok ? 0 : 4);
+    return (c->body_sys == 1 && c->dsync_ok ? 1 : 0) | ((c->size > 1 && c->dsync && !c->dsync_ok && !shared_gpu) ? 2 : 0) | (c->windows_ok ? 0 : 4) |
+           (c->rejected_why.empty() ? 0 : 8);
   }
   if (n == "windows_ok") return c->windows_ok ? 1 : 0;
   if (n == "sched_channels") return c->sched_channels;
@@ -1592,6 +1929,18 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
   if (n == "tree_piece_bytes") return c->tree_piece_bytes;
   if (n == "tuned") return c->tuned ? 1 : 0;
   if (n == "tune_mask") return c->tune_mask;
+  // schedules whose answers the library found wrong on this machine (xmpi_tune, xmpi_init's self-check): how many in all, and per
+  // collective (0 allreduce, 1 allgather, 2 bcast, 3 reduce) a bit per candidate -- the numbering of tune_mask
+  if (n == "tune_rejected") return __builtin_popcount(c->tune_rejected[0]) + __builtin_popcount(c->tune_rejected[1]) + __builtin_popcount(c->tune_rejected[2]) + __builtin_popcount(c->tune_rejected[3]);
+  if (n.rfind("tune_rejected_", 0) == 0) {
+    const int coll = atoi(name + 14);
+    return (coll >= 0 && coll < 4 && name[14] >= '0' && name[14] <= '3' && !name[15]) ? (long)c->tune_rejected[coll] : -1;
+  }
+  if (n == "selfcheck") return c->selfcheck;
+  if (n == "init_selfcheck_ms") return c->selfcheck_ms < 0 ? -1 : (long)(c->selfcheck_ms + 0.999);  // xmpi_init's self-check: -1 = did not run
+  if (n == "init_selfcheck_us") return c->selfcheck_ms < 0 ? -1 : (long)(c->selfcheck_ms * 1e3);
+  if (n == "tune_us") return (long)(c->tune_ms * 1e3);              // the last xmpi_tune, all of it
+  if (n == "tune_check_us") return (long)(c->tune_check_ms * 1e3);  // ... the part spent checking answers (expected results, poison, compare)
   if (n.rfind("tune_", 0) == 0) {  // tune_<algo|split|unroll>_<collective 0..3>_<size class>: the table of xmpi_tune
     int coll = -1, cls = -1;
     char what[16] = {0};
@@ -1910,103 +2259,117 @@ int xmpi_tune_decide(const double* us, int n, double margin) {
 }
 
 // Times the schedules this job's layout offers for allreduce-sum f32, allgather, bcast and reduce on the real buffers, size class by size
-// class, lets every rank see the same (max over ranks) figures and fills the table AUTO consults (dsync.cpp tuned_choice).
-// Collective: every rank calls it with the same max_bytes.  With ranks that meet on the host there is nothing to choose.
+// class -- after CHECKING each one's answer at that size (above) --, lets every rank see the same (max over ranks) figures and fills the
+// table AUTO consults (dsync.cpp tuned_choice).  A candidate that was wrong on ANY rank at ANY size leaves the collective's table on
+// EVERY rank (xmpi_get_param "tune_rejected_<collective>", xmpi_degraded(), xmpi_last_error()); a wrong DEFAULT walks the ladder the
+// mapping vote walks: split -> its system-scope data kernel -> the one-kernel fold -> (no right schedule left for some size) the ranks
+// meet on the host.  Collective: every rank calls it with the same max_bytes.  With ranks that meet on the host there is nothing to choose.
 int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
   XMPI_ENTER(c);
   drain_worker(c);
   if (!dsync_usable(c) || c->size < 2) return XMPI_OK;
+  const double t_begin = now_seconds();
   max_bytes = std::min<size_t>(std::max<size_t>(max_bytes, 1024), (size_t)1 << 30);
-  void* send = heap_alloc(c->device, max_bytes);
-  void* recv = heap_alloc(c->device, max_bytes);
-  if (!send || !recv) {
-    if (send) (void)heap_free(send);
-    if (recv) (void)heap_free(recv);
-    set_last_error("xmpi_tune: out of device memory");
-    return XMPI_ERR_NOMEM;
-  }
-  int rc = XMPI_OK;
+  AnswerCheck chk;
+  int rc;
   {
     std::lock_guard<std::mutex> g(c->coll_mu);
-    if (hipMemsetAsync(send, 0, max_bytes, c->local_stream) != hipSuccess || hipStreamSynchronize(c->local_stream) != hipSuccess)
-      rc = hip_fail(hipGetLastError(), "hipMemset", __FILE__, __LINE__);
+    rc = chk.open(c, max_bytes);
   }
-  struct Cand {
-    int algo, split, unroll;
-  };
-  const int u0 = (int)std::max<long>(1, std::min<long>(2, c->dsync_unroll));
-  std::vector<Cand> cands = {{XMPI_ALGO_ZCOPY, 0, u0},  // the default comes first (xmpi_tune_decide keeps it on a tie)
-                             {XMPI_ALGO_ZCOPY, 0, 3 - u0},
-                             {XMPI_ALGO_ZCOPY, 1, u0},
-                             {XMPI_ALGO_ZPUSH, 0, u0},
-                             {XMPI_ALGO_RING, 0, u0}};
-  cands.push_back({XMPI_ALGO_RHD, 0, u0});
-  cands.push_back({XMPI_ALGO_LL, 0, u0});                                          // candidate 6
-  // the push forms of the stepped kernels (sched_steps.h): the same schedules with every payload byte STORED over its link
-  // instead of loaded -- which of the two a link moves faster is the machine's to say
-  cands.push_back({XMPI_ALGO_RING_PUSH, 0, u0});                                   // candidate 7
-  cands.push_back({XMPI_ALGO_RHD_PUSH, 0, u0});                                    // candidate 8
-  // bcast and reduce: the tree kernels in both forms against the fold's two halves
-  cands.push_back({XMPI_ALGO_TREE, 0, u0});                                        // candidate 9
-  cands.push_back({XMPI_ALGO_TREE_PUSH, 0, u0});                                   // candidate 10
-  // which candidates a collective has: (the fold, LL lines) all four; allreduce every form of the fold and ring / halving in
-  // both forms; allgather the ring; bcast the tree (its fold is one kernel whatever the size); reduce what allreduce has of the
-  // fold, and the tree
-  auto offered = [&](int coll, const Cand& cd) {
-    const bool tree = cd.algo == XMPI_ALGO_TREE || cd.algo == XMPI_ALGO_TREE_PUSH;
-    const bool ring = cd.algo == XMPI_ALGO_RING || cd.algo == XMPI_ALGO_RING_PUSH;
-    const bool rhd = cd.algo == XMPI_ALGO_RHD || cd.algo == XMPI_ALGO_RHD_PUSH;
-    switch (coll) {
-      case COLL_ALLREDUCE: return !tree;
-      case COLL_ALLGATHER: return !tree && !rhd && cd.algo != XMPI_ALGO_ZPUSH && cd.unroll == u0;
-      case COLL_BCAST: return !ring && !rhd && cd.algo != XMPI_ALGO_ZPUSH && cd.unroll == u0 && cd.split == 0;
-      default: return !ring && !rhd && cd.unroll == u0;  // COLL_REDUCE
-    }
-  };
-  const long keep_split = c->dsync_split_bytes, keep_unroll = c->dsync_unroll;
+  if (rc != XMPI_OK) return rc;
+  const std::vector<TuneCand> cands = tune_candidates(c);
+  const long keep_split = c->dsync_split_bytes;
   const bool keep_tuned = c->tuned;
   c->tuned = false;
+  c->tune_running = true;
   memset(c->tune_algo, -1, sizeof c->tune_algo);
   memset(c->tune_split, -1, sizeof c->tune_split);
   memset(c->tune_unroll, 0, sizeof c->tune_unroll);
-  for (int coll : {(int)COLL_ALLREDUCE, (int)COLL_ALLGATHER, (int)COLL_BCAST, (int)COLL_REDUCE}) {
+  memset(c->tune_rejected, 0, sizeof c->tune_rejected);
+  std::string why;
+  bool none_right = false;
+  struct Row {
+    size_t per_rank;
+    std::vector<double> worst;
+  };
+  std::vector<Row> all_rows[4];
+  uint32_t ll_out = 0;  // LL lines are ONE mechanism under all four collectives: wrong for one, trusted for none (apply_rejections)
+  for (int coll : {(int)COLL_ALLREDUCE, (int)COLL_REDUCE, (int)COLL_ALLGATHER, (int)COLL_BCAST}) {  // (the two that share the expected sum side by side)
+    std::vector<Row>& rows = all_rows[coll];
+    uint32_t rejected = ll_out;
     for (size_t bytes = 1024; bytes <= max_bytes && rc == XMPI_OK; bytes *= 4) {
       const size_t per_rank = coll == COLL_ALLGATHER ? bytes / (size_t)c->size / 16 * 16 : bytes;
       if (per_rank < 16) continue;
       const int iters = bytes <= ((size_t)1 << 20) ? 20 : (bytes <= ((size_t)32 << 20) ? 6 : 3);
       std::vector<double> us(cands.size(), 0.0), worst(cands.size(), 0.0);
+      std::vector<uint64_t> bad(cands.size(), 0), worst_bad(cands.size(), 0);
+      std::vector<int> ks;
+      for (size_t k = 0; k < cands.size(); k++) {
+        if (!tune_offered(c, coll, cands[k])) continue;
+        if (cands[k].algo == XMPI_ALGO_LL && per_rank > kLLMaxPayload) continue;
+        if (k > 0 && !((c->tune_mask >> k) & 1)) continue;  // a schedule the caller has ruled out on this machine (never the default)
+        if ((rejected >> k) & 1u) continue;                 // ... or a smaller size has (the vote: the same on every rank)
+        ks.push_back((int)k);
+      }
+      {
+        std::lock_guard<std::mutex> g(c->coll_mu);
+        rc = chk.expect_for(coll, per_rank);
+      }
       // few iterations fit a large message into a tuning budget, and a few iterations are noisy (eight processes on one GPU:
       // +-6 % between two runs of one schedule): large sizes are measured twice, the candidates interleaved, and the better
       // figure of each counts
       const int rounds = bytes > ((size_t)1 << 20) ? 2 : 1;
-      for (int round = 0; round < rounds && rc == XMPI_OK; round++) {
-        for (size_t k = 0; k < cands.size() && rc == XMPI_OK; k++) {
-          const Cand& cd = cands[k];
-          if (cd.algo < 0) continue;
-          if (!offered(coll, cd)) continue;
-          if (cd.algo == XMPI_ALGO_LL && per_rank > kLLMaxPayload) continue;
-          if (k > 0 && !((c->tune_mask >> k) & 1)) continue;  // a schedule the caller has ruled out on this machine (never the default)
-          rc = xmpi_barrier(c);
-          if (rc != XMPI_OK) break;
-          std::lock_guard<std::mutex> g(c->coll_mu);
-          c->dsync_split_bytes = cd.split ? 1 : 0;
-          c->dsync_unroll = cd.unroll;
-          double t0 = 0;
-          for (int i = -1; i < iters && rc == XMPI_OK; i++) {  // i = -1: a warm-up that also maps whatever is new
-            if (i == 0) t0 = now_seconds();
-            rc = dsync_collective(c, coll, 0, coll == COLL_BCAST ? recv : send, recv, per_rank / 4, XMPI_F32, XMPI_SUM, c->local_stream,
-                                  /*blocking=*/i == -1 || i == iters - 1, cd.algo);
-          }
-          const double t_us = (now_seconds() - t0) / iters * 1e6;
-          us[k] = round == 0 ? t_us : std::min(us[k], t_us);
-          c->dsync_split_bytes = keep_split;
-          c->dsync_unroll = keep_unroll;
-        }
+      for (int round = 0; round < rounds && rc == XMPI_OK; round++)
+        rc = tune_measure(c, chk, cands, coll, per_rank, ks, iters, /*check=*/round == 0, /*keep_min=*/round > 0, us.data(), bad.data());
+      if (rc != XMPI_OK) break;
+      // every rank must read the same figures: the slowest rank's times, the worst rank's answers
+      rc = vote_max(c, us.data(), bad.data(), (int)cands.size(), worst.data(), worst_bad.data());
+      if (rc != XMPI_OK) break;
+      // the ladder's first rung: meet / body / done gave wrong answers with the data kernel that relies on the meet and done
+      // kernels' acquire / release once per XCD -- its system-scope form relies on nothing (what the XCD probe would have chosen)
+      if (worst_bad[xmpi_comm::CAND_SPLIT] && !c->body_sys) {
+        c->body_sys = 1;
+        us[xmpi_comm::CAND_SPLIT] = 0;
+        bad[xmpi_comm::CAND_SPLIT] = 0;
+        rc = tune_measure(c, chk, cands, coll, per_rank, {xmpi_comm::CAND_SPLIT}, iters, true, false, us.data(), bad.data());
+        std::vector<double> w2(cands.size(), 0.0);
+        std::vector<uint64_t> b2(cands.size(), 0);
+        if (rc == XMPI_OK) rc = vote_max(c, us.data(), bad.data(), (int)cands.size(), w2.data(), b2.data());
+        if (rc != XMPI_OK) break;
+        char t[200];
+        snprintf(t, sizeof t, "%s: split gave wrong answers at %zu B per rank (%llu bytes differ on the worst rank); its system-scope data kernel %s",
+                 coll_name(coll), per_rank, (unsigned long long)worst_bad[xmpi_comm::CAND_SPLIT], b2[xmpi_comm::CAND_SPLIT] ? "does too" : "is right and takes over (body_sys)");
+        why += std::string(why.empty() ? "" : "; ") + t;
+        worst[xmpi_comm::CAND_SPLIT] = w2[xmpi_comm::CAND_SPLIT];
+        worst_bad[xmpi_comm::CAND_SPLIT] = b2[xmpi_comm::CAND_SPLIT];
+        if (b2[xmpi_comm::CAND_SPLIT]) c->body_sys = 0;
       }
-      if (rc != XMPI_OK) break;
-      // every rank must read the same figures: the slowest rank's
-      rc = collective(c, COLL_ALLREDUCE, XMPI_ALGO_DIRECT, 0, us.data(), worst.data(), us.size(), XMPI_F64, XMPI_MAX);
-      if (rc != XMPI_OK) break;
+      for (size_t k = 0; k < cands.size(); k++)
+        if (worst_bad[k] && !((rejected >> k) & 1u)) {
+          rejected |= 1u << k;
+          char t[200];
+          snprintf(t, sizeof t, "%s: %s gives wrong answers on this machine (first at %zu B per rank: %llu bytes differ on the worst rank)", coll_name(coll),
+                   kCandName[k], per_rank, (unsigned long long)worst_bad[k]);
+          why += std::string(why.empty() ? "" : "; ") + t;
+        }
+      rows.push_back({per_rank, worst});
+    }
+    if (rc != XMPI_OK) break;
+    c->tune_rejected[coll] = rejected;
+    ll_out |= rejected & (1u << xmpi_comm::CAND_LL);
+  }
+  // the tables, once the rejected sets are known: what was wrong at one size is not trusted at another
+  for (int coll = 0; coll < 4 && rc == XMPI_OK; coll++) {
+    std::vector<Row>& rows = all_rows[coll];
+    const uint32_t rejected = c->tune_rejected[coll] | ll_out;
+    for (size_t ri = 0; ri < rows.size(); ri++) {
+      const size_t per_rank = rows[ri].per_rank;
+      std::vector<double>& worst = rows[ri].worst;
+      bool ran = false;
+      for (size_t k = 0; k < cands.size(); k++) {
+        ran = ran || worst[k] > 0;
+        if ((rejected >> k) & 1u) worst[k] = 0;
+      }
       // "the default stays on a tie" -- and the untuned library already runs meet / body / done from dsync_split_bytes on: there
       // candidate 2 is the default, so it is decided with the two swapped
       // (what dsync_split_bytes is compared with: the bytes one rank's kernel moves -- dsync.cpp launch)
@@ -2016,7 +2379,10 @@ int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
       if (split_is_default) std::swap(worst[0], worst[2]);
       int best = xmpi_tune_decide(worst.data(), (int)worst.size(), 0.03);
       if (split_is_default && (best == 0 || best == 2)) best = 2 - best;
-      if (best < 0) continue;
+      if (best < 0) {
+        if (ran) none_right = true;  // every schedule this collective has at this size is wrong here
+        continue;
+      }
       int k = 0;
       while (k + 1 < xmpi_comm::kTuneClasses && (per_rank >> (k + 9)) != 0) k++;
       for (int kk = k; kk < xmpi_comm::kTuneClasses && kk < k + 2; kk++) {  // this class and the one to the next measured size
@@ -2024,7 +2390,7 @@ int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
         c->tune_split[coll][kk] = (int8_t)cands[(size_t)best].split;
         c->tune_unroll[coll][kk] = (int8_t)cands[(size_t)best].unroll;
       }
-      if (bytes == 1024)  // below the smallest measured size: what won there
+      if (ri == 0)  // below the smallest measured size: what won there
         for (int kk = 0; kk < k; kk++) {
           c->tune_algo[coll][kk] = c->tune_algo[coll][k];
           c->tune_split[coll][kk] = c->tune_split[coll][k];
@@ -2037,16 +2403,21 @@ int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
       }
     }
   }
-  c->dsync_split_bytes = keep_split;
-  c->dsync_unroll = keep_unroll;
-  (void)heap_free(send);
-  (void)heap_free(recv);
+  c->tune_running = false;
+  {
+    std::lock_guard<std::mutex> g(c->coll_mu);
+    chk.close();
+  }
+  c->tune_check_ms = chk.spent_s * 1e3;
   if (rc != XMPI_OK) {
     c->tuned = keep_tuned;
     return rc;
   }
   c->tuned = true;
-  return xmpi_barrier(c);
+  note_rejections(c, "xmpi_tune", why, none_right);
+  rc = xmpi_barrier(c);
+  c->tune_ms = (now_seconds() - t_begin) * 1e3;
+  return rc;
 }
 
 // The step program a stepped kernel (sched.hip) runs on `rank` for ring channel `channel`, as text -- produced by the very

@@ -165,6 +165,18 @@ struct xmpi_comm {
   int8_t tune_unroll[4][kTuneClasses];
   bool tuned = false;
   long tune_mask = -1;  // candidates xmpi_tune may time (bit per candidate; see xmpi_set_param "tune_mask")
+  // The candidates by number: what tune_mask and tune_rejected_<collective> name bit by bit.
+  enum { CAND_FOLD = 0, CAND_FOLD_U2 = 1, CAND_SPLIT = 2, CAND_ZPUSH = 3, CAND_RING = 4, CAND_RHD = 5, CAND_LL = 6, CAND_RING_PUSH = 7,
+         CAND_RHD_PUSH = 8, CAND_TREE = 9, CAND_TREE_PUSH = 10, CAND_COUNT = 11 };
+  // Schedules whose ANSWERS were wrong on this machine (xmpi_tune and xmpi_init's self-check run every candidate once on patterned
+  // inputs whose sum is exact in any association, compare with the locally computed result and vote: wrong on ANY rank = rejected on
+  // EVERY rank).  A rejected schedule is never AUTO's choice again and a caller who names it is refused -- the same on every rank.
+  uint32_t tune_rejected[4] = {0, 0, 0, 0};
+  bool tune_running = false;     // xmpi_tune / the self-check are running candidates themselves (no refusal)
+  std::string rejected_why;      // which, where first, how wrong (also appended to degraded_why)
+  long selfcheck = -1;           // xmpi_init checks what untuned AUTO can reach; XMPI_SELFCHECK (-1: when the ranks sit on different GPUs)
+  double selfcheck_ms = -1;      // what it cost (-1: did not run)
+  double tune_ms = 0, tune_check_ms = 0;  // the last xmpi_tune: all of it / the part spent checking answers
   uint32_t* dsync_status = nullptr;          // pinned host word a kernel writes its first failure to ...
   uint32_t* dsync_status_dev = nullptr;      // ... and its device address
   int xcds = 0;                  // XCDs of this rank's GPU as a 1024-block probe grid found them (0: not probed)

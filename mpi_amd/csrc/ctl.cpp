@@ -78,6 +78,7 @@ size_t Ctl::layout_bytes(int size) {
   b += sizeof(BufDesc) * (size_t)size * 2;
   b += sizeof(RetireLog) * (size_t)size;
   b += sizeof(PubTable) * (size_t)size;
+  b += sizeof(TuneVote) * (size_t)size;
   b += 64 * (size_t)size * size;  // acked[reader][owner]
   return (b + 4095) / 4096 * 4096;
 }
@@ -300,6 +301,8 @@ int Ctl::join(const std::string& key, int rank, int size, const CtlConfig& cfg, 
   p += sizeof(RetireLog) * (size_t)size;
   c->pub_ = reinterpret_cast<PubTable*>(p);
   p += sizeof(PubTable) * (size_t)size;
+  c->vote_ = reinterpret_cast<TuneVote*>(p);
+  p += sizeof(TuneVote) * (size_t)size;
   c->acked_ = reinterpret_cast<std::atomic<uint64_t>*>(p);
   c->lanes_ = reinterpret_cast<char*>(base) + ctl_bytes;
 

@@ -19,7 +19,7 @@ constexpr int kMaxLanes = 4;
 constexpr int kMailEntries = 4;  // concurrent messages per ordered rank pair
 constexpr int kHostLaneSlots = 4;  // pieces of a host-resident payload in flight per mail entry (the host lanes, below)
 constexpr uint64_t kCtlMagic = 0x584D504943544C31ull;  // "XMPICTL1"
-constexpr uint32_t kCtlVersion = 9;  // layout of the block: bump with every change of the structs below
+constexpr uint32_t kCtlVersion = 10;  // layout of the block: bump with every change of the structs below
 
 struct alignas(64) Counter {
   std::atomic<uint64_t> v;
@@ -126,6 +126,15 @@ struct alignas(64) PubTable {
   PubEntry e[kPubRing];
 };
 
+// xmpi_tune / xmpi_init's self-check: every rank publishes a row -- mean time and number of WRONG bytes per candidate schedule --,
+// all meet at a barrier and read the same maxima.  Through this block and not through a collective: the vote judges the transports,
+// it must not ride on one of them.
+constexpr int kTuneCands = 16;
+struct alignas(64) TuneVote {
+  double us[kTuneCands];
+  uint64_t bad[kTuneCands];
+};
+
 struct CtlConfig {
   int32_t lanes;        // FIFO lanes per ordered pair for collectives
   int32_t fifo_depth;   // slots per collective pipe
@@ -174,6 +183,7 @@ class Ctl {
   BufDesc* desc(int r, uint64_t seq) { return &desc_[(size_t)r * 2 + (size_t)(seq & 1)]; }
   RetireLog* retired(int r) { return &retire_[r]; }
   PubTable* published(int r) { return &pub_[r]; }
+  TuneVote* vote(int r) { return &vote_[r]; }
   // how many of rank `owner`'s published entries rank `reader` has mapped (written by `reader` only)
   std::atomic<uint64_t>* acked(int reader, int owner) { return &acked_[((size_t)reader * size_ + owner) * 8]; }
   // Host lanes: host-resident payloads (what a Go program hands to Send: slices) travel between the processes of a node
@@ -213,6 +223,7 @@ class Ctl {
   BufDesc* desc_ = nullptr;
   RetireLog* retire_ = nullptr;
   PubTable* pub_ = nullptr;
+  TuneVote* vote_ = nullptr;
   std::atomic<uint64_t>* acked_ = nullptr;  // [reader][owner], one cache line each
   char* lanes_ = nullptr;
   bool creator_ = false;

@@ -900,8 +900,23 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
     // untuned: short messages go as {data, flag} lines (ll.hip) -- one one-way hop instead of two round trips
     if (algo == XMPI_ALGO_AUTO && c->zero_copy && send_bytes <= (size_t)std::max<long>(0, c->ll_bytes)) algo = XMPI_ALGO_LL;
   }
+  // A schedule whose ANSWERS xmpi_tune or xmpi_init's self-check found wrong on this machine (tune_rejected: the outcome of a vote,
+  // the same bits on every rank) is not run for a caller: AUTO never leads here (the table leaves it out, apply_rejections the untuned
+  // rules), so this is a caller -- or a table written by hand -- naming it.  Every rank refuses alike, before anything is lent,
+  // announced or moved.
+  const uint32_t rejected = (c->tune_running || coll < 0 || coll >= 4) ? 0u : c->tune_rejected[coll];
+  auto refuse = [&](int cand) {
+    static const char* const what[] = {"the one-kernel fold", "the one-kernel fold", "meet / body / done", "push-only", "the ring kernel", "the halving kernel",
+                                       "LL lines", "the ring kernel's push form", "the halving kernel's push form", "the tree kernel", "the tree kernel's push form"};
+    set_last_error(std::string(coll_name(coll)) + " by " + what[cand] + ": refused -- it gave wrong answers on this machine when the library checked it (xmpi_get_param "
+                   "\"tune_rejected_" + std::to_string(coll) + "\"; xmpi_degraded() says where)");
+    return XMPI_ERR_UNSUPPORTED;
+  };
   if (algo == XMPI_ALGO_LL) {
-    if (send_bytes <= kLLMaxPayload) return dsync_ll(c, coll, root, sendbuf, recvbuf, count, dtype, op, stream, blocking, capturing);
+    if (send_bytes <= kLLMaxPayload) {
+      if ((rejected >> xmpi_comm::CAND_LL) & 1u) return refuse(xmpi_comm::CAND_LL);
+      return dsync_ll(c, coll, root, sendbuf, recvbuf, count, dtype, op, stream, blocking, capturing);
+    }
     algo = XMPI_ALGO_ZCOPY;  // named, but too long for the slots: the fold (the same decision on every rank)
   }
   // the push forms of the stepped kernels: the same schedule, the data stored into the peer instead of loaded from it
@@ -921,6 +936,25 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
                        (sched_algo == XMPI_ALGO_RHD && coll == COLL_ALLREDUCE) ||
                        (sched_algo == XMPI_ALGO_TREE && (coll == COLL_BCAST || coll == COLL_REDUCE));
   const bool push = algo == XMPI_ALGO_ZPUSH;
+  if (rejected) {
+    const bool fold_no = (rejected >> xmpi_comm::CAND_FOLD) & 1u, split_no = (rejected >> xmpi_comm::CAND_SPLIT) & 1u;
+    if (stepped) {
+      const int cand = sched_algo == XMPI_ALGO_RING ? (sched_push ? xmpi_comm::CAND_RING_PUSH : xmpi_comm::CAND_RING)
+                       : sched_algo == XMPI_ALGO_RHD ? (sched_push ? xmpi_comm::CAND_RHD_PUSH : xmpi_comm::CAND_RHD)
+                                                     : (sched_push ? xmpi_comm::CAND_TREE_PUSH : xmpi_comm::CAND_TREE);
+      if ((rejected >> cand) & 1u) return refuse(cand);
+    } else if (push && (coll == COLL_ALLREDUCE || coll == COLL_REDUCE) && !capturing) {
+      if ((rejected >> xmpi_comm::CAND_ZPUSH) & 1u) return refuse(xmpi_comm::CAND_ZPUSH);
+    } else if (coll == COLL_BCAST) {  // (its fold is one kernel whatever the size)
+      if (fold_no) return refuse(xmpi_comm::CAND_FOLD);
+    } else {
+      // one kernel or meet / body / done is each rank's own choice (the two mix: dsync_begin / the meet kernel speak one protocol):
+      // a rank keeps to the one of the two that is right here
+      if (fold_no && split_no) return refuse(xmpi_comm::CAND_FOLD);
+      if (split_no) split_pref = 0;
+      else if (fold_no && c->dsync_res) split_pref = 1;
+    }
+  }
   RoctxRange range("xmpi:dsync %s algo=%s bytes=%zu epoch=%llu %s", coll_name(coll), algo_name(algo), send_bytes,
                    (unsigned long long)c->dsync_epoch + 1, blocking ? "blocking" : capturing ? "captured" : "enqueued");
 

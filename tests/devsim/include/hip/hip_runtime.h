@@ -47,8 +47,31 @@ struct KernelLaunch {
   const char* name;
   hipEvent_t ev_start, ev_stop;
   uint64_t gen_start = 0, gen_stop = 0;  // which record of the two events this launch is (0: the next one, when it runs)
+  unsigned tag = 0;  // kernels whose argument names a schedule and a form (the stepped kernels): 0x100 | schedule << 1 | push
 };
 void enqueue_kernel(hipStream_t stream, KernelLaunch&& k);
+
+// ---- DEVSIM_CORRUPT_FORM (runtime.cpp): a node that gets ONE kind of data access of ONE kernel wrong -------------------------------
+// The data accesses of the kernels that pass through a name a host compiler can redefine -- non-temporal stores (kdev.h stp<1>: the
+// fold kernels), the system-scope packet accessors (devsim/sys128.h: the stepped kernels, the split form's system-scope body) and
+// the 8-byte system-scope stores (LL lines) -- hand their value to corrupt_bits() first, which flips a bit when the running kernel,
+// the kind of access and the owner of the address are what the test asked for.  Off (one load of a flag) otherwise.
+enum { ACC_NT_STORE = 1, ACC_SYS_STORE = 2, ACC_SYS_LOAD = 4, ACC_FLAG_STORE = 8 };
+extern bool g_corrupt_armed;
+void corrupt_bits(const void* addr, void* value, unsigned bytes, int kind);
+template <typename T>
+inline void nt_store(T* p, T v) {
+  if (g_corrupt_armed) corrupt_bits(p, &v, (unsigned)sizeof(T), ACC_NT_STORE);
+  *p = v;
+}
+template <typename A>
+inline auto sched_tag(const A& a, int) -> decltype((void)a.sched, (void)a.push, 0u) {
+  return 0x100u | ((unsigned)a.sched << 1) | ((unsigned)a.push & 1u);
+}
+template <typename A>
+inline unsigned sched_tag(const A&, long) {
+  return 0u;
+}
 
 template <typename... KArgs, typename... Args>
 inline void launch(void (*kern)(KArgs...), dim3 grid, dim3 block, hipStream_t stream, hipEvent_t es, hipEvent_t ee, const char* name,
@@ -61,6 +84,7 @@ inline void launch(void (*kern)(KArgs...), dim3 grid, dim3 block, hipStream_t st
   k.ev_start = es;
   k.ev_stop = ee;
   k.lane = [kern, held]() { std::apply(kern, held); };
+  k.tag = (0u | ... | sched_tag(args, 0));
   enqueue_kernel(stream, std::move(k));
 }
 
@@ -87,7 +111,9 @@ template <typename T, typename V>
 DEVSIM_FLAG_FN void a_store(T* p, V v, int order) {
   sync_point();
   DEVSIM_FLAG_TOUCH(p, sizeof(T), 1);
-  __atomic_store_n(p, (T)v, st_order(order));
+  T w = (T)v;
+  if (sizeof(T) == 8 && g_corrupt_armed) corrupt_bits(p, &w, 8, ACC_FLAG_STORE);
+  __atomic_store_n(p, w, st_order(order));
 }
 template <typename T, typename V>
 DEVSIM_FLAG_FN T a_fetch_add(T* p, V v) {
@@ -179,6 +205,7 @@ DEVSIM_FLAG_FN double a_add_double(double* p, double v) {
 #define __hip_atomic_exchange(p, v, order, scope) ::devsim::a_exchange(p, v)
 #define __hip_atomic_compare_exchange_strong(p, expect, desired, so, fo, scope) ::devsim::a_cas(p, expect, desired)
 
+#define __builtin_nontemporal_store(v, p) ::devsim::nt_store(p, v)
 #define __builtin_amdgcn_s_sleep(n) ::devsim::yield_lane()
 #define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(order)
 #define __builtin_amdgcn_readfirstlane(v) (v)

@@ -669,6 +669,89 @@ void run_kernel(const KernelLaunch& k, int device) {
 
 }  // namespace
 
+// ---- DEVSIM_CORRUPT_FORM=<form>[@<device>] ------------------------------------------------------------------------------------------
+// A node on which ONE schedule gives wrong answers -- the things only a node can say ("Open": plain stores into
+// peer memory, system-scope loads / stores over a link, 8-byte lines into an uncached allocation of another device).  On <device>
+// (default 1) the named kernel's data accesses of the named kind THAT TOUCH ANOTHER DEVICE'S MEMORY get bit 0 of their first byte
+// flipped:
+//   fold       dsync_fold_kernel: its (non-temporal) stores into the peers' receive buffers -- the one-kernel fold, push-only, bcast
+//   split      dsync_body_kernel: the same stores of the split form's data kernel (run with XMPI_KERNEL_MODE=1: non-temporal stores at
+//              every size) -- its system-scope form (body_sys) is NOT affected: the ladder's first rung
+//   split_sys  dsync_body_kernel in both forms
+//   ring | rhd | tree             dsync_sched_kernel, pull form of that schedule: what it LOADS from a peer
+//   ring_push | rhd_push | tree_push    ... push form: what it STORES into a peer
+//   ll         the LL kernels (launched and agent): the lines they store into the peers' flag allocations (data half of a line)
+// Found by xmpi_tune / xmpi_init's self-check, or not at all: that is the test (tests/test_devsim.py).
+namespace {
+struct CorruptSpec {
+  bool on = false;
+  int device = 1, kinds = 0;
+  const char* names[3] = {nullptr, nullptr, nullptr};
+  unsigned scheds = 0;  // bit per DsyncSched value; 0 = the kernel carries no schedule
+  int push = -1;
+  bool ll_lines = false;
+  CorruptSpec() {
+    const char* e = getenv("DEVSIM_CORRUPT_FORM");
+    if (!e || !*e) return;
+    std::string f = e;
+    const size_t at = f.find('@');
+    if (at != std::string::npos) {
+      device = atoi(f.c_str() + at + 1);
+      f.resize(at);
+    }
+    auto sched = [&](unsigned mask, int p) {
+      names[0] = "dsync_sched_kernel";
+      scheds = mask;
+      push = p;
+      kinds = p ? ACC_SYS_STORE : ACC_SYS_LOAD;
+    };
+    if (f == "fold") names[0] = "dsync_fold_kernel", kinds = ACC_NT_STORE;
+    else if (f == "split") names[0] = "dsync_body_kernel", kinds = ACC_NT_STORE;
+    else if (f == "split_sys") names[0] = "dsync_body_kernel", kinds = ACC_NT_STORE | ACC_SYS_STORE;
+    else if (f == "ring" || f == "ring_push") sched(1u << 1 | 1u << 3, f == "ring_push");
+    else if (f == "rhd" || f == "rhd_push") sched(1u << 2, f == "rhd_push");
+    else if (f == "tree" || f == "tree_push") sched(1u << 4 | 1u << 5, f == "tree_push");
+    else if (f == "ll") names[0] = "ll_reduce_kernel", names[1] = "ll_copy_kernel", names[2] = "ll_agent_kernel", kinds = ACC_FLAG_STORE, ll_lines = true;
+    else {
+      fprintf(stderr, "devsim: DEVSIM_CORRUPT_FORM=%s: no such form\n", e);
+      abort();
+    }
+    on = true;
+  }
+};
+CorruptSpec& corrupt_spec() {
+  static CorruptSpec* s = new CorruptSpec;
+  return *s;
+}
+std::atomic<uint64_t> g_corrupted{0};
+}  // namespace
+bool g_corrupt_armed = corrupt_spec().on;
+
+void corrupt_bits(const void* addr, void* value, unsigned bytes, int kind) {
+  const CorruptSpec& cs = corrupt_spec();
+  const BlockRunner* r = tl_runner;
+  if (!(cs.kinds & kind) || !r || !r->k || !r->k->name || tl_device != cs.device) return;
+  bool named = false;
+  for (const char* n : cs.names) named = named || (n && strstr(r->k->name, n));
+  if (!named) return;
+  if (cs.scheds) {
+    const unsigned tag = r->k->tag;
+    if (!(tag & 0x100u) || !((cs.scheds >> ((tag & 0xffu) >> 1)) & 1u) || (int)(tag & 1u) != cs.push) return;
+  }
+  {
+    std::lock_guard<std::mutex> g(g_mem_mu);
+    const Alloc* a = find_alloc_locked(addr);
+    if (!a || !(a->kind == KIND_DEVICE || a->kind == KIND_IPC) || a->device == tl_device) return;  // (another device's memory only)
+    if (cs.ll_lines) {  // the LL slots of a flag allocation (kernels.h kLLOff = 1 MiB), not its flag words
+      if (!(a->flags & (hipDeviceMallocUncached | hipDeviceMallocFinegrained)) || (uintptr_t)addr - (uintptr_t)a->base < ((uintptr_t)1 << 20)) return;
+    }
+  }
+  (void)bytes;
+  *reinterpret_cast<unsigned char*>(value) ^= 1u;
+  if (g_corrupted.fetch_add(1) == 0 && env_long("DEVSIM_CORRUPT_VERBOSE", 0))
+    fprintf(stderr, "devsim[%d]: DEVSIM_CORRUPT_FORM: first flipped bit in %s on device %d\n", (int)getpid(), r->k->name, tl_device);
+}
+
 // ---- what the kernels call ---------------------------------------------------------------------------------------------------------
 void syncthreads() {
   BlockRunner* r = tl_runner;

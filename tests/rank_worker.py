@@ -64,8 +64,8 @@ def main():
     from tests import scenarios
     comm = xmpi.Comm(rank, size, args.get("device", -1), key)
     try:
-        if name != "degraded":  # nothing a test machine should refuse to map: a job that quietly ran a level down would still pass
-            assert comm.get_param("degraded") & 6 == 0, f"the job is degraded: {comm.degraded()}"
+        if name not in ("degraded", "corrupt"):  # nothing a test machine should refuse to map or get wrong: a job that quietly ran a level down would still pass
+            assert comm.get_param("degraded") & 14 == 0, f"the job is degraded: {comm.degraded()}"
         for k, v in args.get("params", {}).items():
             comm.set_param(k, v)
         for k, v in args.get("expect_params", {}).items():

@@ -196,6 +196,61 @@ def test_a_mapping_the_driver_refuses_degrades_the_job_not_kills_it(devsim_lib, 
     run_ranks("degraded", size, {"expect": level, "why": why}, timeout=600, env=dict(env, XMPI_INIT_TIMEOUT_S="20", XMPI_TIMEOUT_S="30"))
 
 
+# ---- a node on which one schedule gives WRONG ANSWERS --------------------------------------------------------------------------------
+CORRUPT = [
+    # (what the node gets wrong, rejected candidates per collective 0 allreduce / 1 allgather / 2 bcast / 3 reduce, extra scenario arguments, extra environment)
+    # the one-kernel fold's stores into peer memory: the fold in both unrolls, push-only (its two kernels ARE that kernel) -- the table
+    # says "split" wherever it said "the fold"; bcast takes the tree kernel
+    ("fold", {0: ["fold", "fold2", "zpush"], 1: ["fold"], 2: ["fold"], 3: ["fold", "zpush"]}, {"why": ["allreduce: fold (one kernel) gives wrong answers", "bcast: fold"], "max_bytes": 1 << 20}, {}),  # (1 MiB: bcast's fold beyond zc_bcast_push_bytes, where every rank forwards)
+    # the split form's data kernel with ordinary (cached, non-temporal) stores: the ladder's FIRST rung -- its system-scope form is
+    # right, takes over (degraded bit 1), and nothing is rejected
+    ("split", {}, {"level": 8 | 1, "why": ["its system-scope data kernel is right and takes over"], "params_after": {"body_sys": 1}}, {"XMPI_KERNEL_MODE": "1"}),
+    # ... in both forms: split leaves every table and the untuned rule (dsync_split_bytes 0)
+    ("split_sys", {0: ["split"], 1: ["split"], 3: ["split"]}, {"why": ["its system-scope data kernel does too"], "params_after": {"body_sys": 0, "dsync_split_bytes": 0}},
+     {"XMPI_KERNEL_MODE": "1"}),
+    ("ring", {0: ["ring"], 1: ["ring"]}, {}, {}),            # what the ring kernel LOADS over a link (pull form)
+    ("ring_push", {0: ["ring_push"], 1: ["ring_push"]}, {}, {}),  # ... STORES over a link (push form): the pull form stays
+    ("rhd_push", {0: ["rhd_push"]}, {}, {}),
+    ("tree", {2: ["tree"], 3: ["tree"]}, {}, {}),
+    # LL lines into another device's flag allocation (bcast's lines come from the root, device 0 -- right here, but it is ONE mechanism:
+    # wrong for one collective, trusted for none): no LL for untuned AUTO either
+    ("ll", {0: ["ll"], 1: ["ll"], 2: ["ll"], 3: ["ll"]}, {"params_after": {"ll_bytes": 0, "agent_ll": 0}}, {}),
+]
+
+
+@pytest.mark.parametrize("form,rejected,extra,env", CORRUPT, ids=[c[0] for c in CORRUPT])
+def test_the_tuner_drops_a_schedule_that_gives_wrong_answers_here(devsim_lib, form, rejected, extra, env):
+    """DEVSIM_CORRUPT_FORM: device 1 flips a bit in that kernel's data accesses to other devices' memory.  xmpi_tune checks every
+    candidate's answer (patterned inputs, the expected result computed locally, a job-wide vote) BEFORE it believes its time: exactly
+    the schedules that run that kernel are rejected -- on every rank, by name, with the reason readable --, AUTO stays oracle-exact,
+    a rejected schedule named by a caller is refused on every rank alike, everything else still runs (tests/scenarios.py sc_corrupt)"""
+    run_ranks("corrupt", 4, dict({"rejected": {str(k): v for k, v in rejected.items()}}, **extra), timeout=600,
+              env=dict({"DEVSIM_CORRUPT_FORM": form, "XMPI_SELFCHECK": "0"}, **env))
+
+
+SELFCHECK = [
+    # an UNTUNED job (nobody calls xmpi_tune): xmpi_init's self-check runs what untuned AUTO can reach on patterned inputs.  LL lines
+    # wrong: no LL for AUTO (the fold takes the small messages)
+    ("ll", {0: ["ll"], 1: ["ll"], 2: ["ll"], 3: ["ll"]}, {"level": 8, "params_after": {"ll_bytes": 0, "agent_ll": 0}}, {}),
+    # split wrong with ordinary stores: the system-scope data kernel takes over
+    ("split", {}, {"level": 8 | 1, "params_after": {"body_sys": 1}, "why": ["xmpi_init self-check", "takes over"]}, {"XMPI_KERNEL_MODE": "1"}),
+    ("split_sys", {0: ["split"]}, {"level": 8, "params_after": {"dsync_split_bytes": 0}}, {"XMPI_KERNEL_MODE": "1"}),
+    # the one-kernel fold wrong: an untuned job has no table to route round it -- the ranks meet on the host (level 2), every collective right
+    ("fold", {0: ["fold"], 1: ["fold"], 2: ["fold"], 3: ["fold"]}, {"level": 8 | 2, "why": ["the ranks meet on the host"]}, {}),
+]
+
+
+@pytest.mark.parametrize("form,rejected,extra,env", SELFCHECK, ids=[c[0] for c in SELFCHECK])
+def test_init_checks_what_untuned_auto_can_reach(devsim_lib, form, rejected, extra, env):
+    """the same node, a job that never tunes: ranks on different GPUs => xmpi_init runs the self-check by default (XMPI_SELFCHECK)"""
+    run_ranks("corrupt", 4, dict({"rejected": {str(k): v for k, v in rejected.items()}, "tune": 0}, **extra), timeout=600,
+              env=dict({"DEVSIM_CORRUPT_FORM": form}, **env))
+
+
+def test_the_selfcheck_runs_where_ranks_sit_on_different_gpus_and_finds_nothing_on_a_healthy_node(devsim_lib):
+    run_ranks("corrupt", 3, {"rejected": {}, "tune": 0, "params_after": {"selfcheck": 1}, "expect_selfcheck": 1}, timeout=600)
+
+
 def test_nothing_degraded_on_a_healthy_node(devsim_lib):
     run_ranks("degraded", 3, {"expect": 0, "why": ""}, timeout=600)
 

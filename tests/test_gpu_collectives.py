@@ -274,6 +274,18 @@ def test_library_tuner_from_the_environment():
     run_ranks("tune", 4, {"tuned_by_init": True}, timeout=600, env={"XMPI_AUTOTUNE_BYTES": str(2 << 20)})
 
 
+@pytest.mark.parametrize("size", [2, 8])
+def test_init_selfcheck_on_the_gpu(size):
+    """XMPI_SELFCHECK=1 (the default only where ranks sit on different GPUs): xmpi_init runs what untuned AUTO can reach -- LL lines,
+    the one-kernel fold, meet / body / done, the other collectives' folds -- on patterned inputs and compares with the locally
+    computed result before the first caller's data goes through; on this machine nothing is rejected, nothing degraded, the cost is
+    readable, and every collective is exact afterwards (tests/scenarios.py sc_corrupt with nothing corrupt; the fault injections run
+    on virtual devices in the CPU suite)"""
+    outs = run_ranks("corrupt", size, {"rejected": {}, "tune": 0, "params_after": {"selfcheck": 1}, "report_selfcheck": 1}, timeout=300,
+                     env={"XMPI_SELFCHECK": "1"})
+    assert any("init_selfcheck_us" in o for o in outs), outs[0][-500:]
+
+
 def test_library_tuner_threads():
     """ranks that meet on the host have one schedule: nothing to tune, AUTO unchanged"""
     run_threads("tune", 3)
