@@ -700,6 +700,9 @@ static int init_selfcheck(xmpi_comm* c) {
   }
   if (rc != XMPI_OK) return rc;
   XMPI_TRACE_STEP(c->rank, "self-check: buffers ready");
+  // (what the job's first xmpi_malloc and first kernel pay anyway -- the first arena allocated, exported, mapped by every peer;
+  // the code object loaded -- reported apart from the checks themselves)
+  c->selfcheck_setup_ms = (now_seconds() - t_begin) * 1e3;
   const std::vector<TuneCand> cands = tune_candidates(c);
   c->tune_running = true;
   std::string why;
@@ -775,6 +778,12 @@ static int init_selfcheck(xmpi_comm* c) {
 }  // namespace xmpi
 
 using namespace xmpi;
+
+// XMPI_ERR_PEER out of a call that waited for a peer: say which peer, if the watchdog knows (ctl.cpp check_peers)
+static int why_peer(xmpi_comm* c, int rc, const char* what) {
+  if (rc == XMPI_ERR_PEER && c->ctl) set_last_error(std::string(what) + ": " + c->ctl->abort_reason());
+  return rc;
+}
 
 extern "C" {
 
@@ -1067,6 +1076,13 @@ int xmpi_init(int rank, int size, int device, const char* job_key, xmpi_comm** o
   XMPI_TRACE_STEP(rank, "init: connecting flag pages");
   rc = dsync_connect(c, timeout > 0 ? timeout : 3600.0);
   if (rc != XMPI_OK) return fail(rc);
+  // the helper thread: maps what peers register, and watches over their processes -- unless one of them cannot be seen from here
+  // even now, when it certainly lives (ranks in different pid namespaces sharing /dev/shm: no way to ask, so nobody asks)
+  c->watchdog_ms = std::max<long>(0, env_long("XMPI_WATCHDOG_MS", 50));
+  for (int p = 0; p < size && c->watchdog_ms > 0; p++)
+    if (p != rank && ctl->peer_gone(p)) c->watchdog_ms = 0;
+  ctl->set_watch(c->watchdog_ms > 0);
+  dsync_start_helper(c);
   XMPI_TRACE_STEP(rank, "init: final barrier");
   c->dsync_unroll = env_long("XMPI_DSYNC_UNROLL", c->dsync_sharers > 1 ? 1 : 2);
   // ranks sharing a GPU: fewer, longer blocks (8 processes on one MI355X: 4 MiB 170 -> 90 us, 16 MiB 231 -> 169 us);
@@ -1273,7 +1289,7 @@ int xmpi_send(xmpi_comm* c, const void* buf, size_t count, xmpi_dtype dtype, int
     set_last_error("send: bad dtype / destination / buffer");
     return XMPI_ERR_ARG;
   }
-  return p2p_send(c, buf, count * es, (int)dtype, dest, tag);
+  return why_peer(c, p2p_send(c, buf, count * es, (int)dtype, dest, tag), "send");
 }
 
 int xmpi_send_nowait(xmpi_comm* c, const void* buf, size_t count, xmpi_dtype dtype, int dest, int tag) {
@@ -1283,13 +1299,13 @@ int xmpi_send_nowait(xmpi_comm* c, const void* buf, size_t count, xmpi_dtype dty
     set_last_error("send: bad dtype / destination / buffer");
     return XMPI_ERR_ARG;
   }
-  return p2p_send(c, buf, count * es, (int)dtype, dest, tag, /*wait_ack=*/false);
+  return why_peer(c, p2p_send(c, buf, count * es, (int)dtype, dest, tag, /*wait_ack=*/false), "send");
 }
 
 int xmpi_wait(xmpi_comm* c, int dest, int tag) {
   XMPI_ENTER(c);
   if (dest < 0 || dest >= c->size) return XMPI_ERR_ARG;
-  return p2p_wait(c, dest, tag);
+  return why_peer(c, p2p_wait(c, dest, tag), "wait");
 }
 
 int xmpi_recv(xmpi_comm* c, void* buf, size_t capacity, xmpi_dtype dtype, int src, int tag, size_t* got) {
@@ -1302,7 +1318,7 @@ int xmpi_recv(xmpi_comm* c, void* buf, size_t capacity, xmpi_dtype dtype, int sr
   size_t got_bytes = 0;
   int rc = p2p_recv(c, buf, capacity * es, (int)dtype, src, tag, &got_bytes);
   if (got) *got = got_bytes / es;
-  return rc;
+  return why_peer(c, rc, "receive");
 }
 
 int xmpi_probe(xmpi_comm* c, int src, int tag, size_t* count, xmpi_dtype* dtype) {
@@ -1505,6 +1521,7 @@ int xmpi_stream_sync(xmpi_comm* c, void* stream) {
   std::lock_guard<std::mutex> g(c->coll_mu);
   const int prc = c->dsync_ok ? dsync_p2p_reap(c) : XMPI_OK;  // the stream-ordered sends / receives that have completed
   const int crc = dsync_check(c);
+  if (crc == XMPI_OK && prc == XMPI_ERR_PEER) set_last_error("send / receive: the job was aborted while the kernel waited: " + c->ctl->abort_reason());
   return crc != XMPI_OK ? crc : prc;
 }
 
@@ -1866,6 +1883,8 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
   if (n == "piece_bytes") return c->piece_bytes;
   if (n == "copy_engine") return c->copy_engine;
   if (n == "timeout_s") return c->timeout_s;
+  if (n == "watchdog_ms") return c->watchdog_ms;
+  if (n == "dead_rank") return c->ctl->dead_rank();  // the first rank whose process the watchdog found gone; -1 = none
   if (n == "zero_copy") return c->zero_copy;
   if (n == "heap_arenas" || n == "heap_reserved" || n == "heap_in_use") {
     size_t a = 0, r = 0, u = 0;
@@ -1939,6 +1958,7 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
   if (n == "selfcheck") return c->selfcheck;
   if (n == "init_selfcheck_ms") return c->selfcheck_ms < 0 ? -1 : (long)(c->selfcheck_ms + 0.999);  // xmpi_init's self-check: -1 = did not run
   if (n == "init_selfcheck_us") return c->selfcheck_ms < 0 ? -1 : (long)(c->selfcheck_ms * 1e3);
+  if (n == "init_selfcheck_setup_us") return c->selfcheck_ms < 0 ? -1 : (long)(c->selfcheck_setup_ms * 1e3);  // ... of which: its buffers (the job's first arena, the first kernel's code object)
   if (n == "tune_us") return (long)(c->tune_ms * 1e3);              // the last xmpi_tune, all of it
   if (n == "tune_check_us") return (long)(c->tune_check_ms * 1e3);  // ... the part spent checking answers (expected results, poison, compare)
   if (n.rfind("tune_", 0) == 0) {  // tune_<algo|split|unroll>_<collective 0..3>_<size class>: the table of xmpi_tune

@@ -176,6 +176,7 @@ struct xmpi_comm {
   std::string rejected_why;      // which, where first, how wrong (also appended to degraded_why)
   long selfcheck = -1;           // xmpi_init checks what untuned AUTO can reach; XMPI_SELFCHECK (-1: when the ranks sit on different GPUs)
   double selfcheck_ms = -1;      // what it cost (-1: did not run)
+  double selfcheck_setup_ms = 0; // ... of which: its buffers (the first arena: allocated, exported, mapped by every peer)
   double tune_ms = 0, tune_check_ms = 0;  // the last xmpi_tune: all of it / the part spent checking answers
   uint32_t* dsync_status = nullptr;          // pinned host word a kernel writes its first failure to ...
   uint32_t* dsync_status_dev = nullptr;      // ... and its device address
@@ -248,6 +249,7 @@ struct xmpi_comm {
   long piece_bytes = 0;  // 0 = choose per operation
   long copy_engine = 0;  // 0 = hipMemcpyAsync (SDMA / runtime blit), 1 = xmpi copy kernel
   long timeout_s = 0;  // no-progress limit of steady-state waits in seconds; 0 = for ever (the reference blocks indefinitely)
+  long watchdog_ms = 50;  // how often the helper thread asks whether the peers' processes still exist (0 = never); XMPI_WATCHDOG_MS
   double last_run_us = 0, last_sync_us = 0;  // timing of the most recent collective (diagnostic)
 
   // scratch
@@ -318,6 +320,7 @@ void stream_release(int device, hipStream_t s);
 int dsync_prepare(xmpi_comm* c);
 int dsync_connect(xmpi_comm* c, double timeout_s);
 void dsync_finalize(xmpi_comm* c);
+void dsync_start_helper(xmpi_comm* c);
 void dsync_stop_helper(xmpi_comm* c);
 void dsync_service(xmpi_comm* c);
 bool dsync_usable(const xmpi_comm* c);

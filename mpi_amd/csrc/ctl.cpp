@@ -70,6 +70,49 @@ static uint64_t proc_start_time(int pid) {
   return start;
 }
 
+// is process `pid` still the one that started at `start` (and not a zombie waiting to be reaped)?
+static bool process_alive(int pid, uint64_t start) {
+  char path[64], buf[1024];
+  snprintf(path, sizeof path, "/proc/%d/stat", pid);
+  FILE* f = fopen(path, "r");
+  if (!f) return errno != ENOENT && errno != ESRCH;  // (no /proc to ask: assume it lives -- never a false alarm)
+  const size_t n = fread(buf, 1, sizeof buf - 1, f);
+  fclose(f);
+  buf[n] = 0;
+  const char* p = strrchr(buf, ')');
+  if (!p || !p[1] || !p[2]) return true;
+  const char state = p[2];
+  if (state == 'Z' || state == 'X' || state == 'x') return false;  // exited, not yet reaped by its parent
+  return start == 0 || proc_start_time(pid) == start;  // (a recycled pid is another process)
+}
+
+bool Ctl::peer_gone(int r) {
+  if (r < 0 || r >= size_ || r == rank_) return false;
+  RankInfo* ri = &ranks_[r];
+  const int st = ri->state.load(std::memory_order_acquire);
+  if (st < 1 || st >= 3) return false;  // never joined (the bootstrap's clock covers that) / left properly
+  if (ri->pid == (int32_t)getpid()) return false;  // a thread of this process
+  return !process_alive(ri->pid, ri->start_time);
+}
+
+int Ctl::check_peers() {
+  for (int r = 0; r < size_; r++)
+    if (peer_gone(r)) {
+      int32_t none = 0;
+      if (hdr_->dead_rank.compare_exchange_strong(none, r + 1, std::memory_order_acq_rel))
+        fprintf(stderr, "xmpi: rank %d: the process of rank %d (pid %d) is gone: the job is aborted\n", rank_, r, (int)ranks_[r].pid);
+      set_abort(XMPI_ERR_PEER);
+      return r;
+    }
+  return -1;
+}
+
+std::string Ctl::abort_reason() {
+  const int d = dead_rank();
+  if (d >= 0 && d < size_) return "the process of rank " + std::to_string(d) + " (pid " + std::to_string(ranks_[d].pid) + ") is gone";
+  return "a peer rank aborted the job";
+}
+
 size_t Ctl::layout_bytes(int size) {
   size_t b = sizeof(CtlHeader);
   b += sizeof(RankInfo) * (size_t)size;
@@ -205,6 +248,7 @@ int Ctl::join(const std::string& key, int rank, int size, const CtlConfig& cfg, 
     h->cfg = cfg;
     h->cfg.host_lane_bytes = lanes_ok ? lane_bytes_for(size) : 0;
     h->abort_code.store(0);
+    h->dead_rank.store(0);
     h->bar_count.store(0);
     h->bar_gen.store(0);
     h->magic.store(kCtlMagic, std::memory_order_release);
@@ -317,6 +361,7 @@ int Ctl::join(const std::string& key, int rank, int size, const CtlConfig& cfg, 
     return XMPI_ERR_BOOTSTRAP;
   }
   me->pid = (int32_t)getpid();
+  me->start_time = proc_start_time(getpid());
   me->device = -1;
   me->state.store(1, std::memory_order_release);
   const double left = timeout_s - (now_seconds() - t0);
@@ -354,6 +399,7 @@ void Ctl::unlink_name() {
 
 int Ctl::wait_all_state(int state, double timeout_s) {
   const double t0 = now_seconds();
+  double looked = t0;
   Backoff bo;
   for (;;) {
     bool all = true;
@@ -364,7 +410,12 @@ int Ctl::wait_all_state(int state, double timeout_s) {
       }
     if (all) return XMPI_OK;
     if (aborted()) return XMPI_ERR_PEER;
-    if (now_seconds() - t0 > timeout_s) return XMPI_ERR_TIMEOUT;
+    const double t = now_seconds();
+    if (t - t0 > timeout_s) return XMPI_ERR_TIMEOUT;
+    if (watch_ && t - looked > 0.05) {  // (a rank that waits for a peer that is gone: an error now, not when a clock runs out)
+      looked = t;
+      (void)check_peers();
+    }
     bo.pause();
   }
 }
@@ -379,11 +430,17 @@ int Ctl::barrier(double timeout_s, Backoff* ext) {
     return XMPI_OK;
   }
   const double t0 = now_seconds();
+  double looked = t0;
   Backoff own;
   Backoff& bo = ext ? *ext : own;
   while (hdr_->bar_gen.load(std::memory_order_acquire) == gen) {
     if (aborted()) return XMPI_ERR_PEER;
-    if (now_seconds() - t0 > timeout_s) return XMPI_ERR_TIMEOUT;
+    const double t = now_seconds();
+    if (t - t0 > timeout_s) return XMPI_ERR_TIMEOUT;
+    if (watch_ && t - looked > 0.05) {
+      looked = t;
+      (void)check_peers();
+    }
     bo.pause();
   }
   return XMPI_OK;

@@ -19,7 +19,7 @@ constexpr int kMaxLanes = 4;
 constexpr int kMailEntries = 4;  // concurrent messages per ordered rank pair
 constexpr int kHostLaneSlots = 4;  // pieces of a host-resident payload in flight per mail entry (the host lanes, below)
 constexpr uint64_t kCtlMagic = 0x584D504943544C31ull;  // "XMPICTL1"
-constexpr uint32_t kCtlVersion = 10;  // layout of the block: bump with every change of the structs below
+constexpr uint32_t kCtlVersion = 11;  // layout of the block: bump with every change of the structs below
 
 struct alignas(64) Counter {
   std::atomic<uint64_t> v;
@@ -80,6 +80,7 @@ struct alignas(64) RankInfo {
   char maps_why[96];        // the first mapping this rank could not make, in words ("" = none)
   int64_t ll_choice;        // the LL limit this rank would choose from what IT sees (ranks on its GPU, its environment): the job
                             // takes the smallest -- LL or fold is a protocol choice every rank must make alike
+  uint64_t start_time;      // /proc/<pid>/stat starttime of the process that joined as this rank (with pid: is it still THAT process?)
 };
 constexpr int32_t kMapsWindows = 1, kMapsFlags = 2;
 
@@ -153,6 +154,7 @@ struct alignas(64) CtlHeader {
   uint64_t creator_start;  // /proc/<pid>/stat starttime of the creator (stale-segment check)
   CtlConfig cfg;
   std::atomic<int32_t> abort_code;  // != 0: some rank failed; everybody stops waiting
+  std::atomic<int32_t> dead_rank;   // rank + 1 of the first rank whose PROCESS was found gone (peer_gone below); 0 = none
   alignas(64) std::atomic<uint32_t> bar_count;
   alignas(64) std::atomic<uint32_t> bar_gen;
 };
@@ -205,6 +207,15 @@ class Ctl {
     hdr_->abort_code.compare_exchange_strong(z, code);
   }
   int aborted() const { return hdr_->abort_code.load(std::memory_order_acquire); }
+  // The process that joined as rank r no longer exists (it exited, crashed or was killed) and never left the job properly
+  // (RankInfo.state 3, xmpi_finalize).  What the reference's peers learn from their sockets at once (network.go:555,611,623: a lost
+  // connection is an I/O error in Send / Receive) has to be looked for here: nobody closes a shared-memory block on a crash.
+  bool peer_gone(int r);
+  // the first rank found gone, or -1; check_peers looks at every other rank and raises the job's abort flag for the first one gone
+  int dead_rank() const { return hdr_->dead_rank.load(std::memory_order_acquire) - 1; }
+  int check_peers();
+  void set_watch(bool on) { watch_ = on; }  // barrier / wait_all_state look for dead peers while they wait (xmpi_init: XMPI_WATCHDOG_MS > 0)
+  std::string abort_reason();  // "rank 3's process (pid 1234) is gone" / "a peer rank aborted the job"
   // rank 0 removes the name (the mapping stays valid until every rank unmaps)
   void unlink_name();
 
@@ -227,6 +238,7 @@ class Ctl {
   std::atomic<uint64_t>* acked_ = nullptr;  // [reader][owner], one cache line each
   char* lanes_ = nullptr;
   bool creator_ = false;
+  bool watch_ = false;
 };
 
 double now_seconds();

@@ -279,20 +279,40 @@ int dsync_connect(xmpi_comm* c, double timeout_s) {
   c->dsync_base = base;
   c->dsync_tag = base + 1;
   c->dsync_ok = true;
-  // A rank must map what its peers register even while its own threads are blocked somewhere the library cannot
-  // see (a hipStreamSynchronize of the caller's, a long computation): a helper looks once a millisecond -- one load
-  // per peer when there is nothing to do.  (Every wait loop of the library looks as well, so inside the library
-  // the answer comes within microseconds.)
+  return XMPI_OK;
+}
+
+// The rank's helper thread (xmpi_init starts it for every job of more than one process):
+//  * A rank must map what its peers register even while its own threads are blocked somewhere the library cannot see (a
+//    hipStreamSynchronize of the caller's, a long computation): the helper looks once a millisecond -- one load per peer when
+//    there is nothing to do.  (Every wait loop of the library looks as well, so inside the library the answer comes within
+//    microseconds.)
+//  * A peer whose PROCESS is gone is an error at once, with default settings (XMPI_TIMEOUT_S = 0: wait for ever): every
+//    watchdog_ms (50) the helper asks the kernel whether the processes that joined as the other ranks still exist (pid + start
+//    time, ctl.cpp peer_gone) and raises the job's abort flag for the first one that does not -- every host wait loop and every
+//    waiting kernel (kdev.h spin_until, the LL and receive agents) polls that flag and comes back with XMPI_ERR_PEER.  What the
+//    reference's peers get from their sockets (network.go:555,611,623: a lost connection fails Send / Receive immediately).
+void dsync_start_helper(xmpi_comm* c) {
+  if (c->size < 2 || c->dsync_helper.joinable()) return;
+  bool other_process = false;
+  for (int p = 0; p < c->size; p++) other_process = other_process || c->ctl->info(p)->pid != (int32_t)getpid();
+  const bool watch = c->watchdog_ms > 0 && other_process;
+  if (!c->dsync_ok && !watch) return;
   c->dsync_helper_stop = false;
-  c->dsync_helper = std::thread([c] {
+  c->dsync_helper = std::thread([c, watch] {
     (void)hipSetDevice(c->device);
+    const long every = std::max<long>(1, c->watchdog_ms);
+    double next_look = now_seconds() + (double)every * 1e-3;
     while (!c->dsync_helper_stop.load(std::memory_order_acquire)) {
       dsync_service(c);
+      if (watch && now_seconds() >= next_look) {
+        if (!c->ctl->aborted()) (void)c->ctl->check_peers();
+        next_look = now_seconds() + (double)every * 1e-3;
+      }
       timespec ts{0, 1000000};
       nanosleep(&ts, nullptr);
     }
   });
-  return XMPI_OK;
 }
 
 void dsync_stop_helper(xmpi_comm* c) {
@@ -467,7 +487,7 @@ int await_acks(xmpi_comm* c, uint64_t pub_index) {
       if (p != c->rank && c->ctl->acked(p, c->rank)->load(std::memory_order_acquire) < pub_index) all = false;
     if (all) return XMPI_OK;
     if (c->ctl->aborted()) {
-      set_last_error("a peer rank aborted the job");
+      set_last_error(c->ctl->abort_reason());
       return XMPI_ERR_PEER;
     }
     if (now_seconds() - t0 > wait_limit(c)) {
@@ -1431,7 +1451,7 @@ int p2p_status_to_rc(uint64_t st) {
       set_last_error("receive: the sender's buffer is not mapped here");
       return XMPI_ERR_STATE;
     }
-    set_last_error("send / receive: the job was aborted while the kernel waited");
+    set_last_error("send / receive: the job was aborted while the kernel waited");  // (callers with the communicator at hand say why: abort_reason)
     return XMPI_ERR_PEER;
   }
   if (st == 6) set_last_error("receive: the message does not fit the buffer");
@@ -1598,7 +1618,7 @@ int dsync_check(xmpi_comm* c) {
                    "xcd_done_mask); set XMPI_BODY_SYS=1");
     rc = XMPI_ERR_STATE;
   } else {
-    set_last_error("collective: the job was aborted while the kernel waited for a peer");
+    set_last_error("collective: the job was aborted while the kernel waited for a peer: " + c->ctl->abort_reason());
   }
   c->ctl->set_abort(rc);
   return rc;

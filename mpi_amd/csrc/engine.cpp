@@ -578,7 +578,7 @@ struct Exec {
         continue;
       }
       if (c->ctl->aborted()) {
-        set_last_error("a peer rank aborted the job");
+        set_last_error(c->ctl->abort_reason());
         return XMPI_ERR_PEER;
       }
       if (c->timeout_s > 0 && now_seconds() - last_progress > (double)c->timeout_s) {

@@ -2563,37 +2563,60 @@ def sc_degraded(comm, args):
 
 def sc_peer_dies(comm, args):
     """The last rank leaves without a word (os._exit after a collective that worked) -- a process that crashed.  The reference's
-    peers see their TCP connection fail (network.go:518-571: Send / Receive return the error); here nobody is told, so every wait
-    has a clock: the survivors' next collective and a Receive from the dead rank must come back with an ERROR within the no-progress
-    limit (XMPI_TIMEOUT_S), the kernels that were waiting must have ended (the device is usable afterwards), nothing hangs."""
+    peers see their TCP connection fail at once (network.go:555,611,623: Send / Receive return the I/O error); here nobody closes
+    a shared-memory block on a crash, so the library LOOKS: every rank's helper thread asks every 50 ms whether the processes that
+    joined as the other ranks still exist and raises the job's abort flag, which every host wait loop and every waiting kernel
+    polls.  `no_timeout`: with DEFAULT settings (XMPI_TIMEOUT_S unset = wait for ever) the survivors' next collective -- one kernel,
+    meet / body / done, the ring kernel, LL lines launched or by the lingering agent -- or Receive (blocking or stream-ordered) from
+    the dead rank comes back with XMPI_ERR_PEER within a second, naming the rank; the kernels that were waiting have ended (the
+    device is usable afterwards), nothing hangs.  Without `no_timeout` (the test sets XMPI_TIMEOUT_S and XMPI_WATCHDOG_MS=0): the
+    same through the no-progress limit alone."""
     import time
     rank, size = comm.rank(), comm.size()
     allreduce_case(comm, xmpi.I64, 4099, xmpi.ALGO_AUTO, exact=True)
+    what = args.get("what", "allreduce")
+    if what == "ll_agent":  # a blocking LL collective that worked: its agent lingers behind it on every rank
+        comm.set_param("ll_agent_us", 200000)
+        small = comm.alloc(512 * 8)
+        comm.fill(small, 512, xmpi.I64, xmpi.PAT_INDEX, rank)
+        comm.allreduce(small, small, 512, xmpi.I64, xmpi.SUM, xmpi.ALGO_LL)
     comm.barrier()
     if rank == size - 1:
         sys.stdout.flush()
         os._exit(0)
     limit = comm.get_param("timeout_s")
-    assert 0 < limit <= 30, "the test sets XMPI_TIMEOUT_S"
+    if args.get("no_timeout"):
+        assert limit == 0 and comm.get_param("watchdog_ms") > 0, "default settings: no no-progress limit, the watchdog on"
+    else:
+        assert 0 < limit <= 30 and comm.get_param("watchdog_ms") == 0, "the test sets XMPI_TIMEOUT_S and turns the watchdog off"
     buf, out = comm.alloc(4099 * 8), comm.alloc(4099 * 8)
     comm.fill(buf, 4099, xmpi.I64, xmpi.PAT_INDEX, rank)
     t0 = time.time()
-    what = args.get("what", "allreduce")
     try:
         if what == "recv":
             comm.recv(out, 4099, xmpi.I64, size - 1, 3)
+        elif what == "recv_on_stream":
+            comm.recv_on_stream(out, 4099, xmpi.I64, size - 1, 3)
+            comm.stream_sync()
         else:
             comm.set_param("dsync_split_bytes", 1 if what == "split" else 0)
-            comm.set_param("ll_bytes", comm.get_param("ll_max_bytes") if what == "ll" else 0)
-            n = 512 if what == "ll" else 4099
-            comm.allreduce(buf, out, n, xmpi.I64, xmpi.SUM, {"ring": xmpi.ALGO_RING, "ll": xmpi.ALGO_LL}.get(what, xmpi.ALGO_ZCOPY))
+            comm.set_param("ll_bytes", comm.get_param("ll_max_bytes") if what in ("ll", "ll_agent") else 0)
+            if what == "ll":
+                comm.set_param("agent_ll", 0)
+            n = 512 if what in ("ll", "ll_agent") else 4099
+            comm.allreduce(buf, out, n, xmpi.I64, xmpi.SUM, {"ring": xmpi.ALGO_RING, "ll": xmpi.ALGO_LL, "ll_agent": xmpi.ALGO_LL}.get(what, xmpi.ALGO_ZCOPY))
     except xmpi.XmpiError as e:
         took = time.time() - t0
-        assert took < 3 * limit + 10, f"{what}: the error took {took:.0f} s with a limit of {limit} s"
+        if args.get("no_timeout"):
+            assert took < args.get("within", 1.0), f"{what}: the error took {took:.2f} s"
+            assert e.code == xmpi.ERR_PEER, e
+            assert comm.get_param("dead_rank") == size - 1, comm.get_param("dead_rank")
+        else:
+            assert took < 3 * limit + 10, f"{what}: the error took {took:.0f} s with a limit of {limit} s"
         # the device still works: a local kernel on the same buffers, checked
         comm.fill(out, 16, xmpi.I64, xmpi.PAT_INDEX, 7)
         assert out.download(np.int64, 16).tobytes() == oracle.fill(16, xmpi.I64, xmpi.PAT_INDEX, 7).tobytes()
-        print(f"rank {rank}/{size} peer_dies[{what}]: ok (error after {took:.1f} s: {str(e)[:100]})")
+        print(f"rank {rank}/{size} peer_dies[{what}]: ok (error after {took:.2f} s: {str(e)[:160]})")
         sys.stdout.flush()
         os._exit(0)  # (the job is broken: no finalize barrier to meet the dead rank in)
     raise AssertionError(f"{what} with a dead peer returned without an error")

@@ -274,8 +274,17 @@ def test_no_transport_at_all_fails_init_on_every_rank_at_once(devsim_lib):
 def test_a_peer_that_dies_is_an_error_not_a_hang(devsim_lib, what):
     """the last of 3 ranks exits without a word; the survivors' next collective (one kernel / meet-body-done / ring kernel / LL
     lines) or Receive from it returns an error within the no-progress limit, the waiting kernels have ended, the device works"""
-    outs = run_ranks("peer_dies", 3, {"what": what}, timeout=120, env={"XMPI_TIMEOUT_S": "4"})
+    outs = run_ranks("peer_dies", 3, {"what": what}, timeout=120, env={"XMPI_TIMEOUT_S": "4", "XMPI_WATCHDOG_MS": "0"})
     assert sum("ok (error after" in o for o in outs) == 2, "\n".join(outs)
+
+
+@pytest.mark.parametrize("what", ["allreduce", "split", "ring", "ll", "ll_agent", "recv", "recv_on_stream"])
+def test_a_peer_that_dies_is_an_error_at_once_with_default_settings(devsim_lib, what):
+    """XMPI_TIMEOUT_S unset (wait for ever, the default): the watchdog -- every rank's helper thread asks every 50 ms whether the
+    other ranks' processes still exist -- raises the job's abort flag; XMPI_ERR_PEER within a second, the dead rank named"""
+    outs = run_ranks("peer_dies", 3, {"what": what, "no_timeout": 1, "within": 1.5}, timeout=120, env={"XMPI_TIMEOUT_S": "0"})
+    assert sum("ok (error after" in o for o in outs) == 2, "\n".join(outs)
+    assert all("the process of rank 2" in o for o in outs[:2]), "\n".join(outs)
 
 
 @pytest.mark.parametrize("what", ["length", "length_split", "schedule", "form", "operation", "root", "shape", "collective"])

@@ -296,8 +296,22 @@ def test_a_peer_that_dies_is_an_error_not_a_hang(what):
     """rank 1 of 2 exits without a word after a collective that worked: rank 0's next allreduce (its kernel waits for a flag word
     that will never come) / Receive returns an error within the no-progress limit, the kernel has ended, the GPU still works
     (the reference's peers get a TCP error: network.go:518-571)"""
-    outs = run_ranks("peer_dies", 2, {"what": what}, timeout=120, env={"XMPI_TIMEOUT_S": "5"})
+    outs = run_ranks("peer_dies", 2, {"what": what}, timeout=120, env={"XMPI_TIMEOUT_S": "5", "XMPI_WATCHDOG_MS": "0"})
     assert sum("ok (error after" in o for o in outs) == 1, "\n".join(outs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("what", ["allreduce", "split", "ring", "ll", "ll_agent", "recv", "recv_on_stream"])
+def test_a_peer_that_dies_is_an_error_at_once_with_default_settings(what):
+    """XMPI_TIMEOUT_S unset = wait for ever (the default, as the reference's blocking calls): rank 1 of 2 exits without a word and
+    rank 0's next collective -- one kernel, meet / body / done, the ring kernel, LL lines launched or by the lingering agent -- or
+    Receive (blocking / stream-ordered) comes back with XMPI_ERR_PEER WITHIN A SECOND, naming the rank: the helper thread asks every
+    50 ms whether the peers' processes still exist (pid + start time) and raises the job's abort flag, which the waiting kernel
+    polls; the kernel has ended, the GPU still works.  (The reference's peers get the error from their sockets at once:
+    network.go:555,611,623.)"""
+    outs = run_ranks("peer_dies", 2, {"what": what, "no_timeout": 1, "within": 1.0}, timeout=120, env={"XMPI_TIMEOUT_S": "0"})
+    assert sum("ok (error after" in o for o in outs) == 1, "\n".join(outs)
+    assert "the process of rank 1" in outs[0], outs[0]
 
 
 @pytest.mark.parametrize("what", ["length", "length_split", "schedule", "form", "root", "shape", "collective"])
