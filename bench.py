@@ -49,6 +49,7 @@ import numpy as np  # noqa: E402
 from mpi_amd import xmpi  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s
+HBM_ACHIEVABLE_GBPS = 6300.0  # ... what a streaming kernel achieves of it (the guide's float4-copy figure)
 XGMI_LINK_GBPS = 153.6   # per-link peak, both directions together (task statement: 7 links x ~153 GB/s per GPU)
 XGMI_DIR_GBPS = 76.8     # ... one direction, nominal: what bounds a schedule's busiest link direction
 ALGO_NAME = {xmpi.ALGO_RING: "ring", xmpi.ALGO_RHD: "rhd", xmpi.ALGO_DIRECT: "direct", xmpi.ALGO_ZCOPY: "zcopy",
@@ -325,6 +326,32 @@ def rank_main(job: Job, grank: int):
             "split" if comm.get_param("dsync_split_launches") > sl0 else "one kernel")
     prof = {k: comm.prof_get(k) for k in (xmpi.PROF_REDUCE2, xmpi.PROF_REDUCEN, xmpi.PROF_COPY, xmpi.PROF_PEER,
                                           xmpi.PROF_ZCOPY)}
+    # the spread of the sampled launches of the timed region, by kind (ns -> us)
+    prof_span = {k: (comm.get_param(f"prof_min_ns_{k}") / 1e3, comm.get_param(f"prof_max_ns_{k}") / 1e3)
+                 for k in (xmpi.PROF_REDUCE2, xmpi.PROF_REDUCEN, xmpi.PROF_COPY, xmpi.PROF_PEER, xmpi.PROF_ZCOPY)}
+
+    # ---- the box, right behind the timed region and on ITS sixteen buffers: the fold's access pattern without the arithmetic -- R sources
+    # -> R destinations in one launch, same grid, same cache policy (xmpi_copy_local_pairs) -- by rank 0 alone, everybody else parked.
+    # The same binary ran the fold in 669 ... 763 us on different boxes (r04 / r05): `box_copy_us` says what THIS box's memory gave the
+    # pattern on THESE buffers, `frac_of_box` = box_copy_us / the fold's avg launch says how much of it the fold used.
+    box = None
+    comm.barrier()
+    if lead and R > 1 and len(job.bufs) == R and prof[xmpi.PROF_ZCOPY][0]:
+        try:
+            comm.prof_reset()
+            comm.prof_enable(True)
+            comm.set_param("prof_every", 1)
+            bs, bd = [job.bufs[k][0] for k in range(R)], [job.bufs[k][1] for k in range(R)]
+            for j in range(8):
+                comm.copy_local_pairs(bd, bs, nbytes)
+            n_b, ms_b, by_b = comm.prof_get(xmpi.PROF_ZCOPY)
+            box = {"box_copy_us": ms_b * 1e3 / n_b, "box_copy_us_min": comm.get_param(f"prof_min_ns_{xmpi.PROF_ZCOPY}") / 1e3,
+                   "box_copy_us_max": comm.get_param(f"prof_max_ns_{xmpi.PROF_ZCOPY}") / 1e3, "box_copy_launches": n_b,
+                   "box_copy_bytes_per_launch": by_b / n_b, "box_copy_GBps": by_b / (ms_b * 1e-3) / 1e9}
+            comm.prof_enable(False)
+        except Exception as e:  # noqa: BLE001  (the line does not depend on it)
+            box = {"error": repr(e)[:200]}
+    comm.barrier()
 
     # the same kernel with the GPU to itself (rank 0 only, everybody else parked at a barrier):
     # one ring-step chunk (S / R) per launch
@@ -417,7 +444,7 @@ def rank_main(job: Job, grank: int):
     slot = lambda b: (b.ptr >> 12) & 15  # noqa: E731 -- the 4 KiB slot of the 64 KiB frame a block starts in (heap.cpp colouring)
     out = {"degraded": {"level": comm.get_param("degraded"), "why": comm.degraded()},
            "slots": {"send": slot(send), "recv": slot(recv)}, "form": form, "link": link, "transport": transport, "devices": ndev_used, "dsync": comm.get_param("dsync"), "t_step": t_step, "prof": prof, "tune": tune, "best": best, "best_ring": best_ring, "ring_named": ring_named, "parity": parity,
-           "algo": algo, "nbytes": nbytes, "count": count, "iso": iso, "parity_failures": parity_failures,
+           "algo": algo, "nbytes": nbytes, "count": count, "iso": iso, "box": box, "prof_span": prof_span, "parity_failures": parity_failures,
            "shared_stream": comm.get_param("shared_stream"), "slot_bytes": comm.get_param("slot_bytes"),
            "zero_copy_probe": {"dsync": "ok: ranks meet on the device" if comm.get_param("dsync") == 1 else "ok (ranks that share a process meet on the host)",
                                "host": "device rendezvous failed, host rendezvous ok",
@@ -675,6 +702,22 @@ def cpu_baseline(ranks: int, count: int, reps: int = 2):
                       f"(oracle/refpath.cpp restating network.go:518-625; no Go toolchain in the image)"}
 
 
+def cpu_by_ranks(cb, ranks: int, count: int, sub=(2, 4)):
+    """cpu_baseline + `by_ranks`: the reference path at every rank count of the metric (1 rank: no message, nothing to time) -- the
+    full communicator's entry is the sample already taken; the smaller ones one repetition each"""
+    if not isinstance(cb, dict) or "value" not in cb:
+        return cb
+    by = {}
+    for r in sorted({x for x in sub if 1 < x < ranks}):
+        row = cpu_baseline(r, count, 1)
+        by[str(r)] = ({"algbw_GBps": round(row["value"], 5), "busbw_GBps": round(row["busbw_GBps"], 5), "seconds_per_allreduce": round(row["seconds_per_allreduce"], 4),
+                       "cores": row["cores"], "repetitions": 1} if isinstance(row, dict) and "value" in row else {"error": (row or {}).get("error", "no result")[:120]})
+    by[str(ranks)] = {"algbw_GBps": round(cb["value"], 5), "busbw_GBps": round(cb["busbw_GBps"], 5), "seconds_per_allreduce": round(cb["seconds_per_allreduce"], 4),
+                      "cores": cb["cores"], "repetitions": None}
+    cb["by_ranks"] = by
+    return cb
+
+
 def multiprocess_sweep(ranks: int):
     """examples/coll_sweep through the launcher: ONE OS PROCESS PER RANK (the production layout), all on this box's
     GPU(s).  Processes meet on the device (flag words in HBM) -- the figure the rank-threads of this bench cannot give."""
@@ -870,6 +913,8 @@ def main():
     else:
         nc, msc, bc = r0["prof"][xmpi.PROF_COPY]
         kname, launches, ms, by = "copy16_kernel", nc, msc, bc
+    kind = (xmpi.PROF_ZCOPY if (launches, ms, by) == (nz, msz, bz) and nz else xmpi.PROF_REDUCE2 if (launches, ms, by) == (n2, ms2, b2) and n2 else
+            xmpi.PROF_REDUCEN if (launches, ms, by) == (nn, msn, bn) and nn else xmpi.PROF_COPY)
     achieved = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     # HBM traffic per launch comes from separate rocprofv3 --pmc passes (committed under profiles/); it is
     # attached only when this run launched the same kernel on the same number of bytes
@@ -889,6 +934,12 @@ def main():
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_from_profile": True, "traffic_source": traffic_src,
             "kernel_detail": kname,
             "launches": launches, "avg_launch_us": (ms * 1e3 / launches) if launches else None,
+            # the spread of the sampled launches; against what a streaming kernel achieves on this part (MI355X_MICROARCH.md: ~6.3 TB/s of the
+            # 8 TB/s peak); and against THIS box on THESE buffers (the fold's access pattern without the arithmetic, right behind the timed region)
+            "kernel_us_min": r0["prof_span"][kind][0], "kernel_us_max": r0["prof_span"][kind][1],
+            "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBPS,
+            "box_copy_us": (r0.get("box") or {}).get("box_copy_us"),
+            "frac_of_box": ((r0["box"]["box_copy_us"] / (ms * 1e3 / launches)) if launches and ms > 0 and (r0.get("box") or {}).get("box_copy_us") else None),
             "algorithmic_bytes_per_launch": (by / launches) if launches else None,
             "note": "live HIP events on the kernel's own stream inside the timed region (rank 0's launches); "
                     "algorithmic bytes: 12 B per output element for reduce2 (2 reads + 1 write), (N+1) x 4 B for the "
@@ -993,13 +1044,19 @@ def main():
         line["degraded"] = r0["degraded"]
     if (args.gpus > 1 or job.procs > 1) and not args.no_probe:
         line["zero_copy_probe"] = r0["zero_copy_probe"]
-    extras_out = {"timed_buffer_slots": {str(g): job.result[g].get("slots") for g in sorted(job.result)},
+    extras_out = {"timed_buffer_slots": {str(g): job.result[g].get("slots") for g in sorted(job.result)}, "box": r0.get("box"),
                   "autotune": r0["tune"], "parity_failures": r0["parity_failures"], "other_kernels": others,
                   "roofline_isolated": r0["iso"], "extras": r0["extras"], "roofline_note": roof.pop("note", None),
                   "traffic_source": roof.pop("traffic_source", None), "kernel_detail": roof.pop("kernel_detail", None)}
     if args.gpus == 1 and not args.no_cpu and job.proc_rank == 0:
         cb = cpu_baseline(R, args.cpu_count or r0["count"], args.cpu_reps)
+        # north_star: bus bandwidth "at 1, 2, 4 and 8 ranks ... next to the reference's loopback-TCP path timed ... in the same run": the
+        # same bytes per rank at every rank count of the metric (one repetition at 2 and 4: they are the cheaper legs)
+        cb = cpu_by_ranks(cb, R, args.cpu_count or r0["count"])
         line["cpu_baseline"] = cb
+        for rk, row in (cb.get("by_ranks") or {}).items():
+            if rk in size_rows and "algbw_GBps" in row and (args.cpu_count or r0["count"]) * 4 == size_rows[rk]["bytes"]:
+                size_rows[rk]["cpu_algbw_GBps"] = row["algbw_GBps"]
         if isinstance(r0["extras"], dict) and "bounce_sweep_u8" in r0["extras"]:
             extras_out["extras"]["cpu_reference_bounce_u8"] = cpu_bounce()  # same lengths, the reference path on the host
     else:  # (not "unmeasured": the reference path is timed once, on the N = 1 run's host cores)

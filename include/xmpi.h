@@ -341,6 +341,10 @@ int xmpi_copy_local(xmpi_comm* comm, void* dst, const void* src, size_t bytes);
 int xmpi_reduce_local_multi(xmpi_comm* comm, void* const* dsts, int ndst, const void* const* srcs,
                             int nsrc, size_t count, xmpi_dtype dtype, xmpi_op op);
 int xmpi_copy_local_multi(xmpi_comm* comm, void* const* dsts, int ndst, const void* src, size_t bytes);
+/* (No counterpart in the reference.)  dsts[k] = srcs[k], k < n <= 16, in ONE launch with the access pattern of xmpi_reduce_local_multi on
+ * the same pointers (same grid and cache policy, n loads + n stores per 16-byte packet): the fold without its arithmetic -- what this
+ * machine's memory gives that pattern on those buffers (bench.py roofline.box_copy_us).  16-byte aligned pointers. */
+int xmpi_copy_local_pairs(xmpi_comm* comm, void* const* dsts, const void* const* srcs, int n, size_t bytes);
 
 /* Verification kernels (LDS + wavefront-shuffle reductions; replace bytes.Equal /
  * floats.Equal of examples/bounce/bounce.go:105,133 for HBM-resident data). */

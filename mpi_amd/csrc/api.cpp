@@ -1669,9 +1669,7 @@ static int timed_launch(xmpi_comm* c, int kind, size_t bytes, hipError_t (*launc
   XMPI_HIP(hipStreamSynchronize(s));
   float ms = 0.f;
   XMPI_HIP(hipEventElapsedTime(&ms, a, b));
-  c->prof[kind].launches++;
-  c->prof[kind].total_ms += ms;
-  c->prof[kind].bytes += bytes;
+  c->prof[kind].add(ms, bytes);
   ev_put(c, a, true);
   ev_put(c, b, true);
   return XMPI_OK;
@@ -1728,6 +1726,18 @@ int xmpi_reduce_local_multi(xmpi_comm* c, void* const* dsts, int ndst, const voi
                         Ctx* x = (Ctx*)p;
                         return launch_reduce_n_multi(x->d, x->nd, x->s, x->ns, x->n, x->dt, x->op, x->c->local_stream,
                                                      es, ee);
+                      },
+                      &ctx);
+}
+
+int xmpi_copy_local_pairs(xmpi_comm* c, void* const* dsts, const void* const* srcs, int n, size_t bytes) {
+  XMPI_ENTER(c);
+  if (n < 1 || n > kMaxReduceSrcs || !dsts || !srcs) return XMPI_ERR_ARG;
+  struct Ctx { xmpi_comm* c; void* const* d; const void* const* s; int n; size_t bytes; } ctx{c, dsts, srcs, n, bytes};
+  return timed_launch(c, PROF_ZCOPY, (size_t)(2 * n) * bytes,
+                      [](void* p, hipEvent_t es, hipEvent_t ee) {
+                        Ctx* x = (Ctx*)p;
+                        return launch_copy_pairs(x->d, x->s, x->n, x->bytes, x->c->local_stream, es, ee);
                       },
                       &ctx);
 }
@@ -1971,6 +1981,11 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
       if (w == "unroll") return c->tune_unroll[coll][cls];
     }
     return -1;
+  }
+  if (n.rfind("prof_min_ns_", 0) == 0 || n.rfind("prof_max_ns_", 0) == 0) {  // the shortest / longest sampled launch of kind 0..4 since xmpi_prof_reset
+    const int kind = name[12] - '0';
+    if (kind < 0 || kind >= PROF_KINDS || name[13]) return -1;
+    return (long)((n[5] == 'i' ? c->prof[kind].min_ms : c->prof[kind].max_ms) * 1e6);
   }
   if (n == "p2p_direct_count") return (long)c->p2p_direct_count;
   if (n == "p2p_staged_count") return (long)c->p2p_staged_count;

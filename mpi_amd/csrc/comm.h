@@ -36,6 +36,14 @@ struct ProfCounter {
   uint64_t launches = 0;
   double total_ms = 0.0;
   uint64_t bytes = 0;
+  double min_ms = 0.0, max_ms = 0.0;  // of the sampled launches (0: none yet)
+  void add(double ms, uint64_t nbytes) {
+    min_ms = launches ? (ms < min_ms ? ms : min_ms) : ms;
+    max_ms = launches ? (ms > max_ms ? ms : max_ms) : ms;
+    launches++;
+    total_ms += ms;
+    bytes += nbytes;
+  }
 };
 
 enum ProfKind { PROF_REDUCE2 = 0, PROF_REDUCEN = 1, PROF_COPY = 2, PROF_PEER = 3, PROF_ZCOPY = 4, PROF_KINDS = 5 };

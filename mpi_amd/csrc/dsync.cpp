@@ -1586,9 +1586,7 @@ void dsync_prof_harvest(xmpi_comm* c) {
       continue;
     }
     ProfCounter& pc = c->prof[PROF_ZCOPY];
-    pc.launches++;
-    pc.total_ms += ms;
-    pc.bytes += p.bytes;
+    pc.add(ms, p.bytes);
     ev_put(c, p.start, true);
     ev_put(c, p.stop, true);
     c->dsync_prof_pending.erase(c->dsync_prof_pending.begin() + (long)i);

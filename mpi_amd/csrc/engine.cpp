@@ -228,9 +228,7 @@ struct Exec {
       float ms = 0.f;
       XMPI_HIP(hipEventElapsedTime(&ms, f.start, f.stop));
       ProfCounter& pc = c->prof[f.prof_kind];
-      pc.launches++;
-      pc.total_ms += ms;
-      pc.bytes += f.prof_bytes;
+      pc.add(ms, f.prof_bytes);
       ev_put(c, f.start, true);
       ev_put(c, f.stop, true);
     }

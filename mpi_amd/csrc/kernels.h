@@ -45,6 +45,11 @@ hipError_t launch_reduce_n_multi(void* const* dsts, int ndst, const void* const*
 hipError_t launch_copy_multi(void* const* dsts, int ndst, const void* src, size_t bytes, hipStream_t stream,
                              hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
+// dsts[k] = srcs[k], k < n, in ONE launch with the access pattern of launch_reduce_n_multi on the same pointers (same grid, same
+// cache policy, n loads and n stores per 16-byte packet index): the fold without its arithmetic.  16-byte aligned pointers only.
+hipError_t launch_copy_pairs(void* const* dsts, const void* const* srcs, int n, size_t bytes, hipStream_t stream, hipEvent_t ev_start = nullptr,
+                             hipEvent_t ev_stop = nullptr);
+
 // *d_out += number of differing bytes (d_out: 8-byte device word, caller zeroes it)
 hipError_t launch_count_mismatch(const void* a, const void* b, size_t bytes, uint64_t* d_out,
                                  hipStream_t stream);

@@ -226,6 +226,30 @@ __global__ __launch_bounds__(kBlock) void reduce_n_multi_kernel(MultiPtrs q, int
   }
 }
 
+// The fold above with the arithmetic taken out: dst[k][i] = src[k][i] for the same N sources and N destinations -- the same
+// loads, the same stores, the same grid, the same cache policy, no adds.  What THIS box's memory system gives the fold's access
+// pattern on THESE buffers: bench.py runs it right behind the timed region (roofline.box_copy_us) so that a reader can tell the
+// box from the code (the same binary ran the fold in 669 ... 763 us on different boxes).
+template <int NSRC, int MODE>
+__global__ __launch_bounds__(kBlock) void copy_pairs_kernel(MultiPtrs q, int n_rt, size_t npack, size_t bytes) {
+  const int n = (NSRC > 0) ? NSRC : n_rt;
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < npack; i += stride) {
+    if constexpr (NSRC > 0) {
+      pack_t v[NSRC];
+#pragma unroll
+      for (int s = 0; s < NSRC; s++) v[s] = ldp<MODE>(reinterpret_cast<const pack_t*>(q.src[s]) + i);
+#pragma unroll
+      for (int k = 0; k < NSRC; k++) stp<(MODE != 0) ? 1 : 0>(reinterpret_cast<pack_t*>(q.dst[k]) + i, v[k]);
+    } else {
+      for (int k = 0; k < n; k++) reinterpret_cast<pack_t*>(q.dst[k])[i] = reinterpret_cast<const pack_t*>(q.src[k])[i];
+    }
+  }
+  const size_t done = npack * 16;
+  if (blockIdx.x == 0 && done + threadIdx.x < bytes)
+    for (int k = 0; k < n; k++) reinterpret_cast<uint8_t*>(q.dst[k])[done + threadIdx.x] = reinterpret_cast<const uint8_t*>(q.src[k])[done + threadIdx.x];
+}
+
 // any alignment: one element per lane per iteration
 template <typename T, int OP>
 __global__ __launch_bounds__(kBlock) void reduce_n_multi_elem_kernel(MultiPtrs q, int nsrc, int ndst, size_t count) {
@@ -1085,6 +1109,35 @@ hipError_t launch_reduce_n_multi(void* const* dsts, int ndst, const void* const*
     case DT_BF16: return reduce_n_multi_op<bf16_t>(q, nsrc, ndst, count, vec, op, s, es, ee);
     default: return hipErrorInvalidValue;
   }
+}
+
+hipError_t launch_copy_pairs(void* const* dsts, const void* const* srcs, int n, size_t bytes, hipStream_t s, hipEvent_t es, hipEvent_t ee) {
+  if (n < 1 || n > kMaxReduceSrcs) return hipErrorInvalidValue;
+  MultiPtrs q;
+  for (int i = 0; i < kMaxReduceSrcs; i++) {
+    q.src[i] = (i < n) ? srcs[i] : nullptr;
+    q.dst[i] = (i < n) ? dsts[i] : nullptr;
+    if (i < n && (!aligned16(q.src[i]) || !aligned16(q.dst[i]))) return hipErrorInvalidValue;
+  }
+  if (bytes == 0) {
+    if (es) (void)hipEventRecord(es, s);
+    if (ee) (void)hipEventRecord(ee, s);
+    return hipSuccess;
+  }
+  const size_t npack = bytes / 16;
+  const int grid = grid_for(npack, kBlock);                       // (as reduce_n_multi_typed: one packet per lane)
+  const int mode = kernel_mode_for((size_t)(2 * n) * bytes);      // ... and its cache policy for that many bytes
+#define XMPI_CPP(NS)                                                                                                  \
+  case NS:                                                                                                            \
+    if (mode != 0) XMPI_LAUNCH((copy_pairs_kernel<NS, 2>), dim3(grid), dim3(kBlock), s, es, ee, q, n, npack, bytes);  \
+    else XMPI_LAUNCH((copy_pairs_kernel<NS, 0>), dim3(grid), dim3(kBlock), s, es, ee, q, n, npack, bytes);            \
+    break;
+  switch (n) {
+    XMPI_CPP(1) XMPI_CPP(2) XMPI_CPP(3) XMPI_CPP(4) XMPI_CPP(5) XMPI_CPP(6) XMPI_CPP(7) XMPI_CPP(8)
+    default: XMPI_LAUNCH((copy_pairs_kernel<0, 0>), dim3(grid), dim3(kBlock), s, es, ee, q, n, npack, bytes); break;
+  }
+#undef XMPI_CPP
+  return hipGetLastError();
 }
 
 hipError_t launch_copy_multi(void* const* dsts, int ndst, const void* src, size_t bytes, hipStream_t s,

@@ -168,9 +168,7 @@ struct Launcher {
       float ms = 0.f;
       XMPI_HIP(hipEventElapsedTime(&ms, start, stop));
       ProfCounter& pc = c->prof[PROF_ZCOPY];
-      pc.launches++;
-      pc.total_ms += ms;
-      pc.bytes += bytes;
+      pc.add(ms, bytes);
       ev_put(c, start, true);
       ev_put(c, stop, true);
       start = stop = nullptr;
@@ -509,9 +507,7 @@ static int zc_run(xmpi_comm* c, int coll, int root, const void* sendbuf, void* r
         float ms = 0.f;
         XMPI_HIP(hipEventElapsedTime(&ms, ev.first, ev.second));
         ProfCounter& pc = c->prof[PROF_ZCOPY];
-        pc.launches++;
-        pc.total_ms += ms;
-        pc.bytes += (size_t)(N + nd) * cnt * es;
+        pc.add(ms, (size_t)(N + nd) * cnt * es);
         ev_put(c, ev.first, true);
         ev_put(c, ev.second, true);
       }

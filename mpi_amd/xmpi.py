@@ -86,6 +86,7 @@ SYMBOLS = [
     ("xmpi_deregister", _I, [_P, _P]),
     ("xmpi_reduce_local_multi", _I, [_P, C.POINTER(_P), _I, C.POINTER(_P), _I, _Z, _I, _I]),
     ("xmpi_copy_local_multi", _I, [_P, C.POINTER(_P), _I, _P, _Z]),
+    ("xmpi_copy_local_pairs", _I, [_P, C.POINTER(_P), C.POINTER(_P), _I, _Z]),
     ("xmpi_zc_chunk", _I, [_Z, _Z, _I, _I, C.POINTER(_Z), C.POINTER(_Z)]),
     ("xmpi_allreduce_on_stream", _I, [_P, _P, _P, _Z, _I, _I, _P]),
     ("xmpi_allgather_on_stream", _I, [_P, _P, _P, _Z, _I, _P]),
@@ -408,6 +409,12 @@ class Comm:
         s = (_P * len(srcs))(*[_ptr(x) for x in srcs])
         _check(lib().xmpi_reduce_local_multi(self.handle, d, len(dsts), s, len(srcs), count, dtype, op),
                "reduce_local_multi")
+
+    def copy_local_pairs(self, dsts: Sequence, srcs: Sequence, nbytes: int) -> None:
+        """dsts[k] = srcs[k] in one launch with the fold's access pattern (reduce_local_multi without the arithmetic)"""
+        d = (_P * len(dsts))(*[_ptr(x) for x in dsts])
+        s_ = (_P * len(srcs))(*[_ptr(x) for x in srcs])
+        _check(lib().xmpi_copy_local_pairs(self.handle, d, s_, len(srcs), nbytes), "xmpi_copy_local_pairs")
 
     def copy_local_multi(self, dsts: Sequence, src, nbytes: int) -> None:
         d = (_P * len(dsts))(*[_ptr(x) for x in dsts])

@@ -78,3 +78,37 @@ def test_cpu_reference_bounce_runs_the_reference_lengths():
         pytest.skip("oracle/refpath_bin not built")
     assert [r["bytes"] for r in rows] == [0, 1, 10, 100, 1000, 10**4, 10**5, 10**6, 10**7]  # bounce.go:33
     assert all(r["round_trip_us"] > 0 for r in rows)
+
+
+def test_cpu_baseline_at_every_rank_count_of_the_metric():
+    """north_star: bus bandwidth at 1 / 2 / 4 / 8 ranks next to the reference's loopback-TCP path timed in the same run -- the
+    cpu_baseline object carries `by_ranks` (2, 4 and the full communicator; one rank sends no message)"""
+    m = _bench()
+    cb = m.cpu_baseline(8, 1 << 14, 1)
+    if cb is None:
+        pytest.skip("oracle/refpath_bin not built")
+    cb = m.cpu_by_ranks(cb, 8, 1 << 14)
+    assert sorted(cb["by_ranks"]) == ["2", "4", "8"], cb
+    for r, row in cb["by_ranks"].items():
+        assert "error" not in row, row
+        assert row["algbw_GBps"] > 0 and abs(row["busbw_GBps"] - row["algbw_GBps"] * 2 * (int(r) - 1) / int(r)) < 1e-3 * row["busbw_GBps"] + 1e-5
+    assert cb["by_ranks"]["8"]["algbw_GBps"] == round(cb["value"], 5)
+    assert m.cpu_by_ranks({"error": "x"}, 8, 16) == {"error": "x"}  # (a failed sample stays what it is)
+
+
+def test_the_quoted_pmc_profile_is_not_stale():
+    """bench.py reads roofline.traffic from profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, committed): the file must
+    come from the newest round that has a profile directory, and every kernel it names must still be a kernel of the sources --
+    a stale profile quoted beside a live time would be a figure for another binary"""
+    import glob
+    import json
+    import re
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+        pmc = json.load(f)
+    rounds = sorted(int(m.group(1)) for d in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]")) for m in [re.search(r"r(\d\d)$", d)] if m)
+    assert pmc["round"] == rounds[-1], f"profiles/pmc_traffic.json is round {pmc['round']}, the newest profile directory is r{rounds[-1]:02d}: re-run the --pmc passes"
+    src = "".join(open(f).read() for f in glob.glob(os.path.join(ROOT, "mpi_amd", "csrc", "*.hip")))
+    for row in pmc["rows"]:
+        stem = row["kernel"].split("<")[0]
+        assert re.search(r"__global__[^;{]*\b" + re.escape(stem) + r"\s*\(", src), f"{stem}: named by profiles/pmc_traffic.json, not a kernel of mpi_amd/csrc/*.hip"
+        assert row["traffic_bytes_per_launch"] > 0 and row["algorithmic_bytes_per_launch"] > 0

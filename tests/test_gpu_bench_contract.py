@@ -19,7 +19,7 @@ def test_bench_json_contract():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")]
     assert len(lines) == 1 and r.stdout.strip().split("\n")[-1] == lines[0]
-    assert len(lines[0]) < 6000, len(lines[0])  # the driver's parser must see the whole line (round 2's 20 KB line was lost)
+    assert len(lines[0]) < 4096, len(lines[0])  # the driver's parser must see the whole line (round 2's 20 KB line was lost)
     d = json.loads(lines[0])
     for k in REQUIRED:
         assert k in d, k
@@ -35,7 +35,14 @@ def test_bench_json_contract():
     ro = d["roofline"]
     assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0
     assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9 and ro["launches"] > 0
+    # box against code: the spread of the sampled launches, the fold against what a streaming kernel achieves on this part, and against
+    # THIS box on THESE buffers -- the fold's access pattern without the arithmetic, run right behind the timed region
+    assert 0 < ro["kernel_us_min"] <= ro["avg_launch_us"] <= ro["kernel_us_max"]
+    assert abs(ro["frac_of_achievable"] - ro["achieved"] / 6300.0) < 1e-9
+    assert ro["box_copy_us"] > 0 and abs(ro["frac_of_box"] - ro["box_copy_us"] / ro["avg_launch_us"]) < 1e-9
+    assert ro["frac_of_box"] >= 0.9, ro  # (16 MiB per rank lives in the caches; the 256 MiB line is held to 0.97 by scripts/r06_profile.sh's reader)
     cb = d["cpu_baseline"]
+    assert sorted(cb["by_ranks"]) == ["2", "4", "8"] and all(v["algbw_GBps"] > 0 for v in cb["by_ranks"].values()), cb
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert abs(cb["value"] - 65536 * 4 / cb["seconds_per_allreduce"] / 1e9) < 1e-6 * cb["value"]  # algbw too, not x ranks
     assert d["parity"]["checked"] and d["parity"]["ok"] and d["parity"]["bit_identical"] and "whole buffer" in d["parity"]["coverage"]
