@@ -1985,7 +1985,7 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
   if (n.rfind("prof_min_ns_", 0) == 0 || n.rfind("prof_max_ns_", 0) == 0) {  // the shortest / longest sampled launch of kind 0..4 since xmpi_prof_reset
     const int kind = name[12] - '0';
     if (kind < 0 || kind >= PROF_KINDS || name[13]) return -1;
-    return (long)((n[5] == 'i' ? c->prof[kind].min_ms : c->prof[kind].max_ms) * 1e6);
+    return (long)((n[6] == 'i' ? c->prof[kind].min_ms : c->prof[kind].max_ms) * 1e6);
   }
   if (n == "p2p_direct_count") return (long)c->p2p_direct_count;
   if (n == "p2p_staged_count") return (long)c->p2p_staged_count;

@@ -414,6 +414,37 @@ def test_the_scale_command_on_virtual_gpus(devsim_lib, gpus, tmp_path):
         assert d["roofline_hbm"]["bound"] == "hbm" and "ring" not in d
 
 
+@pytest.mark.parametrize("gpus", [8, 4, 2])
+def test_the_scale_command_as_a_lone_process(devsim_lib, gpus, tmp_path):
+    """`python bench.py --gpus N --steps K --warmup W` WITHOUT torch.distributed.run -- the `--gpus 1` command's shape carried to
+    N GPUs: ONE process hosts all 8 ranks as threads and drives every GPU (bench.py Job.device_of: ranks spread over the visible
+    devices; same-pid peers address each other's memory by pointer instead of through hipIpc, peer access enabled by xmpi_init --
+    dsync.cpp dsync_connect).  At N = 8 every rank thread has a GPU to itself: the ranks meet on the device, the library tunes
+    itself, the line's roofline is the link roofline -- the same line the torchrun form gives."""
+    import json
+    import sys
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "tests", "devsim", "site"), XMPI_DEVSIM_LIB=devsim_lib, DEVSIM_DEVICES=str(gpus),
+               XMPI_TIMEOUT_S="60", XMPI_BENCH_EXTRAS_DIR=str(tmp_path))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--size-mib", "0.25", "--no-cpu",
+                        "--no-production"], capture_output=True, text=True, timeout=900, cwd=str(tmp_path), env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == gpus and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong"
+    assert d["config"]["ranks"] == 8 and d["config"]["ranks_per_gpu"] == 8 // gpus
+    assert d["parity"]["ok"] is True and d["parity_failures"] == 0 and d["value"] > 0
+    assert d["roofline"]["bound"] == "xgmi" and d["xgmi"]["meaningful"] is (gpus == 8)
+    if gpus == 8:
+        assert d["config"]["transport"] == "xGMI (one rank per GPU)" and d["ranks_meet"] == "on the device (dsync)" and d["config"]["tuned"]
+        assert d["roofline_hbm"]["kernel"].startswith("dsync_") and d["ring"]["best"] in ("pull", "push")
+        assert "rejected" not in d["config"]["tuned"]  # (the tuner checked every candidate's answer: nothing wrong on these devices)
+    else:
+        assert d["config"]["transport"].startswith(f"mixed: 8 ranks on {gpus} GPUs") and d["roofline"]["ranks_per_gpu"] == 8 // gpus
+
+
 def test_the_8gpu_script_rehearsal(stage, devsim_lib, tmp_path):
     """scripts/profile_8gpu.sh -- the one command for the day an 8-GPU node exists -- with XMPI_8GPU_REHEARSAL=1 (small sizes, no
     rocprofv3, no GPU suite): every other command line of it as written, on 8 virtual GPUs; every file it leaves parses, every
@@ -444,7 +475,8 @@ def test_the_8gpu_script_rehearsal(stage, devsim_lib, tmp_path):
         if name == "cfg5_n8.json":
             assert d["rows"], d
     assert seen == {"auto", "fused", "fused2", "split", "zpush", "ring", "ring_push", "rhd", "rhd_push"}, seen
-    assert open(os.path.join(out, "prod.err")).read().strip() == ""
+    # (nothing but the launcher's one line per job: `xmpirun: 8 ranks on 8 GPUs`)
+    assert [ln for ln in open(os.path.join(out, "prod.err")).read().splitlines() if ln.strip() and not ln.startswith("xmpirun: ")] == []
     # ... and the one-screen reading of it names what the first hour on a node has to look at
     rep = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "first_hour_report.py"), out], capture_output=True, text=True, timeout=120)
     assert rep.returncode == 0, rep.stderr[-2000:]

@@ -35,6 +35,48 @@ def test_launcher_contract(tmp_path):
     assert len({ln.split("job=")[1] for ln in lines}) == 1
 
 
+def _fake_kfd(root, gpus, cpus=1):
+    """a KFD topology directory: `cpus` CPU nodes (simd_count 0) and `gpus` GPU nodes, as /sys/class/kfd/kfd/topology lays them out"""
+    for i in range(cpus + gpus):
+        d = root / "nodes" / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count {64 if i < cpus else 0}\nsimd_count {0 if i < cpus else 1024}\nmem_banks_count 1\ngfx_target_version {0 if i < cpus else 90500}\n")
+    return str(root)
+
+
+def test_launcher_counts_the_gpus_the_ranks_will_see(tmp_path):
+    """G comes from the KFD topology (the nodes with SIMDs: a CPU node, or another vendor's render node, is no GPU) narrowed by
+    ROCR_VISIBLE_DEVICES and HIP_VISIBLE_DEVICES: on a masked node -- 4 of 8 GPUs visible -- 8 ranks sit two per GPU on devices
+    0 .. 3 (rank 5 on device 1, not on a device 5 that xmpi_init would refuse); the launcher says so once; an XMPI_DEVICE that no
+    rank will see is refused with a sentence.  (gompirun.go:57-93: N copies on one machine.)"""
+    script = tmp_path / "probe.sh"
+    script.write_text("#!/bin/sh\necho \"rank=$XMPI_RANK dev=$XMPI_DEVICE queues=$GPU_MAX_HW_QUEUES\"\n")
+    script.chmod(0o755)
+    kfd = _fake_kfd(tmp_path / "kfd", 8)
+    base = {k: v for k, v in os.environ.items() if k not in ("XMPI_NGPUS", "XMPI_DEVICE", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES",
+                                                              "GPU_MAX_HW_QUEUES")}
+    base["XMPI_KFD_TOPOLOGY"] = kfd
+
+    def run(n, **env):
+        r = subprocess.run([os.path.join(BIN, "xmpirun"), str(n), str(script)], capture_output=True, text=True, timeout=60, env={**base, **env})
+        return r, sorted(r.stdout.strip().split("\n"), key=lambda ln: int(ln.split()[0].split("=")[1])) if r.stdout.strip() else []
+
+    r, lines = run(8)
+    assert r.returncode == 0 and "xmpirun: 8 ranks on 8 GPUs (KFD topology)" in r.stderr and r.stderr.count("xmpirun:") == 1, r.stderr
+    assert [ln.split()[1] for ln in lines] == [f"dev={i}" for i in range(8)] and all(ln.endswith("queues=") for ln in lines)
+    r, lines = run(8, HIP_VISIBLE_DEVICES="0,1,2,3")
+    assert r.returncode == 0 and "8 ranks on 4 GPUs" in r.stderr and "4 of 8 visible" in r.stderr and "several ranks per GPU" in r.stderr, r.stderr
+    assert [ln.split()[1] for ln in lines] == [f"dev={i % 4}" for i in range(8)] and all(ln.endswith("queues=2") for ln in lines)
+    r, lines = run(4, ROCR_VISIBLE_DEVICES="4,5,6,7,9", HIP_VISIBLE_DEVICES="1,3")  # (9: no such GPU -- the list ends there; HIP's indices count within ROCr's four)
+    assert "4 ranks on 2 GPUs" in r.stderr and [ln.split()[1] for ln in lines] == ["dev=0", "dev=1", "dev=0", "dev=1"], r.stderr + r.stdout
+    r, lines = run(2, ROCR_VISIBLE_DEVICES="GPU-abcdef0123456789,GPU-0123456789abcdef,GPU-00000000deadbeef")  # UUIDs are taken at their word
+    assert "2 ranks on 3 GPUs" in r.stderr, r.stderr
+    r, lines = run(8, HIP_VISIBLE_DEVICES="0,1,2,3", XMPI_DEVICE="5")
+    assert r.returncode == 2 and lines == [] and "XMPI_DEVICE=5" in r.stderr and "4 GPUs" in r.stderr, r.stderr
+    r, lines = run(3, XMPI_NGPUS="2")  # an explicit count wins
+    assert "3 ranks on 2 GPUs (XMPI_NGPUS)" in r.stderr and [ln.split()[1] for ln in lines] == ["dev=0", "dev=1", "dev=0"]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [1, 2, 4])
 def test_helloworld_program(n):
