@@ -77,6 +77,96 @@ def test_launcher_counts_the_gpus_the_ranks_will_see(tmp_path):
     assert "3 ranks on 2 GPUs (XMPI_NGPUS)" in r.stderr and [ln.split()[1] for ln in lines] == ["dev=0", "dev=1", "dev=0"]
 
 
+def test_pin_parity_script_rehearsal(tmp_path):
+    """scripts/pin_parity.sh -- the one command for the day a Go toolchain exists (the image has none: `go: command not found`) --
+    rehearsed with a stub `go` on PATH that records where and how it was called: the sequence a maintainer would otherwise type
+     -- go mod init in a COPY of the reference, collectives.go dropped in with its build tag stripped,
+    go mod edit -replace in a copy of go/, go vet / build, go run ./golden -out tests/golden, the reference's helloworld.go and
+    bounce.go byte for byte beside the one-line Register file -- and that the reference checkout is only ever read
+    (/root/reference is read-only for us; here: a read-only copy, hashed before and after).  (mpi.go:56-67.)"""
+    import hashlib
+    import shutil
+    import stat
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("the reference checkout is not on this machine")
+    ref = tmp_path / "ref_ro"
+    shutil.copytree("/root/reference", ref)
+
+    def tree_hash(root):
+        h = hashlib.sha256()
+        for d, _, fs in sorted(os.walk(root)):
+            for f in sorted(fs):
+                h.update(os.path.relpath(os.path.join(d, f), root).encode())
+                h.update(open(os.path.join(d, f), "rb").read())
+        return h.hexdigest(), sorted(os.listdir(root))
+    before = tree_hash(ref)
+    for d, ds, fs in os.walk(ref):
+        for x in fs:
+            os.chmod(os.path.join(d, x), stat.S_IRUSR | stat.S_IRGRP | stat.S_IROTH)
+        os.chmod(d, stat.S_IRUSR | stat.S_IXUSR)
+    log = tmp_path / "go.log"
+    stub = tmp_path / "bin"
+    stub.mkdir()
+    (stub / "go").write_text(f"""#!/bin/bash
+echo "$PWD|$*" >> {log}
+case "$1 $2" in
+  "version "*) echo "go version go1.22.0 stub/amd64";;
+  "mod init") echo "module $3" > go.mod;;
+  "mod edit") echo "// $3 $4" >> go.mod;;
+esac
+prev=""
+for a in "$@"; do
+  if [ "$prev" = "-o" ]; then printf '#!/bin/sh\nexit 0\n' > "$a"; chmod +x "$a"; fi
+  prev="$a"
+done
+exit 0
+""")
+    (stub / "go").chmod(0o755)
+    env = dict(os.environ, PATH=f"{stub}:{os.environ['PATH']}", REF=str(ref), PIN_PARITY_REHEARSAL="1", PIN_PARITY_KEEP="1")
+    try:
+        r = subprocess.run(["bash", os.path.join(ROOT, "scripts", "pin_parity.sh")], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    finally:
+        for d, ds, fs in os.walk(ref):
+            os.chmod(d, 0o755)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert tree_hash(ref) == before, "the reference checkout was written to"
+    calls = [ln.split("|", 1) for ln in log.read_text().splitlines()]
+    work = next(cwd for cwd, a in calls if a == "mod init github.com/btracey/mpi")
+    T = os.path.dirname(work)
+    assert work == os.path.join(T, "ref") and T.startswith("/tmp/pin_parity.")
+    seq = [(os.path.relpath(cwd, T), a) for cwd, a in calls if not a.startswith("version")]
+    want = [("ref", "mod init github.com/btracey/mpi"),
+            ("go", f"mod edit -replace github.com/btracey/mpi={T}/ref"),
+            ("ref", "vet ."), ("ref", "build ."),
+            ("go", "vet ./..."), ("go", "build ./..."),
+            ("go", f"run ./golden -out {ROOT}/tests/golden"),
+            ("run", f"build -o {T}/run/helloworld.bin ./helloworld"),
+            ("run", f"build -o {T}/run/bounce.bin ./bounce")]
+    assert seq == want, seq
+    # what the compiler would have been given: collectives.go as a file of package mpi (tag stripped), the shim's sources, the
+    # reference's programs byte for byte, each beside the one-line Register
+    col = open(os.path.join(T, "ref", "collectives.go")).read()
+    assert not col.startswith("//go:build") and "\npackage mpi\n" in col and "type Collective interface" in col
+    assert os.path.exists(os.path.join(T, "go", "xgmi", "xgmi.go")) and os.path.exists(os.path.join(T, "go", "golden", "gen_golden.go"))
+    for prog in ("helloworld", "bounce"):
+        assert open(os.path.join(T, "run", prog, prog + ".go"), "rb").read() == open(f"/root/reference/examples/{prog}/{prog}.go", "rb").read()
+        reg = open(os.path.join(T, "run", prog, "register_xgmi.go")).read()
+        assert "func init() { mpi.Register(&xgmi.Backend{}) }" in reg and reg.startswith("package main")
+    mod = open(os.path.join(T, "run", "go.mod")).read()
+    assert f"replace github.com/btracey/mpi => {T}/ref" in mod and f"replace github.com/btracey/mpi-xgmi => {T}/go" in mod
+    assert "go test ./xgmi skipped" in r.stdout and "the programs were built, not run" in r.stdout and "[pin_parity] done" in r.stdout
+    assert "parity stays unpinned" in r.stdout or "parity PINNED" in r.stdout  # (the stub writes no fixtures; a tree that has them says so)
+    shutil.rmtree(T, ignore_errors=True)
+
+
+def test_pin_parity_script_says_what_is_missing(tmp_path):
+    """without a Go toolchain (this image) the script stops at once with the sentence, touching nothing"""
+    env = {k: v for k, v in os.environ.items()}
+    env["PATH"] = ":".join(d for d in env["PATH"].split(":") if not os.path.exists(os.path.join(d, "go")))
+    r = subprocess.run(["bash", os.path.join(ROOT, "scripts", "pin_parity.sh")], capture_output=True, text=True, timeout=60, env=env, cwd=str(tmp_path))
+    assert r.returncode == 1 and "no Go toolchain on PATH" in r.stderr
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [1, 2, 4])
 def test_helloworld_program(n):
