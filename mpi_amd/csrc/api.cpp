@@ -1949,7 +1949,8 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
   if (n == "degraded") {
     bool shared_gpu = false;  // (ranks hosted by threads of one process on one GPU meet on the host by design, not by degradation)
     for (int p = 0; p < c->size; p++) shared_gpu = shared_gpu || c->peer_coloc[p];
-    return (c->body_sys == 1 && c->dsync_ok ? 1 : 0) | ((c->size > 1 && c->dsync && !c->dsync_ok && !shared_gpu) ? 2 : 0) | (c->windows_ok ? 0 : 4) |
+    // (... and so do more ranks than the device side is sized for)
+    return (c->body_sys == 1 && c->dsync_ok ? 1 : 0) | ((c->size > 1 && c->size <= kDsyncRanks && c->dsync && !c->dsync_ok && !shared_gpu) ? 2 : 0) | (c->windows_ok ? 0 : 4) |
            (c->rejected_why.empty() ? 0 : 8);
   }
   if (n == "windows_ok") return c->windows_ok ? 1 : 0;
@@ -2464,7 +2465,7 @@ int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
 // (host logic only; tests/sched_sim.py executes all ranks' programs on the CPU).  Returns the needed length.
 int xmpi_sched_dump(int sched, int form, int in_place, int size, int rank, int root, int pieces, size_t count, size_t elem_size, int nchan,
                     int channel, char* out, size_t cap) {
-  if (size < 1 || size > kMaxRanks || rank < 0 || rank >= size || root < 0 || root >= size || elem_size < 1 || nchan < 1 ||
+  if (size < 1 || size > kDsyncRanks || rank < 0 || rank >= size || root < 0 || root >= size || elem_size < 1 || nchan < 1 ||
       nchan > kMaxSchedChannels || channel < 0 || channel >= nchan || sched < SCHED_RING_ALLREDUCE || sched > SCHED_TREE_REDUCE ||
       form < 0 || form > 1 || (sched == SCHED_TREE_REDUCE && pieces > 127))  // (a step number must fit the low byte of a flag word)
     return XMPI_ERR_ARG;
@@ -2485,7 +2486,7 @@ int xmpi_sched_dump(int sched, int form, int in_place, int size, int rank, int r
     for (int i = 0; i < size; i++) a.order[ch][i] = (uint8_t)ord[(size_t)i];
   }
   // recognisable addresses: rank r's send / receive buffer / landing block = ((r+1) << 44) | (kind << 42) | 2^41 (+ a signed offset)
-  uint64_t send[kMaxRanks], recv[kMaxRanks], land[kMaxRanks];
+  uint64_t send[kDsyncRanks], recv[kDsyncRanks], land[kDsyncRanks];
   auto fake = [](int r, int kind) { return ((uint64_t)(r + 1) << 44) | ((uint64_t)kind << 42) | (1ull << 41); };
   for (int r = 0; r < size; r++) {
     // in place: the send buffer IS the receive buffer (tree reduce: at the root only -- nobody else has one; allgather: the
@@ -2538,7 +2539,7 @@ int xmpi_sched_dump(int sched, int form, int in_place, int size, int rank, int r
 }
 
 size_t xmpi_sched_land_bytes(int sched, int in_place, int size, int rank, int root, size_t count, size_t elem_size) {
-  if (size < 1 || size > kMaxRanks || rank < 0 || rank >= size || root < 0 || root >= size) return 0;
+  if (size < 1 || size > kDsyncRanks || rank < 0 || rank >= size || root < 0 || root >= size) return 0;
   DsyncSchedArgs a;
   memset(&a, 0, sizeof a);
   a.d.me = rank;

@@ -239,6 +239,8 @@ struct xmpi_comm {
     std::vector<void*> bufs;
   };
   std::vector<DsyncDeferred> dsync_deferred;  // arena blocks lent to collectives still on a stream
+  std::vector<void*> dsync_leaked;            // ... whose event could not even be recorded: given back at finalize
+  uint64_t dsync_selftest_token = 0;          // what xmpi_init's flag self-test left in the peers' pages (0: it did not run)
   struct DsyncProf {
     hipEvent_t start, stop;
     size_t bytes;

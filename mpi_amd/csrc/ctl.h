@@ -14,7 +14,11 @@
 
 namespace xmpi {
 
-constexpr int kMaxRanks = 8;  // one node of eight MI355X, one rank per GPU (the device side is sized by it: kernels.h kDsyncRanks)
+// A job has at most 16 ranks (the reference takes len(addrs): network.go:94-109).  The DEVICE side -- flag pages, the kernels'
+// tables -- is sized for the machine this is written for, one node of eight MI355X with one rank per GPU (kernels.h kDsyncRanks = 8:
+// registers and LDS of the hot kernels); a job of 9 .. 16 ranks (two per GPU, say) runs on the generic path: its ranks meet on the
+// host (zcopy.cpp's rendezvous, the step tables through the windows), whose tables are sized by this constant.
+constexpr int kMaxRanks = 16;
 constexpr int kMaxLanes = 4;
 constexpr int kMailEntries = 4;  // concurrent messages per ordered rank pair
 constexpr int kHostLaneSlots = 4;  // pieces of a host-resident payload in flight per mail entry (the host lanes, below)

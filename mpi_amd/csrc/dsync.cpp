@@ -31,7 +31,7 @@
 
 namespace xmpi {
 
-static_assert(kDsyncRanks == kMaxRanks, "dsync tables are sized by kMaxRanks");
+static_assert(kDsyncRanks <= kMaxRanks, "the device side serves a subset of the jobs the host side admits");
 static_assert(sizeof(DsyncPage) <= kStepOff, "flag page");
 constexpr size_t kPageBytes = kDsyncPageBytes;  // the page, the step flags of the stepped kernels, the Send / Receive boxes
 
@@ -47,7 +47,7 @@ void idle_hook(void* arg) { dsync_service((xmpi_comm*)arg); }
 int dsync_prepare(xmpi_comm* c) {
   RankInfo* me = c->ctl->info(c->rank);
   me->flag_addr = 0;
-  if (c->size < 2 || !c->dsync) return XMPI_OK;
+  if (c->size < 2 || !c->dsync || c->size > kDsyncRanks) return XMPI_OK;  // (more ranks than the device side is sized for: they meet on the host)
   // a rank without a flag page does not fail the job: every rank sees flag_addr == 0 and keeps to the host-synchronised path;
   // it says why (xmpi_degraded)
   auto none = [&](const char* what, hipError_t e) {
@@ -101,7 +101,7 @@ int dsync_connect(xmpi_comm* c, double timeout_s) {
   if (c->size < 2) return XMPI_OK;
   const int N = c->size, mypid = (int)getpid();
   RankInfo* me = c->ctl->info(c->rank);
-  bool usable = true;
+  bool usable = N <= kDsyncRanks;
   int sharers = 0, sharers_job = 1;
   for (int p = 0; p < N; p++) {
     const RankInfo* a = c->ctl->info(p);
@@ -151,10 +151,21 @@ int dsync_connect(xmpi_comm* c, double timeout_s) {
   // a peer's 8-byte store to the lane that polls it here.  Try it now, with a clock (a few seconds, inside xmpi_init), rather than
   // find out in the first collective, which by default waits for ever: every rank stores a token into every peer's page and waits
   // for theirs.  A rank whose words do not arrive votes "flags: no" below, and the job meets on the host.
+  // The ranks get here after unsynchronised work (seven hipIpcOpenMemHandle calls, the registration of the control block,
+  // hipMallocs): the self-test's clock is to measure whether the flags carry a store, not how far apart the ranks arrive -- so
+  // they meet first.  Every rank, whatever it could map: a barrier only some ranks reach is a hang.
+  {
+    const int brc = c->ctl->barrier(timeout_s);
+    if (brc != XMPI_OK) {
+      set_last_error("xmpi_init: a peer did not reach the flag self-test");
+      return brc;
+    }
+  }
   if (mapped && c->dsync_status_dev) {
     uint64_t token = 0;
     for (int p = 0; p < N; p++) token = std::max(token, c->ctl->info(p)->flag_epoch);
     token += 1;  // (above every token an earlier communicator left in these never-cleared pages: dsync_finalize moves the mark on)
+    c->dsync_selftest_token = token;  // ... this one included, whatever the vote below says (dsync_finalize)
     const double limit_s = std::min(5.0, std::max(1.0, timeout_s / 4));
     __atomic_store_n(c->dsync_status + 12, 0u, __ATOMIC_RELAXED);
     hipError_t e = launch_flag_selftest(c->peer_page, c->rank, N, token, (uint64_t)(limit_s * 1e8), c->dsync_abort_dev, c->dsync_status_dev + 12,
@@ -329,6 +340,9 @@ void dsync_finalize(xmpi_comm* c) {
   uint64_t last = c->dsync_epoch;
   if (c->ctl) last = std::max<uint64_t>(last, c->ctl->info(c->rank)->flag_epoch);  // (a communicator that never got going)
   if (c->dsync_status) last = std::max<uint64_t>(last, __atomic_load_n((const uint64_t*)(c->dsync_status + 2), __ATOMIC_ACQUIRE));
+  // the flag self-test's token lies in the peers' (never cleared) pages whatever the vote said: the next communicator's token -- and
+  // epochs -- start above it, or a stale token would pass a self-test no store arrived for
+  last = std::max<uint64_t>(last, c->dsync_selftest_token);
   last += 1;  // every communicator gets a number of its own (dsync_tag = base + 1), also one that never ran a collective: the
               // tag marks its translation-cache entries and its Send / Receive message numbers in the (uncleared) page
   for (auto& p : c->dsync_prof_pending) {
@@ -356,6 +370,8 @@ void dsync_finalize(xmpi_comm* c) {
     for (void* p : b.bufs) (void)heap_free(p);
   }
   c->dsync_deferred.clear();
+  for (void* p : c->dsync_leaked) (void)heap_free(p);
+  c->dsync_leaked.clear();
   if (c->land_block) (void)heap_free(c->land_block);
   c->land_block = nullptr;
   c->land_block_bytes = 0;
@@ -985,9 +1001,23 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
   r.send = sendbuf;
   r.recv = recv_significant ? recvbuf : const_cast<void*>(sendbuf);
   const bool in_place = sendbuf == recvbuf;
-  std::vector<void*> lent;
+  std::vector<void*> lent, outgrown;
+  // what may still be in use by collectives enqueued EARLIER goes back behind an event on the stream (or, failing that, at finalize)
+  auto defer_free = [&](std::vector<void*>& bufs) {
+    if (bufs.empty()) return;
+    xmpi_comm::DsyncDeferred d;
+    if (hipEventCreateWithFlags(&d.done, hipEventDisableTiming) == hipSuccess && hipEventRecord(d.done, stream) == hipSuccess) {
+      d.bufs = bufs;
+      c->dsync_deferred.push_back(d);
+    } else {
+      (void)hipGetLastError();
+      for (void* p : bufs) c->dsync_leaked.push_back(p);  // given back by dsync_finalize
+    }
+    bufs.clear();
+  };
   auto fail = [&](int rc) {
     for (void* p : lent) (void)heap_free(p);
+    defer_free(outgrown);
     c->ctl->set_abort(rc);
     return rc;
   };
@@ -1037,7 +1067,9 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
   // exported and mapped by every peer per step -- 100 ms instead of 9).
   auto own_block = [&](size_t bytes) -> void* {
     if (!c->land_block || c->land_block_bytes < bytes) {
-      if (c->land_block) lent.push_back(c->land_block);  // (goes back once THIS collective's kernel -- behind every earlier one -- has passed)
+      // the outgrown block goes back once THIS collective's kernel -- behind every earlier one -- has passed.  Not through `lent`:
+      // a failure path gives `lent` back at once, and earlier ENQUEUED collectives may still be landing in this block
+      if (c->land_block) outgrown.push_back(c->land_block);
       c->land_block = heap_alloc(c->device, bytes);
       c->land_block_bytes = c->land_block ? bytes : 0;
     }
@@ -1394,6 +1426,8 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
   if (!blocking) {
     if (pstart) c->dsync_prof_pending.push_back({pstart, pstop, traffic});
     if (out_src) DS_HIP(hipMemcpyAsync(recvbuf, out_src, recv_bytes, hipMemcpyDeviceToDevice, stream));
+    lent.insert(lent.end(), outgrown.begin(), outgrown.end());
+    outgrown.clear();
     if (!lent.empty()) {
       xmpi_comm::DsyncDeferred d;
       if (hipEventCreateWithFlags(&d.done, hipEventDisableTiming) != hipSuccess) return fail(XMPI_ERR_HIP);
@@ -1406,6 +1440,8 @@ int dsync_collective(xmpi_comm* c, int coll, int root, const void* sendbuf, void
 
   rc = wait_blocking(c, stream, done_dev != nullptr, done_id);
   if (rc != XMPI_OK) return fail(rc);
+  lent.insert(lent.end(), outgrown.begin(), outgrown.end());  // (the stream has passed this collective, and with it every earlier one)
+  outgrown.clear();
   if (c->api_calls.load(std::memory_order_relaxed) == calls_at_entry) c->agent_quiet_at = calls_at_entry;  // (as in dsync_ll: the next blocking small collective need not ask the streams)
   if (host_out) {
     memcpy(recvbuf, c->host_bounce + xmpi_comm::kHostBounce, recv_bytes);

@@ -1099,7 +1099,11 @@ int p2p_send(xmpi_comm* c, const void* buf, size_t bytes, int dtype, int dest, i
   }
   // A registered source (xmpi_malloc / xmpi_register) is offered to the receiver, which then copies
   // straight out of it: one pass over the data and one xGMI crossing instead of slot-in + slot-out.
-  const bool offered = wait_ack && dev_now && c->p2p_direct_bytes >= 0 && bytes >= (size_t)std::max<long>(1, c->p2p_direct_bytes) &&
+  // (A job without windows has no mail slots: the offer is the ONLY way a device payload travels there, whatever p2p_direct_bytes
+  // says -- "always through the mail slots" (< 0) or a threshold above this message would leave the receiver waiting for slots
+  // nobody fills, for ever by default.)
+  const bool must_offer = !c->windows_ok && bytes > 0;
+  const bool offered = wait_ack && dev_now && (must_offer || (c->p2p_direct_bytes >= 0 && bytes >= (size_t)std::max<long>(1, c->p2p_direct_bytes))) &&
                        zc_export(c, buf, bytes, &m->src);
   m->direct.store(offered ? DIRECT_OFFERED : DIRECT_NONE, std::memory_order_relaxed);
   m->state.store(MAIL_POSTED, std::memory_order_release);
@@ -1530,6 +1534,12 @@ int p2p_recv(xmpi_comm* c, void* buf, size_t cap_bytes, int dtype, int src, int 
       return XMPI_ERR_UNSUPPORTED;
     }
     m->direct.store(DIRECT_DECLINED, std::memory_order_release);  // host destination / not mappable: use the slots
+  }
+  if (!c->windows_ok && bytes > 0) {  // a message that was not even offered (a sender of another mind): there are no slots to wait on
+    set_last_error("receive: the message was posted for the mail slots, which this job does not have (xmpi_degraded)");
+    m->status.store(XMPI_ERR_UNSUPPORTED, std::memory_order_release);
+    m->state.store(MAIL_DONE, std::memory_order_release);
+    return XMPI_ERR_UNSUPPORTED;
   }
   __atomic_fetch_add(&c->p2p_staged_count, 1, __ATOMIC_RELAXED);
   const size_t slot = c->p2p_slot_bytes;

@@ -72,7 +72,7 @@ void set_grid_cap(int cap);
 // that this rank's buffers are ready and where they are, waits until every peer said the same, moves the
 // data straight between the user buffers, and leaves only after every peer has finished reading this
 // rank's input and writing its output.  The host enqueues it on a stream and never polls.
-constexpr int kDsyncRanks = 8;    // = kMaxRanks of ctl.h: the machine is one node of eight GPUs, one rank per GPU
+constexpr int kDsyncRanks = 8;    // the machine is one node of eight GPUs, one rank per GPU; larger jobs (<= kMaxRanks of ctl.h) meet on the host
 constexpr int kDsyncArenas = 32;  // live allocations of one peer this rank can translate
 
 // written by ONE peer (slot p of rank q's page by rank p), read by the owner's kernels

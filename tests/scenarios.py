@@ -165,7 +165,7 @@ def allgather_case(comm, dtype, count, algo, inplace=False):
 def sc_allgather(comm, args):
     for dtype in (xmpi.I64, xmpi.U8, xmpi.F32):
         for algo in (xmpi.ALGO_RING, xmpi.ALGO_DIRECT, xmpi.ALGO_AUTO):
-            for count in (0, 1, 5, 1000, 4099, (1 << 20) + 3):
+            for count in args.get("counts", (0, 1, 5, 1000, 4099, (1 << 20) + 3)):
                 allgather_case(comm, dtype, count, algo)
     allgather_case(comm, xmpi.I64, 70001, xmpi.ALGO_RING, inplace=True)
     allgather_case(comm, xmpi.I64, 70001, xmpi.ALGO_DIRECT, inplace=True)

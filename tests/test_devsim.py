@@ -166,9 +166,21 @@ SCENARIOS = [
 ]
 
 
+# More ranks than the device side is sized for (kernels.h kDsyncRanks = 8: one node, one rank per GPU; the job limit is ctl.h
+# kMaxRanks = 16 -- the reference takes len(addrs), network.go:94-109): 9 .. 16 ranks, two per virtual GPU, run on the generic path
+# -- the ranks meet on the host (zcopy.cpp's rendezvous with up to 16 sources per fold, the step tables through the windows) --
+# and every result still matches the oracle.  Not a degradation (get_param("degraded") stays 0) and no device-synchronised form.
+SCENARIOS += [
+    ("allreduce_small", 9, {"counts": [1, 1000, 4099], "dtypes": [4, 2], "expect_params": {"dsync": 0, "degraded": 0}}),
+    ("bcast_reduce", 11, {"expect_params": {"dsync": 0}}),
+    ("allgather", 12, {"counts": [0, 1, 1000, 4099, 65536 + 3], "expect_params": {"dsync": 0}}),
+    ("helloworld", 16, {"expect_params": {"dsync": 0, "degraded": 0}}),
+]
+
+
 @pytest.mark.parametrize("scenario,size,args", SCENARIOS, ids=[f"{s}-{n}" for s, n, _ in SCENARIOS])
 def test_gpu_scenarios_on_virtual_devices(devsim_lib, scenario, size, args):
-    run_ranks(scenario, size, args, timeout=600)
+    run_ranks(scenario, size, args, timeout=600, env={"DEVSIM_DEVICES": "8"} if size > 8 else None)
 
 
 DEGRADED = [
