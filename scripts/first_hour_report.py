@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """What scripts/profile_8gpu.sh left behind, read in the order DESIGN.md section 0 says to read it:
 
-    python scripts/first_hour_report.py [profiles/r05_8gpu]
+    python scripts/first_hour_report.py [profiles/r06_8gpu]
 
 One screen: did the job degrade; what one link gives each engine, reads against writes; what the library's tuner chose; every
 schedule by name against the time its busiest link direction needs at 76.8 GB/s (fold 0.25 S, ring 0.292 S,
@@ -31,7 +31,7 @@ def last_json(path):
 
 def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "profiles", "r05_8gpu")
+    d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "profiles", "r06_8gpu")
     lines = glob.glob(os.path.join(d, "bench_n*.json"))
     line = next((x for x in (last_json(f) for f in sorted(lines) if not f.endswith("_extras.json")) if x), None)
     print(f"== {d}")
@@ -54,6 +54,8 @@ def main():
                 verdict = "reads and writes alike" if 0.85 < r / w < 1.18 else ("READS SLOWER: the push forms / push-only should win" if r < w else "writes slower: the pull forms should win")
                 print(f"   link probe {eng:15s} write {w:7.1f}  read {r:7.1f}  both ways {probe.get(eng + '_bidir_each_GBps', 0):7.1f} GB/s  -> {verdict}")
         print("   the tuner chose:", line["config"].get("tuned"))
+        # (xmpi_tune checks every candidate's ANSWER on patterned inputs before it believes its time: a schedule wrong on any rank is out on every rank)
+        print("   schedules whose answers the library found WRONG on this node:", (line["config"].get("tuned") or {}).get("rejected", "none"))
         ex = last_json(os.path.join(d, f"bench_n{n}_extras.json")) or {}
         for coll, row in ((ex.get("autotune") or {}).get("tables_other") or {}).items():
             print(f"      {coll:9s} 1 KiB, 4 KiB ... :", " ".join(row))
@@ -68,7 +70,8 @@ def main():
             continue
         S = p["bytes_per_rank"]
         print(f"3. {os.path.basename(f)}: {p['ranks']} ranks x {S >> 20 if S >= 1 << 20 else S / 1048576:g} MiB, exact = {p.get('exact')}, sharers {p.get('sharers')}, "
-              f"XCD masks meet / done {p.get('xcd_meet_mask'):#x} / {p.get('xcd_done_mask'):#x} (short launches: {p.get('xcd_short')}), body_sys {p.get('body_sys')}")
+              f"XCD masks meet / done {p.get('xcd_meet_mask'):#x} / {p.get('xcd_done_mask'):#x} (short launches: {p.get('xcd_short')}), body_sys {p.get('body_sys')}; "
+              f"self-check at init {p.get('init_selfcheck_us')} us, schedules rejected {p.get('tune_rejected')}, degraded {p.get('degraded')}")
         for row in p["rows"]:
             share = SHARE.get(row["mode"])
             bound_us = share * S / (DIR_GBPS * 1e9) * 1e6 if share else None

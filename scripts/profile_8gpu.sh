@@ -1,6 +1,6 @@
 #!/bin/bash
 # One command for an 8-GPU MI355X node: the SCALE line plus the link roofline and per-rank kernel evidence.
-# Run from the repo root; writes under profiles/r05_8gpu/ (small files only).
+# Run from the repo root; writes under profiles/r06_8gpu/ (small files only).
 #   bash scripts/profile_8gpu.sh [N=8]
 # 1. bench.py --gpus N under torch.distributed.run (one process per GPU, ranks meet on the device): the compact JSON line with
 #    value = algbw @ 256 MiB f32, busbw, `xgmi` {link_probe taken before anything is tuned: SDMA vs copy kernel, write / read /
@@ -22,7 +22,7 @@
 set -x
 N=${1:-8}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-O=${XMPI_8GPU_OUT:-$ROOT/profiles/r05_8gpu}
+O=${XMPI_8GPU_OUT:-$ROOT/profiles/r06_8gpu}
 mkdir -p $O
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0 XMPI_TIMEOUT_S=${XMPI_TIMEOUT_S:-120}
 BIN=$ROOT/mpi_amd/bin

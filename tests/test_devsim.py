@@ -492,7 +492,7 @@ def test_the_8gpu_script_rehearsal(stage, devsim_lib, tmp_path):
     # ... and the one-screen reading of it names what the first hour on a node has to look at
     rep = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "first_hour_report.py"), out], capture_output=True, text=True, timeout=120)
     assert rep.returncode == 0, rep.stderr[-2000:]
-    for needle in ("degraded: no", "link roofline: schedule", "link probe sys_kernel", "the tuner chose", "bcast     1 KiB", "reduce    1 KiB", "ring by name, pull", "ring by name, push",
+    for needle in ("degraded: no", "link roofline: schedule", "link probe sys_kernel", "the tuner chose", "found WRONG on this node: none", "self-check at init", "schedules rejected 0", "bcast     1 KiB", "reduce    1 KiB", "ring by name, pull", "ring by name, push",
                    "ring_push", "rhd_push", "XCD masks meet / done 0xff / 0xff", "link bound", "cfg 5"):
         assert needle in rep.stdout, (needle, rep.stdout[-3000:])
 
