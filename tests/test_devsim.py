@@ -439,8 +439,9 @@ def test_the_scale_command_as_a_lone_process(devsim_lib, gpus, tmp_path):
                XMPI_TIMEOUT_S="60", XMPI_BENCH_EXTRAS_DIR=str(tmp_path))
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
         env.pop(k, None)
+    # (--no-probe: the child-process probe of every schedule is the torchrun form's test above; here: the lone process' own path)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--size-mib", "0.25", "--no-cpu",
-                        "--no-production"], capture_output=True, text=True, timeout=900, cwd=str(tmp_path), env=env)
+                        "--no-production", "--no-probe"], capture_output=True, text=True, timeout=900, cwd=str(tmp_path), env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
