@@ -681,6 +681,41 @@ static void note_rejections(xmpi_comm* c, const char* who, const std::string& wh
   if (c->rank == 0) fprintf(stderr, "xmpi: degraded: %s\n", text.c_str());
 }
 
+// Send / Receive out of registered HBM straight into HBM -- the receiver's kernel LOADS the payload out of the sender's memory (the
+// lingering receive agent up to 512 KiB, the pull kernel above: engine.cpp p2p_recv) --: every rank sends `bytes` of its pattern to its
+// right neighbour and counts what differs in what its left one sent (even ranks send first, odd ranks receive first: the blocking
+// pair is a rendezvous, network.go:569).  Collective.
+static int p2p_check_round(xmpi_comm* c, AnswerCheck& chk, size_t bytes, uint64_t* bad) {
+  const int N = c->size, right = (c->rank + 1) % N, left = (c->rank + N - 1) % N;
+  const int tag = 0x7fff5c5c;
+  hipStream_t s = c->local_stream;
+  *bad = 0;
+  int rc = job_barrier(c);
+  if (rc != XMPI_OK) return rc;
+  XMPI_HIP(launch_fill(chk.expect, bytes / 4, XMPI_F32, kCheckPattern, kCheckSeed + (uint64_t)left, s));
+  XMPI_HIP(hipMemsetAsync(chk.recv, 0xA5, bytes, s));
+  XMPI_HIP(hipStreamSynchronize(s));
+  chk.have_coll = -1;
+  size_t got = 0;
+  if (c->rank % 2 == 0) {
+    rc = p2p_send(c, chk.send, bytes, XMPI_F32, right, tag);
+    if (rc == XMPI_OK) rc = p2p_recv(c, chk.recv, bytes, XMPI_F32, left, tag, &got);
+  } else {
+    rc = p2p_recv(c, chk.recv, bytes, XMPI_F32, left, tag, &got);
+    if (rc == XMPI_OK) rc = p2p_send(c, chk.send, bytes, XMPI_F32, right, tag);
+  }
+  if (rc != XMPI_OK) return rc;
+  if (got != bytes) {
+    *bad = bytes;
+    return XMPI_OK;
+  }
+  XMPI_HIP(hipMemsetAsync(c->dev_words, 0, 32, s));
+  XMPI_HIP(launch_count_mismatch(chk.recv, chk.expect, bytes, c->dev_words, s));
+  XMPI_HIP(hipMemcpyAsync(bad, c->dev_words, 8, hipMemcpyDeviceToHost, s));
+  XMPI_HIP(hipStreamSynchronize(s));
+  return XMPI_OK;
+}
+
 // xmpi_init's self-check (XMPI_SELFCHECK; default: on when the ranks sit on different GPUs): what UNTUNED AUTO can reach -- LL lines
 // up to ll_bytes, the one-kernel fold, meet / body / done -- runs once, multi-tile, on patterned inputs before the first caller's
 // data does; the other three collectives' folds ride along.  A job that tunes (xmpi_tune, XMPI_AUTOTUNE_BYTES) checks every
@@ -692,11 +727,12 @@ static int init_selfcheck(xmpi_comm* c) {
   // zc_bcast_push_bytes, where every rank forwards its chunk
   const size_t kFold = (size_t)128 << 10, kSplit = (size_t)256 << 10;
   const size_t kBcast = (size_t)std::max<long>(0, c->zc_bcast_push_bytes) + 16384 <= kSplit * 2 ? (size_t)std::max<long>(0, c->zc_bcast_push_bytes) + 16384 : kSplit;
+  const size_t kP2PShort = (size_t)64 << 10, kP2PLong = (size_t)768 << 10;  // the receive agent's side of its 512 KiB limit, and the pull kernel's
   AnswerCheck chk;
   int rc;
   {
     std::lock_guard<std::mutex> g(c->coll_mu);
-    rc = chk.open(c, std::max(kSplit, kBcast));
+    rc = chk.open(c, std::max(std::max(kSplit, kBcast), kP2PLong));
   }
   if (rc != XMPI_OK) return rc;
   XMPI_TRACE_STEP(c->rank, "self-check: buffers ready");
@@ -763,13 +799,41 @@ static int init_selfcheck(xmpi_comm* c) {
         fold_wrong = true;
       }
     }
+    if (rc != XMPI_OK) break;
+    // Send / Receive: the receiver's direct pull out of the sender's registered memory, short (agent) and long (pull kernel).  Wrong:
+    // the messages travel through the mail slots of the windows instead (p2p_direct_bytes < 0: pushed by the sender's copy engine,
+    // drained locally -- two copies, no load over a link), checked in turn; wrong again, or no windows: xmpi_init fails on every rank.
+    for (int attempt = 0; attempt < 2 && rc == XMPI_OK; attempt++) {
+      uint64_t mine[2] = {0, 0}, worst[2] = {0, 0};
+      if ((rc = p2p_check_round(c, chk, kP2PShort, &mine[0])) != XMPI_OK) break;
+      if ((rc = p2p_check_round(c, chk, kP2PLong, &mine[1])) != XMPI_OK) break;
+      if ((rc = vote_max(c, nullptr, mine, 2, nullptr, worst)) != XMPI_OK) break;
+      if (!worst[0] && !worst[1]) break;
+      char t[240];
+      snprintf(t, sizeof t, "Send / Receive: %s gives wrong answers on this machine (%llu of %zu / %llu of %zu bytes differ on the worst rank)",
+               attempt == 0 ? "the receiver's direct pull out of the sender's registered memory" : "the mail slots too", (unsigned long long)worst[0], kP2PShort,
+               (unsigned long long)worst[1], kP2PLong);
+      why += std::string(why.empty() ? "" : "; ") + t;
+      if (attempt == 0 && c->windows_ok && c->p2p_direct_bytes >= 0) {
+        c->p2p_direct_bytes = -1;
+        c->p2p_rejected |= 1u;
+        why += ": messages travel through the mail slots";
+        continue;
+      }
+      c->p2p_rejected |= 2u;
+      set_last_error("xmpi_init self-check: " + why + ": no way left to move a message between GPUs that gives right answers");
+      rc = XMPI_ERR_HIP;
+    }
   } while (false);
   c->tune_running = false;
   {
     std::lock_guard<std::mutex> g(c->coll_mu);
     chk.close();
   }
-  if (rc != XMPI_OK) return rc;
+  if (rc != XMPI_OK) {
+    if (c->rank == 0 && (c->p2p_rejected & 2u)) fprintf(stderr, "xmpi: %s\n", xmpi_last_error());
+    return rc;
+  }
   // an untuned job has no table to route round a wrong fold: the one-kernel fold is what every collective's AUTO comes down to
   note_rejections(c, "xmpi_init self-check", why, fold_wrong);
   c->selfcheck_ms = (now_seconds() - t_begin) * 1e3;
@@ -1967,6 +2031,7 @@ long xmpi_get_param(const xmpi_comm* c, const char* name) {
     return (coll >= 0 && coll < 4 && name[14] >= '0' && name[14] <= '3' && !name[15]) ? (long)c->tune_rejected[coll] : -1;
   }
   if (n == "selfcheck") return c->selfcheck;
+  if (n == "p2p_rejected") return (long)c->p2p_rejected;  // the self-check's verdict on Send / Receive: bit 0 the direct pull (-> mail slots), bit 1 everything
   if (n == "init_selfcheck_ms") return c->selfcheck_ms < 0 ? -1 : (long)(c->selfcheck_ms + 0.999);  // xmpi_init's self-check: -1 = did not run
   if (n == "init_selfcheck_us") return c->selfcheck_ms < 0 ? -1 : (long)(c->selfcheck_ms * 1e3);
   if (n == "init_selfcheck_setup_us") return c->selfcheck_ms < 0 ? -1 : (long)(c->selfcheck_setup_ms * 1e3);  // ... of which: its buffers (the job's first arena, the first kernel's code object)

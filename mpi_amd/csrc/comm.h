@@ -180,6 +180,7 @@ struct xmpi_comm {
   // inputs whose sum is exact in any association, compare with the locally computed result and vote: wrong on ANY rank = rejected on
   // EVERY rank).  A rejected schedule is never AUTO's choice again and a caller who names it is refused -- the same on every rank.
   uint32_t tune_rejected[4] = {0, 0, 0, 0};
+  uint32_t p2p_rejected = 0;     // ... and ways of moving a message (the self-check): bit 0 the receiver's direct pull, bit 1 every way
   bool tune_running = false;     // xmpi_tune / the self-check are running candidates themselves (no refusal)
   std::string rejected_why;      // which, where first, how wrong (also appended to degraded_why)
   long selfcheck = -1;           // xmpi_init checks what untuned AUTO can reach; XMPI_SELFCHECK (-1: when the ranks sit on different GPUs)

@@ -75,7 +75,9 @@ static bool process_alive(int pid, uint64_t start) {
   char path[64], buf[1024];
   snprintf(path, sizeof path, "/proc/%d/stat", pid);
   FILE* f = fopen(path, "r");
-  if (!f) return errno != ENOENT && errno != ESRCH;  // (no /proc to ask: assume it lives -- never a false alarm)
+  // no such entry: the process is gone (ranks that cannot see each other's /proc entries at all -- other pid namespaces -- never get
+  // here: xmpi_init tries every LIVE peer once and switches the watchdog off); any other failure to look: assume it lives
+  if (!f) return errno != ENOENT && errno != ESRCH;
   const size_t n = fread(buf, 1, sizeof buf - 1, f);
   fclose(f);
   buf[n] = 0;

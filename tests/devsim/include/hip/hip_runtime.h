@@ -52,17 +52,23 @@ struct KernelLaunch {
 void enqueue_kernel(hipStream_t stream, KernelLaunch&& k);
 
 // ---- DEVSIM_CORRUPT_FORM (runtime.cpp): a node that gets ONE kind of data access of ONE kernel wrong -------------------------------
-// The data accesses of the kernels that pass through a name a host compiler can redefine -- non-temporal stores (kdev.h stp<1>: the
-// fold kernels), the system-scope packet accessors (devsim/sys128.h: the stepped kernels, the split form's system-scope body) and
+// The data accesses of the kernels that pass through a name a host compiler can redefine -- non-temporal stores and loads (kdev.h
+// stp<1> / ldp<2>: the fold kernels, the Receive's copy kernels), the system-scope packet accessors (devsim/sys128.h: the stepped kernels, the split form's system-scope body) and
 // the 8-byte system-scope stores (LL lines) -- hand their value to corrupt_bits() first, which flips a bit when the running kernel,
 // the kind of access and the owner of the address are what the test asked for.  Off (one load of a flag) otherwise.
-enum { ACC_NT_STORE = 1, ACC_SYS_STORE = 2, ACC_SYS_LOAD = 4, ACC_FLAG_STORE = 8 };
+enum { ACC_NT_STORE = 1, ACC_SYS_STORE = 2, ACC_SYS_LOAD = 4, ACC_FLAG_STORE = 8, ACC_NT_LOAD = 16 };
 extern bool g_corrupt_armed;
 void corrupt_bits(const void* addr, void* value, unsigned bytes, int kind);
 template <typename T>
 inline void nt_store(T* p, T v) {
   if (g_corrupt_armed) corrupt_bits(p, &v, (unsigned)sizeof(T), ACC_NT_STORE);
   *p = v;
+}
+template <typename T>
+inline T nt_load(const T* p) {
+  T v = *p;
+  if (g_corrupt_armed) corrupt_bits(p, &v, (unsigned)sizeof(T), ACC_NT_LOAD);
+  return v;
 }
 template <typename A>
 inline auto sched_tag(const A& a, int) -> decltype((void)a.sched, (void)a.push, 0u) {
@@ -206,6 +212,7 @@ DEVSIM_FLAG_FN double a_add_double(double* p, double v) {
 #define __hip_atomic_compare_exchange_strong(p, expect, desired, so, fo, scope) ::devsim::a_cas(p, expect, desired)
 
 #define __builtin_nontemporal_store(v, p) ::devsim::nt_store(p, v)
+#define __builtin_nontemporal_load(p) ::devsim::nt_load(p)
 #define __builtin_amdgcn_s_sleep(n) ::devsim::yield_lane()
 #define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(order)
 #define __builtin_amdgcn_readfirstlane(v) (v)

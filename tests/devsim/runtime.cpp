@@ -681,6 +681,7 @@ void run_kernel(const KernelLaunch& k, int device) {
 //   ring | rhd | tree             dsync_sched_kernel, pull form of that schedule: what it LOADS from a peer
 //   ring_push | rhd_push | tree_push    ... push form: what it STORES into a peer
 //   ll         the LL kernels (launched and agent): the lines they store into the peers' flag allocations (data half of a line)
+//   p2p        the blocking Receive's copy kernels (the lingering agent, the pull kernel): what they LOAD out of the sender's memory
 // Found by xmpi_tune / xmpi_init's self-check, or not at all: that is the test (tests/test_devsim.py).
 namespace {
 struct CorruptSpec {
@@ -711,6 +712,7 @@ struct CorruptSpec {
     else if (f == "ring" || f == "ring_push") sched(1u << 1 | 1u << 3, f == "ring_push");
     else if (f == "rhd" || f == "rhd_push") sched(1u << 2, f == "rhd_push");
     else if (f == "tree" || f == "tree_push") sched(1u << 4 | 1u << 5, f == "tree_push");
+    else if (f == "p2p") names[0] = "p2p_agent_kernel", names[1] = "p2p_pull_kernel", kinds = ACC_NT_LOAD;
     else if (f == "ll") names[0] = "ll_reduce_kernel", names[1] = "ll_copy_kernel", names[2] = "ll_agent_kernel", kinds = ACC_FLAG_STORE, ll_lines = true;
     else {
       fprintf(stderr, "devsim: DEVSIM_CORRUPT_FORM=%s: no such form\n", e);

@@ -2721,6 +2721,22 @@ def sc_corrupt(comm, args):
         for root in sorted({0, size - 1}):
             bcast_case(comm, xmpi.I64, count, root, xmpi.ALGO_AUTO, what="bcast on the corrupt machine")
             reduce_case(comm, xmpi.I64, count, root, xmpi.ALGO_AUTO, what="reduce on the corrupt machine")
+    # Send / Receive out of registered HBM into HBM, short (the lingering agent copies) and long (the pull kernel): every rank sends its
+    # pattern to its right neighbour -- whatever way the library now moves a message (p2p_rejected), what arrives is what was sent
+    right, left = (rank + 1) % size, (rank + size - 1) % size
+    for n in (70001, 300007):
+        a, b = comm.alloc(n * 4), comm.alloc(n * 4)
+        comm.fill(a, n, xmpi.F32, xmpi.PAT_SIGNED, 900 + rank)
+        comm.memset(b, 0xA5, n * 4)
+        if rank % 2 == 0:
+            comm.send(a, n, xmpi.F32, right, 21)
+            comm.recv(b, n, xmpi.F32, left, 21)
+        else:
+            comm.recv(b, n, xmpi.F32, left, 21)
+            comm.send(a, n, xmpi.F32, right, 21)
+        assert b.download(np.float32, n).tobytes() == oracle.fill(n, xmpi.F32, xmpi.PAT_SIGNED, 900 + left).tobytes(), f"Send / Receive of {n} floats differs"
+        a.free()
+        b.free()
     # by name: the rejected ones are REFUSED on every rank alike (nobody hangs waiting for a rank that refused); every other one
     # still runs and is right
     calls = {0: lambda a, n: allreduce_case(comm, xmpi.F32, n, a, exact=False), 1: lambda a, n: allgather_case(comm, xmpi.I64, n, a),

@@ -249,6 +249,10 @@ SELFCHECK = [
     ("split_sys", {0: ["split"]}, {"level": 8, "params_after": {"dsync_split_bytes": 0}}, {"XMPI_KERNEL_MODE": "1"}),
     # the one-kernel fold wrong: an untuned job has no table to route round it -- the ranks meet on the host (level 2), every collective right
     ("fold", {0: ["fold"], 1: ["fold"], 2: ["fold"], 3: ["fold"]}, {"level": 8 | 2, "why": ["the ranks meet on the host"]}, {}),
+    # what the blocking Receive's copy kernels LOAD out of the sender's memory (agent and pull kernel): messages go through the mail
+    # slots instead (the sender's engine pushes, the receiver drains locally), checked in turn -- and every echo is right
+    ("p2p", {}, {"level": 8, "why": ["Send / Receive: the receiver's direct pull", "messages travel through the mail slots"],
+                 "params_after": {"p2p_rejected": 1, "p2p_direct_bytes": -1}}, {}),
 ]
 
 
