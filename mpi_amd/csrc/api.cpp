@@ -832,6 +832,7 @@ static int init_selfcheck(xmpi_comm* c) {
   }
   if (rc != XMPI_OK) {
     if (c->rank == 0 && (c->p2p_rejected & 2u)) fprintf(stderr, "xmpi: %s\n", xmpi_last_error());
+    if (!(c->p2p_rejected & 2u)) c->ctl->set_abort(rc);  // (a verdict every rank reached together needs no abort; a failure of this rank alone does)
     return rc;
   }
   // an untuned job has no table to route round a wrong fold: the one-kernel fold is what every collective's AUTO comes down to
@@ -2512,6 +2513,7 @@ int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
   c->tune_check_ms = chk.spent_s * 1e3;
   if (rc != XMPI_OK) {
     c->tuned = keep_tuned;
+    c->ctl->set_abort(rc);  // (the other ranks are in, or on their way to, a barrier of this very call: they must not wait for this one)
     return rc;
   }
   c->tuned = true;
