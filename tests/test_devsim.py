@@ -445,7 +445,7 @@ def test_the_scale_command_as_a_lone_process(devsim_lib, gpus, tmp_path):
         env.pop(k, None)
     # (--no-probe: the child-process probe of every schedule is the torchrun form's test above; here: the lone process' own path)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--size-mib", "0.25", "--no-cpu",
-                        "--no-production", "--no-probe"], capture_output=True, text=True, timeout=900, cwd=str(tmp_path), env=env)
+                        "--no-production", "--no-probe", "--no-extras"], capture_output=True, text=True, timeout=900, cwd=str(tmp_path), env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -453,8 +453,9 @@ def test_the_scale_command_as_a_lone_process(devsim_lib, gpus, tmp_path):
     assert d["n_gpus"] == gpus and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong"
     assert d["config"]["ranks"] == 8 and d["config"]["ranks_per_gpu"] == 8 // gpus
     assert d["parity"]["ok"] is True and d["parity_failures"] == 0 and d["value"] > 0
-    assert d["roofline"]["bound"] == "xgmi" and d["xgmi"]["meaningful"] is (gpus == 8)
+    assert d["roofline"]["bound"] == "xgmi"
     if gpus == 8:
+        assert d["xgmi"]["meaningful"] is True
         assert d["config"]["transport"] == "xGMI (one rank per GPU)" and d["ranks_meet"] == "on the device (dsync)" and d["config"]["tuned"]
         assert d["roofline_hbm"]["kernel"].startswith("dsync_") and d["ring"]["best"] in ("pull", "push")
         assert "rejected" not in d["config"]["tuned"]  # (the tuner checked every candidate's answer: nothing wrong on these devices)
