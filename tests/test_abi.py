@@ -146,11 +146,12 @@ def test_the_go_shim_calls_the_boundary_as_declared():
 
 
 def test_design_describes_head_and_history_lives_in_the_changelog():
-    """DESIGN.md is what the next hardware session reads first: what HEAD does, under 30 KB, no round-by-round history (that is
-    CHANGELOG.md's), the 8-GPU checklist at the top naming the one script (rehearsed on virtual GPUs by tests/test_devsim.py)"""
+    """DESIGN.md is what the next hardware session reads first: what HEAD does, under 36 KB (30 before the answer checks, the
+    self-check and the watchdog had to be described), no round-by-round history (that is CHANGELOG.md's), the 8-GPU checklist at the
+    top naming the one script (rehearsed on virtual GPUs by tests/test_devsim.py)"""
     import re
     text = open(os.path.join(ROOT, "DESIGN.md")).read()
-    assert len(text.encode()) < 30 * 1024, len(text.encode())
+    assert len(text.encode()) < 36 * 1024, len(text.encode())
     assert not re.search(r"\bround\s+\d", text, re.I), re.search(r"\bround\s+\d", text, re.I)
     assert "## 0. The first hour on an 8-GPU node" in text and "scripts/profile_8gpu.sh" in text
     for form in ("Fold, one kernel", "Fold, split", "Push-only", "Stepped kernels", "pull", "push", "LL lines", "LL agent", "Host rendezvous",
