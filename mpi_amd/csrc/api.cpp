@@ -464,6 +464,7 @@ static int collective(xmpi_comm* c, int coll, int algo, int root, const void* se
 const char* const kCandName[xmpi_comm::CAND_COUNT] = {"fold (one kernel)", "fold (one kernel, 2 packets in flight)", "split (meet / body / done)",
                                                       "push-only", "ring kernel", "halving kernel", "LL lines", "ring kernel, push form",
                                                       "halving kernel, push form", "tree kernel", "tree kernel, push form"};
+constexpr long kTuneTimeoutS = 20;  // no-progress limit of a candidate run in a job that otherwise waits for ever
 constexpr uint64_t kCheckSeed = 0x7A11D;
 constexpr int kCheckPattern = 3;
 
@@ -613,7 +614,11 @@ static bool tune_offered(const xmpi_comm* c, int coll, const TuneCand& cd) {
 // this rank's receive buffer that differ from the expected result.  Collective: every rank passes the same arguments.
 static int tune_measure(xmpi_comm* c, AnswerCheck& chk, const std::vector<TuneCand>& cands, int coll, size_t per_rank, const std::vector<int>& ks,
                         int iters, bool check, bool keep_min, double* us, uint64_t* bad) {
-  const long keep_split = c->dsync_split_bytes, keep_unroll = c->dsync_unroll;
+  const long keep_split = c->dsync_split_bytes, keep_unroll = c->dsync_unroll, keep_timeout = c->timeout_s;
+  // A candidate that HANGS on this machine (flag words that never arrive over a link, say) must not hang the job that merely asked
+  // which schedule is fastest: with the default "wait for ever" every wait of a candidate run -- host loops and waiting kernels -- has
+  // a no-progress limit of its own; the error names the candidate (leave it out with tune_mask, or set XMPI_TIMEOUT_S).
+  if (keep_timeout == 0) c->timeout_s = kTuneTimeoutS;
   int rc = XMPI_OK;
   for (size_t j = 0; j < ks.size() && rc == XMPI_OK; j++) {
     const int k = ks[j];
@@ -639,7 +644,12 @@ static int tune_measure(xmpi_comm* c, AnswerCheck& chk, const std::vector<TuneCa
     }
     c->dsync_split_bytes = keep_split;
     c->dsync_unroll = keep_unroll;
+    if (rc == XMPI_ERR_TIMEOUT && keep_timeout == 0)
+      set_last_error(std::string(coll_name(coll)) + " by " + kCandName[k] + " at " + std::to_string(per_rank) + " B per rank did not complete within " +
+                     std::to_string(kTuneTimeoutS) + " s while the library was checking / timing it on this machine (" + xmpi_last_error() +
+                     "): leave it out (xmpi_set_param \"tune_mask\") or give the job a no-progress limit (XMPI_TIMEOUT_S)");
   }
+  c->timeout_s = keep_timeout;
   return rc;
 }
 
@@ -697,6 +707,8 @@ static int p2p_check_round(xmpi_comm* c, AnswerCheck& chk, size_t bytes, uint64_
   XMPI_HIP(hipStreamSynchronize(s));
   chk.have_coll = -1;
   size_t got = 0;
+  const long keep_timeout = c->timeout_s;
+  if (keep_timeout == 0) c->timeout_s = kTuneTimeoutS;  // (as tune_measure: a message that never arrives is an error of the check, not a hang of Init)
   if (c->rank % 2 == 0) {
     rc = p2p_send(c, chk.send, bytes, XMPI_F32, right, tag);
     if (rc == XMPI_OK) rc = p2p_recv(c, chk.recv, bytes, XMPI_F32, left, tag, &got);
@@ -704,6 +716,7 @@ static int p2p_check_round(xmpi_comm* c, AnswerCheck& chk, size_t bytes, uint64_
     rc = p2p_recv(c, chk.recv, bytes, XMPI_F32, left, tag, &got);
     if (rc == XMPI_OK) rc = p2p_send(c, chk.send, bytes, XMPI_F32, right, tag);
   }
+  c->timeout_s = keep_timeout;
   if (rc != XMPI_OK) return rc;
   if (got != bytes) {
     *bad = bytes;
@@ -724,20 +737,19 @@ static int init_selfcheck(xmpi_comm* c) {
   const double t_begin = now_seconds();
   t_api_call = c->api_calls.fetch_add(1, std::memory_order_relaxed) + 1;  // (as a public call: XMPI_ENTER)
   // the diagnostic counters count the CALLER's traffic (tests and benchmarks read them as such): what the check itself moves is taken out again
+  // (NOT the agents' launch counts: they number the launches -- engine.cpp agent_submit -- and must go on counting)
   struct Counters {
-    uint64_t v[13];
+    uint64_t v[11];
   };
   auto counters = [&]() {
-    return Counters{{c->p2p_direct_count, c->p2p_staged_count, c->p2p_lane_count, c->p2p_agent_served, c->p2p_agent_launches, c->dsync_launches,
-                     c->dsync_ll_launches, c->dsync_ll_agent, c->ll_agent_launches, c->dsync_split_launches, c->dsync_sched_launches, c->dsync_bounced,
-                     c->host_bounce_calls}};
+    return Counters{{c->p2p_direct_count, c->p2p_staged_count, c->p2p_lane_count, c->p2p_agent_served, c->dsync_launches, c->dsync_ll_launches,
+                     c->dsync_ll_agent, c->dsync_split_launches, c->dsync_sched_launches, c->dsync_bounced, c->host_bounce_calls}};
   };
   const Counters before = counters();
   auto restore = [&]() {
-    uint64_t* const at[13] = {&c->p2p_direct_count, &c->p2p_staged_count, &c->p2p_lane_count, &c->p2p_agent_served, &c->p2p_agent_launches, &c->dsync_launches,
-                              &c->dsync_ll_launches, &c->dsync_ll_agent, &c->ll_agent_launches, &c->dsync_split_launches, &c->dsync_sched_launches,
-                              &c->dsync_bounced, &c->host_bounce_calls};
-    for (int k = 0; k < 13; k++) *at[k] = before.v[k];
+    uint64_t* const at[11] = {&c->p2p_direct_count, &c->p2p_staged_count, &c->p2p_lane_count, &c->p2p_agent_served, &c->dsync_launches, &c->dsync_ll_launches,
+                              &c->dsync_ll_agent, &c->dsync_split_launches, &c->dsync_sched_launches, &c->dsync_bounced, &c->host_bounce_calls};
+    for (int k = 0; k < 11; k++) *at[k] = before.v[k];
   };
   // several 4 KiB tiles per rank's chunk at 8 ranks (fold: 4; split: 8 one-tile blocks, one per XCD); bcast just above
   // zc_bcast_push_bytes, where every rank forwards its chunk
