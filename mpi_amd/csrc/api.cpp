@@ -737,19 +737,21 @@ static int init_selfcheck(xmpi_comm* c) {
   const double t_begin = now_seconds();
   t_api_call = c->api_calls.fetch_add(1, std::memory_order_relaxed) + 1;  // (as a public call: XMPI_ENTER)
   // the diagnostic counters count the CALLER's traffic (tests and benchmarks read them as such): what the check itself moves is taken out again
-  // (NOT the agents' launch counts: they number the launches -- engine.cpp agent_submit -- and must go on counting)
+  // (the receive agent's launches are NUMBERED by a counter of their own -- p2p_agent_launch_no, engine.cpp agent_submit -- which goes on counting)
   struct Counters {
-    uint64_t v[11];
+    uint64_t v[13];
   };
   auto counters = [&]() {
-    return Counters{{c->p2p_direct_count, c->p2p_staged_count, c->p2p_lane_count, c->p2p_agent_served, c->dsync_launches, c->dsync_ll_launches,
-                     c->dsync_ll_agent, c->dsync_split_launches, c->dsync_sched_launches, c->dsync_bounced, c->host_bounce_calls}};
+    return Counters{{c->p2p_direct_count, c->p2p_staged_count, c->p2p_lane_count, c->p2p_agent_served, c->p2p_agent_launches, c->dsync_launches,
+                     c->dsync_ll_launches, c->dsync_ll_agent, c->ll_agent_launches, c->dsync_split_launches, c->dsync_sched_launches, c->dsync_bounced,
+                     c->host_bounce_calls}};
   };
   const Counters before = counters();
   auto restore = [&]() {
-    uint64_t* const at[11] = {&c->p2p_direct_count, &c->p2p_staged_count, &c->p2p_lane_count, &c->p2p_agent_served, &c->dsync_launches, &c->dsync_ll_launches,
-                              &c->dsync_ll_agent, &c->dsync_split_launches, &c->dsync_sched_launches, &c->dsync_bounced, &c->host_bounce_calls};
-    for (int k = 0; k < 11; k++) *at[k] = before.v[k];
+    uint64_t* const at[13] = {&c->p2p_direct_count, &c->p2p_staged_count, &c->p2p_lane_count, &c->p2p_agent_served, &c->p2p_agent_launches, &c->dsync_launches,
+                              &c->dsync_ll_launches, &c->dsync_ll_agent, &c->ll_agent_launches, &c->dsync_split_launches, &c->dsync_sched_launches,
+                              &c->dsync_bounced, &c->host_bounce_calls};
+    for (int k = 0; k < 13; k++) *at[k] = before.v[k];
   };
   // several 4 KiB tiles per rank's chunk at 8 ranks (fold: 4; split: 8 one-tile blocks, one per XCD); bcast just above
   // zc_bcast_push_bytes, where every rank forwards its chunk

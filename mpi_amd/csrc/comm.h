@@ -149,6 +149,7 @@ struct xmpi_comm {
   bool agent_running = false;        // launched and not yet known to have gone
   hipStream_t agent_stream = nullptr;
   uint64_t p2p_agent_served = 0, p2p_agent_launches = 0;  // messages the agent copied; times it had to be launched
+  uint64_t p2p_agent_launch_no = 0;  // ... numbering those launches (P2PAgentArgs::launch): functional, never reset
   struct P2PPending {
     int slot;
     uint64_t id;

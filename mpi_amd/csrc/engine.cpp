@@ -783,7 +783,7 @@ static bool agent_submit(xmpi_comm* c, void* dst, const void* from, size_t bytes
     a.rec = c->p2p_rec;
     a.ctl_dev = (uint64_t)(uintptr_t)c->ctl_dev;
     a.seq0 = seq;
-    a.launch = (c->p2p_agent_launches + 1) & 0x7fffff;
+    a.launch = (c->p2p_agent_launch_no + 1) & 0x7fffff;
     a.alone_bytes = 64 << 10;
     a.patience_ticks = (uint64_t)c->p2p_agent_us * 100;  // wall_clock64 runs at 100 MHz
     a.mail_done_value = MAIL_DONE;
@@ -792,6 +792,7 @@ static bool agent_submit(xmpi_comm* c, void* dst, const void* from, size_t bytes
       return false;
     }
     c->agent_running = true;
+    c->p2p_agent_launch_no++;  // numbers the launches (never reset); p2p_agent_launches beside it is the caller's diagnostic count
     c->p2p_agent_launches++;
     return true;
   };
