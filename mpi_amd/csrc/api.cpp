@@ -464,6 +464,7 @@ static int collective(xmpi_comm* c, int coll, int algo, int root, const void* se
 const char* const kCandName[xmpi_comm::CAND_COUNT] = {"fold (one kernel)", "fold (one kernel, 2 packets in flight)", "split (meet / body / done)",
                                                       "push-only", "ring kernel", "halving kernel", "LL lines", "ring kernel, push form",
                                                       "halving kernel, push form", "tree kernel", "tree kernel, push form"};
+constexpr size_t kSecondPassBytes = (size_t)8 << 20;  // per rank: beyond, nothing of a buffer survives in an L2 (4 MiB per XCD) from one run to the next
 constexpr long kTuneTimeoutS = 20;  // no-progress limit of a candidate run in a job that otherwise waits for ever
 constexpr uint64_t kCheckSeed = 0x7A11D;
 constexpr int kCheckPattern = 3;
@@ -500,8 +501,8 @@ static int vote_max(xmpi_comm* c, const double* us, const uint64_t* bad, int n, 
 
 struct AnswerCheck {
   xmpi_comm* c = nullptr;
-  char *send = nullptr, *recv = nullptr, *expect = nullptr;
-  size_t cap = 0;          // bytes of each
+  char *send = nullptr, *recv = nullptr, *expect = nullptr, *expect2 = nullptr;
+  size_t cap = 0, cap2 = 0;  // bytes of each (expect2: the second pass is for messages a cache could still hold)
   int have_coll = -1;      // what `expect` holds
   size_t have_bytes = 0;
   double spent_s = 0;
@@ -512,7 +513,9 @@ struct AnswerCheck {
     send = (char*)heap_alloc(c->device, cap);
     recv = (char*)heap_alloc(c->device, cap);
     expect = (char*)heap_alloc(c->device, cap);
-    if (!send || !recv || !expect) {
+    cap2 = std::min(cap, kSecondPassBytes * (size_t)c->size);
+    expect2 = (char*)heap_alloc(c->device, cap2);
+    if (!send || !recv || !expect || !expect2) {
       close();
       set_last_error("xmpi_tune: out of device memory");
       return XMPI_ERR_NOMEM;
@@ -529,7 +532,8 @@ struct AnswerCheck {
     if (send) (void)heap_free(send);
     if (recv) (void)heap_free(recv);
     if (expect) (void)heap_free(expect);
-    send = recv = expect = nullptr;
+    if (expect2) (void)heap_free(expect2);
+    send = recv = expect = expect2 = nullptr;
   }
   size_t recv_bytes(int coll, size_t per_rank) const { return coll == COLL_ALLGATHER ? per_rank * (size_t)c->size : per_rank; }
   // `expect` = what `coll` over `per_rank` bytes per rank (root 0) must leave in the receive buffer.  The pattern is a function of
@@ -565,13 +569,36 @@ struct AnswerCheck {
     spent_s += now_seconds() - t0;
     return XMPI_OK;
   }
-  int verdict(int coll, size_t per_rank, uint64_t* bad) {
+  // The SECOND pass: the inputs change IN PLACE between two runs (every rank's buffer := 2 x itself, one local kernel; the expected
+  // result doubles with it, exactly) -- what a caller's buffers do from one step to the next.  A reader that still holds lines of a
+  // peer's buffer from the run before -- an L2 the schedule's acquire did not reach: the split form's once-per-XCD acquire is
+  // exactly that bet -- folds OLD data, and only a changed input shows it: the first run of a fresh buffer never can.  For messages a
+  // cache could still hold (kSecondPassBytes per rank); afterwards the inputs are what they were (refilled).
+  bool second_pass(int coll, size_t per_rank) const { return per_rank <= kSecondPassBytes && recv_bytes(coll, per_rank) <= cap2; }
+  int change_inputs(int coll, size_t per_rank) {
+    const double t0 = now_seconds();
+    hipStream_t s = c->local_stream;
+    if (coll != COLL_BCAST) XMPI_HIP(launch_reduce2(send, send, send, per_rank / 4, XMPI_F32, XMPI_SUM, s));
+    else if (c->rank == 0) XMPI_HIP(launch_reduce2(recv, recv, recv, per_rank / 4, XMPI_F32, XMPI_SUM, s));
+    XMPI_HIP(launch_reduce2(expect2, expect, expect, recv_bytes(coll, per_rank) / 4, XMPI_F32, XMPI_SUM, s));
+    spent_s += now_seconds() - t0;
+    return XMPI_OK;
+  }
+  int restore_inputs(int coll, size_t per_rank) {
+    const double t0 = now_seconds();
+    hipStream_t s = c->local_stream;
+    if (coll != COLL_BCAST) XMPI_HIP(launch_fill(send, per_rank / 4, XMPI_F32, kCheckPattern, kCheckSeed + (uint64_t)c->rank, s));
+    else if (c->rank == 0) XMPI_HIP(launch_fill(recv, per_rank / 4, XMPI_F32, kCheckPattern, kCheckSeed, s));
+    spent_s += now_seconds() - t0;
+    return XMPI_OK;
+  }
+  int verdict(int coll, size_t per_rank, uint64_t* bad, bool second = false) {
     *bad = 0;
     if (coll == COLL_REDUCE && c->rank != 0) return XMPI_OK;
     const double t0 = now_seconds();
     hipStream_t s = c->local_stream;
     XMPI_HIP(hipMemsetAsync(c->dev_words, 0, 32, s));
-    XMPI_HIP(launch_count_mismatch(recv, expect, recv_bytes(coll, per_rank), c->dev_words, s));
+    XMPI_HIP(launch_count_mismatch(recv, second ? expect2 : expect, recv_bytes(coll, per_rank), c->dev_words, s));
     XMPI_HIP(hipMemcpyAsync(bad, c->dev_words, 8, hipMemcpyDeviceToHost, s));
     XMPI_HIP(hipStreamSynchronize(s));
     spent_s += now_seconds() - t0;
@@ -636,7 +663,22 @@ static int tune_measure(xmpi_comm* c, AnswerCheck& chk, const std::vector<TuneCa
       if (i == 0) t0 = now_seconds();
       rc = dsync_collective(c, coll, 0, coll == COLL_BCAST ? chk.recv : chk.send, chk.recv, per_rank / 4, XMPI_F32, XMPI_SUM, c->local_stream,
                             /*blocking=*/i == -1 || i == iters - 1, cd.algo);
-      if (i == -1 && check && rc == XMPI_OK) rc = chk.verdict(coll, per_rank, &bad[k]);
+      if (i == -1 && check && rc == XMPI_OK) {
+        rc = chk.verdict(coll, per_rank, &bad[k]);
+        // ... and once more with the inputs changed in place -- whatever THIS rank's first verdict was: the ranks see different
+        // verdicts (a wrong byte lands in one rank's buffer), and a run only some of them make is a hang
+        if (rc == XMPI_OK && chk.second_pass(coll, per_rank)) {
+          uint64_t bad2 = 0;
+          rc = chk.change_inputs(coll, per_rank);
+          if (rc == XMPI_OK) rc = chk.arm(coll, per_rank);
+          if (rc == XMPI_OK)
+            rc = dsync_collective(c, coll, 0, coll == COLL_BCAST ? chk.recv : chk.send, chk.recv, per_rank / 4, XMPI_F32, XMPI_SUM, c->local_stream, true, cd.algo);
+          if (rc == XMPI_OK) rc = chk.verdict(coll, per_rank, &bad2, /*second=*/true);
+          // (every rank has left the run -- a blocking collective ends behind every peer's reads of this rank's buffers -- : refill)
+          if (rc == XMPI_OK) rc = chk.restore_inputs(coll, per_rank);
+          bad[k] = std::max(bad[k], bad2);
+        }
+      }
     }
     if (iters > 0) {
       const double t_us = (now_seconds() - t0) / iters * 1e6;

@@ -681,6 +681,10 @@ void run_kernel(const KernelLaunch& k, int device) {
 //   ring | rhd | tree             dsync_sched_kernel, pull form of that schedule: what it LOADS from a peer
 //   ring_push | rhd_push | tree_push    ... push form: what it STORES into a peer
 //   ll         the LL kernels (launched and agent): the lines they store into the peers' flag allocations (data half of a line)
+//   split_stale | fold_stale   the (non-temporal) LOADS of the split form's data kernel / the one-kernel fold from a peer's memory return
+//              what the FIRST load of that address returned -- an L2 that keeps lines of a peer's buffer across collectives because
+//              the schedule's acquire never reached it.  Invisible to a check that reads every buffer once; the check's second pass
+//              (the inputs changed in place) is there for exactly this
 //   p2p        the blocking Receive's copy kernels (the lingering agent, the pull kernel): what they LOAD out of the sender's memory
 // Found by xmpi_tune / xmpi_init's self-check, or not at all: that is the test (tests/test_devsim.py).
 namespace {
@@ -691,6 +695,7 @@ struct CorruptSpec {
   unsigned scheds = 0;  // bit per DsyncSched value; 0 = the kernel carries no schedule
   int push = -1;
   bool ll_lines = false;
+  bool stale = false;  // not a flipped bit: a load returns what the FIRST load of that address returned (a cache nobody invalidated)
   CorruptSpec() {
     const char* e = getenv("DEVSIM_CORRUPT_FORM");
     if (!e || !*e) return;
@@ -712,6 +717,8 @@ struct CorruptSpec {
     else if (f == "ring" || f == "ring_push") sched(1u << 1 | 1u << 3, f == "ring_push");
     else if (f == "rhd" || f == "rhd_push") sched(1u << 2, f == "rhd_push");
     else if (f == "tree" || f == "tree_push") sched(1u << 4 | 1u << 5, f == "tree_push");
+    else if (f == "split_stale") names[0] = "dsync_body_kernel", kinds = ACC_NT_LOAD, stale = true;
+    else if (f == "fold_stale") names[0] = "dsync_fold_kernel", kinds = ACC_NT_LOAD, stale = true;
     else if (f == "p2p") names[0] = "p2p_agent_kernel", names[1] = "p2p_pull_kernel", kinds = ACC_NT_LOAD;
     else if (f == "ll") names[0] = "ll_reduce_kernel", names[1] = "ll_copy_kernel", names[2] = "ll_agent_kernel", kinds = ACC_FLAG_STORE, ll_lines = true;
     else {
@@ -747,6 +754,21 @@ void corrupt_bits(const void* addr, void* value, unsigned bytes, int kind) {
     if (cs.ll_lines) {  // the LL slots of a flag allocation (kernels.h kLLOff = 1 MiB), not its flag words
       if (!(a->flags & (hipDeviceMallocUncached | hipDeviceMallocFinegrained)) || (uintptr_t)addr - (uintptr_t)a->base < ((uintptr_t)1 << 20)) return;
     }
+  }
+  if (cs.stale) {
+    static std::mutex mu;
+    static std::map<uintptr_t, std::array<unsigned char, 16>>* first = new std::map<uintptr_t, std::array<unsigned char, 16>>;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = first->find((uintptr_t)addr);
+    if (it == first->end()) {
+      std::array<unsigned char, 16> v{};
+      memcpy(v.data(), value, std::min<unsigned>(bytes, 16));
+      (*first)[(uintptr_t)addr] = v;
+    } else {
+      if (memcmp(value, it->second.data(), std::min<unsigned>(bytes, 16)) != 0) g_corrupted.fetch_add(1);
+      memcpy(value, it->second.data(), std::min<unsigned>(bytes, 16));
+    }
+    return;
   }
   (void)bytes;
   *reinterpret_cast<unsigned char*>(value) ^= 1u;

@@ -220,6 +220,13 @@ CORRUPT = [
     # ... in both forms: split leaves every table and the untuned rule (dsync_split_bytes 0)
     ("split_sys", {0: ["split"], 1: ["split"], 3: ["split"]}, {"why": ["its system-scope data kernel does too"], "params_after": {"body_sys": 0, "dsync_split_bytes": 0}},
      {"XMPI_KERNEL_MODE": "1"}),
+    # NOT a flipped bit: the data kernel's loads from a peer's memory return what the FIRST load of that address returned -- an L2 the
+    # once-per-XCD acquire never reached.  Every buffer read once: nothing to see; the check's SECOND pass (every rank's input changed in
+    # place between two runs) catches it -- and the system-scope data kernel, which no cache serves, takes over
+    ("split_stale", {}, {"level": 8 | 1, "why": ["its system-scope data kernel is right and takes over"], "params_after": {"body_sys": 1}}, {"XMPI_KERNEL_MODE": "1"}),
+    # ... the same in the one-kernel fold (its per-block acquire is what prevents this on a GPU): out where it LOADS from peers -- allreduce
+    # and reduce; push-only, allgather and bcast read local memory only and stay
+    ("fold_stale", {0: ["fold", "fold2"], 3: ["fold"]}, {}, {}),
     ("ring", {0: ["ring"], 1: ["ring"]}, {}, {}),            # what the ring kernel LOADS over a link (pull form)
     ("ring_push", {0: ["ring_push"], 1: ["ring_push"]}, {}, {}),  # ... STORES over a link (push form): the pull form stays
     ("rhd_push", {0: ["rhd_push"]}, {}, {}),
