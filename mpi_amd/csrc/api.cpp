@@ -464,7 +464,7 @@ static int collective(xmpi_comm* c, int coll, int algo, int root, const void* se
 const char* const kCandName[xmpi_comm::CAND_COUNT] = {"fold (one kernel)", "fold (one kernel, 2 packets in flight)", "split (meet / body / done)",
                                                       "push-only", "ring kernel", "halving kernel", "LL lines", "ring kernel, push form",
                                                       "halving kernel, push form", "tree kernel", "tree kernel, push form"};
-constexpr size_t kSecondPassBytes = (size_t)8 << 20;  // per rank: beyond, nothing of a buffer survives in an L2 (4 MiB per XCD) from one run to the next
+constexpr size_t kSecondPassBytes = (size_t)1 << 20;  // per rank: eight ranks' buffers of that size sit in the L2s (8 x 4 MiB) together from one run to the next
 constexpr long kTuneTimeoutS = 20;  // no-progress limit of a candidate run in a job that otherwise waits for ever
 constexpr uint64_t kCheckSeed = 0x7A11D;
 constexpr int kCheckPattern = 3;
@@ -506,16 +506,28 @@ struct AnswerCheck {
   int have_coll = -1;      // what `expect` holds
   size_t have_bytes = 0;
   double spent_s = 0;
+  uint64_t* host_word = nullptr;      // pinned: where a count reaches the host without a device-to-host copy (kernels.hip word_to_host_kernel)
+  uint64_t* host_word_dev = nullptr;
+  bool twice = true;       // the caller's say on the second pass (xmpi_tune: every other size class)
 
   int open(xmpi_comm* comm, size_t max_bytes) {
     c = comm;
     cap = max_bytes;
     send = (char*)heap_alloc(c->device, cap);
     recv = (char*)heap_alloc(c->device, cap);
-    expect = (char*)heap_alloc(c->device, cap);
+    // (the expected results are this rank's own business: plain device memory -- a block of a registered arena is exported and mapped
+    // by every peer, and four 256 MiB blocks per rank grew the arenas by a GiB each: 8 .. 33 s of mapping on a fresh box)
     cap2 = std::min(cap, kSecondPassBytes * (size_t)c->size);
-    expect2 = (char*)heap_alloc(c->device, cap2);
-    if (!send || !recv || !expect || !expect2) {
+    if (hipMalloc((void**)&expect, cap) != hipSuccess) expect = nullptr;
+    if (hipMalloc((void**)&expect2, cap2) != hipSuccess) expect2 = nullptr;
+    if (hipHostMalloc((void**)&host_word, 64, hipHostMallocMapped) == hipSuccess) {
+      void* dev = nullptr;
+      if (hipHostGetDevicePointer(&dev, host_word, 0) == hipSuccess) host_word_dev = (uint64_t*)dev;
+    } else {
+      host_word = nullptr;
+    }
+    (void)hipGetLastError();
+    if (!send || !recv || !expect || !expect2 || !host_word_dev) {
       close();
       set_last_error("xmpi_tune: out of device memory");
       return XMPI_ERR_NOMEM;
@@ -531,8 +543,11 @@ struct AnswerCheck {
     }
     if (send) (void)heap_free(send);
     if (recv) (void)heap_free(recv);
-    if (expect) (void)heap_free(expect);
-    if (expect2) (void)heap_free(expect2);
+    if (expect) (void)hipFree(expect);
+    if (expect2) (void)hipFree(expect2);
+    if (host_word) (void)hipHostFree(host_word);
+    host_word = host_word_dev = nullptr;
+    (void)hipGetLastError();
     send = recv = expect = expect2 = nullptr;
   }
   size_t recv_bytes(int coll, size_t per_rank) const { return coll == COLL_ALLGATHER ? per_rank * (size_t)c->size : per_rank; }
@@ -565,7 +580,9 @@ struct AnswerCheck {
     const double t0 = now_seconds();
     // (bcast: the root's buffer is the input; reduce: only the root's is written)
     const bool untouched = (coll == COLL_BCAST && c->rank == 0) || (coll == COLL_REDUCE && c->rank != 0);
-    if (!untouched) XMPI_HIP(hipMemsetAsync(recv, 0xA5, recv_bytes(coll, per_rank), c->local_stream));
+    // (a kernel of the library's own on the rank's stream -- the constant 166.0, which no sum of sixteen pattern values can be --, not
+    // hipMemsetAsync: the runtime's fills do not run on the stream's queue alone, see count_to_host)
+    if (!untouched) XMPI_HIP(launch_fill(recv, recv_bytes(coll, per_rank) / 4, XMPI_F32, /*pattern=*/2, /*seed=*/165, c->local_stream));
     spent_s += now_seconds() - t0;
     return XMPI_OK;
   }
@@ -573,8 +590,11 @@ struct AnswerCheck {
   // result doubles with it, exactly) -- what a caller's buffers do from one step to the next.  A reader that still holds lines of a
   // peer's buffer from the run before -- an L2 the schedule's acquire did not reach: the split form's once-per-XCD acquire is
   // exactly that bet -- folds OLD data, and only a changed input shows it: the first run of a fresh buffer never can.  For messages a
-  // cache could still hold (kSecondPassBytes per rank); afterwards the inputs are what they were (refilled).
-  bool second_pass(int coll, size_t per_rank) const { return per_rank <= kSecondPassBytes && recv_bytes(coll, per_rank) <= cap2; }
+  // cache could still hold whole (kSecondPassBytes per rank); afterwards the inputs are what they were (refilled).
+  bool second_pass(int coll, size_t per_rank) const {
+    static const bool on = env_long("XMPI_CHECK_PASSES", 2) >= 2;  // (1: the first pass only -- A/B of what the second one costs)
+    return on && per_rank <= kSecondPassBytes && recv_bytes(coll, per_rank) <= cap2;
+  }
   int change_inputs(int coll, size_t per_rank) {
     const double t0 = now_seconds();
     hipStream_t s = c->local_stream;
@@ -592,15 +612,23 @@ struct AnswerCheck {
     spent_s += now_seconds() - t0;
     return XMPI_OK;
   }
+  // c->dev_words[0] -> *out, behind everything on the stream; no copy engine involved
+  hipError_t count_to_host(uint64_t* out) {
+    hipStream_t s = c->local_stream;
+    __atomic_store_n(host_word, ~0ull, __ATOMIC_RELAXED);
+    hipError_t e = launch_word_to_host(host_word_dev, c->dev_words, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    *out = __atomic_load_n(host_word, __ATOMIC_ACQUIRE);
+    return e;
+  }
   int verdict(int coll, size_t per_rank, uint64_t* bad, bool second = false) {
     *bad = 0;
     if (coll == COLL_REDUCE && c->rank != 0) return XMPI_OK;
     const double t0 = now_seconds();
     hipStream_t s = c->local_stream;
-    XMPI_HIP(hipMemsetAsync(c->dev_words, 0, 32, s));
+    XMPI_HIP(launch_signal(c->dev_words, 0, s));
     XMPI_HIP(launch_count_mismatch(recv, second ? expect2 : expect, recv_bytes(coll, per_rank), c->dev_words, s));
-    XMPI_HIP(hipMemcpyAsync(bad, c->dev_words, 8, hipMemcpyDeviceToHost, s));
-    XMPI_HIP(hipStreamSynchronize(s));
+    XMPI_HIP(count_to_host(bad));
     spent_s += now_seconds() - t0;
     return XMPI_OK;
   }
@@ -657,20 +685,39 @@ static int tune_measure(xmpi_comm* c, AnswerCheck& chk, const std::vector<TuneCa
     std::lock_guard<std::mutex> g(c->coll_mu);
     c->dsync_split_bytes = cd.split ? 1 : 0;
     c->dsync_unroll = cd.unroll;
-    if (check) rc = chk.arm(coll, per_rank);
+    const bool tr = trace_on() && per_rank >= ((size_t)64 << 20);
+    const double tb = now_seconds();
+    double t_arm = 0, t_run = 0, t_verdict = 0;
+    // The check's rank-local kernels (poison, compare, refill) and a collective's WAITING kernels must not share the GPU: which ranks
+    // poison or compare depends on the collective (bcast: everybody but the root; reduce: the root alone), so some ranks would be
+    // spinning in the next collective's kernel while another still streams 256 MiB through a local one -- and with eight processes on
+    // ONE GPU that mix stalled the tree kernels for 8 .. 60 s at a time (round-6 profiles/r06/tune_stall).  So every rank's local
+    // kernels have ended, on every rank, before any rank launches a kernel that waits for a peer: stream sync + the job's barrier.
+    auto settle = [&]() -> int {
+      if (hipStreamSynchronize(c->local_stream) != hipSuccess) return hip_fail(hipGetLastError(), "hipStreamSynchronize", __FILE__, __LINE__);
+      return job_barrier(c);
+    };
+    if (check) {
+      rc = chk.arm(coll, per_rank);
+      if (rc == XMPI_OK) rc = settle();
+    }
+    t_arm = now_seconds() - tb;
     double t0 = now_seconds();
     for (int i = -1; i < iters && rc == XMPI_OK; i++) {
       if (i == 0) t0 = now_seconds();
       rc = dsync_collective(c, coll, 0, coll == COLL_BCAST ? chk.recv : chk.send, chk.recv, per_rank / 4, XMPI_F32, XMPI_SUM, c->local_stream,
                             /*blocking=*/i == -1 || i == iters - 1, cd.algo);
+      if (i == -1) t_run = now_seconds() - tb - t_arm;
       if (i == -1 && check && rc == XMPI_OK) {
         rc = chk.verdict(coll, per_rank, &bad[k]);
+        t_verdict = now_seconds() - tb - t_arm - t_run;
         // ... and once more with the inputs changed in place -- whatever THIS rank's first verdict was: the ranks see different
         // verdicts (a wrong byte lands in one rank's buffer), and a run only some of them make is a hang
-        if (rc == XMPI_OK && chk.second_pass(coll, per_rank)) {
+        if (rc == XMPI_OK && chk.twice && chk.second_pass(coll, per_rank)) {
           uint64_t bad2 = 0;
           rc = chk.change_inputs(coll, per_rank);
           if (rc == XMPI_OK) rc = chk.arm(coll, per_rank);
+          if (rc == XMPI_OK) rc = settle();
           if (rc == XMPI_OK)
             rc = dsync_collective(c, coll, 0, coll == COLL_BCAST ? chk.recv : chk.send, chk.recv, per_rank / 4, XMPI_F32, XMPI_SUM, c->local_stream, true, cd.algo);
           if (rc == XMPI_OK) rc = chk.verdict(coll, per_rank, &bad2, /*second=*/true);
@@ -678,6 +725,7 @@ static int tune_measure(xmpi_comm* c, AnswerCheck& chk, const std::vector<TuneCa
           if (rc == XMPI_OK) rc = chk.restore_inputs(coll, per_rank);
           bad[k] = std::max(bad[k], bad2);
         }
+        if (rc == XMPI_OK && iters > 0) rc = settle();  // ... before the timed runs
       }
     }
     if (iters > 0) {
@@ -686,6 +734,10 @@ static int tune_measure(xmpi_comm* c, AnswerCheck& chk, const std::vector<TuneCa
     }
     c->dsync_split_bytes = keep_split;
     c->dsync_unroll = keep_unroll;
+    if (tr)
+      fprintf(stderr, "[xmpi %d %.6f] tune:   %s %zu B by %s: %.0f us%s; arm %.1f ms, first run %.1f ms, verdict %.1f ms, all %.1f ms\n", c->rank, now_seconds(),
+              coll_name(coll), per_rank, kCandName[k], iters > 0 ? us[k] : 0.0, check ? " (checked)" : "", t_arm * 1e3, t_run * 1e3, t_verdict * 1e3,
+              (now_seconds() - tb) * 1e3);
     if (rc == XMPI_ERR_TIMEOUT && keep_timeout == 0)
       set_last_error(std::string(coll_name(coll)) + " by " + kCandName[k] + " at " + std::to_string(per_rank) + " B per rank did not complete within " +
                      std::to_string(kTuneTimeoutS) + " s while the library was checking / timing it on this machine (" + xmpi_last_error() +
@@ -745,7 +797,7 @@ static int p2p_check_round(xmpi_comm* c, AnswerCheck& chk, size_t bytes, uint64_
   int rc = job_barrier(c);
   if (rc != XMPI_OK) return rc;
   XMPI_HIP(launch_fill(chk.expect, bytes / 4, XMPI_F32, kCheckPattern, kCheckSeed + (uint64_t)left, s));
-  XMPI_HIP(hipMemsetAsync(chk.recv, 0xA5, bytes, s));
+  XMPI_HIP(launch_fill(chk.recv, bytes / 4, XMPI_F32, 2, 165, s));
   XMPI_HIP(hipStreamSynchronize(s));
   chk.have_coll = -1;
   size_t got = 0;
@@ -764,10 +816,9 @@ static int p2p_check_round(xmpi_comm* c, AnswerCheck& chk, size_t bytes, uint64_
     *bad = bytes;
     return XMPI_OK;
   }
-  XMPI_HIP(hipMemsetAsync(c->dev_words, 0, 32, s));
+  XMPI_HIP(launch_signal(c->dev_words, 0, s));
   XMPI_HIP(launch_count_mismatch(chk.recv, chk.expect, bytes, c->dev_words, s));
-  XMPI_HIP(hipMemcpyAsync(bad, c->dev_words, 8, hipMemcpyDeviceToHost, s));
-  XMPI_HIP(hipStreamSynchronize(s));
+  XMPI_HIP(chk.count_to_host(bad));
   return XMPI_OK;
 }
 
@@ -2494,6 +2545,8 @@ int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
       // +-6 % between two runs of one schedule): large sizes are measured twice, the candidates interleaved, and the better
       // figure of each counts
       const int rounds = bytes > ((size_t)1 << 20) ? 2 : 1;
+      // (the check's second pass -- inputs changed in place -- at every other size up to 1 MiB: 4 KiB, 64 KiB, 1 MiB; halves what it costs)
+      chk.twice = bytes == ((size_t)4 << 10) || bytes == ((size_t)64 << 10) || bytes == ((size_t)1 << 20);
       for (int round = 0; round < rounds && rc == XMPI_OK; round++)
         rc = tune_measure(c, chk, cands, coll, per_rank, ks, iters, /*check=*/round == 0, /*keep_min=*/round > 0, us.data(), bad.data());
       if (rc != XMPI_OK) break;
@@ -2528,6 +2581,7 @@ int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
           why += std::string(why.empty() ? "" : "; ") + t;
         }
       rows.push_back({per_rank, worst});
+      if (trace_on()) fprintf(stderr, "[xmpi %d %.6f] tune: %s %zu B per rank done\n", c->rank, now_seconds(), coll_name(coll), per_rank);
     }
     if (rc != XMPI_OK) break;
     c->tune_rejected[coll] = rejected;

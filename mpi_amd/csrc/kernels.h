@@ -260,6 +260,8 @@ hipError_t launch_ll_agent(const LLAgentArgs& a, hipStream_t stream);
 hipError_t launch_dsync_fold(const DsyncArgs& a, int nsrc, int dtype, int op, int grid_x, int unroll, hipStream_t stream,
                              hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
+// one lane: *dst (pinned host memory, as the device addresses it) = *src (device memory), system-scope release -- in stream order
+hipError_t launch_word_to_host(uint64_t* dst, const uint64_t* src, hipStream_t stream);
 // one lane: system-scope release store of `value` to *flag (host-registered or device memory)
 hipError_t launch_signal(uint64_t* flag, uint64_t value, hipStream_t stream);
 

@@ -629,6 +629,13 @@ __global__ __launch_bounds__(kBlock) void fill_kernel(void* buf, size_t count, i
 
 // ---- cross-process completion flag -----------------------------------------------------------
 
+// one device word -> a word the host can read (pinned, mapped), in stream order: how a verification kernel's count reaches the host
+// WITHOUT a device-to-host copy (a copy engine's queue is one more hardware queue per process: with eight processes on one GPU the
+// scheduler then time-slices all of them -- seconds per collective while kernels wait for each other)
+__global__ void word_to_host_kernel(uint64_t* dst, const uint64_t* src) {
+  __hip_atomic_store(dst, *src, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ void signal_kernel(uint64_t* flag, uint64_t value) {
   // everything earlier on this stream has completed (stream order); publish system-wide
   __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1229,6 +1236,11 @@ hipError_t launch_fill(void* buf, size_t count, int dtype, int pattern, uint64_t
 void set_kernel_mode(int mode) { g_kernel_mode = (mode < 0 || mode > 2) ? -1 : mode; }
 int get_kernel_mode() { return g_kernel_mode; }
 void set_grid_cap(int cap) { g_grid_cap = cap < 0 ? 0 : cap; }
+
+hipError_t launch_word_to_host(uint64_t* dst, const uint64_t* src, hipStream_t s) {
+  hipLaunchKernelGGL(word_to_host_kernel, dim3(1), dim3(1), 0, s, dst, src);
+  return hipGetLastError();
+}
 
 hipError_t launch_signal(uint64_t* flag, uint64_t value, hipStream_t s) {
   hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(1), 0, s, flag, value);
