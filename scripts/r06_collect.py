@@ -24,7 +24,8 @@ def main():
     for f in sorted(glob.glob(os.path.join(SRC, "*.json")) + glob.glob(os.path.join(SRC, "*.log"))):
         if os.path.getsize(f):
             shutil.copy(f, os.path.join(DST, os.path.basename(f)))
-    n1 = sorted(glob.glob(os.path.join(SRC, "stats_n1", "*", "*_kernel_stats.csv")), key=os.path.getsize)
+    # (gpurun MERGES a call's files into gpurun_out/: the csv of every earlier call is still there under its own pid -- the newest is this call's)
+    n1 = sorted(glob.glob(os.path.join(SRC, "stats_n1", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
     if n1:
         shutil.copy(n1[-1], os.path.join(DST, "bench_zcopy_kernel_stats.csv"))
     want = {"reduce_n_multi_kernel<float, 0, 8, 2>": ("zcopy, 8 rank threads, one launch folds all chunks", 4294967296),
