@@ -74,6 +74,7 @@ def parse_args():
     ap.add_argument("--probe", action="store_true",
                     help="(internal) a short zero-copy allreduce in a job of its own; the exit status is the verdict")
     ap.add_argument("--no-probe", action="store_true", help="skip the zero-copy probe before a multi-GPU run")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the headline's call on HOST slices (pcie_inclusive; one GPU only)")
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the live HBM-traffic measurement (two rocprofv3 --pmc child passes of this bench, N = 1 only): roofline.traffic then "
                          "comes from the committed profile")
@@ -620,6 +621,26 @@ def rank_main(job: Job, grank: int):
                                                                 "need ranks that meet on the device: cfg5_allreduce_f16_sweep_one_process_per_rank)"}
                 for b in (s5, r5, ref5):
                     b.free()
+            # The headline's call with HOST slices -- what a program written against the reference passes (a []float32 in host memory,
+            # mpi.go:126-128 / helloworld.go:53-81): every rank's buffer goes up and its result comes down over the GPU's PCIe link INSIDE
+            # the call.  The PCIe-inclusive rate, reported beside `value` and never as `value`.  Pageable memory, as a Go
+            # slice is; all R ranks share this GPU's one link.
+            if dtype == xmpi.F32 and not multi and not a.no_host_leg:
+                run(algo)
+                want_h = recv.download(np.float32, count)
+                hx = send.download(np.float32, count)
+                ho = np.zeros(count, dtype=np.float32)
+                comm.allreduce(hx, ho, count, dtype, xmpi.SUM, xmpi.ALGO_AUTO)  # (warm: staging blocks, first touch of `ho`)
+                t_h = timed(comm, lambda: comm.allreduce(hx, ho, count, dtype, xmpi.SUM, xmpi.ALGO_AUTO), 2)
+                err_h = float(np.max(np.abs(ho - want_h))) if count else 0.0
+                ok_h = all_max(comm, 0.0 if err_h <= 1e-6 * R else 1.0) == 0.0  # (|delta| <= 1e-6 x sum_i |x_i|, x in [0, 1): at most 1e-6 x R)
+                if not ok_h:
+                    parity_failures.append({"host_slices_allreduce": {"rank": grank, "max_abs_err": err_h}})
+                extras["host_slices_allreduce"] = {"bytes_per_rank": nbytes, "ranks": R, "ms_per_step": t_h * 1e3, "algbw_GBps": nbytes / t_h / 1e9,
+                                                   "pcie_bytes_per_step_each_direction": nbytes * R, "pcie_GBps_each_direction": nbytes * R / t_h / 1e9,
+                                                   "memory": "pageable (numpy), as a Go slice", "steps": 2, "parity_ok": ok_h, "max_abs_err": err_h,
+                                                   "bit_identical_to_the_device_run": bool(np.array_equal(ho, want_h))}
+                del hx, ho, want_h
             if link is not None:
                 extras["xgmi_link_probe"] = link
     except Exception as e:  # noqa: BLE001  (an extra that fails must not cost the line)
@@ -1131,6 +1152,9 @@ def main():
                                           "enqueued": round(r1k["queued_us"], 1), "by_ll_agent": r1k.get("by_agent")}
         except (KeyError, IndexError, TypeError):
             pass
+    hs = r0["extras"].get("host_slices_allreduce") if isinstance(r0["extras"], dict) else None
+    if hs:  # the PCIe-inclusive rate of the headline's call (host slices in, host slices out): beside `value`, never `value`
+        line["pcie_inclusive"] = {"algbw_GBps": round(hs["algbw_GBps"], 2), "ms_per_step": round(hs["ms_per_step"], 1), "parity_ok": hs["parity_ok"]}
     if job.cfg3 is not None:
         extras_out["extras"]["cfg3_allgather_i64_16MiB_4ranks_one_process_per_rank"] = job.cfg3
     if job.cfg5 is not None:

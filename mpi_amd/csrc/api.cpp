@@ -2526,7 +2526,11 @@ int xmpi_tune(xmpi_comm* c, size_t max_bytes) {
     for (size_t bytes = 1024; bytes <= max_bytes && rc == XMPI_OK; bytes *= 4) {
       const size_t per_rank = coll == COLL_ALLGATHER ? bytes / (size_t)c->size / 16 * 16 : bytes;
       if (per_rank < 16) continue;
-      const int iters = bytes <= ((size_t)1 << 20) ? 20 : (bytes <= ((size_t)32 << 20) ? 6 : 3);
+      // (XMPI_TUNE_ITERS: a cap on the timed runs per candidate -- the rehearsals on virtual devices, where a "kernel" is a host thread and
+      // a time means nothing, keep every candidate's CHECKED run and pay for two timed ones)
+      static const long iters_cap = env_long("XMPI_TUNE_ITERS", 0);
+      const int by_size = bytes <= ((size_t)1 << 20) ? 20 : (bytes <= ((size_t)32 << 20) ? 6 : 3);
+      const int iters = iters_cap > 0 ? (int)std::min<long>(by_size, iters_cap) : by_size;
       std::vector<double> us(cands.size(), 0.0), worst(cands.size(), 0.0);
       std::vector<uint64_t> bad(cands.size(), 0), worst_bad(cands.size(), 0);
       std::vector<int> ks;

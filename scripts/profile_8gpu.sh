@@ -17,7 +17,7 @@
 #    system-scope data kernel meet another GPU's memory for the first time; then the split form with and without body_sys, small
 #    collectives with and without LL lines, and a marker trace (named ranges between the kernels).
 # Rehearsal (tests/test_devsim.py, no GPU): XMPI_8GPU_REHEARSAL=1 shrinks every size, skips the GPU suite and the rocprofv3 steps and
-# writes under $XMPI_8GPU_OUT -- every OTHER command line below runs as written, on tests/devsim's virtual GPUs, so that a typo in a
+# writes under $XMPI_8GPU_OUT (bench.py without its child-process probe of every schedule: tests/test_devsim.py rehearses that with the scale command itself) -- every OTHER command line below runs as written, on tests/devsim's virtual GPUs, so that a typo in a
 # mode name or an environment variable is found before the one chance on a real node is spent on it.
 set -x
 N=${1:-8}
@@ -27,7 +27,7 @@ mkdir -p $O
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0 XMPI_TIMEOUT_S=${XMPI_TIMEOUT_S:-120}
 BIN=$ROOT/mpi_amd/bin
 REH=${XMPI_8GPU_REHEARSAL:-0}
-if [ "$REH" = 1 ]; then L=131072; M=65536; S=16384; C5=1048576; C3=16384; K="2 1"; KS="2 1"; CS="65536 2"; BARGS="--steps 2 --warmup 1 --size-mib 0.25 --no-cpu"
+if [ "$REH" = 1 ]; then L=131072; M=65536; S=16384; C5=1048576; C3=16384; K="2 1"; KS="2 1"; CS="65536 2"; BARGS="--steps 2 --warmup 1 --size-mib 0.25 --no-cpu --no-probe"
 else L=268435456; M=16777216; S=1048576; C5=1073741824; C3=2097152; K="20 5"; KS="200 10"; CS="1048576 200"; BARGS="--steps 20 --warmup 5"; fi
 cd $ROOT
 if [ "$REH" != 1 ]; then

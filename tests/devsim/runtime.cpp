@@ -486,24 +486,63 @@ struct BlockRunner {
 #ifdef DEVSIM_TSAN_FIBERS
   void* sched_fiber = nullptr;
 #endif
+  // Every resident block of every launch is a thread with a runner of its own: mapping, faulting in (a page or two per lane) and
+  // unmapping 256 .. 1024 lane stacks per block-thread per launch was most of what a collective cost here (system time twice the user
+  // time: eight ranks x 24 threads a launch).  Stack regions are kept and handed from launch to launch -- the pages stay.
+  struct StackPool {
+    std::mutex mu;
+    std::vector<std::pair<char*, size_t>> idle;
+  };
+  static StackPool& pool() {
+    static StackPool* p = new StackPool;  // (never destroyed: kernels may still run while the process exits)
+    return *p;
+  }
+  void give_back() {
+    if (!stacks) return;
+    {
+      std::lock_guard<std::mutex> g(pool().mu);  // (also the happens-before edge the sanitizer needs between two threads' uses of a region)
+      if (pool().idle.size() < 48) {  // (two launches in flight of 24 resident blocks each; a region keeps a page or two per lane)
+        pool().idle.emplace_back(stacks, nstacks);
+        stacks = nullptr;
+        nstacks = 0;
+        return;
+      }
+    }
+    munmap(stacks, nstacks * cfg().stack_bytes);
+    stacks = nullptr;
+    nstacks = 0;
+  }
   ~BlockRunner() {
 #ifdef DEVSIM_TSAN_FIBERS
     for (Lane& l : lanes)
       if (l.fiber) __tsan_destroy_fiber(l.fiber);
 #endif
-    if (stacks) munmap(stacks, nstacks * cfg().stack_bytes);
+    give_back();
   }
   void ensure(size_t n) {
     if (n <= nstacks) return;
-    if (stacks) munmap(stacks, nstacks * cfg().stack_bytes);
-    stacks = (char*)mmap(nullptr, n * cfg().stack_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-    if (stacks == MAP_FAILED) {
-      perror("devsim: lane stacks");
-      abort();
+    give_back();
+    {
+      std::lock_guard<std::mutex> g(pool().mu);
+      auto& idle = pool().idle;
+      for (size_t i = idle.size(); i-- > 0;)
+        if (idle[i].second >= n) {
+          stacks = idle[i].first;
+          nstacks = idle[i].second;
+          idle.erase(idle.begin() + (long)i);
+          break;
+        }
     }
-    nstacks = n;
-    lanes.resize(n);
-    xchg.resize(n);
+    if (!stacks) {
+      stacks = (char*)mmap(nullptr, n * cfg().stack_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+      if (stacks == MAP_FAILED) {
+        perror("devsim: lane stacks");
+        abort();
+      }
+      nstacks = n;
+    }
+    lanes.resize(nstacks);
+    xchg.resize(nstacks);
   }
   void to_lane(int i);
   void to_sched();

@@ -43,13 +43,17 @@ def _everything_built():
 def devsim_lib():
     from tests.devsim import build
     path = build.build_lib()
-    old = os.environ.get("XMPI_DEVSIM_LIB")
+    old = {k: os.environ.get(k) for k in ("XMPI_DEVSIM_LIB", "XMPI_TUNE_ITERS")}
     os.environ["XMPI_DEVSIM_LIB"] = path  # (run_ranks hands the environment on to the rank processes)
+    # a "kernel" here is a host thread: the tuner's TIMES mean nothing, its checked run of every candidate at every size is what these
+    # tests are about -- two timed runs per candidate instead of twenty (the lone-process scale command: 66 -> 18 s, nearly all of it tuning)
+    os.environ["XMPI_TUNE_ITERS"] = "2"
     yield path
-    if old is None:
-        del os.environ["XMPI_DEVSIM_LIB"]
-    else:
-        os.environ["XMPI_DEVSIM_LIB"] = old
+    for k, v in old.items():
+        if v is None:
+            del os.environ[k]
+        else:
+            os.environ[k] = v
 
 
 @pytest.fixture(scope="module")
@@ -66,7 +70,8 @@ def tsan_bin():
 
 def run(binp, *args, **env):
     e = dict(os.environ, TSAN_OPTIONS="exitcode=66 halt_on_error=0 report_signal_unsafe=0", **{k: str(v) for k, v in env.items()})
-    e.pop("XMPI_DEVSIM_LIB", None)
+    for k in ("XMPI_DEVSIM_LIB", "XMPI_TUNE_ITERS"):
+        e.pop(k, None)  # (what the devsim_lib fixture sets for the tests further down is not for the drivers' runs)
     return subprocess.run([binp, *args], capture_output=True, text=True, timeout=900, env=e, cwd="/tmp")
 
 

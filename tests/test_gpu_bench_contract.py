@@ -85,6 +85,11 @@ def test_bench_extras_tables():
     assert {x["bytes"] for x in rows if x["ranks"] == 8} == {1 << 10, 1 << 12, 1 << 14, 1 << 16, 1 << 18, 1 << 20, 1 << 22, 1 << 24}
     c3 = ex["cfg3_allgather_i64_16MiB_4ranks"]
     assert c3["ranks"] == 4 and c3["auto"]["ms"] > 0 and c3["ring"]["ms"] > 0
+    # the headline's call on HOST slices (what a caller of the reference passes): buffers up and results down over PCIe inside the call --
+    # the PCIe-inclusive rate beside `value`, never as `value`; right to the line's tolerance, and far below the HBM-resident figure
+    hs, pi = ex["host_slices_allreduce"], d["pcie_inclusive"]
+    assert hs["parity_ok"] is True and hs["ranks"] == 8 and hs["bytes_per_rank"] == 16 << 20 and hs["max_abs_err"] <= 8e-6, hs
+    assert pi["parity_ok"] is True and abs(pi["algbw_GBps"] - hs["algbw_GBps"]) < 0.01 and 0 < hs["algbw_GBps"] < d["value"], (pi, d["value"])
     mp = ex["multiprocess_sweep"]  # eight PROCESSES on this GPU, meeting on the device
     assert mp["ranks"] == 8 and mp["exact"] is True and "device" in mp["meet"], mp
     assert mp["rows"][0]["bytes"] == 1024 and mp["rows"][0]["queued_us"] < 1000, mp["rows"][0]
