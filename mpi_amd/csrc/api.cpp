@@ -361,6 +361,9 @@ static void stop_worker(xmpi_comm* c) {
   c->worker_started = false;
 }
 
+static int collective_on_host_meeting_ranks(xmpi_comm* c, int coll, int algo, int root, const void* sendbuf, void* recvbuf, size_t count, int dtype,
+                                            int op);
+
 static int collective(xmpi_comm* c, int coll, int algo, int root, const void* sendbuf, void* recvbuf, size_t count,
                       int dtype, int op) {
   drain_worker(c);
@@ -376,10 +379,6 @@ static int collective(xmpi_comm* c, int coll, int algo, int root, const void* se
   }
   RoctxRange range("xmpi:%s algo=%s bytes=%zu rank=%d/%d", coll_name(coll), algo_name(algo), count * es, c->rank, c->size);
   std::lock_guard<std::mutex> g(c->coll_mu);
-  // Zero-copy first (zcopy.cpp): when every rank's buffers are registered HBM one kernel per rank does
-  // the whole collective in place.  Whether that holds is decided collectively, so either every rank
-  // returns from here or every rank goes on to the staged schedule below.
-  const bool zc_algo = algo == XMPI_ALGO_ZCOPY || algo == XMPI_ALGO_ZPUSH || algo == XMPI_ALGO_LL;
   // One process per GPU (the production layout): the ranks meet on the device (dsync.cpp) -- one kernel per
   // rank, enqueued on this communicator's stream, no host barrier.  Whether this path is taken depends on the
   // job's layout and the arguments only, so every rank decides alike; buffers the peers cannot map are stood in
@@ -388,6 +387,55 @@ static int collective(xmpi_comm* c, int coll, int algo, int root, const void* se
   // the schedule inside one kernel per rank; with ranks that meet on the host they name the staged schedules below.
   if (dsync_takes(c, coll, algo))
     return dsync_collective(c, coll, root, sendbuf, recvbuf, count, dtype, op, c->local_stream, /*blocking=*/true, algo);
+  // Ranks that meet on the host, HOST slices (what a program written against the reference passes, helloworld.go:53-81): stood in
+  // for by blocks of the registered arenas -- the heap keeps them from call to call, so the zero-copy fold applies and nothing is
+  // hipMalloc'ed / hipFree'd per call (35 ms per 256 MiB buffer with eight rank threads at it: scripts/r06_hostleg_probe.py) --, one copy up,
+  // one copy down on the communicator's stream.  No arena memory left: the staged path's own temporary buffers (below).
+  const bool send_host = !is_device_pointer(sendbuf), recv_host = !is_device_pointer(recvbuf);
+  if (send_host || recv_host) {
+    const size_t send_bytes = count * es, recv_bytes = coll == COLL_ALLGATHER ? send_bytes * (size_t)c->size : send_bytes;
+    const bool in_place = sendbuf == recvbuf && coll != COLL_ALLGATHER;
+    void* up_recv = recv_host ? heap_alloc(c->device, recv_bytes) : nullptr;
+    void* up_send = send_host && !(in_place && recv_host) ? heap_alloc(c->device, send_bytes) : nullptr;
+    if ((recv_host && !up_recv) || (send_host && !(in_place && recv_host) && !up_send)) {
+      if (up_recv) (void)heap_free(up_recv);
+      if (up_send) (void)heap_free(up_send);
+      (void)hipGetLastError();
+      return collective_on_host_meeting_ranks(c, coll, algo, root, sendbuf, recvbuf, count, dtype, op);
+    }
+    void* drecv = recv_host ? up_recv : recvbuf;
+    const void* dsend = !send_host ? sendbuf : (in_place && recv_host) ? drecv : up_send;
+    auto done = [&](int rc) {
+      if (up_recv) (void)heap_free(up_recv);
+      if (up_send) (void)heap_free(up_send);
+      return rc;
+    };
+    hipStream_t s = c->local_stream;
+    // (what goes up: the operand; a broadcast's message at its root -- in `recvbuf` --; nothing else has a say in the result)
+    const void* src_up = coll == COLL_BCAST ? (c->rank == root && recv_host ? recvbuf : nullptr) : (send_host ? sendbuf : nullptr);
+    void* dst_up = coll == COLL_BCAST ? drecv : const_cast<void*>(dsend);
+    if (src_up) {
+      if (hipMemcpyAsync(dst_up, src_up, send_bytes, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        return done(hip_fail(hipGetLastError(), "hipMemcpyAsync(host slice -> its stand-in)", __FILE__, __LINE__));
+    }
+    int rc = collective_on_host_meeting_ranks(c, coll, algo, root, dsend, drecv, count, dtype, op);
+    if (rc == XMPI_OK && recv_host && (coll != COLL_REDUCE || c->rank == root)) {
+      if (hipMemcpyAsync(recvbuf, drecv, recv_bytes, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        rc = hip_fail(hipGetLastError(), "hipMemcpyAsync(stand-in -> host slice)", __FILE__, __LINE__);
+    }
+    return done(rc);
+  }
+  return collective_on_host_meeting_ranks(c, coll, algo, root, sendbuf, recvbuf, count, dtype, op);
+}
+
+// (called with c->coll_mu held; ranks that meet on the host)
+static int collective_on_host_meeting_ranks(xmpi_comm* c, int coll, int algo, int root, const void* sendbuf, void* recvbuf, size_t count, int dtype,
+                                            int op) {
+  const size_t es = xmpi_dtype_size((xmpi_dtype)dtype);
+  // Zero-copy first (zcopy.cpp): when every rank's buffers are registered HBM one kernel per rank does
+  // the whole collective in place.  Whether that holds is decided collectively, so either every rank
+  // returns from here or every rank goes on to the staged schedule below.
+  const bool zc_algo = algo == XMPI_ALGO_ZCOPY || algo == XMPI_ALGO_ZPUSH || algo == XMPI_ALGO_LL;
   if (c->size > 1 && (zc_algo || (algo == XMPI_ALGO_AUTO && c->zero_copy))) {
     bool done = false;
     int zrc = zero_copy_collective(c, coll, root, sendbuf, recvbuf, count, dtype, op, algo == XMPI_ALGO_ZPUSH, &done);
