@@ -302,17 +302,27 @@ def sc_zero_copy(comm, args):
                     recv.free()
                 send.free()
 
-    # buffers the peers cannot map.  Ranks that meet through the control block (threads of one process on one
-    # GPU) all fall back to the staged schedule, together; ranks that meet on the device (dsync.cpp: one process
-    # per rank) stand a registered arena block in for such a buffer and run the same kernel
+    # buffers the peers cannot map.  HOST slices (what a caller of the reference passes): a registered arena block stands in for
+    # each and the same kernel runs -- with ranks that meet on the device (dsync.cpp: one process per rank) and with ranks that meet
+    # through the control block (api.cpp collective) alike: nobody falls back to the staged schedule
     dsync = comm.get_param("dsync") == 1
     bounced0 = comm.get_param("dsync_bounced")
+    staged0, zc0 = comm.get_param("zc_fallbacks_unregistered"), comm.get_param("zc_seq")
     x = oracle.fill(1000, xmpi.F32, xmpi.PAT_UNIFORM, 5 + rank)
     out = np.zeros_like(x)
     comm.allreduce(x, out, 1000, xmpi.F32, xmpi.SUM, Z)  # host memory
     want = oracle.reduce_ranks([oracle.fill(1000, xmpi.F32, xmpi.PAT_UNIFORM, 5 + r) for r in range(size)], xmpi.F32, 0)
     assert out.tobytes() == want.tobytes()
     assert not dsync or comm.get_param("dsync_bounced") == bounced0 + 2, "host send + receive buffer: two stand-ins"
+    if not dsync and comm.get_param("zero_copy") == 1 and size > 1:
+        assert comm.get_param("zc_seq") > zc0 and comm.get_param("zc_fallbacks_unregistered") == staged0, _zc_why(comm)
+    y = x.copy()  # ... in place, and a host operand with a result in HBM
+    comm.allreduce(y, y, 1000, xmpi.F32, xmpi.SUM, Z)
+    assert y.tobytes() == want.tobytes(), "allreduce of a host slice in place"
+    dres = comm.alloc(4000)
+    comm.allreduce(x, dres, 1000, xmpi.F32, xmpi.SUM, Z)
+    assert dres.download(np.float32, 1000).tobytes() == want.tobytes(), "host operand, result in HBM"
+    dres.free()
     # device memory from another allocator (here: plain hipMalloc) on ONE rank: staged until it is registered,
     # zero-copy while it is, staged again after deregistration
     import ctypes

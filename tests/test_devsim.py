@@ -191,6 +191,18 @@ def test_gpu_scenarios_on_virtual_devices(devsim_lib, scenario, size, args):
     run_ranks(scenario, size, args, timeout=600, env={"DEVSIM_DEVICES": "8"} if size > 8 else None)
 
 
+@pytest.mark.parametrize("layout", ["threads", "processes", "processes_on_the_host"])
+def test_host_slices_run_the_schedules_registered_buffers_run(devsim_lib, layout):
+    """what a caller of the reference passes -- host slices -- is stood in for by arena blocks and takes the zero-copy path in every
+    layout: rank threads of one process and processes that meet through the control block (api.cpp collective: no fallback to the
+    staged schedule, `zc_fallbacks_unregistered` stays), processes that meet on the device (dsync.cpp: `dsync_bounced`); out of place,
+    in place, host operand with the result in HBM: bit-exact against the oracle (tests/scenarios.py sc_zero_copy)"""
+    if layout == "threads":
+        run_threads("zero_copy", 4, {"counts": [1, 4099]})
+    else:
+        run_ranks("zero_copy", 3, {"counts": [1, 4099]}, timeout=600, env={"XMPI_DSYNC": "0"} if layout.endswith("host") else None)
+
+
 DEGRADED = [
     # every open of another device's UNCACHED allocation fails (the flag pages: "has never executed anywhere" before an 8-GPU
     # node): the ranks meet on the host, zero-copy collectives with a host rendezvous, everything else as before
