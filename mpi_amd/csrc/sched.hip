@@ -257,10 +257,10 @@ __device__ __forceinline__ void tile_apply(char* D, char* D2, const char* A, con
       if (phi - plo == kSchedTileBytes) {  // a whole tile: every load issued before the first use
         constexpr int U = (int)(kSchedTileBytes / 16 / kBlock);
         const pack_t* pa = reinterpret_cast<const pack_t*>(A + plo) + t;
-        const pack_t* pb = reinterpret_cast<const pack_t*>(B + plo) + t;
-        const pack_t* pc = reinterpret_cast<const pack_t*>(C + plo) + t;
+        const pack_t* pb = NS >= 2 ? reinterpret_cast<const pack_t*>(B + plo) + t : nullptr;
+        const pack_t* pc = NS == 3 ? reinterpret_cast<const pack_t*>(C + plo) + t : nullptr;  // (no arithmetic on a null base: C, D2 may be)
         pack_t* pd = reinterpret_cast<pack_t*>(D + plo) + t;
-        pack_t* pd2 = reinterpret_cast<pack_t*>(D2 + plo) + t;
+        pack_t* pd2 = D2 ? reinterpret_cast<pack_t*>(D2 + plo) + t : nullptr;
         pack_t va[U], vb[U], vc[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {

@@ -99,6 +99,20 @@ def build_traffic_lib(force: bool = False) -> str:
     return TRAFFIC_LIB
 
 
+UBSAN_BIN = os.path.join(HERE, "devsim_ubsan_bin")
+
+
+def build_driver_ubsan(force: bool = False) -> str:
+    """the driver with -fsanitize=undefined,bounds over the library whole, kernels included (no GPU pool offers a sanitizer run: on the CPU
+    build only) -- found: pointer arithmetic on the null bases of a stepped kernel's unused operands (sched.hip tile_apply)"""
+    objs, rebuilt = _objects("ubsan", _flags("-O1", "-fsanitize=undefined,bounds", "-fno-omit-frame-pointer"), [os.path.join(HERE, "driver.cpp")], force)
+    link = b._digest(objs, "devsim ubsan driver link")
+    if force or rebuilt or b._stale(UBSAN_BIN, link):
+        b._run([_clang(), "-fsanitize=undefined", *objs, "-o", UBSAN_BIN, "-lpthread", "-lrt", "-ldl"])
+        b._record(UBSAN_BIN, link)
+    return UBSAN_BIN
+
+
 def build_driver(tsan: bool, force: bool = False) -> str:
     driver = os.path.join(HERE, "driver.cpp")
     if tsan:
@@ -191,6 +205,8 @@ if __name__ == "__main__":
         print("built:", [build_mutant(m, force) for m in MUTATIONS])
     elif "--traffic" in sys.argv:
         print("built:", build_traffic_lib(force))
+    elif "--ubsan" in sys.argv:
+        print("built:", build_driver_ubsan(force))
     elif "--driver" in sys.argv:
         print("built:", build_driver(False, force))
     else:

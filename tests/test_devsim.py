@@ -28,7 +28,7 @@ def _everything_built():
     """the four artefacts side by side (a cold build of each is ~1 min of clang++ on the kernel templates; nothing when current)"""
     import sys
     jobs = [subprocess.Popen([sys.executable, "-m", "tests.devsim.build", *flag], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-            for flag in ([], ["--tsan"], ["--traffic"])]
+            for flag in ([], ["--tsan"], ["--traffic"], ["--ubsan"])]
     out, _ = jobs[1].communicate()  # the mutants swap single objects of the sanitizer build: they start when it is there
     assert jobs[1].returncode == 0, out[-4000:]
     jobs[1] = subprocess.Popen([sys.executable, "-m", "tests.devsim.build", "--mutant"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -110,6 +110,18 @@ def test_device_protocols_are_race_free(tsan_bin, ranks, fuzz):
     r = run(tsan_bin, str(ranks), "1", DEVSIM_FUZZ=fuzz)
     assert "ThreadSanitizer" not in r.stderr, r.stderr[-6000:]
     assert r.returncode == 0 and "devsim driver ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("ranks,fuzz", [(4, 3), (8, 5)])
+def test_the_undefined_behaviour_sanitizer_finds_nothing(ranks, fuzz):
+    """-fsanitize=undefined,bounds over the library whole -- host sources AND the kernel sources, compiled for the CPU -- while the driver
+    walks every form of every collective, Send / Receive, the agents, graphs (the GPU pool offers no sanitizer run: this is where one
+    can).  What it found when first run: pointer arithmetic on the null bases of a stepped kernel's unused operands (sched.hip
+    tile_apply: `C + lo`, `D2 + lo` with C / D2 null -- never dereferenced, undefined all the same)"""
+    from tests.devsim import build
+    r = run(build.build_driver_ubsan(), str(ranks), str(fuzz), UBSAN_OPTIONS="print_stacktrace=1")
+    assert r.returncode == 0 and "devsim driver ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "runtime error" not in r.stderr, r.stderr[-4000:]
 
 
 @pytest.mark.parametrize("ranks,fuzz", [(4, 3), (8, 5)])
