@@ -99,6 +99,18 @@ def test_bounce_against_the_reference_path(product_is_even):
         assert len(row["bytes_us"]) == 8 and len(row["float64_us"]) == 8  # lengths 0 ... 1e6
 
 
+def test_the_gob_reader_survives_noise_under_the_address_sanitizer(tmp_path):
+    """100 000 messages -- noise, and valid `initialMessage` / `message` / slice / string / []byte values with bits flipped and tails cut
+    off -- through parse_initial / parse_tagged / open_value with -fsanitize=address,undefined: what a stranger on the port, or a peer
+    of another version, can send (network.go:242-351 reads the same bytes with encoding/gob, which returns an error)"""
+    exe = str(tmp_path / "gobwire_fuzz")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Wextra", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                           "-I", os.path.join(ROOT, "mpi_amd", "host"), os.path.join(ROOT, "tests", "gobwire_fuzz.cpp"), "-o", exe])
+    out = subprocess.run([exe, "100000"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("ok ") and int(out.stdout.split()[1]) > 10000, out.stdout[-500:] + out.stderr[-3000:]
+    assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-3000:]
+
+
 def test_tcp_backend_error_values(tmp_path):
     """duplicate {peer, tag} -> TagExists as an error value (the reference panics, network.go:469); wrong password ->
     Init fails on both sides (network.go:343-346); Rank() == -1 / Size() == 0 before Init (network.go:41-50)"""
