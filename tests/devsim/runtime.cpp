@@ -1046,6 +1046,34 @@ hipError_t hipFree(void* ptr) {
   return hipSuccess;
 }
 
+// ---- guarded allocations (tests/scenarios.py sc_guard) --------------------------------------------------------------------------
+// Device memory whose LAST byte is the last byte of a page, the page behind it inaccessible: a kernel that reads or writes one byte
+// past a buffer's end -- a tail handled a packet too wide, a tile rounded up -- faults here, where a GPU serves the access out of the
+// 2 MiB granule the allocation sits in and nobody ever knows.  The pointer returned is `bytes` before the guard page (so only as
+// aligned as `bytes` is); release with devsim_guarded_free(ptr, bytes): -2 when the bytes in FRONT of the buffer (0xEE) were written.
+// This process' mapping only: ranks must be threads.
+extern "C" void* devsim_guarded_alloc(size_t bytes) {
+  const size_t page = 4096, data = (std::max<size_t>(bytes, 1) + page - 1) / page * page;
+  void* base = nullptr;
+  if (hipMalloc(&base, data + page) != hipSuccess) return nullptr;
+  memset(base, 0xEE, data);
+  if (mprotect((char*)base + data, page, PROT_NONE) != 0) {
+    (void)hipFree(base);
+    return nullptr;
+  }
+  return (char*)base + data - bytes;
+}
+extern "C" int devsim_guarded_free(void* ptr, size_t bytes) {
+  if (!ptr) return 0;
+  const size_t page = 4096, data = (std::max<size_t>(bytes, 1) + page - 1) / page * page;
+  char* base = (char*)ptr + bytes - data;
+  int rc = 0;
+  for (char* q = base; q < (char*)ptr; q++)  // what lies in FRONT of the buffer was filled with 0xEE: a store below the buffer's start shows here
+    if ((unsigned char)*q != 0xEE) rc = -2;
+  (void)mprotect(base + data, page, PROT_READ | PROT_WRITE);
+  return hipFree(base) == hipSuccess ? rc : -1;
+}
+
 hipError_t hipHostMalloc(void** ptr, size_t bytes, unsigned flags) {
   startup();
   if (!ptr) return fail(hipErrorInvalidValue);

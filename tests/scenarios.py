@@ -2767,7 +2767,152 @@ def sc_corrupt(comm, args):
     comm.barrier()
 
 
+def sc_guard(comm, args):
+    """Virtual devices only (tests/devsim/runtime.cpp devsim_guarded_alloc): every buffer ends on the last byte of a page with an
+    inaccessible page behind it, so a kernel that touches ONE byte past a buffer's end faults -- a tail a packet too wide, a tile
+    rounded up: on a GPU such an access is served out of the allocation's 2 MiB granule and nobody ever knows.  Ranks are threads of
+    this process (the guard is this mapping's).  The local kernels at ragged counts of every width, then every collective by every name
+    a caller can give, out of REGISTERED user memory (xmpi_register: the buffers themselves, no stand-ins) -- results against the oracle."""
+    import ctypes
+    L = xmpi.lib()
+    assert hasattr(L, "devsim_guarded_alloc"), "sc_guard runs on tests/devsim only"
+    L.devsim_guarded_alloc.restype, L.devsim_guarded_alloc.argtypes = ctypes.c_void_p, [ctypes.c_size_t]
+    L.devsim_guarded_free.restype, L.devsim_guarded_free.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]
+    rank, size = comm.rank(), comm.size()
+    comm.sync()  # (this thread's device)
+
+    def galloc(nbytes):
+        p = L.devsim_guarded_alloc(nbytes)
+        assert p, "devsim_guarded_alloc"
+        return p
+
+    def gfree(p, nbytes):
+        rc = L.devsim_guarded_free(p, nbytes)
+        assert rc == 0, "somebody stored BELOW a buffer's start" if rc == -2 else "devsim_guarded_free"
+
+    def down(p, dtype, count):
+        out = np.empty(count, dtype=xmpi.NUMPY_DTYPE[dtype])
+        comm.memcpy(out, p, out.nbytes)
+        return out
+
+    counts = args.get("counts", [1, 3, 17, 255, 1000, 4099, 65536 + 5])
+    if args.get("overrun"):  # the seeded fault: a kernel asked to read ONE byte more than the buffer has must take the process down
+        a = galloc(4099)
+        comm.fill(a, 4099, xmpi.U8, xmpi.PAT_UNIFORM, 1)
+        comm.checksum(a, 4099)
+        print("guard: in bounds ok, now one byte past the end", flush=True)
+        comm.checksum(a, 4100)
+        raise AssertionError("a read past the guarded end went unnoticed")
+    # ---- the local kernels: two- and N-operand reduce, copy, fill, verify -----------------------------------------------------
+    for dtype in (xmpi.U8, xmpi.F16, xmpi.BF16, xmpi.I32, xmpi.F32, xmpi.I64, xmpi.F64):
+        es = xmpi.DTYPE_SIZE[dtype]
+        for count in counts:
+            nb = count * es
+            a, b, c3, d = galloc(nb), galloc(nb), galloc(nb), galloc(nb)
+            for p, seed in ((a, 11), (b, 12), (c3, 13)):
+                comm.fill(p, count, dtype, xmpi.PAT_UNIFORM, seed + rank)
+            ins = [oracle.fill(count, dtype, xmpi.PAT_UNIFORM, sd + rank) for sd in (11, 12, 13)]
+            assert down(a, dtype, count).tobytes() == ins[0].tobytes(), "fill"
+            comm.reduce_local(d, a, b, count, dtype, xmpi.SUM)
+            check_reduced(down(d, dtype, count), ins[:2], dtype, xmpi.SUM, True, f"guard: reduce2 {xmpi.DTYPE_NAME[dtype]} n={count}")
+            comm.reduce_local_n(d, [a, b, c3], count, dtype, xmpi.SUM)
+            check_reduced(down(d, dtype, count), ins, dtype, xmpi.SUM, True, f"guard: reduce_n {xmpi.DTYPE_NAME[dtype]} n={count}")
+            comm.reduce_local_multi([d, c3], [a, b], count, dtype, xmpi.SUM)
+            check_reduced(down(c3, dtype, count), ins[:2], dtype, xmpi.SUM, True, f"guard: reduce_multi {xmpi.DTYPE_NAME[dtype]} n={count}")
+            comm.copy_local(d, a, nb)
+            assert down(d, dtype, count).tobytes() == ins[0].tobytes(), "copy"
+            comm.copy_local_multi([d, c3], b, nb)
+            assert down(c3, dtype, count).tobytes() == ins[1].tobytes(), "copy_multi"
+            if nb % 16 == 0:  # (bench.py's box copy: 16-byte aligned buffers only, anything else is refused)
+                comm.copy_local_pairs([d, c3], [a, b], nb)
+                assert down(d, dtype, count).tobytes() == ins[0].tobytes() and down(c3, dtype, count).tobytes() == ins[1].tobytes(), "copy_pairs"
+            comm.copy_local(c3, b, nb)
+            comm.copy_local(d, b, nb)
+            assert comm.count_mismatch(d, c3, nb) == 0 and comm.count_mismatch(a, b, nb) == oracle.count_mismatch(ins[0], ins[1])
+            comm.checksum(a, nb)
+            if dtype in (xmpi.F32, xmpi.F16):  # (what bench.py's parity check runs over the timed buffers)
+                comm.diff_stats(a, b, count, dtype)
+            for p in (a, b, c3, d):
+                gfree(p, nb)
+    comm.barrier()
+    # ---- collectives out of registered user memory that ends at a guard page -------------------------------------------------------
+    dsync = comm.get_param("dsync") == 1
+    allreduce_algos = [xmpi.ALGO_AUTO, xmpi.ALGO_ZCOPY, xmpi.ALGO_ZPUSH, xmpi.ALGO_RING, xmpi.ALGO_RHD, xmpi.ALGO_DIRECT]
+    if dsync:
+        allreduce_algos += [xmpi.ALGO_RING_PUSH, xmpi.ALGO_RHD_PUSH, xmpi.ALGO_LL]
+    for dtype, count in ((xmpi.F32, 1), (xmpi.U8, 7), (xmpi.I64, 333), (xmpi.F16, 1001), (xmpi.F32, 4099), (xmpi.BF16, 2049), (xmpi.F32, 65536 + 5), (xmpi.F64, 8191)):
+        es = xmpi.DTYPE_SIZE[dtype]
+        nb = count * es
+        send, recv = galloc(nb), galloc(nb)
+        comm.register(send, nb)
+        comm.register(recv, nb)
+        comm.fill(send, count, dtype, xmpi.PAT_UNIFORM, 300 + rank)
+        ins = [oracle.fill(count, dtype, xmpi.PAT_UNIFORM, 300 + r) for r in range(size)]
+        for split in ((0, 1) if dsync else (0,)):
+            if dsync:
+                comm.set_param("dsync_split_bytes", 1 if split else 0)
+            for algo in allreduce_algos:
+                if algo == xmpi.ALGO_LL and nb > 8192:
+                    continue
+                comm.memset(recv, 0xA5, nb)
+                comm.allreduce(send, recv, count, dtype, xmpi.SUM, algo)
+                # (rank-order schedules are bit-identical to the oracle; fp16 k/64 inputs are exactly summable in any order)
+                exact = algo in (xmpi.ALGO_DIRECT, xmpi.ALGO_ZCOPY, xmpi.ALGO_AUTO, xmpi.ALGO_ZPUSH, xmpi.ALGO_LL) or size <= 2 or dtype == xmpi.F16
+                check_reduced(down(recv, dtype, count), ins, dtype, xmpi.SUM, exact, f"guard: allreduce {xmpi.DTYPE_NAME[dtype]} n={count} algo={algo} split={split}")
+        # in place
+        comm.memcpy(recv, send, nb)
+        comm.allreduce(recv, recv, count, dtype, xmpi.SUM, xmpi.ALGO_AUTO)
+        check_reduced(down(recv, dtype, count), ins, dtype, xmpi.SUM, True, f"guard: allreduce in place {xmpi.DTYPE_NAME[dtype]} n={count}")
+        # reduce to a root, broadcast from it
+        root = size // 2
+        for algo in (xmpi.ALGO_AUTO, xmpi.ALGO_TREE) + ((xmpi.ALGO_TREE_PUSH,) if dsync else ()):
+            comm.memset(recv, 0xA5, nb)
+            comm.reduce(send, recv, count, dtype, xmpi.SUM, root, algo)
+            if rank == root:
+                check_reduced(down(recv, dtype, count), ins, dtype, xmpi.SUM, algo == xmpi.ALGO_AUTO or size <= 2 or dtype == xmpi.F16,
+                              f"guard: reduce {xmpi.DTYPE_NAME[dtype]} n={count} algo={algo}")
+            comm.memcpy(recv, send, nb)
+            comm.bcast(recv, count, dtype, root, algo)
+            assert down(recv, dtype, count).tobytes() == ins[root].tobytes(), f"guard: bcast {xmpi.DTYPE_NAME[dtype]} n={count} algo={algo}"
+        comm.deregister(send)
+        comm.deregister(recv)
+        gfree(recv, nb)
+        # allgather: the receive buffer ends at the guard, every rank's block inside it
+        big = galloc(nb * size)
+        comm.register(big, nb * size)
+        for algo in (xmpi.ALGO_AUTO, xmpi.ALGO_RING) + ((xmpi.ALGO_RING_PUSH,) if dsync else ()):
+            comm.memset(big, 0x5A, nb * size)
+            comm.allgather(send, big, count, dtype, algo)
+            got = down(big, dtype, count * size)
+            assert got.tobytes() == oracle.allgather(ins, dtype).tobytes(), f"guard: allgather {xmpi.DTYPE_NAME[dtype]} n={count} algo={algo}"
+        comm.deregister(big)
+        gfree(big, nb * size)
+        gfree(send, nb)
+    if dsync:
+        comm.set_param("dsync_split_bytes", 4 << 20)
+    # Send / Receive out of and into guarded memory
+    if size >= 2:
+        for dtype, count in ((xmpi.U8, 1), (xmpi.F32, 4099), (xmpi.U8, 65536 * 3 + 1), (xmpi.F64, 100001)):
+            es = xmpi.DTYPE_SIZE[dtype]
+            nb = count * es
+            buf = galloc(nb)
+            comm.register(buf, nb)
+            peer = rank ^ 1
+            if peer < size:
+                if rank & 1 == 0:
+                    comm.fill(buf, count, dtype, xmpi.PAT_SIGNED, 900 + rank)
+                    comm.send(buf, count, dtype, peer, 21)
+                else:
+                    comm.memset(buf, 0, nb)
+                    comm.recv(buf, count, dtype, peer, 21)
+                    assert down(buf, dtype, count).tobytes() == oracle.fill(count, dtype, xmpi.PAT_SIGNED, 900 + peer).tobytes(), f"guard: p2p n={count}"
+            comm.barrier()
+            comm.deregister(buf)
+            gfree(buf, nb)
+
+
 SCENARIOS = {
+    "guard": sc_guard,
     "corrupt": sc_corrupt,
     "mismatch": sc_mismatch,
     "linkprobe": sc_linkprobe,

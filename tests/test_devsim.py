@@ -203,6 +203,23 @@ def test_gpu_scenarios_on_virtual_devices(devsim_lib, scenario, size, args):
     run_ranks(scenario, size, args, timeout=600, env={"DEVSIM_DEVICES": "8"} if size > 8 else None)
 
 
+@pytest.mark.parametrize("devices,ranks", [(1, 4), (4, 4), (3, 3), (8, 8)])
+def test_no_kernel_touches_a_byte_past_its_buffers(devsim_lib, devices, ranks):
+    """every buffer ends on the last byte of a page with an inaccessible page behind it (runtime.cpp devsim_guarded_alloc): the local
+    kernels at ragged counts of every element width, then -- out of registered user memory -- every collective by every name, in place
+    and out, Send / Receive; rank threads sharing ONE device (the host rendezvous, `reduce_n_multi_kernel`: the headline's kernel)
+    and on a device each (the device-synchronised kernels: fold, split, stepped pull / push, LL; 3, 4 and 8 ranks).  An access one byte past a buffer's end -- which
+    a GPU serves out of the allocation's granule without a word -- kills the process here; the results are held to the oracle"""
+    import sys
+    e = dict(os.environ, DEVSIM_DEVICES=str(devices), XMPI_TIMEOUT_S="60")
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "rank_worker.py"), "--threads", "guard", str(ranks)]
+    p = subprocess.run(cmd + ['{"counts": [1, 17, 4099]}' if ranks == 8 else "{}"], cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert p.returncode == 0 and f"{ranks} rank threads guard: ok" in p.stdout, p.stdout[-4000:]
+    if devices == 1:  # ... and the guard is real: a checksum asked for one byte more than the buffer has dies of it
+        p = subprocess.run(cmd[:-1] + ["1", '{"overrun": 1}'], cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        assert p.returncode < 0 and "one byte past the end" in p.stdout and "went unnoticed" not in p.stdout, (p.returncode, p.stdout[-2000:])
+
+
 @pytest.mark.parametrize("layout", ["threads", "processes", "processes_on_the_host"])
 def test_host_slices_run_the_schedules_registered_buffers_run(devsim_lib, layout):
     """what a caller of the reference passes -- host slices -- is stood in for by arena blocks and takes the zero-copy path in every
