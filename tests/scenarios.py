@@ -2907,6 +2907,27 @@ def sc_guard(comm, args):
                     comm.recv(buf, count, dtype, peer, 21)
                     assert down(buf, dtype, count).tobytes() == oracle.fill(count, dtype, xmpi.PAT_SIGNED, 900 + peer).tobytes(), f"guard: p2p n={count}"
             comm.barrier()
+            # ... and the stream-ordered pair (one kernel on each side: sched.hip), with an allreduce enqueued behind it on the same stream
+            if dsync and peer < size and size % 2 == 0:
+                st = comm.stream_create()
+                out = galloc(nb)
+                comm.register(out, nb)
+                if rank & 1 == 0:
+                    comm.fill(buf, count, dtype, xmpi.PAT_SIGNED, 950 + rank)
+                    comm.send_on_stream(buf, count, dtype, peer, 22, st)
+                else:
+                    comm.memset(buf, 0, nb)
+                    comm.recv_on_stream(buf, count, dtype, peer, 22, st)
+                comm.allreduce_on_stream(buf, out, count, dtype, xmpi.SUM, st)
+                comm.stream_sync(st)
+                if rank & 1:
+                    assert down(buf, dtype, count).tobytes() == oracle.fill(count, dtype, xmpi.PAT_SIGNED, 950 + peer).tobytes(), f"guard: stream p2p n={count}"
+                ins2 = [oracle.fill(count, dtype, xmpi.PAT_SIGNED, 950 + (r & ~1)) for r in range(size)]
+                check_reduced(down(out, dtype, count), ins2, dtype, xmpi.SUM, True, f"guard: allreduce_on_stream behind a receive n={count}")
+                comm.stream_destroy(st)
+                comm.barrier()
+                comm.deregister(out)
+                gfree(out, nb)
             comm.deregister(buf)
             gfree(buf, nb)
 
