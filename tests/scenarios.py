@@ -2890,6 +2890,33 @@ def sc_guard(comm, args):
         gfree(send, nb)
     if dsync:
         comm.set_param("dsync_split_bytes", 4 << 20)
+    # ... and out of guarded memory nobody registered: arena blocks stand in (ranks that meet on the device) or the staged schedules
+    # take it through the windows (ranks that meet on the host) -- the copies in and out at ragged lengths
+    for dtype, count in ((xmpi.U8, 3), (xmpi.F32, 4099), (xmpi.U8, 65536 * 3 + 1)):
+        es = xmpi.DTYPE_SIZE[dtype]
+        nb = count * es
+        send, recv, big = galloc(nb), galloc(nb), galloc(nb * size)
+        comm.fill(send, count, dtype, xmpi.PAT_UNIFORM, 500 + rank)
+        ins = [oracle.fill(count, dtype, xmpi.PAT_UNIFORM, 500 + r) for r in range(size)]
+        for algo in (xmpi.ALGO_AUTO, xmpi.ALGO_RING, xmpi.ALGO_DIRECT):
+            comm.memset(recv, 0xA5, nb)
+            comm.allreduce(send, recv, count, dtype, xmpi.SUM, algo)
+            check_reduced(down(recv, dtype, count), ins, dtype, xmpi.SUM, algo != xmpi.ALGO_RING or size <= 2, f"guard: unregistered allreduce n={count} algo={algo}")
+        comm.allgather(send, big, count, dtype, xmpi.ALGO_AUTO)
+        assert down(big, dtype, count * size).tobytes() == oracle.allgather(ins, dtype).tobytes(), f"guard: unregistered allgather n={count}"
+        comm.memcpy(recv, send, nb)
+        comm.bcast(recv, count, dtype, size - 1, xmpi.ALGO_AUTO)
+        assert down(recv, dtype, count).tobytes() == ins[size - 1].tobytes(), f"guard: unregistered bcast n={count}"
+        if size >= 2 and (rank ^ 1) < size:
+            if rank & 1 == 0:
+                comm.send(send, count, dtype, rank ^ 1, 23)
+            else:
+                comm.recv(recv, count, dtype, rank ^ 1, 23)
+                assert down(recv, dtype, count).tobytes() == ins[rank ^ 1].tobytes(), f"guard: unregistered p2p n={count}"
+        comm.barrier()
+        gfree(send, nb)
+        gfree(recv, nb)
+        gfree(big, nb * size)
     # Send / Receive out of and into guarded memory
     if size >= 2:
         for dtype, count in ((xmpi.U8, 1), (xmpi.F32, 4099), (xmpi.U8, 65536 * 3 + 1), (xmpi.F64, 100001)):
