@@ -39,10 +39,13 @@ typedef enum {
   XMPI_F32 = 4,
   XMPI_F64 = 5,
   XMPI_BF16 = 6,
-  XMPI_DTYPE_COUNT = 7
+  XMPI_DTYPE_COUNT = 7,
+  /* (every int is a value of the type: what a binding passes out of range -- cgo hands over a uint32 -- comes back as
+   * XMPI_ERR_ARG instead of being undefined behaviour in the C++ that reads it; the same for the two enums below) */
+  XMPI_DTYPE_ANY_INT = 0x7fffffff
 } xmpi_dtype;
 
-typedef enum { XMPI_SUM = 0, XMPI_PROD = 1, XMPI_MIN = 2, XMPI_MAX = 3, XMPI_OP_COUNT = 4 } xmpi_op;
+typedef enum { XMPI_SUM = 0, XMPI_PROD = 1, XMPI_MIN = 2, XMPI_MAX = 3, XMPI_OP_COUNT = 4, XMPI_OP_ANY_INT = 0x7fffffff } xmpi_op;
 
 /* collective schedules */
 /* With one process per GPU, RING (allreduce, allgather), RHD (allreduce) and TREE (bcast) are ONE kernel per rank that
@@ -85,7 +88,8 @@ typedef enum {
   XMPI_ALGO_RING_PUSH = 8, /* allreduce, allgather */
   XMPI_ALGO_RHD_PUSH = 9,  /* allreduce            */
   XMPI_ALGO_TREE_PUSH = 10, /* bcast, reduce       */
-  XMPI_ALGO_COUNT = 11
+  XMPI_ALGO_COUNT = 11,
+  XMPI_ALGO_ANY_INT = 0x7fffffff
 } xmpi_algo;
 
 /* error codes */
