@@ -216,8 +216,12 @@ def test_no_kernel_touches_a_byte_past_its_buffers(devsim_lib, devices, ranks):
     p = subprocess.run(cmd + ['{"counts": [1, 17, 4099]}' if ranks == 8 else "{}"], cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert p.returncode == 0 and f"{ranks} rank threads guard: ok" in p.stdout, p.stdout[-4000:]
     if devices == 1:  # ... and the guard is real: a checksum asked for one byte more than the buffer has dies of it
-        p = subprocess.run(cmd[:-1] + ["1", '{"overrun": 1}'], cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
-        assert p.returncode < 0 and "one byte past the end" in p.stdout and "went unnoticed" not in p.stdout, (p.returncode, p.stdout[-2000:])
+        p = subprocess.Popen(cmd[:-1] + ["1", '{"overrun": 1}'], cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        out, _ = p.communicate(timeout=300)
+        import glob
+        for f in glob.glob(f"/dev/shm/devsim.{p.pid}.*") + glob.glob(f"/dev/shm/xmpi-*-th{p.pid}-*"):  # (it died with its allocations mapped)
+            os.unlink(f)
+        assert p.returncode < 0 and "one byte past the end" in out and "went unnoticed" not in out, (p.returncode, out[-2000:])
 
 
 @pytest.mark.parametrize("layout", ["threads", "processes", "processes_on_the_host"])
